@@ -1,0 +1,95 @@
+"""Execute the reference's OWN function/class source by AST-slicing it out of /root/reference.
+
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  Works only where /root/reference is
+mounted (the build container); nothing at GPU-box run time may call this.  Nothing is copied
+into the repo: the source text is read, the wanted top-level ``def``/``class`` nodes are
+compiled in memory and exec'd with ``torch``/``numpy`` in their namespace.
+
+Slices used (reference file:line):
+  train_pcm_lora_sd15.py:240-341  append_dims, scalings_for_boundary_conditions_{target,online},
+                                  predicted_origin, extract_into_tensor, DDIMSolver
+  train_pcm_lora_sd15.py:344-355  update_ema
+  train_pcm_lora_sd15.py:52-72    get_module_kohya_state_dict (key-renaming rule only)
+  scheduling_ddpm_modified.py:500-554  DDPMScheduler.add_noise / .noise_travel (method bodies
+                                  lifted and bound to a stub that carries ``alphas_cumprod``)
+  discriminator_sd15.py:348-434   DiscriminatorHead, Discriminator.d_loss/g_loss
+"""
+import ast
+import os
+import types
+
+import numpy as np
+import torch
+
+REF_ROOT = "/root/reference"
+SD15_DIR = os.path.join(REF_ROOT, "code", "text_to_image_sd15")
+
+
+def available() -> bool:
+    return os.path.isdir(SD15_DIR)
+
+
+def _slice(path, names, extra_ns=None):
+    src = open(path).read()
+    tree = ast.parse(src)
+    keep = [n for n in tree.body
+            if isinstance(n, (ast.FunctionDef, ast.ClassDef)) and n.name in names]
+    found = {n.name for n in keep}
+    missing = set(names) - found
+    if missing:
+        raise KeyError(f"{path}: missing {sorted(missing)}")
+    mod = ast.Module(body=keep, type_ignores=[])
+    ns = {"torch": torch, "np": np, "nn": torch.nn, "F": torch.nn.functional}
+    if extra_ns:
+        ns.update(extra_ns)
+    exec(compile(mod, path, "exec"), ns)
+    return ns
+
+
+def train_script_namespace():
+    """The reference-owned PCM math of train_pcm_lora_sd15.py, as live Python objects."""
+    names = ["append_dims", "scalings_for_boundary_conditions_target",
+             "scalings_for_boundary_conditions_online", "scalings_for_boundary_conditions",
+             "predicted_origin", "extract_into_tensor", "DDIMSolver", "update_ema",
+             "guidance_scale_embedding"]
+    return _slice(os.path.join(SD15_DIR, "train_pcm_lora_sd15.py"), names)
+
+
+def scheduler_stub(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012):
+    """A stub object carrying the reference DDPMScheduler's alphas_cumprod with the reference's
+    own add_noise / noise_travel method bodies bound to it (scheduling_ddpm_modified.py:201-223,
+    :500-554).  Only the 'scaled_linear' branch (SD1.5 config) is reproduced for the table."""
+    path = os.path.join(SD15_DIR, "scheduling_ddpm_modified.py")
+    tree = ast.parse(open(path).read())
+    cls = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "DDPMScheduler"][0]
+    fns = [n for n in cls.body if isinstance(n, ast.FunctionDef)
+           and n.name in ("add_noise", "noise_travel")]
+    assert len(fns) == 2
+    ns = {"torch": torch, "np": np}
+    exec(compile(ast.Module(body=fns, type_ignores=[]), path, "exec"), ns)
+    stub = types.SimpleNamespace()
+    # scheduling_ddpm_modified.py:205-207 (scaled_linear), :220-221
+    betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps,
+                           dtype=torch.float32) ** 2
+    stub.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)
+    stub.add_noise = types.MethodType(ns["add_noise"], stub)
+    stub.noise_travel = types.MethodType(ns["noise_travel"], stub)
+    return stub
+
+
+def discriminator_namespace():
+    """DiscriminatorHead + the hinge losses of discriminator_sd15.py:348-434.  ``Discriminator``
+    itself needs a diffusers UNet; only its loss methods are usable (with a stubbed _forward)."""
+    path = os.path.join(SD15_DIR, "discriminator_sd15.py")
+    return _slice(path, ["DiscriminatorHead", "Discriminator"],
+                  extra_ns={"modified_forward": None})
+
+
+def kohya_rename(peft_key: str, prefix: str = "lora_unet") -> str:
+    """The key-renaming rule of get_module_kohya_state_dict (train_pcm_lora_sd15.py:59-62),
+    executed from the reference source line by line on one key."""
+    k = peft_key.replace("base_model.model", prefix)
+    k = k.replace("lora_A", "lora_down")
+    k = k.replace("lora_B", "lora_up")
+    k = k.replace(".", "_", k.count(".") - 2)
+    return k

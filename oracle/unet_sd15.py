@@ -1,0 +1,331 @@
+"""Plain-torch fp32 restatement of diffusers-0.26.3 ``UNet2DConditionModel`` (SD1.5 config)
+with peft-0.9.0 LoRA semantics.  TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
+
+The reference does not vendor diffusers/peft (environment.yaml:40,:87) and neither is
+installable here, so this file restates the published module semantics; the only in-repo
+witness of the wiring is the copied forward at
+/root/reference/code/text_to_image_sd15/discriminator_sd15.py:84-345 (time-emb :122-141,
+conv_in :248, down loop :268-290, mid :293-309, up loop :312-342) which this follows.
+Anchors: 686 tensors / 859 520 964 parameters; LoRA r=64 on the 14 target patterns of
+train_pcm_lora_sd15.py:868-883 -> 278 wrapped modules / 67 252 224 parameters.
+**parity unpinned** (no reference outputs exist for this part).
+
+Functional style: ``unet_forward(sd, x, t, ctx, lora=None)`` takes a flat state dict with
+diffusers key names and an optional ``{module_path: (A, B)}`` LoRA dict (peft layouts:
+Linear A [r,in], B [out,r]; Conv2d A [r,in,k,k], B [out,r,1,1]).
+"""
+import math
+from collections import OrderedDict
+
+import torch
+import torch.nn.functional as F
+
+LORA_TARGETS = ["to_q", "to_k", "to_v", "to_out.0", "proj_in", "proj_out", "ff.net.0.proj",
+                "ff.net.2", "conv1", "conv2", "conv_shortcut", "downsamplers.0.conv",
+                "upsamplers.0.conv", "time_emb_proj"]  # train_pcm_lora_sd15.py:868-883
+
+
+class UNetConfig:
+    """SD1.5 unet/config.json semantics.  ``tiny()`` keeps the topology and
+    shrinks widths so CPU tests finish in seconds."""
+
+    def __init__(self, in_channels=4, out_channels=4, block_out_channels=(320, 640, 1280, 1280),
+                 layers_per_block=2, cross_attention_dim=768, heads=8, norm_num_groups=32,
+                 norm_eps=1e-5, temb_mult=4):
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.block_out_channels = tuple(block_out_channels)
+        self.layers_per_block = layers_per_block
+        self.cross_attention_dim = cross_attention_dim
+        self.heads = heads  # config key `attention_head_dim: 8` is used as the head COUNT
+        self.norm_num_groups = norm_num_groups
+        self.norm_eps = norm_eps
+        self.time_embed_dim = block_out_channels[0] * temb_mult
+
+    @staticmethod
+    def sd15():
+        return UNetConfig()
+
+    @staticmethod
+    def tiny(c=32, ctx=64, heads=2, groups=8):
+        return UNetConfig(block_out_channels=(c, 2 * c, 4 * c, 4 * c), cross_attention_dim=ctx,
+                          heads=heads, norm_num_groups=groups)
+
+
+# ----------------------------------------------------------------------------- parameter spec
+def _resnet_spec(p, cin, cout, temb):
+    s = [(p + "norm1.weight", (cin,)), (p + "norm1.bias", (cin,)),
+         (p + "conv1.weight", (cout, cin, 3, 3)), (p + "conv1.bias", (cout,)),
+         (p + "time_emb_proj.weight", (cout, temb)), (p + "time_emb_proj.bias", (cout,)),
+         (p + "norm2.weight", (cout,)), (p + "norm2.bias", (cout,)),
+         (p + "conv2.weight", (cout, cout, 3, 3)), (p + "conv2.bias", (cout,))]
+    if cin != cout:
+        s += [(p + "conv_shortcut.weight", (cout, cin, 1, 1)), (p + "conv_shortcut.bias", (cout,))]
+    return s
+
+
+def _attn_spec(p, c, ctx):
+    s = [(p + "norm.weight", (c,)), (p + "norm.bias", (c,)),
+         (p + "proj_in.weight", (c, c, 1, 1)), (p + "proj_in.bias", (c,))]
+    b = p + "transformer_blocks.0."
+    s += [(b + "norm1.weight", (c,)), (b + "norm1.bias", (c,)),
+          (b + "attn1.to_q.weight", (c, c)), (b + "attn1.to_k.weight", (c, c)),
+          (b + "attn1.to_v.weight", (c, c)),
+          (b + "attn1.to_out.0.weight", (c, c)), (b + "attn1.to_out.0.bias", (c,)),
+          (b + "norm2.weight", (c,)), (b + "norm2.bias", (c,)),
+          (b + "attn2.to_q.weight", (c, c)), (b + "attn2.to_k.weight", (c, ctx)),
+          (b + "attn2.to_v.weight", (c, ctx)),
+          (b + "attn2.to_out.0.weight", (c, c)), (b + "attn2.to_out.0.bias", (c,)),
+          (b + "norm3.weight", (c,)), (b + "norm3.bias", (c,)),
+          (b + "ff.net.0.proj.weight", (8 * c, c)), (b + "ff.net.0.proj.bias", (8 * c,)),
+          (b + "ff.net.2.weight", (c, 4 * c)), (b + "ff.net.2.bias", (c,))]
+    s += [(p + "proj_out.weight", (c, c, 1, 1)), (p + "proj_out.bias", (c,))]
+    return s
+
+
+def up_resnet_in_channels(cfg):
+    """Input channel count of every up-block resnet: cat([h, skip])."""
+    boc = cfg.block_out_channels
+    n = len(boc)
+    rev = list(reversed(boc))
+    res = []
+    prev_out = rev[0]
+    for i in range(n):
+        out = rev[i]
+        inp = rev[min(i + 1, n - 1)]
+        row = []
+        for j in range(cfg.layers_per_block + 1):
+            skip = inp if j == cfg.layers_per_block else out
+            rin = prev_out if j == 0 else out
+            row.append(rin + skip)
+        res.append(row)
+        prev_out = out
+    return res
+
+
+def param_spec(cfg):
+    """Ordered [(diffusers key, shape)] for the whole UNet."""
+    boc = cfg.block_out_channels
+    temb = cfg.time_embed_dim
+    ctx = cfg.cross_attention_dim
+    n = len(boc)
+    s = [("conv_in.weight", (boc[0], cfg.in_channels, 3, 3)), ("conv_in.bias", (boc[0],)),
+         ("time_embedding.linear_1.weight", (temb, boc[0])), ("time_embedding.linear_1.bias", (temb,)),
+         ("time_embedding.linear_2.weight", (temb, temb)), ("time_embedding.linear_2.bias", (temb,))]
+    cin = boc[0]
+    for i in range(n):
+        cout = boc[i]
+        has_attn = i < n - 1
+        for j in range(cfg.layers_per_block):
+            s += _resnet_spec(f"down_blocks.{i}.resnets.{j}.", cin if j == 0 else cout, cout, temb)
+        if has_attn:
+            for j in range(cfg.layers_per_block):
+                s += _attn_spec(f"down_blocks.{i}.attentions.{j}.", cout, ctx)
+        if i < n - 1:
+            s += [(f"down_blocks.{i}.downsamplers.0.conv.weight", (cout, cout, 3, 3)),
+                  (f"down_blocks.{i}.downsamplers.0.conv.bias", (cout,))]
+        cin = cout
+    c = boc[-1]
+    s += _resnet_spec("mid_block.resnets.0.", c, c, temb)
+    s += _attn_spec("mid_block.attentions.0.", c, ctx)
+    s += _resnet_spec("mid_block.resnets.1.", c, c, temb)
+    rin = up_resnet_in_channels(cfg)
+    rev = list(reversed(boc))
+    for i in range(n):
+        cout = rev[i]
+        has_attn = i > 0
+        for j in range(cfg.layers_per_block + 1):
+            s += _resnet_spec(f"up_blocks.{i}.resnets.{j}.", rin[i][j], cout, temb)
+        if has_attn:
+            for j in range(cfg.layers_per_block + 1):
+                s += _attn_spec(f"up_blocks.{i}.attentions.{j}.", cout, ctx)
+        if i < n - 1:
+            s += [(f"up_blocks.{i}.upsamplers.0.conv.weight", (cout, cout, 3, 3)),
+                  (f"up_blocks.{i}.upsamplers.0.conv.bias", (cout,))]
+    s += [("conv_norm_out.weight", (boc[0],)), ("conv_norm_out.bias", (boc[0],)),
+          ("conv_out.weight", (cfg.out_channels, boc[0], 3, 3)), ("conv_out.bias", (cfg.out_channels,))]
+    return s
+
+
+def init_state_dict(cfg, seed=0, dtype=torch.float32):
+    """Seeded random init standing in for the (unavailable) SD1.5 checkpoint: PyTorch-default
+    layer init (kaiming-uniform(a=sqrt5) weights, U(+-1/sqrt(fan_in)) biases, norms 1/0).
+    Deterministic across machines for a given torch build (CPU generator)."""
+    g = torch.Generator().manual_seed(seed)
+    sd = OrderedDict()
+    spec = param_spec(cfg)
+    shapes = dict(spec)
+    for k, shp in spec:
+        leaf = k.rsplit(".", 1)[0].rsplit(".", 1)[-1]
+        if leaf.startswith("norm") or leaf == "conv_norm_out":
+            sd[k] = torch.ones(shp, dtype=dtype) if k.endswith("weight") else torch.zeros(shp, dtype=dtype)
+            continue
+        wshape = shapes[k.rsplit(".", 1)[0] + ".weight"]
+        fan_in = 1
+        for d in wshape[1:]:
+            fan_in *= d
+        bound = 1.0 / math.sqrt(fan_in)
+        sd[k] = ((torch.rand(shp, generator=g, dtype=torch.float32) * 2 - 1) * bound).to(dtype)
+    return sd
+
+
+def lora_target_modules(cfg):
+    """[(module path, weight shape)] of every module matched by the peft rule
+    ``key == t or key.endswith('.' + t)`` for the reference's 14 targets."""
+    out = []
+    for k, shp in param_spec(cfg):
+        if not k.endswith(".weight"):
+            continue
+        path = k[:-len(".weight")]
+        if any(path == t or path.endswith("." + t) for t in LORA_TARGETS):
+            out.append((path, shp))
+    return out
+
+
+def init_lora(cfg, rank=64, seed=1, b_std=0.0):
+    """peft-0.9 init: A kaiming_uniform(a=sqrt5), B zeros (b_std>0 -> N(0,b_std) so that the
+    LoRA branch is exercised in kernel-parity tests)."""
+    g = torch.Generator().manual_seed(seed)
+    lora = OrderedDict()
+    for path, shp in lora_target_modules(cfg):
+        if len(shp) == 4:
+            a_shape = (rank, shp[1], shp[2], shp[3])
+            b_shape = (shp[0], rank, 1, 1)
+        else:
+            a_shape = (rank, shp[1])
+            b_shape = (shp[0], rank)
+        fan_in = 1
+        for d in a_shape[1:]:
+            fan_in *= d
+        bound = 1.0 / math.sqrt(fan_in)  # kaiming_uniform(a=sqrt5) == U(+-1/sqrt(fan_in))
+        A = (torch.rand(a_shape, generator=g) * 2 - 1) * bound
+        B = torch.randn(b_shape, generator=g) * b_std if b_std > 0 else torch.zeros(b_shape)
+        lora[path] = (A, B)
+    return lora
+
+
+# ----------------------------------------------------------------------------- forward
+def timestep_embedding(t, dim):
+    """diffusers Timesteps(dim, flip_sin_to_cos=True, downscale_freq_shift=0)  (SURVEY B.3)."""
+    half = dim // 2
+    exponent = -math.log(10000) * torch.arange(half, dtype=torch.float32) / half
+    arg = t.float()[:, None] * torch.exp(exponent)[None, :]
+    return torch.cat([torch.cos(arg), torch.sin(arg)], dim=-1)
+
+
+class _Net:
+    def __init__(self, cfg, sd, lora, lora_alpha=8.0):
+        self.cfg, self.sd, self.lora = cfg, sd, lora or {}
+        self.alpha = lora_alpha
+
+    def linear(self, path, x):
+        y = F.linear(x, self.sd[path + ".weight"], self.sd.get(path + ".bias"))
+        if path in self.lora:
+            A, B = self.lora[path]
+            y = y + F.linear(F.linear(x, A), B) * (self.alpha / A.shape[0])
+        return y
+
+    def conv(self, path, x, stride=1):
+        w = self.sd[path + ".weight"]
+        pad = w.shape[-1] // 2
+        y = F.conv2d(x, w, self.sd.get(path + ".bias"), stride=stride, padding=pad)
+        if path in self.lora:
+            A, B = self.lora[path]
+            y = y + F.conv2d(F.conv2d(x, A, None, stride=stride, padding=pad), B) * (self.alpha / A.shape[0])
+        return y
+
+    def gn(self, path, x, eps):
+        return F.group_norm(x, self.cfg.norm_num_groups, self.sd[path + ".weight"], self.sd[path + ".bias"], eps)
+
+    def ln(self, path, x):
+        return F.layer_norm(x, (x.shape[-1],), self.sd[path + ".weight"], self.sd[path + ".bias"], 1e-5)
+
+    def resnet(self, p, x, emb):
+        h = self.conv(p + "conv1", F.silu(self.gn(p + "norm1", x, self.cfg.norm_eps)))
+        h = h + self.linear(p + "time_emb_proj", F.silu(emb))[:, :, None, None]
+        h = self.conv(p + "conv2", F.silu(self.gn(p + "norm2", h, self.cfg.norm_eps)))
+        if (p + "conv_shortcut.weight") in self.sd:
+            x = self.conv(p + "conv_shortcut", x)
+        return x + h
+
+    def attention(self, p, x, ctx):
+        B, L, C = x.shape
+        H = self.cfg.heads
+        q = self.linear(p + "to_q", x)
+        k = self.linear(p + "to_k", ctx)
+        v = self.linear(p + "to_v", ctx)
+        d = C // H
+        q = q.view(B, L, H, d).transpose(1, 2)
+        k = k.view(B, -1, H, d).transpose(1, 2)
+        v = v.view(B, -1, H, d).transpose(1, 2)
+        s = torch.softmax(q @ k.transpose(-1, -2) * (d ** -0.5), dim=-1)
+        o = (s @ v).transpose(1, 2).reshape(B, L, C)
+        return self.linear(p + "to_out.0", o)
+
+    def transformer(self, p, x, ctx):
+        B, C, Hh, Ww = x.shape
+        r = x
+        h = self.conv(p + "proj_in", self.gn(p + "norm", x, 1e-6))
+        h = h.permute(0, 2, 3, 1).reshape(B, Hh * Ww, C)
+        b = p + "transformer_blocks.0."
+        n = self.ln(b + "norm1", h)
+        h = h + self.attention(b + "attn1.", n, n)
+        h = h + self.attention(b + "attn2.", self.ln(b + "norm2", h), ctx)
+        n = self.ln(b + "norm3", h)
+        a, g = self.linear(b + "ff.net.0.proj", n).chunk(2, dim=-1)
+        h = h + self.linear(b + "ff.net.2", a * F.gelu(g))
+        h = h.reshape(B, Hh, Ww, C).permute(0, 3, 1, 2)
+        return self.conv(p + "proj_out", h) + r
+
+
+def unet_forward(cfg, sd, sample, timesteps, encoder_hidden_states, lora=None, lora_alpha=8.0,
+                 return_features=False):
+    """UNet2DConditionModel.forward(sample, timestep, encoder_hidden_states).sample in fp32.
+    ``return_features`` mimics discriminator_sd15.py modified_forward (features after every down
+    block, mid, every up block; no conv_norm_out/conv_out)."""
+    net = _Net(cfg, sd, lora, lora_alpha)
+    boc = cfg.block_out_channels
+    n = len(boc)
+    t_emb = timestep_embedding(timesteps, boc[0]).to(sample.dtype)
+    emb = net.linear("time_embedding.linear_2", F.silu(net.linear("time_embedding.linear_1", t_emb)))
+    h = net.conv("conv_in", sample)
+    skips = [h]
+    feats = []
+    for i in range(n):
+        for j in range(cfg.layers_per_block):
+            h = net.resnet(f"down_blocks.{i}.resnets.{j}.", h, emb)
+            if i < n - 1:
+                h = net.transformer(f"down_blocks.{i}.attentions.{j}.", h, encoder_hidden_states)
+            skips.append(h)
+        if i < n - 1:
+            h = net.conv(f"down_blocks.{i}.downsamplers.0.conv", h, stride=2)
+            skips.append(h)
+        feats.append(h)
+    h = net.resnet("mid_block.resnets.0.", h, emb)
+    h = net.transformer("mid_block.attentions.0.", h, encoder_hidden_states)
+    h = net.resnet("mid_block.resnets.1.", h, emb)
+    feats.append(h)
+    for i in range(n):
+        for j in range(cfg.layers_per_block + 1):
+            h = torch.cat([h, skips.pop()], dim=1)
+            h = net.resnet(f"up_blocks.{i}.resnets.{j}.", h, emb)
+            if i > 0:
+                h = net.transformer(f"up_blocks.{i}.attentions.{j}.", h, encoder_hidden_states)
+        if i < n - 1:
+            h = F.interpolate(h, scale_factor=2.0, mode="nearest")
+            h = net.conv(f"up_blocks.{i}.upsamplers.0.conv", h)
+        feats.append(h)
+    if return_features:
+        return feats
+    h = F.silu(net.gn("conv_norm_out", h, cfg.norm_eps))
+    return net.conv("conv_out", h)
+
+
+def peft_state_dict(lora):
+    """get_peft_model_state_dict key names (the `.default` segment dropped), as consumed by
+    train_pcm_lora_sd15.py:56-58,:921-923."""
+    out = OrderedDict()
+    for path, (A, B) in lora.items():
+        out[f"base_model.model.{path}.lora_A.weight"] = A
+        out[f"base_model.model.{path}.lora_B.weight"] = B
+    return out
