@@ -1,0 +1,201 @@
+/* pcm_hip.h — C ABI of libpcm_hip.so: the MI355X (gfx950) kernels behind the phased-consistency
+ * distillation step of G-U-N/Phased-Consistency-Model (SD1.5 PCM-LoRA).
+ *
+ * Drop-in boundary.  The reference has no FFI of its own: its operator surface is
+ * the set of torch/diffusers/peft calls reached from
+ *   code/text_to_image_sd15/train_pcm_lora_sd15.py:1115-1301  (the step)
+ *   code/text_to_image_sd15/discriminator_sd15.py:84-345       (UNet wiring, copied from diffusers)
+ * Each entry point below names the reference call site / library op it replaces.
+ *
+ * Contract
+ *  - plain pointers + sizes; the CALLER owns every buffer; the library never allocates or frees
+ *    device memory and keeps no mutable global state (one immutable 16-byte zero page lives in
+ *    the code object for out-of-bounds LDS-DMA lanes).
+ *  - every call enqueues on `stream` (a hipStream_t passed as void*; torch's current stream)
+ *    and returns without synchronising; safe under hipGraph stream capture.
+ *  - return 0 on success, a negative PCM_E* code otherwise; never throws.  pcm_last_error()
+ *    returns a thread-local message.
+ *  - layouts: activations channels-last  [B, H*W, C]  (== token layout [B, L, C]); bf16 as raw
+ *    uint16; weights bf16 [N][K] with K contiguous (conv: K = (kh, kw, ci), ci fastest);
+ *    LoRA master weights stay in peft layout (A [r,in(,k,k)], B [out,r(,1,1)]) in fp32 — the
+ *    bf16 operand copies are produced by pcm_pack_* below.
+ */
+#ifndef PCM_HIP_H
+#define PCM_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PCM_OK 0
+#define PCM_EINVAL (-1)      /* bad shape / argument */
+#define PCM_EALIGN (-2)      /* pointer or stride not 16-byte aligned */
+#define PCM_EHIP (-3)        /* HIP runtime error at launch */
+#define PCM_EUNSUPPORTED (-4)
+
+#define PCM_BF16 0
+#define PCM_F32 1
+
+#define PCM_ACT_NONE 0
+#define PCM_ACT_SILU 1
+
+const char* pcm_last_error(void);
+int pcm_abi_version(void);
+
+/* ---- contraction: Linear / conv1x1 / conv3x3 (implicit GEMM) + LoRA injection --------------
+ * replaces F.linear / F.conv2d inside diffusers ResnetBlock2D.conv1/conv2, Attention.to_q/k/v/
+ * to_out.0, FeedForward, proj_in/out, Down/Upsample2D.conv and peft lora.Linear/lora.Conv2d
+ * ( y = base(x) + (alpha/r) * B(A(x)), train_pcm_lora_sd15.py:866-885 ), forward and dgrad.
+ *
+ * out[m][n] = act( sum_seg sum_k A_seg[m][k] * W_seg[n][k] + bias[n] + rowvec[m / rows_per_batch][n] )
+ *             + residual[m][n]
+ * A segment is either a plain row-major matrix or an implicit im2col view of an NHWC tensor. */
+#define PCM_SEG_PLAIN 0
+#define PCM_SEG_CONV3X3 1
+#define PCM_SRC_DIRECT 0    /* conv reads the source tensor as is */
+#define PCM_SRC_UPSAMPLE2 1 /* conv runs on the nearest-2x upsampling of the source (Upsample2D) */
+#define PCM_SRC_ZEROINS2 2  /* conv runs on the zero-insertion-2x of the source (stride-2 dgrad) */
+typedef struct {
+  const void* a; /* bf16: plain [M][lda]  |  conv NHWC [B][Hs][Ws][C] */
+  const void* w; /* bf16 [N][K] */
+  int K;         /* plain: columns, %8==0 ; conv: 9*C with C%64==0 */
+  int lda;       /* plain only (elements) */
+  int mode;      /* PCM_SEG_* */
+  int Hs, Ws, C; /* conv: SOURCE tensor dims */
+  int stride;    /* conv: 1 or 2 (output pixel -> input pixel step, on the virtual input) */
+  int src_mode;  /* PCM_SRC_* */
+} pcm_gemm_seg;
+
+typedef struct {
+  int M, N;
+  int Ho, Wo;             /* conv: output spatial dims (M = B*Ho*Wo); plain: ignored */
+  const float* bias;      /* [N] or NULL */
+  const void* rowvec;     /* bf16 [M/rows_per_batch][N] or NULL (time-embedding add, :ResnetBlock2D) */
+  int rows_per_batch;
+  const void* residual;   /* bf16 [M][ldr] or NULL; added AFTER act */
+  int ldr;
+  void* out;              /* [M][ldo] */
+  int ldo;
+  int out_dtype;          /* PCM_BF16 | PCM_F32 */
+  int act;                /* PCM_ACT_* */
+  float alpha;            /* scales the accumulated sum before bias (1.0 normally) */
+} pcm_gemm_epi;
+
+int pcm_gemm_bf16(const pcm_gemm_seg* segs, int nseg, const pcm_gemm_epi* epi, void* stream);
+
+/* LoRA weight gradients (autograd of peft lora.Linear / lora.Conv2d under loss.backward(),
+ * train_pcm_lora_sd15.py:1296).  G[g][r] += alpha * sum_m Big[m][g] * Small[m][r], r in [0,64).
+ * Big is plain [M][ldb] (G columns) or the im2col view of an NHWC tensor; Small is [M][64].
+ * Accumulates with fp32 atomics into `out` at  out[g*g_stride + r*r_stride]  or, for
+ * out_conv=1 (peft Conv2d A layout [r][C][3][3]):  g=(tap,ci) -> out[r*9*C + ci*9 + tap]. */
+typedef struct {
+  const void* big; int ldb; int G;      /* plain: G columns (%8==0) */
+  int mode; int Hs, Ws, C, stride, src_mode, Ho, Wo; /* conv view (G = 9*C) */
+  const void* small_; int lds_;         /* bf16 [M][lds_], 64 columns used */
+  int M;
+  float* out; long g_stride, r_stride; int out_conv;
+  float alpha;
+} pcm_wgrad_args;
+int pcm_lora_wgrad_bf16(const pcm_wgrad_args* a, void* stream);
+
+/* ---- GroupNorm(32)(+SiLU), channels-last  (diffusers ResnetBlock2D.norm1/2, conv_norm_out,
+ * Transformer2DModel.norm) --------------------------------------------------------------- */
+/* stats[b][g] = {sum, sumsq} in fp64, zeroed by the call itself */
+int pcm_groupnorm_stats(const void* x, double* stats, int B, int HW, int C, int G, void* stream);
+int pcm_groupnorm_apply(const void* x, const double* stats, const float* gamma, const float* beta,
+                        void* y, int B, int HW, int C, int G, float eps, int act, void* stream);
+/* backward wrt x only (norm affine params are frozen): two launches */
+int pcm_groupnorm_bwd_stats(const void* x, const void* dy, const double* stats, const float* gamma,
+                            const float* beta, double* bstats, int B, int HW, int C, int G,
+                            float eps, int act, void* stream);
+int pcm_groupnorm_bwd_apply(const void* x, const void* dy, const double* stats, const double* bstats,
+                            const float* gamma, const float* beta, void* dx, int B, int HW, int C,
+                            int G, float eps, int act, void* stream);
+
+/* ---- LayerNorm over the last dim (BasicTransformerBlock.norm1/2/3) ----------------------- */
+int pcm_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean,
+                      float* rstd, int M, int C, float eps, void* stream);
+/* dx = LN backward (+ optional accumulate of `dres` into dx: the residual-branch gradient) */
+int pcm_layernorm_bwd(const void* x, const void* dy, const float* gamma, const float* mean,
+                      const float* rstd, const void* dres, void* dx, int M, int C, void* stream);
+
+/* ---- GEGLU (diffusers GEGLU: h, g = proj(x).chunk(2,-1); h * gelu_erf(g)) ---------------- */
+int pcm_geglu_fwd(const void* hg, void* out, int M, int C4, void* stream);           /* hg [M][2*C4] */
+int pcm_geglu_bwd(const void* hg, const void* dout, void* dhg, int M, int C4, void* stream);
+
+/* ---- scaled-dot-product attention (Attention.processor: torch SDPA / xformers
+ * memory_efficient_attention, train_pcm_lora_sd15.py:947-957) ------------------------------
+ * q [B][Lq][ldq], k/v [B][Lk][ldk], head h occupies columns [h*d, (h+1)*d); o like q.
+ * lse [B][H][Lq] fp32 in the log2 domain of the scaled scores. d in {40, 80, 160} (or any
+ * multiple of 8 up to 160). */
+int pcm_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H,
+                 int Lq, int Lk, int d, int ldq, int ldk, int ldo, float scale, void* stream);
+int pcm_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dO,
+                 const float* lse, float* delta /*[B][H][Lq] scratch*/, void* dq, void* dk, void* dv,
+                 int B, int H, int Lq, int Lk, int d, int ldq, int ldk, int ldo, float scale,
+                 void* stream);
+
+/* ---- small data-movement ops of the UNet wiring (discriminator_sd15.py:312-342) ---------- */
+int pcm_upsample2x_nhwc(const void* x, void* y, int B, int H, int W, int C, void* stream);
+int pcm_pool2x_sum_nhwc(const void* dy, void* dx, int B, int H, int W, int C, void* stream); /* bwd of upsample: dx[H][W] from dy[2H][2W] */
+int pcm_concat_channels(const void* a, int Ca, const void* b, int Cb, void* out, long rows, void* stream);
+int pcm_split_channels(const void* in, void* a, int Ca, void* b, int Cb, long rows, int accumulate_a, void* stream);
+int pcm_add_bf16(const void* a, const void* b, void* out, long n, void* stream);
+int pcm_colsum_bf16(const void* x, void* out /*bf16 [B][C]*/, int B, int HW, int C, void* stream); /* d(time_emb_proj out) */
+int pcm_silu_bf16(const void* x, void* y, long n, void* stream);
+
+/* conv_in (4->C0, NCHW fp32 latent in, NHWC bf16 out) and conv_out (C0->4, NHWC bf16 in, NCHW fp32
+ * out) + its input gradient — UNet2DConditionModel.conv_in / conv_out, not LoRA targets. */
+int pcm_conv_in_fwd(const float* x_nchw, const float* w /*[C0][4][3][3]*/, const float* bias, void* y,
+                    int B, int H, int W, int C0, void* stream);
+int pcm_conv_out_fwd(const void* x, const float* w /*[4][C0][3][3]*/, const float* bias, float* y_nchw,
+                     int B, int H, int W, int C0, void* stream);
+int pcm_conv_out_bwd(const float* dy_nchw, const float* w, void* dx, int B, int H, int W, int C0, void* stream);
+
+/* sinusoidal timestep projection (diffusers Timesteps(320, flip_sin_to_cos=True, shift=0)) */
+int pcm_timestep_embedding(const int64_t* t, void* out /*bf16 [B][dim]*/, int B, int dim, void* stream);
+
+/* ---- phased-consistency math on latents, NCHW fp32 [B][4][H][W] (reference-owned) -------- */
+/* add_noise: scheduling_ddpm_modified.py:500-524 */
+int pcm_add_noise(const float* x, const float* noise, const float* alphas_cumprod, const int64_t* t,
+                  float* out, int B, int per_sample, void* stream);
+/* predicted_origin(epsilon) + ddim_style_multiphase_pred + boundary blend
+ * (train_pcm_lora_sd15.py:268-280, :321-341, :1212/:1280):
+ *   x0 = (sample - sigma_t*eps)/alpha_t ; e = largest edge <= index ;
+ *   jump = sqrt(acp_prev[e])*x0 + sqrt(1-acp_prev[e])*eps ; out = c_skip*sample + (1-c_skip)*jump
+ * target_mode=0: online (c_skip=0) ; 1: target (c_skip = index in edges).  Also writes
+ * coef[b] = d out / d eps (used by the backward) and end_t[b] = ddim_timesteps_prev[e]. */
+int pcm_phase_jump(const float* eps, const float* sample, const int64_t* t, const int64_t* index,
+                   const float* alphas_cumprod, const float* acp_prev /*[N_ddim]*/,
+                   const int64_t* t_prev /*[N_ddim]*/, const int64_t* edges, int n_edges, int target_mode,
+                   float* out, float* coef, int64_t* end_t, int B, int per_sample, void* stream);
+/* CFG-augmented DDIM step (train_pcm_lora_sd15.py:1224-1258) */
+int pcm_cfg_ddim_step(const float* eps_c, const float* eps_u, const float* sample, const int64_t* t,
+                      const int64_t* index, const float* w, const float* alphas_cumprod,
+                      const float* acp_prev, float* x_prev, int B, int per_sample, void* stream);
+/* loss (l2 | huber, :1283-1293) forward + gradient wrt the student's eps prediction:
+ * loss[0] = mean(...) ; d_eps = dloss/dmodel_pred * coef[b] */
+int pcm_consistency_loss(const float* model_pred, const float* target, const float* coef, int huber,
+                         float huber_c, float* loss, float* d_eps, int B, int per_sample, void* stream);
+
+/* ---- optimizer (torch.optim.AdamW + clip_grad_norm_, train_pcm_lora_sd15.py:1297-1301) ---- */
+int pcm_sumsq_f32(const float* g, double* out /*1, zeroed by the call*/, long n, void* stream);
+int pcm_adamw_clip_step(float* p, const float* g, float* m, float* v, const double* gradsq,
+                        float max_norm, float lr, float beta1, float beta2, float eps, float wd,
+                        int step, float grad_scale, long n, void* stream);
+/* update_ema (train_pcm_lora_sd15.py:344-355; defined by the reference, never called) */
+int pcm_ema_update(float* target, const float* source, float rate, long n, void* stream);
+
+/* ---- operand packing (fp32 master -> bf16 MFMA operand layouts) -------------------------- */
+/* linear weight [N][K] fp32 -> bf16 [N][K] (scaled) and/or transposed bf16 [K][N] */
+int pcm_pack_linear(const float* w, void* w_nk, void* w_kn, int N, int K, float scale, void* stream);
+/* conv weight [N][C][3][3] fp32 -> fwd operand bf16 [N][(kh,kw,c)] and/or dgrad operand
+ * bf16 [C][(kh',kw',n)] with the taps flipped */
+int pcm_pack_conv3x3(const float* w, void* w_fwd, void* w_dgrad, int N, int C, float scale, void* stream);
+int pcm_cast_f32_bf16(const float* x, void* y, long n, void* stream);
+int pcm_cast_bf16_f32(const void* x, float* y, long n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

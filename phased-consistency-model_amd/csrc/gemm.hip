@@ -1,0 +1,254 @@
+// pcm_gemm_bf16 — the contraction workhorse of the UNet hot path on gfx950.
+//
+//   out[m][n] = act(alpha * sum_seg sum_k A_seg[m][k] * W_seg[n][k] + bias[n] + rowvec[m/rpb][n]) + res[m][n]
+//
+// One kernel serves Linear, conv1x1, conv3x3 (implicit im2col over channels-last activations,
+// stride 1/2, nearest-2x-upsampled or zero-inserted sources) and the LoRA injection: the low-rank
+// branch s*B(A(x)) is a SECOND K-segment accumulated into the same fp32 MFMA accumulators
+// (K' = K + r), so base + LoRA are rounded to bf16 once.  The same kernel runs dgrad with
+// pre-transposed / tap-flipped weight operands (weights are frozen, so both orientations stay
+// resident in HBM).
+//
+// Structure (CDNA4): 256 threads = 4 waves (2x2), block tile (64*TM) x (64*TN), BK = 64;
+// tiles are staged HBM -> LDS by LDS-DMA (global_load_lds, 16 B/lane, two stages); the LDS image
+// is lane-linear, so the bank-conflict swizzle (16-B chunk ^ ((row>>1)&7)) is applied to the
+// per-lane SOURCE address and to the ds_read_b128 fragment reads.  Out-of-range rows / padding
+// taps / K tails fetch a 16-byte zero page.  MFMA: v_mfma_f32_32x32x16_bf16 with the WEIGHT tile
+// as the A operand, so every lane owns 4 consecutive output channels per accumulator quad
+// (8-byte bf16 stores, channel-contiguous).
+#include "pcm_common.h"
+
+__device__ __attribute__((aligned(16))) static const uint4 pcm_zero_page = {0u, 0u, 0u, 0u};
+
+struct SegDev {
+  const bf16_t* a;
+  const bf16_t* w;
+  int K, lda, mode, Hs, Ws, C, stride, src_mode, ktiles;
+};
+struct GemmDev {
+  SegDev seg[2];
+  int nseg, M, N, Ho, Wo;
+  const float* bias;
+  const bf16_t* rowvec;
+  int rpb;
+  const bf16_t* res;
+  int ldr;
+  void* out;
+  int ldo, out_f32, act;
+  float alpha;
+  int tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+template <int TM, int TN>
+__global__ __launch_bounds__(256) void pcm_gemm_kernel(GemmDev g) {
+  constexpr int BM = 64 * TM, BN = 64 * TN;
+  constexpr int STAGE = (BM + BN) * 128;
+  PCM_DYN_SMEM(smem);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & 1, wn = wave >> 1;
+  // XCD-aware bijective remap: consecutive logical tiles stay on one XCD (private L2)
+  int nwg = g.tiles_m * g.tiles_n, bid = blockIdx.x;
+  {
+    int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tile_n = bid % g.tiles_n, tile_m = bid / g.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  // ---- per-thread loader rows (fixed over the K loop) ----
+  constexpr int AI = BM / 32, WI = BN / 32;  // wave-instructions per wave for the A / W tile
+  const int lrow = lane >> 3, lchunk = lane & 7;
+  int a_b[AI], a_y[AI], a_x[AI];  // conv: batch, out-y, out-x ; plain: a_b = m (or -1)
+  const int HoWo = g.Ho * g.Wo;
+#pragma unroll
+  for (int j = 0; j < AI; j++) {
+    int row = 8 * (wave + 4 * j) + lrow;
+    int m = m0 + row;
+    if (m < g.M) {
+      if (g.seg[0].mode == PCM_SEG_CONV3X3 || (g.nseg > 1 && g.seg[1].mode == PCM_SEG_CONV3X3)) {
+        int b = m / HoWo, rem = m - b * HoWo;
+        a_b[j] = b; a_y[j] = rem / g.Wo; a_x[j] = rem - a_y[j] * g.Wo;
+      } else { a_b[j] = 0; a_y[j] = 0; a_x[j] = 0; }
+    } else { a_b[j] = -1; a_y[j] = 0; a_x[j] = 0; }
+  }
+
+  auto issue = [&](int seg_i, int k0, int stage) {
+    const SegDev& s = g.seg[seg_i];
+    char* base = smem + stage * STAGE;
+    // activation tile
+    int tap_y = 0, tap_x = 0, ci0 = 0;
+    if (s.mode == PCM_SEG_CONV3X3) {
+      int tap = k0 / s.C;
+      ci0 = k0 - tap * s.C;
+      tap_y = tap / 3; tap_x = tap - tap_y * 3;
+    }
+#pragma unroll
+    for (int j = 0; j < AI; j++) {
+      int q = wave + 4 * j;
+      int row = 8 * q + lrow;
+      int c = lchunk ^ ((row >> 1) & 7);
+      const void* src = &pcm_zero_page;
+      int m = m0 + row;
+      if (a_b[j] >= 0) {
+        if (s.mode == PCM_SEG_PLAIN) {
+          int k = k0 + 8 * c;
+          if (k < s.K) src = s.a + (size_t)m * s.lda + k;
+        } else {
+          int vy = a_y[j] * s.stride + tap_y - 1, vx = a_x[j] * s.stride + tap_x - 1;
+          int sh = s.src_mode != PCM_SRC_DIRECT;
+          int Hv = s.Hs << sh, Wv = s.Ws << sh;
+          bool ok = vy >= 0 && vy < Hv && vx >= 0 && vx < Wv;
+          if (s.src_mode == PCM_SRC_ZEROINS2) ok = ok && !((vy | vx) & 1);
+          if (ok) {
+            int sy = vy >> sh, sx = vx >> sh;
+            src = s.a + ((size_t)(a_b[j] * s.Hs + sy) * s.Ws + sx) * s.C + ci0 + 8 * c;
+          }
+        }
+      }
+      __builtin_amdgcn_global_load_lds(PCM_AS1(src), PCM_AS3(base + q * 1024), 16, 0, 0);
+    }
+    // weight tile
+    char* wbase = base + BM * 128;
+#pragma unroll
+    for (int j = 0; j < WI; j++) {
+      int q = wave + 4 * j;
+      int row = 8 * q + lrow;
+      int c = lchunk ^ ((row >> 1) & 7);
+      const void* src = &pcm_zero_page;
+      int n = n0 + row, k = k0 + 8 * c;
+      if (n < g.N && k < s.K) src = s.w + (size_t)n * s.K + k;
+      __builtin_amdgcn_global_load_lds(PCM_AS1(src), PCM_AS3(wbase + q * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; i++)
+#pragma unroll
+    for (int j = 0; j < TM; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+  const int total_kt = g.seg[0].ktiles + (g.nseg > 1 ? g.seg[1].ktiles : 0);
+  issue(0, 0, 0);
+  const int frow = lane & 31, hi = lane >> 5;
+  for (int kt = 0; kt < total_kt; kt++) {
+    __syncthreads();  // tile kt landed (hipcc drains the LDS-DMA queue before the barrier); stage (kt+1)&1 free
+    if (kt + 1 < total_kt) {
+      int nk = kt + 1;
+      int si = (nk >= g.seg[0].ktiles) ? 1 : 0;
+      int k0 = (si ? nk - g.seg[0].ktiles : nk) * 64;
+      issue(si, k0, nk & 1);
+    }
+    const char* At = smem + (kt & 1) * STAGE;
+    const char* Wt = At + BM * 128;
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {
+      bf16x8 wf[TN], af[TM];
+#pragma unroll
+      for (int i = 0; i < TN; i++)
+        wf[i] = *(const bf16x8*)(Wt + lds_off(wn * 32 * TN + i * 32 + frow, 2 * ks + hi));
+#pragma unroll
+      for (int j = 0; j < TM; j++)
+        af[j] = *(const bf16x8*)(At + lds_off(wm * 32 * TM + j * 32 + frow, 2 * ks + hi));
+#pragma unroll
+      for (int i = 0; i < TN; i++)
+#pragma unroll
+        for (int j = 0; j < TM; j++)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue: lane owns column m, 4 consecutive channels n per accumulator quad ----
+#pragma unroll
+  for (int j = 0; j < TM; j++) {
+    int m = m0 + wm * 32 * TM + j * 32 + frow;
+    if (m >= g.M) continue;
+    const bf16_t* rv = g.rowvec ? g.rowvec + (size_t)(m / g.rpb) * g.N : nullptr;
+#pragma unroll
+    for (int i = 0; i < TN; i++) {
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        int n = n0 + wn * 32 * TN + i * 32 + 8 * q + 4 * hi;
+        if (n >= g.N) continue;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) v[e] = acc[i][j][4 * q + e] * g.alpha;
+        if (g.bias) {
+          float4 b4 = *(const float4*)(g.bias + n);
+          v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+        }
+        if (rv) {
+          uint2 t = *(const uint2*)(rv + n);
+          v[0] += bf2f((bf16_t)(t.x & 0xffff)); v[1] += bf2f((bf16_t)(t.x >> 16));
+          v[2] += bf2f((bf16_t)(t.y & 0xffff)); v[3] += bf2f((bf16_t)(t.y >> 16));
+        }
+        if (g.act == PCM_ACT_SILU) {
+#pragma unroll
+          for (int e = 0; e < 4; e++) v[e] = silu_f(v[e]);
+        }
+        if (g.res) {
+          uint2 t = *(const uint2*)(g.res + (size_t)m * g.ldr + n);
+          v[0] += bf2f((bf16_t)(t.x & 0xffff)); v[1] += bf2f((bf16_t)(t.x >> 16));
+          v[2] += bf2f((bf16_t)(t.y & 0xffff)); v[3] += bf2f((bf16_t)(t.y >> 16));
+        }
+        if (g.out_f32) {
+          *(float4*)((float*)g.out + (size_t)m * g.ldo + n) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+          *(uint2*)((bf16_t*)g.out + (size_t)m * g.ldo + n) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+        }
+      }
+    }
+  }
+}
+
+extern "C" int pcm_gemm_bf16(const pcm_gemm_seg* segs, int nseg, const pcm_gemm_epi* e, void* stream) {
+  PCM_CHECK(segs && e && nseg >= 1 && nseg <= 2, PCM_EINVAL, "pcm_gemm_bf16: nseg must be 1 or 2");
+  PCM_CHECK(e->M > 0 && e->N > 0 && (e->N % 4) == 0, PCM_EINVAL, "pcm_gemm_bf16: M>0, N>0, N%%4==0 required (M=%d N=%d)", e->M, e->N);
+  GemmDev g;
+  memset(&g, 0, sizeof(g));
+  bool any_conv = false;
+  for (int i = 0; i < nseg; i++) {
+    const pcm_gemm_seg& s = segs[i];
+    SegDev& d = g.seg[i];
+    PCM_CHECK(s.a && s.w, PCM_EINVAL, "pcm_gemm_bf16: null operand in segment %d", i);
+    PCM_CHECK(PCM_ALIGNED16(s.a) && PCM_ALIGNED16(s.w), PCM_EALIGN, "pcm_gemm_bf16: operands must be 16-byte aligned");
+    PCM_CHECK(s.K > 0 && (s.K % 8) == 0, PCM_EINVAL, "pcm_gemm_bf16: K%%8 != 0 (K=%d)", s.K);
+    d.a = (const bf16_t*)s.a; d.w = (const bf16_t*)s.w; d.K = s.K; d.lda = s.lda; d.mode = s.mode;
+    d.Hs = s.Hs; d.Ws = s.Ws; d.C = s.C; d.stride = s.stride; d.src_mode = s.src_mode;
+    d.ktiles = (s.K + 63) / 64;
+    if (s.mode == PCM_SEG_CONV3X3) {
+      any_conv = true;
+      PCM_CHECK(s.C > 0 && (s.C % 64) == 0 && s.K == 9 * s.C, PCM_EINVAL, "pcm_gemm_bf16: conv segment needs C%%64==0 and K==9*C (C=%d K=%d)", s.C, s.K);
+      PCM_CHECK(s.stride == 1 || s.stride == 2, PCM_EINVAL, "pcm_gemm_bf16: conv stride must be 1 or 2");
+      PCM_CHECK(s.Hs > 0 && s.Ws > 0, PCM_EINVAL, "pcm_gemm_bf16: conv source dims");
+    } else {
+      PCM_CHECK(s.mode == PCM_SEG_PLAIN, PCM_EINVAL, "pcm_gemm_bf16: bad segment mode");
+      PCM_CHECK(s.lda >= s.K && (s.lda % 8) == 0, PCM_EALIGN, "pcm_gemm_bf16: lda must be >=K and %%8==0");
+    }
+  }
+  if (any_conv) PCM_CHECK(e->Ho > 0 && e->Wo > 0 && (e->M % (e->Ho * e->Wo)) == 0, PCM_EINVAL, "pcm_gemm_bf16: M must be B*Ho*Wo for conv");
+  PCM_CHECK(e->out && PCM_ALIGNED16(e->out) && (e->ldo % 4) == 0 && e->ldo >= e->N, PCM_EALIGN, "pcm_gemm_bf16: out/ldo alignment");
+  if (e->residual) PCM_CHECK((((uintptr_t)e->residual) & 7) == 0 && (e->ldr % 4) == 0, PCM_EALIGN, "pcm_gemm_bf16: residual alignment");
+  if (e->rowvec) PCM_CHECK(e->rows_per_batch > 0, PCM_EINVAL, "pcm_gemm_bf16: rows_per_batch");
+  g.nseg = nseg; g.M = e->M; g.N = e->N; g.Ho = e->Ho > 0 ? e->Ho : 1; g.Wo = e->Wo > 0 ? e->Wo : 1;
+  g.bias = e->bias; g.rowvec = (const bf16_t*)e->rowvec; g.rpb = e->rows_per_batch > 0 ? e->rows_per_batch : 1;
+  g.res = (const bf16_t*)e->residual; g.ldr = e->ldr; g.out = e->out; g.ldo = e->ldo;
+  g.out_f32 = e->out_dtype == PCM_F32; g.act = e->act; g.alpha = e->alpha;
+  // tile choice: 128x128 when N is a multiple of 128 and the grid still fills the chip, else 128x64 / 64x64
+  int TMv = 2, TNv = 2;
+  if ((e->N % 128) != 0) TNv = 1;
+  long blocks = (long)((e->M + 127) / 128) * ((e->N + 64 * TNv - 1) / (64 * TNv));
+  if (blocks < 256) { TNv = 1; blocks = (long)((e->M + 127) / 128) * ((e->N + 63) / 64); }
+  if (blocks < 256) TMv = 1;
+  g.tiles_m = (e->M + 64 * TMv - 1) / (64 * TMv);
+  g.tiles_n = (e->N + 64 * TNv - 1) / (64 * TNv);
+  dim3 grid(g.tiles_m * g.tiles_n), block(256);
+  size_t smem = 2 * (64 * TMv + 64 * TNv) * 128;
+  if (TMv == 2 && TNv == 2) PCM_LAUNCH((pcm_gemm_kernel<2, 2>), grid, block, smem, stream, g);
+  else if (TMv == 2 && TNv == 1) PCM_LAUNCH((pcm_gemm_kernel<2, 1>), grid, block, smem, stream, g);
+  else PCM_LAUNCH((pcm_gemm_kernel<1, 1>), grid, block, smem, stream, g);
+  return pcm_post_launch("pcm_gemm_bf16");
+}

@@ -1,0 +1,82 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels of the PCM distillation hot path.
+// wave = 64 lanes; bf16 is carried as raw uint16 bits; fp32 accumulation everywhere.
+#pragma once
+#ifdef PCM_HOST_EMU  // set ONLY by tests/emu/build_emu.py (host index-math checks); never in the product build
+#include "hip_emu.h"
+#else
+#include <hip/hip_runtime.h>
+#define PCM_LAUNCH(kern, grid, block, smem, stream, ...) \
+  hipLaunchKernelGGL(kern, (grid), (block), (smem), (hipStream_t)(stream), __VA_ARGS__)
+#define PCM_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
+#define PCM_AS1(p) ((const __attribute__((address_space(1))) void*)(p))
+#define PCM_AS3(p) ((__attribute__((address_space(3))) void*)(p))
+#define PCM_EXPF(x) __expf(x)
+#define PCM_EXP2F(x) __builtin_amdgcn_exp2f(x)
+#endif
+#include <stdint.h>
+#include <string.h>
+
+#include "../../include/pcm_hip.h"
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short bf16_t;
+
+// thread-local last-error string (C-ABI: never throw across the boundary)
+void pcm_set_error(const char* fmt, ...);
+#define PCM_CHECK(cond, code, ...)      \
+  do {                                  \
+    if (!(cond)) {                      \
+      pcm_set_error(__VA_ARGS__);       \
+      return (code);                    \
+    }                                   \
+  } while (0)
+#define PCM_ALIGNED16(p) ((((uintptr_t)(p)) & 15) == 0)
+int pcm_post_launch(const char* what);
+
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((unsigned)h) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {  // round-to-nearest-even, NaN kept quiet
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {
+  return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+}
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + PCM_EXPF(-x)); }
+__device__ __forceinline__ float silu_grad_f(float x) {
+  float s = 1.0f / (1.0f + PCM_EXPF(-x));
+  return s * (1.0f + x * (1.0f - s));
+}
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_erf_grad_f(float x) {
+  return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * PCM_EXPF(-0.5f * x * x);
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+// 8x8 bf16 transpose in registers: r[j] = row j (8 bf16 as 4 dwords) -> o[c] = column c (8 rows)
+__device__ __forceinline__ void transpose8x8_bf16(const uint4 (&r)[8], uint4 (&o)[8]) {
+  unsigned p[4][8];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const unsigned a[4] = {r[2 * i].x, r[2 * i].y, r[2 * i].z, r[2 * i].w};
+    const unsigned b[4] = {r[2 * i + 1].x, r[2 * i + 1].y, r[2 * i + 1].z, r[2 * i + 1].w};
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+      p[i][2 * d] = (a[d] & 0xffffu) | (b[d] << 16);
+      p[i][2 * d + 1] = (a[d] >> 16) | (b[d] & 0xffff0000u);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 8; c++) o[c] = make_uint4(p[0][c], p[1][c], p[2][c], p[3][c]);
+}

@@ -1,0 +1,144 @@
+"""ctypes binding of libpcm_hip.so (include/pcm_hip.h).
+
+The product path has exactly one implementation per op — the HIP library.  ``lib()`` raises
+``RuntimeError`` when it is missing; there is no torch-op or CPU fallback.  Tests may construct
+``Lib(path)`` on another build of the SAME sources (tests/emu) to check index math on the host.
+"""
+import ctypes as C
+import os
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(HERE, "lib", "libpcm_hip.so")
+
+PCM_BF16, PCM_F32 = 0, 1
+ACT_NONE, ACT_SILU = 0, 1
+SEG_PLAIN, SEG_CONV3X3 = 0, 1
+SRC_DIRECT, SRC_UPSAMPLE2, SRC_ZEROINS2 = 0, 1, 2
+
+vp = C.c_void_p
+
+
+class GemmSeg(C.Structure):
+    _fields_ = [("a", vp), ("w", vp), ("K", C.c_int), ("lda", C.c_int), ("mode", C.c_int),
+                ("Hs", C.c_int), ("Ws", C.c_int), ("C", C.c_int), ("stride", C.c_int),
+                ("src_mode", C.c_int)]
+
+
+class GemmEpi(C.Structure):
+    _fields_ = [("M", C.c_int), ("N", C.c_int), ("Ho", C.c_int), ("Wo", C.c_int), ("bias", vp),
+                ("rowvec", vp), ("rows_per_batch", C.c_int), ("residual", vp), ("ldr", C.c_int),
+                ("out", vp), ("ldo", C.c_int), ("out_dtype", C.c_int), ("act", C.c_int),
+                ("alpha", C.c_float)]
+
+
+class WgradArgs(C.Structure):
+    _fields_ = [("big", vp), ("ldb", C.c_int), ("G", C.c_int), ("mode", C.c_int), ("Hs", C.c_int),
+                ("Ws", C.c_int), ("C", C.c_int), ("stride", C.c_int), ("src_mode", C.c_int),
+                ("Ho", C.c_int), ("Wo", C.c_int), ("small_", vp), ("lds_", C.c_int), ("M", C.c_int),
+                ("out", vp), ("g_stride", C.c_long), ("r_stride", C.c_long), ("out_conv", C.c_int),
+                ("alpha", C.c_float)]
+
+
+i32, i64, f32 = C.c_int, C.c_long, C.c_float
+_PROTOS = {
+    "pcm_gemm_bf16": [C.POINTER(GemmSeg), i32, C.POINTER(GemmEpi), vp],
+    "pcm_lora_wgrad_bf16": [C.POINTER(WgradArgs), vp],
+    "pcm_groupnorm_stats": [vp, vp, i32, i32, i32, i32, vp],
+    "pcm_groupnorm_apply": [vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp],
+    "pcm_groupnorm_bwd_stats": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp],
+    "pcm_groupnorm_bwd_apply": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp],
+    "pcm_layernorm_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, f32, vp],
+    "pcm_layernorm_bwd": [vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
+    "pcm_geglu_fwd": [vp, vp, i32, i32, vp],
+    "pcm_geglu_bwd": [vp, vp, vp, i32, i32, vp],
+    "pcm_attn_fwd": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp],
+    "pcm_attn_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp],
+    "pcm_upsample2x_nhwc": [vp, vp, i32, i32, i32, i32, vp],
+    "pcm_pool2x_sum_nhwc": [vp, vp, i32, i32, i32, i32, vp],
+    "pcm_concat_channels": [vp, i32, vp, i32, vp, i64, vp],
+    "pcm_split_channels": [vp, vp, i32, vp, i32, i64, i32, vp],
+    "pcm_add_bf16": [vp, vp, vp, i64, vp],
+    "pcm_colsum_bf16": [vp, vp, i32, i32, i32, vp],
+    "pcm_silu_bf16": [vp, vp, i64, vp],
+    "pcm_conv_in_fwd": [vp, vp, vp, vp, i32, i32, i32, i32, vp],
+    "pcm_conv_out_fwd": [vp, vp, vp, vp, i32, i32, i32, i32, vp],
+    "pcm_conv_out_bwd": [vp, vp, vp, i32, i32, i32, i32, vp],
+    "pcm_timestep_embedding": [vp, vp, i32, i32, vp],
+    "pcm_add_noise": [vp, vp, vp, vp, vp, i32, i32, vp],
+    "pcm_phase_jump": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, i32, i32, vp],
+    "pcm_cfg_ddim_step": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
+    "pcm_consistency_loss": [vp, vp, vp, i32, f32, vp, vp, i32, i32, vp],
+    "pcm_sumsq_f32": [vp, vp, i64, vp],
+    "pcm_adamw_clip_step": [vp, vp, vp, vp, vp, f32, f32, f32, f32, f32, f32, i32, f32, i64, vp],
+    "pcm_ema_update": [vp, vp, f32, i64, vp],
+    "pcm_pack_linear": [vp, vp, vp, i32, i32, f32, vp],
+    "pcm_pack_conv3x3": [vp, vp, vp, i32, i32, f32, vp],
+    "pcm_cast_f32_bf16": [vp, vp, i64, vp],
+    "pcm_cast_bf16_f32": [vp, vp, i64, vp],
+}
+
+
+class PcmError(RuntimeError):
+    pass
+
+
+def ptr(t):
+    """Raw device/host pointer of a tensor (or None)."""
+    if t is None:
+        return None
+    return vp(t.data_ptr())
+
+
+class Lib:
+    """Loaded C-ABI library with checked calls: ``lib.call('pcm_x', args...)``."""
+
+    def __init__(self, path=DEFAULT_LIB):
+        if not os.path.exists(path):
+            raise RuntimeError(
+                f"pcm_amd: HIP library not found at {path}. Build it with "
+                "`python __graft_entry__.py` (or pcm_amd/build.py). There is no fallback path.")
+        self.path = path
+        self.dll = C.CDLL(path)
+        self.dll.pcm_last_error.restype = C.c_char_p
+        self.dll.pcm_abi_version.restype = C.c_int
+        self.fn = {}
+        for name, argt in _PROTOS.items():
+            f = getattr(self.dll, name, None)
+            if f is None:
+                continue  # checked by tests/test_capi_symbols.py; calling a missing symbol raises below
+            f.argtypes = argt
+            f.restype = C.c_int
+            self.fn[name] = f
+
+    def call(self, name, *args):
+        f = self.fn.get(name)
+        if f is None:
+            raise PcmError(f"{name}: symbol not exported by {self.path}")
+        rc = f(*args)
+        if rc != 0:
+            raise PcmError(f"{name} failed (rc={rc}): {self.dll.pcm_last_error().decode()}")
+
+    @staticmethod
+    def stream():
+        """torch's current HIP stream as a void* (NULL on CPU tensors / host-emulation tests)."""
+        if torch.cuda.is_available():
+            return vp(torch.cuda.current_stream().cuda_stream)
+        return vp(0)
+
+
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = Lib()
+    return _LIB
+
+
+def set_lib(l):
+    """Tests only: point the op layer at another build of the same C ABI (tests/emu)."""
+    global _LIB
+    _LIB = l

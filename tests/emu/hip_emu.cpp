@@ -1,0 +1,120 @@
+// TEST INFRASTRUCTURE ONLY — fiber scheduler for tests/emu/hip_emu.h
+#include "hip_emu.h"
+
+namespace pcm_emu {
+std::vector<Fiber> g_fibers;
+std::vector<WaveScratch> g_waves;
+ucontext_t g_sched;
+Fiber* g_cur = nullptr;
+int g_block_arrived = 0, g_block_alive = 0;
+dim3 g_threadIdx, g_blockIdx, g_blockDim, g_gridDim;
+std::function<void()> g_body;
+char* g_dyn_smem = nullptr;
+static const size_t STACK = 256 * 1024;
+
+void yield_to_sched() { swapcontext(&g_cur->ctx, &g_sched); }
+
+void wave_sync() {
+  Fiber* f = g_cur;
+  WaveScratch& w = g_waves[f->wave];
+  w.arrived++;
+  if (w.arrived == w.alive) {
+    w.arrived = 0;
+    w.gen++;
+    for (auto& o : g_fibers)
+      if (o.wave == f->wave && o.st == WAIT_WAVE) o.st = RUNNABLE;
+    return;  // last arriver continues immediately
+  }
+  f->st = WAIT_WAVE;
+  yield_to_sched();
+}
+
+void block_sync() {
+  Fiber* f = g_cur;
+  g_block_arrived++;
+  if (g_block_arrived == g_block_alive) {
+    g_block_arrived = 0;
+    for (auto& o : g_fibers)
+      if (o.st == WAIT_BLOCK) o.st = RUNNABLE;
+    return;
+  }
+  f->st = WAIT_BLOCK;
+  yield_to_sched();
+}
+
+static void trampoline() {
+  g_body();
+  Fiber* f = g_cur;
+  f->st = DONE;
+  // a finished lane no longer takes part in rendezvous
+  WaveScratch& w = g_waves[f->wave];
+  w.alive--;
+  g_block_alive--;
+  if (w.alive > 0 && w.arrived == w.alive) {
+    w.arrived = 0; w.gen++;
+    for (auto& o : g_fibers) if (o.wave == f->wave && o.st == WAIT_WAVE) o.st = RUNNABLE;
+  }
+  if (g_block_alive > 0 && g_block_arrived == g_block_alive) {
+    g_block_arrived = 0;
+    for (auto& o : g_fibers) if (o.st == WAIT_BLOCK) o.st = RUNNABLE;
+  }
+  swapcontext(&f->ctx, &g_sched);
+}
+
+void launch(dim3 grid, dim3 block, size_t smem, std::function<void()> body) {
+  int nthreads = block.x * block.y * block.z;
+  int nwaves = (nthreads + 63) / 64;
+  g_body = body;
+  g_blockDim = block;
+  g_gridDim = grid;
+  std::vector<char> dyn(smem + 64);
+  g_dyn_smem = (char*)(((uintptr_t)dyn.data() + 63) & ~(uintptr_t)63);
+  if ((int)g_fibers.size() < nthreads) {
+    size_t old = g_fibers.size();
+    g_fibers.resize(nthreads);
+    for (size_t i = old; i < g_fibers.size(); i++) g_fibers[i].stack = (char*)malloc(STACK);
+  }
+  for (unsigned bz = 0; bz < grid.z; bz++)
+    for (unsigned by = 0; by < grid.y; by++)
+      for (unsigned bx = 0; bx < grid.x; bx++) {
+        g_blockIdx = dim3(bx, by, bz);
+        g_waves.assign(nwaves, WaveScratch());
+        for (int w = 0; w < nwaves; w++) {
+          g_waves[w].arrived = 0; g_waves[w].gen = 0;
+          g_waves[w].alive = std::min(64, nthreads - 64 * w);
+        }
+        g_block_arrived = 0;
+        g_block_alive = nthreads;
+        for (int t = 0; t < nthreads; t++) {
+          Fiber& f = g_fibers[t];
+          f.st = RUNNABLE;
+          f.lin = t; f.wave = t / 64; f.lane = t % 64;
+          f.tid = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
+          getcontext(&f.ctx);
+          f.ctx.uc_stack.ss_sp = f.stack;
+          f.ctx.uc_stack.ss_size = STACK;
+          f.ctx.uc_link = &g_sched;
+          makecontext(&f.ctx, trampoline, 0);
+        }
+        int done = 0;
+        while (done < nthreads) {
+          bool progressed = false;
+          for (int t = 0; t < nthreads; t++) {
+            Fiber& f = g_fibers[t];
+            if (f.st != RUNNABLE) continue;
+            progressed = true;
+            g_cur = &f;
+            g_threadIdx = f.tid;
+            swapcontext(&g_sched, &f.ctx);
+            if (f.st == DONE) done++;
+          }
+          if (!progressed) {
+            fprintf(stderr, "pcm_emu: DEADLOCK in block (%u,%u,%u): %d/%d done (divergent barrier?)\n",
+                    bx, by, bz, done, nthreads);
+            abort();
+          }
+        }
+      }
+  g_cur = nullptr;
+}
+}  // namespace pcm_emu

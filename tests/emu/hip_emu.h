@@ -1,0 +1,194 @@
+// TEST INFRASTRUCTURE ONLY — host emulation of the small HIP/gfx950 subset the kernels in
+// phased-consistency-model_amd/csrc use, so that their index math (MFMA fragment layouts, LDS
+// tiling, im2col masks, reductions) can be checked on the GPU-less build container.
+// The shipped library is built by hipcc for gfx950 and never sees this header
+// (csrc/pcm_common.h includes it only under -DPCM_HOST_EMU, which only tests/emu/build_emu.py sets).
+//
+// Model: one block at a time; every thread of the block is a ucontext fiber; __syncthreads and
+// wave-collectives (shuffles, MFMA, global_load_lds) are cooperative rendezvous points.
+// MFMA fragment layouts follow /opt/skills/guides/cdna_hip_programming.md §3.
+#pragma once
+#include <ucontext.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __shared__ static
+#define __restrict__ __restrict
+
+struct dim3 {
+  unsigned x, y, z;
+  dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct float2 { float x, y; };
+struct float4 { float x, y, z, w; };
+struct uint2 { unsigned x, y; };
+struct uint4 { unsigned x, y, z, w; };
+struct int4 { int x, y, z, w; };
+static inline float4 make_float4(float a, float b, float c, float d) { return {a, b, c, d}; }
+static inline float2 make_float2(float a, float b) { return {a, b}; }
+static inline uint4 make_uint4(unsigned a, unsigned b, unsigned c, unsigned d) { return {a, b, c, d}; }
+static inline uint2 make_uint2(unsigned a, unsigned b) { return {a, b}; }
+
+typedef void* hipStream_t;
+typedef int hipError_t;
+#define hipSuccess 0
+static inline hipError_t hipGetLastError() { return 0; }
+static inline const char* hipGetErrorString(hipError_t) { return "emu"; }
+static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return 0; }
+
+namespace pcm_emu {
+
+enum State { RUNNABLE, WAIT_WAVE, WAIT_BLOCK, DONE };
+struct Fiber {
+  ucontext_t ctx;
+  char* stack;
+  State st;
+  dim3 tid;
+  int lin, wave, lane;
+};
+struct WaveScratch {
+  // double-buffered exchange area (see hip_emu.h header comment in launch())
+  uint64_t u64[2][64];
+  short ab[2][2][64][8];
+  const void* gp[2][64];
+  void* lp[2][64];
+  int arrived, alive, gen;
+};
+
+extern std::vector<Fiber> g_fibers;
+extern std::vector<WaveScratch> g_waves;
+extern ucontext_t g_sched;
+extern Fiber* g_cur;
+extern int g_block_arrived, g_block_alive;
+extern dim3 g_threadIdx, g_blockIdx, g_blockDim, g_gridDim;
+extern std::function<void()> g_body;
+extern char* g_dyn_smem;
+
+void yield_to_sched();
+void wave_sync();
+void block_sync();
+void launch(dim3 grid, dim3 block, size_t smem, std::function<void()> body);
+
+inline int lane_id() { return g_cur->lane; }
+inline WaveScratch& wave() { return g_waves[g_cur->wave]; }
+
+template <typename T>
+inline T shfl_idx(T v, int src) {
+  static_assert(sizeof(T) <= 8, "");
+  WaveScratch& w = wave();
+  int b = w.gen & 1;
+  uint64_t bits = 0;
+  memcpy(&bits, &v, sizeof(T));
+  w.u64[b][lane_id()] = bits;
+  wave_sync();
+  T out;
+  memcpy(&out, &w.u64[b][src & 63], sizeof(T));
+  return out;
+}
+
+typedef short bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+inline float bf2f(short s) {
+  uint32_t u = ((uint32_t)(uint16_t)s) << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+// D[i][j] += sum_k A[i][k] B[k][j];  A: lane l holds A[l&31][8*(l>>5)+e]; B: B[8*(l>>5)+e][l&31];
+// D: lane l reg r -> j = l&31, i = (r&3) + 8*(r>>2) + 4*(l>>5)
+inline f32x16_t mfma_32x32x16_bf16(bf16x8_t a, bf16x8_t b, f32x16_t c, int, int, int) {
+  WaveScratch& w = wave();
+  int bsel = w.gen & 1, l = lane_id();
+  for (int e = 0; e < 8; e++) { w.ab[bsel][0][l][e] = a[e]; w.ab[bsel][1][l][e] = b[e]; }
+  wave_sync();
+  int j = l & 31;
+  for (int r = 0; r < 16; r++) {
+    int i = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+    float acc = c[r];
+    for (int k = 0; k < 16; k++)
+      acc = fmaf(bf2f(w.ab[bsel][0][i + 32 * (k >> 3)][k & 7]), bf2f(w.ab[bsel][1][j + 32 * (k >> 3)][k & 7]), acc);
+    c[r] = acc;
+  }
+  return c;
+}
+// A: lane l holds A[l&15][8*(l>>4)+e]; B[8*(l>>4)+e][l&15]; D: j = l&15, i = 4*(l>>4)+r
+inline f32x4_t mfma_16x16x32_bf16(bf16x8_t a, bf16x8_t b, f32x4_t c, int, int, int) {
+  WaveScratch& w = wave();
+  int bsel = w.gen & 1, l = lane_id();
+  for (int e = 0; e < 8; e++) { w.ab[bsel][0][l][e] = a[e]; w.ab[bsel][1][l][e] = b[e]; }
+  wave_sync();
+  int j = l & 15;
+  for (int r = 0; r < 4; r++) {
+    int i = 4 * (l >> 4) + r;
+    float acc = c[r];
+    for (int k = 0; k < 32; k++)
+      acc = fmaf(bf2f(w.ab[bsel][0][i + 16 * (k >> 3)][k & 7]), bf2f(w.ab[bsel][1][j + 16 * (k >> 3)][k & 7]), acc);
+    c[r] = acc;
+  }
+  return c;
+}
+
+// LDS-DMA: LDS dst = (first lane's ldsptr) + lane*size ; src = own gptr (offset must be 0)
+inline void global_load_lds(const void* g, void* lds, int size, int offset, int) {
+  if (offset != 0) { fprintf(stderr, "emu: global_load_lds offset!=0 unsupported\n"); abort(); }
+  WaveScratch& w = wave();
+  int bsel = w.gen & 1, l = lane_id();
+  w.gp[bsel][l] = g;
+  w.lp[bsel][l] = lds;
+  wave_sync();
+  memcpy((char*)w.lp[bsel][0] + (size_t)l * size, g, size);
+}
+
+}  // namespace pcm_emu
+
+#define threadIdx (pcm_emu::g_threadIdx)
+#define blockIdx (pcm_emu::g_blockIdx)
+#define blockDim (pcm_emu::g_blockDim)
+#define gridDim (pcm_emu::g_gridDim)
+#define __syncthreads() pcm_emu::block_sync()
+#define __builtin_amdgcn_s_barrier() pcm_emu::block_sync()
+#define __builtin_amdgcn_s_setprio(x) ((void)0)
+#define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define __builtin_amdgcn_s_waitcnt(x) ((void)0)
+#define __builtin_amdgcn_mfma_f32_32x32x16_bf16 pcm_emu::mfma_32x32x16_bf16
+#define __builtin_amdgcn_mfma_f32_16x16x32_bf16 pcm_emu::mfma_16x16x32_bf16
+#define __builtin_amdgcn_global_load_lds(g, l, s, o, a) pcm_emu::global_load_lds((const void*)(g), (void*)(l), s, o, a)
+#define __builtin_amdgcn_readfirstlane(x) pcm_emu::shfl_idx((x), 0)
+#define PCM_AS1(p) (p)
+#define PCM_AS3(p) (p)
+
+template <typename T> static inline T __shfl_xor(T v, int m, int = 64) { return pcm_emu::shfl_idx(v, pcm_emu::lane_id() ^ m); }
+template <typename T> static inline T __shfl_down(T v, int d, int = 64) {
+  int s = pcm_emu::lane_id() + d;
+  return pcm_emu::shfl_idx(v, s > 63 ? pcm_emu::lane_id() : s);
+}
+template <typename T> static inline T __shfl(T v, int s, int = 64) { return pcm_emu::shfl_idx(v, s); }
+
+static inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
+static inline double atomicAdd(double* p, double v) { double o = *p; *p = o + v; return o; }
+static inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
+static inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
+#define PCM_EXPF(x) expf(x)
+#define PCM_EXP2F(x) exp2f(x)
+static inline float __fdividef(float a, float b) { return a / b; }
+static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
+static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
+static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
+
+#define PCM_LAUNCH(kern, grid, block, smem, stream, ...) \
+  pcm_emu::launch((grid), (block), (smem), [=]() { kern(__VA_ARGS__); })
+#define PCM_DYN_SMEM(name) char* name = pcm_emu::g_dyn_smem

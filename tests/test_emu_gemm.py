@@ -1,0 +1,70 @@
+"""Host-emulation checks of pcm_gemm_bf16 index math (MFMA fragment layout, LDS swizzle, im2col
+masks, LoRA second segment, epilogue) against plain torch fp32 on the same bf16-rounded inputs."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from emu_lib import emu_lib
+from pcm_amd import capi, ops
+
+
+@pytest.fixture(autouse=True)
+def _use_emu():
+    capi.set_lib(emu_lib())
+    yield
+    capi.set_lib(None)
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).bfloat16()
+
+
+def test_plain_gemm_bias_residual_lora():
+    M, N, K = 200, 192, 136   # ragged M, N%128!=0, K tail (136 = 2*64 + 8)
+    x, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.1)
+    t, bl = rnd(M, 64, seed=3), rnd(N, 64, seed=4, scale=0.1)
+    bias = torch.randn(N, generator=torch.Generator().manual_seed(5))
+    res = rnd(M, N, seed=6)
+    out = torch.empty(M, N, dtype=torch.bfloat16)
+    ops.gemm([ops.Seg(x, w), ops.Seg(t, bl)], M, N, out, bias=bias, residual=res)
+    ref = x.float() @ w.float().T + t.float() @ bl.float().T + bias + res.float()
+    assert torch.allclose(out.float(), ref, rtol=1e-2, atol=2e-2), (out.float() - ref).abs().max()
+    # asymmetric check: fp32 output, silu, alpha
+    out32 = torch.empty(M, N, dtype=torch.float32)
+    ops.gemm([ops.Seg(x, w)], M, N, out32, act=capi.ACT_SILU, alpha=0.5)
+    ref = F.silu(0.5 * (x.float() @ w.float().T))
+    assert torch.allclose(out32, ref, rtol=1e-4, atol=1e-4), (out32 - ref).abs().max()
+
+
+@pytest.mark.parametrize("stride,src_mode", [(1, capi.SRC_DIRECT), (2, capi.SRC_DIRECT),
+                                             (1, capi.SRC_UPSAMPLE2), (1, capi.SRC_ZEROINS2)])
+def test_conv3x3_implicit_gemm(stride, src_mode):
+    B, Hs, Ws, Ci, Co = 2, 6, 5, 64, 64
+    x = rnd(B, Hs, Ws, Ci, seed=7)
+    w = rnd(Co, Ci, 3, 3, seed=8, scale=0.05)
+    xn = x.float().permute(0, 3, 1, 2)
+    if src_mode == capi.SRC_UPSAMPLE2:
+        xv = F.interpolate(xn, scale_factor=2.0, mode="nearest")
+    elif src_mode == capi.SRC_ZEROINS2:
+        xv = torch.zeros(B, Ci, 2 * Hs, 2 * Ws)
+        xv[:, :, ::2, ::2] = xn
+    else:
+        xv = xn
+    ref = F.conv2d(xv, w.float(), None, stride=stride, padding=1)
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    M = B * Ho * Wo
+    wk = w.permute(0, 2, 3, 1).reshape(Co, 9 * Ci).contiguous()
+    temb = rnd(B, Co, seed=9)
+    out = torch.empty(M, Co, dtype=torch.float32)
+    ops.gemm([ops.Seg(x, wk, conv=dict(Hs=Hs, Ws=Ws, stride=stride, src_mode=src_mode))], M, Co, out,
+             rowvec=temb, rows_per_batch=Ho * Wo, Ho=Ho, Wo=Wo)
+    ref = ref + temb.float()[:, :, None, None]
+    ref = ref.permute(0, 2, 3, 1).reshape(M, Co)
+    assert torch.allclose(out, ref, rtol=1e-3, atol=1e-3), (out - ref).abs().max()
+
+
+def test_gemm_rejects_bad_args():
+    x, w = rnd(8, 12), rnd(8, 12)
+    with pytest.raises(capi.PcmError):
+        ops.gemm([ops.Seg(x, w)], 8, 8, torch.empty(8, 8, dtype=torch.bfloat16))  # K%8 != 0

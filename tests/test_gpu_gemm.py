@@ -1,0 +1,69 @@
+"""GPU parity of pcm_gemm_bf16 vs torch fp32 on the same bf16-rounded inputs (through the C ABI)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _hip():
+    from pcm_amd import capi
+    capi.set_lib(None)
+    assert torch.cuda.is_available()
+    capi.lib()  # raises loudly if libpcm_hip.so is missing
+    yield
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).bfloat16().cuda()
+
+
+@pytest.mark.parametrize("M,N,K", [(200, 192, 136), (4096, 320, 320), (1024, 1280, 1280), (77 * 2, 640, 768),
+                                   (16, 1280, 320), (8192, 2560, 320)])
+def test_plain_gemm(M, N, K):
+    from pcm_amd import capi, ops
+    x, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05)
+    t, bl = rnd(M, 64, seed=3), rnd(N, 64, seed=4, scale=0.05)
+    bias = torch.randn(N, generator=torch.Generator().manual_seed(5)).cuda()
+    res = rnd(M, N, seed=6)
+    out = torch.empty(M, N, dtype=torch.float32, device="cuda")
+    ops.gemm([ops.Seg(x, w), ops.Seg(t, bl)], M, N, out, bias=bias, residual=res)
+    ref = x.float() @ w.float().T + t.float() @ bl.float().T + bias + res.float()
+    torch.cuda.synchronize()
+    err = (out - ref).abs().max().item()
+    assert err < 2e-3 * max(1.0, ref.abs().max().item()), err
+    outb = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    ops.gemm([ops.Seg(x, w)], M, N, outb, act=capi.ACT_SILU, alpha=0.5)
+    ref = F.silu(0.5 * (x.float() @ w.float().T))
+    assert torch.allclose(outb.float(), ref, rtol=1e-2, atol=1e-2)
+
+
+@pytest.mark.parametrize("stride,src_mode", [(1, 0), (2, 0), (1, 1), (1, 2)])
+@pytest.mark.parametrize("B,Hs,Ci,Co", [(2, 16, 64, 64), (2, 32, 320, 640), (1, 8, 1280, 1280)])
+def test_conv3x3(stride, src_mode, B, Hs, Ci, Co):
+    from pcm_amd import capi, ops
+    Ws = Hs
+    x = rnd(B, Hs, Ws, Ci, seed=7)
+    w = rnd(Co, Ci, 3, 3, seed=8, scale=0.02)
+    xn = x.float().permute(0, 3, 1, 2)
+    if src_mode == capi.SRC_UPSAMPLE2:
+        xv = F.interpolate(xn, scale_factor=2.0, mode="nearest")
+    elif src_mode == capi.SRC_ZEROINS2:
+        xv = torch.zeros(B, Ci, 2 * Hs, 2 * Ws, device="cuda")
+        xv[:, :, ::2, ::2] = xn
+    else:
+        xv = xn
+    ref = F.conv2d(xv, w.float(), None, stride=stride, padding=1)
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    M = B * Ho * Wo
+    wk = w.permute(0, 2, 3, 1).reshape(Co, 9 * Ci).contiguous()
+    temb = rnd(B, Co, seed=9)
+    out = torch.empty(M, Co, dtype=torch.float32, device="cuda")
+    ops.gemm([ops.Seg(x, wk, conv=dict(Hs=Hs, Ws=Ws, stride=stride, src_mode=src_mode))], M, Co, out,
+             rowvec=temb, rows_per_batch=Ho * Wo, Ho=Ho, Wo=Wo)
+    ref = (ref + temb.float()[:, :, None, None]).permute(0, 2, 3, 1).reshape(M, Co)
+    torch.cuda.synchronize()
+    err = (out - ref).abs().max().item()
+    assert err < 3e-3 * max(1.0, ref.abs().max().item()), err
