@@ -141,7 +141,7 @@ int pcm_pool2x_sum_nhwc(const void* dy, void* dx, int B, int H, int W, int C, vo
 int pcm_concat_channels(const void* a, int Ca, const void* b, int Cb, void* out, long rows, void* stream);
 int pcm_split_channels(const void* in, void* a, int Ca, void* b, int Cb, long rows, int accumulate_a, void* stream);
 int pcm_add_bf16(const void* a, const void* b, void* out, long n, void* stream);
-int pcm_colsum_bf16(const void* x, void* out /*bf16 [B][C]*/, int B, int HW, int C, void* stream); /* d(time_emb_proj out) */
+int pcm_colsum_bf16(const void* x, void* out /*fp32 [B][C], zeroed by the call*/, int B, int HW, int C, void* stream); /* d(time_emb_proj out) */
 int pcm_silu_bf16(const void* x, void* y, long n, void* stream);
 
 /* conv_in (4->C0, NCHW fp32 latent in, NHWC bf16 out) and conv_out (C0->4, NHWC bf16 in, NCHW fp32
@@ -155,28 +155,36 @@ int pcm_conv_out_bwd(const float* dy_nchw, const float* w, void* dx, int B, int 
 /* sinusoidal timestep projection (diffusers Timesteps(320, flip_sin_to_cos=True, shift=0)) */
 int pcm_timestep_embedding(const int64_t* t, void* out /*bf16 [B][dim]*/, int B, int dim, void* stream);
 
-/* ---- phased-consistency math on latents, NCHW fp32 [B][4][H][W] (reference-owned) -------- */
-/* add_noise: scheduling_ddpm_modified.py:500-524 */
+/* ---- phased-consistency math on latents, NCHW [B][4][H][W] (reference-owned) -------------
+ * The reference's DDIM tables ddim_alpha_cumprods_prev are float64 (np.asarray over python floats,
+ * train_pcm_lora_sd15.py:297-299), so its jump / x_prev / target tensors are float64 and are cast
+ * with .float() only at the UNet input and in the loss (:1264, :1285-1290).  These kernels keep
+ * that: fp32 where the reference is fp32 (no FMA contraction), fp64 where it is fp64. */
+/* add_noise: scheduling_ddpm_modified.py:500-524 (fp32) */
 int pcm_add_noise(const float* x, const float* noise, const float* alphas_cumprod, const int64_t* t,
                   float* out, int B, int per_sample, void* stream);
 /* predicted_origin(epsilon) + ddim_style_multiphase_pred + boundary blend
  * (train_pcm_lora_sd15.py:268-280, :321-341, :1212/:1280):
  *   x0 = (sample - sigma_t*eps)/alpha_t ; e = largest edge <= index ;
- *   jump = sqrt(acp_prev[e])*x0 + sqrt(1-acp_prev[e])*eps ; out = c_skip*sample + (1-c_skip)*jump
- * target_mode=0: online (c_skip=0) ; 1: target (c_skip = index in edges).  Also writes
- * coef[b] = d out / d eps (used by the backward) and end_t[b] = ddim_timesteps_prev[e]. */
-int pcm_phase_jump(const float* eps, const float* sample, const int64_t* t, const int64_t* index,
-                   const float* alphas_cumprod, const float* acp_prev /*[N_ddim]*/,
-                   const int64_t* t_prev /*[N_ddim]*/, const int64_t* edges, int n_edges, int target_mode,
+ *   jump = sqrt(acp_prev[e])*x0 + sqrt(1-acp_prev[e])*eps ; out = c_skip ? sample : jump
+ * sample is fp32 (online: noisy_model_input) or fp64 (target: x_prev) per sample_f64.
+ * target_mode=0: online (c_skip=0) ; 1: target (c_skip = index in edges).  out is fp32 (= .float()).
+ * Also writes coef[b] = d out / d eps (backward of the online branch) and
+ * end_t[b] = ddim_timesteps_prev[e].  acp_prev is the fp64 table. */
+int pcm_phase_jump(const float* eps, const void* sample, int sample_f64, const int64_t* t,
+                   const int64_t* index, const float* alphas_cumprod, const double* acp_prev,
+                   const int64_t* t_prev, const int64_t* edges, int n_edges, int target_mode,
                    float* out, float* coef, int64_t* end_t, int B, int per_sample, void* stream);
-/* CFG-augmented DDIM step (train_pcm_lora_sd15.py:1224-1258) */
+/* CFG-augmented DDIM step (train_pcm_lora_sd15.py:1224-1258): x_prev in fp64 (+ fp32 copy) */
 int pcm_cfg_ddim_step(const float* eps_c, const float* eps_u, const float* sample, const int64_t* t,
                       const int64_t* index, const float* w, const float* alphas_cumprod,
-                      const float* acp_prev, float* x_prev, int B, int per_sample, void* stream);
+                      const double* acp_prev, double* x_prev, float* x_prev_f32, int B,
+                      int per_sample, void* stream);
 /* loss (l2 | huber, :1283-1293) forward + gradient wrt the student's eps prediction:
- * loss[0] = mean(...) ; d_eps = dloss/dmodel_pred * coef[b] */
+ * loss[0] = mean(...) (accumulated in fp64, zeroed by the call) ; d_eps = dloss/dmodel_pred * coef[b] * grad_scale */
 int pcm_consistency_loss(const float* model_pred, const float* target, const float* coef, int huber,
-                         float huber_c, float* loss, float* d_eps, int B, int per_sample, void* stream);
+                         float huber_c, double* loss, float* d_eps, float grad_scale, int B,
+                         int per_sample, void* stream);
 
 /* ---- optimizer (torch.optim.AdamW + clip_grad_norm_, train_pcm_lora_sd15.py:1297-1301) ---- */
 int pcm_sumsq_f32(const float* g, double* out /*1, zeroed by the call*/, long n, void* stream);

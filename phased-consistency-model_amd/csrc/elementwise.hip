@@ -1,0 +1,306 @@
+// Data-movement and small-operator kernels of the UNet wiring (channels-last bf16, 16 B/lane):
+// nearest-2x upsample and its adjoint, channel concat/split for the skip connections, residual add,
+// SiLU, GEGLU fwd/bwd, pixel-sum (gradient of the broadcast time-embedding add), the 4-channel
+// edge convolutions conv_in / conv_out (+ conv_out input-gradient) and the sinusoidal timestep
+// projection.  All HBM-bound; grid-stride with ~2048 workgroups.
+#include "pcm_common.h"
+
+__device__ __forceinline__ void ew_unpack8(const uint4& v, float (&f)[8]) {
+  f[0] = bf2f((bf16_t)(v.x & 0xffff)); f[1] = bf2f((bf16_t)(v.x >> 16));
+  f[2] = bf2f((bf16_t)(v.y & 0xffff)); f[3] = bf2f((bf16_t)(v.y >> 16));
+  f[4] = bf2f((bf16_t)(v.z & 0xffff)); f[5] = bf2f((bf16_t)(v.z >> 16));
+  f[6] = bf2f((bf16_t)(v.w & 0xffff)); f[7] = bf2f((bf16_t)(v.w >> 16));
+}
+__device__ __forceinline__ uint4 ew_pack8(const float (&f)[8]) {
+  return make_uint4(pack_bf2(f[0], f[1]), pack_bf2(f[2], f[3]), pack_bf2(f[4], f[5]), pack_bf2(f[6], f[7]));
+}
+static inline int ew_blocks(long nvec) {
+  long b = (nvec + 255) / 256;
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+#define EW_LOOP(v, nvec) for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < (nvec); v += (long)gridDim.x * blockDim.x)
+
+// ---- upsample / pool ----
+__global__ __launch_bounds__(256) void upsample2x_kernel(const uint4* x, uint4* y, int B, int H, int W, int CV) {
+  long nvec = (long)B * 4 * H * W * CV;
+  EW_LOOP(v, nvec) {
+    int cv = (int)(v % CV); long p = v / CV;
+    int ox = (int)(p % (2 * W)); long q = p / (2 * W);
+    int oy = (int)(q % (2 * H)); int b = (int)(q / (2 * H));
+    y[v] = x[(((long)b * H + (oy >> 1)) * W + (ox >> 1)) * CV + cv];
+  }
+}
+__global__ __launch_bounds__(256) void pool2x_kernel(const uint4* dy, uint4* dx, int B, int H, int W, int CV) {
+  long nvec = (long)B * H * W * CV;
+  EW_LOOP(v, nvec) {
+    int cv = (int)(v % CV); long p = v / CV;
+    int x_ = (int)(p % W); long q = p / W;
+    int y_ = (int)(q % H); int b = (int)(q / H);
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int dy_ = 0; dy_ < 2; dy_++)
+#pragma unroll
+      for (int dx_ = 0; dx_ < 2; dx_++) {
+        float f[8];
+        ew_unpack8(dy[(((long)b * 2 * H + 2 * y_ + dy_) * 2 * W + 2 * x_ + dx_) * CV + cv], f);
+#pragma unroll
+        for (int e = 0; e < 8; e++) acc[e] += f[e];
+      }
+    dx[v] = ew_pack8(acc);
+  }
+}
+extern "C" int pcm_upsample2x_nhwc(const void* x, void* y, int B, int H, int W, int C, void* stream) {
+  PCM_CHECK(x && y && (C % 8) == 0 && PCM_ALIGNED16(x) && PCM_ALIGNED16(y), PCM_EALIGN, "pcm_upsample2x_nhwc: C%%8, alignment");
+  PCM_LAUNCH(upsample2x_kernel, dim3(ew_blocks((long)B * 4 * H * W * (C / 8))), dim3(256), 0, stream, (const uint4*)x, (uint4*)y, B, H, W, C / 8);
+  return pcm_post_launch("pcm_upsample2x_nhwc");
+}
+extern "C" int pcm_pool2x_sum_nhwc(const void* dy, void* dx, int B, int H, int W, int C, void* stream) {
+  PCM_CHECK(dy && dx && (C % 8) == 0 && PCM_ALIGNED16(dy) && PCM_ALIGNED16(dx), PCM_EALIGN, "pcm_pool2x_sum_nhwc: C%%8, alignment");
+  PCM_LAUNCH(pool2x_kernel, dim3(ew_blocks((long)B * H * W * (C / 8))), dim3(256), 0, stream, (const uint4*)dy, (uint4*)dx, B, H, W, C / 8);
+  return pcm_post_launch("pcm_pool2x_sum_nhwc");
+}
+
+// ---- concat / split ----
+__global__ __launch_bounds__(256) void concat_kernel(const uint4* a, int CVa, const uint4* b, int CVb, uint4* out, long rows) {
+  int CV = CVa + CVb;
+  long nvec = rows * CV;
+  EW_LOOP(v, nvec) {
+    int cv = (int)(v % CV); long r = v / CV;
+    out[v] = cv < CVa ? a[r * CVa + cv] : b[r * CVb + (cv - CVa)];
+  }
+}
+__global__ __launch_bounds__(256) void split_kernel(const uint4* in, uint4* a, int CVa, uint4* b, int CVb, long rows, int acc_a) {
+  int CV = CVa + CVb;
+  long nvec = rows * CV;
+  EW_LOOP(v, nvec) {
+    int cv = (int)(v % CV); long r = v / CV;
+    uint4 val = in[v];
+    if (cv < CVa) {
+      if (acc_a) {
+        float f[8], g[8];
+        ew_unpack8(val, f); ew_unpack8(a[r * CVa + cv], g);
+#pragma unroll
+        for (int e = 0; e < 8; e++) f[e] += g[e];
+        val = ew_pack8(f);
+      }
+      a[r * CVa + cv] = val;
+    } else {
+      b[r * CVb + (cv - CVa)] = val;
+    }
+  }
+}
+extern "C" int pcm_concat_channels(const void* a, int Ca, const void* b, int Cb, void* out, long rows, void* stream) {
+  PCM_CHECK(a && b && out && (Ca % 8) == 0 && (Cb % 8) == 0, PCM_EINVAL, "pcm_concat_channels: C%%8");
+  PCM_LAUNCH(concat_kernel, dim3(ew_blocks(rows * ((Ca + Cb) / 8))), dim3(256), 0, stream, (const uint4*)a, Ca / 8, (const uint4*)b, Cb / 8, (uint4*)out, rows);
+  return pcm_post_launch("pcm_concat_channels");
+}
+extern "C" int pcm_split_channels(const void* in, void* a, int Ca, void* b, int Cb, long rows, int accumulate_a, void* stream) {
+  PCM_CHECK(in && a && b && (Ca % 8) == 0 && (Cb % 8) == 0, PCM_EINVAL, "pcm_split_channels: C%%8");
+  PCM_LAUNCH(split_kernel, dim3(ew_blocks(rows * ((Ca + Cb) / 8))), dim3(256), 0, stream, (const uint4*)in, (uint4*)a, Ca / 8, (uint4*)b, Cb / 8, rows, accumulate_a);
+  return pcm_post_launch("pcm_split_channels");
+}
+
+// ---- add / silu / geglu ----
+__global__ __launch_bounds__(256) void add_kernel(const uint4* a, const uint4* b, uint4* o, long nvec) {
+  EW_LOOP(v, nvec) {
+    float f[8], g[8];
+    ew_unpack8(a[v], f); ew_unpack8(b[v], g);
+#pragma unroll
+    for (int e = 0; e < 8; e++) f[e] += g[e];
+    o[v] = ew_pack8(f);
+  }
+}
+__global__ __launch_bounds__(256) void silu_kernel(const uint4* a, uint4* o, long nvec) {
+  EW_LOOP(v, nvec) {
+    float f[8];
+    ew_unpack8(a[v], f);
+#pragma unroll
+    for (int e = 0; e < 8; e++) f[e] = silu_f(f[e]);
+    o[v] = ew_pack8(f);
+  }
+}
+extern "C" int pcm_add_bf16(const void* a, const void* b, void* out, long n, void* stream) {
+  PCM_CHECK(a && b && out && (n % 8) == 0, PCM_EINVAL, "pcm_add_bf16: n%%8");
+  PCM_LAUNCH(add_kernel, dim3(ew_blocks(n / 8)), dim3(256), 0, stream, (const uint4*)a, (const uint4*)b, (uint4*)out, n / 8);
+  return pcm_post_launch("pcm_add_bf16");
+}
+extern "C" int pcm_silu_bf16(const void* x, void* y, long n, void* stream) {
+  PCM_CHECK(x && y && (n % 8) == 0, PCM_EINVAL, "pcm_silu_bf16: n%%8");
+  PCM_LAUNCH(silu_kernel, dim3(ew_blocks(n / 8)), dim3(256), 0, stream, (const uint4*)x, (uint4*)y, n / 8);
+  return pcm_post_launch("pcm_silu_bf16");
+}
+// hg [M][2*C4]: h = cols [0,C4), g = cols [C4, 2*C4)
+__global__ __launch_bounds__(256) void geglu_fwd_kernel(const uint4* hg, uint4* out, long M, int CV4) {
+  long nvec = M * CV4;
+  EW_LOOP(v, nvec) {
+    int cv = (int)(v % CV4); long r = v / CV4;
+    float h[8], g[8];
+    ew_unpack8(hg[r * 2 * CV4 + cv], h); ew_unpack8(hg[r * 2 * CV4 + CV4 + cv], g);
+#pragma unroll
+    for (int e = 0; e < 8; e++) h[e] *= gelu_erf_f(g[e]);
+    out[v] = ew_pack8(h);
+  }
+}
+__global__ __launch_bounds__(256) void geglu_bwd_kernel(const uint4* hg, const uint4* dout, uint4* dhg, long M, int CV4) {
+  long nvec = M * CV4;
+  EW_LOOP(v, nvec) {
+    int cv = (int)(v % CV4); long r = v / CV4;
+    float h[8], g[8], d[8], dh[8], dg[8];
+    ew_unpack8(hg[r * 2 * CV4 + cv], h); ew_unpack8(hg[r * 2 * CV4 + CV4 + cv], g); ew_unpack8(dout[v], d);
+#pragma unroll
+    for (int e = 0; e < 8; e++) { dh[e] = d[e] * gelu_erf_f(g[e]); dg[e] = d[e] * h[e] * gelu_erf_grad_f(g[e]); }
+    dhg[r * 2 * CV4 + cv] = ew_pack8(dh);
+    dhg[r * 2 * CV4 + CV4 + cv] = ew_pack8(dg);
+  }
+}
+extern "C" int pcm_geglu_fwd(const void* hg, void* out, int M, int C4, void* stream) {
+  PCM_CHECK(hg && out && (C4 % 8) == 0, PCM_EINVAL, "pcm_geglu_fwd: C4%%8");
+  PCM_LAUNCH(geglu_fwd_kernel, dim3(ew_blocks((long)M * (C4 / 8))), dim3(256), 0, stream, (const uint4*)hg, (uint4*)out, (long)M, C4 / 8);
+  return pcm_post_launch("pcm_geglu_fwd");
+}
+extern "C" int pcm_geglu_bwd(const void* hg, const void* dout, void* dhg, int M, int C4, void* stream) {
+  PCM_CHECK(hg && dout && dhg && (C4 % 8) == 0, PCM_EINVAL, "pcm_geglu_bwd: C4%%8");
+  PCM_LAUNCH(geglu_bwd_kernel, dim3(ew_blocks((long)M * (C4 / 8))), dim3(256), 0, stream, (const uint4*)hg, (const uint4*)dout, (uint4*)dhg, (long)M, C4 / 8);
+  return pcm_post_launch("pcm_geglu_bwd");
+}
+
+// ---- pixel sum: out[b][c] = sum_hw x[b][hw][c]  (fp32, zeroed here) ----
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* x, float* out, int HW, int C, int CVL, int ppb) {
+  const int b = blockIdx.y, zc = blockIdx.z;
+  const int cvl = threadIdx.x % CVL, pl = threadIdx.x / CVL, k = blockDim.x / CVL;
+  const int c0 = (zc * CVL + cvl) * 8;
+  float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int p0 = blockIdx.x * ppb, p1 = p0 + ppb; if (p1 > HW) p1 = HW;
+  for (int p = p0 + pl; p < p1; p += k) {
+    float f[8];
+    ew_unpack8(*(const uint4*)(x + ((size_t)b * HW + p) * C + c0), f);
+#pragma unroll
+    for (int e = 0; e < 8; e++) s[e] += f[e];
+  }
+#pragma unroll
+  for (int e = 0; e < 8; e++) atomicAdd(&out[(size_t)b * C + c0 + e], s[e]);
+}
+extern "C" int pcm_colsum_bf16(const void* x, void* out, int B, int HW, int C, void* stream) {
+  PCM_CHECK(x && out && (C % 8) == 0 && PCM_ALIGNED16(x), PCM_EALIGN, "pcm_colsum_bf16: C%%8, alignment");
+  int CV = C / 8, split = 1;
+  while (CV / split > 256 || (CV % split) != 0) split++;
+  int CVL = CV / split, k = 256 / CVL;
+  int chunks = (1024 + B * split - 1) / (B * split);
+  int maxc = (HW + k - 1) / k; if (chunks > maxc) chunks = maxc; if (chunks < 1) chunks = 1;
+  int ppb = (HW + chunks - 1) / chunks; chunks = (HW + ppb - 1) / ppb;
+  hipMemsetAsync(out, 0, sizeof(float) * (size_t)B * C, (hipStream_t)stream);
+  PCM_LAUNCH(colsum_kernel, dim3(chunks, B, split), dim3(CVL * k), 0, stream, (const bf16_t*)x, (float*)out, HW, C, CVL, ppb);
+  return pcm_post_launch("pcm_colsum_bf16");
+}
+
+// ---- 4-channel edge convolutions -------------------------------------------------------
+// conv4: in NCHW fp32 [B][4][H][W] -> out NHWC bf16 [B][H][W][C0], 3x3 pad 1.
+// flip=0: w [C0][4][3][3] (conv_in).  flip=1: w [4][C0][3][3] read transposed with flipped taps
+// (input gradient of conv_out).  Weights staged in LDS as wl[j=(ci,tap)][c].
+__global__ __launch_bounds__(256) void conv4_kernel(const float* x, const float* w, const float* bias, bf16_t* y,
+                                                    int B, int H, int W, int C0, int flip) {
+  PCM_DYN_SMEM(smem);
+  float* wl = (float*)smem;  // [36][C0]
+  for (int i = threadIdx.x; i < 36 * C0; i += blockDim.x) {
+    int j = i / C0, c = i - j * C0;
+    int ci = j / 9, tap = j - ci * 9;
+    wl[i] = flip ? w[((size_t)ci * C0 + c) * 9 + (8 - tap)] : w[((size_t)c * 4 + ci) * 9 + tap];
+  }
+  __syncthreads();
+  const int CV = C0 / 8;
+  long nvec = (long)B * H * W * CV;
+  EW_LOOP(v, nvec) {
+    int cv = (int)(v % CV); long p = v / CV;
+    int px = (int)(p % W); long q = p / W;
+    int py = (int)(q % H); int b = (int)(q / H);
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) acc[e] = bias ? bias[cv * 8 + e] : 0.f;
+    for (int ci = 0; ci < 4; ci++)
+#pragma unroll
+      for (int tap = 0; tap < 9; tap++) {
+        int iy = py + tap / 3 - 1, ix = px + tap % 3 - 1;
+        if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+        float xv = x[(((size_t)b * 4 + ci) * H + iy) * W + ix];
+        const float* wr = wl + (ci * 9 + tap) * C0 + cv * 8;
+#pragma unroll
+        for (int e = 0; e < 8; e++) acc[e] += xv * wr[e];
+      }
+    *(uint4*)(y + v * 8) = ew_pack8(acc);
+  }
+}
+extern "C" int pcm_conv_in_fwd(const float* x, const float* w, const float* bias, void* y, int B, int H, int W, int C0, void* stream) {
+  PCM_CHECK(x && w && y && (C0 % 8) == 0 && C0 <= 1024, PCM_EINVAL, "pcm_conv_in_fwd: C0%%8, C0<=1024");
+  PCM_LAUNCH(conv4_kernel, dim3(ew_blocks((long)B * H * W * (C0 / 8))), dim3(256), 36 * C0 * 4, stream, x, w, bias, (bf16_t*)y, B, H, W, C0, 0);
+  return pcm_post_launch("pcm_conv_in_fwd");
+}
+extern "C" int pcm_conv_out_bwd(const float* dy, const float* w, void* dx, int B, int H, int W, int C0, void* stream) {
+  PCM_CHECK(dy && w && dx && (C0 % 8) == 0 && C0 <= 1024, PCM_EINVAL, "pcm_conv_out_bwd: C0%%8, C0<=1024");
+  PCM_LAUNCH(conv4_kernel, dim3(ew_blocks((long)B * H * W * (C0 / 8))), dim3(256), 36 * C0 * 4, stream, dy, w, (const float*)nullptr, (bf16_t*)dx, B, H, W, C0, 1);
+  return pcm_post_launch("pcm_conv_out_bwd");
+}
+// conv_out: x NHWC bf16 [B][H][W][C0] -> y NCHW fp32 [B][4][H][W]; one wave per output pixel
+__global__ __launch_bounds__(256) void conv_out_kernel(const bf16_t* x, const float* w, const float* bias, float* y,
+                                                       int B, int H, int W, int C0) {
+  PCM_DYN_SMEM(smem);
+  float* wl = (float*)smem;  // [9][4][C0]
+  for (int i = threadIdx.x; i < 36 * C0; i += blockDim.x) {
+    int tap = i / (4 * C0), r = i - tap * 4 * C0, o = r / C0, c = r - o * C0;
+    wl[i] = w[((size_t)o * C0 + c) * 9 + tap];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, CV = C0 / 8;
+  long npix = (long)B * H * W;
+  for (long p = (long)blockIdx.x * 4 + wv; p < npix; p += (long)gridDim.x * 4) {
+    int px = (int)(p % W); long q = p / W;
+    int py = (int)(q % H); int b = (int)(q / H);
+    float acc[4] = {0, 0, 0, 0};
+    for (int tap = 0; tap < 9; tap++) {
+      int iy = py + tap / 3 - 1, ix = px + tap % 3 - 1;
+      if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+      const bf16_t* xr = x + (((size_t)b * H + iy) * W + ix) * C0;
+      for (int cv = lane; cv < CV; cv += 64) {
+        float f[8];
+        ew_unpack8(*(const uint4*)(xr + cv * 8), f);
+#pragma unroll
+        for (int o = 0; o < 4; o++) {
+          const float* wr = wl + (tap * 4 + o) * C0 + cv * 8;
+#pragma unroll
+          for (int e = 0; e < 8; e++) acc[o] += f[e] * wr[e];
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 0; o < 4; o++) acc[o] = wave_sum(acc[o]);
+    if (lane < 4) {
+      float v = lane == 0 ? acc[0] : lane == 1 ? acc[1] : lane == 2 ? acc[2] : acc[3];
+      y[(((size_t)b * 4 + lane) * H + py) * W + px] = v + (bias ? bias[lane] : 0.f);
+    }
+  }
+}
+extern "C" int pcm_conv_out_fwd(const void* x, const float* w, const float* bias, float* y, int B, int H, int W, int C0, void* stream) {
+  PCM_CHECK(x && w && y && (C0 % 8) == 0 && C0 <= 1024 && PCM_ALIGNED16(x), PCM_EINVAL, "pcm_conv_out_fwd: C0%%8, C0<=1024");
+  long npix = (long)B * H * W;
+  long blocks = (npix + 3) / 4; if (blocks > 2048) blocks = 2048;
+  PCM_LAUNCH(conv_out_kernel, dim3((int)blocks), dim3(256), 36 * C0 * 4, stream, (const bf16_t*)x, w, bias, y, B, H, W, C0);
+  return pcm_post_launch("pcm_conv_out_fwd");
+}
+
+// ---- timestep projection: [cos(t f_i) | sin(t f_i)], f_i = exp(-ln(1e4) i / half) ----
+__global__ __launch_bounds__(256) void temb_kernel(const int64_t* t, bf16_t* out, int B, int dim) {
+  int half = dim / 2;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * half) return;
+  int b = i / half, j = i - b * half;
+  float f = expf(-9.210340371976184f * (float)j / (float)half);
+  float arg = (float)t[b] * f;
+  out[(size_t)b * dim + j] = f2bf(cosf(arg));
+  out[(size_t)b * dim + half + j] = f2bf(sinf(arg));
+}
+extern "C" int pcm_timestep_embedding(const int64_t* t, void* out, int B, int dim, void* stream) {
+  PCM_CHECK(t && out && (dim % 2) == 0, PCM_EINVAL, "pcm_timestep_embedding: dim even");
+  PCM_LAUNCH(temb_kernel, dim3((B * dim / 2 + 255) / 256), dim3(256), 0, stream, t, (bf16_t*)out, B, dim);
+  return pcm_post_launch("pcm_timestep_embedding");
+}

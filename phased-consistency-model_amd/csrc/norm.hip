@@ -1,0 +1,367 @@
+// GroupNorm(32)(+SiLU) and LayerNorm on channels-last bf16 activations, forward and input-gradient
+// (norm affine parameters are frozen in PCM-LoRA distillation, so no dgamma/dbeta).
+// HBM-bound: every pass streams 16 B/lane; statistics are reduced in fp32 per thread, per block in
+// LDS and across blocks with fp64 atomics (E[x^2]-E[x]^2 is then safe), so one launch covers all
+// (batch, group) pairs with >> 256 workgroups.
+#include "pcm_common.h"
+
+// ------------------------------------------------------------------------------------------
+// group statistics.  MODE 0: (sum x, sum x^2).  MODE 1 (backward): (sum dz*gamma, sum dz*gamma*xhat)
+// thread -> fixed 8-channel vector cv, strided over pixels; blockDim.x = CVL * k.
+// ------------------------------------------------------------------------------------------
+struct GNArgs {
+  const bf16_t* x;
+  const bf16_t* dy;
+  const double* stats;
+  const float* gamma;
+  const float* beta;
+  double* out;
+  int HW, C, G, cpg, CVL, csplit, ppb, act;
+  float eps;
+};
+
+__device__ __forceinline__ void unpack8(const uint4& v, float (&f)[8]) {
+  f[0] = bf2f((bf16_t)(v.x & 0xffff)); f[1] = bf2f((bf16_t)(v.x >> 16));
+  f[2] = bf2f((bf16_t)(v.y & 0xffff)); f[3] = bf2f((bf16_t)(v.y >> 16));
+  f[4] = bf2f((bf16_t)(v.z & 0xffff)); f[5] = bf2f((bf16_t)(v.z >> 16));
+  f[6] = bf2f((bf16_t)(v.w & 0xffff)); f[7] = bf2f((bf16_t)(v.w >> 16));
+}
+__device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
+  return make_uint4(pack_bf2(f[0], f[1]), pack_bf2(f[2], f[3]), pack_bf2(f[4], f[5]), pack_bf2(f[6], f[7]));
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void gn_stats_kernel(GNArgs a) {
+  __shared__ float red[2][2560];  // per-channel partials of this block's channel slice
+  __shared__ float gconst[2][32];
+  const int b = blockIdx.y, zc = blockIdx.z;      // batch, channel split
+  const int cvl = threadIdx.x % a.CVL, pl = threadIdx.x / a.CVL, k = blockDim.x / a.CVL;
+  const int c0 = (zc * a.CVL + cvl) * 8;          // first channel of this thread's vector
+  const int Cl = a.CVL * 8;                        // channels in this block's slice
+  for (int i = threadIdx.x; i < Cl; i += blockDim.x) { red[0][i] = 0.f; red[1][i] = 0.f; }
+  float ga[8], be[8], mu[8], rs[8];
+  if (MODE == 1) {
+    const double n = (double)a.HW * a.cpg;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      int c = c0 + e, g = c / a.cpg;
+      double s = a.stats[((size_t)b * a.G + g) * 2], ss = a.stats[((size_t)b * a.G + g) * 2 + 1];
+      double m = s / n, var = ss / n - m * m;
+      mu[e] = (float)m; rs[e] = (float)(1.0 / sqrt((var > 0 ? var : 0) + (double)a.eps));
+      ga[e] = a.gamma[c]; be[e] = a.beta[c];
+    }
+  }
+  __syncthreads();
+  float s1[8], s2[8];
+#pragma unroll
+  for (int e = 0; e < 8; e++) { s1[e] = 0.f; s2[e] = 0.f; }
+  const int p_begin = blockIdx.x * a.ppb;
+  int p_end = p_begin + a.ppb; if (p_end > a.HW) p_end = a.HW;
+  const bf16_t* xb = a.x + (size_t)b * a.HW * a.C + c0;
+  const bf16_t* dyb = MODE == 1 ? a.dy + (size_t)b * a.HW * a.C + c0 : nullptr;
+  for (int p = p_begin + pl; p < p_end; p += k) {
+    float xv[8];
+    unpack8(*(const uint4*)(xb + (size_t)p * a.C), xv);
+    if (MODE == 0) {
+#pragma unroll
+      for (int e = 0; e < 8; e++) { s1[e] += xv[e]; s2[e] += xv[e] * xv[e]; }
+    } else {
+      float dv[8];
+      unpack8(*(const uint4*)(dyb + (size_t)p * a.C), dv);
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        float xh = (xv[e] - mu[e]) * rs[e];
+        float dz = dv[e];
+        if (a.act == PCM_ACT_SILU) dz *= silu_grad_f(xh * ga[e] + be[e]);
+        float t = dz * ga[e];
+        s1[e] += t; s2[e] += t * xh;
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; e++) { atomicAdd(&red[0][cvl * 8 + e], s1[e]); atomicAdd(&red[1][cvl * 8 + e], s2[e]); }
+  __syncthreads();
+  const int gl = Cl / a.cpg;  // groups in this slice
+  if ((int)threadIdx.x < gl) {
+    float t1 = 0.f, t2 = 0.f;
+    for (int i = 0; i < a.cpg; i++) { t1 += red[0][threadIdx.x * a.cpg + i]; t2 += red[1][threadIdx.x * a.cpg + i]; }
+    int g = zc * gl + threadIdx.x;
+    atomicAdd(&a.out[((size_t)b * a.G + g) * 2], (double)t1);
+    atomicAdd(&a.out[((size_t)b * a.G + g) * 2 + 1], (double)t2);
+  }
+}
+
+// apply.  MODE 0: y = act(xhat*gamma+beta).  MODE 1: dx = rstd*(dz*gamma - g1/n - xhat*g2/n)
+struct GNApply {
+  const bf16_t* x;
+  const bf16_t* dy;
+  const double* stats;
+  const double* bstats;
+  const float* gamma;
+  const float* beta;
+  bf16_t* y;
+  int HW, C, G, cpg, act, vec_per_block;
+  float eps;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256) void gn_apply_kernel(GNApply a) {
+  __shared__ float sc[2560], sh[2560];     // per-channel scale / shift (MODE0) or gamma*rstd / beta... (MODE1)
+  __shared__ float gm[32], gr[32], g1[32], g2[32];
+  const int b = blockIdx.y;
+  const double n = (double)a.HW * a.cpg;
+  if ((int)threadIdx.x < a.G) {
+    int g = threadIdx.x;
+    double s = a.stats[((size_t)b * a.G + g) * 2], ss = a.stats[((size_t)b * a.G + g) * 2 + 1];
+    double m = s / n, var = ss / n - m * m;
+    gm[g] = (float)m;
+    gr[g] = (float)(1.0 / sqrt((var > 0 ? var : 0) + (double)a.eps));
+    if (MODE == 1) {
+      g1[g] = (float)(a.bstats[((size_t)b * a.G + g) * 2] / n);
+      g2[g] = (float)(a.bstats[((size_t)b * a.G + g) * 2 + 1] / n);
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < a.C; c += blockDim.x) {
+    int g = c / a.cpg;
+    if (MODE == 0) {
+      float s_ = gr[g] * a.gamma[c];
+      sc[c] = s_; sh[c] = a.beta[c] - gm[g] * s_;
+    } else {
+      sc[c] = a.gamma[c]; sh[c] = a.beta[c];
+    }
+  }
+  __syncthreads();
+  const int CV = a.C / 8;
+  const size_t nvec = (size_t)a.HW * CV;
+  const size_t v0 = (size_t)blockIdx.x * a.vec_per_block;
+  size_t v1 = v0 + a.vec_per_block; if (v1 > nvec) v1 = nvec;
+  const bf16_t* xb = a.x + (size_t)b * a.HW * a.C;
+  bf16_t* yb = a.y + (size_t)b * a.HW * a.C;
+  const bf16_t* dyb = MODE == 1 ? a.dy + (size_t)b * a.HW * a.C : nullptr;
+  for (size_t v = v0 + threadIdx.x; v < v1; v += blockDim.x) {
+    int c0 = (int)(v % CV) * 8;
+    float xv[8], o[8];
+    unpack8(*(const uint4*)(xb + v * 8), xv);
+    if (MODE == 0) {
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        float z = xv[e] * sc[c0 + e] + sh[c0 + e];
+        o[e] = a.act == PCM_ACT_SILU ? silu_f(z) : z;
+      }
+    } else {
+      float dv[8];
+      unpack8(*(const uint4*)(dyb + v * 8), dv);
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        int c = c0 + e, g = c / a.cpg;
+        float xh = (xv[e] - gm[g]) * gr[g];
+        float dz = dv[e];
+        if (a.act == PCM_ACT_SILU) dz *= silu_grad_f(xh * sc[c] + sh[c]);
+        o[e] = gr[g] * (dz * sc[c] - g1[g] - xh * g2[g]);
+      }
+    }
+    *(uint4*)(yb + v * 8) = pack8(o);
+  }
+}
+
+static int gn_check(const char* what, int B, int HW, int C, int G) {
+  PCM_CHECK(B > 0 && HW > 0 && C > 0 && G > 0 && G <= 32 && (C % G) == 0 && (C % 8) == 0 && C <= 2560 * 8, PCM_EINVAL,
+            "%s: need G<=32, C%%G==0, C%%8==0 (B=%d HW=%d C=%d G=%d)", what, B, HW, C, G);
+  return PCM_OK;
+}
+
+template <int MODE>
+static int gn_stats_launch(const char* what, GNArgs a, int B, void* stream) {
+  int CV = a.C / 8;
+  int split = 1;
+  // channel split so a block's slice has <= 256 vectors and whole groups
+  while (CV / split > 256 || (CV % split) != 0 || ((a.C / split) % a.cpg) != 0) {
+    split++;
+    PCM_CHECK(split <= a.G, PCM_EUNSUPPORTED, "%s: cannot split C=%d over groups of %d", what, a.C, a.cpg);
+  }
+  a.CVL = CV / split; a.csplit = split;
+  PCM_CHECK(a.CVL * 8 <= 2560, PCM_EUNSUPPORTED, "%s: channel slice too large", what);
+  int k = 256 / a.CVL; if (k < 1) k = 1;
+  int threads = a.CVL * k;
+  int chunks = (2048 + B * split - 1) / (B * split);
+  int maxchunks = (a.HW + k - 1) / k; if (chunks > maxchunks) chunks = maxchunks; if (chunks < 1) chunks = 1;
+  a.ppb = (a.HW + chunks - 1) / chunks;
+  chunks = (a.HW + a.ppb - 1) / a.ppb;
+  hipMemsetAsync(a.out, 0, sizeof(double) * 2 * B * a.G, (hipStream_t)stream);
+  PCM_LAUNCH((gn_stats_kernel<MODE>), dim3(chunks, B, split), dim3(threads), 0, stream, a);
+  return pcm_post_launch(what);
+}
+
+extern "C" int pcm_groupnorm_stats(const void* x, double* stats, int B, int HW, int C, int G, void* stream) {
+  if (int rc = gn_check("pcm_groupnorm_stats", B, HW, C, G)) return rc;
+  PCM_CHECK(x && stats && PCM_ALIGNED16(x), PCM_EALIGN, "pcm_groupnorm_stats: x must be 16-byte aligned");
+  GNArgs a; memset(&a, 0, sizeof(a));
+  a.x = (const bf16_t*)x; a.out = stats; a.HW = HW; a.C = C; a.G = G; a.cpg = C / G;
+  return gn_stats_launch<0>("pcm_groupnorm_stats", a, B, stream);
+}
+
+extern "C" int pcm_groupnorm_bwd_stats(const void* x, const void* dy, const double* stats, const float* gamma,
+                                       const float* beta, double* bstats, int B, int HW, int C, int G,
+                                       float eps, int act, void* stream) {
+  if (int rc = gn_check("pcm_groupnorm_bwd_stats", B, HW, C, G)) return rc;
+  PCM_CHECK(x && dy && stats && gamma && beta && bstats && PCM_ALIGNED16(x) && PCM_ALIGNED16(dy), PCM_EALIGN,
+            "pcm_groupnorm_bwd_stats: null/unaligned argument");
+  GNArgs a; memset(&a, 0, sizeof(a));
+  a.x = (const bf16_t*)x; a.dy = (const bf16_t*)dy; a.stats = stats; a.gamma = gamma; a.beta = beta;
+  a.out = bstats; a.HW = HW; a.C = C; a.G = G; a.cpg = C / G; a.eps = eps; a.act = act;
+  return gn_stats_launch<1>("pcm_groupnorm_bwd_stats", a, B, stream);
+}
+
+template <int MODE>
+static int gn_apply_launch(const char* what, GNApply a, int B, void* stream) {
+  size_t nvec = (size_t)a.HW * (a.C / 8);
+  int blocks = (int)((nvec + 256 * 8 - 1) / (256 * 8));
+  int cap = (4096 + B - 1) / B; if (blocks > cap) blocks = cap; if (blocks < 1) blocks = 1;
+  a.vec_per_block = (int)((nvec + blocks - 1) / blocks);
+  blocks = (int)((nvec + a.vec_per_block - 1) / a.vec_per_block);
+  PCM_LAUNCH((gn_apply_kernel<MODE>), dim3(blocks, B), dim3(256), 0, stream, a);
+  return pcm_post_launch(what);
+}
+
+extern "C" int pcm_groupnorm_apply(const void* x, const double* stats, const float* gamma, const float* beta,
+                                   void* y, int B, int HW, int C, int G, float eps, int act, void* stream) {
+  if (int rc = gn_check("pcm_groupnorm_apply", B, HW, C, G)) return rc;
+  PCM_CHECK(x && stats && gamma && beta && y && PCM_ALIGNED16(x) && PCM_ALIGNED16(y) && C <= 2560, PCM_EALIGN,
+            "pcm_groupnorm_apply: null/unaligned argument or C>2560");
+  GNApply a; memset(&a, 0, sizeof(a));
+  a.x = (const bf16_t*)x; a.stats = stats; a.gamma = gamma; a.beta = beta; a.y = (bf16_t*)y;
+  a.HW = HW; a.C = C; a.G = G; a.cpg = C / G; a.act = act; a.eps = eps;
+  return gn_apply_launch<0>("pcm_groupnorm_apply", a, B, stream);
+}
+
+extern "C" int pcm_groupnorm_bwd_apply(const void* x, const void* dy, const double* stats, const double* bstats,
+                                       const float* gamma, const float* beta, void* dx, int B, int HW, int C,
+                                       int G, float eps, int act, void* stream) {
+  if (int rc = gn_check("pcm_groupnorm_bwd_apply", B, HW, C, G)) return rc;
+  PCM_CHECK(x && dy && stats && bstats && gamma && beta && dx && PCM_ALIGNED16(x) && PCM_ALIGNED16(dy) &&
+                PCM_ALIGNED16(dx) && C <= 2560, PCM_EALIGN, "pcm_groupnorm_bwd_apply: null/unaligned argument or C>2560");
+  GNApply a; memset(&a, 0, sizeof(a));
+  a.x = (const bf16_t*)x; a.dy = (const bf16_t*)dy; a.stats = stats; a.bstats = bstats; a.gamma = gamma;
+  a.beta = beta; a.y = (bf16_t*)dx; a.HW = HW; a.C = C; a.G = G; a.cpg = C / G; a.act = act; a.eps = eps;
+  return gn_apply_launch<1>("pcm_groupnorm_bwd_apply", a, B, stream);
+}
+
+// ------------------------------------------------------------------------------------------
+// LayerNorm over the last dim: one wave per row, 16 B/lane, row kept in registers (C <= 1536*... see VPL)
+// ------------------------------------------------------------------------------------------
+template <int VPL>  // 16-byte vectors per lane: C <= 512*VPL
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* x, const float* gamma, const float* beta, bf16_t* y,
+                                                     float* mean, float* rstd, int M, int C, float eps) {
+  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int CV = C / 8;
+  float v[VPL][8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; i++) {
+    int cv = lane + 64 * i;
+    if (cv < CV) {
+      unpack8(*(const uint4*)(x + (size_t)row * C + cv * 8), v[i]);
+#pragma unroll
+      for (int e = 0; e < 8; e++) s += v[i][e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; e++) v[i][e] = 0.f;
+    }
+  }
+  const float mu = wave_sum(s) / C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; i++)
+    if (lane + 64 * i < CV) {
+#pragma unroll
+      for (int e = 0; e < 8; e++) { float d = v[i][e] - mu; q += d * d; }
+    }
+  const float rs = rsqrtf(wave_sum(q) / C + eps);
+  if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+#pragma unroll
+  for (int i = 0; i < VPL; i++) {
+    int cv = lane + 64 * i;
+    if (cv < CV) {
+      float o[8];
+      float4 g0 = *(const float4*)(gamma + cv * 8), g1 = *(const float4*)(gamma + cv * 8 + 4);
+      float4 b0 = *(const float4*)(beta + cv * 8), b1 = *(const float4*)(beta + cv * 8 + 4);
+      const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+      const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+      for (int e = 0; e < 8; e++) o[e] = (v[i][e] - mu) * rs * gg[e] + bb[e];
+      *(uint4*)(y + (size_t)row * C + cv * 8) = pack8(o);
+    }
+  }
+}
+
+// dx = rstd * (dy*g - mean(dy*g) - xhat * mean(dy*g*xhat)) (+ dres)
+template <int VPL>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* x, const bf16_t* dy, const float* gamma, const float* mean,
+                                                     const float* rstd, const bf16_t* dres, bf16_t* dx, int M, int C) {
+  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int CV = C / 8;
+  const float mu = mean[row], rs = rstd[row];
+  float xh[VPL][8], dg[VPL][8];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; i++) {
+    int cv = lane + 64 * i;
+    if (cv < CV) {
+      float xv[8], dv[8];
+      unpack8(*(const uint4*)(x + (size_t)row * C + cv * 8), xv);
+      unpack8(*(const uint4*)(dy + (size_t)row * C + cv * 8), dv);
+      float4 g0 = *(const float4*)(gamma + cv * 8), g1 = *(const float4*)(gamma + cv * 8 + 4);
+      const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        xh[i][e] = (xv[e] - mu) * rs;
+        dg[i][e] = dv[e] * gg[e];
+        s1 += dg[i][e]; s2 += dg[i][e] * xh[i][e];
+      }
+    }
+  }
+  s1 = wave_sum(s1) / C; s2 = wave_sum(s2) / C;
+#pragma unroll
+  for (int i = 0; i < VPL; i++) {
+    int cv = lane + 64 * i;
+    if (cv < CV) {
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; e++) o[e] = rs * (dg[i][e] - s1 - xh[i][e] * s2);
+      if (dres) {
+        float r[8];
+        unpack8(*(const uint4*)(dres + (size_t)row * C + cv * 8), r);
+#pragma unroll
+        for (int e = 0; e < 8; e++) o[e] += r[e];
+      }
+      *(uint4*)(dx + (size_t)row * C + cv * 8) = pack8(o);
+    }
+  }
+}
+
+extern "C" int pcm_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean,
+                                 float* rstd, int M, int C, float eps, void* stream) {
+  PCM_CHECK(x && gamma && beta && y && mean && rstd && M > 0 && C > 0 && (C % 8) == 0 && C <= 2048, PCM_EINVAL,
+            "pcm_layernorm_fwd: need C%%8==0, C<=2048 (M=%d C=%d)", M, C);
+  PCM_CHECK(PCM_ALIGNED16(x) && PCM_ALIGNED16(y) && PCM_ALIGNED16(gamma) && PCM_ALIGNED16(beta), PCM_EALIGN, "pcm_layernorm_fwd: alignment");
+  dim3 grid((M + 3) / 4), block(256);
+  if (C <= 512) PCM_LAUNCH((ln_fwd_kernel<1>), grid, block, 0, stream, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, M, C, eps);
+  else if (C <= 1024) PCM_LAUNCH((ln_fwd_kernel<2>), grid, block, 0, stream, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, M, C, eps);
+  else PCM_LAUNCH((ln_fwd_kernel<4>), grid, block, 0, stream, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, M, C, eps);
+  return pcm_post_launch("pcm_layernorm_fwd");
+}
+
+extern "C" int pcm_layernorm_bwd(const void* x, const void* dy, const float* gamma, const float* mean, const float* rstd,
+                                 const void* dres, void* dx, int M, int C, void* stream) {
+  PCM_CHECK(x && dy && gamma && mean && rstd && dx && M > 0 && C > 0 && (C % 8) == 0 && C <= 2048, PCM_EINVAL,
+            "pcm_layernorm_bwd: need C%%8==0, C<=2048 (M=%d C=%d)", M, C);
+  PCM_CHECK(PCM_ALIGNED16(x) && PCM_ALIGNED16(dy) && PCM_ALIGNED16(dx) && PCM_ALIGNED16(gamma) && (!dres || PCM_ALIGNED16(dres)), PCM_EALIGN, "pcm_layernorm_bwd: alignment");
+  dim3 grid((M + 3) / 4), block(256);
+  if (C <= 512) PCM_LAUNCH((ln_bwd_kernel<1>), grid, block, 0, stream, (const bf16_t*)x, (const bf16_t*)dy, gamma, mean, rstd, (const bf16_t*)dres, (bf16_t*)dx, M, C);
+  else if (C <= 1024) PCM_LAUNCH((ln_bwd_kernel<2>), grid, block, 0, stream, (const bf16_t*)x, (const bf16_t*)dy, gamma, mean, rstd, (const bf16_t*)dres, (bf16_t*)dx, M, C);
+  else PCM_LAUNCH((ln_bwd_kernel<4>), grid, block, 0, stream, (const bf16_t*)x, (const bf16_t*)dy, gamma, mean, rstd, (const bf16_t*)dres, (bf16_t*)dx, M, C);
+  return pcm_post_launch("pcm_layernorm_bwd");
+}

@@ -1,0 +1,120 @@
+// Optimizer + parameter packing for the 67 M LoRA parameters (one flat fp32 buffer):
+// global-norm clip + AdamW in a single pass with the clip coefficient read from device memory
+// (no host sync: accelerate.clip_grad_norm_ + optimizer.step(), train_pcm_lora_sd15.py:1297-1301),
+// EMA (the reference's dead update_ema, :344-355) and the fp32 -> bf16 MFMA-operand packers.
+#include "pcm_common.h"
+
+#define OP_LOOP(i, n) for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (long)gridDim.x * blockDim.x)
+static inline int op_blocks(long n) { long b = (n + 255) / 256; return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b)); }
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* g, double* out, long n) {
+  __shared__ double red[4];
+  double acc = 0.0;
+  OP_LOOP(i, n) { double v = (double)g[i]; acc += v * v; }
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+extern "C" int pcm_sumsq_f32(const float* g, double* out, long n, void* stream) {
+  PCM_CHECK(g && out && n > 0, PCM_EINVAL, "pcm_sumsq_f32: null/empty");
+  hipMemsetAsync(out, 0, sizeof(double), (hipStream_t)stream);
+  PCM_LAUNCH(sumsq_kernel, dim3(op_blocks(n)), dim3(256), 0, stream, g, out, n);
+  return pcm_post_launch("pcm_sumsq_f32");
+}
+
+// torch.optim.AdamW single-tensor semantics; g' = g * grad_scale * min(1, max_norm/(||g*grad_scale|| + 1e-6))
+__global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, float* m, float* v, const double* gradsq,
+                                                    float max_norm, float lr, float b1, float b2, float eps, float wd,
+                                                    float bc1, float bc2_sqrt, float gscale, long n) {
+  float coef = gscale;
+  if (gradsq && max_norm > 0.f) {
+    float norm = (float)sqrt(*gradsq) * gscale;
+    float c = max_norm / (norm + 1e-6f);
+    coef *= c < 1.0f ? c : 1.0f;
+  }
+  const float step_size = lr / bc1;
+  OP_LOOP(i, n) {
+    float gi = g[i] * coef;
+    float pi = p[i] * (1.0f - lr * wd);
+    float mi = m[i] + (gi - m[i]) * (1.0f - b1);
+    float vi = v[i] * b2 + gi * gi * (1.0f - b2);
+    float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = pi - step_size * (mi / denom);
+    m[i] = mi; v[i] = vi;
+  }
+}
+extern "C" int pcm_adamw_clip_step(float* p, const float* g, float* m, float* v, const double* gradsq, float max_norm, float lr,
+                                   float beta1, float beta2, float eps, float wd, int step, float grad_scale, long n,
+                                   void* stream) {
+  PCM_CHECK(p && g && m && v && n > 0 && step >= 1, PCM_EINVAL, "pcm_adamw_clip_step: null/empty or step<1");
+  float bc1 = 1.0f - powf(beta1, (float)step);
+  float bc2s = sqrtf(1.0f - powf(beta2, (float)step));
+  PCM_LAUNCH(adamw_kernel, dim3(op_blocks(n)), dim3(256), 0, stream, p, g, m, v, gradsq, max_norm, lr, beta1, beta2, eps, wd, bc1, bc2s, grad_scale, n);
+  return pcm_post_launch("pcm_adamw_clip_step");
+}
+
+__global__ __launch_bounds__(256) void ema_kernel(float* t, const float* s, float rate, long n) {
+  OP_LOOP(i, n) t[i] = t[i] * rate + s[i] * (1.0f - rate);  // targ.mul_(rate).add_(src, alpha=1-rate)
+}
+extern "C" int pcm_ema_update(float* target, const float* source, float rate, long n, void* stream) {
+  PCM_CHECK(target && source && n > 0, PCM_EINVAL, "pcm_ema_update: null/empty");
+  PCM_LAUNCH(ema_kernel, dim3(op_blocks(n)), dim3(256), 0, stream, target, source, rate, n);
+  return pcm_post_launch("pcm_ema_update");
+}
+
+__global__ __launch_bounds__(256) void cast_f2b_kernel(const float* x, bf16_t* y, long n) { OP_LOOP(i, n) y[i] = f2bf(x[i]); }
+__global__ __launch_bounds__(256) void cast_b2f_kernel(const bf16_t* x, float* y, long n) { OP_LOOP(i, n) y[i] = bf2f(x[i]); }
+extern "C" int pcm_cast_f32_bf16(const float* x, void* y, long n, void* stream) {
+  PCM_CHECK(x && y && n > 0, PCM_EINVAL, "pcm_cast_f32_bf16: null/empty");
+  PCM_LAUNCH(cast_f2b_kernel, dim3(op_blocks(n)), dim3(256), 0, stream, x, (bf16_t*)y, n);
+  return pcm_post_launch("pcm_cast_f32_bf16");
+}
+extern "C" int pcm_cast_bf16_f32(const void* x, float* y, long n, void* stream) {
+  PCM_CHECK(x && y && n > 0, PCM_EINVAL, "pcm_cast_bf16_f32: null/empty");
+  PCM_LAUNCH(cast_b2f_kernel, dim3(op_blocks(n)), dim3(256), 0, stream, (const bf16_t*)x, y, n);
+  return pcm_post_launch("pcm_cast_bf16_f32");
+}
+
+// w [N][K] fp32 -> w_nk bf16 [N][K] * scale  and/or  w_kn bf16 [K][N] * scale
+__global__ __launch_bounds__(256) void pack_linear_kernel(const float* w, bf16_t* w_nk, bf16_t* w_kn, int N, int K, float scale) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const int k0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+  for (int r = ty; r < 32; r += 8) {
+    int n = n0 + r, k = k0 + tx;
+    float v = (n < N && k < K) ? w[(size_t)n * K + k] * scale : 0.f;
+    tile[r][tx] = v;
+    if (w_nk && n < N && k < K) w_nk[(size_t)n * K + k] = f2bf(v);
+  }
+  __syncthreads();
+  if (w_kn)
+    for (int r = ty; r < 32; r += 8) {
+      int k = k0 + r, n = n0 + tx;
+      if (k < K && n < N) w_kn[(size_t)k * N + n] = f2bf(tile[tx][r]);
+    }
+}
+extern "C" int pcm_pack_linear(const float* w, void* w_nk, void* w_kn, int N, int K, float scale, void* stream) {
+  PCM_CHECK(w && (w_nk || w_kn) && N > 0 && K > 0, PCM_EINVAL, "pcm_pack_linear: null/empty");
+  PCM_LAUNCH(pack_linear_kernel, dim3((K + 31) / 32, (N + 31) / 32), dim3(256), 0, stream, w, (bf16_t*)w_nk, (bf16_t*)w_kn, N, K, scale);
+  return pcm_post_launch("pcm_pack_linear");
+}
+
+// w [N][C][3][3] fp32 -> fwd [N][tap][c] ; dgrad [C][tap'][n] with tap' = 8 - tap
+__global__ __launch_bounds__(256) void pack_conv_kernel(const float* w, bf16_t* wf, bf16_t* wd, int N, int C, float scale) {
+  long total = (long)N * C * 9;
+  OP_LOOP(i, total) {
+    // iterate in fwd-output order so the fwd store is coalesced
+    int c = (int)(i % C); long r = i / C;
+    int tap = (int)(r % 9); int n = (int)(r / 9);
+    float v = w[((size_t)n * C + c) * 9 + tap] * scale;
+    bf16_t h = f2bf(v);
+    if (wf) wf[i] = h;
+    if (wd) wd[((size_t)c * 9 + (8 - tap)) * N + n] = h;
+  }
+}
+extern "C" int pcm_pack_conv3x3(const float* w, void* w_fwd, void* w_dgrad, int N, int C, float scale, void* stream) {
+  PCM_CHECK(w && (w_fwd || w_dgrad) && N > 0 && C > 0, PCM_EINVAL, "pcm_pack_conv3x3: null/empty");
+  PCM_LAUNCH(pack_conv_kernel, dim3(op_blocks((long)N * C * 9)), dim3(256), 0, stream, w, (bf16_t*)w_fwd, (bf16_t*)w_dgrad, N, C, scale);
+  return pcm_post_launch("pcm_pack_conv3x3");
+}

@@ -1,0 +1,156 @@
+// The reference-owned phased-consistency math on [B,4,H,W] latents, fused into four launches
+// and free of host round-trips (the reference rebuilds the phase-edge table with numpy and
+// copies it H2D three times per step: train_pcm_lora_sd15.py:1157-1163, :322-328).
+// Precision follows the reference op by op: fp32 ops are rounded individually (no FMA
+// contraction) and the DDIM jump / x_prev / target are fp64 like the reference's float64
+// ddim_alpha_cumprods_prev table makes them.
+#include "pcm_common.h"
+
+#ifdef PCM_HOST_EMU
+static inline float __fmul_rn(float a, float b) { volatile float r = a * b; return r; }
+static inline float __fadd_rn(float a, float b) { volatile float r = a + b; return r; }
+static inline float __fsub_rn(float a, float b) { volatile float r = a - b; return r; }
+static inline float __fdiv_rn(float a, float b) { volatile float r = a / b; return r; }
+static inline float __fsqrt_rn(float a) { volatile float r = sqrtf(a); return r; }
+static inline double __dmul_rn(double a, double b) { volatile double r = a * b; return r; }
+static inline double __dadd_rn(double a, double b) { volatile double r = a + b; return r; }
+static inline double __dsub_rn(double a, double b) { volatile double r = a - b; return r; }
+static inline double __ddiv_rn(double a, double b) { volatile double r = a / b; return r; }
+static inline double __dsqrt_rn(double a) { volatile double r = sqrt(a); return r; }
+#endif
+
+#define PM_LOOP(i, n) for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (long)gridDim.x * blockDim.x)
+static inline int pm_blocks(long n) { long b = (n + 255) / 256; return (int)(b > 1024 ? 1024 : (b < 1 ? 1 : b)); }
+
+// scheduling_ddpm_modified.py:513-523: sa = acp[t]**0.5 ; sb = (1-acp[t])**0.5 ; sa*x + sb*noise
+__global__ __launch_bounds__(256) void add_noise_kernel(const float* x, const float* noise, const float* acp, const int64_t* t,
+                                                        float* out, int B, int ps) {
+  long n = (long)B * ps;
+  PM_LOOP(i, n) {
+    int b = (int)(i / ps);
+    float a = acp[t[b]];
+    float sa = __fsqrt_rn(a), sb = __fsqrt_rn(__fsub_rn(1.0f, a));
+    out[i] = __fadd_rn(__fmul_rn(sa, x[i]), __fmul_rn(sb, noise[i]));
+  }
+}
+extern "C" int pcm_add_noise(const float* x, const float* noise, const float* acp, const int64_t* t, float* out, int B,
+                             int per_sample, void* stream) {
+  PCM_CHECK(x && noise && acp && t && out && B > 0 && per_sample > 0, PCM_EINVAL, "pcm_add_noise: null/empty");
+  PCM_LAUNCH(add_noise_kernel, dim3(pm_blocks((long)B * per_sample)), dim3(256), 0, stream, x, noise, acp, t, out, B, per_sample);
+  return pcm_post_launch("pcm_add_noise");
+}
+
+template <bool S64>
+__global__ __launch_bounds__(256) void phase_jump_kernel(const float* eps, const void* sample_, const int64_t* t, const int64_t* index,
+                                                         const float* acp, const double* acp_prev, const int64_t* t_prev,
+                                                         const int64_t* edges, int n_edges, int target_mode, float* out,
+                                                         float* coef, int64_t* end_t, int B, int ps) {
+  long n = (long)B * ps;
+  PM_LOOP(i, n) {
+    int b = (int)(i / ps);
+    int64_t idx = index[b];
+    // largest phase edge <= idx (train_pcm_lora_sd15.py:329-335); c_skip = idx in edges (:250-253)
+    int64_t e = edges[0];
+    bool is_edge = false;
+    for (int k = 0; k < n_edges; k++) {
+      if (edges[k] <= idx) e = edges[k];
+      is_edge = is_edge || (edges[k] == idx);
+    }
+    float a = acp[t[b]];
+    float alpha_t = __fsqrt_rn(a), sigma_t = __fsqrt_rn(__fsub_rn(1.0f, a));  // :812-813 fp32 tables
+    double ap = acp_prev[e];
+    double sa = __dsqrt_rn(ap), sb = __dsqrt_rn(__dsub_rn(1.0, ap));
+    float ep = eps[i];
+    float prod = __fmul_rn(sigma_t, ep);
+    double jump, smp;
+    if (S64) {
+      smp = ((const double*)sample_)[i];
+      double x0 = __ddiv_rn(__dsub_rn(smp, (double)prod), (double)alpha_t);
+      jump = __dadd_rn(__dmul_rn(sa, x0), __dmul_rn(sb, (double)ep));
+    } else {
+      float s32 = ((const float*)sample_)[i];
+      smp = (double)s32;
+      float x0 = __fdiv_rn(__fsub_rn(s32, prod), alpha_t);
+      jump = __dadd_rn(__dmul_rn(sa, (double)x0), __dmul_rn(sb, (double)ep));
+    }
+    out[i] = (float)((target_mode && is_edge) ? smp : jump);
+    if (i % ps == 0) {
+      if (coef) coef[b] = (float)(sb - sa * (double)sigma_t / (double)alpha_t);
+      if (end_t) end_t[b] = t_prev[e];
+    }
+  }
+}
+extern "C" int pcm_phase_jump(const float* eps, const void* sample, int sample_f64, const int64_t* t, const int64_t* index,
+                              const float* acp, const double* acp_prev, const int64_t* t_prev, const int64_t* edges,
+                              int n_edges, int target_mode, float* out, float* coef, int64_t* end_t, int B,
+                              int per_sample, void* stream) {
+  PCM_CHECK(eps && sample && t && index && acp && acp_prev && t_prev && edges && out && n_edges > 0 && B > 0, PCM_EINVAL,
+            "pcm_phase_jump: null/empty argument");
+  dim3 grid(pm_blocks((long)B * per_sample)), block(256);
+  if (sample_f64) PCM_LAUNCH((phase_jump_kernel<true>), grid, block, 0, stream, eps, sample, t, index, acp, acp_prev, t_prev, edges, n_edges, target_mode, out, coef, end_t, B, per_sample);
+  else PCM_LAUNCH((phase_jump_kernel<false>), grid, block, 0, stream, eps, sample, t, index, acp, acp_prev, t_prev, edges, n_edges, target_mode, out, coef, end_t, B, per_sample);
+  return pcm_post_launch("pcm_phase_jump");
+}
+
+// train_pcm_lora_sd15.py:1224-1258
+__global__ __launch_bounds__(256) void cfg_ddim_kernel(const float* ec, const float* eu, const float* sample, const int64_t* t,
+                                                       const int64_t* index, const float* w, const float* acp,
+                                                       const double* acp_prev, double* xp, float* xp32, int B, int ps) {
+  long n = (long)B * ps;
+  PM_LOOP(i, n) {
+    int b = (int)(i / ps);
+    float a = acp[t[b]];
+    float alpha_t = __fsqrt_rn(a), sigma_t = __fsqrt_rn(__fsub_rn(1.0f, a));
+    float s = sample[i], c = ec[i], u = eu[i], wb = w[b];
+    float x0c = __fdiv_rn(__fsub_rn(s, __fmul_rn(sigma_t, c)), alpha_t);
+    float x0u = __fdiv_rn(__fsub_rn(s, __fmul_rn(sigma_t, u)), alpha_t);
+    float x0 = __fadd_rn(x0c, __fmul_rn(wb, __fsub_rn(x0c, x0u)));   // :1254
+    float pn = __fadd_rn(c, __fmul_rn(wb, __fsub_rn(c, u)));          // :1255-1257
+    double ap = acp_prev[index[b]];
+    double r = __dadd_rn(__dmul_rn(__dsqrt_rn(ap), (double)x0), __dmul_rn(__dsqrt_rn(__dsub_rn(1.0, ap)), (double)pn));  // :313-319
+    xp[i] = r;
+    if (xp32) xp32[i] = (float)r;
+  }
+}
+extern "C" int pcm_cfg_ddim_step(const float* eps_c, const float* eps_u, const float* sample, const int64_t* t, const int64_t* index,
+                                 const float* w, const float* acp, const double* acp_prev, double* x_prev, float* x_prev_f32,
+                                 int B, int per_sample, void* stream) {
+  PCM_CHECK(eps_c && eps_u && sample && t && index && w && acp && acp_prev && x_prev && B > 0, PCM_EINVAL, "pcm_cfg_ddim_step: null/empty");
+  PCM_LAUNCH(cfg_ddim_kernel, dim3(pm_blocks((long)B * per_sample)), dim3(256), 0, stream, eps_c, eps_u, sample, t, index, w, acp, acp_prev, x_prev, x_prev_f32, B, per_sample);
+  return pcm_post_launch("pcm_cfg_ddim_step");
+}
+
+// train_pcm_lora_sd15.py:1283-1293 + d loss / d eps of the online branch
+__global__ __launch_bounds__(256) void loss_kernel(const float* mp, const float* tg, const float* coef, int huber, float hc,
+                                                   double* loss, float* d_eps, float gscale, int B, int ps) {
+  __shared__ double red[4];
+  long n = (long)B * ps;
+  double acc = 0.0;
+  const float inv_n = 1.0f / (float)n;
+  PM_LOOP(i, n) {
+    float d = __fsub_rn(mp[i], tg[i]);
+    float g;
+    if (huber) {
+      float r = __fsqrt_rn(__fadd_rn(__fmul_rn(d, d), __fmul_rn(hc, hc)));
+      acc += (double)__fsub_rn(r, hc);
+      g = d / r;
+    } else {
+      acc += (double)__fmul_rn(d, d);
+      g = 2.0f * d;
+    }
+    if (d_eps) d_eps[i] = g * inv_n * coef[i / ps] * gscale;
+  }
+  // block reduce (fp64 via two fp32-pair shuffles is overkill here: go through LDS)
+  double v = acc;
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(loss, (red[0] + red[1] + red[2] + red[3]) / (double)n);
+}
+extern "C" int pcm_consistency_loss(const float* model_pred, const float* target, const float* coef, int huber, float huber_c,
+                                    double* loss, float* d_eps, float grad_scale, int B, int per_sample, void* stream) {
+  PCM_CHECK(model_pred && target && loss && B > 0 && per_sample > 0 && (!d_eps || coef), PCM_EINVAL, "pcm_consistency_loss: null/empty");
+  hipMemsetAsync(loss, 0, sizeof(double), (hipStream_t)stream);
+  PCM_LAUNCH(loss_kernel, dim3(pm_blocks((long)B * per_sample)), dim3(256), 0, stream, model_pred, target, coef, huber, huber_c, loss, d_eps, grad_scale, B, per_sample);
+  return pcm_post_launch("pcm_consistency_loss");
+}

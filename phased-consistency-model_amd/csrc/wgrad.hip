@@ -1,0 +1,120 @@
+// pcm_lora_wgrad_bf16 — weight gradients of the rank-64 LoRA factors (the only trainable
+// parameters of PCM-LoRA distillation):
+//     G[g][r] += alpha * sum_m Big[m][g] * Small[m][r]
+//   dB[n][r] : Big = dY [M][N],            Small = t = x A^T   [M][64]
+//   dA[r][k] : Big = x  [M][K] or im2col,  Small = u = dY B    [M][64]
+// The contraction index m is the SLOW dimension of both operands, so tiles are transposed on the
+// way into LDS: each thread loads an 8(m) x 8(col) bf16 block (8 x 16 B), transposes it in
+// registers and writes 8 x ds_write_b128 into a [col][m] image whose 16-B chunks are XOR-swizzled
+// with ((row ^ (row>>3)) & 15) — conflict-free for both the transposed writes and the
+// ds_read_b128 MFMA fragment reads.  Block = 64 cols of Big x 64 ranks, 128 rows of m per step,
+// split over M across workgroups, fp32 atomics into the flat gradient buffer.
+#include "pcm_common.h"
+
+struct WgDev {
+  const bf16_t* big; int ldb, G, mode, Hs, Ws, C, stride, src_mode, Ho, Wo;
+  const bf16_t* small_; int lds_, M;
+  float* out; long g_stride, r_stride; int out_conv; float alpha; int m_per_block;
+};
+
+__device__ __forceinline__ int wg_off(int row, int chunk) { return row * 256 + ((chunk ^ ((row ^ (row >> 3)) & 15)) << 4); }
+
+__global__ __launch_bounds__(256) void pcm_wgrad_kernel(WgDev a) {
+  __shared__ __attribute__((aligned(16))) char lds[2 * 64 * 256];
+  char* Bt = lds;             // [64 g][128 m]
+  char* St = lds + 64 * 256;  // [64 r][128 m]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int which = tid >> 7, u = tid & 127, mg = u >> 3, cg = u & 7;  // unit: rows 8mg.., cols 8cg..
+  const int g0 = blockIdx.x * 64;
+  const int m_begin = blockIdx.y * a.m_per_block;
+  int m_end = m_begin + a.m_per_block; if (m_end > a.M) m_end = a.M;
+  const int wg = wave & 1, wr = wave >> 1;
+  const int frow = lane & 31, hi = lane >> 5;
+  int tap_y = 0, tap_x = 0, ci0 = 0;
+  if (a.mode == PCM_SEG_CONV3X3) {
+    int tap = g0 / a.C; ci0 = g0 - tap * a.C; tap_y = tap / 3; tap_x = tap - tap_y * 3;
+  }
+  const int HoWo = a.Ho * a.Wo;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; r++) acc[r] = 0.f;
+
+  for (int mc = m_begin; mc < m_end; mc += 128) {
+    uint4 rr[8], oo[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      int m = mc + 8 * mg + j;
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (m < m_end) {
+        if (which == 1) {
+          v = *(const uint4*)(a.small_ + (size_t)m * a.lds_ + 8 * cg);
+        } else if (a.mode == PCM_SEG_PLAIN) {
+          int g = g0 + 8 * cg;
+          if (g < a.G) v = *(const uint4*)(a.big + (size_t)m * a.ldb + g);
+        } else {
+          int b = m / HoWo, rem = m - b * HoWo, oy = rem / a.Wo, ox = rem - oy * a.Wo;
+          int vy = oy * a.stride + tap_y - 1, vx = ox * a.stride + tap_x - 1;
+          int sh = a.src_mode != PCM_SRC_DIRECT;
+          bool ok = vy >= 0 && vy < (a.Hs << sh) && vx >= 0 && vx < (a.Ws << sh);
+          if (a.src_mode == PCM_SRC_ZEROINS2) ok = ok && !((vy | vx) & 1);
+          if (ok) v = *(const uint4*)(a.big + ((size_t)(b * a.Hs + (vy >> sh)) * a.Ws + (vx >> sh)) * a.C + ci0 + 8 * cg);
+        }
+      }
+      rr[j] = v;
+    }
+    transpose8x8_bf16(rr, oo);
+    __syncthreads();  // previous chunk's fragment reads are done
+    char* T = which ? St : Bt;
+#pragma unroll
+    for (int e = 0; e < 8; e++) *(uint4*)(T + wg_off(8 * cg + e, mg)) = oo[e];
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 8; ks++) {
+      bf16x8 af = *(const bf16x8*)(Bt + wg_off(32 * wg + frow, 2 * ks + hi));
+      bf16x8 bf = *(const bf16x8*)(St + wg_off(32 * wr + frow, 2 * ks + hi));
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc, 0, 0, 0);
+    }
+  }
+  // D[i = g][j = r]: lane -> r = 32wr + (lane&31); regs -> g = 32wg + (q&3) + 8(q>>2) + 4hi
+  const int r = 32 * wr + frow;
+#pragma unroll
+  for (int q = 0; q < 16; q++) {
+    int g = g0 + 32 * wg + (q & 3) + 8 * (q >> 2) + 4 * hi;
+    if (g >= a.G) continue;
+    size_t off;
+    if (a.out_conv) {
+      int tap = g / a.C, ci = g - tap * a.C;
+      off = (size_t)r * 9 * a.C + (size_t)ci * 9 + tap;
+    } else {
+      off = (size_t)g * a.g_stride + (size_t)r * a.r_stride;
+    }
+    atomicAdd(a.out + off, acc[q] * a.alpha);
+  }
+}
+
+extern "C" int pcm_lora_wgrad_bf16(const pcm_wgrad_args* p, void* stream) {
+  PCM_CHECK(p && p->big && p->small_ && p->out && p->M > 0 && p->G > 0, PCM_EINVAL, "pcm_lora_wgrad_bf16: null/empty");
+  PCM_CHECK(PCM_ALIGNED16(p->big) && PCM_ALIGNED16(p->small_) && (p->lds_ % 8) == 0 && p->lds_ >= 64, PCM_EALIGN,
+            "pcm_lora_wgrad_bf16: operand alignment / small ld");
+  WgDev a; memset(&a, 0, sizeof(a));
+  a.big = (const bf16_t*)p->big; a.ldb = p->ldb; a.G = p->G; a.mode = p->mode; a.Hs = p->Hs; a.Ws = p->Ws; a.C = p->C;
+  a.stride = p->stride; a.src_mode = p->src_mode; a.Ho = p->Ho > 0 ? p->Ho : 1; a.Wo = p->Wo > 0 ? p->Wo : 1;
+  a.small_ = (const bf16_t*)p->small_; a.lds_ = p->lds_; a.M = p->M; a.out = p->out; a.g_stride = p->g_stride;
+  a.r_stride = p->r_stride; a.out_conv = p->out_conv; a.alpha = p->alpha;
+  if (p->mode == PCM_SEG_CONV3X3) {
+    PCM_CHECK(p->C > 0 && (p->C % 64) == 0 && p->G == 9 * p->C && (p->M % (a.Ho * a.Wo)) == 0 && (p->stride == 1 || p->stride == 2),
+              PCM_EINVAL, "pcm_lora_wgrad_bf16: conv view needs C%%64==0, G==9*C, M==B*Ho*Wo");
+  } else {
+    PCM_CHECK(p->mode == PCM_SEG_PLAIN && (p->G % 8) == 0 && (p->ldb % 8) == 0 && p->ldb >= p->G && !p->out_conv, PCM_EINVAL,
+              "pcm_lora_wgrad_bf16: plain view needs G%%8==0, ldb%%8==0");
+  }
+  int tiles_g = (p->G + 63) / 64;
+  int chunks = (p->M + 127) / 128;
+  int msplit = (1024 + tiles_g - 1) / tiles_g;
+  if (msplit > chunks) msplit = chunks;
+  if (msplit < 1) msplit = 1;
+  a.m_per_block = ((chunks + msplit - 1) / msplit) * 128;
+  msplit = (p->M + a.m_per_block - 1) / a.m_per_block;
+  PCM_LAUNCH(pcm_wgrad_kernel, dim3(tiles_g, msplit), dim3(256), 0, stream, a);
+  return pcm_post_launch("pcm_lora_wgrad_bf16");
+}

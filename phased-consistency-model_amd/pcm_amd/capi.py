@@ -67,9 +67,9 @@ _PROTOS = {
     "pcm_conv_out_bwd": [vp, vp, vp, i32, i32, i32, i32, vp],
     "pcm_timestep_embedding": [vp, vp, i32, i32, vp],
     "pcm_add_noise": [vp, vp, vp, vp, vp, i32, i32, vp],
-    "pcm_phase_jump": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, i32, i32, vp],
-    "pcm_cfg_ddim_step": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
-    "pcm_consistency_loss": [vp, vp, vp, i32, f32, vp, vp, i32, i32, vp],
+    "pcm_phase_jump": [vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, i32, i32, vp],
+    "pcm_cfg_ddim_step": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
+    "pcm_consistency_loss": [vp, vp, vp, i32, f32, vp, vp, f32, i32, i32, vp],
     "pcm_sumsq_f32": [vp, vp, i64, vp],
     "pcm_adamw_clip_step": [vp, vp, vp, vp, vp, f32, f32, f32, f32, f32, f32, i32, f32, i64, vp],
     "pcm_ema_update": [vp, vp, f32, i64, vp],

@@ -1,0 +1,240 @@
+"""Kernel parity cases shared by the host-emulation (CPU) and the GPU test files.  Every case
+compares the C-ABI op against plain torch fp32 evaluated on the SAME bf16-rounded inputs."""
+import torch
+import torch.nn.functional as F
+
+from pcm_amd import capi, ops
+
+
+def rnd(*shape, seed=0, scale=1.0, dev="cpu", dtype=torch.bfloat16, shift=0.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale + shift).to(dtype).to(dev)
+
+
+def close(a, b, rtol, atol, what=""):
+    a, b = a.float().cpu(), b.float().cpu()
+    err = (a - b).abs()
+    tol = atol + rtol * b.abs()
+    assert bool((err <= tol).all()), f"{what}: max err {err.max().item():.3e} (max ref {b.abs().max().item():.3e})"
+
+
+def case_groupnorm(dev, B, HW, C, G, act, eps=1e-5):
+    x = rnd(B, HW, C, seed=1, dev=dev, shift=0.3)
+    gamma = rnd(C, seed=2, dev=dev, dtype=torch.float32, shift=1.0, scale=0.2)
+    beta = rnd(C, seed=3, dev=dev, dtype=torch.float32, scale=0.2)
+    dy = rnd(B, HW, C, seed=4, dev=dev)
+    y, stats = ops.groupnorm_fwd(x, gamma, beta, G, eps, act)
+    xr = x.float().cpu().permute(0, 2, 1).requires_grad_(True)  # [B, C, HW]
+    z = F.group_norm(xr, G, gamma.cpu(), beta.cpu(), eps)
+    ref = F.silu(z) if act else z
+    close(y.permute(0, 2, 1), ref.detach(), 1e-2, 1e-2, "gn fwd")
+    ref.backward(dy.float().cpu().permute(0, 2, 1))
+    dx = ops.groupnorm_bwd(x, dy, stats, gamma, beta, G, eps, act)
+    close(dx.permute(0, 2, 1), xr.grad, 1e-2, 2e-2, "gn bwd")
+
+
+def case_layernorm(dev, M, C):
+    x = rnd(M, C, seed=1, dev=dev, shift=0.2)
+    gamma = rnd(C, seed=2, dev=dev, dtype=torch.float32, shift=1.0, scale=0.2)
+    beta = rnd(C, seed=3, dev=dev, dtype=torch.float32, scale=0.2)
+    dy = rnd(M, C, seed=4, dev=dev)
+    dres = rnd(M, C, seed=5, dev=dev)
+    y, mean, rstd = ops.layernorm_fwd(x, gamma, beta)
+    xr = x.float().cpu().requires_grad_(True)
+    ref = F.layer_norm(xr, (C,), gamma.cpu(), beta.cpu(), 1e-5)
+    close(y, ref.detach(), 1e-2, 1e-2, "ln fwd")
+    ref.backward(dy.float().cpu())
+    dx = ops.layernorm_bwd(x, dy, gamma, mean, rstd, dres)
+    close(dx, xr.grad + dres.float().cpu(), 1e-2, 2e-2, "ln bwd")
+
+
+def case_elementwise(dev):
+    B, H, W, C = 2, 3, 5, 64
+    x = rnd(B, H * W, C, seed=1, dev=dev)
+    up = ops.upsample2x(x, B, H, W)
+    ref = F.interpolate(x.float().cpu().view(B, H, W, C).permute(0, 3, 1, 2), scale_factor=2.0, mode="nearest")
+    assert torch.equal(up.float().cpu().view(B, 2 * H, 2 * W, C).permute(0, 3, 1, 2), ref)
+    dy = rnd(B, 4 * H * W, C, seed=2, dev=dev)
+    dx = ops.pool2x_sum(dy, B, H, W)
+    refp = F.avg_pool2d(dy.float().cpu().view(B, 2 * H, 2 * W, C).permute(0, 3, 1, 2), 2) * 4
+    close(dx.view(B, H, W, C).permute(0, 3, 1, 2), refp, 1e-2, 1e-2, "pool")
+    a, b = rnd(7, 64, seed=3, dev=dev), rnd(7, 128, seed=4, dev=dev)
+    cat = ops.concat_channels(a, b)
+    assert torch.equal(cat.cpu(), torch.cat([a.cpu(), b.cpu()], -1))
+    acc = rnd(7, 64, seed=5, dev=dev)
+    acc0 = acc.clone()
+    a2, b2 = ops.split_channels(cat, 64, a_out=acc, accumulate_a=True)
+    assert torch.equal(b2.cpu(), b.cpu())
+    close(a2, acc0.float().cpu() + a.float().cpu(), 1e-2, 1e-2, "split acc")
+    close(ops.add(a, acc0), a.float().cpu() + acc0.float().cpu(), 1e-2, 1e-2, "add")
+    close(ops.silu(a), F.silu(a.float().cpu()), 1e-2, 1e-2, "silu")
+    hg = rnd(5, 128, seed=6, dev=dev)
+    hr = hg.float().cpu().requires_grad_(True)
+    h, g = hr.chunk(2, -1)
+    refg = h * F.gelu(g)
+    close(ops.geglu_fwd(hg), refg.detach(), 1e-2, 1e-2, "geglu")
+    do = rnd(5, 64, seed=7, dev=dev)
+    refg.backward(do.float().cpu())
+    close(ops.geglu_bwd(hg, do), hr.grad, 1e-2, 2e-2, "geglu bwd")
+    xs = rnd(2, 37, 320, seed=8, dev=dev)
+    close(ops.colsum(xs), xs.float().cpu().sum(1), 1e-4, 1e-3, "colsum")
+    close(ops.cast_f32(ops.cast_bf16(xs.float())), xs, 0, 0, "cast")
+
+
+def case_edge_convs(dev, B=2, H=6, W=5, C0=64):
+    x = rnd(B, 4, H, W, seed=1, dev=dev, dtype=torch.float32)
+    w = rnd(C0, 4, 3, 3, seed=2, dev=dev, dtype=torch.float32, scale=0.2)
+    bias = rnd(C0, seed=3, dev=dev, dtype=torch.float32)
+    y = ops.conv_in_fwd(x, w, bias, C0)
+    ref = F.conv2d(x.cpu(), w.cpu(), bias.cpu(), padding=1)
+    close(y.view(B, H, W, C0).permute(0, 3, 1, 2), ref, 1e-2, 1e-2, "conv_in")
+    xo = rnd(B, H * W, C0, seed=4, dev=dev)
+    wo = rnd(4, C0, 3, 3, seed=5, dev=dev, dtype=torch.float32, scale=0.1)
+    bo = rnd(4, seed=6, dev=dev, dtype=torch.float32)
+    xr = xo.float().cpu().view(B, H, W, C0).permute(0, 3, 1, 2).requires_grad_(True)
+    refo = F.conv2d(xr, wo.cpu(), bo.cpu(), padding=1)
+    yo = ops.conv_out_fwd(xo, wo, bo, B, H, W)
+    close(yo, refo.detach(), 1e-4, 1e-4, "conv_out")
+    dy = rnd(B, 4, H, W, seed=7, dev=dev, dtype=torch.float32)
+    refo.backward(dy.cpu())
+    dx = ops.conv_out_bwd(dy, wo, C0)
+    close(dx.view(B, H, W, C0).permute(0, 3, 1, 2), xr.grad, 1e-2, 1e-2, "conv_out bwd")
+
+
+def case_timestep_embedding(dev):
+    from oracle.unet_sd15 import timestep_embedding
+    t = torch.tensor([0, 19, 259, 999, 500], dtype=torch.int64, device=dev)
+    out = ops.timestep_embedding(t, 320)
+    ref = timestep_embedding(t.cpu(), 320)
+    close(out, ref, 0, 8e-3, "timestep embedding")  # bf16 output, |v|<=1
+
+
+def case_pcm_math(dev, golden):
+    """Reference-owned math: compared with the fixtures produced by executing the reference's own
+    source (tests/golden/make_golden.py).  fp32 ops bit-exact; fp64 jump cast to fp32 bit-exact."""
+    from oracle import pcm_math as M
+    g = golden
+    acp = g["alphas_cumprod"].to(dev)
+    s = M.DDIMSolver(g["alphas_cumprod"].numpy(), 1000, 50)
+    acp_prev = s.ddim_alpha_cumprods_prev.to(dev)
+    assert acp_prev.dtype == torch.float64
+    t_prev = s.ddim_timesteps_prev.to(dev)
+    idx, x, eps, noise = [g[k].to(dev) for k in ("index", "x", "eps", "noise")]
+    start = g["start_timesteps"].to(dev)
+    assert torch.equal(ops.add_noise(x, noise, acp, start).cpu(), g["add_noise_fp32"])
+    for m in (1, 2, 4, 8):
+        edges = M.phase_edges(50, m).to(dev)
+        out, coef, end_t = ops.phase_jump(eps, x, start, idx, acp, acp_prev, t_prev, edges, target_mode=False)
+        assert torch.equal(end_t.cpu(), g[f"multiphase_{m}_t"])
+        # reference chain (oracle restatement, pinned bit-exactly to the reference source):
+        # predicted_origin in fp32, then the fp64 jump, then .float()
+        a_s, s_s = torch.sqrt(g["alphas_cumprod"]), torch.sqrt(1 - g["alphas_cumprod"])
+        x0_32 = M.predicted_origin(g["eps"], g["start_timesteps"], g["x"], "epsilon", a_s, s_s)
+        assert torch.equal(x0_32, g["predicted_origin_epsilon"])
+        jref, _ = s.ddim_style_multiphase_pred(x0_32, g["eps"], g["index"], m)
+        assert torch.equal(out.cpu(), jref.float()), m
+        # target mode with an fp64 sample: c_skip * x_prev + c_out * jump
+        x64 = x.double()
+        outt, _, _ = ops.phase_jump(eps, x64, start, idx, acp, acp_prev, t_prev, edges, target_mode=True)
+        a_s, s_s = torch.sqrt(g["alphas_cumprod"]), torch.sqrt(1 - g["alphas_cumprod"])
+        x0 = M.predicted_origin(g["eps"], g["start_timesteps"], g["x"].double(), "epsilon", a_s, s_s)
+        jump, _ = s.ddim_style_multiphase_pred(x0, g["eps"], g["index"], m)
+        cs = M.append_dims(g[f"target_c_skip_{m}"], 4)
+        ref = (cs * g["x"].double() + (1 - cs) * jump).float()
+        assert torch.equal(outt.cpu(), ref), m
+        # coef = d out / d eps  (finite check against autograd of the oracle chain)
+        e2 = g["eps"].clone().requires_grad_(True)
+        x0g = M.predicted_origin(e2, g["start_timesteps"], g["x"], "epsilon", a_s, s_s)
+        j2, _ = s.ddim_style_multiphase_pred(x0g, e2, g["index"], m)
+        j2.sum().backward()
+        close(coef, e2.grad[:, 0, 0, 0], 1e-5, 1e-6, "coef")
+    # CFG ddim step vs oracle restatement (itself pinned to the reference)
+    w = (torch.rand(idx.shape[0], generator=torch.Generator().manual_seed(3)) + 4.0).to(dev)
+    eu = rnd(*eps.shape, seed=11, dev=dev, dtype=torch.float32)
+    xp, xp32 = ops.cfg_ddim_step(eps, eu, x, start, idx, w, acp, acp_prev)
+    a_s, s_s = torch.sqrt(g["alphas_cumprod"]), torch.sqrt(1 - g["alphas_cumprod"])
+    c0 = M.predicted_origin(g["eps"], g["start_timesteps"], g["x"], "epsilon", a_s, s_s)
+    u0 = M.predicted_origin(eu.cpu(), g["start_timesteps"], g["x"], "epsilon", a_s, s_s)
+    wc = w.cpu().reshape(-1, 1, 1, 1)
+    px0 = c0 + wc * (c0 - u0)
+    pn = g["eps"] + wc * (g["eps"] - eu.cpu())
+    ref = s.ddim_step(px0, pn, g["index"])
+    assert ref.dtype == torch.float64
+    assert torch.equal(xp.cpu(), ref) and torch.equal(xp32.cpu(), ref.float())
+    # loss
+    for huber in (True, False):
+        mp = g["x"].clone().requires_grad_(True)
+        ref_l = M.consistency_loss(mp, g["eps"], "huber" if huber else "l2", 0.001)
+        ref_l.backward()
+        coef1 = torch.ones(idx.shape[0], device=dev) * 0.5
+        loss, d = ops.consistency_loss(x, eps, coef1, huber, 0.001)
+        assert abs(loss.item() - ref_l.item()) <= 2e-6 * abs(ref_l.item())
+        close(d, mp.grad * 0.5, 1e-5, 1e-9, "loss grad")
+
+
+def case_optim(dev):
+    from oracle.pcm_step import StepConfig, adamw_step, clip_grad_norm_
+    n = 5000
+    p = rnd(n, seed=1, dev=dev, dtype=torch.float32)
+    cfg = StepConfig(lr=1e-2)
+    pr = p.cpu().clone()
+    m = torch.zeros_like(p); v = torch.zeros_like(p)
+    state = {}
+    for step in (1, 2, 3):
+        g = rnd(n, seed=10 + step, dev=dev, dtype=torch.float32, scale=0.05 * step)
+        gs = ops.sumsq(g)
+        assert abs(gs.item() - float((g.double().cpu() ** 2).sum())) < 1e-9 * gs.item() + 1e-12
+        ops.adamw_clip_step(p, g, m, v, gs, cfg.max_grad_norm, cfg.lr, cfg.adam_beta1, cfg.adam_beta2,
+                            cfg.adam_epsilon, cfg.adam_weight_decay, step)
+        gr = [g.cpu().clone()]
+        clip_grad_norm_(gr, cfg.max_grad_norm)
+        adamw_step([pr], gr, state, step, cfg)
+        close(p, pr, 1e-5, 1e-6, f"adamw step {step}")
+    t = rnd(100, seed=2, dev=dev, dtype=torch.float32)
+    s_ = rnd(100, seed=3, dev=dev, dtype=torch.float32)
+    ref = t.cpu() * 0.99 + s_.cpu() * 0.01
+    ops.ema_update(t, s_, 0.99)
+    close(t, ref, 1e-6, 1e-7, "ema")
+
+
+def case_pack(dev):
+    w = rnd(70, 40, seed=1, dev=dev, dtype=torch.float32)
+    nk, kn = ops.pack_linear(w, scale=0.125)
+    ref = (w.cpu() * 0.125).bfloat16()
+    assert torch.equal(nk.cpu(), ref) and torch.equal(kn.cpu(), ref.T.contiguous())
+    wc = rnd(16, 24, 3, 3, seed=2, dev=dev, dtype=torch.float32)
+    f, d = ops.pack_conv3x3(wc)
+    rb = wc.cpu().bfloat16()
+    assert torch.equal(f.cpu(), rb.permute(0, 2, 3, 1).reshape(16, -1))
+    assert torch.equal(d.cpu(), rb.flip(2, 3).permute(1, 2, 3, 0).reshape(24, -1))
+
+
+def case_wgrad_plain(dev, M, N, K):
+    dy = rnd(M, N, seed=1, dev=dev)
+    t = rnd(M, 64, seed=2, dev=dev)
+    x = rnd(M, K, seed=3, dev=dev)
+    u = rnd(M, 64, seed=4, dev=dev)
+    dB = torch.zeros(N, 64, dtype=torch.float32, device=dev)
+    ops.lora_wgrad(dy, t, dB, 0.125, M, g_stride=64, r_stride=1)
+    close(dB, 0.125 * dy.float().cpu().T @ t.float().cpu(), 2e-3, 2e-3 * M ** 0.5, "dB")
+    dA = torch.zeros(64, K, dtype=torch.float32, device=dev)
+    ops.lora_wgrad(x, u, dA, 0.125, M, g_stride=1, r_stride=K)
+    close(dA, 0.125 * u.float().cpu().T @ x.float().cpu(), 2e-3, 2e-3 * M ** 0.5, "dA")
+
+
+def case_wgrad_conv(dev, B, Hs, Ws, C, stride, src_mode=0):
+    x = rnd(B, Hs, Ws, C, seed=1, dev=dev)
+    xn = x.float().cpu().permute(0, 3, 1, 2)
+    if src_mode == capi.SRC_UPSAMPLE2:
+        xv = F.interpolate(xn, scale_factor=2.0, mode="nearest")
+    else:
+        xv = xn
+    A = torch.zeros(64, C, 3, 3, requires_grad=True)
+    y = F.conv2d(xv, A, None, stride=stride, padding=1)
+    Ho, Wo = y.shape[2], y.shape[3]
+    M = B * Ho * Wo
+    u = rnd(M, 64, seed=2, dev=dev)
+    y.backward(u.float().cpu().view(B, Ho, Wo, 64).permute(0, 3, 1, 2))
+    dA = torch.zeros(64, C, 3, 3, dtype=torch.float32, device=dev)
+    ops.lora_wgrad(x, u, dA, 1.0, M, conv=dict(Hs=Hs, Ws=Ws, Ho=Ho, Wo=Wo, stride=stride, src_mode=src_mode), out_conv=True)
+    close(dA, A.grad, 2e-3, 2e-3 * M ** 0.5, "dA conv")

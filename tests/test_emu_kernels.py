@@ -1,0 +1,58 @@
+"""Host-emulation (CPU) runs of the kernel parity cases: index math of every kernel at small sizes."""
+import pytest
+
+import kernel_cases as K
+from emu_lib import emu_lib
+from pcm_amd import capi
+
+
+@pytest.fixture(autouse=True)
+def _use_emu():
+    capi.set_lib(emu_lib())
+    yield
+    capi.set_lib(None)
+
+
+@pytest.mark.parametrize("B,HW,C,G,act", [(2, 40, 320, 32, 1), (1, 9, 64, 8, 0), (2, 16, 2560, 32, 1), (1, 30, 960, 32, 1)])
+def test_groupnorm(B, HW, C, G, act):
+    K.case_groupnorm("cpu", B, HW, C, G, act)
+
+
+@pytest.mark.parametrize("M,C", [(9, 320), (5, 640), (6, 1280), (3, 64)])
+def test_layernorm(M, C):
+    K.case_layernorm("cpu", M, C)
+
+
+def test_elementwise():
+    K.case_elementwise("cpu")
+
+
+def test_edge_convs():
+    K.case_edge_convs("cpu")
+
+
+def test_timestep_embedding():
+    K.case_timestep_embedding("cpu")
+
+
+def test_pcm_math_bit_exact_vs_reference_golden(golden):
+    K.case_pcm_math("cpu", golden)
+
+
+def test_optim():
+    K.case_optim("cpu")
+
+
+def test_pack():
+    K.case_pack("cpu")
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 192, 72), (64, 64, 64)])
+def test_wgrad_plain(M, N, K):
+    import kernel_cases
+    kernel_cases.case_wgrad_plain("cpu", M, N, K)
+
+
+@pytest.mark.parametrize("stride,src_mode", [(1, 0), (2, 0), (1, 1)])
+def test_wgrad_conv(stride, src_mode):
+    K.case_wgrad_conv("cpu", 2, 6, 5, 64, stride, src_mode)
