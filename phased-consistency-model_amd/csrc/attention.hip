@@ -1,0 +1,430 @@
+// Scaled-dot-product attention over latent tokens for the SD1.5 UNet (8 heads, head_dim 40/80/160,
+// Lq in {4096,1024,256,64}, Lk = Lq (self) or 77 (text)), flash-style: scores never leave the CU.
+//
+// Forward / dQ kernels: a workgroup owns 128 query rows (4 waves x 32) and streams 64-key tiles.
+//   S^T = K Q^T is computed "swapped" (MFMA A = K tile from LDS, B = Q fragments in registers), so a
+//   lane holds 16+16 scores of ONE query row: row max/sum need a single cross-half shuffle.
+//   P^T feeds the second MFMA (O^T = V^T P^T) straight from the accumulator registers: the MFMA
+//   contraction slot (hi, e) of step ss is DEFINED as key 16ss + 8(e>>2) + 4hi + (e&3) — exactly
+//   what the lane already holds — and the V tile is staged transposed into LDS in that same key
+//   order (8x8 register transposes), so no permlane / LDS round trip for P.
+// dK/dV kernel: a workgroup owns 128 key rows and streams 64-query tiles with the roles swapped
+//   (S = Q K^T, lane = one key), the same slot trick on the query index.
+// head_dim 40 is padded to 48 for QK^T (K-step 16) and to 64 for the PV tile (32-row output tiles);
+// padded rows of the accumulators are never stored.
+#include "pcm_common.h"
+
+#define LOG2E 1.4426950408889634f
+
+template <int D>
+struct AttnCfg {
+  static constexpr int DK16 = (D + 15) / 16;     // QK^T K-steps of 16
+  static constexpr int KCH = 2 * DK16;           // 16-B chunks per row-major row (incl. zero pad)
+  static constexpr int RKU = KCH | 1;            // row stride in 16-B units (odd -> conflict-free ds_read_b128)
+  static constexpr int DV = (D + 31) / 32;       // 32-row tiles of the transposed output
+  static constexpr int DG = D / 8;               // 8-wide column groups
+};
+
+// row-major tile image: [rows][RKU*16 B]; chunk c of row r at (r*RKU + c)*16
+// transposed tile image: [d rows][64 slots] bf16 = 8 chunks of 16 B, XOR-swizzled
+__device__ __forceinline__ int tr_off(int drow, int chunk) { return drow * 128 + ((chunk ^ ((drow >> 1) & 7)) << 4); }
+
+// load a [rows x D] row-major tile (row stride ld elements) into the padded row-major LDS image
+template <int D, int ROWS>
+__device__ __forceinline__ void load_rowmajor(char* dst, const bf16_t* src, int ld, int row0, int nrows_valid, int tid) {
+  using C = AttnCfg<D>;
+  for (int u = tid; u < ROWS * C::DG; u += 256) {
+    int r = u / C::DG, c = u - r * C::DG;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (row0 + r < nrows_valid) v = *(const uint4*)(src + (size_t)(row0 + r) * ld + 8 * c);
+    *(uint4*)(dst + (r * C::RKU + c) * 16) = v;
+  }
+}
+template <int D, int ROWS>
+__device__ __forceinline__ void zero_pad_chunks(char* dst, int tid) {
+  using C = AttnCfg<D>;
+  constexpr int NP = C::KCH - C::DG;
+  if (NP > 0)
+    for (int u = tid; u < ROWS * NP; u += 256) {
+      int r = u / NP, c = C::DG + (u - r * NP);
+      *(uint4*)(dst + (r * C::RKU + c) * 16) = make_uint4(0u, 0u, 0u, 0u);
+    }
+}
+// load a [64 x D] tile TRANSPOSED into the [d][64-slot] image; slot (ss, hi, e) <-> row 16ss+8(e>>2)+4hi+(e&3)
+template <int D>
+__device__ __forceinline__ void load_transposed64(char* dst, const bf16_t* src, int ld, int row0, int nrows_valid, int tid) {
+  using C = AttnCfg<D>;
+  if (tid < 8 * C::DG) {
+    int sh = tid & 7, dg = tid >> 3;  // sh = 2*ss + hi
+    int ss = sh >> 1, hi = sh & 1;
+    uint4 rr[8], oo[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      int r = row0 + 16 * ss + 8 * (e >> 2) + 4 * hi + (e & 3);
+      rr[e] = r < nrows_valid ? *(const uint4*)(src + (size_t)r * ld + 8 * dg) : make_uint4(0u, 0u, 0u, 0u);
+    }
+    transpose8x8_bf16(rr, oo);
+#pragma unroll
+    for (int dd = 0; dd < 8; dd++) *(uint4*)(dst + tr_off(8 * dg + dd, sh)) = oo[dd];
+  }
+}
+// fragment straight from global: row-major [row][16s + 8hi ..]; zero outside [0, D) / invalid rows
+template <int D>
+__device__ __forceinline__ bf16x8 gfrag(const bf16_t* base, int ld, int row, int nrows_valid, int s, int hi) {
+  int c = 16 * s + 8 * hi;
+  bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (row < nrows_valid && c < D) return *(const bf16x8*)(base + (size_t)row * ld + c);
+  return z;
+}
+__device__ __forceinline__ bf16x8 pack_frag(const f32x16& p, int half) {
+  bf16x8 f;
+#pragma unroll
+  for (int e = 0; e < 8; e++) f[e] = (short)f2bf(p[8 * half + e]);
+  return f;
+}
+
+// ============================================================================ forward
+template <int D>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t* o, float* lse,
+                                                       int H, int Lq, int Lk, int ldq, int ldk, int ldo, float scale) {
+  using C = AttnCfg<D>;
+  __shared__ __attribute__((aligned(16))) char Ks[64 * C::RKU * 16];
+  __shared__ __attribute__((aligned(16))) char Vt[C::DV * 32 * 128];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 128 + wave * 32;
+  const bf16_t* qb = q + (size_t)b * Lq * ldq + h * D;
+  const bf16_t* kb = k + (size_t)b * Lk * ldk + h * D;
+  const bf16_t* vb = v + (size_t)b * Lk * ldk + h * D;
+  bf16x8 qf[C::DK16];
+#pragma unroll
+  for (int s = 0; s < C::DK16; s++) qf[s] = gfrag<D>(qb, ldq, q0 + l31, Lq, s, hi);
+  f32x16 acc_o[C::DV];
+#pragma unroll
+  for (int i = 0; i < C::DV; i++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc_o[i][r] = 0.f;
+  float m_run = -1e30f, l_run = 0.f;
+  const float sc = scale * LOG2E;
+  zero_pad_chunks<D, 64>(Ks, tid);
+  for (int kv0 = 0; kv0 < Lk; kv0 += 64) {
+    __syncthreads();
+    load_rowmajor<D, 64>(Ks, kb, ldk, kv0, Lk, tid);
+    load_transposed64<D>(Vt, vb, ldk, kv0, Lk, tid);
+    __syncthreads();
+    f32x16 s_[2];
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+#pragma unroll
+      for (int r = 0; r < 16; r++) s_[t][r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < C::DK16; s++) {
+        bf16x8 kf = *(const bf16x8*)(Ks + ((32 * t + l31) * C::RKU + 2 * s + hi) * 16);
+        s_[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], s_[t], 0, 0, 0);
+      }
+    }
+    float mx = -1e30f;
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        int kv = kv0 + 32 * t + 4 * hi + (r & 3) + 8 * (r >> 2);
+        float x = kv < Lk ? s_[t][r] * sc : -1e30f;
+        s_[t][r] = x;
+        mx = fmaxf(mx, x);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float m_new = fmaxf(m_run, mx);
+    float alpha = PCM_EXP2F(m_run - m_new);
+    float psum = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        float p = PCM_EXP2F(s_[t][r] - m_new);
+        s_[t][r] = p;
+        psum += p;
+      }
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int i = 0; i < C::DV; i++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc_o[i][r] *= alpha;
+    bf16x8 pf[4];
+#pragma unroll
+    for (int ss = 0; ss < 4; ss++) pf[ss] = pack_frag(s_[ss >> 1], ss & 1);
+#pragma unroll
+    for (int i = 0; i < C::DV; i++)
+#pragma unroll
+      for (int ss = 0; ss < 4; ss++) {
+        bf16x8 vf = *(const bf16x8*)(Vt + tr_off(32 * i + l31, 2 * ss + hi));
+        acc_o[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[ss], acc_o[i], 0, 0, 0);
+      }
+  }
+  float l_tot = l_run + __shfl_xor(l_run, 32);
+  float inv = 1.0f / l_tot;
+  int qrow = q0 + l31;
+  if (qrow < Lq) {
+    if (hi == 0 && lse) lse[((size_t)b * H + h) * Lq + qrow] = m_run + log2f(l_tot);
+    bf16_t* orow = o + ((size_t)b * Lq + qrow) * ldo + h * D;
+#pragma unroll
+    for (int i = 0; i < C::DV; i++)
+#pragma unroll
+      for (int qd = 0; qd < 4; qd++) {
+        int dcol = 32 * i + 8 * qd + 4 * hi;
+        if (dcol < D)
+          *(uint2*)(orow + dcol) = make_uint2(pack_bf2(acc_o[i][4 * qd] * inv, acc_o[i][4 * qd + 1] * inv),
+                                              pack_bf2(acc_o[i][4 * qd + 2] * inv, acc_o[i][4 * qd + 3] * inv));
+      }
+  }
+}
+
+// ============================================================================ backward: delta
+// delta[b][h][q] = sum_d dO[q][d] * O[q][d]
+__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* o, const bf16_t* dO, float* delta, int H, int Lq, int d, int ldo) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;  // over B*Lq*H
+  long total = (long)gridDim.y * Lq * H;
+  (void)total;
+  int b = blockIdx.y;
+  if (idx >= (long)Lq * H) return;
+  int qrow = (int)(idx / H), h = (int)(idx % H);
+  const bf16_t* op = o + ((size_t)b * Lq + qrow) * ldo + h * d;
+  const bf16_t* dp = dO + ((size_t)b * Lq + qrow) * ldo + h * d;
+  float acc = 0.f;
+  for (int c = 0; c < d; c += 8) {
+    uint4 a = *(const uint4*)(op + c), g = *(const uint4*)(dp + c);
+    const unsigned aw[4] = {a.x, a.y, a.z, a.w}, gw[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      acc += bf2f((bf16_t)(aw[e] & 0xffff)) * bf2f((bf16_t)(gw[e] & 0xffff));
+      acc += bf2f((bf16_t)(aw[e] >> 16)) * bf2f((bf16_t)(gw[e] >> 16));
+    }
+  }
+  delta[((size_t)b * H + h) * Lq + qrow] = acc;
+}
+
+// ============================================================================ backward: dQ
+template <int D>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* q, const bf16_t* k, const bf16_t* v, const bf16_t* dO,
+                                                          const float* lse, const float* delta, bf16_t* dq, int H, int Lq,
+                                                          int Lk, int ldq, int ldk, int ldo, float scale) {
+  using C = AttnCfg<D>;
+  __shared__ __attribute__((aligned(16))) char Ks[64 * C::RKU * 16];
+  __shared__ __attribute__((aligned(16))) char Vs[64 * C::RKU * 16];
+  __shared__ __attribute__((aligned(16))) char Kt[C::DV * 32 * 128];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 128 + wave * 32;
+  const bf16_t* qb = q + (size_t)b * Lq * ldq + h * D;
+  const bf16_t* dob = dO + (size_t)b * Lq * ldo + h * D;
+  const bf16_t* kb = k + (size_t)b * Lk * ldk + h * D;
+  const bf16_t* vb = v + (size_t)b * Lk * ldk + h * D;
+  bf16x8 qf[C::DK16], dof[C::DK16];
+#pragma unroll
+  for (int s = 0; s < C::DK16; s++) {
+    qf[s] = gfrag<D>(qb, ldq, q0 + l31, Lq, s, hi);
+    dof[s] = gfrag<D>(dob, ldo, q0 + l31, Lq, s, hi);
+  }
+  const int qrow = q0 + l31;
+  const float L2 = qrow < Lq ? lse[((size_t)b * H + h) * Lq + qrow] : 0.f;
+  const float dl = qrow < Lq ? delta[((size_t)b * H + h) * Lq + qrow] : 0.f;
+  f32x16 acc[C::DV];
+#pragma unroll
+  for (int i = 0; i < C::DV; i++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[i][r] = 0.f;
+  const float sc = scale * LOG2E;
+  zero_pad_chunks<D, 64>(Ks, tid);
+  zero_pad_chunks<D, 64>(Vs, tid);
+  for (int kv0 = 0; kv0 < Lk; kv0 += 64) {
+    __syncthreads();
+    load_rowmajor<D, 64>(Ks, kb, ldk, kv0, Lk, tid);
+    load_rowmajor<D, 64>(Vs, vb, ldk, kv0, Lk, tid);
+    load_transposed64<D>(Kt, kb, ldk, kv0, Lk, tid);
+    __syncthreads();
+    f32x16 s_[2], dp[2];
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+#pragma unroll
+      for (int r = 0; r < 16; r++) { s_[t][r] = 0.f; dp[t][r] = 0.f; }
+#pragma unroll
+      for (int s = 0; s < C::DK16; s++) {
+        bf16x8 kf = *(const bf16x8*)(Ks + ((32 * t + l31) * C::RKU + 2 * s + hi) * 16);
+        bf16x8 vf = *(const bf16x8*)(Vs + ((32 * t + l31) * C::RKU + 2 * s + hi) * 16);
+        s_[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], s_[t], 0, 0, 0);
+        dp[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[s], dp[t], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        int kv = kv0 + 32 * t + 4 * hi + (r & 3) + 8 * (r >> 2);
+        float p = kv < Lk ? PCM_EXP2F(s_[t][r] * sc - L2) : 0.f;
+        s_[t][r] = p * (dp[t][r] - dl) * scale;  // dS^T
+      }
+    bf16x8 df[4];
+#pragma unroll
+    for (int ss = 0; ss < 4; ss++) df[ss] = pack_frag(s_[ss >> 1], ss & 1);
+#pragma unroll
+    for (int i = 0; i < C::DV; i++)
+#pragma unroll
+      for (int ss = 0; ss < 4; ss++) {
+        bf16x8 ktf = *(const bf16x8*)(Kt + tr_off(32 * i + l31, 2 * ss + hi));
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf, df[ss], acc[i], 0, 0, 0);
+      }
+  }
+  if (qrow < Lq) {
+    bf16_t* orow = dq + ((size_t)b * Lq + qrow) * ldq + h * D;
+#pragma unroll
+    for (int i = 0; i < C::DV; i++)
+#pragma unroll
+      for (int qd = 0; qd < 4; qd++) {
+        int dcol = 32 * i + 8 * qd + 4 * hi;
+        if (dcol < D)
+          *(uint2*)(orow + dcol) = make_uint2(pack_bf2(acc[i][4 * qd], acc[i][4 * qd + 1]), pack_bf2(acc[i][4 * qd + 2], acc[i][4 * qd + 3]));
+      }
+  }
+}
+
+// ============================================================================ backward: dK, dV
+template <int D>
+__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16_t* q, const bf16_t* k, const bf16_t* v, const bf16_t* dO,
+                                                            const float* lse, const float* delta, bf16_t* dk, bf16_t* dv, int H,
+                                                            int Lq, int Lk, int ldq, int ldk, int ldo, float scale) {
+  using C = AttnCfg<D>;
+  __shared__ __attribute__((aligned(16))) char Qs[64 * C::RKU * 16];
+  __shared__ __attribute__((aligned(16))) char Os[64 * C::RKU * 16];
+  __shared__ __attribute__((aligned(16))) char Qt[C::DV * 32 * 128];
+  __shared__ __attribute__((aligned(16))) char Ot[C::DV * 32 * 128];
+  __shared__ float L2s[64], dls[64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y, kv0 = blockIdx.x * 128 + wave * 32;
+  const bf16_t* qb = q + (size_t)b * Lq * ldq + h * D;
+  const bf16_t* dob = dO + (size_t)b * Lq * ldo + h * D;
+  const bf16_t* kb = k + (size_t)b * Lk * ldk + h * D;
+  const bf16_t* vb = v + (size_t)b * Lk * ldk + h * D;
+  bf16x8 kf[C::DK16], vf[C::DK16];
+#pragma unroll
+  for (int s = 0; s < C::DK16; s++) {
+    kf[s] = gfrag<D>(kb, ldk, kv0 + l31, Lk, s, hi);
+    vf[s] = gfrag<D>(vb, ldk, kv0 + l31, Lk, s, hi);
+  }
+  f32x16 acc_k[C::DV], acc_v[C::DV];
+#pragma unroll
+  for (int i = 0; i < C::DV; i++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) { acc_k[i][r] = 0.f; acc_v[i][r] = 0.f; }
+  const float sc = scale * LOG2E;
+  const bool kv_ok = (kv0 + l31) < Lk;
+  zero_pad_chunks<D, 64>(Qs, tid);
+  zero_pad_chunks<D, 64>(Os, tid);
+  for (int qq0 = 0; qq0 < Lq; qq0 += 64) {
+    __syncthreads();
+    load_rowmajor<D, 64>(Qs, qb, ldq, qq0, Lq, tid);
+    load_rowmajor<D, 64>(Os, dob, ldo, qq0, Lq, tid);
+    load_transposed64<D>(Qt, qb, ldq, qq0, Lq, tid);
+    load_transposed64<D>(Ot, dob, ldo, qq0, Lq, tid);
+    if (tid < 64) {
+      int qr = qq0 + tid;
+      L2s[tid] = qr < Lq ? lse[((size_t)b * H + h) * Lq + qr] : 0.f;
+      dls[tid] = qr < Lq ? delta[((size_t)b * H + h) * Lq + qr] : 0.f;
+    }
+    __syncthreads();
+    f32x16 s_[2], dp[2];
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+#pragma unroll
+      for (int r = 0; r < 16; r++) { s_[t][r] = 0.f; dp[t][r] = 0.f; }
+#pragma unroll
+      for (int s = 0; s < C::DK16; s++) {
+        bf16x8 qfr = *(const bf16x8*)(Qs + ((32 * t + l31) * C::RKU + 2 * s + hi) * 16);
+        bf16x8 ofr = *(const bf16x8*)(Os + ((32 * t + l31) * C::RKU + 2 * s + hi) * 16);
+        s_[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfr, kf[s], s_[t], 0, 0, 0);   // S[q][kv]
+        dp[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ofr, vf[s], dp[t], 0, 0, 0);   // dP[q][kv]
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        int ql = 32 * t + 4 * hi + (r & 3) + 8 * (r >> 2);
+        bool ok = kv_ok && (qq0 + ql) < Lq;
+        float p = ok ? PCM_EXP2F(s_[t][r] * sc - L2s[ql]) : 0.f;
+        dp[t][r] = p * (dp[t][r] - dls[ql]) * scale;  // dS[q][kv]
+        s_[t][r] = p;
+      }
+    bf16x8 pf[4], df[4];
+#pragma unroll
+    for (int ss = 0; ss < 4; ss++) { pf[ss] = pack_frag(s_[ss >> 1], ss & 1); df[ss] = pack_frag(dp[ss >> 1], ss & 1); }
+#pragma unroll
+    for (int i = 0; i < C::DV; i++)
+#pragma unroll
+      for (int ss = 0; ss < 4; ss++) {
+        bf16x8 otf = *(const bf16x8*)(Ot + tr_off(32 * i + l31, 2 * ss + hi));
+        bf16x8 qtf = *(const bf16x8*)(Qt + tr_off(32 * i + l31, 2 * ss + hi));
+        acc_v[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(otf, pf[ss], acc_v[i], 0, 0, 0);  // dV^T[d][kv]
+        acc_k[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf, df[ss], acc_k[i], 0, 0, 0);  // dK^T[d][kv]
+      }
+  }
+  if (kv_ok) {
+    bf16_t* krow = dk + ((size_t)b * Lk + kv0 + l31) * ldk + h * D;
+    bf16_t* vrow = dv + ((size_t)b * Lk + kv0 + l31) * ldk + h * D;
+#pragma unroll
+    for (int i = 0; i < C::DV; i++)
+#pragma unroll
+      for (int qd = 0; qd < 4; qd++) {
+        int dcol = 32 * i + 8 * qd + 4 * hi;
+        if (dcol < D) {
+          *(uint2*)(krow + dcol) = make_uint2(pack_bf2(acc_k[i][4 * qd], acc_k[i][4 * qd + 1]), pack_bf2(acc_k[i][4 * qd + 2], acc_k[i][4 * qd + 3]));
+          *(uint2*)(vrow + dcol) = make_uint2(pack_bf2(acc_v[i][4 * qd], acc_v[i][4 * qd + 1]), pack_bf2(acc_v[i][4 * qd + 2], acc_v[i][4 * qd + 3]));
+        }
+      }
+  }
+}
+
+static int attn_check(const char* what, const void* q, const void* k, const void* v, int B, int H, int Lq, int Lk, int d,
+                      int ldq, int ldk, int ldo) {
+  PCM_CHECK(q && k && v && B > 0 && H > 0 && Lq > 0 && Lk > 0, PCM_EINVAL, "%s: null/empty", what);
+  PCM_CHECK(d == 40 || d == 80 || d == 160 || d == 32 || d == 64, PCM_EUNSUPPORTED, "%s: head_dim %d not in {32,40,64,80,160}", what, d);
+  PCM_CHECK((ldq % 8) == 0 && (ldk % 8) == 0 && (ldo % 8) == 0 && PCM_ALIGNED16(q) && PCM_ALIGNED16(k) && PCM_ALIGNED16(v), PCM_EALIGN,
+            "%s: strides must be %%8 and pointers 16-byte aligned", what);
+  return PCM_OK;
+}
+
+#define ATTN_DISPATCH(d, CALL)          \
+  switch (d) {                          \
+    case 32: { CALL(32); } break;       \
+    case 40: { CALL(40); } break;       \
+    case 64: { CALL(64); } break;       \
+    case 80: { CALL(80); } break;       \
+    default: { CALL(160); } break;      \
+  }
+
+extern "C" int pcm_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int Lq, int Lk,
+                            int d, int ldq, int ldk, int ldo, float scale, void* stream) {
+  if (int rc = attn_check("pcm_attn_fwd", q, k, v, B, H, Lq, Lk, d, ldq, ldk, ldo)) return rc;
+  PCM_CHECK(o && PCM_ALIGNED16(o), PCM_EALIGN, "pcm_attn_fwd: o");
+  dim3 grid((Lq + 127) / 128, H, B), block(256);
+#define FWD_CALL(DD) PCM_LAUNCH((attn_fwd_kernel<DD>), grid, block, 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse, H, Lq, Lk, ldq, ldk, ldo, scale)
+  ATTN_DISPATCH(d, FWD_CALL)
+  return pcm_post_launch("pcm_attn_fwd");
+}
+
+extern "C" int pcm_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dO, const float* lse,
+                            float* delta, void* dq, void* dk, void* dv, int B, int H, int Lq, int Lk, int d, int ldq, int ldk,
+                            int ldo, float scale, void* stream) {
+  if (int rc = attn_check("pcm_attn_bwd", q, k, v, B, H, Lq, Lk, d, ldq, ldk, ldo)) return rc;
+  PCM_CHECK(o && dO && lse && delta && PCM_ALIGNED16(o) && PCM_ALIGNED16(dO), PCM_EALIGN, "pcm_attn_bwd: o/dO/lse/delta");
+  PCM_LAUNCH(attn_delta_kernel, dim3((Lq * H + 255) / 256, B), dim3(256), 0, stream, (const bf16_t*)o, (const bf16_t*)dO, delta, H, Lq, d, ldo);
+  if (dq) {
+    dim3 grid((Lq + 127) / 128, H, B), block(256);
+#define DQ_CALL(DD) PCM_LAUNCH((attn_bwd_dq_kernel<DD>), grid, block, 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)dO, lse, delta, (bf16_t*)dq, H, Lq, Lk, ldq, ldk, ldo, scale)
+    ATTN_DISPATCH(d, DQ_CALL)
+  }
+  if (dk && dv) {
+    dim3 grid((Lk + 127) / 128, H, B), block(256);
+#define DKV_CALL(DD) PCM_LAUNCH((attn_bwd_dkdv_kernel<DD>), grid, block, 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)dO, lse, delta, (bf16_t*)dk, (bf16_t*)dv, H, Lq, Lk, ldq, ldk, ldo, scale)
+    ATTN_DISPATCH(d, DKV_CALL)
+  }
+  return pcm_post_launch("pcm_attn_bwd");
+}

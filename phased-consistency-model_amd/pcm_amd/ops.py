@@ -300,3 +300,28 @@ def lora_wgrad(big, small, out, alpha, M, G=None, conv=None, g_stride=None, r_st
     a.r_stride = r_stride if r_stride is not None else 0
     a.out_conv = 1 if out_conv else 0
     capi.lib().call("pcm_lora_wgrad_bf16", C.byref(a), _stream())
+
+
+def attn_fwd(q, k, v, H, d, scale=None):
+    """q [B, Lq, >=H*d] (row stride = q.stride(1)), k/v [B, Lk, ...] -> (o [B, Lq, H*d], lse [B,H,Lq])."""
+    B, Lq, Lk = q.shape[0], q.shape[1], k.shape[1]
+    scale = scale if scale is not None else d ** -0.5
+    o = torch.empty(B, Lq, H * d, dtype=BF16, device=q.device)
+    lse = torch.empty(B, H, Lq, dtype=torch.float32, device=q.device)
+    assert q.stride(2) == 1 and k.stride(2) == 1 and v.stride(2) == 1 and k.stride(1) == v.stride(1)
+    capi.lib().call("pcm_attn_fwd", ptr(q), ptr(k), ptr(v), ptr(o), ptr(lse), B, H, Lq, Lk, d, q.stride(1), k.stride(1),
+                    o.stride(1), scale, _stream())
+    return o, lse
+
+
+def attn_bwd(q, k, v, o, dO, lse, H, d, scale=None, need_dkv=True):
+    B, Lq, Lk = q.shape[0], q.shape[1], k.shape[1]
+    scale = scale if scale is not None else d ** -0.5
+    assert q.is_contiguous() and k.is_contiguous() and v.is_contiguous() and o.is_contiguous() and dO.is_contiguous()
+    delta = torch.empty(B, H, Lq, dtype=torch.float32, device=q.device)
+    dq = torch.empty_like(q)
+    dk = torch.empty_like(k) if need_dkv else None
+    dv = torch.empty_like(v) if need_dkv else None
+    capi.lib().call("pcm_attn_bwd", ptr(q), ptr(k), ptr(v), ptr(o), ptr(dO), ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv),
+                    B, H, Lq, Lk, d, q.stride(1), k.stride(1), o.stride(1), scale, _stream())
+    return dq, dk, dv

@@ -238,3 +238,28 @@ def case_wgrad_conv(dev, B, Hs, Ws, C, stride, src_mode=0):
     dA = torch.zeros(64, C, 3, 3, dtype=torch.float32, device=dev)
     ops.lora_wgrad(x, u, dA, 1.0, M, conv=dict(Hs=Hs, Ws=Ws, Ho=Ho, Wo=Wo, stride=stride, src_mode=src_mode), out_conv=True)
     close(dA, A.grad, 2e-3, 2e-3 * M ** 0.5, "dA conv")
+
+
+def case_attention(dev, B, H, Lq, Lk, d, spike=False):
+    q = rnd(B, Lq, H * d, seed=1, dev=dev)
+    k = rnd(B, Lk, H * d, seed=2, dev=dev)
+    v = rnd(B, Lk, H * d, seed=3, dev=dev)
+    if spike:  # force a large running-max jump late in the key stream (online-softmax rescale path)
+        k[:, Lk - 3, :] = k[:, Lk - 3, :] * 6
+    dO = rnd(B, Lq, H * d, seed=4, dev=dev)
+    qr, kr, vr = [t.float().cpu().requires_grad_(True) for t in (q, k, v)]
+
+    def heads(t, L):
+        return t.view(B, L, H, d).transpose(1, 2)
+    s = heads(qr, Lq) @ heads(kr, Lk).transpose(-1, -2) * d ** -0.5
+    ref = (torch.softmax(s, -1) @ heads(vr, Lk)).transpose(1, 2).reshape(B, Lq, H * d)
+    o, lse = ops.attn_fwd(q, k, v, H, d)
+    close(o, ref.detach(), 2e-2, 2e-2, "attn fwd")
+    ref_lse = torch.logsumexp(s.detach(), -1) * 1.4426950408889634
+    close(lse, ref_lse, 1e-3, 2e-2, "lse")
+    ref.backward(dO.float().cpu())
+    dq, dk, dv = ops.attn_bwd(q, k, v, o, dO, lse, H, d)
+    sc = max(1.0, float(qr.grad.abs().max()))
+    close(dq, qr.grad, 3e-2, 3e-2 * sc, "dq")
+    close(dk, kr.grad, 3e-2, 3e-2 * max(1.0, float(kr.grad.abs().max())), "dk")
+    close(dv, vr.grad, 3e-2, 3e-2 * max(1.0, float(vr.grad.abs().max())), "dv")

@@ -56,3 +56,8 @@ def test_wgrad_plain(M, N, K):
 @pytest.mark.parametrize("stride,src_mode", [(1, 0), (2, 0), (1, 1)])
 def test_wgrad_conv(stride, src_mode):
     K.case_wgrad_conv("cpu", 2, 6, 5, 64, stride, src_mode)
+
+
+@pytest.mark.parametrize("B,H,Lq,Lk,d,spike", [(1, 2, 100, 77, 40, False), (2, 1, 70, 130, 80, True), (1, 1, 40, 64, 160, False)])
+def test_attention(B, H, Lq, Lk, d, spike):
+    K.case_attention("cpu", B, H, Lq, Lk, d, spike)

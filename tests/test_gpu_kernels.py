@@ -1,0 +1,69 @@
+"""GPU parity of every C-ABI kernel vs torch fp32 on the same bf16-rounded inputs, at UNet sizes."""
+import pytest
+import torch
+
+import kernel_cases as K
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _hip():
+    from pcm_amd import capi
+    capi.set_lib(None)
+    assert torch.cuda.is_available()
+    capi.lib()  # raises loudly if libpcm_hip.so is missing
+    yield
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("B,HW,C,G,act", [(2, 4096, 320, 32, 1), (2, 1024, 640, 32, 0), (2, 256, 2560, 32, 1),
+                                          (1, 4096, 960, 32, 1), (3, 64, 1280, 32, 1), (2, 1024, 1920, 32, 1)])
+def test_groupnorm(B, HW, C, G, act):
+    K.case_groupnorm("cuda", B, HW, C, G, act, eps=1e-6 if act == 0 else 1e-5)
+
+
+@pytest.mark.parametrize("M,C", [(4099, 320), (1024, 640), (300, 1280)])
+def test_layernorm(M, C):
+    K.case_layernorm("cuda", M, C)
+
+
+def test_elementwise():
+    K.case_elementwise("cuda")
+
+
+def test_edge_convs():
+    K.case_edge_convs("cuda", B=2, H=64, W=64, C0=320)
+
+
+def test_timestep_embedding():
+    K.case_timestep_embedding("cuda")
+
+
+def test_pcm_math_bit_exact_vs_reference_golden(golden):
+    K.case_pcm_math("cuda", golden)
+
+
+def test_optim():
+    K.case_optim("cuda")
+
+
+def test_pack():
+    K.case_pack("cuda")
+
+
+@pytest.mark.parametrize("M,N,K_", [(4096, 320, 320), (1000, 1280, 768), (16, 640, 1280)])
+def test_wgrad_plain(M, N, K_):
+    K.case_wgrad_plain("cuda", M, N, K_)
+
+
+@pytest.mark.parametrize("stride,src_mode,C", [(1, 0, 320), (2, 0, 64), (1, 1, 128)])
+def test_wgrad_conv(stride, src_mode, C):
+    K.case_wgrad_conv("cuda", 2, 16, 16, C, stride, src_mode)
+
+
+@pytest.mark.parametrize("B,H,Lq,Lk,d,spike", [(1, 8, 1024, 1024, 40, False), (2, 8, 256, 77, 80, False),
+                                               (2, 8, 256, 256, 160, True), (1, 8, 64, 64, 160, False),
+                                               (1, 2, 4096, 4096, 40, True), (1, 8, 4096, 77, 40, False)])
+def test_attention(B, H, Lq, Lk, d, spike):
+    K.case_attention("cuda", B, H, Lq, Lk, d, spike)
