@@ -6,18 +6,27 @@
 // ddim_alpha_cumprods_prev table makes them.
 #include "pcm_common.h"
 
-#ifdef PCM_HOST_EMU
-static inline float __fmul_rn(float a, float b) { volatile float r = a * b; return r; }
-static inline float __fadd_rn(float a, float b) { volatile float r = a + b; return r; }
-static inline float __fsub_rn(float a, float b) { volatile float r = a - b; return r; }
-static inline float __fdiv_rn(float a, float b) { volatile float r = a / b; return r; }
-static inline float __fsqrt_rn(float a) { volatile float r = sqrtf(a); return r; }
-static inline double __dmul_rn(double a, double b) { volatile double r = a * b; return r; }
-static inline double __dadd_rn(double a, double b) { volatile double r = a + b; return r; }
-static inline double __dsub_rn(double a, double b) { volatile double r = a - b; return r; }
-static inline double __ddiv_rn(double a, double b) { volatile double r = a / b; return r; }
-static inline double __dsqrt_rn(double a) { volatile double r = sqrt(a); return r; }
-#endif
+// Individually rounded IEEE ops: FMA contraction is switched off for this file and sqrt / divide
+// are the correctly rounded forms (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt), so the
+// fp32 chain is bit-identical to the reference's eager torch ops.  (HIP's __fmul_rn & co. are plain
+// operators without OCML_BASIC_ROUNDED_OPERATIONS and __fsqrt_rn is the native approximate sqrt.)
+#pragma clang fp contract(off)
+#define __fmul_rn(a, b) pm_mul(a, b)
+#define __fadd_rn(a, b) pm_add(a, b)
+#define __fsub_rn(a, b) pm_sub(a, b)
+#define __fdiv_rn(a, b) pm_div(a, b)
+#define __fsqrt_rn(a) pm_sqrt(a)
+#define __dmul_rn(a, b) pm_mul(a, b)
+#define __dadd_rn(a, b) pm_add(a, b)
+#define __dsub_rn(a, b) pm_sub(a, b)
+#define __ddiv_rn(a, b) pm_div(a, b)
+#define __dsqrt_rn(a) pm_sqrt(a)
+template <typename T> __device__ __forceinline__ T pm_mul(T a, T b) { return a * b; }
+template <typename T> __device__ __forceinline__ T pm_add(T a, T b) { return a + b; }
+template <typename T> __device__ __forceinline__ T pm_sub(T a, T b) { return a - b; }
+template <typename T> __device__ __forceinline__ T pm_div(T a, T b) { return a / b; }
+__device__ __forceinline__ float pm_sqrt(float a) { return __builtin_sqrtf(a); }
+__device__ __forceinline__ double pm_sqrt(double a) { return __builtin_sqrt(a); }
 
 #define PM_LOOP(i, n) for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (long)gridDim.x * blockDim.x)
 static inline int pm_blocks(long n) { long b = (n + 255) / 256; return (int)(b > 1024 ? 1024 : (b < 1 ? 1 : b)); }

@@ -1,0 +1,521 @@
+"""SD1.5 UNet forward and LoRA-only backward as an explicit schedule of C-ABI kernel launches.
+
+No autograd and no tracing compiler: the UNet is a static graph, so forward and backward are
+written out once as launch sequences on torch's current HIP stream (capturable in a hipGraph).
+Activations are channels-last bf16 ``[B, H*W, C]``; base weights are frozen, packed once into bf16
+MFMA operand layouts in BOTH orientations (forward and dgrad; 2 x 1.7 GB resident in HBM), the
+LoRA factors live in one flat fp32 buffer (master / grad / Adam m,v) with bf16 operand copies that
+are refreshed after every optimizer step.
+
+Mirrors diffusers' ``UNet2DConditionModel.forward(sample, timestep, encoder_hidden_states).sample``
+(reference wiring: discriminator_sd15.py:84-345) and peft's ``lora.Linear`` / ``lora.Conv2d``
+(train_pcm_lora_sd15.py:866-885).
+"""
+import math
+from collections import OrderedDict
+
+import torch
+
+from . import capi, ops
+from .ops import Seg
+from .unet_spec import UNetConfig, lora_target_modules, param_spec
+
+BF16 = torch.bfloat16
+
+
+# ----------------------------------------------------------------------------------------------
+# frozen base weights, packed
+# ----------------------------------------------------------------------------------------------
+class PackedLayer:
+    """One Linear / conv1x1 / conv3x3 of the base model in MFMA operand layouts."""
+    __slots__ = ("kind", "N", "K", "C", "w_fwd", "w_bwd", "bias")
+
+    def __init__(self, w, bias, device, need_bwd):
+        w = w.to(device=device, dtype=torch.float32).contiguous()
+        self.N = w.shape[0]
+        self.bias = None if bias is None else bias.to(device=device, dtype=torch.float32).contiguous()
+        if w.dim() == 4 and w.shape[-1] == 3:
+            self.kind, self.C = "conv3", w.shape[1]
+            self.K = 9 * self.C
+            self.w_fwd, self.w_bwd = ops.pack_conv3x3(w, True, need_bwd)
+        else:
+            self.kind, self.C = "lin", 0
+            self.K = w.numel() // self.N
+            self.w_fwd, self.w_bwd = ops.pack_linear(w.view(self.N, self.K), True, need_bwd)
+
+
+class UNetWeights:
+    """Frozen SD1.5 UNet weights (diffusers key names in, packed operands out).  One instance is
+    shared by the teacher, the online student and the target passes (the reference loads the same
+    checkpoint twice: train_pcm_lora_sd15.py:840-851)."""
+
+    def __init__(self, cfg: UNetConfig, state_dict, device, need_bwd=True):
+        self.cfg, self.device = cfg, torch.device(device)
+        spec = param_spec(cfg)
+        missing = [k for k, _ in spec if k not in state_dict]
+        if missing:
+            raise KeyError(f"UNetWeights: {len(missing)} missing keys, e.g. {missing[:3]}")
+        for k, shp in spec:
+            if tuple(state_dict[k].shape) != tuple(shp):
+                raise ValueError(f"UNetWeights: {k} has shape {tuple(state_dict[k].shape)}, expected {shp}")
+        self.layers, self.norms = {}, {}
+        f32 = dict(device=self.device, dtype=torch.float32)
+        for k, shp in spec:
+            if not k.endswith(".weight"):
+                continue
+            path = k[:-7]
+            leaf = path.rsplit(".", 1)[-1]
+            if leaf.startswith("norm") or leaf == "conv_norm_out":
+                self.norms[path] = (state_dict[k].to(**f32).contiguous(), state_dict[path + ".bias"].to(**f32).contiguous())
+            elif path in ("conv_in", "conv_out"):
+                continue
+            else:
+                self.layers[path] = PackedLayer(state_dict[k], state_dict.get(path + ".bias"), self.device, need_bwd)
+        self.conv_in = (state_dict["conv_in.weight"].to(**f32).contiguous(), state_dict["conv_in.bias"].to(**f32).contiguous())
+        self.conv_out = (state_dict["conv_out.weight"].to(**f32).contiguous(), state_dict["conv_out.bias"].to(**f32).contiguous())
+
+
+# ----------------------------------------------------------------------------------------------
+# LoRA state
+# ----------------------------------------------------------------------------------------------
+class LoraModule:
+    __slots__ = ("path", "kind", "N", "K", "C", "r", "A", "B", "gA", "gB", "A_fwd", "A_bwd", "Bs_fwd", "Bs_bwd")
+
+
+class LoraState:
+    """peft-0.9 LoRA factors for the reference's 14 target patterns in ONE flat fp32 buffer
+    (+ grads + Adam moments), plus the bf16 operand copies the kernels read.
+    scaling = lora_alpha / r (peft default lora_alpha = 8; LoraConfig at :866 does not set it)."""
+
+    def __init__(self, cfg: UNetConfig, rank=64, lora_alpha=8.0, device="cuda", seed=1, b_std=0.0):
+        if rank != 64:
+            raise ValueError("pcm_amd: the HIP LoRA kernels are built for rank 64 (reference recipe --lora_rank=64)")
+        self.cfg, self.rank, self.alpha, self.scaling = cfg, rank, lora_alpha, lora_alpha / rank
+        self.device = torch.device(device)
+        targets = lora_target_modules(cfg)
+        total = 0
+        layout = []
+        for path, shp in targets:
+            ain = math.prod(shp[1:])
+            layout.append((path, shp, total, total + rank * ain))
+            total += rank * ain + shp[0] * rank
+        self.numel = total
+        self.params = torch.zeros(total, dtype=torch.float32, device=self.device)
+        self.grads = torch.zeros_like(self.params)
+        self.exp_avg = torch.zeros_like(self.params)
+        self.exp_avg_sq = torch.zeros_like(self.params)
+        self.gradsq = torch.zeros(1, dtype=torch.float64, device=self.device)
+        self.modules = OrderedDict()
+        g = torch.Generator().manual_seed(seed)
+        for path, shp, oa, ob in layout:
+            m = LoraModule()
+            m.path, m.N, m.r = path, shp[0], rank
+            ain = math.prod(shp[1:])
+            if len(shp) == 4 and shp[-1] == 3:
+                m.kind, m.C, m.K = "conv3", shp[1], 9 * shp[1]
+                a_shape, b_shape = (rank, shp[1], 3, 3), (shp[0], rank, 1, 1)
+            elif len(shp) == 4:
+                m.kind, m.C, m.K = "lin", 0, shp[1]
+                a_shape, b_shape = (rank, shp[1], 1, 1), (shp[0], rank, 1, 1)
+            else:
+                m.kind, m.C, m.K = "lin", 0, shp[1]
+                a_shape, b_shape = (rank, shp[1]), (shp[0], rank)
+            m.A = self.params[oa:oa + rank * ain].view(a_shape)
+            m.B = self.params[ob:ob + shp[0] * rank].view(b_shape)
+            m.gA = self.grads[oa:oa + rank * ain].view(a_shape)
+            m.gB = self.grads[ob:ob + shp[0] * rank].view(b_shape)
+            # peft init: kaiming_uniform_(A, a=sqrt(5)) == U(+-1/sqrt(fan_in)); B = 0
+            bound = 1.0 / math.sqrt(ain)
+            m.A.copy_(((torch.rand(a_shape, generator=g) * 2 - 1) * bound).to(self.device))
+            if b_std > 0:
+                m.B.copy_((torch.randn(b_shape, generator=g) * b_std).to(self.device))
+            bf = dict(dtype=BF16, device=self.device)
+            if m.kind == "conv3":
+                m.A_fwd, m.A_bwd = torch.empty(rank, m.K, **bf), torch.empty(m.C, 9 * rank, **bf)
+            else:
+                m.A_fwd, m.A_bwd = torch.empty(rank, m.K, **bf), torch.empty(m.K, rank, **bf)
+            m.Bs_fwd, m.Bs_bwd = torch.empty(m.N, rank, **bf), torch.empty(rank, m.N, **bf)
+            self.modules[path] = m
+        self.repack()
+
+    def repack(self):
+        """fp32 master -> bf16 operand copies (after init / load / every optimizer step)."""
+        for m in self.modules.values():
+            if m.kind == "conv3":
+                ops.pack_conv3x3(m.A, True, True, 1.0, m.A_fwd, m.A_bwd)
+            else:
+                ops.pack_linear(m.A.view(self.rank, m.K), True, True, 1.0, m.A_fwd, m.A_bwd)
+            ops.pack_linear(m.B.view(m.N, self.rank), True, True, self.scaling, m.Bs_fwd, m.Bs_bwd)
+
+    def zero_grad(self):
+        self.grads.zero_()
+
+    # ---- checkpoint formats (train_pcm_lora_sd15.py:52-72, :918-944, :1374-1382) ----
+    def peft_state_dict(self):
+        out = OrderedDict()
+        for p, m in self.modules.items():
+            out[f"base_model.model.{p}.lora_A.weight"] = m.A.detach().clone()
+            out[f"base_model.model.{p}.lora_B.weight"] = m.B.detach().clone()
+        return out
+
+    def load_peft_state_dict(self, sd):
+        for p, m in self.modules.items():
+            m.A.copy_(sd[f"base_model.model.{p}.lora_A.weight"].to(self.device).view_as(m.A))
+            m.B.copy_(sd[f"base_model.model.{p}.lora_B.weight"].to(self.device).view_as(m.B))
+        self.repack()
+
+
+# ----------------------------------------------------------------------------------------------
+# one (optionally LoRA-wrapped) contraction layer: forward, dgrad, LoRA wgrad
+# ----------------------------------------------------------------------------------------------
+class Geo:
+    """conv geometry: source tensor dims, stride, source mode, output dims."""
+    __slots__ = ("Hs", "Ws", "stride", "src_mode", "Ho", "Wo")
+
+    def __init__(self, Hs, Ws, stride=1, src_mode=capi.SRC_DIRECT):
+        self.Hs, self.Ws, self.stride, self.src_mode = Hs, Ws, stride, src_mode
+        Hv, Wv = (Hs * 2, Ws * 2) if src_mode != capi.SRC_DIRECT else (Hs, Ws)
+        self.Ho, self.Wo = (Hv - 1) // stride + 1, (Wv - 1) // stride + 1
+
+    def conv(self):
+        return dict(Hs=self.Hs, Ws=self.Ws, stride=self.stride, src_mode=self.src_mode)
+
+
+def layer_fwd(W: UNetWeights, lora, path, x, M, geo=None, save=None, rowvec=None, rows_per_batch=0, residual=None,
+              act=capi.ACT_NONE, out_dtype=BF16):
+    """y = base(x) + s*B(A(x)) [+ bias + rowvec + residual].  x: [M, K] (lin) or NHWC source (conv3).
+    ``save`` (dict) receives what the backward needs."""
+    L = W.layers[path]
+    lm = lora.modules.get(path) if lora is not None else None
+    conv = geo.conv() if L.kind == "conv3" else None
+    Ho, Wo = (geo.Ho, geo.Wo) if conv else (0, 0)
+    segs = [Seg(x, L.w_fwd, conv=conv)]
+    t = None
+    if lm is not None:
+        t = torch.empty(M, lm.r, dtype=BF16, device=x.device)
+        ops.gemm([Seg(x, lm.A_fwd, conv=conv)], M, lm.r, t, Ho=Ho, Wo=Wo)
+        segs.append(Seg(t, lm.Bs_fwd))
+    y = torch.empty(M, L.N, dtype=out_dtype, device=x.device)
+    ops.gemm(segs, M, L.N, y, bias=L.bias, rowvec=rowvec, rows_per_batch=rows_per_batch, residual=residual, act=act, Ho=Ho, Wo=Wo)
+    if save is not None:
+        save["x"], save["t"], save["M"], save["geo"] = x, t, M, geo
+    return y
+
+
+def layer_bwd(W: UNetWeights, lora, path, dy, saved, need_dx=True, residual=None):
+    """dy [M, N] -> dx ([M_in, K] or NHWC of the source); accumulates LoRA grads.  ``residual`` is
+    added to dx in the GEMM epilogue."""
+    L = W.layers[path]
+    lm = lora.modules.get(path) if lora is not None else None
+    x, t, M, geo = saved["x"], saved["t"], saved["M"], saved["geo"]
+    u = None
+    if lm is not None:
+        u = torch.empty(M, lm.r, dtype=BF16, device=dy.device)
+        ops.gemm([Seg(dy, lm.Bs_bwd)], M, lm.r, u)                      # u = dy (sB)   [M, r]
+        ops.lora_wgrad(dy, t, lm.gB, lora.scaling, M, G=L.N, g_stride=lm.r, r_stride=1)   # dB = s dy^T t
+        if L.kind == "conv3":
+            ops.lora_wgrad(x, u, lm.gA, 1.0, M, conv=dict(Hs=geo.Hs, Ws=geo.Ws, Ho=geo.Ho, Wo=geo.Wo, stride=geo.stride,
+                                                          src_mode=geo.src_mode), out_conv=True)
+        else:
+            ops.lora_wgrad(x, u, lm.gA, 1.0, M, G=L.K, g_stride=1, r_stride=L.K)          # dA = u^T x
+    if not need_dx:
+        return None
+    if L.kind == "conv3":
+        # input gradient = 3x3 conv of dy with tap-flipped, in/out-transposed weights, evaluated on the
+        # (virtual) input grid; a stride-2 forward reads dy zero-inserted
+        if geo.src_mode == capi.SRC_UPSAMPLE2:
+            Hin, Win = 2 * geo.Hs, 2 * geo.Ws  # gradient wrt the upsampled image (pooled by the caller)
+        else:
+            Hin, Win = geo.Hs, geo.Ws
+        B = M // (geo.Ho * geo.Wo)
+        Min = B * Hin * Win
+        dconv = dict(Hs=geo.Ho, Ws=geo.Wo, stride=1, src_mode=capi.SRC_ZEROINS2 if geo.stride == 2 else capi.SRC_DIRECT)
+        segs = [Seg(dy, L.w_bwd, conv=dconv)]
+        if lm is not None:
+            segs.append(Seg(u, lm.A_bwd, conv=dconv))
+        dx = torch.empty(Min, L.C, dtype=BF16, device=dy.device)
+        ops.gemm(segs, Min, L.C, dx, residual=residual, Ho=Hin, Wo=Win)
+        return dx
+    segs = [Seg(dy, L.w_bwd)]
+    if lm is not None:
+        segs.append(Seg(u, lm.A_bwd))
+    dx = torch.empty(M, L.K, dtype=BF16, device=dy.device)
+    ops.gemm(segs, M, L.K, dx, residual=residual)
+    return dx
+
+
+# ----------------------------------------------------------------------------------------------
+# UNet blocks
+# ----------------------------------------------------------------------------------------------
+class UNet:
+    """Runner bound to frozen weights and (optionally) LoRA factors.
+
+    forward(sample[B,4,H,W] fp32 NCHW, timesteps[B] int64, encoder_hidden_states[B,77,768]) ->
+    eps [B,4,H,W] fp32 (``UNet2DConditionModel.forward(...).sample``).  With ``save=True`` the call
+    returns a tape for ``backward(d_eps)`` which accumulates LoRA grads into ``lora.grads``.
+    """
+
+    def __init__(self, weights: UNetWeights, lora: LoraState = None):
+        self.W, self.lora, self.cfg = weights, lora, weights.cfg
+
+    # ---- norm helpers ----
+    def _gn(self, path, x, act, eps, save):
+        g, b = self.W.norms[path]
+        y, stats = ops.groupnorm_fwd(x, g, b, self.cfg.norm_num_groups, eps, act)
+        if save is not None:
+            save["gn_x"], save["gn_stats"] = x, stats
+        return y
+
+    def _gn_bwd(self, path, dy, act, eps, saved):
+        g, b = self.W.norms[path]
+        return ops.groupnorm_bwd(saved["gn_x"], dy, saved["gn_stats"], g, b, self.cfg.norm_num_groups, eps, act)
+
+    # ---- resnet ----
+    def resnet_fwd(self, p, x, emb_act, B, H, Wd, tape):
+        W, lora = self.W, self.lora
+        M = B * H * Wd
+        Cout = W.layers[p + "conv1"].N
+        sv = {} if tape is not None else None
+        s1 = {} if sv is not None else None
+        n1 = self._gn(p + "norm1", x, capi.ACT_SILU, self.cfg.norm_eps, s1)
+        st = {} if sv is not None else None
+        temb = layer_fwd(W, lora, p + "time_emb_proj", emb_act, B, save=st)                 # [B, Cout]
+        geo = Geo(H, Wd)
+        c1 = {} if sv is not None else None
+        h = layer_fwd(W, lora, p + "conv1", n1, M, geo, save=c1, rowvec=temb, rows_per_batch=H * Wd)
+        s2 = {} if sv is not None else None
+        n2 = self._gn(p + "norm2", h.view(B, H * Wd, Cout), capi.ACT_SILU, self.cfg.norm_eps, s2)
+        sc = None
+        if (p + "conv_shortcut") in W.layers:
+            sc = {} if sv is not None else None
+            res = layer_fwd(W, lora, p + "conv_shortcut", x.view(M, -1), M, save=sc)
+        else:
+            res = x.view(M, -1)
+        c2 = {} if sv is not None else None
+        out = layer_fwd(W, lora, p + "conv2", n2, M, geo, save=c2, residual=res)
+        if tape is not None:
+            tape.append(("resnet", p, dict(s1=s1, st=st, c1=c1, s2=s2, sc=sc, c2=c2, B=B, H=H, W=Wd, Cout=Cout)))
+        return out.view(B, H * Wd, Cout)
+
+    def resnet_bwd(self, p, d_out, sv, need_dx=True):
+        W, lora = self.W, self.lora
+        B, H, Wd, Cout = sv["B"], sv["H"], sv["W"], sv["Cout"]
+        M = B * H * Wd
+        d_out = d_out.view(M, Cout)
+        d_n2 = layer_bwd(W, lora, p + "conv2", d_out, sv["c2"])
+        d_h = self._gn_bwd(p + "norm2", d_n2.view(B, H * Wd, Cout), capi.ACT_SILU, self.cfg.norm_eps, sv["s2"])
+        d_temb = ops.cast_bf16(ops.colsum(d_h))                                               # [B, Cout]
+        layer_bwd(W, lora, p + "time_emb_proj", d_temb, sv["st"], need_dx=False)
+        d_n1 = layer_bwd(W, lora, p + "conv1", d_h.view(M, Cout), sv["c1"], need_dx=need_dx)
+        if not need_dx:
+            if sv["sc"] is not None:
+                layer_bwd(W, lora, p + "conv_shortcut", d_out, sv["sc"], need_dx=False)
+            return None
+        Cin = d_n1.shape[-1]
+        d_x = self._gn_bwd(p + "norm1", d_n1.view(B, H * Wd, Cin), capi.ACT_SILU, self.cfg.norm_eps, sv["s1"])
+        if sv["sc"] is not None:
+            d_x = layer_bwd(W, lora, p + "conv_shortcut", d_out, sv["sc"], residual=d_x.view(M, Cin))
+        else:
+            d_x = ops.add(d_x.view(M, Cin), d_out)
+        return d_x.view(B, H * Wd, Cin)
+
+    # ---- transformer (Transformer2DModel with one BasicTransformerBlock) ----
+    def _attn_fwd(self, p, xn, ctx, B, L, Lk, C, resid, sv):
+        W, lora, Hh = self.W, self.lora, self.cfg.heads
+        d = C // Hh
+        M = B * L
+        sq, sk, svv, so = ({} if sv is not None else None for _ in range(4))
+        q = layer_fwd(W, lora, p + "to_q", xn, M, save=sq)
+        Mk = B * Lk
+        k = layer_fwd(W, lora, p + "to_k", ctx, Mk, save=sk)
+        v = layer_fwd(W, lora, p + "to_v", ctx, Mk, save=svv)
+        o, lse = ops.attn_fwd(q.view(B, L, C), k.view(B, Lk, C), v.view(B, Lk, C), Hh, d)
+        out = layer_fwd(W, lora, p + "to_out.0", o.view(M, C), M, save=so, residual=resid)
+        if sv is not None:
+            sv.update(sq=sq, sk=sk, sv=svv, so=so, q=q, k=k, v=v, o=o, lse=lse, L=L, Lk=Lk)
+        return out
+
+    def _attn_bwd(self, p, d_out, sv, B, C, need_dctx):
+        """returns (d_xn [M,C], d_ctx or None)"""
+        W, lora, Hh = self.W, self.lora, self.cfg.heads
+        d, L, Lk = C // Hh, sv["L"], sv["Lk"]
+        d_o = layer_bwd(W, lora, p + "to_out.0", d_out, sv["so"])
+        dq, dk, dv = ops.attn_bwd(sv["q"].view(B, L, C), sv["k"].view(B, Lk, C), sv["v"].view(B, Lk, C), sv["o"],
+                                  d_o.view(B, L, C), sv["lse"], Hh, d)
+        d_xn = layer_bwd(W, lora, p + "to_q", dq.view(B * L, C), sv["sq"])
+        if need_dctx:  # self-attention: K/V inputs are xn too
+            d_xn = layer_bwd(W, lora, p + "to_k", dk.view(B * Lk, C), sv["sk"], residual=d_xn)
+            d_xn = layer_bwd(W, lora, p + "to_v", dv.view(B * Lk, C), sv["sv"], residual=d_xn)
+        else:          # cross-attention: text embeddings need no gradient
+            layer_bwd(W, lora, p + "to_k", dk.view(B * Lk, C), sv["sk"], need_dx=False)
+            layer_bwd(W, lora, p + "to_v", dv.view(B * Lk, C), sv["sv"], need_dx=False)
+        return d_xn
+
+    def transformer_fwd(self, p, x, text, B, H, Wd, tape):
+        W, lora = self.W, self.lora
+        C, L, M = x.shape[-1], H * Wd, B * H * Wd
+        Lt = text.shape[1]
+        rec = tape is not None
+        sgn, spi, sa1, sa2, sf0, sf2, spo = ({} if rec else None for _ in range(7))
+        n = self._gn(p + "norm", x, capi.ACT_NONE, 1e-6, sgn)
+        h = layer_fwd(W, lora, p + "proj_in", n.view(M, C), M, save=spi)
+        b = p + "transformer_blocks.0."
+        g1, b1 = W.norms[b + "norm1"]
+        n1, mu1, rs1 = ops.layernorm_fwd(h, g1, b1)
+        h1 = self._attn_fwd(b + "attn1.", n1, n1, B, L, L, C, h, sa1)
+        g2, b2 = W.norms[b + "norm2"]
+        n2, mu2, rs2 = ops.layernorm_fwd(h1, g2, b2)
+        h2 = self._attn_fwd(b + "attn2.", n2, text.view(B * Lt, -1), B, L, Lt, C, h1, sa2)
+        g3, b3 = W.norms[b + "norm3"]
+        n3, mu3, rs3 = ops.layernorm_fwd(h2, g3, b3)
+        hg = layer_fwd(W, lora, b + "ff.net.0.proj", n3, M, save=sf0)
+        gg = ops.geglu_fwd(hg)
+        h3 = layer_fwd(W, lora, b + "ff.net.2", gg, M, save=sf2, residual=h2)
+        out = layer_fwd(W, lora, p + "proj_out", h3, M, save=spo, residual=x.view(M, C))
+        if rec:
+            tape.append(("transformer", p, dict(sgn=sgn, spi=spi, sa1=sa1, sa2=sa2, sf0=sf0, sf2=sf2, spo=spo, B=B, H=H, W=Wd, C=C,
+                                                h=h, mu1=mu1, rs1=rs1, h1=h1, mu2=mu2, rs2=rs2, h2=h2, mu3=mu3, rs3=rs3, hg=hg)))
+        return out.view(B, L, C)
+
+    def transformer_bwd(self, p, d_out, sv):
+        W, lora = self.W, self.lora
+        B, H, Wd, C = sv["B"], sv["H"], sv["W"], sv["C"]
+        M = B * H * Wd
+        d_out = d_out.view(M, C)
+        b = p + "transformer_blocks.0."
+        d_h3 = layer_bwd(W, lora, p + "proj_out", d_out, sv["spo"])                      # residual r: + d_out at the end
+        # ff: h3 = h2 + ff2(geglu(ff0(LN3(h2))))
+        d_gg = layer_bwd(W, lora, b + "ff.net.2", d_h3, sv["sf2"])
+        d_hg = ops.geglu_bwd(sv["hg"], d_gg)
+        d_n3 = layer_bwd(W, lora, b + "ff.net.0.proj", d_hg, sv["sf0"])
+        d_h2 = ops.layernorm_bwd(sv["h2"], d_n3, W.norms[b + "norm3"][0], sv["mu3"], sv["rs3"], dres=d_h3)
+        # attn2: h2 = h1 + attn2(LN2(h1), text)
+        d_n2 = self._attn_bwd(b + "attn2.", d_h2, sv["sa2"], B, C, need_dctx=False)
+        d_h1 = ops.layernorm_bwd(sv["h1"], d_n2, W.norms[b + "norm2"][0], sv["mu2"], sv["rs2"], dres=d_h2)
+        # attn1: h1 = h + attn1(LN1(h))
+        d_n1 = self._attn_bwd(b + "attn1.", d_h1, sv["sa1"], B, C, need_dctx=True)
+        d_h = ops.layernorm_bwd(sv["h"], d_n1, W.norms[b + "norm1"][0], sv["mu1"], sv["rs1"], dres=d_h1)
+        d_n = layer_bwd(W, lora, p + "proj_in", d_h, sv["spi"])
+        d_x = self._gn_bwd(p + "norm", d_n.view(B, H * Wd, C), capi.ACT_NONE, 1e-6, sv["sgn"])
+        return ops.add(d_x.view(M, C), d_out).view(B, H * Wd, C)
+
+    # ---- whole network ----
+    def forward(self, sample, timesteps, encoder_hidden_states, save=False):
+        cfg, W, lora = self.cfg, self.W, self.lora
+        B, _, H, Wd = sample.shape
+        boc, n = cfg.block_out_channels, len(cfg.block_out_channels)
+        tape = [] if save else None
+        text = encoder_hidden_states if encoder_hidden_states.dtype == BF16 else ops.cast_bf16(encoder_hidden_states.contiguous())
+        t_emb = ops.timestep_embedding(timesteps, boc[0])
+        e1 = layer_fwd(W, None, "time_embedding.linear_1", t_emb, B, act=capi.ACT_SILU)
+        emb_act = layer_fwd(W, None, "time_embedding.linear_2", e1, B, act=capi.ACT_SILU)  # silu(emb): only use of emb
+        h = ops.conv_in_fwd(sample.contiguous(), W.conv_in[0], W.conv_in[1], boc[0])
+        skips = [(h, H, Wd)]
+        for i in range(n):
+            for j in range(cfg.layers_per_block):
+                h = self.resnet_fwd(f"down_blocks.{i}.resnets.{j}.", h, emb_act, B, H, Wd, tape)
+                if i < n - 1:
+                    h = self.transformer_fwd(f"down_blocks.{i}.attentions.{j}.", h, text, B, H, Wd, tape)
+                skips.append((h, H, Wd))
+            if i < n - 1:
+                geo = Geo(H, Wd, stride=2)
+                sv = {} if save else None
+                h = layer_fwd(W, lora, f"down_blocks.{i}.downsamplers.0.conv", h, B * geo.Ho * geo.Wo, geo, save=sv)
+                H, Wd = geo.Ho, geo.Wo
+                h = h.view(B, H * Wd, -1)
+                if save:
+                    tape.append(("down", f"down_blocks.{i}.downsamplers.0.conv", dict(sv=sv, B=B, H=H, W=Wd)))
+                skips.append((h, H, Wd))
+        h = self.resnet_fwd("mid_block.resnets.0.", h, emb_act, B, H, Wd, tape)
+        h = self.transformer_fwd("mid_block.attentions.0.", h, text, B, H, Wd, tape)
+        h = self.resnet_fwd("mid_block.resnets.1.", h, emb_act, B, H, Wd, tape)
+        for i in range(n):
+            for j in range(cfg.layers_per_block + 1):
+                s, _, _ = skips.pop()
+                Ch = h.shape[-1]
+                h = ops.concat_channels(h, s)
+                if save:
+                    tape.append(("cat", None, dict(Ch=Ch, skip_index=len(skips))))
+                h = self.resnet_fwd(f"up_blocks.{i}.resnets.{j}.", h, emb_act, B, H, Wd, tape)
+                if i > 0:
+                    h = self.transformer_fwd(f"up_blocks.{i}.attentions.{j}.", h, text, B, H, Wd, tape)
+            if i < n - 1:
+                geo = Geo(H, Wd, stride=1, src_mode=capi.SRC_UPSAMPLE2)   # nearest-2x fused into the conv loader
+                sv = {} if save else None
+                h = layer_fwd(W, lora, f"up_blocks.{i}.upsamplers.0.conv", h, B * geo.Ho * geo.Wo, geo, save=sv)
+                if save:
+                    tape.append(("up", f"up_blocks.{i}.upsamplers.0.conv", dict(sv=sv, B=B, H=H, W=Wd)))
+                H, Wd = geo.Ho, geo.Wo
+                h = h.view(B, H * Wd, -1)
+        sgn = {} if save else None
+        hn = self._gn("conv_norm_out", h, capi.ACT_SILU, cfg.norm_eps, sgn)
+        out = ops.conv_out_fwd(hn, W.conv_out[0], W.conv_out[1], B, H, Wd)
+        if save:
+            tape.append(("out", None, dict(sgn=sgn, B=B, H=H, W=Wd, n_skips=1 + sum(cfg.layers_per_block + (1 if i < n - 1 else 0) for i in range(n)))))
+            return out, tape
+        return out
+
+    def backward(self, d_eps, tape):
+        """d_eps [B,4,H,W] fp32 -> LoRA grads accumulated in self.lora.grads."""
+        W, lora, cfg = self.W, self.lora, self.cfg
+        kind, _, sv = tape[-1]
+        assert kind == "out"
+        B, H, Wd = sv["B"], sv["H"], sv["W"]
+        d_hn = ops.conv_out_bwd(d_eps.contiguous(), W.conv_out[0], cfg.block_out_channels[0])
+        d_h = self._gn_bwd("conv_norm_out", d_hn, capi.ACT_SILU, cfg.norm_eps, sv["sgn"])
+        d_skips = {}
+        first_resnet = "down_blocks.0.resnets.0."  # its input (conv_in output) has nothing trainable upstream
+        idx = len(tape) - 2
+        while idx >= 0:
+            kind, p, sv = tape[idx]
+            if kind == "resnet":
+                d_h = self.resnet_bwd(p, d_h, sv, need_dx=(p != first_resnet))
+            elif kind == "transformer":
+                d_h = self.transformer_bwd(p, d_h, sv)
+            elif kind == "cat":
+                d_h, d_s = ops.split_channels(d_h, sv["Ch"])
+                d_skips[sv["skip_index"]] = d_s
+            elif kind == "up":
+                geo = sv["sv"]["geo"]
+                d_up = layer_bwd(W, lora, p, d_h.view(-1, d_h.shape[-1]), sv["sv"])
+                d_h = ops.pool2x_sum(d_up.view(sv["B"], 4 * geo.Hs * geo.Ws, -1), sv["B"], geo.Hs, geo.Ws)
+            elif kind == "down":
+                d_h = layer_bwd(W, lora, p, d_h.view(-1, d_h.shape[-1]), sv["sv"])
+                geo = sv["sv"]["geo"]
+                d_h = d_h.view(sv["B"], geo.Hs * geo.Ws, -1)
+            # the input of this op may also have fed a skip connection: add that gradient
+            if kind in ("resnet", "down") and d_h is not None:
+                si = self._skip_index_of_input(tape, idx)
+                if si is not None and si in d_skips:
+                    d_h = ops.add(d_h, d_skips.pop(si).view_as(d_h))
+            idx -= 1
+        return None
+
+    def _skip_index_of_input(self, tape, idx):
+        """If the input tensor of tape[idx] is a down-path skip tensor, return its index in the skip
+        stack (0 = conv_in output), else None."""
+        kind, p, _ = tape[idx]
+        if p is None or not p.startswith("down_blocks"):
+            # mid_block.resnets.0 consumes the last skip
+            if p == "mid_block.resnets.0.":
+                return self._n_down_skips() - 1
+            return None
+        cfg = self.cfg
+        parts = p.split(".")
+        i = int(parts[1])
+        # skip stack: 0 = conv_in; block i pushes layers_per_block layer outputs (+1 downsampler output)
+        base = 1 + i * (cfg.layers_per_block + 1)
+        if parts[2] == "resnets":
+            j = int(parts[3])
+            # input of resnet j: previous skip (block output j-1, or previous block's last / conv_in)
+            return base + j - 1
+        if parts[2] == "attentions":
+            return None  # input is the resnet output inside the same layer (not a skip)
+        if parts[2] == "downsamplers":
+            return base + cfg.layers_per_block - 1
+        return None
+
+    def _n_down_skips(self):
+        cfg = self.cfg
+        n = len(cfg.block_out_channels)
+        return 1 + sum(cfg.layers_per_block + (1 if i < n - 1 else 0) for i in range(n))
