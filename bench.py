@@ -1,0 +1,160 @@
+#!/usr/bin/env python
+"""bench.py — distillation images/sec of the SD1.5 PCM-LoRA step on MI355X (BASELINE.json metric).
+
+A "step" = one full phased-consistency distillation step of train_pcm_lora_sd15.py:1117-1301 on a
+synthetic batch already resident in HBM: student forward (grad) + batched teacher cond/uncond
+forward + target forward + PCM solver math + loss + LoRA-only backward + grad all-reduce + clip +
+AdamW + operand repack.  Workload = BASELINE.json configs[1]: SD1.5 UNet (random init, no weights
+offline), 4 phases, 512 px (64x64x4 latents), per-GPU batch 16, bf16 MFMA compute / fp32 accumulate.
+
+Launch:  python bench.py --gpus 1            (single process)
+         python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "phased-consistency-model_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+# algorithmic work (SURVEY §8d / BASELINE.md §2), TFLOP per sample
+TF_STUDENT_FWD, TF_TEACHER_FWD, TF_BWD = 0.8976, 0.8033, 1.12
+TF_STEP = 2 * TF_STUDENT_FWD + 2 * TF_TEACHER_FWD + TF_BWD     # 4.52
+PEAK_BF16_TFLOPS = 2500.0                                        # dense MFMA bf16, MI355X_MICROARCH.md
+
+
+def cpu_baseline(seed):
+    """The oracle (CPU fp32 restatement of the reference step) timed on this host: BASELINE.json
+    configs[0] (bs 2, 2 phases, CFG solver on, fp32).  Bounded sample: ONE full step."""
+    from oracle import pcm_step as OS
+    from oracle import unet_sd15 as O
+    torch.set_num_threads(os.cpu_count())
+    oc = O.UNetConfig.sd15()
+    sd = O.init_state_dict(oc, 0)
+    lora = O.init_lora(oc, 64, seed=1)
+    cfg = OS.StepConfig(multiphase=2, loss_type="huber", lr=5e-6, adam_weight_decay=1e-3, w_min=4.0, w_max=5.0)
+    inp = OS.draw_inputs(2, cfg, seed=seed)
+    t0 = time.time()
+    out = OS.distill_step(oc, sd, lora, inp, cfg, {}, 1)
+    dt = time.time() - t0
+    return {"value": 2.0 / dt, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "1 full fp32 step, bs 2, 2 phases, SD1.5 UNet random init (oracle/pcm_step.py), %.1f s, loss %.5f" % (dt, float(out["loss"]))}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=16, help="per-GPU batch (BASELINE config: 16)")
+    ap.add_argument("--multiphase", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        torch.distributed.init_process_group("nccl", rank=rank, world_size=world)
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from pcm_amd import capi, ops
+    from pcm_amd.model import LoraState, UNetWeights
+    from pcm_amd.trainer import Distiller, StepConfig
+    from pcm_amd.unet_spec import UNetConfig, random_state_dict
+    capi.lib()  # fail loudly if the HIP library is missing
+
+    ucfg = UNetConfig.sd15()
+    with torch.no_grad():
+        sd = random_state_dict(ucfg, seed=0, device=dev)
+        W = UNetWeights(ucfg, sd, dev)
+        del sd
+        lora = LoraState(ucfg, 64, 8.0, dev, seed=1)   # peft init (B = 0), as the reference starts
+    cfg = StepConfig(multiphase=args.multiphase, loss_type="huber", learning_rate=5e-6, adam_weight_decay=1e-3,
+                     w_min=4.0, w_max=5.0)                 # train_pcm_lora_sd15.sh:5-29 hyper-parameters
+    D = Distiller(W, lora, cfg, world_size=world)
+    B = args.batch
+    seed = 453645634 + rank                                # train_pcm_lora_sd15.sh:26 + per-rank offset (:797)
+    g = torch.Generator(device=dev).manual_seed(seed)
+    uncond = torch.randn(B, 77, 768, generator=g, device=dev)
+
+    def draw():
+        return dict(latents=torch.randn(B, 4, 64, 64, generator=g, device=dev),
+                    prompt_embeds=torch.randn(B, 77, 768, generator=g, device=dev),
+                    noise=torch.randn(B, 4, 64, 64, generator=g, device=dev),
+                    index=torch.randint(0, cfg.num_ddim_timesteps, (B,), generator=g, device=dev),
+                    w=(cfg.w_max - cfg.w_min) * torch.rand(B, generator=g, device=dev) + cfg.w_min)
+
+    batches = [draw() for _ in range(args.warmup + args.steps)]   # resident in HBM before timing
+
+    def run(b):
+        return D.step(b["latents"], b["prompt_embeds"], uncond, b["noise"], b["index"], b["w"])
+
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for b in batches[:args.warmup]:
+        run(b)
+    sync()
+    t0 = time.perf_counter()
+    last = None
+    for b in batches[args.warmup:]:
+        last = run(b)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    ms = dt * 1e3 / args.steps
+    value = world * B / (dt / args.steps)
+    loss = float(last["loss"].item())
+
+    roofline = None
+    if rank == 0 and not args.no_roofline:
+        # dominant kernel family = pcm_gemm_bf16 (conv3x3 implicit GEMM / Linear / LoRA): one extra,
+        # instrumented step with HIP events around every launch on the launch stream.
+        ops.GEMM_PROFILE = []
+        run(batches[-1])
+        torch.cuda.synchronize()
+        prof, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
+        flops = sum(p[0] for p in prof)
+        tms = sum(p[1].elapsed_time(p[2]) for p in prof)
+        ach = flops / (tms * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None, "kernel": "pcm_gemm_kernel (all launches of one step)",
+                    "launches": len(prof), "algorithmic_tflop_per_step": round(flops / 1e12, 2), "kernel_ms_per_step": round(tms, 2),
+                    "step_tflops_algorithmic": round(TF_STEP * B / (ms * 1e-3), 1)}
+    if world > 1:
+        torch.distributed.barrier()
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(453645634)
+    if rank == 0:
+        line = {"metric": "distillation images/sec (two UNet fwd + bwd) SD1.5 512px bs=16", "value": round(value, 3),
+                "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                "config": {"workload": "SD1.5 PCM-LoRA distillation step, %d phases, 64x64x4 latents, per-GPU batch %d, "
+                                       "LoRA r=64 (67.25M trainable), huber, AdamW, random-init UNet (859.5M)" % (args.multiphase, B),
+                           "global_batch": world * B, "parallelism": "dp%d" % world, "loss_last": round(loss, 6)},
+                "roofline": roofline, "cpu_baseline": cpu}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -9,6 +9,7 @@ from . import capi
 from .capi import GemmEpi, GemmSeg, WgradArgs, ptr
 
 BF16 = torch.bfloat16
+GEMM_PROFILE = None  # set to a list by bench.py to time every pcm_gemm_bf16 launch
 
 
 def _chk(t, dtype=None):
@@ -57,6 +58,13 @@ def gemm(segs, M, N, out, bias=None, rowvec=None, rows_per_batch=0, residual=Non
     e.ldo = ldo if ldo is not None else out.shape[-1]
     e.out_dtype = capi.PCM_F32 if out.dtype == torch.float32 else capi.PCM_BF16
     e.act, e.alpha = act, alpha
+    if GEMM_PROFILE is not None:  # bench.py roofline leg: HIP events around every contraction launch
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        capi.lib().call("pcm_gemm_bf16", arr, len(segs), C.byref(e), capi.Lib.stream())
+        ev1.record()
+        GEMM_PROFILE.append((2.0 * M * N * sum(s.w.shape[-1] for s in segs), ev0, ev1))
+        return out
     capi.lib().call("pcm_gemm_bf16", arr, len(segs), C.byref(e), capi.Lib.stream())
     return out
 

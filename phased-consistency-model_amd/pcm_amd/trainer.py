@@ -1,0 +1,137 @@
+"""The phased-consistency distillation step (reference: train_pcm_lora_sd15.py:1139-1301) as host
+code over the HIP kernels: DDIM tables built once on device (the reference rebuilds the phase-edge
+table with numpy three times per step), student / teacher(cond+uncond batched) / target forwards,
+fused PCM math, LoRA-only backward, one flat all-reduce (RCCL over xGMI), fused clip+AdamW.
+
+Behavioural notes kept from the reference: the "target network" is the ONLINE
+LoRA weights under no-grad (update_ema is defined but never called; ``ema_rate`` here defaults to
+None = reference behaviour); ``w`` only scales the teacher CFG step; index 0 is a boundary sample.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import capi, ops
+from .model import LoraState, UNet, UNetWeights
+
+
+class StepConfig:
+    """Hyper-parameters with the reference's argparse names and defaults (train_pcm_lora_sd15.py:381-735)."""
+
+    def __init__(self, num_ddim_timesteps=50, multiphase=8, w_min=5.0, w_max=15.0, loss_type="l2", huber_c=0.001,
+                 learning_rate=1e-4, adam_beta1=0.9, adam_beta2=0.999, adam_weight_decay=1e-2, adam_epsilon=1e-8,
+                 max_grad_norm=1.0, lora_rank=64, lora_alpha=8.0, not_apply_cfg_solver=False, num_train_timesteps=1000,
+                 beta_start=0.00085, beta_end=0.012, ema_rate=None):
+        self.__dict__.update({k: v for k, v in locals().items() if k != "self"})
+
+
+def scaled_linear_alphas_cumprod(n=1000, beta_start=0.00085, beta_end=0.012):
+    """DDPMScheduler 'scaled_linear' table (scheduling_ddpm_modified.py:205-207,:220-221), fp32."""
+    betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, n, dtype=torch.float32) ** 2
+    return torch.cumprod(1.0 - betas, dim=0)
+
+
+class DDIMTables:
+    """DDIMSolver.__init__ (train_pcm_lora_sd15.py:289-311) + the phase edges (:1157-1163, :322-328),
+    resident on the device.  ``acp_prev`` is float64 exactly like the reference's
+    ddim_alpha_cumprods_prev (np.asarray over python floats)."""
+
+    def __init__(self, cfg: StepConfig, device):
+        acp = scaled_linear_alphas_cumprod(cfg.num_train_timesteps, cfg.beta_start, cfg.beta_end)
+        a = acp.numpy()
+        step_ratio = cfg.num_train_timesteps // cfg.num_ddim_timesteps
+        t = (np.arange(1, cfg.num_ddim_timesteps + 1) * step_ratio).round().astype(np.int64) - 1
+        t_prev = np.asarray([0] + t[:-1].tolist())
+        acp_prev = np.asarray([a[0]] + a[t[:-1]].tolist())          # float64, as in the reference
+        edges = np.floor(np.linspace(0, cfg.num_ddim_timesteps, num=cfg.multiphase, endpoint=False)).astype(np.int64)
+        self.topk = step_ratio
+        self.acp = acp.to(device)
+        self.ddim_timesteps = torch.from_numpy(t).long().to(device)
+        self.ddim_timesteps_prev = torch.from_numpy(t_prev).long().to(device)
+        self.acp_prev = torch.from_numpy(acp_prev).to(device)
+        assert self.acp_prev.dtype == torch.float64
+        self.edges = torch.from_numpy(edges).long().to(device)
+
+
+class Distiller:
+    """Owns the frozen UNet weights, the LoRA state and the optimizer state of one rank."""
+
+    def __init__(self, weights: UNetWeights, lora: LoraState, cfg: StepConfig, world_size=1, process_group=None):
+        self.W, self.lora, self.cfg = weights, lora, cfg
+        self.device = lora.device
+        self.tables = DDIMTables(cfg, self.device)
+        self.student = UNet(weights, lora)
+        self.teacher = UNet(weights, None)
+        self.world_size, self.pg = world_size, process_group
+        self.step_count = 0
+        self.ema = None
+        if cfg.ema_rate is not None:
+            self.ema = lora.params.clone()
+
+    # ---- a2: timestep sampling (train_pcm_lora_sd15.py:1143-1155) ----
+    def timesteps_for(self, index):
+        start = self.tables.ddim_timesteps[index]
+        t = torch.clamp(start - self.tables.topk, min=0)
+        return start, t
+
+    def step(self, latents, prompt_embeds, uncond_prompt_embeds, noise, index, w, lr=None, update=True):
+        """One distillation step on this rank's batch.  All inputs are device tensors:
+        latents/noise [B,4,H,W] fp32, prompt embeds [B,77,768], index [B] int64, w [B] fp32.
+        Returns a dict of device tensors (no host sync)."""
+        cfg, T = self.cfg, self.tables
+        B = latents.shape[0]
+        start_t, t_n = self.timesteps_for(index)
+        noisy = ops.add_noise(latents, noise, T.acp, start_t)                                   # :1178
+        # online student forward at t_{n+k} (grad) ---------------------------------------------- :1192
+        eps_s, tape = self.student.forward(noisy, start_t, prompt_embeds, save=True)
+        model_pred, coef, end_t = ops.phase_jump(eps_s, noisy, start_t, index, T.acp, T.acp_prev, T.ddim_timesteps_prev,
+                                                 T.edges, target_mode=False)                     # :1200-1212
+        # teacher cond (+ uncond) in ONE batched forward (no grad, no LoRA) --------------------- :1217-1252
+        if cfg.not_apply_cfg_solver:
+            eps_c = self.teacher.forward(noisy, start_t, prompt_embeds)
+            eps_u = eps_c
+        else:
+            both = self.teacher.forward(torch.cat([noisy, noisy]), torch.cat([start_t, start_t]),
+                                        torch.cat([prompt_embeds, uncond_prompt_embeds]))
+            eps_c, eps_u = both[:B], both[B:]
+        x_prev64, x_prev32 = ops.cfg_ddim_step(eps_c, eps_u, noisy, start_t, index, w, T.acp, T.acp_prev)   # :1254-1258
+        # target forward: same online weights (incl. LoRA) at (x_prev, t_n), no grad ------------ :1261-1268
+        eps_t = self.student.forward(x_prev32, t_n, prompt_embeds)
+        target, _, _ = ops.phase_jump(eps_t, x_prev64, t_n, index, T.acp, T.acp_prev, T.ddim_timesteps_prev, T.edges,
+                                      target_mode=True)                                          # :1269-1280
+        loss, d_eps = ops.consistency_loss(model_pred, target, coef, cfg.loss_type == "huber", cfg.huber_c)   # :1283-1293
+        out = dict(loss=loss, noisy_model_input=noisy, noise_pred=eps_s, model_pred=model_pred, cond_teacher_output=eps_c,
+                   uncond_teacher_output=eps_u, x_prev=x_prev64, target_noise_pred=eps_t, target=target,
+                   start_timesteps=start_t, timesteps=t_n, end_timesteps=end_t)
+        if not update:
+            out["tape"], out["d_eps"] = tape, d_eps
+            return out
+        self.lora.zero_grad()
+        self.student.backward(d_eps, tape)                                                       # :1296
+        self.optimizer_step(lr)
+        out["grad_sumsq"] = self.lora.gradsq
+        return out
+
+    def all_reduce_grads(self):
+        """DDP: one all-reduce (sum) of the flat 67 M-element LoRA gradient buffer over RCCL/xGMI;
+        the 1/world_size mean is folded into the AdamW kernel's grad_scale."""
+        if self.world_size > 1:
+            torch.distributed.all_reduce(self.lora.grads, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+
+    def optimizer_step(self, lr=None):
+        cfg, lo = self.cfg, self.lora
+        self.all_reduce_grads()
+        self.step_count += 1
+        gscale = 1.0 / self.world_size
+        ops.sumsq(lo.grads, lo.gradsq)                                                           # :1298 clip_grad_norm_
+        ops.adamw_clip_step(lo.params, lo.grads, lo.exp_avg, lo.exp_avg_sq, lo.gradsq, cfg.max_grad_norm,
+                            cfg.learning_rate if lr is None else lr, cfg.adam_beta1, cfg.adam_beta2, cfg.adam_epsilon,
+                            cfg.adam_weight_decay, self.step_count, gscale)                     # :1299
+        if self.ema is not None:
+            ops.ema_update(self.ema, lo.params, cfg.ema_rate)
+        lo.repack()
+
+    def grad_norm(self):
+        """Host read of the last global grad norm (forces a sync; for logging only)."""
+        return math.sqrt(float(self.lora.gradsq.item())) / self.world_size

@@ -110,18 +110,19 @@ def lora_target_modules(cfg):
     return out
 
 
-def random_state_dict(cfg, seed=0):
-    """Seeded stand-in for the (offline-unavailable) SD1.5 checkpoint: PyTorch-default layer init."""
-    g = torch.Generator().manual_seed(seed)
+def random_state_dict(cfg, seed=0, device="cpu"):
+    """Seeded stand-in for the (offline-unavailable) SD1.5 checkpoint: PyTorch-default layer init.
+    device="cpu" reproduces the oracle's init bit for bit; a GPU device draws on-device (bench)."""
+    g = torch.Generator(device=device).manual_seed(seed)
     spec = param_spec(cfg)
     shapes = dict(spec)
     sd = OrderedDict()
     for k, shp in spec:
         leaf = k.rsplit(".", 1)[0].rsplit(".", 1)[-1]
         if leaf.startswith("norm") or leaf == "conv_norm_out":
-            sd[k] = torch.ones(shp) if k.endswith("weight") else torch.zeros(shp)
+            sd[k] = torch.ones(shp, device=device) if k.endswith("weight") else torch.zeros(shp, device=device)
             continue
         w = shapes[k.rsplit(".", 1)[0] + ".weight"]
         bound = 1.0 / math.sqrt(math.prod(w[1:]))
-        sd[k] = (torch.rand(shp, generator=g) * 2 - 1) * bound
+        sd[k] = (torch.rand(shp, generator=g, device=device) * 2 - 1) * bound
     return sd
