@@ -35,17 +35,28 @@ def cpu_baseline(seed):
     configs[0] (bs 2, 2 phases, CFG solver on, fp32).  Bounded sample: ONE full step."""
     from oracle import pcm_step as OS
     from oracle import unet_sd15 as O
-    torch.set_num_threads(os.cpu_count())
+    # torch's default intra-op thread count honours the container's CPU affinity / quota; forcing
+    # os.cpu_count() threads oversubscribes a quota-limited box.
     oc = O.UNetConfig.sd15()
     sd = O.init_state_dict(oc, 0)
     lora = O.init_lora(oc, 64, seed=1)
     cfg = OS.StepConfig(multiphase=2, loss_type="huber", lr=5e-6, adam_weight_decay=1e-3, w_min=4.0, w_max=5.0)
-    inp = OS.draw_inputs(2, cfg, seed=seed)
+    bs = 1
+    inp = OS.draw_inputs(bs, cfg, seed=seed)
     t0 = time.time()
     out = OS.distill_step(oc, sd, lora, inp, cfg, {}, 1)
     dt = time.time() - t0
-    return {"value": 2.0 / dt, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "1 full fp32 step, bs 2, 2 phases, SD1.5 UNet random init (oracle/pcm_step.py), %.1f s, loss %.5f" % (dt, float(out["loss"]))}
+    return {"value": bs / dt, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "1 full fp32 step (4 UNet fwd + bwd + AdamW), bs %d, 2 phases, SD1.5 UNet random init "
+                      "(oracle/pcm_step.py), %.1f s, loss %.5f" % (bs, dt, float(out["loss"]))}
+
+
+def log(msg):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print("[bench %7.1fs] %s" % (time.time() - T0, msg), file=sys.stderr, flush=True)
+
+
+T0 = time.time()
 
 
 def main():
@@ -74,6 +85,7 @@ def main():
     from pcm_amd.trainer import Distiller, StepConfig
     from pcm_amd.unet_spec import UNetConfig, random_state_dict
     capi.lib()  # fail loudly if the HIP library is missing
+    log("library loaded")
 
     ucfg = UNetConfig.sd15()
     with torch.no_grad():
@@ -84,6 +96,8 @@ def main():
     cfg = StepConfig(multiphase=args.multiphase, loss_type="huber", learning_rate=5e-6, adam_weight_decay=1e-3,
                      w_min=4.0, w_max=5.0)                 # train_pcm_lora_sd15.sh:5-29 hyper-parameters
     D = Distiller(W, lora, cfg, world_size=world)
+    torch.cuda.synchronize()
+    log("weights packed, LoRA state ready (%.1f GB allocated)" % (torch.cuda.memory_allocated() / 2**30))
     B = args.batch
     seed = 453645634 + rank                                # train_pcm_lora_sd15.sh:26 + per-rank offset (:797)
     g = torch.Generator(device=dev).manual_seed(seed)
@@ -106,8 +120,10 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for b in batches[:args.warmup]:
+    for i, b in enumerate(batches[:args.warmup]):
         run(b)
+        torch.cuda.synchronize()
+        log("warmup step %d done" % i)
     sync()
     t0 = time.perf_counter()
     last = None
@@ -120,6 +136,7 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     ms = dt * 1e3 / args.steps
+    log("timed %d steps: %.1f ms/step" % (args.steps, ms))
     value = world * B / (dt / args.steps)
     loss = float(last["loss"].item())
 
@@ -134,6 +151,7 @@ def main():
         flops = sum(p[0] for p in prof)
         tms = sum(p[1].elapsed_time(p[2]) for p in prof)
         ach = flops / (tms * 1e-3) / 1e12
+        log("roofline leg done")
         roofline = {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None, "kernel": "pcm_gemm_kernel (all launches of one step)",
                     "launches": len(prof), "algorithmic_tflop_per_step": round(flops / 1e12, 2), "kernel_ms_per_step": round(tms, 2),
