@@ -16,7 +16,7 @@ __device__ __forceinline__ uint4 ew_pack8(const float (&f)[8]) {
 }
 static inline int ew_blocks(long nvec) {
   long b = (nvec + 255) / 256;
-  if (b > 4096) b = 4096;
+  if (b > PCM_GRID_CAP(4096)) b = PCM_GRID_CAP(4096);
   if (b < 1) b = 1;
   return (int)b;
 }
@@ -187,7 +187,7 @@ extern "C" int pcm_colsum_bf16(const void* x, void* out, int B, int HW, int C, v
   int CV = C / 8, split = 1;
   while (CV / split > 256 || (CV % split) != 0) split++;
   int CVL = CV / split, k = 256 / CVL;
-  int chunks = (1024 + B * split - 1) / (B * split);
+  int chunks = (PCM_GRID_CAP(1024) + B * split - 1) / (B * split);
   int maxc = (HW + k - 1) / k; if (chunks > maxc) chunks = maxc; if (chunks < 1) chunks = 1;
   int ppb = (HW + chunks - 1) / chunks; chunks = (HW + ppb - 1) / ppb;
   hipMemsetAsync(out, 0, sizeof(float) * (size_t)B * C, (hipStream_t)stream);
@@ -283,7 +283,7 @@ __global__ __launch_bounds__(256) void conv_out_kernel(const bf16_t* x, const fl
 extern "C" int pcm_conv_out_fwd(const void* x, const float* w, const float* bias, float* y, int B, int H, int W, int C0, void* stream) {
   PCM_CHECK(x && w && y && (C0 % 8) == 0 && C0 <= 1024 && PCM_ALIGNED16(x), PCM_EINVAL, "pcm_conv_out_fwd: C0%%8, C0<=1024");
   long npix = (long)B * H * W;
-  long blocks = (npix + 3) / 4; if (blocks > 2048) blocks = 2048;
+  long blocks = (npix + 3) / 4; if (blocks > PCM_GRID_CAP(2048)) blocks = PCM_GRID_CAP(2048);
   PCM_LAUNCH(conv_out_kernel, dim3((int)blocks), dim3(256), 36 * C0 * 4, stream, (const bf16_t*)x, w, bias, y, B, H, W, C0);
   return pcm_post_launch("pcm_conv_out_fwd");
 }

@@ -184,7 +184,7 @@ static int gn_stats_launch(const char* what, GNArgs a, int B, void* stream) {
   PCM_CHECK(a.CVL * 8 <= 2560, PCM_EUNSUPPORTED, "%s: channel slice too large", what);
   int k = 256 / a.CVL; if (k < 1) k = 1;
   int threads = a.CVL * k;
-  int chunks = (2048 + B * split - 1) / (B * split);
+  int chunks = (PCM_GRID_CAP(2048) + B * split - 1) / (B * split);
   int maxchunks = (a.HW + k - 1) / k; if (chunks > maxchunks) chunks = maxchunks; if (chunks < 1) chunks = 1;
   a.ppb = (a.HW + chunks - 1) / chunks;
   chunks = (a.HW + a.ppb - 1) / a.ppb;
@@ -217,7 +217,7 @@ template <int MODE>
 static int gn_apply_launch(const char* what, GNApply a, int B, void* stream) {
   size_t nvec = (size_t)a.HW * (a.C / 8);
   int blocks = (int)((nvec + 256 * 8 - 1) / (256 * 8));
-  int cap = (4096 + B - 1) / B; if (blocks > cap) blocks = cap; if (blocks < 1) blocks = 1;
+  int cap = (PCM_GRID_CAP(4096) + B - 1) / B; if (blocks > cap) blocks = cap; if (blocks < 1) blocks = 1;
   a.vec_per_block = (int)((nvec + blocks - 1) / blocks);
   blocks = (int)((nvec + a.vec_per_block - 1) / a.vec_per_block);
   PCM_LAUNCH((gn_apply_kernel<MODE>), dim3(blocks, B), dim3(256), 0, stream, a);

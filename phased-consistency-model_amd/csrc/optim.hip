@@ -5,7 +5,7 @@
 #include "pcm_common.h"
 
 #define OP_LOOP(i, n) for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (long)gridDim.x * blockDim.x)
-static inline int op_blocks(long n) { long b = (n + 255) / 256; return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b)); }
+static inline int op_blocks(long n) { long b = (n + 255) / 256; return (int)(b > PCM_GRID_CAP(2048) ? PCM_GRID_CAP(2048) : (b < 1 ? 1 : b)); }
 
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* g, double* out, long n) {
   __shared__ double red[4];

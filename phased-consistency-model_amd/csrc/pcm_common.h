@@ -15,6 +15,12 @@
 #endif
 #include <stdint.h>
 #include <string.h>
+// grid-stride kernels: cap of the launch grid (the host emulator runs blocks serially, keep it small there)
+#ifdef PCM_HOST_EMU
+#define PCM_GRID_CAP(n) 4
+#else
+#define PCM_GRID_CAP(n) (n)
+#endif
 
 #include "../../include/pcm_hip.h"
 

@@ -29,7 +29,7 @@ __device__ __forceinline__ float pm_sqrt(float a) { return __builtin_sqrtf(a); }
 __device__ __forceinline__ double pm_sqrt(double a) { return __builtin_sqrt(a); }
 
 #define PM_LOOP(i, n) for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (long)gridDim.x * blockDim.x)
-static inline int pm_blocks(long n) { long b = (n + 255) / 256; return (int)(b > 1024 ? 1024 : (b < 1 ? 1 : b)); }
+static inline int pm_blocks(long n) { long b = (n + 255) / 256; return (int)(b > PCM_GRID_CAP(1024) ? PCM_GRID_CAP(1024) : (b < 1 ? 1 : b)); }
 
 // scheduling_ddpm_modified.py:513-523: sa = acp[t]**0.5 ; sb = (1-acp[t])**0.5 ; sa*x + sb*noise
 __global__ __launch_bounds__(256) void add_noise_kernel(const float* x, const float* noise, const float* acp, const int64_t* t,

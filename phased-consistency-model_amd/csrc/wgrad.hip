@@ -110,7 +110,7 @@ extern "C" int pcm_lora_wgrad_bf16(const pcm_wgrad_args* p, void* stream) {
   }
   int tiles_g = (p->G + 63) / 64;
   int chunks = (p->M + 127) / 128;
-  int msplit = (1024 + tiles_g - 1) / tiles_g;
+  int msplit = (PCM_GRID_CAP(1024) + tiles_g - 1) / tiles_g;
   if (msplit > chunks) msplit = chunks;
   if (msplit < 1) msplit = 1;
   a.m_per_block = ((chunks + msplit - 1) / msplit) * 128;

@@ -1,0 +1,110 @@
+"""Checkpoint formats of the reference trainer, written without diffusers/peft installed:
+
+* peft adapter dir   — ``adapter_model.safetensors`` + ``adapter_config.json``
+                        (``unet.save_pretrained(output_dir)``, train_pcm_lora_sd15.py:928,:1378)
+* diffusers LoRA     — ``unet_lora/pytorch_lora_weights.safetensors`` with the ``unet.`` prefix
+                        (``StableDiffusionPipeline.save_lora_weights``, :924-926,:1380-1382)
+* kohya-ss dict      — ``get_module_kohya_state_dict`` (:52-72): what ``log_validation`` / the demo's
+                        ``pipe.load_lora_weights`` consume (``pcm_sd15_*_converted.safetensors``)
+* trainer state      — optimizer moments + step (the reference leaves this to accelerate.save_state)
+"""
+import json
+import os
+import shutil
+
+import torch
+from safetensors.torch import load_file, save_file
+
+from .unet_spec import LORA_TARGETS
+
+
+def peft_state_dict(lora):
+    return {k: v.detach().cpu().contiguous() for k, v in lora.peft_state_dict().items()}
+
+
+def kohya_state_dict(peft_sd, lora_alpha, prefix="lora_unet", dtype=torch.float16):
+    """train_pcm_lora_sd15.py:52-72."""
+    out = {}
+    for peft_key, weight in peft_sd.items():
+        k = peft_key.replace("base_model.model", prefix)
+        k = k.replace("lora_A", "lora_down").replace("lora_B", "lora_up")
+        k = k.replace(".", "_", k.count(".") - 2)
+        out[k] = weight.to(dtype)
+        if "lora_down" in k:
+            out[f'{k.split(".")[0]}.alpha'] = torch.tensor(lora_alpha).to(dtype)
+    return out
+
+
+def adapter_config(lora):
+    """The fields peft 0.9 writes for LoraConfig(r, target_modules) (:866-884)."""
+    return {"peft_type": "LORA", "task_type": None, "base_model_name_or_path": None, "r": lora.rank,
+            "lora_alpha": lora.alpha, "lora_dropout": 0.0, "bias": "none", "fan_in_fan_out": False,
+            "init_lora_weights": True, "inference_mode": True, "target_modules": list(LORA_TARGETS),
+            "modules_to_save": None, "rank_pattern": {}, "alpha_pattern": {}, "use_rslora": False, "revision": None,
+            "layers_pattern": None, "layers_to_transform": None, "megatron_config": None, "megatron_core": "megatron.core",
+            "loftq_config": {}, "use_dora": False}
+
+
+def save_lora(lora, output_dir, kohya=True):
+    os.makedirs(os.path.join(output_dir, "unet_lora"), exist_ok=True)
+    sd = peft_state_dict(lora)
+    save_file(sd, os.path.join(output_dir, "adapter_model.safetensors"))
+    with open(os.path.join(output_dir, "adapter_config.json"), "w") as f:
+        json.dump(adapter_config(lora), f, indent=2)
+    save_file({"unet." + k: v for k, v in sd.items()}, os.path.join(output_dir, "unet_lora", "pytorch_lora_weights.safetensors"))
+    if kohya:
+        save_file(kohya_state_dict(sd, lora.alpha), os.path.join(output_dir, "pcm_lora_kohya_converted.safetensors"))
+
+
+def load_lora(lora, input_dir):
+    lora.load_peft_state_dict(load_file(os.path.join(input_dir, "adapter_model.safetensors")))
+
+
+def save_state(distiller, output_dir, global_step):
+    """checkpoint-N directory: adapter + diffusers LoRA (the reference's save hook) + optimizer state."""
+    save_lora(distiller.lora, output_dir, kohya=False)
+    lo = distiller.lora
+    save_file({"exp_avg": lo.exp_avg.detach().cpu(), "exp_avg_sq": lo.exp_avg_sq.detach().cpu()},
+              os.path.join(output_dir, "optimizer.safetensors"))
+    with open(os.path.join(output_dir, "trainer_state.json"), "w") as f:
+        json.dump({"global_step": global_step, "optimizer_step": distiller.step_count}, f)
+
+
+def load_state(distiller, input_dir):
+    load_lora(distiller.lora, input_dir)
+    p = os.path.join(input_dir, "optimizer.safetensors")
+    if os.path.exists(p):
+        st = load_file(p)
+        distiller.lora.exp_avg.copy_(st["exp_avg"].to(distiller.lora.device))
+        distiller.lora.exp_avg_sq.copy_(st["exp_avg_sq"].to(distiller.lora.device))
+    with open(os.path.join(input_dir, "trainer_state.json")) as f:
+        st = json.load(f)
+    distiller.step_count = st["optimizer_step"]
+    return st["global_step"]
+
+
+def rotate_checkpoints(output_dir, total_limit):
+    """train_pcm_lora_sd15.py:1311-1337: keep at most total_limit-1 before saving a new one."""
+    if total_limit is None:
+        return
+    cks = sorted([d for d in os.listdir(output_dir) if d.startswith("checkpoint")], key=lambda x: int(x.split("-")[1]))
+    if len(cks) >= total_limit:
+        for d in cks[0:len(cks) - total_limit + 1]:
+            shutil.rmtree(os.path.join(output_dir, d))
+
+
+def latest_checkpoint(output_dir):
+    """:1086-1091"""
+    if not os.path.isdir(output_dir):
+        return None
+    dirs = sorted([d for d in os.listdir(output_dir) if d.startswith("checkpoint")], key=lambda x: int(x.split("-")[1]))
+    return dirs[-1] if dirs else None
+
+
+def load_unet_state_dict(pretrained_dir):
+    """diffusers layout: <dir>/unet/diffusion_pytorch_model.safetensors (train_pcm_lora_sd15.py:840-851)."""
+    for name in ("diffusion_pytorch_model.safetensors", "diffusion_pytorch_model.fp16.safetensors"):
+        p = os.path.join(pretrained_dir, "unet", name)
+        if os.path.exists(p):
+            return load_file(p)
+    raise FileNotFoundError(f"no unet/diffusion_pytorch_model*.safetensors under {pretrained_dir}")

@@ -1,0 +1,110 @@
+"""CPU tests of the host logic: CLI flag surface vs the reference, checkpoint formats, lr schedule,
+C-ABI symbol export (no compute calls)."""
+import ast
+import importlib.util
+import json
+import os
+import re
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "phased-consistency-model_amd")
+REF = "/root/reference/code/text_to_image_sd15/train_pcm_lora_sd15.py"
+
+
+def load_cli():
+    spec = importlib.util.spec_from_file_location("pcm_cli", os.path.join(PKG, "train_pcm_lora_sd15.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_cli_accepts_reference_launch_line_with_abbreviation():
+    cli = load_cli()
+    a = cli.parse_args(["--pretrained_teacher_model=./stable-diffusion-v1-5", "--output_dir=out", "--tracker_project_nam=proj",
+                        "--mixed_precision=fp16", "--resolution=512", "--lora_rank=64", "--learning_rate=5e-6", "--loss_type=huber",
+                        "--adam_weight_decay=1e-3", "--max_train_steps=5000", "--max_train_samples=4000000",
+                        "--dataloader_num_workers=16", "--w_min=4", "--w_max=5", "--validation_steps=500", "--checkpointing_steps=1000",
+                        "--checkpoints_total_limit=10", "--train_batch_size=20", "--enable_xformers_memory_efficient_attention",
+                        "--gradient_accumulation_steps=1", "--use_8bit_adam", "--report_to=wandb", "--resume_from_checkpoint=latest",
+                        "--seed=453645634", "--num_ddim_timesteps=50", "--multiphase=4", "--gradient_checkpointing"])
+    assert a.tracker_project_name == "proj" and a.multiphase == 4 and a.loss_type == "huber" and a.w_min == 4.0
+
+
+@pytest.mark.skipif(not os.path.exists(REF), reason="/root/reference not mounted")
+def test_cli_flags_and_defaults_match_reference():
+    tree = ast.parse(open(REF).read())
+    fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "parse_args"][0]
+    ref = {}
+    for node in ast.walk(fn):
+        if isinstance(node, ast.Call) and getattr(node.func, "attr", "") == "add_argument":
+            name = node.args[0].value.lstrip("-")
+            kw = {k.arg: k.value for k in node.keywords}
+            default = ast.literal_eval(kw["default"]) if "default" in kw else (False if "action" in kw else None)
+            ref[name] = default
+    cli = load_cli()
+    ours = vars(cli.parse_args(["--pretrained_teacher_model", "x"]))
+    assert len(ref) == 51
+    for k, v in ref.items():
+        assert k in ours, k
+        if k != "pretrained_teacher_model":
+            assert ours[k] == v, (k, ours[k], v)
+
+
+def test_capi_exports_every_declared_symbol():
+    from pcm_amd import build as B
+    from pcm_amd import capi
+    lib = B.build()
+    header = open(os.path.join(ROOT, "include", "pcm_hip.h")).read()
+    declared = set(re.findall(r"^\s*(?:int|const char\*)\s+(pcm_\w+)\s*\(", header, flags=re.M))
+    L = capi.Lib(lib)
+    for name in declared:
+        assert hasattr(L.dll, name), f"{name} declared in include/pcm_hip.h but not exported"
+    assert declared - {"pcm_last_error", "pcm_abi_version"} == set(capi._PROTOS), (declared ^ set(capi._PROTOS))
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    from pcm_amd import capi
+    with pytest.raises(RuntimeError, match="no fallback"):
+        capi.Lib(str(tmp_path / "nope.so"))
+
+
+def test_checkpoint_formats_roundtrip(tmp_path):
+    from emu_lib import emu_lib
+    from oracle import pcm_math as M
+    from pcm_amd import capi, checkpoint as ck
+    from pcm_amd.model import LoraState
+    from pcm_amd.unet_spec import UNetConfig
+    from safetensors.torch import load_file
+    capi.set_lib(emu_lib())
+    try:
+        cfg = UNetConfig(block_out_channels=(64, 128, 128, 128), cross_attention_dim=64, heads=2)
+        lora = LoraState(cfg, 64, 8.0, "cpu", seed=3, b_std=0.01)
+        ck.save_lora(lora, str(tmp_path))
+        sd = load_file(str(tmp_path / "adapter_model.safetensors"))
+        k0 = "base_model.model.down_blocks.0.attentions.0.transformer_blocks.0.attn1.to_out.0.lora_A.weight"
+        assert k0 in sd and sd[k0].shape == (64, 64)
+        assert sd["base_model.model.down_blocks.0.resnets.0.conv1.lora_A.weight"].shape == (64, 64, 3, 3)
+        assert sd["base_model.model.down_blocks.0.resnets.0.conv1.lora_B.weight"].shape == (64, 64, 1, 1)
+        dl = load_file(str(tmp_path / "unet_lora" / "pytorch_lora_weights.safetensors"))
+        assert set(dl) == {"unet." + k for k in sd}
+        ko = load_file(str(tmp_path / "pcm_lora_kohya_converted.safetensors"))
+        kk = "lora_unet_down_blocks_0_attentions_0_transformer_blocks_0_attn1_to_out_0"
+        assert kk + ".lora_down.weight" in ko and kk + ".lora_up.weight" in ko and float(ko[kk + ".alpha"]) == 8.0
+        assert all(M.kohya_key(k) in ko for k in sd)              # oracle restatement of the reference's renaming rule
+        cfgj = json.load(open(tmp_path / "adapter_config.json"))
+        assert cfgj["r"] == 64 and cfgj["lora_alpha"] == 8.0 and "to_out.0" in cfgj["target_modules"]
+        lora2 = LoraState(cfg, 64, 8.0, "cpu", seed=99)
+        ck.load_lora(lora2, str(tmp_path))
+        assert torch.equal(lora2.params, lora.params)
+    finally:
+        capi.set_lib(None)
+
+
+def test_lr_schedule_constant_ignores_warmup():
+    cli = load_cli()
+    a = cli.parse_args(["--pretrained_teacher_model", "x", "--learning_rate", "5e-6", "--lr_warmup_steps", "500"])
+    assert cli.lr_at(a, 0) == 5e-6 and cli.lr_at(a, 10000) == 5e-6

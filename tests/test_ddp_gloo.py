@@ -1,0 +1,64 @@
+"""world_size-2 CPU test (gloo) of the data-parallel exchange step: one flat all-reduce of the LoRA
+gradient buffer + the 1/world mean folded into the fused clip+AdamW kernel (host-emulated here)."""
+import os
+import sys
+
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, outdir):
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "phased-consistency-model_amd"), os.path.join(ROOT, "tests")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    from emu_lib import emu_lib
+    from pcm_amd import capi
+    from pcm_amd.model import LoraState, UNetWeights
+    from pcm_amd.trainer import Distiller, StepConfig
+    from pcm_amd.unet_spec import UNetConfig, random_state_dict
+    capi.set_lib(emu_lib())
+    cfg = UNetConfig(block_out_channels=(64, 64), layers_per_block=1, cross_attention_dim=64, heads=2)
+    lora = LoraState(cfg, 64, 8.0, "cpu", seed=5, b_std=0.01)
+    D = Distiller.__new__(Distiller)       # exchange step only: no UNet weights needed
+    D.lora, D.cfg, D.world_size, D.pg, D.step_count, D.ema = lora, StepConfig(learning_rate=1e-3), world, None, 0, None
+    g = torch.Generator().manual_seed(100 + rank)
+    lora.grads.copy_(torch.randn(lora.numel, generator=g) * 1e-3)
+    mine = lora.grads.clone()
+    D.optimizer_step()
+    torch.save((rank, mine, lora.params.clone(), float(lora.gradsq.item())), os.path.join(outdir, f"r{rank}.pt"))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_allreduce_and_step(tmp_path):
+    ctx = mp.get_context("spawn")
+    port = 29731
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, str(tmp_path))) for r in range(2)]
+    for p in ps:
+        p.start()
+    for p in ps:
+        p.join(300)
+        assert p.exitcode == 0
+    res = [torch.load(os.path.join(str(tmp_path), f"r{r}.pt")) for r in range(2)]
+    (_, g0, p0, s0), (_, g1, p1, s1) = res
+    assert torch.equal(p0, p1), "ranks diverged after the exchange step"
+    # single-process reference with the MEAN gradient (DDP semantics) via the oracle's AdamW/clip
+    sys.path[:0] = [ROOT]
+    from oracle.pcm_step import StepConfig as OC, adamw_step, clip_grad_norm_
+    from emu_lib import emu_lib
+    from pcm_amd import capi
+    from pcm_amd.model import LoraState
+    from pcm_amd.unet_spec import UNetConfig
+    capi.set_lib(emu_lib())
+    try:
+        lora = LoraState(UNetConfig(block_out_channels=(64, 64), layers_per_block=1, cross_attention_dim=64, heads=2), 64, 8.0, "cpu", seed=5, b_std=0.01)
+    finally:
+        capi.set_lib(None)
+    ref_p = lora.params.clone()
+    gm = [(g0 + g1) / 2]
+    assert abs(s0 - float(((g0 + g1).double() ** 2).sum())) < 1e-9 * s0      # the kernel sees the SUM; scale folded in
+    clip_grad_norm_(gm, 1.0)
+    adamw_step([ref_p], gm, {}, 1, OC(lr=1e-3, adam_weight_decay=1e-2))
+    assert torch.allclose(p0, ref_p, rtol=1e-5, atol=1e-7)
