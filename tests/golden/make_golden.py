@@ -51,6 +51,40 @@ def main():
         out[f"target_c_skip_{M}"], out[f"target_c_out_{M}"] = cs, co
         cs, co = ns["scalings_for_boundary_conditions_online"](index, edges)
         out[f"online_c_skip_{M}"], out[f"online_c_out_{M}"] = cs, co
+    # ---- the step's fused chains, evaluated with the reference's own functions (fixtures for the
+    # fused HIP kernels pcm_phase_jump / pcm_cfg_ddim_step / pcm_consistency_loss) ----
+    x0_32 = ns["predicted_origin"](eps, start, x, "epsilon", alpha_s, sigma_s)
+    x64 = x.double()
+    x0_64 = ns["predicted_origin"](eps, start, x64, "epsilon", alpha_s, sigma_s)
+    for M in (1, 2, 4, 8):
+        jump, _ = solver.ddim_style_multiphase_pred(x0_32, eps, index, M)          # online branch (:1200-1212)
+        out[f"chain_online_{M}"] = jump.float()
+        e2 = eps.clone().requires_grad_(True)
+        j2, _ = solver.ddim_style_multiphase_pred(ns["predicted_origin"](e2, start, x, "epsilon", alpha_s, sigma_s), e2, index, M)
+        j2.sum().backward()
+        out[f"chain_coef_{M}"] = e2.grad[:, 0, 0, 0].float().clone()
+        jt, _ = solver.ddim_style_multiphase_pred(x0_64, eps, index, M)            # target branch on fp64 x_prev (:1269-1280)
+        cs = ns["append_dims"](out[f"target_c_skip_{M}"], 4)
+        out[f"chain_target_{M}"] = (cs * x64 + (1.0 - cs) * jt).float()
+    gw = torch.Generator().manual_seed(3)
+    w = torch.rand(B, generator=gw) + 4.0
+    eps_u = torch.randn(shape, generator=gw)
+    out["cfg_w"], out["cfg_eps_u"] = w, eps_u
+    wc = w.reshape(B, 1, 1, 1)
+    c0 = ns["predicted_origin"](eps, start, x, "epsilon", alpha_s, sigma_s)
+    u0 = ns["predicted_origin"](eps_u, start, x, "epsilon", alpha_s, sigma_s)
+    xprev = solver.ddim_step(c0 + wc * (c0 - u0), eps + wc * (eps - eps_u), index)  # :1254-1258
+    assert xprev.dtype == torch.float64
+    out["cfg_x_prev"] = xprev
+    for lt in ("huber", "l2"):
+        mp = x.clone().requires_grad_(True)
+        if lt == "l2":
+            loss = torch.nn.functional.mse_loss(mp.float(), eps.float(), reduction="mean")
+        else:
+            loss = torch.mean(torch.sqrt((mp.float() - eps.float()) ** 2 + 0.001 ** 2) - 0.001)   # :1288-1293
+        loss.backward()
+        out[f"loss_{lt}"] = loss.detach().reshape(1)
+        out[f"loss_{lt}_grad"] = mp.grad.clone()
     out["add_noise_fp32"] = sched.add_noise(x, noise, start)
     out["add_noise_bf16"] = sched.add_noise(x.bfloat16(), noise.bfloat16(), start)
     tgt = torch.clamp(start + torch.randint(0, 250, (B,), generator=g), max=999)

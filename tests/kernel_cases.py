@@ -110,66 +110,33 @@ def case_timestep_embedding(dev):
 
 
 def case_pcm_math(dev, golden):
-    """Reference-owned math: compared with the fixtures produced by executing the reference's own
-    source (tests/golden/make_golden.py).  fp32 ops bit-exact; fp64 jump cast to fp32 bit-exact."""
-    from oracle import pcm_math as M
+    """Reference-owned math: the fused HIP kernels against fixtures produced by EXECUTING THE
+    REFERENCE'S OWN SOURCE in the build container (tests/golden/make_golden.py).  Bit-exact."""
     g = golden
     acp = g["alphas_cumprod"].to(dev)
-    s = M.DDIMSolver(g["alphas_cumprod"].numpy(), 1000, 50)
-    acp_prev = s.ddim_alpha_cumprods_prev.to(dev)
-    assert acp_prev.dtype == torch.float64
-    t_prev = s.ddim_timesteps_prev.to(dev)
+    acp_prev = g["ddim_alpha_cumprods_prev"].to(dev)
+    assert acp_prev.dtype == torch.float64          # the reference's table is float64
+    t_prev = g["ddim_timesteps_prev"].to(dev)
     idx, x, eps, noise = [g[k].to(dev) for k in ("index", "x", "eps", "noise")]
     start = g["start_timesteps"].to(dev)
     assert torch.equal(ops.add_noise(x, noise, acp, start).cpu(), g["add_noise_fp32"])
+    import numpy as np
     for m in (1, 2, 4, 8):
-        edges = M.phase_edges(50, m).to(dev)
+        edges = torch.from_numpy(np.floor(np.linspace(0, 50, num=m, endpoint=False)).astype(np.int64)).to(dev)
         out, coef, end_t = ops.phase_jump(eps, x, start, idx, acp, acp_prev, t_prev, edges, target_mode=False)
         assert torch.equal(end_t.cpu(), g[f"multiphase_{m}_t"])
-        # reference chain (oracle restatement, pinned bit-exactly to the reference source):
-        # predicted_origin in fp32, then the fp64 jump, then .float()
-        a_s, s_s = torch.sqrt(g["alphas_cumprod"]), torch.sqrt(1 - g["alphas_cumprod"])
-        x0_32 = M.predicted_origin(g["eps"], g["start_timesteps"], g["x"], "epsilon", a_s, s_s)
-        assert torch.equal(x0_32, g["predicted_origin_epsilon"])
-        jref, _ = s.ddim_style_multiphase_pred(x0_32, g["eps"], g["index"], m)
-        assert torch.equal(out.cpu(), jref.float()), m
-        # target mode with an fp64 sample: c_skip * x_prev + c_out * jump
-        x64 = x.double()
-        outt, _, _ = ops.phase_jump(eps, x64, start, idx, acp, acp_prev, t_prev, edges, target_mode=True)
-        a_s, s_s = torch.sqrt(g["alphas_cumprod"]), torch.sqrt(1 - g["alphas_cumprod"])
-        x0 = M.predicted_origin(g["eps"], g["start_timesteps"], g["x"].double(), "epsilon", a_s, s_s)
-        jump, _ = s.ddim_style_multiphase_pred(x0, g["eps"], g["index"], m)
-        cs = M.append_dims(g[f"target_c_skip_{m}"], 4)
-        ref = (cs * g["x"].double() + (1 - cs) * jump).float()
-        assert torch.equal(outt.cpu(), ref), m
-        # coef = d out / d eps  (finite check against autograd of the oracle chain)
-        e2 = g["eps"].clone().requires_grad_(True)
-        x0g = M.predicted_origin(e2, g["start_timesteps"], g["x"], "epsilon", a_s, s_s)
-        j2, _ = s.ddim_style_multiphase_pred(x0g, e2, g["index"], m)
-        j2.sum().backward()
-        close(coef, e2.grad[:, 0, 0, 0], 1e-5, 1e-6, "coef")
-    # CFG ddim step vs oracle restatement (itself pinned to the reference)
-    w = (torch.rand(idx.shape[0], generator=torch.Generator().manual_seed(3)) + 4.0).to(dev)
-    eu = rnd(*eps.shape, seed=11, dev=dev, dtype=torch.float32)
-    xp, xp32 = ops.cfg_ddim_step(eps, eu, x, start, idx, w, acp, acp_prev)
-    a_s, s_s = torch.sqrt(g["alphas_cumprod"]), torch.sqrt(1 - g["alphas_cumprod"])
-    c0 = M.predicted_origin(g["eps"], g["start_timesteps"], g["x"], "epsilon", a_s, s_s)
-    u0 = M.predicted_origin(eu.cpu(), g["start_timesteps"], g["x"], "epsilon", a_s, s_s)
-    wc = w.cpu().reshape(-1, 1, 1, 1)
-    px0 = c0 + wc * (c0 - u0)
-    pn = g["eps"] + wc * (g["eps"] - eu.cpu())
-    ref = s.ddim_step(px0, pn, g["index"])
-    assert ref.dtype == torch.float64
-    assert torch.equal(xp.cpu(), ref) and torch.equal(xp32.cpu(), ref.float())
-    # loss
-    for huber in (True, False):
-        mp = g["x"].clone().requires_grad_(True)
-        ref_l = M.consistency_loss(mp, g["eps"], "huber" if huber else "l2", 0.001)
-        ref_l.backward()
-        coef1 = torch.ones(idx.shape[0], device=dev) * 0.5
-        loss, d = ops.consistency_loss(x, eps, coef1, huber, 0.001)
-        assert abs(loss.item() - ref_l.item()) <= 2e-6 * abs(ref_l.item())
-        close(d, mp.grad * 0.5, 1e-5, 1e-9, "loss grad")
+        assert torch.equal(out.cpu(), g[f"chain_online_{m}"]), m
+        close(coef, g[f"chain_coef_{m}"], 1e-5, 1e-6, "coef")
+        outt, _, _ = ops.phase_jump(eps, x.double(), start, idx, acp, acp_prev, t_prev, edges, target_mode=True)
+        assert torch.equal(outt.cpu(), g[f"chain_target_{m}"]), m
+    xp, xp32 = ops.cfg_ddim_step(eps, g["cfg_eps_u"].to(dev), x, start, idx, g["cfg_w"].to(dev), acp, acp_prev)
+    assert torch.equal(xp.cpu(), g["cfg_x_prev"]) and torch.equal(xp32.cpu(), g["cfg_x_prev"].float())
+    coef1 = torch.full((idx.shape[0],), 0.5, device=dev)
+    for lt in ("huber", "l2"):
+        loss, d = ops.consistency_loss(x, eps, coef1, lt == "huber", 0.001)
+        ref = float(g[f"loss_{lt}"])
+        assert abs(loss.item() - ref) <= 2e-6 * abs(ref), (lt, loss.item(), ref)
+        close(d, g[f"loss_{lt}_grad"] * 0.5, 1e-5, 1e-9, "loss grad")
 
 
 def case_optim(dev):
