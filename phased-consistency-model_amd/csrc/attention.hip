@@ -68,6 +68,58 @@ __device__ __forceinline__ void load_transposed64(char* dst, const bf16_t* src, 
     for (int dd = 0; dd < 8; dd++) *(uint4*)(dst + tr_off(8 * dg + dd, sh)) = oo[dd];
   }
 }
+// ---- register staging (issue the NEXT tile's global loads before computing on the current tile;
+// the LDS write happens after the next barrier, so L2/HBM latency hides under the MFMA phase) ----
+template <int D, int ROWS>
+struct RowStage {
+  using C = AttnCfg<D>;
+  static constexpr int N = (ROWS * C::DG + 255) / 256;
+  uint4 r[N];
+  __device__ __forceinline__ void load(const bf16_t* src, int ld, int row0, int nrows_valid, int tid) {
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      int u = tid + 256 * i;
+      int rr = u / C::DG, c = u - rr * C::DG;
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (u < ROWS * C::DG && row0 + rr < nrows_valid) v = *(const uint4*)(src + (size_t)(row0 + rr) * ld + 8 * c);
+      r[i] = v;
+    }
+  }
+  __device__ __forceinline__ void store(char* dst, int tid) const {
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      int u = tid + 256 * i;
+      int rr = u / C::DG, c = u - rr * C::DG;
+      if (u < ROWS * C::DG) *(uint4*)(dst + (rr * C::RKU + c) * 16) = r[i];
+    }
+  }
+};
+template <int D>
+struct TransStage {
+  using C = AttnCfg<D>;
+  uint4 rr[8];
+  __device__ __forceinline__ void load(const bf16_t* src, int ld, int row0, int nrows_valid, int tid) {
+    if (tid < 8 * C::DG) {
+      int sh = tid & 7, dg = tid >> 3, ss = sh >> 1, hi = sh & 1;
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        int r = row0 + 16 * ss + 8 * (e >> 2) + 4 * hi + (e & 3);
+        rr[e] = r < nrows_valid ? *(const uint4*)(src + (size_t)r * ld + 8 * dg) : make_uint4(0u, 0u, 0u, 0u);
+      }
+    }
+  }
+  __device__ __forceinline__ void store(char* dst, int tid) const {
+    if (tid < 8 * C::DG) {
+      int sh = tid & 7, dg = tid >> 3;
+      uint4 oo[8];
+      transpose8x8_bf16(rr, oo);
+#pragma unroll
+      for (int dd = 0; dd < 8; dd++) *(uint4*)(dst + tr_off(8 * dg + dd, sh)) = oo[dd];
+    }
+  }
+};
+template <int D> struct AttnPrefetch { static constexpr bool value = D <= 80; };
+
 // fragment straight from global: row-major [row][16s + 8hi ..]; zero outside [0, D) / invalid rows
 template <int D>
 __device__ __forceinline__ bf16x8 gfrag(const bf16_t* base, int ld, int row, int nrows_valid, int s, int hi) {
@@ -76,11 +128,11 @@ __device__ __forceinline__ bf16x8 gfrag(const bf16_t* base, int ld, int row, int
   if (row < nrows_valid && c < D) return *(const bf16x8*)(base + (size_t)row * ld + c);
   return z;
 }
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ bf16x8 pack_frag(const f32x16& p, int half) {
-  bf16x8 f;
-#pragma unroll
-  for (int e = 0; e < 8; e++) f[e] = (short)f2bf(p[8 * half + e]);
-  return f;
+  u32x4_t w = {pack_bf2(p[8 * half + 0], p[8 * half + 1]), pack_bf2(p[8 * half + 2], p[8 * half + 3]),
+               pack_bf2(p[8 * half + 4], p[8 * half + 5]), pack_bf2(p[8 * half + 6], p[8 * half + 7])};
+  return __builtin_bit_cast(bf16x8, w);
 }
 
 // ============================================================================ forward
@@ -106,11 +158,19 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* q, const bf
   float m_run = -1e30f, l_run = 0.f;
   const float sc = scale * LOG2E;
   zero_pad_chunks<D, 64>(Ks, tid);
+  RowStage<D, 64> kst;
+  TransStage<D> vst;
+  if (AttnPrefetch<D>::value) { kst.load(kb, ldk, 0, Lk, tid); vst.load(vb, ldk, 0, Lk, tid); }
   for (int kv0 = 0; kv0 < Lk; kv0 += 64) {
     __syncthreads();
-    load_rowmajor<D, 64>(Ks, kb, ldk, kv0, Lk, tid);
-    load_transposed64<D>(Vt, vb, ldk, kv0, Lk, tid);
+    if (AttnPrefetch<D>::value) {
+      kst.store(Ks, tid); vst.store(Vt, tid);
+    } else {
+      load_rowmajor<D, 64>(Ks, kb, ldk, kv0, Lk, tid);
+      load_transposed64<D>(Vt, vb, ldk, kv0, Lk, tid);
+    }
     __syncthreads();
+    if (AttnPrefetch<D>::value && kv0 + 64 < Lk) { kst.load(kb, ldk, kv0 + 64, Lk, tid); vst.load(vb, ldk, kv0 + 64, Lk, tid); }
     f32x16 s_[2];
 #pragma unroll
     for (int t = 0; t < 2; t++) {
@@ -122,34 +182,43 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* q, const bf
         s_[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], s_[t], 0, 0, 0);
       }
     }
+    // online softmax in the log2 domain on RAW scores: p = exp2(s*sc - m); masks only on the tail tile
+    if (kv0 + 64 > Lk) {
+#pragma unroll
+      for (int t = 0; t < 2; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          int kv = kv0 + 32 * t + 4 * hi + (r & 3) + 8 * (r >> 2);
+          if (kv >= Lk) s_[t][r] = -1e30f;
+        }
+    }
     float mx = -1e30f;
 #pragma unroll
     for (int t = 0; t < 2; t++)
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        int kv = kv0 + 32 * t + 4 * hi + (r & 3) + 8 * (r >> 2);
-        float x = kv < Lk ? s_[t][r] * sc : -1e30f;
-        s_[t][r] = x;
-        mx = fmaxf(mx, x);
-      }
+      for (int r = 0; r < 16; r++) mx = fmaxf(mx, s_[t][r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32));
-    float m_new = fmaxf(m_run, mx);
-    float alpha = PCM_EXP2F(m_run - m_new);
+    float m_new = fmaxf(m_run, mx * sc);
     float psum = 0.f;
 #pragma unroll
     for (int t = 0; t < 2; t++)
 #pragma unroll
       for (int r = 0; r < 16; r++) {
-        float p = PCM_EXP2F(s_[t][r] - m_new);
+        float p = PCM_EXP2F(fmaf(s_[t][r], sc, -m_new));
         s_[t][r] = p;
         psum += p;
       }
-    l_run = l_run * alpha + psum;
-    m_run = m_new;
+    if (__all(m_new == m_run)) {      // running max unchanged for the whole wave: no rescale pass
+      l_run += psum;
+    } else {
+      float alpha = PCM_EXP2F(m_run - m_new);
+      l_run = l_run * alpha + psum;
+      m_run = m_new;
 #pragma unroll
-    for (int i = 0; i < C::DV; i++)
+      for (int i = 0; i < C::DV; i++)
 #pragma unroll
-      for (int r = 0; r < 16; r++) acc_o[i][r] *= alpha;
+        for (int r = 0; r < 16; r++) acc_o[i][r] *= alpha;
+    }
     bf16x8 pf[4];
 #pragma unroll
     for (int ss = 0; ss < 4; ss++) pf[ss] = pack_frag(s_[ss >> 1], ss & 1);
@@ -235,12 +304,22 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* q, const
   const float sc = scale * LOG2E;
   zero_pad_chunks<D, 64>(Ks, tid);
   zero_pad_chunks<D, 64>(Vs, tid);
+  RowStage<D, 64> kst, vst;
+  TransStage<D> ktst;
+  if (AttnPrefetch<D>::value) { kst.load(kb, ldk, 0, Lk, tid); vst.load(vb, ldk, 0, Lk, tid); ktst.load(kb, ldk, 0, Lk, tid); }
   for (int kv0 = 0; kv0 < Lk; kv0 += 64) {
     __syncthreads();
-    load_rowmajor<D, 64>(Ks, kb, ldk, kv0, Lk, tid);
-    load_rowmajor<D, 64>(Vs, vb, ldk, kv0, Lk, tid);
-    load_transposed64<D>(Kt, kb, ldk, kv0, Lk, tid);
+    if (AttnPrefetch<D>::value) {
+      kst.store(Ks, tid); vst.store(Vs, tid); ktst.store(Kt, tid);
+    } else {
+      load_rowmajor<D, 64>(Ks, kb, ldk, kv0, Lk, tid);
+      load_rowmajor<D, 64>(Vs, vb, ldk, kv0, Lk, tid);
+      load_transposed64<D>(Kt, kb, ldk, kv0, Lk, tid);
+    }
     __syncthreads();
+    if (AttnPrefetch<D>::value && kv0 + 64 < Lk) {
+      kst.load(kb, ldk, kv0 + 64, Lk, tid); vst.load(vb, ldk, kv0 + 64, Lk, tid); ktst.load(kb, ldk, kv0 + 64, Lk, tid);
+    }
     f32x16 s_[2], dp[2];
 #pragma unroll
     for (int t = 0; t < 2; t++) {
@@ -258,10 +337,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* q, const
     for (int t = 0; t < 2; t++)
 #pragma unroll
       for (int r = 0; r < 16; r++) {
-        int kv = kv0 + 32 * t + 4 * hi + (r & 3) + 8 * (r >> 2);
-        float p = kv < Lk ? PCM_EXP2F(s_[t][r] * sc - L2) : 0.f;
+        float p = PCM_EXP2F(fmaf(s_[t][r], sc, -L2));
         s_[t][r] = p * (dp[t][r] - dl) * scale;  // dS^T
       }
+    if (kv0 + 64 > Lk) {
+#pragma unroll
+      for (int t = 0; t < 2; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          int kv = kv0 + 32 * t + 4 * hi + (r & 3) + 8 * (r >> 2);
+          if (kv >= Lk) s_[t][r] = 0.f;
+        }
+    }
     bf16x8 df[4];
 #pragma unroll
     for (int ss = 0; ss < 4; ss++) df[ss] = pack_frag(s_[ss >> 1], ss & 1);
@@ -316,20 +403,40 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16_t* q, con
     for (int r = 0; r < 16; r++) { acc_k[i][r] = 0.f; acc_v[i][r] = 0.f; }
   const float sc = scale * LOG2E;
   const bool kv_ok = (kv0 + l31) < Lk;
+  const bool blk_full = ((int)blockIdx.x * 128 + 128) <= Lk;
   zero_pad_chunks<D, 64>(Qs, tid);
   zero_pad_chunks<D, 64>(Os, tid);
+  RowStage<D, 64> qst, ost;
+  TransStage<D> qtst, otst;
+  float l2r = 0.f, dlr = 0.f;
+  auto stage_load = [&](int q0_) {
+    qst.load(qb, ldq, q0_, Lq, tid); ost.load(dob, ldo, q0_, Lq, tid);
+    qtst.load(qb, ldq, q0_, Lq, tid); otst.load(dob, ldo, q0_, Lq, tid);
+    if (tid < 64) {
+      int qr = q0_ + tid;
+      l2r = qr < Lq ? lse[((size_t)b * H + h) * Lq + qr] : 0.f;
+      dlr = qr < Lq ? delta[((size_t)b * H + h) * Lq + qr] : 0.f;
+    }
+  };
+  if (AttnPrefetch<D>::value) stage_load(0);
   for (int qq0 = 0; qq0 < Lq; qq0 += 64) {
     __syncthreads();
-    load_rowmajor<D, 64>(Qs, qb, ldq, qq0, Lq, tid);
-    load_rowmajor<D, 64>(Os, dob, ldo, qq0, Lq, tid);
-    load_transposed64<D>(Qt, qb, ldq, qq0, Lq, tid);
-    load_transposed64<D>(Ot, dob, ldo, qq0, Lq, tid);
-    if (tid < 64) {
-      int qr = qq0 + tid;
-      L2s[tid] = qr < Lq ? lse[((size_t)b * H + h) * Lq + qr] : 0.f;
-      dls[tid] = qr < Lq ? delta[((size_t)b * H + h) * Lq + qr] : 0.f;
+    if (AttnPrefetch<D>::value) {
+      qst.store(Qs, tid); ost.store(Os, tid); qtst.store(Qt, tid); otst.store(Ot, tid);
+      if (tid < 64) { L2s[tid] = l2r; dls[tid] = dlr; }
+    } else {
+      load_rowmajor<D, 64>(Qs, qb, ldq, qq0, Lq, tid);
+      load_rowmajor<D, 64>(Os, dob, ldo, qq0, Lq, tid);
+      load_transposed64<D>(Qt, qb, ldq, qq0, Lq, tid);
+      load_transposed64<D>(Ot, dob, ldo, qq0, Lq, tid);
+      if (tid < 64) {
+        int qr = qq0 + tid;
+        L2s[tid] = qr < Lq ? lse[((size_t)b * H + h) * Lq + qr] : 0.f;
+        dls[tid] = qr < Lq ? delta[((size_t)b * H + h) * Lq + qr] : 0.f;
+      }
     }
     __syncthreads();
+    if (AttnPrefetch<D>::value && qq0 + 64 < Lq) stage_load(qq0 + 64);
     f32x16 s_[2], dp[2];
 #pragma unroll
     for (int t = 0; t < 2; t++) {
@@ -348,11 +455,19 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16_t* q, con
 #pragma unroll
       for (int r = 0; r < 16; r++) {
         int ql = 32 * t + 4 * hi + (r & 3) + 8 * (r >> 2);
-        bool ok = kv_ok && (qq0 + ql) < Lq;
-        float p = ok ? PCM_EXP2F(s_[t][r] * sc - L2s[ql]) : 0.f;
+        float p = PCM_EXP2F(fmaf(s_[t][r], sc, -L2s[ql]));
         dp[t][r] = p * (dp[t][r] - dls[ql]) * scale;  // dS[q][kv]
         s_[t][r] = p;
       }
+    if (!blk_full || qq0 + 64 > Lq) {
+#pragma unroll
+      for (int t = 0; t < 2; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          int ql = 32 * t + 4 * hi + (r & 3) + 8 * (r >> 2);
+          if (!kv_ok || (qq0 + ql) >= Lq) { s_[t][r] = 0.f; dp[t][r] = 0.f; }
+        }
+    }
     bf16x8 pf[4], df[4];
 #pragma unroll
     for (int ss = 0; ss < 4; ss++) { pf[ss] = pack_frag(s_[ss >> 1], ss & 1); df[ss] = pack_frag(dp[ss >> 1], ss & 1); }

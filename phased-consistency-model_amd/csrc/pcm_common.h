@@ -42,6 +42,7 @@ void pcm_set_error(const char* fmt, ...);
 int pcm_post_launch(const char* what);
 
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((unsigned)h) << 16); }
+#ifdef PCM_HOST_EMU
 __device__ __forceinline__ bf16_t f2bf(float f) {  // round-to-nearest-even, NaN kept quiet
   unsigned u = __float_as_uint(f);
   if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
@@ -51,6 +52,16 @@ __device__ __forceinline__ bf16_t f2bf(float f) {  // round-to-nearest-even, NaN
 __device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {
   return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
 }
+#else
+// gfx950 has a hardware RNE convert (v_cvt_pk_bf16_f32): one instruction per two values
+typedef __bf16 pcm_bf2_t __attribute__((ext_vector_type(2)));
+typedef float pcm_f2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {
+  pcm_f2_t v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, pcm_bf2_t));
+}
+__device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack_bf2(f, 0.f) & 0xffffu); }
+#endif
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + PCM_EXPF(-x)); }
 __device__ __forceinline__ float silu_grad_f(float x) {
   float s = 1.0f / (1.0f + PCM_EXPF(-x));

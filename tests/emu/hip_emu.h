@@ -178,6 +178,16 @@ template <typename T> static inline T __shfl_down(T v, int d, int = 64) {
 }
 template <typename T> static inline T __shfl(T v, int s, int = 64) { return pcm_emu::shfl_idx(v, s); }
 
+static inline int __all(int pred) {
+  pcm_emu::WaveScratch& w = pcm_emu::wave();
+  int b = w.gen & 1;
+  w.u64[b][pcm_emu::lane_id()] = pred ? 1 : 0;
+  int alive = w.alive;
+  pcm_emu::wave_sync();
+  int ok = 1;
+  for (int i = 0; i < 64 && i < alive; i++) ok &= (int)w.u64[b][i];
+  return ok;
+}
 static inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
 static inline double atomicAdd(double* p, double v) { double o = *p; *p = o + v; return o; }
 static inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
