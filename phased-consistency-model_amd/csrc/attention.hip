@@ -70,51 +70,85 @@ __device__ __forceinline__ void load_transposed64(char* dst, const bf16_t* src, 
 }
 // ---- register staging (issue the NEXT tile's global loads before computing on the current tile;
 // the LDS write happens after the next barrier, so L2/HBM latency hides under the MFMA phase) ----
+// Loads are UNCONDITIONAL from clamped addresses (a predicated load + zero select makes hipcc wait
+// vmcnt(0) right after issue: WAW on the destination); out-of-range rows are zeroed at store time.
 template <int D, int ROWS>
 struct RowStage {
   using C = AttnCfg<D>;
   static constexpr int N = (ROWS * C::DG + 255) / 256;
   uint4 r[N];
+  int row0_;
   __device__ __forceinline__ void load(const bf16_t* src, int ld, int row0, int nrows_valid, int tid) {
+    row0_ = row0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      int u = tid + 256 * i;
+      if (u >= ROWS * C::DG) u = ROWS * C::DG - 1;
+      int rr = u / C::DG, c = u - rr * C::DG;
+      int row = row0 + rr;
+      if (row >= nrows_valid) row = nrows_valid - 1;
+      r[i] = *(const uint4*)(src + (size_t)row * ld + 8 * c);
+    }
+  }
+  __device__ __forceinline__ void store(char* dst, int nrows_valid, int tid) const {
 #pragma unroll
     for (int i = 0; i < N; i++) {
       int u = tid + 256 * i;
       int rr = u / C::DG, c = u - rr * C::DG;
-      uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (u < ROWS * C::DG && row0 + rr < nrows_valid) v = *(const uint4*)(src + (size_t)(row0 + rr) * ld + 8 * c);
-      r[i] = v;
-    }
-  }
-  __device__ __forceinline__ void store(char* dst, int tid) const {
-#pragma unroll
-    for (int i = 0; i < N; i++) {
-      int u = tid + 256 * i;
-      int rr = u / C::DG, c = u - rr * C::DG;
-      if (u < ROWS * C::DG) *(uint4*)(dst + (rr * C::RKU + c) * 16) = r[i];
-    }
-  }
-};
-template <int D>
-struct TransStage {
-  using C = AttnCfg<D>;
-  uint4 rr[8];
-  __device__ __forceinline__ void load(const bf16_t* src, int ld, int row0, int nrows_valid, int tid) {
-    if (tid < 8 * C::DG) {
-      int sh = tid & 7, dg = tid >> 3, ss = sh >> 1, hi = sh & 1;
-#pragma unroll
-      for (int e = 0; e < 8; e++) {
-        int r = row0 + 16 * ss + 8 * (e >> 2) + 4 * hi + (e & 3);
-        rr[e] = r < nrows_valid ? *(const uint4*)(src + (size_t)r * ld + 8 * dg) : make_uint4(0u, 0u, 0u, 0u);
+      if (u < ROWS * C::DG) {
+        uint4 v = r[i];
+        if (row0_ + rr >= nrows_valid) v = make_uint4(0u, 0u, 0u, 0u);
+        *(uint4*)(dst + (rr * C::RKU + c) * 16) = v;
       }
     }
   }
-  __device__ __forceinline__ void store(char* dst, int tid) const {
-    if (tid < 8 * C::DG) {
-      int sh = tid & 7, dg = tid >> 3;
-      uint4 oo[8];
-      transpose8x8_bf16(rr, oo);
+};
+// transposing stage in 4x4 blocks: a unit = 4 consecutive rows x 4 columns (4 x 8-B loads, 8 VGPRs),
+// transposed in registers and written as 4 x ds_write_b64.  Row group rg = rows 4rg..4rg+3 maps to
+// slot chunk 2*ss+hi with ss = rg>>2, hi = rg&1 and element half (rg>>1)&1 (same slot order as above).
+template <int D>
+struct TransStage {
+  using C = AttnCfg<D>;
+  static constexpr int DQ = D / 4;
+  static constexpr int N = (16 * DQ + 255) / 256;
+  uint2 rr[N][4];
+  int row0_;
+  __device__ __forceinline__ void load(const bf16_t* src, int ld, int row0, int nrows_valid, int tid) {
+    row0_ = row0;
 #pragma unroll
-      for (int dd = 0; dd < 8; dd++) *(uint4*)(dst + tr_off(8 * dg + dd, sh)) = oo[dd];
+    for (int i = 0; i < N; i++) {
+      int u = tid + 256 * i;
+      if (u >= 16 * DQ) u = 16 * DQ - 1;
+      int dq = u % DQ, rg = u / DQ;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        int r = row0 + 4 * rg + j;
+        if (r >= nrows_valid) r = nrows_valid - 1;
+        rr[i][j] = *(const uint2*)(src + (size_t)r * ld + 4 * dq);
+      }
+    }
+  }
+  __device__ __forceinline__ void store(char* dst, int nrows_valid, int tid) const {
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      int u = tid + 256 * i;
+      if (u < 16 * DQ) {
+        int dq = u % DQ, rg = u / DQ;
+        int chunk = 2 * (rg >> 2) + (rg & 1), half = (rg >> 1) & 1;
+        unsigned a[4], b[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          bool ok = row0_ + 4 * rg + j < nrows_valid;
+          a[j] = ok ? rr[i][j].x : 0u; b[j] = ok ? rr[i][j].y : 0u;
+        }
+        uint2 o[4];
+        o[0] = make_uint2((a[0] & 0xffffu) | (a[1] << 16), (a[2] & 0xffffu) | (a[3] << 16));
+        o[1] = make_uint2((a[0] >> 16) | (a[1] & 0xffff0000u), (a[2] >> 16) | (a[3] & 0xffff0000u));
+        o[2] = make_uint2((b[0] & 0xffffu) | (b[1] << 16), (b[2] & 0xffffu) | (b[3] << 16));
+        o[3] = make_uint2((b[0] >> 16) | (b[1] & 0xffff0000u), (b[2] >> 16) | (b[3] & 0xffff0000u));
+#pragma unroll
+        for (int c = 0; c < 4; c++) *(uint2*)(dst + tr_off(4 * dq + c, chunk) + 8 * half) = o[c];
+      }
     }
   }
 };
@@ -164,7 +198,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* q, const bf
   for (int kv0 = 0; kv0 < Lk; kv0 += 64) {
     __syncthreads();
     if (AttnPrefetch<D>::value) {
-      kst.store(Ks, tid); vst.store(Vt, tid);
+      kst.store(Ks, Lk, tid); vst.store(Vt, Lk, tid);
     } else {
       load_rowmajor<D, 64>(Ks, kb, ldk, kv0, Lk, tid);
       load_transposed64<D>(Vt, vb, ldk, kv0, Lk, tid);
@@ -310,7 +344,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* q, const
   for (int kv0 = 0; kv0 < Lk; kv0 += 64) {
     __syncthreads();
     if (AttnPrefetch<D>::value) {
-      kst.store(Ks, tid); vst.store(Vs, tid); ktst.store(Kt, tid);
+      kst.store(Ks, Lk, tid); vst.store(Vs, Lk, tid); ktst.store(Kt, Lk, tid);
     } else {
       load_rowmajor<D, 64>(Ks, kb, ldk, kv0, Lk, tid);
       load_rowmajor<D, 64>(Vs, vb, ldk, kv0, Lk, tid);
@@ -412,17 +446,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16_t* q, con
   auto stage_load = [&](int q0_) {
     qst.load(qb, ldq, q0_, Lq, tid); ost.load(dob, ldo, q0_, Lq, tid);
     qtst.load(qb, ldq, q0_, Lq, tid); otst.load(dob, ldo, q0_, Lq, tid);
-    if (tid < 64) {
-      int qr = q0_ + tid;
-      l2r = qr < Lq ? lse[((size_t)b * H + h) * Lq + qr] : 0.f;
-      dlr = qr < Lq ? delta[((size_t)b * H + h) * Lq + qr] : 0.f;
+    {
+      int qr = q0_ + (tid & 63);
+      if (qr >= Lq) qr = Lq - 1;
+      l2r = lse[((size_t)b * H + h) * Lq + qr];
+      dlr = delta[((size_t)b * H + h) * Lq + qr];
     }
   };
   if (AttnPrefetch<D>::value) stage_load(0);
   for (int qq0 = 0; qq0 < Lq; qq0 += 64) {
     __syncthreads();
     if (AttnPrefetch<D>::value) {
-      qst.store(Qs, tid); ost.store(Os, tid); qtst.store(Qt, tid); otst.store(Ot, tid);
+      qst.store(Qs, Lq, tid); ost.store(Os, Lq, tid); qtst.store(Qt, Lq, tid); otst.store(Ot, Lq, tid);
       if (tid < 64) { L2s[tid] = l2r; dls[tid] = dlr; }
     } else {
       load_rowmajor<D, 64>(Qs, qb, ldq, qq0, Lq, tid);
