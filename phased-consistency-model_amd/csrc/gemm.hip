@@ -57,69 +57,103 @@ __global__ __launch_bounds__(256) void pcm_gemm_kernel(GemmDev g) {
   const int tile_n = bid % g.tiles_n, tile_m = bid / g.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
-  // ---- per-thread loader rows (fixed over the K loop) ----
-  constexpr int AI = BM / 32, WI = BN / 32;  // wave-instructions per wave for the A / W tile
+  // ---- loader state.  Each thread owns AI rows of the activation tile and WI rows of the weight tile
+  // (fixed over the K loop).  Source pointers are rebuilt once per (segment, conv tap) and then only
+  // advanced by 128 B per K-tile, so the steady-state issue is {select, add, LDS-DMA} per row.
+  constexpr int AI = BM / 32, WI = BN / 32;
   const int lrow = lane >> 3, lchunk = lane & 7;
-  int a_b[AI], a_y[AI], a_x[AI];  // conv: batch, out-y, out-x ; plain: a_b = m (or -1)
+  const char* zero = (const char*)&pcm_zero_page;
+  int a_m[AI], a_b[AI], a_y[AI], a_x[AI], a_c[AI];
+  const bool any_conv = g.seg[0].mode == PCM_SEG_CONV3X3 || (g.nseg > 1 && g.seg[1].mode == PCM_SEG_CONV3X3);
   const int HoWo = g.Ho * g.Wo;
 #pragma unroll
   for (int j = 0; j < AI; j++) {
     int row = 8 * (wave + 4 * j) + lrow;
+    a_c[j] = lchunk ^ ((row >> 1) & 7);
     int m = m0 + row;
-    if (m < g.M) {
-      if (g.seg[0].mode == PCM_SEG_CONV3X3 || (g.nseg > 1 && g.seg[1].mode == PCM_SEG_CONV3X3)) {
-        int b = m / HoWo, rem = m - b * HoWo;
-        a_b[j] = b; a_y[j] = rem / g.Wo; a_x[j] = rem - a_y[j] * g.Wo;
-      } else { a_b[j] = 0; a_y[j] = 0; a_x[j] = 0; }
-    } else { a_b[j] = -1; a_y[j] = 0; a_x[j] = 0; }
-  }
-
-  auto issue = [&](int seg_i, int k0, int stage) {
-    const SegDev& s = g.seg[seg_i];
-    char* base = smem + stage * STAGE;
-    // activation tile
-    int tap_y = 0, tap_x = 0, ci0 = 0;
-    if (s.mode == PCM_SEG_CONV3X3) {
-      int tap = k0 / s.C;
-      ci0 = k0 - tap * s.C;
-      tap_y = tap / 3; tap_x = tap - tap_y * 3;
+    a_m[j] = m < g.M ? m : -1;
+    a_b[j] = 0; a_y[j] = 0; a_x[j] = 0;
+    if (any_conv && m < g.M) {
+      int bb = m / HoWo, rem = m - bb * HoWo;
+      a_b[j] = bb; a_y[j] = rem / g.Wo; a_x[j] = rem - a_y[j] * g.Wo;
     }
+  }
+  int w_n[WI], w_c[WI];
+#pragma unroll
+  for (int j = 0; j < WI; j++) {
+    int row = 8 * (wave + 4 * j) + lrow;
+    w_c[j] = lchunk ^ ((row >> 1) & 7);
+    int n = n0 + row;
+    w_n[j] = n < g.N ? n : -1;
+  }
+  const char* a_cur[AI];
+  const char* w_cur[WI];
+  int a_inc[AI], w_inc[WI];   // bytes to advance per K-tile (0 for rows that read the zero page)
+  // iterator (wave-uniform)
+  int seg_i = 0, tap = 0, chunk = 0;
+  SegDev cs = g.seg[0];
+  int nchunk = ((cs.mode == PCM_SEG_CONV3X3 ? cs.C : cs.K) + 63) >> 6;
+  int ntap = cs.mode == PCM_SEG_CONV3X3 ? 9 : 1;
+
+  auto prepare_tap = [&]() {
+    const int ty = tap / 3, tx = tap - ty * 3;
 #pragma unroll
     for (int j = 0; j < AI; j++) {
-      int q = wave + 4 * j;
-      int row = 8 * q + lrow;
-      int c = lchunk ^ ((row >> 1) & 7);
-      const void* src = &pcm_zero_page;
-      int m = m0 + row;
-      if (a_b[j] >= 0) {
-        if (s.mode == PCM_SEG_PLAIN) {
-          int k = k0 + 8 * c;
-          if (k < s.K) src = s.a + (size_t)m * s.lda + k;
-        } else {
-          int vy = a_y[j] * s.stride + tap_y - 1, vx = a_x[j] * s.stride + tap_x - 1;
-          int sh = s.src_mode != PCM_SRC_DIRECT;
-          int Hv = s.Hs << sh, Wv = s.Ws << sh;
-          bool ok = vy >= 0 && vy < Hv && vx >= 0 && vx < Wv;
-          if (s.src_mode == PCM_SRC_ZEROINS2) ok = ok && !((vy | vx) & 1);
-          if (ok) {
-            int sy = vy >> sh, sx = vx >> sh;
-            src = s.a + ((size_t)(a_b[j] * s.Hs + sy) * s.Ws + sx) * s.C + ci0 + 8 * c;
-          }
-        }
+      const char* p = zero;
+      bool ok = a_m[j] >= 0;
+      if (cs.mode == PCM_SEG_PLAIN) {
+        p = (const char*)(cs.a + (size_t)(ok ? a_m[j] : 0) * cs.lda + 8 * a_c[j]);
+      } else {
+        int vy = a_y[j] * cs.stride + ty - 1, vx = a_x[j] * cs.stride + tx - 1;
+        int sh = cs.src_mode != PCM_SRC_DIRECT;
+        ok = ok && vy >= 0 && vy < (cs.Hs << sh) && vx >= 0 && vx < (cs.Ws << sh);
+        if (cs.src_mode == PCM_SRC_ZEROINS2) ok = ok && !((vy | vx) & 1);
+        int sy = ok ? (vy >> sh) : 0, sx = ok ? (vx >> sh) : 0;
+        p = (const char*)(cs.a + ((size_t)(a_b[j] * cs.Hs + sy) * cs.Ws + sx) * cs.C + 8 * a_c[j]);
       }
-      __builtin_amdgcn_global_load_lds(PCM_AS1(src), PCM_AS3(base + q * 1024), 16, 0, 0);
+      a_cur[j] = ok ? p : zero;
+      a_inc[j] = ok ? 128 : 0;
     }
-    // weight tile
+#pragma unroll
+    for (int j = 0; j < WI; j++) {
+      bool ok = w_n[j] >= 0;
+      const char* p = (const char*)(cs.w + (size_t)(ok ? w_n[j] : 0) * cs.K + (size_t)tap * cs.C + 8 * w_c[j]);
+      w_cur[j] = ok ? p : zero;
+      w_inc[j] = ok ? 128 : 0;
+    }
+  };
+  auto issue = [&](int stage) {
+    char* base = smem + stage * STAGE;
+    // K tail of a plain segment (K % 64 != 0): lanes beyond K read zeros
+    const bool tail = cs.mode == PCM_SEG_PLAIN && (chunk + 1) * 64 > cs.K;
+#pragma unroll
+    for (int j = 0; j < AI; j++) {
+      const char* src = a_cur[j];
+      if (tail && chunk * 64 + 8 * a_c[j] >= cs.K) src = zero;
+      __builtin_amdgcn_global_load_lds(PCM_AS1(src), PCM_AS3(base + (wave + 4 * j) * 1024), 16, 0, 0);
+      a_cur[j] += a_inc[j];
+    }
     char* wbase = base + BM * 128;
 #pragma unroll
     for (int j = 0; j < WI; j++) {
-      int q = wave + 4 * j;
-      int row = 8 * q + lrow;
-      int c = lchunk ^ ((row >> 1) & 7);
-      const void* src = &pcm_zero_page;
-      int n = n0 + row, k = k0 + 8 * c;
-      if (n < g.N && k < s.K) src = s.w + (size_t)n * s.K + k;
-      __builtin_amdgcn_global_load_lds(PCM_AS1(src), PCM_AS3(wbase + q * 1024), 16, 0, 0);
+      const char* src = w_cur[j];
+      if (tail && chunk * 64 + 8 * w_c[j] >= cs.K) src = zero;
+      __builtin_amdgcn_global_load_lds(PCM_AS1(src), PCM_AS3(wbase + (wave + 4 * j) * 1024), 16, 0, 0);
+      w_cur[j] += w_inc[j];
+    }
+    // advance the iterator
+    chunk++;
+    if (chunk == nchunk) {
+      chunk = 0; tap++;
+      if (tap == ntap) {
+        tap = 0; seg_i++;
+        if (seg_i < g.nseg) {
+          cs = g.seg[1];
+          nchunk = ((cs.mode == PCM_SEG_CONV3X3 ? cs.C : cs.K) + 63) >> 6;
+          ntap = cs.mode == PCM_SEG_CONV3X3 ? 9 : 1;
+        }
+      }
+      if (seg_i < g.nseg) prepare_tap();
     }
   };
 
@@ -132,32 +166,34 @@ __global__ __launch_bounds__(256) void pcm_gemm_kernel(GemmDev g) {
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
   const int total_kt = g.seg[0].ktiles + (g.nseg > 1 ? g.seg[1].ktiles : 0);
-  issue(0, 0, 0);
+  prepare_tap();
+  issue(0);
   const int frow = lane & 31, hi = lane >> 5;
   for (int kt = 0; kt < total_kt; kt++) {
     __syncthreads();  // tile kt landed (hipcc drains the LDS-DMA queue before the barrier); stage (kt+1)&1 free
-    if (kt + 1 < total_kt) {
-      int nk = kt + 1;
-      int si = (nk >= g.seg[0].ktiles) ? 1 : 0;
-      int k0 = (si ? nk - g.seg[0].ktiles : nk) * 64;
-      issue(si, k0, nk & 1);
-    }
+    if (kt + 1 < total_kt) issue((kt + 1) & 1);
     const char* At = smem + (kt & 1) * STAGE;
     const char* Wt = At + BM * 128;
+    // fragment reads are software-pipelined one 16-wide sub-step ahead of the MFMAs
+    bf16x8 wf[2][TN], af[2][TM];
+#pragma unroll
+    for (int i = 0; i < TN; i++) wf[0][i] = *(const bf16x8*)(Wt + lds_off(wn * 32 * TN + i * 32 + frow, hi));
+#pragma unroll
+    for (int j = 0; j < TM; j++) af[0][j] = *(const bf16x8*)(At + lds_off(wm * 32 * TM + j * 32 + frow, hi));
 #pragma unroll
     for (int ks = 0; ks < 4; ks++) {
-      bf16x8 wf[TN], af[TM];
+      const int cur = ks & 1, nxt = cur ^ 1;
+      if (ks < 3) {
 #pragma unroll
-      for (int i = 0; i < TN; i++)
-        wf[i] = *(const bf16x8*)(Wt + lds_off(wn * 32 * TN + i * 32 + frow, 2 * ks + hi));
+        for (int i = 0; i < TN; i++) wf[nxt][i] = *(const bf16x8*)(Wt + lds_off(wn * 32 * TN + i * 32 + frow, 2 * (ks + 1) + hi));
 #pragma unroll
-      for (int j = 0; j < TM; j++)
-        af[j] = *(const bf16x8*)(At + lds_off(wm * 32 * TM + j * 32 + frow, 2 * ks + hi));
+        for (int j = 0; j < TM; j++) af[nxt][j] = *(const bf16x8*)(At + lds_off(wm * 32 * TM + j * 32 + frow, 2 * (ks + 1) + hi));
+      }
 #pragma unroll
       for (int i = 0; i < TN; i++)
 #pragma unroll
         for (int j = 0; j < TM; j++)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[cur][i], af[cur][j], acc[i][j], 0, 0, 0);
     }
   }
 
