@@ -86,8 +86,9 @@ int pcm_gemm_bf16(const pcm_gemm_seg* segs, int nseg, const pcm_gemm_epi* epi, v
 /* LoRA weight gradients (autograd of peft lora.Linear / lora.Conv2d under loss.backward(),
  * train_pcm_lora_sd15.py:1296).  G[g][r] += alpha * sum_m Big[m][g] * Small[m][r], r in [0,64).
  * Big is plain [M][ldb] (G columns) or the im2col view of an NHWC tensor; Small is [M][64].
- * Accumulates with fp32 atomics into `out` at  out[g*g_stride + r*r_stride]  or, for
- * out_conv=1 (peft Conv2d A layout [r][C][3][3]):  g=(tap,ci) -> out[r*9*C + ci*9 + tap]. */
+ * Accumulates with fp32 atomics into `out` at  out[g*g_stride + r*r_stride]  (the kernel puts the
+ * contiguous one of the two output indices along the wave's lanes) or, for out_conv=1 (peft Conv2d A
+ * layout [r][C][3][3], uncoalesced):  g=(tap,ci) -> out[r*9*C + ci*9 + tap]. */
 typedef struct {
   const void* big; int ldb; int G;      /* plain: G columns (%8==0) */
   int mode; int Hs, Ws, C, stride, src_mode, Ho, Wo; /* conv view (G = 9*C) */
@@ -199,7 +200,9 @@ int pcm_ema_update(float* target, const float* source, float rate, long n, void*
 int pcm_pack_linear(const float* w, void* w_nk, void* w_kn, int N, int K, float scale, void* stream);
 /* conv weight [N][C][3][3] fp32 -> fwd operand bf16 [N][(kh,kw,c)] and/or dgrad operand
  * bf16 [C][(kh',kw',n)] with the taps flipped */
-int pcm_pack_conv3x3(const float* w, void* w_fwd, void* w_dgrad, int N, int C, float scale, void* stream);
+/* src_khwc = 0: w is [N][C][3][3] (torch / peft);  1: w is [N][3][3][C] (this library's internal layout of
+ * the LoRA conv-A factors, chosen so their weight-gradient atomics are contiguous) */
+int pcm_pack_conv3x3(const float* w, void* w_fwd, void* w_dgrad, int N, int C, float scale, int src_khwc, void* stream);
 int pcm_cast_f32_bf16(const float* x, void* y, long n, void* stream);
 int pcm_cast_bf16_f32(const void* x, float* y, long n, void* stream);
 

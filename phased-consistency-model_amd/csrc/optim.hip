@@ -101,20 +101,20 @@ extern "C" int pcm_pack_linear(const float* w, void* w_nk, void* w_kn, int N, in
 }
 
 // w [N][C][3][3] fp32 -> fwd [N][tap][c] ; dgrad [C][tap'][n] with tap' = 8 - tap
-__global__ __launch_bounds__(256) void pack_conv_kernel(const float* w, bf16_t* wf, bf16_t* wd, int N, int C, float scale) {
+__global__ __launch_bounds__(256) void pack_conv_kernel(const float* w, bf16_t* wf, bf16_t* wd, int N, int C, float scale, int khwc) {
   long total = (long)N * C * 9;
   OP_LOOP(i, total) {
     // iterate in fwd-output order so the fwd store is coalesced
     int c = (int)(i % C); long r = i / C;
     int tap = (int)(r % 9); int n = (int)(r / 9);
-    float v = w[((size_t)n * C + c) * 9 + tap] * scale;
+    float v = (khwc ? w[i] : w[((size_t)n * C + c) * 9 + tap]) * scale;
     bf16_t h = f2bf(v);
     if (wf) wf[i] = h;
     if (wd) wd[((size_t)c * 9 + (8 - tap)) * N + n] = h;
   }
 }
-extern "C" int pcm_pack_conv3x3(const float* w, void* w_fwd, void* w_dgrad, int N, int C, float scale, void* stream) {
+extern "C" int pcm_pack_conv3x3(const float* w, void* w_fwd, void* w_dgrad, int N, int C, float scale, int src_khwc, void* stream) {
   PCM_CHECK(w && (w_fwd || w_dgrad) && N > 0 && C > 0, PCM_EINVAL, "pcm_pack_conv3x3: null/empty");
-  PCM_LAUNCH(pack_conv_kernel, dim3(op_blocks((long)N * C * 9)), dim3(256), 0, stream, w, (bf16_t*)w_fwd, (bf16_t*)w_dgrad, N, C, scale);
+  PCM_LAUNCH(pack_conv_kernel, dim3(op_blocks((long)N * C * 9)), dim3(256), 0, stream, w, (bf16_t*)w_fwd, (bf16_t*)w_dgrad, N, C, scale, src_khwc);
   return pcm_post_launch("pcm_pack_conv3x3");
 }

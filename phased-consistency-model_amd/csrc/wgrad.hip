@@ -14,7 +14,7 @@
 struct WgDev {
   const bf16_t* big; int ldb, G, mode, Hs, Ws, C, stride, src_mode, Ho, Wo;
   const bf16_t* small_; int lds_, M;
-  float* out; long g_stride, r_stride; int out_conv; float alpha; int m_per_block;
+  float* out; long g_stride, r_stride; int out_conv; float alpha; int m_per_block; int swap;
 };
 
 __device__ __forceinline__ int wg_off(int row, int chunk) { return row * 256 + ((chunk ^ ((row ^ (row >> 3)) & 15)) << 4); }
@@ -39,41 +39,77 @@ __global__ __launch_bounds__(256) void pcm_wgrad_kernel(WgDev a) {
 #pragma unroll
   for (int r = 0; r < 16; r++) acc[r] = 0.f;
 
-  for (int mc = m_begin; mc < m_end; mc += 128) {
-    uint4 rr[8], oo[8];
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-      int m = mc + 8 * mg + j;
-      uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (m < m_end) {
-        if (which == 1) {
-          v = *(const uint4*)(a.small_ + (size_t)m * a.lds_ + 8 * cg);
-        } else if (a.mode == PCM_SEG_PLAIN) {
-          int g = g0 + 8 * cg;
-          if (g < a.G) v = *(const uint4*)(a.big + (size_t)m * a.ldb + g);
-        } else {
-          int b = m / HoWo, rem = m - b * HoWo, oy = rem / a.Wo, ox = rem - oy * a.Wo;
-          int vy = oy * a.stride + tap_y - 1, vx = ox * a.stride + tap_x - 1;
-          int sh = a.src_mode != PCM_SRC_DIRECT;
-          bool ok = vy >= 0 && vy < (a.Hs << sh) && vx >= 0 && vx < (a.Ws << sh);
-          if (a.src_mode == PCM_SRC_ZEROINS2) ok = ok && !((vy | vx) & 1);
-          if (ok) v = *(const uint4*)(a.big + ((size_t)(b * a.Hs + (vy >> sh)) * a.Ws + (vx >> sh)) * a.C + ci0 + 8 * cg);
-        }
-      }
-      rr[j] = v;
+  // Register-staged pipeline: the NEXT 128-row chunk is fetched (unconditional loads from clamped
+  // addresses; validity kept as a bit mask and applied at transpose time) while the MFMAs run on the
+  // current one.
+  uint4 rr[8];
+  unsigned okmask = 0;
+  const int gcol = g0 + 8 * cg;
+  auto fetch = [&](int mc) {
+    okmask = 0;
+    int m = mc + 8 * mg;
+    int b = 0, oy = 0, ox = 0;
+    if (which == 0 && a.mode == PCM_SEG_CONV3X3) {
+      int mm = m < a.M ? m : a.M - 1;
+      b = mm / HoWo; int rem = mm - b * HoWo; oy = rem / a.Wo; ox = rem - oy * a.Wo;
     }
+#pragma unroll
+    for (int j = 0; j < 8; j++, m++) {
+      bool ok = m < m_end;
+      const bf16_t* p;
+      if (which == 1) {
+        p = a.small_ + (size_t)(ok ? m : m_begin) * a.lds_ + 8 * cg;
+      } else if (a.mode == PCM_SEG_PLAIN) {
+        ok = ok && gcol < a.G;
+        p = a.big + (size_t)(ok ? m : m_begin) * a.ldb + (gcol < a.G ? gcol : 0);
+      } else {
+        int vy = oy * a.stride + tap_y - 1, vx = ox * a.stride + tap_x - 1;
+        int sh = a.src_mode != PCM_SRC_DIRECT;
+        ok = ok && vy >= 0 && vy < (a.Hs << sh) && vx >= 0 && vx < (a.Ws << sh);
+        if (a.src_mode == PCM_SRC_ZEROINS2) ok = ok && !((vy | vx) & 1);
+        int sy = ok ? (vy >> sh) : 0, sx = ok ? (vx >> sh) : 0;
+        p = a.big + ((size_t)((ok ? b : 0) * a.Hs + sy) * a.Ws + sx) * a.C + ci0 + 8 * cg;
+        // next output pixel (row-major over (b, oy, ox))
+        ox++;
+        if (ox == a.Wo) { ox = 0; oy++; if (oy == a.Ho) { oy = 0; b++; } }
+      }
+      rr[j] = *(const uint4*)p;
+      okmask |= (ok ? 1u : 0u) << j;
+    }
+  };
+  fetch(m_begin);
+  for (int mc = m_begin; mc < m_end; mc += 128) {
+    uint4 oo[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+      if (!((okmask >> j) & 1)) rr[j] = make_uint4(0u, 0u, 0u, 0u);
     transpose8x8_bf16(rr, oo);
     __syncthreads();  // previous chunk's fragment reads are done
     char* T = which ? St : Bt;
 #pragma unroll
     for (int e = 0; e < 8; e++) *(uint4*)(T + wg_off(8 * cg + e, mg)) = oo[e];
     __syncthreads();
+    if (mc + 128 < m_end) fetch(mc + 128);
 #pragma unroll
     for (int ks = 0; ks < 8; ks++) {
       bf16x8 af = *(const bf16x8*)(Bt + wg_off(32 * wg + frow, 2 * ks + hi));
       bf16x8 bf = *(const bf16x8*)(St + wg_off(32 * wr + frow, 2 * ks + hi));
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc, 0, 0, 0);
+      // lanes run along the MFMA B operand's rows: put the operand whose output index is contiguous
+      // in memory there, so the fp32 atomics of a wave touch 128-B runs
+      acc = a.swap ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf, af, acc, 0, 0, 0)
+                   : __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc, 0, 0, 0);
     }
+  }
+  if (a.swap) {  // D[i = r][j = g]: lane -> g, regs -> r
+    const int g = g0 + 32 * wg + frow;
+    if (g < a.G) {
+#pragma unroll
+      for (int q = 0; q < 16; q++) {
+        int r = 32 * wr + (q & 3) + 8 * (q >> 2) + 4 * hi;
+        atomicAdd(a.out + (size_t)g * a.g_stride + (size_t)r * a.r_stride, acc[q] * a.alpha);
+      }
+    }
+    return;
   }
   // D[i = g][j = r]: lane -> r = 32wr + (lane&31); regs -> g = 32wg + (q&3) + 8(q>>2) + 4hi
   const int r = 32 * wr + frow;
@@ -101,6 +137,7 @@ extern "C" int pcm_lora_wgrad_bf16(const pcm_wgrad_args* p, void* stream) {
   a.stride = p->stride; a.src_mode = p->src_mode; a.Ho = p->Ho > 0 ? p->Ho : 1; a.Wo = p->Wo > 0 ? p->Wo : 1;
   a.small_ = (const bf16_t*)p->small_; a.lds_ = p->lds_; a.M = p->M; a.out = p->out; a.g_stride = p->g_stride;
   a.r_stride = p->r_stride; a.out_conv = p->out_conv; a.alpha = p->alpha;
+  a.swap = (!p->out_conv && p->g_stride < p->r_stride) ? 1 : 0;
   if (p->mode == PCM_SEG_CONV3X3) {
     PCM_CHECK(p->C > 0 && (p->C % 64) == 0 && p->G == 9 * p->C && (p->M % (a.Ho * a.Wo)) == 0 && (p->stride == 1 || p->stride == 2),
               PCM_EINVAL, "pcm_lora_wgrad_bf16: conv view needs C%%64==0, G==9*C, M==B*Ho*Wo");
@@ -110,7 +147,9 @@ extern "C" int pcm_lora_wgrad_bf16(const pcm_wgrad_args* p, void* stream) {
   }
   int tiles_g = (p->G + 63) / 64;
   int chunks = (p->M + 127) / 128;
-  int msplit = (PCM_GRID_CAP(1024) + tiles_g - 1) / tiles_g;
+  // every block ends with 4096 fp32 atomics: split M only as far as needed to fill the chip (~2 blocks/CU)
+  int msplit = (PCM_GRID_CAP(512) + tiles_g - 1) / tiles_g;
+  if (msplit > (chunks + 3) / 4) msplit = (chunks + 3) / 4;
   if (msplit > chunks) msplit = chunks;
   if (msplit < 1) msplit = 1;
   a.m_per_block = ((chunks + msplit - 1) / msplit) * 128;

@@ -113,7 +113,7 @@ class LoraState:
             ain = math.prod(shp[1:])
             if len(shp) == 4 and shp[-1] == 3:
                 m.kind, m.C, m.K = "conv3", shp[1], 9 * shp[1]
-                a_shape, b_shape = (rank, shp[1], 3, 3), (shp[0], rank, 1, 1)
+                a_shape, b_shape = (rank, 3, 3, shp[1]), (shp[0], rank, 1, 1)   # INTERNAL layout [r][kh][kw][ci]
             elif len(shp) == 4:
                 m.kind, m.C, m.K = "lin", 0, shp[1]
                 a_shape, b_shape = (rank, shp[1], 1, 1), (shp[0], rank, 1, 1)
@@ -126,7 +126,10 @@ class LoraState:
             m.gB = self.grads[ob:ob + shp[0] * rank].view(b_shape)
             # peft init: kaiming_uniform_(A, a=sqrt(5)) == U(+-1/sqrt(fan_in)); B = 0
             bound = 1.0 / math.sqrt(ain)
-            m.A.copy_(((torch.rand(a_shape, generator=g) * 2 - 1) * bound).to(self.device))
+            if m.kind == "conv3":   # draw in peft shape [r, C, 3, 3] (same RNG stream as peft order), store permuted
+                m.A.copy_(((torch.rand((rank, shp[1], 3, 3), generator=g) * 2 - 1) * bound).permute(0, 2, 3, 1).to(self.device))
+            else:
+                m.A.copy_(((torch.rand(a_shape, generator=g) * 2 - 1) * bound).to(self.device))
             if b_std > 0:
                 m.B.copy_((torch.randn(b_shape, generator=g) * b_std).to(self.device))
             bf = dict(dtype=BF16, device=self.device)
@@ -142,7 +145,7 @@ class LoraState:
         """fp32 master -> bf16 operand copies (after init / load / every optimizer step)."""
         for m in self.modules.values():
             if m.kind == "conv3":
-                ops.pack_conv3x3(m.A, True, True, 1.0, m.A_fwd, m.A_bwd)
+                ops.pack_conv3x3(m.A, True, True, 1.0, m.A_fwd, m.A_bwd, khwc=True)
             else:
                 ops.pack_linear(m.A.view(self.rank, m.K), True, True, 1.0, m.A_fwd, m.A_bwd)
             ops.pack_linear(m.B.view(m.N, self.rank), True, True, self.scaling, m.Bs_fwd, m.Bs_bwd)
@@ -150,17 +153,30 @@ class LoraState:
     def zero_grad(self):
         self.grads.zero_()
 
+    # conv-A factors are stored [r, kh, kw, ci] internally (contiguous weight-gradient atomics; AdamW is
+    # elementwise so the permutation is invisible to the optimizer); peft layout is [r, ci, kh, kw]
+    @staticmethod
+    def to_peft(m, t):
+        return t.permute(0, 3, 1, 2).contiguous() if m.kind == "conv3" else t
+
+    def A_peft(self, m):
+        return self.to_peft(m, m.A)
+
+    def gA_peft(self, m):
+        return self.to_peft(m, m.gA)
+
     # ---- checkpoint formats (train_pcm_lora_sd15.py:52-72, :918-944, :1374-1382) ----
     def peft_state_dict(self):
         out = OrderedDict()
         for p, m in self.modules.items():
-            out[f"base_model.model.{p}.lora_A.weight"] = m.A.detach().clone()
+            out[f"base_model.model.{p}.lora_A.weight"] = self.A_peft(m).detach().clone()
             out[f"base_model.model.{p}.lora_B.weight"] = m.B.detach().clone()
         return out
 
     def load_peft_state_dict(self, sd):
         for p, m in self.modules.items():
-            m.A.copy_(sd[f"base_model.model.{p}.lora_A.weight"].to(self.device).view_as(m.A))
+            a = sd[f"base_model.model.{p}.lora_A.weight"].to(self.device)
+            m.A.copy_(a.permute(0, 2, 3, 1) if m.kind == "conv3" else a.view_as(m.A))
             m.B.copy_(sd[f"base_model.model.{p}.lora_B.weight"].to(self.device).view_as(m.B))
         self.repack()
 
@@ -215,7 +231,7 @@ def layer_bwd(W: UNetWeights, lora, path, dy, saved, need_dx=True, residual=None
         ops.lora_wgrad(dy, t, lm.gB, lora.scaling, M, G=L.N, g_stride=lm.r, r_stride=1)   # dB = s dy^T t
         if L.kind == "conv3":
             ops.lora_wgrad(x, u, lm.gA, 1.0, M, conv=dict(Hs=geo.Hs, Ws=geo.Ws, Ho=geo.Ho, Wo=geo.Wo, stride=geo.stride,
-                                                          src_mode=geo.src_mode), out_conv=True)
+                                                          src_mode=geo.src_mode), g_stride=1, r_stride=L.K)
         else:
             ops.lora_wgrad(x, u, lm.gA, 1.0, M, G=L.K, g_stride=1, r_stride=L.K)          # dA = u^T x
     if not need_dx:

@@ -223,11 +223,12 @@ def pack_linear(w, want_nk=True, want_kn=True, scale=1.0, out_nk=None, out_kn=No
     return nk, kn
 
 
-def pack_conv3x3(w, want_fwd=True, want_dgrad=True, scale=1.0, out_fwd=None, out_dgrad=None):
-    N, Cc = w.shape[0], w.shape[1]
+def pack_conv3x3(w, want_fwd=True, want_dgrad=True, scale=1.0, out_fwd=None, out_dgrad=None, khwc=False):
+    """w: [N, C, 3, 3] (khwc=False) or [N, 3, 3, C] (khwc=True)."""
+    N, Cc = w.shape[0], (w.shape[3] if khwc else w.shape[1])
     f = (out_fwd if out_fwd is not None else torch.empty(N, 9 * Cc, dtype=BF16, device=w.device)) if want_fwd else None
     d = (out_dgrad if out_dgrad is not None else torch.empty(Cc, 9 * N, dtype=BF16, device=w.device)) if want_dgrad else None
-    capi.lib().call("pcm_pack_conv3x3", ptr(w), ptr(f), ptr(d), N, Cc, scale, _stream())
+    capi.lib().call("pcm_pack_conv3x3", ptr(w), ptr(f), ptr(d), N, Cc, scale, 1 if khwc else 0, _stream())
     return f, d
 
 

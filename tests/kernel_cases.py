@@ -174,6 +174,8 @@ def case_pack(dev):
     rb = wc.cpu().bfloat16()
     assert torch.equal(f.cpu(), rb.permute(0, 2, 3, 1).reshape(16, -1))
     assert torch.equal(d.cpu(), rb.flip(2, 3).permute(1, 2, 3, 0).reshape(24, -1))
+    f2, d2 = ops.pack_conv3x3(wc.permute(0, 2, 3, 1).contiguous(), khwc=True)
+    assert torch.equal(f2.cpu(), f.cpu()) and torch.equal(d2.cpu(), d.cpu())
 
 
 def case_wgrad_plain(dev, M, N, K):
@@ -204,7 +206,10 @@ def case_wgrad_conv(dev, B, Hs, Ws, C, stride, src_mode=0):
     y.backward(u.float().cpu().view(B, Ho, Wo, 64).permute(0, 3, 1, 2))
     dA = torch.zeros(64, C, 3, 3, dtype=torch.float32, device=dev)
     ops.lora_wgrad(x, u, dA, 1.0, M, conv=dict(Hs=Hs, Ws=Ws, Ho=Ho, Wo=Wo, stride=stride, src_mode=src_mode), out_conv=True)
-    close(dA, A.grad, 2e-3, 2e-3 * M ** 0.5, "dA conv")
+    close(dA, A.grad, 2e-3, 2e-3 * M ** 0.5, "dA conv (peft layout)")
+    dA2 = torch.zeros(64, 3, 3, C, dtype=torch.float32, device=dev)   # internal [r][kh][kw][ci] layout, coalesced atomics
+    ops.lora_wgrad(x, u, dA2, 1.0, M, conv=dict(Hs=Hs, Ws=Ws, Ho=Ho, Wo=Wo, stride=stride, src_mode=src_mode), g_stride=1, r_stride=9 * C)
+    close(dA2.permute(0, 3, 1, 2), A.grad, 2e-3, 2e-3 * M ** 0.5, "dA conv (khwc layout)")
 
 
 def case_attention(dev, B, H, Lq, Lk, d, spike=False):

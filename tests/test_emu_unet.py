@@ -47,7 +47,7 @@ def test_unet_forward_backward_vs_oracle():
     W = UNetWeights(pc, sd, "cpu")
     lora = LoraState(pc, 64, 8.0, "cpu", seed=1, b_std=0.05)
     # oracle with the same LoRA values and bf16-rounded operands where the kernels round them
-    olora = {p: (m.A.clone().requires_grad_(True), m.B.clone().requires_grad_(True)) for p, m in lora.modules.items()}
+    olora = {p: (lora.A_peft(m).clone().requires_grad_(True), m.B.clone().requires_grad_(True)) for p, m in lora.modules.items()}
     ref_t = O.unet_forward(oc, sd, x, t, ctx)
     ref_s = O.unet_forward(oc, sd, x, t, ctx, olora, 8.0)
     teacher = UNet(W, None)
@@ -66,7 +66,7 @@ def test_unet_forward_backward_vs_oracle():
     num = den = 0.0
     worst = 0.0
     for p, m in lora.modules.items():
-        for got, ref in ((m.gA, olora[p][0].grad), (m.gB, olora[p][1].grad)):
+        for got, ref in ((lora.gA_peft(m), olora[p][0].grad), (m.gB, olora[p][1].grad)):
             ref = ref.view_as(got)
             num += float(((got - ref) ** 2).sum())
             den += float((ref ** 2).sum())

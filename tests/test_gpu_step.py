@@ -42,8 +42,14 @@ def test_full_step_vs_oracle(setup, b_std):
     inp = OS.draw_inputs(B, ocfg, seed=453645634)
     inp["index"] = torch.tensor([13, 37])
     lora = LoraState(UNetConfig.sd15(), 64, 8.0, "cuda", seed=1, b_std=b_std)
-    olora = {p: (m.A.detach().cpu().clone(), m.B.detach().cpu().clone()) for p, m in lora.modules.items()}
-    p_before = lora.params.detach().cpu().clone()
+    olora = {p: (lora.A_peft(m).detach().cpu().clone(), m.B.detach().cpu().clone()) for p, m in lora.modules.items()}
+    def flat_peft(which):   # this build's flat buffers in the oracle's (peft) order and layout
+        out = []
+        for m in lora.modules.values():
+            a, b = (m.A, m.B) if which == "p" else (m.gA, m.gB)
+            out += [lora.to_peft(m, a).detach().cpu().reshape(-1), b.detach().cpu().reshape(-1)]
+        return torch.cat(out)
+    p_before = flat_peft("p")
     t0 = time.time()
     ref = OS.distill_step(oc, sd, olora, inp, ocfg, {}, 1)
     print("oracle step %.1f s" % (time.time() - t0))
@@ -69,10 +75,10 @@ def test_full_step_vs_oracle(setup, b_std):
     report["grad_norm_rel"] = abs(gn - float(ref["grad_norm"])) / float(ref["grad_norm"])
     coef = min(1.0, 1.0 / (float(ref["grad_norm"]) + 1e-6))
     flat_ref = torch.cat([g.reshape(-1) for g in ref["grads"]]) / coef
-    report["grad_rel"] = rel(lora.grads, flat_ref)
+    report["grad_rel"] = rel(flat_peft("g"), flat_ref)
     flat_p = torch.cat([t.reshape(-1) for ab in olora.values() for t in ab])
-    report["param_rel"] = rel(lora.params, flat_p)
-    d_mine, d_ref = (lora.params.detach().cpu() - p_before).double(), (flat_p - p_before).double()
+    report["param_rel"] = rel(flat_peft("p"), flat_p)
+    d_mine, d_ref = (flat_peft("p") - p_before).double(), (flat_p - p_before).double()
     report["update_cos"] = float((d_mine * d_ref).sum() / (d_mine.norm() * d_ref.norm() + 1e-30))
     print("b_std", b_std, {k: "%.3e" % v for k, v in report.items()}, "loss", loss, rloss)
     import json, os
