@@ -152,6 +152,15 @@ def main():
         tms = sum(p[1].elapsed_time(p[2]) for p in prof)
         ach = flops / (tms * 1e-3) / 1e12
         log("roofline leg done")
+        if os.environ.get("PCM_GEMM_TABLE"):
+            agg = {}
+            for fl, e0, e1, key in prof:
+                a = agg.setdefault(str(key), [0, 0.0, 0.0])
+                a[0] += 1; a[1] += e0.elapsed_time(e1); a[2] += fl
+            rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
+            with open(os.environ["PCM_GEMM_TABLE"], "w") as f:
+                for k, (n, t, fl) in rows:
+                    f.write("%-44s calls %4d  total %8.3f ms  avg %7.1f us  %7.1f TF/s\n" % (k, n, t, 1e3 * t / n, fl / t / 1e9))
         roofline = {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None, "kernel": "pcm_gemm_kernel (all launches of one step)",
                     "launches": len(prof), "algorithmic_tflop_per_step": round(flops / 1e12, 2), "kernel_ms_per_step": round(tms, 2),

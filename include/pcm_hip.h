@@ -22,6 +22,7 @@
  */
 #ifndef PCM_HIP_H
 #define PCM_HIP_H
+#include <stddef.h>
 #include <stdint.h>
 #ifdef __cplusplus
 extern "C" {
@@ -79,8 +80,12 @@ typedef struct {
   int out_dtype;          /* PCM_BF16 | PCM_F32 */
   int act;                /* PCM_ACT_* */
   float alpha;            /* scales the accumulated sum before bias (1.0 normally) */
+  void* workspace;        /* optional fp32 scratch for split-K (under-filled grids with long K); NULL = never split */
+  size_t workspace_bytes; /* >= pcm_gemm_workspace_bytes(...) */
 } pcm_gemm_epi;
 
+/* bytes of `workspace` the call would use (0: no split-K for this shape) */
+size_t pcm_gemm_workspace_bytes(const pcm_gemm_seg* segs, int nseg, const pcm_gemm_epi* epi);
 int pcm_gemm_bf16(const pcm_gemm_seg* segs, int nseg, const pcm_gemm_epi* epi, void* stream);
 
 /* LoRA weight gradients (autograd of peft lora.Linear / lora.Conv2d under loss.backward(),
@@ -203,6 +208,16 @@ int pcm_pack_linear(const float* w, void* w_nk, void* w_kn, int N, int K, float 
 /* src_khwc = 0: w is [N][C][3][3] (torch / peft);  1: w is [N][3][3][C] (this library's internal layout of
  * the LoRA conv-A factors, chosen so their weight-gradient atomics are contiguous) */
 int pcm_pack_conv3x3(const float* w, void* w_fwd, void* w_dgrad, int N, int C, float scale, int src_khwc, void* stream);
+/* all LoRA operand copies in one launch: desc = strided fp32 matrix src[R][Cc] in the flat parameter buffer
+ * -> bf16 copy and/or transpose at element offsets of the flat operand buffer (offset < 0: skip).
+ * descs / blk_start (prefix of 32x32-tile counts, ndesc+1 entries) live in DEVICE memory. */
+typedef struct {
+  long src_off, dst_copy_off, dst_t_off;
+  int R, Cc, lds, ldc, ldt;
+  float scale;
+} pcm_pack_desc;
+int pcm_pack_segmented(const float* src_base, void* dst_base, const pcm_pack_desc* descs, const int* blk_start,
+                       int ndesc, int total_blocks, void* stream);
 int pcm_cast_f32_bf16(const float* x, void* y, long n, void* stream);
 int pcm_cast_bf16_f32(const void* x, float* y, long n, void* stream);
 

@@ -37,6 +37,8 @@ struct GemmDev {
   int ldo, out_f32, act;
   float alpha;
   int tiles_m, tiles_n;
+  int splitk, kt_per_split;   // split-K: blockIdx.y = K slice; raw fp32 partial tiles go to slab ws[slice][M][N]
+  float* ws;
 };
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
@@ -165,8 +167,23 @@ __global__ __launch_bounds__(256) void pcm_gemm_kernel(GemmDev g) {
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
-  const int total_kt = g.seg[0].ktiles + (g.nseg > 1 ? g.seg[1].ktiles : 0);
+  int total_kt = g.seg[0].ktiles + (g.nseg > 1 ? g.seg[1].ktiles : 0);
+  if (g.splitk > 1) {  // this block's K slice: position the iterator at its first K-tile
+    int kt0 = blockIdx.y * g.kt_per_split;
+    int kt1 = kt0 + g.kt_per_split; if (kt1 > total_kt) kt1 = total_kt;
+    total_kt = kt1 - kt0;
+    if (kt0 >= g.seg[0].ktiles) {
+      kt0 -= g.seg[0].ktiles; seg_i = 1; cs = g.seg[1];
+      nchunk = ((cs.mode == PCM_SEG_CONV3X3 ? cs.C : cs.K) + 63) >> 6;
+      ntap = cs.mode == PCM_SEG_CONV3X3 ? 9 : 1;
+    }
+    tap = kt0 / nchunk; chunk = kt0 - tap * nchunk;
+  }
   prepare_tap();
+#pragma unroll
+  for (int j = 0; j < AI; j++) a_cur[j] += (size_t)a_inc[j] * chunk;
+#pragma unroll
+  for (int j = 0; j < WI; j++) w_cur[j] += (size_t)w_inc[j] * chunk;
   issue(0);
   const int frow = lane & 31, hi = lane >> 5;
   for (int kt = 0; kt < total_kt; kt++) {
@@ -198,6 +215,22 @@ __global__ __launch_bounds__(256) void pcm_gemm_kernel(GemmDev g) {
   }
 
   // ---- epilogue: lane owns column m, 4 consecutive channels n per accumulator quad ----
+  if (g.splitk > 1) {  // raw partial sums to this slice's slab; pcm_gemm_finalize_kernel applies the epilogue
+    float* slab = g.ws + (size_t)blockIdx.y * g.M * g.N;
+#pragma unroll
+    for (int j = 0; j < TM; j++) {
+      int m = m0 + wm * 32 * TM + j * 32 + frow;
+      if (m >= g.M) continue;
+#pragma unroll
+      for (int i = 0; i < TN; i++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          int n = n0 + wn * 32 * TN + i * 32 + 8 * q + 4 * hi;
+          if (n < g.N) *(float4*)(slab + (size_t)m * g.N + n) = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+        }
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < TM; j++) {
     int m = m0 + wm * 32 * TM + j * 32 + frow;
@@ -240,6 +273,77 @@ __global__ __launch_bounds__(256) void pcm_gemm_kernel(GemmDev g) {
   }
 }
 
+// split-K finalize: out = act(alpha * sum_slices ws + bias + rowvec) + residual
+__global__ __launch_bounds__(256) void pcm_gemm_finalize_kernel(GemmDev g) {
+  const long nq = (long)g.M * (g.N / 4);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nq; i += (long)gridDim.x * blockDim.x) {
+    int m = (int)(i / (g.N / 4)), n = (int)(i % (g.N / 4)) * 4;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < g.splitk; s++) {
+      float4 p = *(const float4*)(g.ws + ((size_t)s * g.M + m) * g.N + n);
+      v[0] += p.x; v[1] += p.y; v[2] += p.z; v[3] += p.w;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; e++) v[e] *= g.alpha;
+    if (g.bias) {
+      float4 b4 = *(const float4*)(g.bias + n);
+      v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+    }
+    if (g.rowvec) {
+      uint2 t = *(const uint2*)(g.rowvec + (size_t)(m / g.rpb) * g.N + n);
+      v[0] += bf2f((bf16_t)(t.x & 0xffff)); v[1] += bf2f((bf16_t)(t.x >> 16));
+      v[2] += bf2f((bf16_t)(t.y & 0xffff)); v[3] += bf2f((bf16_t)(t.y >> 16));
+    }
+    if (g.act == PCM_ACT_SILU) {
+#pragma unroll
+      for (int e = 0; e < 4; e++) v[e] = silu_f(v[e]);
+    }
+    if (g.res) {
+      uint2 t = *(const uint2*)(g.res + (size_t)m * g.ldr + n);
+      v[0] += bf2f((bf16_t)(t.x & 0xffff)); v[1] += bf2f((bf16_t)(t.x >> 16));
+      v[2] += bf2f((bf16_t)(t.y & 0xffff)); v[3] += bf2f((bf16_t)(t.y >> 16));
+    }
+    if (g.out_f32) *(float4*)((float*)g.out + (size_t)m * g.ldo + n) = make_float4(v[0], v[1], v[2], v[3]);
+    else *(uint2*)((bf16_t*)g.out + (size_t)m * g.ldo + n) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+  }
+}
+
+// tile / split-K plan shared by pcm_gemm_bf16 and pcm_gemm_workspace_bytes
+struct GemmPlan { int TM, TN, tiles_m, tiles_n, splitk, kt_per_split; size_t ws_bytes; };
+static GemmPlan gemm_plan(int M, int N, int total_kt, bool allow_split) {
+  GemmPlan p;
+  p.splitk = 1; p.kt_per_split = total_kt; p.ws_bytes = 0;
+  p.TM = 2; p.TN = (N % 128) != 0 ? 1 : 2;
+  long tiles = (long)((M + 127) / 128) * ((N + 64 * p.TN - 1) / (64 * p.TN));
+  if (tiles < 256 && allow_split && total_kt >= 16) {
+    // under-filled grid with a long K loop: slice K across blockIdx.y (slab reduction, no atomics)
+    int s = (int)((384 + tiles - 1) / tiles);
+    if (s > total_kt / 4) s = total_kt / 4;
+    if (s > 16) s = 16;
+    if (s >= 2) {
+      p.kt_per_split = (total_kt + s - 1) / s;
+      p.splitk = (total_kt + p.kt_per_split - 1) / p.kt_per_split;
+      p.ws_bytes = (size_t)p.splitk * M * N * sizeof(float);
+    }
+  }
+  if (p.splitk == 1) {  // otherwise shrink the tile until the grid fills the chip
+    if (tiles < 256) { p.TN = 1; tiles = (long)((M + 127) / 128) * ((N + 63) / 64); }
+    if (tiles < 256) p.TM = 1;
+  }
+  p.tiles_m = (M + 64 * p.TM - 1) / (64 * p.TM);
+  p.tiles_n = (N + 64 * p.TN - 1) / (64 * p.TN);
+  return p;
+}
+static int gemm_total_kt(const pcm_gemm_seg* segs, int nseg) {
+  int t = 0;
+  for (int i = 0; i < nseg; i++) t += (segs[i].K + 63) / 64;
+  return t;
+}
+extern "C" size_t pcm_gemm_workspace_bytes(const pcm_gemm_seg* segs, int nseg, const pcm_gemm_epi* e) {
+  if (!segs || !e || nseg < 1 || nseg > 2 || e->M <= 0 || e->N <= 0) return 0;
+  return gemm_plan(e->M, e->N, gemm_total_kt(segs, nseg), true).ws_bytes;
+}
+
 extern "C" int pcm_gemm_bf16(const pcm_gemm_seg* segs, int nseg, const pcm_gemm_epi* e, void* stream) {
   PCM_CHECK(segs && e && nseg >= 1 && nseg <= 2, PCM_EINVAL, "pcm_gemm_bf16: nseg must be 1 or 2");
   PCM_CHECK(e->M > 0 && e->N > 0 && (e->N % 4) == 0, PCM_EINVAL, "pcm_gemm_bf16: M>0, N>0, N%%4==0 required (M=%d N=%d)", e->M, e->N);
@@ -273,18 +377,23 @@ extern "C" int pcm_gemm_bf16(const pcm_gemm_seg* segs, int nseg, const pcm_gemm_
   g.bias = e->bias; g.rowvec = (const bf16_t*)e->rowvec; g.rpb = e->rows_per_batch > 0 ? e->rows_per_batch : 1;
   g.res = (const bf16_t*)e->residual; g.ldr = e->ldr; g.out = e->out; g.ldo = e->ldo;
   g.out_f32 = e->out_dtype == PCM_F32; g.act = e->act; g.alpha = e->alpha;
-  // tile choice: 128x128 when N is a multiple of 128 and the grid still fills the chip, else 128x64 / 64x64
-  int TMv = 2, TNv = 2;
-  if ((e->N % 128) != 0) TNv = 1;
-  long blocks = (long)((e->M + 127) / 128) * ((e->N + 64 * TNv - 1) / (64 * TNv));
-  if (blocks < 256) { TNv = 1; blocks = (long)((e->M + 127) / 128) * ((e->N + 63) / 64); }
-  if (blocks < 256) TMv = 1;
-  g.tiles_m = (e->M + 64 * TMv - 1) / (64 * TMv);
-  g.tiles_n = (e->N + 64 * TNv - 1) / (64 * TNv);
-  dim3 grid(g.tiles_m * g.tiles_n), block(256);
+  GemmPlan pl = gemm_plan(e->M, e->N, gemm_total_kt(segs, nseg), e->workspace != nullptr);
+  if (pl.splitk > 1) {
+    PCM_CHECK(e->workspace_bytes >= pl.ws_bytes && PCM_ALIGNED16(e->workspace), PCM_EINVAL,
+              "pcm_gemm_bf16: workspace too small (%zu < %zu) or unaligned", (size_t)e->workspace_bytes, pl.ws_bytes);
+    g.ws = (float*)e->workspace;
+  }
+  const int TMv = pl.TM, TNv = pl.TN;
+  g.tiles_m = pl.tiles_m; g.tiles_n = pl.tiles_n; g.splitk = pl.splitk; g.kt_per_split = pl.kt_per_split;
+  dim3 grid(g.tiles_m * g.tiles_n, pl.splitk), block(256);
   size_t smem = 2 * (64 * TMv + 64 * TNv) * 128;
   if (TMv == 2 && TNv == 2) PCM_LAUNCH((pcm_gemm_kernel<2, 2>), grid, block, smem, stream, g);
   else if (TMv == 2 && TNv == 1) PCM_LAUNCH((pcm_gemm_kernel<2, 1>), grid, block, smem, stream, g);
   else PCM_LAUNCH((pcm_gemm_kernel<1, 1>), grid, block, smem, stream, g);
+  if (pl.splitk > 1) {
+    long nq = (long)e->M * (e->N / 4);
+    long fb = (nq + 255) / 256; if (fb > PCM_GRID_CAP(2048)) fb = PCM_GRID_CAP(2048);
+    PCM_LAUNCH(pcm_gemm_finalize_kernel, dim3((int)fb), dim3(256), 0, stream, g);
+  }
   return pcm_post_launch("pcm_gemm_bf16");
 }

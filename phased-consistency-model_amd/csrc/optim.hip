@@ -118,3 +118,43 @@ extern "C" int pcm_pack_conv3x3(const float* w, void* w_fwd, void* w_dgrad, int 
   PCM_LAUNCH(pack_conv_kernel, dim3(op_blocks((long)N * C * 9)), dim3(256), 0, stream, w, (bf16_t*)w_fwd, (bf16_t*)w_dgrad, N, C, scale, src_khwc);
   return pcm_post_launch("pcm_pack_conv3x3");
 }
+
+// ---- segmented pack: ALL LoRA operand copies refreshed by ONE launch after the optimizer step ----
+// desc d describes a strided 2-D fp32 matrix src[R][Cc] (row stride lds) inside the flat parameter
+// buffer; it is written as bf16 (x scale) to dst_copy[R][Cc] (row stride ldc) and/or transposed to
+// dst_t[Cc][R] (row stride ldt) inside the flat operand buffer.  Blocks map to (desc, 32x32 tile)
+// through the prefix table blk_start.
+__global__ __launch_bounds__(256) void pack_segmented_kernel(const float* src_base, bf16_t* dst_base, const pcm_pack_desc* descs,
+                                                             const int* blk_start, int ndesc) {
+  __shared__ float tile[32][33];
+  const int bid = blockIdx.x;
+  int lo = 0, hi = ndesc - 1;
+  while (lo < hi) {  // last desc with blk_start[d] <= bid
+    int mid = (lo + hi + 1) >> 1;
+    if (blk_start[mid] <= bid) lo = mid; else hi = mid - 1;
+  }
+  const pcm_pack_desc d = descs[lo];
+  const int t = bid - blk_start[lo];
+  const int tiles_c = (d.Cc + 31) >> 5;
+  const int r0 = (t / tiles_c) * 32, c0 = (t % tiles_c) * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const float* src = src_base + d.src_off;
+  for (int r = ty; r < 32; r += 8) {
+    int rr = r0 + r, cc = c0 + tx;
+    float v = (rr < d.R && cc < d.Cc) ? src[(size_t)rr * d.lds + cc] * d.scale : 0.f;
+    tile[r][tx] = v;
+    if (d.dst_copy_off >= 0 && rr < d.R && cc < d.Cc) dst_base[d.dst_copy_off + (size_t)rr * d.ldc + cc] = f2bf(v);
+  }
+  __syncthreads();
+  if (d.dst_t_off >= 0)
+    for (int r = ty; r < 32; r += 8) {
+      int cc = c0 + r, rr = r0 + tx;
+      if (cc < d.Cc && rr < d.R) dst_base[d.dst_t_off + (size_t)cc * d.ldt + rr] = f2bf(tile[tx][r]);
+    }
+}
+extern "C" int pcm_pack_segmented(const float* src_base, void* dst_base, const pcm_pack_desc* descs, const int* blk_start,
+                                  int ndesc, int total_blocks, void* stream) {
+  PCM_CHECK(src_base && dst_base && descs && blk_start && ndesc > 0 && total_blocks > 0, PCM_EINVAL, "pcm_pack_segmented: null/empty");
+  PCM_LAUNCH(pack_segmented_kernel, dim3(total_blocks), dim3(256), 0, stream, src_base, (bf16_t*)dst_base, descs, blk_start, ndesc);
+  return pcm_post_launch("pcm_pack_segmented");
+}

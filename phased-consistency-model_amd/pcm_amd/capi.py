@@ -30,7 +30,7 @@ class GemmEpi(C.Structure):
     _fields_ = [("M", C.c_int), ("N", C.c_int), ("Ho", C.c_int), ("Wo", C.c_int), ("bias", vp),
                 ("rowvec", vp), ("rows_per_batch", C.c_int), ("residual", vp), ("ldr", C.c_int),
                 ("out", vp), ("ldo", C.c_int), ("out_dtype", C.c_int), ("act", C.c_int),
-                ("alpha", C.c_float)]
+                ("alpha", C.c_float), ("workspace", vp), ("workspace_bytes", C.c_size_t)]
 
 
 class WgradArgs(C.Structure):
@@ -39,6 +39,11 @@ class WgradArgs(C.Structure):
                 ("Ho", C.c_int), ("Wo", C.c_int), ("small_", vp), ("lds_", C.c_int), ("M", C.c_int),
                 ("out", vp), ("g_stride", C.c_long), ("r_stride", C.c_long), ("out_conv", C.c_int),
                 ("alpha", C.c_float)]
+
+
+class PackDesc(C.Structure):
+    _fields_ = [("src_off", C.c_long), ("dst_copy_off", C.c_long), ("dst_t_off", C.c_long), ("R", C.c_int), ("Cc", C.c_int),
+                ("lds", C.c_int), ("ldc", C.c_int), ("ldt", C.c_int), ("scale", C.c_float)]
 
 
 i32, i64, f32 = C.c_int, C.c_long, C.c_float
@@ -75,6 +80,7 @@ _PROTOS = {
     "pcm_ema_update": [vp, vp, f32, i64, vp],
     "pcm_pack_linear": [vp, vp, vp, i32, i32, f32, vp],
     "pcm_pack_conv3x3": [vp, vp, vp, i32, i32, f32, i32, vp],
+    "pcm_pack_segmented": [vp, vp, vp, vp, i32, i32, vp],
     "pcm_cast_f32_bf16": [vp, vp, i64, vp],
     "pcm_cast_bf16_f32": [vp, vp, i64, vp],
 }
@@ -103,6 +109,8 @@ class Lib:
         self.dll = C.CDLL(path)
         self.dll.pcm_last_error.restype = C.c_char_p
         self.dll.pcm_abi_version.restype = C.c_int
+        self.dll.pcm_gemm_workspace_bytes.restype = C.c_size_t
+        self.dll.pcm_gemm_workspace_bytes.argtypes = [C.POINTER(GemmSeg), C.c_int, C.POINTER(GemmEpi)]
         self.fn = {}
         for name, argt in _PROTOS.items():
             f = getattr(self.dll, name, None)

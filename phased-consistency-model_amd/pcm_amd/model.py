@@ -132,23 +132,52 @@ class LoraState:
                 m.A.copy_(((torch.rand(a_shape, generator=g) * 2 - 1) * bound).to(self.device))
             if b_std > 0:
                 m.B.copy_((torch.randn(b_shape, generator=g) * b_std).to(self.device))
-            bf = dict(dtype=BF16, device=self.device)
-            if m.kind == "conv3":
-                m.A_fwd, m.A_bwd = torch.empty(rank, m.K, **bf), torch.empty(m.C, 9 * rank, **bf)
-            else:
-                m.A_fwd, m.A_bwd = torch.empty(rank, m.K, **bf), torch.empty(m.K, rank, **bf)
-            m.Bs_fwd, m.Bs_bwd = torch.empty(m.N, rank, **bf), torch.empty(rank, m.N, **bf)
             self.modules[path] = m
+        # bf16 MFMA operand copies of every factor in ONE flat buffer, refreshed by ONE segmented-pack launch
+        import ctypes as C
+        import numpy as np
+        ototal, descs = 0, []
+        r = rank
+
+        def alloc(n):
+            nonlocal ototal
+            off = ototal
+            ototal += (n + 7) // 8 * 8      # keep every operand 16-byte aligned
+            return off
+        layout2 = []
+        for path, shp, oa, ob in layout:
+            m = self.modules[path]
+            o_af, o_ab, o_bf, o_bb = alloc(r * m.K), alloc(m.K * r), alloc(m.N * r), alloc(r * m.N)
+            layout2.append((m, o_af, o_ab, o_bf, o_bb))
+            if m.kind == "conv3":
+                # A internal [r][tap][c] -> fwd operand [r][9C] (copy); dgrad operand [c][(8-tap)][r]: 9 strided transposes
+                descs.append((oa, o_af, -1, r, m.K, m.K, m.K, 0, 1.0))
+                for tap in range(9):
+                    descs.append((oa + tap * m.C, -1, o_ab + (8 - tap) * r, r, m.C, m.K, 0, 9 * r, 1.0))
+            else:
+                descs.append((oa, o_af, o_ab, r, m.K, m.K, m.K, r, 1.0))               # A [r][K] -> copy + A^T [K][r]
+            descs.append((ob, o_bf, o_bb, m.N, r, r, r, m.N, self.scaling))             # s*B [N][r] -> copy + transpose [r][N]
+        self.operands = torch.zeros(ototal, dtype=BF16, device=self.device)
+        for m, o_af, o_ab, o_bf, o_bb in layout2:
+            if m.kind == "conv3":
+                m.A_fwd, m.A_bwd = self.operands[o_af:o_af + r * m.K].view(r, m.K), self.operands[o_ab:o_ab + m.K * r].view(m.C, 9 * r)
+            else:
+                m.A_fwd, m.A_bwd = self.operands[o_af:o_af + r * m.K].view(r, m.K), self.operands[o_ab:o_ab + m.K * r].view(m.K, r)
+            m.Bs_fwd, m.Bs_bwd = self.operands[o_bf:o_bf + m.N * r].view(m.N, r), self.operands[o_bb:o_bb + r * m.N].view(r, m.N)
+        arr = (capi.PackDesc * len(descs))()
+        starts = np.zeros(len(descs) + 1, dtype=np.int32)
+        for i, d in enumerate(descs):
+            (arr[i].src_off, arr[i].dst_copy_off, arr[i].dst_t_off, arr[i].R, arr[i].Cc, arr[i].lds, arr[i].ldc, arr[i].ldt, arr[i].scale) = d
+            starts[i + 1] = starts[i] + ((d[3] + 31) // 32) * ((d[4] + 31) // 32)
+        self._ndesc, self._pack_blocks = len(descs), int(starts[-1])
+        self._descs = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
+        self._blk_start = torch.from_numpy(starts).to(self.device)
         self.repack()
 
     def repack(self):
-        """fp32 master -> bf16 operand copies (after init / load / every optimizer step)."""
-        for m in self.modules.values():
-            if m.kind == "conv3":
-                ops.pack_conv3x3(m.A, True, True, 1.0, m.A_fwd, m.A_bwd, khwc=True)
-            else:
-                ops.pack_linear(m.A.view(self.rank, m.K), True, True, 1.0, m.A_fwd, m.A_bwd)
-            ops.pack_linear(m.B.view(m.N, self.rank), True, True, self.scaling, m.Bs_fwd, m.Bs_bwd)
+        """fp32 master -> bf16 operand copies (after init / load / every optimizer step): one launch."""
+        capi.lib().call("pcm_pack_segmented", ops.ptr(self.params), ops.ptr(self.operands), ops.ptr(self._descs),
+                        ops.ptr(self._blk_start), self._ndesc, self._pack_blocks, capi.Lib.stream())
 
     def zero_grad(self):
         self.grads.zero_()

@@ -58,12 +58,18 @@ def gemm(segs, M, N, out, bias=None, rowvec=None, rows_per_batch=0, residual=Non
     e.ldo = ldo if ldo is not None else out.shape[-1]
     e.out_dtype = capi.PCM_F32 if out.dtype == torch.float32 else capi.PCM_BF16
     e.act, e.alpha = act, alpha
+    e.workspace, e.workspace_bytes = None, 0
+    wsb = capi.lib().dll.pcm_gemm_workspace_bytes(arr, len(segs), C.byref(e))
+    if wsb:   # split-K slabs (caller-owned scratch)
+        ws = torch.empty(wsb // 4, dtype=torch.float32, device=out.device)
+        e.workspace, e.workspace_bytes = ptr(ws), wsb
     if GEMM_PROFILE is not None:  # bench.py roofline leg: HIP events around every contraction launch
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
         capi.lib().call("pcm_gemm_bf16", arr, len(segs), C.byref(e), capi.Lib.stream())
         ev1.record()
-        GEMM_PROFILE.append((2.0 * M * N * sum(s.w.shape[-1] for s in segs), ev0, ev1))
+        GEMM_PROFILE.append((2.0 * M * N * sum(s.w.shape[-1] for s in segs), ev0, ev1,
+                             (M, N, tuple(s.w.shape[-1] for s in segs), "conv" if segs[0].conv else "lin")))
         return out
     capi.lib().call("pcm_gemm_bf16", arr, len(segs), C.byref(e), capi.Lib.stream())
     return out

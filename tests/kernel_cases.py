@@ -235,3 +235,19 @@ def case_attention(dev, B, H, Lq, Lk, d, spike=False):
     close(dq, qr.grad, 3e-2, 3e-2 * sc, "dq")
     close(dk, kr.grad, 3e-2, 3e-2 * max(1.0, float(kr.grad.abs().max())), "dk")
     close(dv, vr.grad, 3e-2, 3e-2 * max(1.0, float(vr.grad.abs().max())), "dv")
+
+
+def case_lora_repack(dev):
+    """The one-launch segmented pack must equal the per-tensor packers."""
+    from pcm_amd.model import LoraState
+    from pcm_amd.unet_spec import UNetConfig
+    cfg = UNetConfig(block_out_channels=(64, 128), layers_per_block=1, cross_attention_dim=64, heads=2)
+    lora = LoraState(cfg, 64, 8.0, dev, seed=3, b_std=0.05)
+    for m in lora.modules.values():
+        if m.kind == "conv3":
+            f, d = ops.pack_conv3x3(m.A, khwc=True)
+        else:
+            f, d = ops.pack_linear(m.A.view(64, m.K))
+        bf, bd = ops.pack_linear(m.B.view(m.N, 64), scale=lora.scaling)
+        assert torch.equal(m.A_fwd.cpu(), f.cpu()) and torch.equal(m.A_bwd.cpu(), d.cpu().view_as(m.A_bwd)), m.path
+        assert torch.equal(m.Bs_fwd.cpu(), bf.cpu()) and torch.equal(m.Bs_bwd.cpu(), bd.cpu()), m.path

@@ -68,3 +68,23 @@ def test_gemm_rejects_bad_args():
     x, w = rnd(8, 12), rnd(8, 12)
     with pytest.raises(capi.PcmError):
         ops.gemm([ops.Seg(x, w)], 8, 8, torch.empty(8, 8, dtype=torch.bfloat16))  # K%8 != 0
+
+
+def test_split_k_plain_and_conv():
+    """Under-filled grids with a long K loop take the split-K path (slab reduction + finalize)."""
+    M, N, K = 130, 192, 1032
+    x, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05)
+    t, bl = rnd(M, 64, seed=3), rnd(N, 64, seed=4, scale=0.1)
+    bias = torch.randn(N, generator=torch.Generator().manual_seed(5))
+    res = rnd(M, N, seed=6)
+    out = torch.empty(M, N, dtype=torch.float32)
+    ops.gemm([ops.Seg(x, w), ops.Seg(t, bl)], M, N, out, bias=bias, residual=res, act=capi.ACT_SILU)
+    ref = F.silu(x.float() @ w.float().T + t.float() @ bl.float().T + bias) + res.float()
+    assert torch.allclose(out, ref, rtol=1e-3, atol=2e-3), (out - ref).abs().max()
+    B, Hs, Ws, Ci, Co = 1, 5, 6, 128, 64
+    xc = rnd(B, Hs, Ws, Ci, seed=7)
+    wc = rnd(Co, Ci, 3, 3, seed=8, scale=0.05)
+    refc = F.conv2d(xc.float().permute(0, 3, 1, 2), wc.float(), None, padding=1).permute(0, 2, 3, 1).reshape(-1, Co)
+    outc = torch.empty(B * Hs * Ws, Co, dtype=torch.bfloat16)
+    ops.gemm([ops.Seg(xc, wc.permute(0, 2, 3, 1).reshape(Co, -1).contiguous(), conv=dict(Hs=Hs, Ws=Ws))], B * Hs * Ws, Co, outc, Ho=Hs, Wo=Ws)
+    assert torch.allclose(outc.float(), refc, rtol=2e-2, atol=2e-2)

@@ -61,3 +61,7 @@ def test_wgrad_conv(stride, src_mode):
 @pytest.mark.parametrize("B,H,Lq,Lk,d,spike", [(1, 2, 100, 77, 40, False), (2, 1, 70, 130, 80, True), (1, 1, 40, 64, 160, False), (1, 1, 300, 330, 40, True)])
 def test_attention(B, H, Lq, Lk, d, spike):
     K.case_attention("cpu", B, H, Lq, Lk, d, spike)
+
+
+def test_lora_repack():
+    K.case_lora_repack("cpu")

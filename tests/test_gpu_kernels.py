@@ -67,3 +67,7 @@ def test_wgrad_conv(stride, src_mode, C):
                                                (1, 2, 4096, 4096, 40, True), (1, 8, 4096, 77, 40, False)])
 def test_attention(B, H, Lq, Lk, d, spike):
     K.case_attention("cuda", B, H, Lq, Lk, d, spike)
+
+
+def test_lora_repack():
+    K.case_lora_repack("cuda")

@@ -33,3 +33,10 @@ for r in res:
     print("%-16s M=%6d N=%5d K=%5d  %8.3f ms  %8.1f TFLOP/s" % r)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 json.dump(res, open(os.path.join(ROOT, "gpurun_out", "gemm_probe.json"), "w"))
+print("---- under-filled / split-K shapes")
+for (name, Hs, Ci, Co) in [("c1280@8 b16", 8, 1280, 1280), ("c2560-1280@8", 8, 2560, 1280), ("cA 1280->64 @8", 8, 1280, 64), ("cA 1280->64 @16", 16, 1280, 64), ("cA 2560->64 @16", 16, 2560, 64)]:
+    x = torch.randn(B, Hs, Hs, Ci, device="cuda").bfloat16(); w = (torch.randn(Co, 9*Ci, device="cuda")*0.02).bfloat16()
+    M = B*Hs*Hs
+    out = torch.empty(M, Co, device="cuda", dtype=torch.bfloat16)
+    ms = bench(lambda: ops.gemm([ops.Seg(x, w, conv=dict(Hs=Hs, Ws=Hs))], M, Co, out, Ho=Hs, Wo=Hs))
+    print("%-16s M=%6d N=%5d K=%5d  %8.3f ms  %8.1f TFLOP/s" % (name, M, Co, 9*Ci, ms, 2.0*M*Co*9*Ci/ms/1e9))
