@@ -43,13 +43,16 @@ struct GemmDev {
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
-template <int TM, int TN>
+// WGM x (4/WGM) waves; each wave owns a (32*TM) x (32*TN) sub-tile: block tile BM = 32*TM*WGM, BN = 32*TN*(4/WGM)
+template <int WGM, int TM, int TN>
 __global__ __launch_bounds__(256) void pcm_gemm_kernel(GemmDev g) {
-  constexpr int BM = 64 * TM, BN = 64 * TN;
+  constexpr int WGN = 4 / WGM;
+  constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN;
   constexpr int STAGE = (BM + BN) * 128;
   PCM_DYN_SMEM(smem);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave & 1, wn = wave >> 1;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: LDS-DMA bases stay in SGPRs
+  const int wm = wave % WGM, wn = wave / WGM;
   // XCD-aware bijective remap: consecutive logical tiles stay on one XCD (private L2)
   int nwg = g.tiles_m * g.tiles_n, bid = blockIdx.x;
   {
@@ -128,20 +131,31 @@ __global__ __launch_bounds__(256) void pcm_gemm_kernel(GemmDev g) {
     char* base = smem + stage * STAGE;
     // K tail of a plain segment (K % 64 != 0): lanes beyond K read zeros
     const bool tail = cs.mode == PCM_SEG_PLAIN && (chunk + 1) * 64 > cs.K;
-#pragma unroll
-    for (int j = 0; j < AI; j++) {
-      const char* src = a_cur[j];
-      if (tail && chunk * 64 + 8 * a_c[j] >= cs.K) src = zero;
-      __builtin_amdgcn_global_load_lds(PCM_AS1(src), PCM_AS3(base + (wave + 4 * j) * 1024), 16, 0, 0);
-      a_cur[j] += a_inc[j];
-    }
     char* wbase = base + BM * 128;
+    if (!tail) {   // steady state: one LDS-DMA + one 64-bit add per row
 #pragma unroll
-    for (int j = 0; j < WI; j++) {
-      const char* src = w_cur[j];
-      if (tail && chunk * 64 + 8 * w_c[j] >= cs.K) src = zero;
-      __builtin_amdgcn_global_load_lds(PCM_AS1(src), PCM_AS3(wbase + (wave + 4 * j) * 1024), 16, 0, 0);
-      w_cur[j] += w_inc[j];
+      for (int j = 0; j < AI; j++) {
+        __builtin_amdgcn_global_load_lds(PCM_AS1(a_cur[j]), PCM_AS3(base + (wave + 4 * j) * 1024), 16, 0, 0);
+        a_cur[j] += a_inc[j];
+      }
+#pragma unroll
+      for (int j = 0; j < WI; j++) {
+        __builtin_amdgcn_global_load_lds(PCM_AS1(w_cur[j]), PCM_AS3(wbase + (wave + 4 * j) * 1024), 16, 0, 0);
+        w_cur[j] += w_inc[j];
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < AI; j++) {
+        const char* src = chunk * 64 + 8 * a_c[j] >= cs.K ? zero : a_cur[j];
+        __builtin_amdgcn_global_load_lds(PCM_AS1(src), PCM_AS3(base + (wave + 4 * j) * 1024), 16, 0, 0);
+        a_cur[j] += a_inc[j];
+      }
+#pragma unroll
+      for (int j = 0; j < WI; j++) {
+        const char* src = chunk * 64 + 8 * w_c[j] >= cs.K ? zero : w_cur[j];
+        __builtin_amdgcn_global_load_lds(PCM_AS1(src), PCM_AS3(wbase + (wave + 4 * j) * 1024), 16, 0, 0);
+        w_cur[j] += w_inc[j];
+      }
     }
     // advance the iterator
     chunk++;
@@ -309,12 +323,15 @@ __global__ __launch_bounds__(256) void pcm_gemm_finalize_kernel(GemmDev g) {
 }
 
 // tile / split-K plan shared by pcm_gemm_bf16 and pcm_gemm_workspace_bytes
-struct GemmPlan { int TM, TN, tiles_m, tiles_n, splitk, kt_per_split; size_t ws_bytes; };
+struct GemmPlan { int BM, BN, tiles_m, tiles_n, splitk, kt_per_split; size_t ws_bytes; };
 static GemmPlan gemm_plan(int M, int N, int total_kt, bool allow_split) {
   GemmPlan p;
   p.splitk = 1; p.kt_per_split = total_kt; p.ws_bytes = 0;
-  p.TM = 2; p.TN = (N % 128) != 0 ? 1 : 2;
-  long tiles = (long)((M + 127) / 128) * ((N + 64 * p.TN - 1) / (64 * p.TN));
+  // 128x128 when N is a multiple of 128; otherwise the tall 256x64 tile (same 64x64 per-wave tile, no N waste at N=320/64)
+  if ((N % 128) == 0) { p.BM = 128; p.BN = 128; } else { p.BM = 256; p.BN = 64; }
+  auto ntiles = [&](int bm, int bn) { return (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
+  long tiles = ntiles(p.BM, p.BN);
+  if (tiles < 256 && p.BM == 256) { p.BM = 128; tiles = ntiles(128, 64); }
   if (tiles < 256 && allow_split && total_kt >= 16) {
     // under-filled grid with a long K loop: slice K across blockIdx.y (slab reduction, no atomics)
     int s = (int)((384 + tiles - 1) / tiles);
@@ -327,11 +344,11 @@ static GemmPlan gemm_plan(int M, int N, int total_kt, bool allow_split) {
     }
   }
   if (p.splitk == 1) {  // otherwise shrink the tile until the grid fills the chip
-    if (tiles < 256) { p.TN = 1; tiles = (long)((M + 127) / 128) * ((N + 63) / 64); }
-    if (tiles < 256) p.TM = 1;
+    if (tiles < 256 && p.BN == 128) { p.BN = 64; tiles = ntiles(128, 64); }
+    if (tiles < 256) { p.BM = 64; p.BN = 64; }
   }
-  p.tiles_m = (M + 64 * p.TM - 1) / (64 * p.TM);
-  p.tiles_n = (N + 64 * p.TN - 1) / (64 * p.TN);
+  p.tiles_m = (M + p.BM - 1) / p.BM;
+  p.tiles_n = (N + p.BN - 1) / p.BN;
   return p;
 }
 static int gemm_total_kt(const pcm_gemm_seg* segs, int nseg) {
@@ -383,13 +400,23 @@ extern "C" int pcm_gemm_bf16(const pcm_gemm_seg* segs, int nseg, const pcm_gemm_
               "pcm_gemm_bf16: workspace too small (%zu < %zu) or unaligned", (size_t)e->workspace_bytes, pl.ws_bytes);
     g.ws = (float*)e->workspace;
   }
-  const int TMv = pl.TM, TNv = pl.TN;
   g.tiles_m = pl.tiles_m; g.tiles_n = pl.tiles_n; g.splitk = pl.splitk; g.kt_per_split = pl.kt_per_split;
   dim3 grid(g.tiles_m * g.tiles_n, pl.splitk), block(256);
-  size_t smem = 2 * (64 * TMv + 64 * TNv) * 128;
-  if (TMv == 2 && TNv == 2) PCM_LAUNCH((pcm_gemm_kernel<2, 2>), grid, block, smem, stream, g);
-  else if (TMv == 2 && TNv == 1) PCM_LAUNCH((pcm_gemm_kernel<2, 1>), grid, block, smem, stream, g);
-  else PCM_LAUNCH((pcm_gemm_kernel<1, 1>), grid, block, smem, stream, g);
+  size_t smem = 2 * (size_t)(pl.BM + pl.BN) * 128;
+  if (pl.BM == 128 && pl.BN == 128) PCM_LAUNCH((pcm_gemm_kernel<2, 2, 2>), grid, block, smem, stream, g);
+  else if (pl.BM == 256 && pl.BN == 64) {
+#ifndef PCM_HOST_EMU
+    static bool lds_ok = false;   // 80 KB of dynamic LDS: above the 64 KB default cap
+    if (!lds_ok) {
+      hipError_t er = hipFuncSetAttribute((const void*)pcm_gemm_kernel<4, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      PCM_CHECK(er == hipSuccess, PCM_EHIP, "pcm_gemm_bf16: hipFuncSetAttribute(LDS %zu) failed: %s", smem, hipGetErrorString(er));
+      lds_ok = true;
+    }
+#endif
+    PCM_LAUNCH((pcm_gemm_kernel<4, 2, 2>), grid, block, smem, stream, g);
+  }
+  else if (pl.BM == 128 && pl.BN == 64) PCM_LAUNCH((pcm_gemm_kernel<2, 2, 1>), grid, block, smem, stream, g);
+  else PCM_LAUNCH((pcm_gemm_kernel<2, 1, 1>), grid, block, smem, stream, g);
   if (pl.splitk > 1) {
     long nq = (long)e->M * (e->N / 4);
     long fb = (nq + 255) / 256; if (fb > PCM_GRID_CAP(2048)) fb = PCM_GRID_CAP(2048);
