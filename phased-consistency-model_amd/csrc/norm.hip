@@ -184,7 +184,8 @@ static int gn_stats_launch(const char* what, GNArgs a, int B, void* stream) {
   PCM_CHECK(a.CVL * 8 <= 2560, PCM_EUNSUPPORTED, "%s: channel slice too large", what);
   int k = 256 / a.CVL; if (k < 1) k = 1;
   int threads = a.CVL * k;
-  int chunks = (PCM_GRID_CAP(2048) + B * split - 1) / (B * split);
+  // each block ends with LDS + fp64 global atomics: ~2 blocks per CU, long pixel runs per thread
+  int chunks = (PCM_GRID_CAP(512) + B * split - 1) / (B * split);
   int maxchunks = (a.HW + k - 1) / k; if (chunks > maxchunks) chunks = maxchunks; if (chunks < 1) chunks = 1;
   a.ppb = (a.HW + chunks - 1) / chunks;
   chunks = (a.HW + a.ppb - 1) / a.ppb;
