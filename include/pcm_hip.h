@@ -196,7 +196,9 @@ int pcm_consistency_loss(const float* model_pred, const float* target, const flo
 int pcm_sumsq_f32(const float* g, double* out /*1, zeroed by the call*/, long n, void* stream);
 int pcm_adamw_clip_step(float* p, const float* g, float* m, float* v, const double* gradsq,
                         float max_norm, float lr, float beta1, float beta2, float eps, float wd,
-                        int step, float grad_scale, long n, void* stream);
+                        int step, float grad_scale, long n,
+                        const int64_t* step_dev /*NULL: use `step`*/, const float* lr_dev /*NULL: use `lr`*/,
+                        void* stream);
 /* update_ema (train_pcm_lora_sd15.py:344-355; defined by the reference, never called) */
 int pcm_ema_update(float* target, const float* source, float rate, long n, void* stream);
 

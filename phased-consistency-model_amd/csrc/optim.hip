@@ -23,10 +23,22 @@ extern "C" int pcm_sumsq_f32(const float* g, double* out, long n, void* stream) 
   return pcm_post_launch("pcm_sumsq_f32");
 }
 
-// torch.optim.AdamW single-tensor semantics; g' = g * grad_scale * min(1, max_norm/(||g*grad_scale|| + 1e-6))
+// torch.optim.AdamW single-tensor semantics; g' = g * grad_scale * min(1, max_norm/(||g*grad_scale|| + 1e-6)).
+// step / lr may come from DEVICE memory (step_dev, lr_dev) so that a captured hipGraph of the training step
+// stays valid while the step count and the learning-rate schedule advance.
 __global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, float* m, float* v, const double* gradsq,
                                                     float max_norm, float lr, float b1, float b2, float eps, float wd,
-                                                    float bc1, float bc2_sqrt, float gscale, long n) {
+                                                    int step, float gscale, long n, const int64_t* step_dev, const float* lr_dev) {
+  __shared__ float hyp[3];
+  if (threadIdx.x == 0) {
+    float st = step_dev ? (float)(*step_dev) : (float)step;
+    hyp[0] = 1.0f - powf(b1, st);
+    hyp[1] = sqrtf(1.0f - powf(b2, st));
+    hyp[2] = lr_dev ? *lr_dev : lr;
+  }
+  __syncthreads();
+  const float bc1 = hyp[0], bc2_sqrt = hyp[1];
+  lr = hyp[2];
   float coef = gscale;
   if (gradsq && max_norm > 0.f) {
     float norm = (float)sqrt(*gradsq) * gscale;
@@ -46,11 +58,9 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, fl
 }
 extern "C" int pcm_adamw_clip_step(float* p, const float* g, float* m, float* v, const double* gradsq, float max_norm, float lr,
                                    float beta1, float beta2, float eps, float wd, int step, float grad_scale, long n,
-                                   void* stream) {
-  PCM_CHECK(p && g && m && v && n > 0 && step >= 1, PCM_EINVAL, "pcm_adamw_clip_step: null/empty or step<1");
-  float bc1 = 1.0f - powf(beta1, (float)step);
-  float bc2s = sqrtf(1.0f - powf(beta2, (float)step));
-  PCM_LAUNCH(adamw_kernel, dim3(op_blocks(n)), dim3(256), 0, stream, p, g, m, v, gradsq, max_norm, lr, beta1, beta2, eps, wd, bc1, bc2s, grad_scale, n);
+                                   const int64_t* step_dev, const float* lr_dev, void* stream) {
+  PCM_CHECK(p && g && m && v && n > 0 && (step >= 1 || step_dev), PCM_EINVAL, "pcm_adamw_clip_step: null/empty or step<1");
+  PCM_LAUNCH(adamw_kernel, dim3(op_blocks(n)), dim3(256), 0, stream, p, g, m, v, gradsq, max_norm, lr, beta1, beta2, eps, wd, step, grad_scale, n, step_dev, lr_dev);
   return pcm_post_launch("pcm_adamw_clip_step");
 }
 

@@ -76,7 +76,7 @@ _PROTOS = {
     "pcm_cfg_ddim_step": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
     "pcm_consistency_loss": [vp, vp, vp, i32, f32, vp, vp, f32, i32, i32, vp],
     "pcm_sumsq_f32": [vp, vp, i64, vp],
-    "pcm_adamw_clip_step": [vp, vp, vp, vp, vp, f32, f32, f32, f32, f32, f32, i32, f32, i64, vp],
+    "pcm_adamw_clip_step": [vp, vp, vp, vp, vp, f32, f32, f32, f32, f32, f32, i32, f32, i64, vp, vp, vp],
     "pcm_ema_update": [vp, vp, f32, i64, vp],
     "pcm_pack_linear": [vp, vp, vp, i32, i32, f32, vp],
     "pcm_pack_conv3x3": [vp, vp, vp, i32, i32, f32, i32, vp],

@@ -282,9 +282,9 @@ def sumsq(g, out=None):
     return out
 
 
-def adamw_clip_step(p, g, m, v, gradsq, max_norm, lr, b1, b2, eps, wd, step, grad_scale=1.0):
+def adamw_clip_step(p, g, m, v, gradsq, max_norm, lr, b1, b2, eps, wd, step, grad_scale=1.0, step_dev=None, lr_dev=None):
     capi.lib().call("pcm_adamw_clip_step", ptr(p), ptr(g), ptr(m), ptr(v), ptr(gradsq), max_norm, lr, b1, b2, eps, wd,
-                    step, grad_scale, p.numel(), _stream())
+                    step, grad_scale, p.numel(), ptr(step_dev), ptr(lr_dev), _stream())
 
 
 def ema_update(target, source, rate):

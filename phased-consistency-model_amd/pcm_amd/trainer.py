@@ -65,6 +65,11 @@ class Distiller:
         self.teacher = UNet(weights, None)
         self.world_size, self.pg = world_size, process_group
         self.step_count = 0
+        # optimizer step count and learning rate also live on the device, so a captured hipGraph of the
+        # step stays valid while both advance
+        self.step_dev = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self.lr_dev = torch.full((1,), float(cfg.learning_rate), dtype=torch.float32, device=self.device)
+        self._graph = None
         self.ema = None
         if cfg.ema_rate is not None:
             self.ema = lora.params.clone()
@@ -75,10 +80,8 @@ class Distiller:
         t = torch.clamp(start - self.tables.topk, min=0)
         return start, t
 
-    def step(self, latents, prompt_embeds, uncond_prompt_embeds, noise, index, w, lr=None, update=True):
-        """One distillation step on this rank's batch.  All inputs are device tensors:
-        latents/noise [B,4,H,W] fp32, prompt embeds [B,77,768], index [B] int64, w [B] fp32.
-        Returns a dict of device tensors (no host sync)."""
+    def forward_backward(self, latents, prompt_embeds, uncond_prompt_embeds, noise, index, w, backward=True):
+        """Everything of the step before the gradient exchange: returns a dict of device tensors."""
         cfg, T = self.cfg, self.tables
         B = latents.shape[0]
         start_t, t_n = self.timesteps_for(index)
@@ -104,14 +107,75 @@ class Distiller:
         out = dict(loss=loss, noisy_model_input=noisy, noise_pred=eps_s, model_pred=model_pred, cond_teacher_output=eps_c,
                    uncond_teacher_output=eps_u, x_prev=x_prev64, target_noise_pred=eps_t, target=target,
                    start_timesteps=start_t, timesteps=t_n, end_timesteps=end_t)
-        if not update:
+        if not backward:
             out["tape"], out["d_eps"] = tape, d_eps
             return out
         self.lora.zero_grad()
         self.student.backward(d_eps, tape)                                                       # :1296
-        self.optimizer_step(lr)
+        return out
+
+    def step(self, latents, prompt_embeds, uncond_prompt_embeds, noise, index, w, lr=None, update=True):
+        """One distillation step on this rank's batch (eager launches).  All inputs are device tensors:
+        latents/noise [B,4,H,W] fp32, prompt embeds [B,77,768], index [B] int64, w [B] fp32.
+        Returns a dict of device tensors (no host sync)."""
+        out = self.forward_backward(latents, prompt_embeds, uncond_prompt_embeds, noise, index, w, backward=update)
+        if not update:
+            return out
+        if lr is not None:
+            self.lr_dev.fill_(float(lr))
+        self.optimizer_step()
         out["grad_sumsq"] = self.lora.gradsq
         return out
+
+    # ---- hipGraph replay of the step: ~5400 launches become two graph launches --------------------
+    def capture(self, B, H=64, W=64, ctx_len=77, ctx_dim=768):
+        """Capture forward+backward and the optimizer as two hipGraphs around the (eager) gradient
+        all-reduce.  The eager warm-up pass runs on scratch state: LoRA / Adam state is restored."""
+        dev = self.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        self._static = dict(latents=torch.zeros(B, 4, H, W, **f32), prompt_embeds=torch.zeros(B, ctx_len, ctx_dim, **f32),
+                            uncond_prompt_embeds=torch.zeros(B, ctx_len, ctx_dim, **f32), noise=torch.zeros(B, 4, H, W, **f32),
+                            index=torch.zeros(B, dtype=torch.int64, device=dev), w=torch.ones(B, **f32))
+        lo = self.lora
+        saved = [t.clone() for t in (lo.params, lo.exp_avg, lo.exp_avg_sq, self.step_dev, self.lr_dev)]
+        if self.ema is not None:
+            saved.append(self.ema.clone())
+        count = self.step_count
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                      # warm-up: lazy init, allocator pools
+            self.forward_backward(**self._static)
+            self._optimizer_apply()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self._g_fb, self._g_opt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._g_fb):
+            self._static_out = self.forward_backward(**self._static)
+        with torch.cuda.graph(self._g_opt, pool=self._g_fb.pool()):
+            self._optimizer_apply()
+        for dst, src in zip((lo.params, lo.exp_avg, lo.exp_avg_sq, self.step_dev, self.lr_dev), saved):
+            dst.copy_(src)
+        if self.ema is not None:
+            self.ema.copy_(saved[-1])
+        self.step_count = count
+        lo.repack()
+        self._static_out["grad_sumsq"] = lo.gradsq
+        self._graph = True
+
+    def step_graphed(self, latents, prompt_embeds, uncond_prompt_embeds, noise, index, w, lr=None):
+        """Same as step() through the captured graphs.  Returned tensors are the graph's static outputs
+        (overwritten by the next call)."""
+        st = self._static
+        st["latents"].copy_(latents); st["prompt_embeds"].copy_(prompt_embeds)
+        st["uncond_prompt_embeds"].copy_(uncond_prompt_embeds); st["noise"].copy_(noise)
+        st["index"].copy_(index); st["w"].copy_(w)
+        if lr is not None:
+            self.lr_dev.fill_(float(lr))
+        self._g_fb.replay()
+        self.all_reduce_grads()
+        self.step_count += 1
+        self._g_opt.replay()
+        return self._static_out
 
     def all_reduce_grads(self):
         """DDP: one all-reduce (sum) of the flat 67 M-element LoRA gradient buffer over RCCL/xGMI;
@@ -119,15 +183,21 @@ class Distiller:
         if self.world_size > 1:
             torch.distributed.all_reduce(self.lora.grads, op=torch.distributed.ReduceOp.SUM, group=self.pg)
 
-    def optimizer_step(self, lr=None):
-        cfg, lo = self.cfg, self.lora
+    def optimizer_step(self):
         self.all_reduce_grads()
         self.step_count += 1
+        self._optimizer_apply()
+
+    def _optimizer_apply(self):
+        """clip + AdamW + EMA + operand repack on the (already reduced) flat gradient buffer; the step
+        count and lr are read from device memory (capturable)."""
+        cfg, lo = self.cfg, self.lora
         gscale = 1.0 / self.world_size
+        self.step_dev += 1
         ops.sumsq(lo.grads, lo.gradsq)                                                           # :1298 clip_grad_norm_
         ops.adamw_clip_step(lo.params, lo.grads, lo.exp_avg, lo.exp_avg_sq, lo.gradsq, cfg.max_grad_norm,
-                            cfg.learning_rate if lr is None else lr, cfg.adam_beta1, cfg.adam_beta2, cfg.adam_epsilon,
-                            cfg.adam_weight_decay, self.step_count, gscale)                     # :1299
+                            cfg.learning_rate, cfg.adam_beta1, cfg.adam_beta2, cfg.adam_epsilon,
+                            cfg.adam_weight_decay, 1, gscale, step_dev=self.step_dev, lr_dev=self.lr_dev)   # :1299
         if self.ema is not None:
             ops.ema_update(self.ema, lo.params, cfg.ema_rate)
         lo.repack()

@@ -23,6 +23,8 @@ def _worker(rank, world, port, outdir):
     lora = LoraState(cfg, 64, 8.0, "cpu", seed=5, b_std=0.01)
     D = Distiller.__new__(Distiller)       # exchange step only: no UNet weights needed
     D.lora, D.cfg, D.world_size, D.pg, D.step_count, D.ema = lora, StepConfig(learning_rate=1e-3), world, None, 0, None
+    D.step_dev = torch.zeros(1, dtype=torch.int64)
+    D.lr_dev = torch.full((1,), 1e-3)
     g = torch.Generator().manual_seed(100 + rank)
     lora.grads.copy_(torch.randn(lora.numel, generator=g) * 1e-3)
     mine = lora.grads.clone()
