@@ -245,6 +245,58 @@ __global__ __launch_bounds__(256) void pcm_gemm_kernel(GemmDev g) {
     }
     return;
   }
+  // bf16 output: stage the fp32 tile through LDS (the K-loop stages are dead now) so that the global side is
+  // whole-row 16-byte accesses: residual / rowvec loads and the output stores of a wave cover contiguous
+  // 256-B row segments instead of 8-B pieces of 32 different rows.
+  if (!g.out_f32 && (g.N % 8) == 0 && (g.ldo % 8) == 0 && (!g.res || ((g.ldr % 8) == 0 && (((uintptr_t)g.res) & 15) == 0)) &&
+      (!g.rowvec || (((uintptr_t)g.rowvec) & 15) == 0)) {
+    constexpr int CH = BN / 4;   // 16-B fp32 chunks per tile row; chunk index XOR-swizzled with the row
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < TM; j++) {
+      const int row = wm * 32 * TM + j * 32 + frow;
+#pragma unroll
+      for (int i = 0; i < TN; i++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int ch = (wn * 32 * TN + i * 32 + 8 * q + 4 * hi) >> 2;
+          *(float4*)(smem + ((size_t)row * CH + (ch ^ (row & (CH - 1)))) * 16) =
+              make_float4(acc[i][j][4 * q] * g.alpha, acc[i][j][4 * q + 1] * g.alpha, acc[i][j][4 * q + 2] * g.alpha, acc[i][j][4 * q + 3] * g.alpha);
+        }
+    }
+    __syncthreads();
+    constexpr int C8 = BN / 8;   // 16-B bf16 output chunks per tile row
+    for (int idx = tid; idx < BM * C8; idx += 256) {
+      const int row = idx / C8, c8 = idx - row * C8;
+      const int m = m0 + row, n = n0 + 8 * c8;
+      if (m >= g.M || n >= g.N) continue;
+      const float4 lo = *(const float4*)(smem + ((size_t)row * CH + ((2 * c8) ^ (row & (CH - 1)))) * 16);
+      const float4 hi4 = *(const float4*)(smem + ((size_t)row * CH + ((2 * c8 + 1) ^ (row & (CH - 1)))) * 16);
+      float v[8] = {lo.x, lo.y, lo.z, lo.w, hi4.x, hi4.y, hi4.z, hi4.w};
+      if (g.bias) {
+        const float4 b0 = *(const float4*)(g.bias + n), b1 = *(const float4*)(g.bias + n + 4);
+        v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+      }
+      if (g.rowvec) {
+        const uint4 t = *(const uint4*)(g.rowvec + (size_t)(m / g.rpb) * g.N + n);
+        const unsigned tw[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int e = 0; e < 4; e++) { v[2 * e] += bf2f((bf16_t)(tw[e] & 0xffff)); v[2 * e + 1] += bf2f((bf16_t)(tw[e] >> 16)); }
+      }
+      if (g.act == PCM_ACT_SILU) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) v[e] = silu_f(v[e]);
+      }
+      if (g.res) {
+        const uint4 t = *(const uint4*)(g.res + (size_t)m * g.ldr + n);
+        const unsigned tw[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int e = 0; e < 4; e++) { v[2 * e] += bf2f((bf16_t)(tw[e] & 0xffff)); v[2 * e + 1] += bf2f((bf16_t)(tw[e] >> 16)); }
+      }
+      *(uint4*)((bf16_t*)g.out + (size_t)m * g.ldo + n) = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < TM; j++) {
     int m = m0 + wm * 32 * TM + j * 32 + frow;
