@@ -43,10 +43,10 @@ struct GemmDev {
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
-// WGM x (4/WGM) waves; each wave owns a (32*TM) x (32*TN) sub-tile: block tile BM = 32*TM*WGM, BN = 32*TN*(4/WGM)
-template <int WGM, int TM, int TN>
-__global__ __launch_bounds__(256) void pcm_gemm_kernel(GemmDev g) {
-  constexpr int WGN = 4 / WGM;
+// NW waves as WGM x (NW/WGM); each wave owns a (32*TM) x (32*TN) sub-tile: block tile BM = 32*TM*WGM, BN = 32*TN*(NW/WGM)
+template <int NW, int WGM, int TM, int TN>
+__global__ __launch_bounds__(64 * NW) void pcm_gemm_kernel(GemmDev g) {
+  constexpr int WGN = NW / WGM;
   constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN;
   constexpr int STAGE = (BM + BN) * 128;
   PCM_DYN_SMEM(smem);
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void pcm_gemm_kernel(GemmDev g) {
   // ---- loader state.  Each thread owns AI rows of the activation tile and WI rows of the weight tile
   // (fixed over the K loop).  Source pointers are rebuilt once per (segment, conv tap) and then only
   // advanced by 128 B per K-tile, so the steady-state issue is {select, add, LDS-DMA} per row.
-  constexpr int AI = BM / 32, WI = BN / 32;
+  constexpr int AI = BM / (8 * NW), WI = BN / (8 * NW);
   const int lrow = lane >> 3, lchunk = lane & 7;
   const char* zero = (const char*)&pcm_zero_page;
   int a_m[AI], a_b[AI], a_y[AI], a_x[AI], a_c[AI];
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void pcm_gemm_kernel(GemmDev g) {
   const int HoWo = g.Ho * g.Wo;
 #pragma unroll
   for (int j = 0; j < AI; j++) {
-    int row = 8 * (wave + 4 * j) + lrow;
+    int row = 8 * (wave + NW * j) + lrow;
     a_c[j] = lchunk ^ ((row >> 1) & 7);
     int m = m0 + row;
     a_m[j] = m < g.M ? m : -1;
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void pcm_gemm_kernel(GemmDev g) {
   int w_n[WI], w_c[WI];
 #pragma unroll
   for (int j = 0; j < WI; j++) {
-    int row = 8 * (wave + 4 * j) + lrow;
+    int row = 8 * (wave + NW * j) + lrow;
     w_c[j] = lchunk ^ ((row >> 1) & 7);
     int n = n0 + row;
     w_n[j] = n < g.N ? n : -1;
@@ -135,25 +135,25 @@ __global__ __launch_bounds__(256) void pcm_gemm_kernel(GemmDev g) {
     if (!tail) {   // steady state: one LDS-DMA + one 64-bit add per row
 #pragma unroll
       for (int j = 0; j < AI; j++) {
-        __builtin_amdgcn_global_load_lds(PCM_AS1(a_cur[j]), PCM_AS3(base + (wave + 4 * j) * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(PCM_AS1(a_cur[j]), PCM_AS3(base + (wave + NW * j) * 1024), 16, 0, 0);
         a_cur[j] += a_inc[j];
       }
 #pragma unroll
       for (int j = 0; j < WI; j++) {
-        __builtin_amdgcn_global_load_lds(PCM_AS1(w_cur[j]), PCM_AS3(wbase + (wave + 4 * j) * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(PCM_AS1(w_cur[j]), PCM_AS3(wbase + (wave + NW * j) * 1024), 16, 0, 0);
         w_cur[j] += w_inc[j];
       }
     } else {
 #pragma unroll
       for (int j = 0; j < AI; j++) {
         const char* src = chunk * 64 + 8 * a_c[j] >= cs.K ? zero : a_cur[j];
-        __builtin_amdgcn_global_load_lds(PCM_AS1(src), PCM_AS3(base + (wave + 4 * j) * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(PCM_AS1(src), PCM_AS3(base + (wave + NW * j) * 1024), 16, 0, 0);
         a_cur[j] += a_inc[j];
       }
 #pragma unroll
       for (int j = 0; j < WI; j++) {
         const char* src = chunk * 64 + 8 * w_c[j] >= cs.K ? zero : w_cur[j];
-        __builtin_amdgcn_global_load_lds(PCM_AS1(src), PCM_AS3(wbase + (wave + 4 * j) * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(PCM_AS1(src), PCM_AS3(wbase + (wave + NW * j) * 1024), 16, 0, 0);
         w_cur[j] += w_inc[j];
       }
     }
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256) void pcm_gemm_kernel(GemmDev g) {
     }
     __syncthreads();
     constexpr int C8 = BN / 8;   // 16-B bf16 output chunks per tile row
-    for (int idx = tid; idx < BM * C8; idx += 256) {
+    for (int idx = tid; idx < BM * C8; idx += 64 * NW) {
       const int row = idx / C8, c8 = idx - row * C8;
       const int m = m0 + row, n = n0 + 8 * c8;
       if (m >= g.M || n >= g.N) continue;
@@ -376,8 +376,17 @@ __global__ __launch_bounds__(256) void pcm_gemm_finalize_kernel(GemmDev g) {
 
 // tile / split-K plan shared by pcm_gemm_bf16 and pcm_gemm_workspace_bytes
 struct GemmPlan { int BM, BN, tiles_m, tiles_n, splitk, kt_per_split; size_t ws_bytes; };
+static int g_force_bm = 0, g_force_bn = 0;
+// tuning hook (tools/ only): force the block tile of subsequent pcm_gemm_bf16 calls; (0,0) restores the planner
+extern "C" void pcm_debug_force_gemm_tile(int bm, int bn) { g_force_bm = bm; g_force_bn = bn; }
+
 static GemmPlan gemm_plan(int M, int N, int total_kt, bool allow_split) {
   GemmPlan p;
+  if (g_force_bm) {
+    p.splitk = 1; p.kt_per_split = total_kt; p.ws_bytes = 0; p.BM = g_force_bm; p.BN = g_force_bn;
+    p.tiles_m = (M + p.BM - 1) / p.BM; p.tiles_n = (N + p.BN - 1) / p.BN;
+    return p;
+  }
   p.splitk = 1; p.kt_per_split = total_kt; p.ws_bytes = 0;
   // 128x128 when N is a multiple of 128; otherwise the tall 256x64 tile (same 64x64 per-wave tile, no N waste at N=320/64)
   if ((N % 128) == 0) { p.BM = 128; p.BN = 128; } else { p.BM = 256; p.BN = 64; }
@@ -453,22 +462,29 @@ extern "C" int pcm_gemm_bf16(const pcm_gemm_seg* segs, int nseg, const pcm_gemm_
     g.ws = (float*)e->workspace;
   }
   g.tiles_m = pl.tiles_m; g.tiles_n = pl.tiles_n; g.splitk = pl.splitk; g.kt_per_split = pl.kt_per_split;
-  dim3 grid(g.tiles_m * g.tiles_n, pl.splitk), block(256);
+  dim3 grid(g.tiles_m * g.tiles_n, pl.splitk);
   size_t smem = 2 * (size_t)(pl.BM + pl.BN) * 128;
-  if (pl.BM == 128 && pl.BN == 128) PCM_LAUNCH((pcm_gemm_kernel<2, 2, 2>), grid, block, smem, stream, g);
-  else if (pl.BM == 256 && pl.BN == 64) {
-#ifndef PCM_HOST_EMU
-    static bool lds_ok = false;   // 80 KB of dynamic LDS: above the 64 KB default cap
-    if (!lds_ok) {
-      hipError_t er = hipFuncSetAttribute((const void*)pcm_gemm_kernel<4, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-      PCM_CHECK(er == hipSuccess, PCM_EHIP, "pcm_gemm_bf16: hipFuncSetAttribute(LDS %zu) failed: %s", smem, hipGetErrorString(er));
-      lds_ok = true;
-    }
+#ifdef PCM_HOST_EMU
+#define PCM_GEMM_LAUNCH(NW, WGM, TM, TN) PCM_LAUNCH((pcm_gemm_kernel<NW, WGM, TM, TN>), grid, dim3(64 * NW), smem, stream, g)
+#else
+  // tiles above 64 KB of dynamic LDS need the per-function cap raised once
+#define PCM_GEMM_LAUNCH(NW, WGM, TM, TN)                                                                          \
+  do {                                                                                                             \
+    static bool lds_ok = false;                                                                                    \
+    if (!lds_ok && smem > 65536) {                                                                                 \
+      hipError_t er = hipFuncSetAttribute((const void*)pcm_gemm_kernel<NW, WGM, TM, TN>,                           \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                  \
+      PCM_CHECK(er == hipSuccess, PCM_EHIP, "pcm_gemm_bf16: hipFuncSetAttribute(LDS %zu): %s", smem, hipGetErrorString(er)); \
+      lds_ok = true;                                                                                               \
+    }                                                                                                              \
+    PCM_LAUNCH((pcm_gemm_kernel<NW, WGM, TM, TN>), grid, dim3(64 * NW), smem, stream, g);                          \
+  } while (0)
 #endif
-    PCM_LAUNCH((pcm_gemm_kernel<4, 2, 2>), grid, block, smem, stream, g);
-  }
-  else if (pl.BM == 128 && pl.BN == 64) PCM_LAUNCH((pcm_gemm_kernel<2, 2, 1>), grid, block, smem, stream, g);
-  else PCM_LAUNCH((pcm_gemm_kernel<2, 1, 1>), grid, block, smem, stream, g);
+  if (pl.BM == 256 && pl.BN == 128) PCM_GEMM_LAUNCH(8, 4, 2, 2);
+  else if (pl.BM == 128 && pl.BN == 128) PCM_GEMM_LAUNCH(4, 2, 2, 2);
+  else if (pl.BM == 256 && pl.BN == 64) PCM_GEMM_LAUNCH(4, 4, 2, 2);
+  else if (pl.BM == 128 && pl.BN == 64) PCM_GEMM_LAUNCH(4, 2, 2, 1);
+  else PCM_GEMM_LAUNCH(4, 2, 1, 1);
   if (pl.splitk > 1) {
     long nq = (long)e->M * (e->N / 4);
     long fb = (nq + 255) / 256; if (fb > PCM_GRID_CAP(2048)) fb = PCM_GRID_CAP(2048);
