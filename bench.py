@@ -52,7 +52,7 @@ def cpu_baseline(seed):
 
 
 def log(msg):
-    if int(os.environ.get("RANK", "0")) == 0:
+    if int(os.environ.get("RANK", "0")) == 0 or os.environ.get("PCM_BENCH_DEBUG"):
         print("[bench %7.1fs] %s" % (time.time() - T0, msg), file=sys.stderr, flush=True)
 
 
@@ -74,10 +74,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "PCM_FORCE_DEVICE" in os.environ:          # single-GPU rehearsal of the N>1 path (with PCM_DIST_BACKEND=gloo)
+        local_rank = int(os.environ["PCM_FORCE_DEVICE"])
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        torch.distributed.init_process_group("nccl", rank=rank, world_size=world)
+        torch.distributed.init_process_group(os.environ.get("PCM_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
@@ -128,10 +130,11 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    log("rank %d: batches ready" % rank)
     for i, b in enumerate(batches[:args.warmup]):
         run(b)
         torch.cuda.synchronize()
-        log("warmup step %d done" % i)
+        log("rank %d: warmup step %d done" % (rank, i))
     sync()
     t0 = time.perf_counter()
     last = None
@@ -150,12 +153,14 @@ def main():
     loss = float(last["loss"].item())
 
     roofline = None
-    if rank == 0 and not args.no_roofline:
+    if not args.no_roofline:
         # dominant kernel family = pcm_gemm_bf16 (conv3x3 implicit GEMM / Linear / LoRA): one extra,
-        # instrumented step with HIP events around every launch on the launch stream.
-        ops.GEMM_PROFILE = []
+        # instrumented step with HIP events around every launch on the launch stream.  Every rank runs
+        # it (the step contains the gradient all-reduce); rank 0 reports.
+        ops.GEMM_PROFILE = [] if rank == 0 else None
         run(batches[-1], eager=True)
         torch.cuda.synchronize()
+    if rank == 0 and not args.no_roofline:
         prof, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
         flops = sum(p[0] for p in prof)
         tms = sum(p[1].elapsed_time(p[2]) for p in prof)
