@@ -39,6 +39,7 @@ extern "C" {
 
 #define PCM_ACT_NONE 0
 #define PCM_ACT_SILU 1
+#define PCM_ACT_LEAKY 2 /* LeakyReLU(0.01): DiscriminatorHead, discriminator_sd15.py:354 */
 
 const char* pcm_last_error(void);
 int pcm_abi_version(void);
@@ -118,6 +119,11 @@ int pcm_groupnorm_bwd_apply(const void* x, const void* dy, const double* stats, 
                             const float* gamma, const float* beta, void* dx, int B, int HW, int C,
                             int G, float eps, int act, void* stream);
 
+/* affine-parameter gradients (the discriminator heads' norms are trainable): dgamma/dbeta fp32 [C], ACCUMULATED */
+int pcm_groupnorm_param_grad(const void* x, const void* dy, const double* stats, const float* gamma,
+                             const float* beta, float* dgamma, float* dbeta, int B, int HW, int C, int G,
+                             float eps, int act, void* stream);
+
 /* ---- LayerNorm over the last dim (BasicTransformerBlock.norm1/2/3) ----------------------- */
 int pcm_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean,
                       float* rstd, int M, int C, float eps, void* stream);
@@ -158,6 +164,11 @@ int pcm_conv_out_fwd(const void* x, const float* w /*[4][C0][3][3]*/, const floa
                      int B, int H, int W, int C0, void* stream);
 int pcm_conv_out_bwd(const float* dy_nchw, const float* w, void* dx, int B, int H, int W, int C0, void* stream);
 
+/* conv1x1 to ONE channel (DiscriminatorHead.conv_out, discriminator_sd15.py:362): out[m] = x[m,:].w + b (fp32);
+ * backward: dx = dy w (bf16, optional), dw += sum_m dy x, db += sum dy (fp32, accumulated) */
+int pcm_rowdot_fwd(const void* x, const float* w, const float* bias, float* out, long M, int C, void* stream);
+int pcm_rowdot_bwd(const void* x, const float* w, const float* dy, void* dx, float* dw, float* db, long M, int C, void* stream);
+
 /* sinusoidal timestep projection (diffusers Timesteps(320, flip_sin_to_cos=True, shift=0)) */
 int pcm_timestep_embedding(const int64_t* t, void* out /*bf16 [B][dim]*/, int B, int dim, void* stream);
 
@@ -191,6 +202,18 @@ int pcm_cfg_ddim_step(const float* eps_c, const float* eps_u, const float* sampl
 int pcm_consistency_loss(const float* model_pred, const float* target, const float* coef, int huber,
                          float huber_c, double* loss, float* d_eps, float grad_scale, int B,
                          int per_sample, void* stream);
+
+/* noise_travel: scheduling_ddpm_modified.py:526-554 (fp32); sqrt_r[b] = d out / d x (optional) */
+int pcm_noise_travel(const float* x, const float* noise, const float* alphas_cumprod, const int64_t* t_cur,
+                     const int64_t* t_tgt, float* out, float* sqrt_r, int B, int per_sample, void* stream);
+/* hinge losses of the latent discriminator on one head's logit map (discriminator_sd15.py:412-434):
+ * mode 0 (d_loss): loss += scale*(mean relu(f+1) + mean relu(1-r)); mode 1 (g_loss): loss += scale*mean relu(1-f);
+ * d_fake / d_real (optional) = d loss / d logit * grad_scale.  `loss` accumulates over heads. */
+int pcm_hinge_loss(const float* fake, const float* real, int mode, float scale, double* loss, float* d_fake,
+                   float* d_real, float grad_scale, long n, void* stream);
+
+/* out[b][:] += x[b][:] * s1[b] * s2[b]  (generator step: d fake_adv -> d eps through noise_travel and the phase jump) */
+int pcm_scale_add_rows(float* out, const float* x, const float* s1, const float* s2, int B, int per_sample, void* stream);
 
 /* ---- optimizer (torch.optim.AdamW + clip_grad_norm_, train_pcm_lora_sd15.py:1297-1301) ---- */
 int pcm_sumsq_f32(const float* g, double* out /*1, zeroed by the call*/, long n, void* stream);

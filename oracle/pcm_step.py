@@ -144,3 +144,55 @@ def distill_step(ucfg, sd, lora, inp, cfg: StepConfig, opt_state, step):
     out["grads"] = grads
     out["grad_norm"] = gn
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# adversarial variant (train_pcm_lora_sd15_adv.py:1288-1431; discriminator_sd15.py:348-434)
+# ---------------------------------------------------------------------------------------------
+def discriminator_forward(ucfg, sd, disc_sd, sample, timestep, ehs, n_feats=9, nh=None):
+    """Discriminator._forward (discriminator_sd15.py:395-402): teacher features -> 36 head outputs."""
+    feats = unet_forward(ucfg, sd, sample, timestep, ehs, return_features=True)
+    outs = []
+    for k, f in enumerate(feats):
+        h = 0
+        while f"heads.{k}.{h}.conv_out.weight" in disc_sd:     # num_h_per_head heads per feature (4 in the reference)
+            outs.append(M.discriminator_head(disc_sd, f, prefix=f"heads.{k}.{h}."))
+            h += 1
+    return outs
+
+
+def distill_step_adv(ucfg, sd, lora, disc_sd, inp, cfg: StepConfig, global_step, adv_weight=0.1):
+    """One step of the adversarial trainer up to (and including) the backward; no optimizer update.
+    inp additionally carries noise_fake, noise_real [B,4,H,W] and adv_u [B] in [0,1).
+    Even global_step -> dict(d_loss, head_grads{name: grad}); odd -> dict(loss_cm, g_loss, lora_grads[list])."""
+    acp, alpha_s, sigma_s, solver = make_solver(cfg)
+    leaves, lora_rg = [], OrderedDict()
+    for k, (a, b) in lora.items():
+        a, b = a.detach().requires_grad_(True), b.detach().requires_grad_(True)
+        lora_rg[k] = (a, b)
+        leaves += [a, b]
+    out = distill_step_forward(ucfg, sd, lora_rg, inp, cfg)
+    model_pred, target, end_t = out["model_pred"], out["target"], out["end_timesteps"]
+    span = cfg.num_train_timesteps // cfg.multiphase
+    adv_t = end_t + torch.clamp((inp["adv_u"] * span).long(), max=span - 1)                     # :1288-1298
+    fake_adv = M.noise_travel(acp, model_pred.float(), inp["noise_fake"], end_t, adv_t)         # :1303-1305
+    pe = inp["prompt_embeds"]
+    res = dict(model_pred=model_pred.detach(), target=target.detach(), adv_timesteps=adv_t, fake_adv=fake_adv.detach())
+    if global_step % 2 == 0:
+        real_adv = M.noise_travel(acp, target.float(), inp["noise_real"], end_t, adv_t)         # :1379-1381
+        dsd = {k: v.detach().clone().requires_grad_(True) for k, v in disc_sd.items()}
+        fake_o = discriminator_forward(ucfg, sd, dsd, fake_adv.detach().float(), adv_t, pe)
+        real_o = discriminator_forward(ucfg, sd, dsd, real_adv.detach().float(), adv_t, pe)
+        loss = M.hinge_d_loss(fake_o, real_o, 1.0)
+        names = list(dsd)
+        grads = torch.autograd.grad(loss, [dsd[n] for n in names])
+        res.update(d_loss=loss.detach(), head_grads=dict(zip(names, grads)), real_adv=real_adv.detach())
+        return res
+    loss_cm = M.consistency_loss(model_pred, target, cfg.loss_type, cfg.huber_c)
+    fake_o = discriminator_forward(ucfg, sd, disc_sd, fake_adv.float(), adv_t, pe)
+    g_loss = M.hinge_g_loss(fake_o, 1.0)
+    loss = loss_cm + adv_weight * g_loss                                                         # :1414-1422
+    grads = torch.autograd.grad(loss, leaves, allow_unused=True)
+    grads = [torch.zeros_like(l) if g is None else g for g, l in zip(grads, leaves)]
+    res.update(loss_cm=loss_cm.detach(), g_loss=g_loss.detach(), lora_grads=grads)
+    return res

@@ -304,3 +304,55 @@ extern "C" int pcm_timestep_embedding(const int64_t* t, void* out, int B, int di
   PCM_LAUNCH(temb_kernel, dim3((B * dim / 2 + 255) / 256), dim3(256), 0, stream, t, (bf16_t*)out, B, dim);
   return pcm_post_launch("pcm_timestep_embedding");
 }
+
+// ---- conv1x1 to ONE channel (DiscriminatorHead.conv_out, discriminator_sd15.py:362): out[m] = x[m,:].w + b ----
+__global__ __launch_bounds__(256) void rowdot_fwd_kernel(const bf16_t* x, const float* w, const float* bias, float* out, long M, int C) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, CV = C / 8;
+  for (long m = (long)blockIdx.x * 4 + wv; m < M; m += (long)gridDim.x * 4) {
+    float acc = 0.f;
+    for (int cv = lane; cv < CV; cv += 64) {
+      float f[8];
+      ew_unpack8(*(const uint4*)(x + m * C + cv * 8), f);
+#pragma unroll
+      for (int e = 0; e < 8; e++) acc += f[e] * w[cv * 8 + e];
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) out[m] = acc + (bias ? bias[0] : 0.f);
+  }
+}
+// dx[m][c] = dy[m] * w[c] ; dw[c] += sum_m dy[m] x[m][c] ; db += sum_m dy[m]
+__global__ __launch_bounds__(256) void rowdot_bwd_kernel(const bf16_t* x, const float* w, const float* dy, bf16_t* dx, float* dw, float* db,
+                                                         long M, int C, int rows_per_block) {
+  const int CV = C / 8;
+  const int cvl = threadIdx.x % CV, pl = threadIdx.x / CV, k = blockDim.x / CV;
+  float s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, wv[8];
+#pragma unroll
+  for (int e = 0; e < 8; e++) wv[e] = w[cvl * 8 + e];
+  long m0 = (long)blockIdx.x * rows_per_block, m1 = m0 + rows_per_block; if (m1 > M) m1 = M;
+  float sb = 0.f;
+  for (long m = m0 + pl; m < m1; m += k) {
+    float d = dy[m], f[8], o[8];
+    ew_unpack8(*(const uint4*)(x + m * C + cvl * 8), f);
+#pragma unroll
+    for (int e = 0; e < 8; e++) { s[e] += d * f[e]; o[e] = d * wv[e]; }
+    if (dx) *(uint4*)(dx + m * C + cvl * 8) = ew_pack8(o);
+    if (cvl == 0) sb += d;
+  }
+#pragma unroll
+  for (int e = 0; e < 8; e++) atomicAdd(&dw[cvl * 8 + e], s[e]);
+  if (cvl == 0 && db) atomicAdd(db, sb);
+}
+extern "C" int pcm_rowdot_fwd(const void* x, const float* w, const float* bias, float* out, long M, int C, void* stream) {
+  PCM_CHECK(x && w && out && M > 0 && (C % 8) == 0 && PCM_ALIGNED16(x), PCM_EINVAL, "pcm_rowdot_fwd: C%%8, alignment");
+  long blocks = (M + 3) / 4; if (blocks > PCM_GRID_CAP(2048)) blocks = PCM_GRID_CAP(2048);
+  PCM_LAUNCH(rowdot_fwd_kernel, dim3((int)blocks), dim3(256), 0, stream, (const bf16_t*)x, w, bias, out, M, C);
+  return pcm_post_launch("pcm_rowdot_fwd");
+}
+extern "C" int pcm_rowdot_bwd(const void* x, const float* w, const float* dy, void* dx, float* dw, float* db, long M, int C, void* stream) {
+  PCM_CHECK(x && w && dy && dw && M > 0 && (C % 8) == 0 && C <= 2048 && PCM_ALIGNED16(x), PCM_EINVAL, "pcm_rowdot_bwd: C%%8, C<=2048, alignment");
+  int CV = C / 8, k = 256 / CV; if (k < 1) k = 1;
+  long blocks = PCM_GRID_CAP(512); long rpb = (M + blocks - 1) / blocks; if (rpb < k) rpb = k;
+  blocks = (M + rpb - 1) / rpb;
+  PCM_LAUNCH(rowdot_bwd_kernel, dim3((int)blocks), dim3(CV * k), 0, stream, (const bf16_t*)x, w, dy, (bf16_t*)dx, dw, db, M, C, (int)rpb);
+  return pcm_post_launch("pcm_rowdot_bwd");
+}

@@ -30,6 +30,13 @@ __device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
   return make_uint4(pack_bf2(f[0], f[1]), pack_bf2(f[2], f[3]), pack_bf2(f[4], f[5]), pack_bf2(f[6], f[7]));
 }
 
+__device__ __forceinline__ float gn_act(float z, int act) {
+  return act == PCM_ACT_SILU ? silu_f(z) : (act == PCM_ACT_LEAKY ? (z > 0.f ? z : 0.01f * z) : z);
+}
+__device__ __forceinline__ float gn_act_grad(float z, int act) {
+  return act == PCM_ACT_SILU ? silu_grad_f(z) : (act == PCM_ACT_LEAKY ? (z > 0.f ? 1.f : 0.01f) : 1.f);
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256) void gn_stats_kernel(GNArgs a) {
   __shared__ float red[2][2560];  // per-channel partials of this block's channel slice
@@ -72,7 +79,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(GNArgs a) {
       for (int e = 0; e < 8; e++) {
         float xh = (xv[e] - mu[e]) * rs[e];
         float dz = dv[e];
-        if (a.act == PCM_ACT_SILU) dz *= silu_grad_f(xh * ga[e] + be[e]);
+        dz *= gn_act_grad(xh * ga[e] + be[e], a.act);
         float t = dz * ga[e];
         s1[e] += t; s2[e] += t * xh;
       }
@@ -147,7 +154,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GNApply a) {
 #pragma unroll
       for (int e = 0; e < 8; e++) {
         float z = xv[e] * sc[c0 + e] + sh[c0 + e];
-        o[e] = a.act == PCM_ACT_SILU ? silu_f(z) : z;
+        o[e] = gn_act(z, a.act);
       }
     } else {
       float dv[8];
@@ -157,7 +164,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GNApply a) {
         int c = c0 + e, g = c / a.cpg;
         float xh = (xv[e] - gm[g]) * gr[g];
         float dz = dv[e];
-        if (a.act == PCM_ACT_SILU) dz *= silu_grad_f(xh * sc[c] + sh[c]);
+        dz *= gn_act_grad(xh * sc[c] + sh[c], a.act);
         o[e] = gr[g] * (dz * sc[c] - g1[g] - xh * g2[g]);
       }
     }
@@ -365,4 +372,56 @@ extern "C" int pcm_layernorm_bwd(const void* x, const void* dy, const float* gam
   else if (C <= 1024) PCM_LAUNCH((ln_bwd_kernel<2>), grid, block, 0, stream, (const bf16_t*)x, (const bf16_t*)dy, gamma, mean, rstd, (const bf16_t*)dres, (bf16_t*)dx, M, C);
   else PCM_LAUNCH((ln_bwd_kernel<4>), grid, block, 0, stream, (const bf16_t*)x, (const bf16_t*)dy, gamma, mean, rstd, (const bf16_t*)dres, (bf16_t*)dx, M, C);
   return pcm_post_launch("pcm_layernorm_bwd");
+}
+
+// ---- GroupNorm affine-parameter gradients (discriminator heads: their norms ARE trainable) ----
+// dgamma[c] += sum_{b,hw} dz * xhat ; dbeta[c] += sum dz ; dz = dy * act'(z)
+__global__ __launch_bounds__(256) void gn_param_grad_kernel(GNArgs a, float* dgamma, float* dbeta) {
+  const int b = blockIdx.y, zc = blockIdx.z;
+  const int cvl = threadIdx.x % a.CVL, pl = threadIdx.x / a.CVL, k = blockDim.x / a.CVL;
+  const int c0 = (zc * a.CVL + cvl) * 8;
+  float ga[8], be[8], mu[8], rs[8], s1[8], s2[8];
+  const double n = (double)a.HW * a.cpg;
+#pragma unroll
+  for (int e = 0; e < 8; e++) {
+    int c = c0 + e, g = c / a.cpg;
+    double s = a.stats[((size_t)b * a.G + g) * 2], ss = a.stats[((size_t)b * a.G + g) * 2 + 1];
+    double m = s / n, var = ss / n - m * m;
+    mu[e] = (float)m; rs[e] = (float)(1.0 / sqrt((var > 0 ? var : 0) + (double)a.eps));
+    ga[e] = a.gamma[c]; be[e] = a.beta[c]; s1[e] = 0.f; s2[e] = 0.f;
+  }
+  const int p_begin = blockIdx.x * a.ppb;
+  int p_end = p_begin + a.ppb; if (p_end > a.HW) p_end = a.HW;
+  const bf16_t* xb = a.x + (size_t)b * a.HW * a.C + c0;
+  const bf16_t* dyb = a.dy + (size_t)b * a.HW * a.C + c0;
+  for (int p = p_begin + pl; p < p_end; p += k) {
+    float xv[8], dv[8];
+    unpack8(*(const uint4*)(xb + (size_t)p * a.C), xv);
+    unpack8(*(const uint4*)(dyb + (size_t)p * a.C), dv);
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      float xh = (xv[e] - mu[e]) * rs[e];
+      float dz = dv[e] * gn_act_grad(xh * ga[e] + be[e], a.act);
+      s1[e] += dz * xh; s2[e] += dz;
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; e++) { atomicAdd(&dgamma[c0 + e], s1[e]); atomicAdd(&dbeta[c0 + e], s2[e]); }
+}
+extern "C" int pcm_groupnorm_param_grad(const void* x, const void* dy, const double* stats, const float* gamma, const float* beta,
+                                        float* dgamma, float* dbeta, int B, int HW, int C, int G, float eps, int act, void* stream) {
+  if (int rc = gn_check("pcm_groupnorm_param_grad", B, HW, C, G)) return rc;
+  PCM_CHECK(x && dy && stats && gamma && beta && dgamma && dbeta && PCM_ALIGNED16(x) && PCM_ALIGNED16(dy), PCM_EALIGN, "pcm_groupnorm_param_grad: null/unaligned");
+  GNArgs a; memset(&a, 0, sizeof(a));
+  a.x = (const bf16_t*)x; a.dy = (const bf16_t*)dy; a.stats = stats; a.gamma = gamma; a.beta = beta;
+  a.HW = HW; a.C = C; a.G = G; a.cpg = C / G; a.eps = eps; a.act = act;
+  int CV = C / 8, split = 1;
+  while (CV / split > 256 || (CV % split) != 0) split++;
+  a.CVL = CV / split;
+  int k = 256 / a.CVL; if (k < 1) k = 1;
+  int chunks = (PCM_GRID_CAP(512) + B * split - 1) / (B * split);
+  int maxchunks = (HW + k - 1) / k; if (chunks > maxchunks) chunks = maxchunks; if (chunks < 1) chunks = 1;
+  a.ppb = (HW + chunks - 1) / chunks; chunks = (HW + a.ppb - 1) / a.ppb;
+  PCM_LAUNCH(gn_param_grad_kernel, dim3(chunks, B, split), dim3(a.CVL * k), 0, stream, a, dgamma, dbeta);
+  return pcm_post_launch("pcm_groupnorm_param_grad");
 }

@@ -163,3 +163,67 @@ extern "C" int pcm_consistency_loss(const float* model_pred, const float* target
   PCM_LAUNCH(loss_kernel, dim3(pm_blocks((long)B * per_sample)), dim3(256), 0, stream, model_pred, target, coef, huber, huber_c, loss, d_eps, grad_scale, B, per_sample);
   return pcm_post_launch("pcm_consistency_loss");
 }
+
+// noise_travel (scheduling_ddpm_modified.py:526-554): r = acp[t_tgt]/acp[t_cur]; sqrt(r) x + sqrt(1-r) noise (fp32);
+// also writes sqrt(r) per sample (d out / d x for the generator step's backward)
+__global__ __launch_bounds__(256) void noise_travel_kernel(const float* x, const float* noise, const float* acp, const int64_t* t_cur,
+                                                           const int64_t* t_tgt, float* out, float* sr, int B, int ps) {
+  long n = (long)B * ps;
+  PM_LOOP(i, n) {
+    int b = (int)(i / ps);
+    float r = __fdiv_rn(acp[t_tgt[b]], acp[t_cur[b]]);
+    float sa = __fsqrt_rn(r), sb = __fsqrt_rn(__fsub_rn(1.0f, r));
+    out[i] = __fadd_rn(__fmul_rn(sa, x[i]), __fmul_rn(sb, noise[i]));
+    if (sr && i % ps == 0) sr[b] = sa;
+  }
+}
+extern "C" int pcm_noise_travel(const float* x, const float* noise, const float* acp, const int64_t* t_cur, const int64_t* t_tgt,
+                                float* out, float* sqrt_r, int B, int per_sample, void* stream) {
+  PCM_CHECK(x && noise && acp && t_cur && t_tgt && out && B > 0 && per_sample > 0, PCM_EINVAL, "pcm_noise_travel: null/empty");
+  PCM_LAUNCH(noise_travel_kernel, dim3(pm_blocks((long)B * per_sample)), dim3(256), 0, stream, x, noise, acp, t_cur, t_tgt, out, sqrt_r, B, per_sample);
+  return pcm_post_launch("pcm_noise_travel");
+}
+
+// hinge losses of the latent discriminator (discriminator_sd15.py:412-434) on ONE head's logit map:
+//   mode 0 (D): loss += scale * (mean relu(f + 1) + mean relu(1 - r)) ; mode 1 (G): loss += scale * mean relu(1 - f)
+// and the gradients wrt the logits (scaled by gscale).  `loss` accumulates across heads (zero it once).
+__global__ __launch_bounds__(256) void hinge_kernel(const float* f, const float* r, int mode, float scale, double* loss, float* df,
+                                                    float* dr, float gscale, long n) {
+  __shared__ double red[4];
+  double acc = 0.0;
+  const float inv = scale / (float)n;
+  PM_LOOP(i, n) {
+    float fv = f[i];
+    if (mode == 0) {
+      float a = fv + 1.0f, b2 = 1.0f - r[i];
+      acc += (double)(a > 0.f ? a : 0.f) + (double)(b2 > 0.f ? b2 : 0.f);
+      if (df) df[i] = a > 0.f ? inv * gscale : 0.f;
+      if (dr) dr[i] = b2 > 0.f ? -inv * gscale : 0.f;
+    } else {
+      float a = 1.0f - fv;
+      acc += (double)(a > 0.f ? a : 0.f);
+      if (df) df[i] = a > 0.f ? -inv * gscale : 0.f;
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(loss, (red[0] + red[1] + red[2] + red[3]) * (double)scale / (double)n);
+}
+extern "C" int pcm_hinge_loss(const float* fake, const float* real, int mode, float scale, double* loss, float* d_fake, float* d_real,
+                              float grad_scale, long n, void* stream) {
+  PCM_CHECK(fake && loss && n > 0 && (mode == 1 || real), PCM_EINVAL, "pcm_hinge_loss: null/empty");
+  PCM_LAUNCH(hinge_kernel, dim3(pm_blocks(n)), dim3(256), 0, stream, fake, real, mode, scale, loss, d_fake, d_real, grad_scale, n);
+  return pcm_post_launch("pcm_hinge_loss");
+}
+
+// out[b][i] += x[b][i] * s1[b] * s2[b]
+__global__ __launch_bounds__(256) void scale_add_rows_kernel(float* out, const float* x, const float* s1, const float* s2, int B, int ps) {
+  long n = (long)B * ps;
+  PM_LOOP(i, n) { int b = (int)(i / ps); out[i] += x[i] * s1[b] * s2[b]; }
+}
+extern "C" int pcm_scale_add_rows(float* out, const float* x, const float* s1, const float* s2, int B, int per_sample, void* stream) {
+  PCM_CHECK(out && x && s1 && s2 && B > 0 && per_sample > 0, PCM_EINVAL, "pcm_scale_add_rows: null/empty");
+  PCM_LAUNCH(scale_add_rows_kernel, dim3(pm_blocks((long)B * per_sample)), dim3(256), 0, stream, out, x, s1, s2, B, per_sample);
+  return pcm_post_launch("pcm_scale_add_rows");
+}

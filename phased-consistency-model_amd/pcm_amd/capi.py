@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(HERE, "lib", "libpcm_hip.so")
 
 PCM_BF16, PCM_F32 = 0, 1
-ACT_NONE, ACT_SILU = 0, 1
+ACT_NONE, ACT_SILU, ACT_LEAKY = 0, 1, 2
 SEG_PLAIN, SEG_CONV3X3 = 0, 1
 SRC_DIRECT, SRC_UPSAMPLE2, SRC_ZEROINS2 = 0, 1, 2
 
@@ -54,6 +54,12 @@ _PROTOS = {
     "pcm_groupnorm_apply": [vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp],
     "pcm_groupnorm_bwd_stats": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp],
     "pcm_groupnorm_bwd_apply": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp],
+    "pcm_groupnorm_param_grad": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp],
+    "pcm_rowdot_fwd": [vp, vp, vp, vp, i64, i32, vp],
+    "pcm_rowdot_bwd": [vp, vp, vp, vp, vp, vp, i64, i32, vp],
+    "pcm_noise_travel": [vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
+    "pcm_scale_add_rows": [vp, vp, vp, vp, i32, i32, vp],
+    "pcm_hinge_loss": [vp, vp, i32, f32, vp, vp, vp, f32, i64, vp],
     "pcm_layernorm_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, f32, vp],
     "pcm_layernorm_bwd": [vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
     "pcm_geglu_fwd": [vp, vp, i32, i32, vp],

@@ -1,0 +1,197 @@
+"""Latent adversarial discriminator of PCM (reference: code/text_to_image_sd15/discriminator_sd15.py).
+
+``Discriminator(unet)`` there = the frozen teacher UNet used as a feature extractor
+(``modified_forward``, :16-345 -> pcm_amd.model.UNet.forward(features=True)) + 9 x 4 trainable
+``DiscriminatorHead``s (:348-393): conv3x3 -> GroupNorm(32) -> LeakyReLU, conv3x3 -> GN -> LeakyReLU (+ skip),
+conv1x1 -> 1 logit map; hinge losses :412-434.
+
+All head parameters live in ONE flat fp32 buffer (+ grad + Adam moments).  conv3x3 weights are stored
+[co][kh][kw][ci] internally (contiguous weight-gradient atomics, direct MFMA operand packing); the
+reference / torch layout [co][ci][kh][kw] is produced on export.
+"""
+import math
+from collections import OrderedDict
+
+import torch
+
+from . import capi, ops
+from .ops import Seg
+
+BF16 = torch.bfloat16
+ADAPTER_DIMS = (320, 640, 1280, 1280, 1280, 1280, 1280, 640, 320)   # discriminator_sd15.py:377
+
+
+class Head:
+    __slots__ = ("C", "p", "g", "wf", "wb")
+
+
+class Discriminator:
+    def __init__(self, adapter_channel_dims=ADAPTER_DIMS, num_h_per_head=4, device="cuda", seed=2, groups=32):
+        self.dims, self.nh, self.device, self.G = tuple(adapter_channel_dims), num_h_per_head, torch.device(device), groups
+        self.head_num = len(self.dims)
+        layout, total = [], 0
+        for k, C in enumerate(self.dims):
+            for h in range(num_h_per_head):
+                names = OrderedDict([("conv1.0.weight", (C, 3, 3, C)), ("conv1.0.bias", (C,)), ("conv1.1.weight", (C,)),
+                                     ("conv1.1.bias", (C,)), ("conv2.0.weight", (C, 3, 3, C)), ("conv2.0.bias", (C,)),
+                                     ("conv2.1.weight", (C,)), ("conv2.1.bias", (C,)), ("conv_out.weight", (C,)),
+                                     ("conv_out.bias", (1,))])
+                offs = {}
+                for n, shp in names.items():
+                    offs[n] = (total, shp)
+                    total += (math.prod(shp) + 3) // 4 * 4          # keep every tensor 16-byte aligned
+                layout.append((k, h, C, offs))
+        self.numel = total
+        f32 = dict(dtype=torch.float32, device=self.device)
+        self.params = torch.zeros(total, **f32)
+        self.grads = torch.zeros(total, **f32)
+        self.exp_avg = torch.zeros(total, **f32)
+        self.exp_avg_sq = torch.zeros(total, **f32)
+        self.gradsq = torch.zeros(1, dtype=torch.float64, device=self.device)
+        self.step_dev = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self.heads = []
+        g = torch.Generator().manual_seed(seed)
+        for k, h, C, offs in layout:
+            hd = Head()
+            hd.C = C
+            hd.p = {n: self.params[o:o + math.prod(shp)].view(shp) for n, (o, shp) in offs.items()}
+            hd.g = {n: self.grads[o:o + math.prod(shp)].view(shp) for n, (o, shp) in offs.items()}
+            # torch default init of nn.Conv2d / nn.GroupNorm (DiscriminatorHead.__init__, :349-362)
+            for cv in ("conv1.0", "conv2.0"):
+                bound = 1.0 / math.sqrt(9 * C)
+                w = (torch.rand(C, C, 3, 3, generator=g) * 2 - 1) * bound
+                hd.p[cv + ".weight"].copy_(w.permute(0, 2, 3, 1).to(self.device))
+                hd.p[cv + ".bias"].copy_(((torch.rand(C, generator=g) * 2 - 1) * bound).to(self.device))
+            for gn in ("conv1.1", "conv2.1"):
+                hd.p[gn + ".weight"].fill_(1.0)
+            bound = 1.0 / math.sqrt(C)
+            hd.p["conv_out.weight"].copy_(((torch.rand(C, generator=g) * 2 - 1) * bound).to(self.device))
+            hd.p["conv_out.bias"].copy_(((torch.rand(1, generator=g) * 2 - 1) * bound).to(self.device))
+            hd.wf = {cv: torch.empty(C, 9 * C, dtype=BF16, device=self.device) for cv in ("conv1.0", "conv2.0")}
+            hd.wb = {cv: torch.empty(C, 9 * C, dtype=BF16, device=self.device) for cv in ("conv1.0", "conv2.0")}
+            self.heads.append((k, hd))
+        self.repack()
+
+    def repack(self):
+        for _, hd in self.heads:
+            for cv in ("conv1.0", "conv2.0"):
+                ops.pack_conv3x3(hd.p[cv + ".weight"], True, True, 1.0, hd.wf[cv], hd.wb[cv], khwc=True)
+
+    def state_dict(self):
+        """reference names / torch layouts: heads.{k}.{h}.conv1.0.weight [C,C,3,3], ... conv_out.weight [1,C,1,1]"""
+        out, cnt = OrderedDict(), {}
+        for k, hd in self.heads:
+            h = cnt.get(k, 0)
+            cnt[k] = h + 1
+            for n, t in hd.p.items():
+                v = t.detach().clone()
+                if n in ("conv1.0.weight", "conv2.0.weight"):
+                    v = v.permute(0, 3, 1, 2).contiguous()
+                elif n == "conv_out.weight":
+                    v = v.view(1, hd.C, 1, 1)
+                out[f"heads.{k}.{h}.{n}"] = v
+        return out
+
+    def load_state_dict(self, sd):
+        cnt = {}
+        for k, hd in self.heads:
+            h = cnt.get(k, 0)
+            cnt[k] = h + 1
+            for n, t in hd.p.items():
+                v = sd[f"heads.{k}.{h}.{n}"].to(self.device)
+                if n in ("conv1.0.weight", "conv2.0.weight"):
+                    v = v.permute(0, 2, 3, 1)
+                t.copy_(v.reshape(t.shape))
+        self.repack()
+
+    # ------------------------------------------------------------------ forward / backward of the heads
+    def forward(self, feats, save=False):
+        """feats: list of 9 (tensor [B, HW, C] bf16, H, W).  Returns list of 36 logit maps fp32 [B*HW] (+ tape)."""
+        logits, tape = [], ([] if save else None)
+        for k, hd in self.heads:
+            f, H, W = feats[k]
+            B, C = f.shape[0], hd.C
+            M = B * H * W
+            geo = dict(Hs=H, Ws=W)
+            a1 = torch.empty(M, C, dtype=BF16, device=f.device)
+            ops.gemm([Seg(f, hd.wf["conv1.0"], conv=geo)], M, C, a1, bias=hd.p["conv1.0.bias"], Ho=H, Wo=W)
+            n1, st1 = ops.groupnorm_fwd(a1.view(B, H * W, C), hd.p["conv1.1.weight"], hd.p["conv1.1.bias"], self.G, 1e-5, capi.ACT_LEAKY)
+            a2 = torch.empty(M, C, dtype=BF16, device=f.device)
+            ops.gemm([Seg(n1, hd.wf["conv2.0"], conv=geo)], M, C, a2, bias=hd.p["conv2.0.bias"], Ho=H, Wo=W)
+            n2, st2 = ops.groupnorm_fwd(a2.view(B, H * W, C), hd.p["conv2.1.weight"], hd.p["conv2.1.bias"], self.G, 1e-5, capi.ACT_LEAKY)
+            h2 = ops.add(n2, n1)                                                         # x = conv2(x) + x   (:366)
+            logits.append(ops.rowdot_fwd(h2, hd.p["conv_out.weight"], hd.p["conv_out.bias"]))
+            if save:
+                tape.append(dict(f=f, H=H, W=W, B=B, a1=a1, st1=st1, n1=n1, a2=a2, st2=st2, h2=h2))
+        return (logits, tape) if save else logits
+
+    def backward(self, d_logits, tape, param_grads=True, feature_grads=False):
+        """d_logits: 36 fp32 [M] gradients.  Accumulates parameter gradients (discriminator step) and / or returns
+        the 9 feature gradients (generator step)."""
+        d_feats = [None] * self.head_num
+        for (k, hd), dl, sv in zip(self.heads, d_logits, tape):
+            B, H, W, C = sv["B"], sv["H"], sv["W"], hd.C
+            M = B * H * W
+            geo = dict(Hs=H, Ws=W)
+            wg = dict(Hs=H, Ws=W, Ho=H, Wo=W)
+            if param_grads:
+                d_h2 = ops.rowdot_bwd(sv["h2"], hd.p["conv_out.weight"], dl, hd.g["conv_out.weight"], hd.g["conv_out.bias"])
+            else:
+                scratch = torch.zeros(C + 4, dtype=torch.float32, device=dl.device)
+                d_h2 = ops.rowdot_bwd(sv["h2"], hd.p["conv_out.weight"], dl, scratch, scratch[C:])
+            # GN2 + LeakyReLU
+            gam2, bet2 = hd.p["conv2.1.weight"], hd.p["conv2.1.bias"]
+            a2 = sv["a2"].view(B, H * W, C)
+            if param_grads:
+                ops.groupnorm_param_grad(a2, d_h2, sv["st2"], gam2, bet2, hd.g["conv2.1.weight"], hd.g["conv2.1.bias"], self.G, 1e-5, capi.ACT_LEAKY)
+            d_a2 = ops.groupnorm_bwd(a2, d_h2, sv["st2"], gam2, bet2, self.G, 1e-5, capi.ACT_LEAKY)
+            if param_grads:
+                self._conv_param_grads(hd, "conv2.0", sv["n1"], d_a2.view(M, C), M, wg)
+            d_n1 = torch.empty(M, C, dtype=BF16, device=dl.device)                     # dgrad(conv2) + skip branch
+            ops.gemm([Seg(d_a2, hd.wb["conv2.0"], conv=geo)], M, C, d_n1, residual=d_h2.view(M, C), Ho=H, Wo=W)
+            gam1, bet1 = hd.p["conv1.1.weight"], hd.p["conv1.1.bias"]
+            a1 = sv["a1"].view(B, H * W, C)
+            if param_grads:
+                ops.groupnorm_param_grad(a1, d_n1.view(B, H * W, C), sv["st1"], gam1, bet1, hd.g["conv1.1.weight"], hd.g["conv1.1.bias"], self.G, 1e-5, capi.ACT_LEAKY)
+            d_a1 = ops.groupnorm_bwd(a1, d_n1.view(B, H * W, C), sv["st1"], gam1, bet1, self.G, 1e-5, capi.ACT_LEAKY)
+            if param_grads:
+                self._conv_param_grads(hd, "conv1.0", sv["f"], d_a1.view(M, C), M, wg)
+            if feature_grads:
+                d_f = torch.empty(M, C, dtype=BF16, device=dl.device)
+                ops.gemm([Seg(d_a1, hd.wb["conv1.0"], conv=geo)], M, C, d_f, residual=None if d_feats[k] is None else d_feats[k].view(M, C),
+                         Ho=H, Wo=W)                                                   # 4 heads share one feature: sum in the epilogue
+                d_feats[k] = d_f.view(B, H * W, C)
+        return d_feats
+
+    def _conv_param_grads(self, hd, name, x, dy, M, wg):
+        """full conv3x3 weight gradient dW[co][tap][ci] = sum_m dy[m][co] * im2col(x)[m][(tap,ci)] as Cout/64 launches of
+        the rank-64 wgrad kernel (64 output channels each), bias gradient = pixel sum of dy."""
+        C = hd.C
+        gW = hd.g[name + ".weight"].view(C, 9 * C)
+        for co in range(0, C, 64):
+            ops.lora_wgrad(x, dy[:, co:co + 64], gW[co:co + 64], 1.0, M, conv=wg, g_stride=1, r_stride=9 * C, lds=C)
+        capi.lib().call("pcm_colsum_bf16", ops.ptr(dy), ops.ptr(hd.g[name + ".bias"]), 1, M, C, capi.Lib.stream())
+
+    # ------------------------------------------------------------------ losses (discriminator_sd15.py:412-434)
+    def d_loss_backward(self, logits_fake_real, tape, B_half, weight=1.0):
+        """logits of the batched [fake; real] pass.  Returns loss (fp64 [1]); accumulates head gradients."""
+        loss = torch.zeros(1, dtype=torch.float64, device=self.device)
+        n_heads = self.head_num * self.nh
+        d_logits = []
+        for lg in logits_fake_real:
+            half = lg.numel() // 2
+            df, dr = ops.hinge_loss(lg[:half], lg[half:], 0, weight / n_heads, loss)
+            d_logits.append(torch.cat([df, dr]))
+        self.backward(d_logits, tape, param_grads=True, feature_grads=False)
+        return loss
+
+    def g_loss_backward(self, logits_fake, tape, weight=1.0, grad_scale=1.0):
+        """Returns (loss fp64 [1], d_feats): gradient of grad_scale * g_loss wrt the 9 teacher features."""
+        loss = torch.zeros(1, dtype=torch.float64, device=self.device)
+        n_heads = self.head_num * self.nh
+        d_logits = []
+        for lg in logits_fake:
+            df, _ = ops.hinge_loss(lg, None, 1, weight / n_heads, loss, grad_scale=grad_scale)
+            d_logits.append(df)
+        d_feats = self.backward(d_logits, tape, param_grads=False, feature_grads=True)
+        return loss, d_feats

@@ -445,7 +445,9 @@ class UNet:
         return ops.add(d_x.view(M, C), d_out).view(B, H * Wd, C)
 
     # ---- whole network ----
-    def forward(self, sample, timesteps, encoder_hidden_states, save=False):
+    def forward(self, sample, timesteps, encoder_hidden_states, save=False, features=False):
+        """``features=True`` is the reference's ``modified_forward`` (discriminator_sd15.py:16-345): returns the 9
+        hidden states after every down block, the mid block and every up block (no conv_norm_out / conv_out)."""
         cfg, W, lora = self.cfg, self.W, self.lora
         B, _, H, Wd = sample.shape
         boc, n = cfg.block_out_channels, len(cfg.block_out_channels)
@@ -456,6 +458,7 @@ class UNet:
         emb_act = layer_fwd(W, None, "time_embedding.linear_2", e1, B, act=capi.ACT_SILU)  # silu(emb): only use of emb
         h = ops.conv_in_fwd(sample.contiguous(), W.conv_in[0], W.conv_in[1], boc[0])
         skips = [(h, H, Wd)]
+        feats = []
         for i in range(n):
             for j in range(cfg.layers_per_block):
                 h = self.resnet_fwd(f"down_blocks.{i}.resnets.{j}.", h, emb_act, B, H, Wd, tape)
@@ -471,9 +474,17 @@ class UNet:
                 if save:
                     tape.append(("down", f"down_blocks.{i}.downsamplers.0.conv", dict(sv=sv, B=B, H=H, W=Wd)))
                 skips.append((h, H, Wd))
+            if features:
+                feats.append((h, H, Wd))
+                if save:
+                    tape.append(("feat", None, dict(k=len(feats) - 1)))
         h = self.resnet_fwd("mid_block.resnets.0.", h, emb_act, B, H, Wd, tape)
         h = self.transformer_fwd("mid_block.attentions.0.", h, text, B, H, Wd, tape)
         h = self.resnet_fwd("mid_block.resnets.1.", h, emb_act, B, H, Wd, tape)
+        if features:
+            feats.append((h, H, Wd))
+            if save:
+                tape.append(("feat", None, dict(k=len(feats) - 1)))
         for i in range(n):
             for j in range(cfg.layers_per_block + 1):
                 s, _, _ = skips.pop()
@@ -492,6 +503,15 @@ class UNet:
                     tape.append(("up", f"up_blocks.{i}.upsamplers.0.conv", dict(sv=sv, B=B, H=H, W=Wd)))
                 H, Wd = geo.Ho, geo.Wo
                 h = h.view(B, H * Wd, -1)
+            if features:
+                feats.append((h, H, Wd))
+                if save:
+                    tape.append(("feat", None, dict(k=len(feats) - 1)))
+        if features:
+            if save:
+                tape.append(("feats_end", None, dict(B=B, H=H, W=Wd)))
+                return feats, tape
+            return feats
         sgn = {} if save else None
         hn = self._gn("conv_norm_out", h, capi.ACT_SILU, cfg.norm_eps, sgn)
         out = ops.conv_out_fwd(hn, W.conv_out[0], W.conv_out[1], B, H, Wd)
@@ -500,21 +520,30 @@ class UNet:
             return out, tape
         return out
 
-    def backward(self, d_eps, tape):
-        """d_eps [B,4,H,W] fp32 -> LoRA grads accumulated in self.lora.grads."""
+    def backward(self, d_eps, tape, d_feats=None, need_input_grad=False):
+        """d_eps [B,4,H,W] fp32 -> LoRA grads accumulated in self.lora.grads (if any).
+        Feature-tap tapes (``forward(features=True, save=True)``) take ``d_feats`` (list of 9 gradients, entries may
+        be None) instead of d_eps.  ``need_input_grad`` also back-propagates through the first resnet and conv_in and
+        returns d sample [B,4,H,W] fp32 (the generator step's path through the frozen teacher, sd15_adv.py:1414-1424)."""
         W, lora, cfg = self.W, self.lora, self.cfg
         kind, _, sv = tape[-1]
-        assert kind == "out"
-        B, H, Wd = sv["B"], sv["H"], sv["W"]
-        d_hn = ops.conv_out_bwd(d_eps.contiguous(), W.conv_out[0], cfg.block_out_channels[0])
-        d_h = self._gn_bwd("conv_norm_out", d_hn, capi.ACT_SILU, cfg.norm_eps, sv["sgn"])
+        if kind == "out":
+            d_hn = ops.conv_out_bwd(d_eps.contiguous(), W.conv_out[0], cfg.block_out_channels[0])
+            d_h = self._gn_bwd("conv_norm_out", d_hn, capi.ACT_SILU, cfg.norm_eps, sv["sgn"])
+        else:
+            assert kind == "feats_end" and d_feats is not None
+            d_h = None
         d_skips = {}
         first_resnet = "down_blocks.0.resnets.0."  # its input (conv_in output) has nothing trainable upstream
         idx = len(tape) - 2
         while idx >= 0:
             kind, p, sv = tape[idx]
-            if kind == "resnet":
-                d_h = self.resnet_bwd(p, d_h, sv, need_dx=(p != first_resnet))
+            if kind == "feat":
+                df = d_feats[sv["k"]]
+                if df is not None:
+                    d_h = df if d_h is None else ops.add(d_h, df.view_as(d_h))
+            elif kind == "resnet":
+                d_h = self.resnet_bwd(p, d_h, sv, need_dx=(need_input_grad or p != first_resnet))
             elif kind == "transformer":
                 d_h = self.transformer_bwd(p, d_h, sv)
             elif kind == "cat":
@@ -534,6 +563,12 @@ class UNet:
                 if si is not None and si in d_skips:
                     d_h = ops.add(d_h, d_skips.pop(si).view_as(d_h))
             idx -= 1
+        if need_input_grad:
+            # d sample = input gradient of conv_in (4 <- C0): the conv_out kernel with in/out-transposed, tap-flipped weights
+            sv = tape[0][2]
+            w = W.conv_in[0]                                              # [C0, 4, 3, 3]
+            wt = w.flip(2, 3).permute(1, 0, 2, 3).contiguous()            # [4, C0, 3, 3]
+            return ops.conv_out_fwd(d_h, wt, None, sv["B"], sv["H"], sv["W"])
         return None
 
     def _skip_index_of_input(self, tape, idx):

@@ -205,3 +205,75 @@ class Distiller:
     def grad_norm(self):
         """Host read of the last global grad norm (forces a sync; for logging only)."""
         return math.sqrt(float(self.lora.gradsq.item())) / self.world_size
+
+
+class AdvDistiller(Distiller):
+    """PCM-LoRA + latent adversarial consistency (reference: train_pcm_lora_sd15_adv.py:1288-1431).
+    Even ``global_step``: discriminator update only; odd: student update with loss_cm + adv_weight * g_loss."""
+
+    def __init__(self, weights, lora, cfg, discriminator, adv_weight=0.1, adv_lr=1e-5, world_size=1, process_group=None):
+        super().__init__(weights, lora, cfg, world_size, process_group)
+        self.disc, self.adv_weight, self.adv_lr = discriminator, adv_weight, adv_lr
+        self.adv_lr_dev = torch.full((1,), float(adv_lr), dtype=torch.float32, device=self.device)
+
+    def step_adv(self, global_step, latents, prompt_embeds, uncond_prompt_embeds, noise, index, w, noise_fake, noise_real, adv_u,
+                 lr=None):
+        """adv_u [B] in [0,1): adv_timesteps = end_timesteps + floor(adv_u * (T // multiphase))   (:1288-1298)."""
+        cfg, T, disc = self.cfg, self.tables, self.disc
+        B = latents.shape[0]
+        is_d = (global_step % 2 == 0)                                                           # :1375 / :1399
+        start_t, t_n = self.timesteps_for(index)
+        noisy = ops.add_noise(latents, noise, T.acp, start_t)
+        if is_d:     # the student forward is not back-propagated on discriminator steps: no tape
+            eps_s, tape = self.student.forward(noisy, start_t, prompt_embeds), None
+        else:
+            eps_s, tape = self.student.forward(noisy, start_t, prompt_embeds, save=True)
+        model_pred, coef, end_t = ops.phase_jump(eps_s, noisy, start_t, index, T.acp, T.acp_prev, T.ddim_timesteps_prev, T.edges, target_mode=False)
+        span = cfg.num_train_timesteps // cfg.multiphase
+        adv_t = end_t + torch.clamp((adv_u * span).long(), max=span - 1)
+        fake_adv, sr = ops.noise_travel(model_pred, noise_fake, T.acp, end_t, adv_t)            # :1303-1305
+        if cfg.not_apply_cfg_solver:
+            eps_c = self.teacher.forward(noisy, start_t, prompt_embeds)
+            eps_u = eps_c
+        else:
+            both = self.teacher.forward(torch.cat([noisy, noisy]), torch.cat([start_t, start_t]), torch.cat([prompt_embeds, uncond_prompt_embeds]))
+            eps_c, eps_u = both[:B], both[B:]
+        x_prev64, x_prev32 = ops.cfg_ddim_step(eps_c, eps_u, noisy, start_t, index, w, T.acp, T.acp_prev)
+        eps_t = self.student.forward(x_prev32, t_n, prompt_embeds)
+        target, _, _ = ops.phase_jump(eps_t, x_prev64, t_n, index, T.acp, T.acp_prev, T.ddim_timesteps_prev, T.edges, target_mode=True)
+        out = dict(model_pred=model_pred, target=target, end_timesteps=end_t, adv_timesteps=adv_t, fake_adv=fake_adv, is_d=is_d)
+        if is_d:
+            real_adv, _ = ops.noise_travel(target, noise_real, T.acp, end_t, adv_t)             # :1379-1381
+            feats = self.teacher.forward(torch.cat([fake_adv, real_adv]), torch.cat([adv_t, adv_t]),
+                                         torch.cat([prompt_embeds, prompt_embeds]), features=True)
+            logits, dtape = disc.forward(feats, save=True)
+            disc.grads.zero_()
+            out["d_loss"] = disc.d_loss_backward(logits, dtape, B)                              # :1383-1391
+            out["real_adv"] = real_adv
+            self._disc_optimizer_step()
+            return out
+        feats, utape = self.teacher.forward(fake_adv, adv_t, prompt_embeds, features=True, save=True)
+        logits, dtape = disc.forward(feats, save=True)
+        g_loss, d_feats = disc.g_loss_backward(logits, dtape, grad_scale=self.adv_weight)       # :1414-1421
+        d_fake = self.teacher.backward(None, utape, d_feats=d_feats, need_input_grad=True)
+        loss_cm, d_eps = ops.consistency_loss(model_pred, target, coef, cfg.loss_type == "huber", cfg.huber_c)
+        ops.scale_add_rows(d_eps, d_fake, sr, coef)          # d fake_adv/d model_pred = sqrt(r); d model_pred/d eps = coef
+        out.update(loss_cm=loss_cm, g_loss=g_loss, d_fake_adv=d_fake, d_eps=d_eps)
+        self.lora.zero_grad()
+        self.student.backward(d_eps, tape)
+        if lr is not None:
+            self.lr_dev.fill_(float(lr))
+        self.optimizer_step()
+        out["grad_sumsq"] = self.lora.gradsq
+        return out
+
+    def _disc_optimizer_step(self):
+        """optimizer_discriminator (:1026-1032): AdamW(lr=adv_lr, betas=(0, 0.999)), global-norm clip over the heads."""
+        cfg, d = self.cfg, self.disc
+        if self.world_size > 1:
+            torch.distributed.all_reduce(d.grads, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+        d.step_dev += 1
+        ops.sumsq(d.grads, d.gradsq)
+        ops.adamw_clip_step(d.params, d.grads, d.exp_avg, d.exp_avg_sq, d.gradsq, cfg.max_grad_norm, self.adv_lr, 0.0, 0.999,
+                            cfg.adam_epsilon, cfg.adam_weight_decay, 1, 1.0 / self.world_size, step_dev=d.step_dev, lr_dev=self.adv_lr_dev)
+        d.repack()

@@ -251,3 +251,133 @@ def case_lora_repack(dev):
         bf, bd = ops.pack_linear(m.B.view(m.N, 64), scale=lora.scaling)
         assert torch.equal(m.A_fwd.cpu(), f.cpu()) and torch.equal(m.A_bwd.cpu(), d.cpu().view_as(m.A_bwd)), m.path
         assert torch.equal(m.Bs_fwd.cpu(), bf.cpu()) and torch.equal(m.Bs_bwd.cpu(), bd.cpu()), m.path
+
+
+def case_adv_kernels(dev, golden):
+    g = golden
+    # noise_travel: bit-exact vs the fixture from the reference's own scheduler source
+    acp = g["alphas_cumprod"].to(dev)
+    out, sr = ops.noise_travel(g["x"].to(dev), g["noise"].to(dev), acp, g["start_timesteps"].to(dev), g["travel_target_t"].to(dev))
+    assert torch.equal(out.cpu(), g["noise_travel"])
+    r = g["alphas_cumprod"][g["travel_target_t"]] / g["alphas_cumprod"][g["start_timesteps"]]
+    close(sr, r ** 0.5, 1e-6, 1e-7, "sqrt_r")
+    # hinge losses vs the fixture (reference Discriminator.d_loss / g_loss, 3 heads)
+    loss = torch.zeros(1, dtype=torch.float64, device=dev)
+    dfs = []
+    for i in range(3):
+        df, dr = ops.hinge_loss(g[f"hinge_fake_{i}"].to(dev).reshape(-1), g[f"hinge_real_{i}"].to(dev).reshape(-1), 0, 1.0 / 3, loss)
+        dfs.append((df, dr))
+    assert abs(loss.item() - float(g["hinge_d_loss"])) < 1e-6
+    f0 = g["hinge_fake_0"].clone().requires_grad_(True)
+    r0 = g["hinge_real_0"].clone().requires_grad_(True)
+    ((torch.relu(f0 + 1).mean() + torch.relu(1 - r0).mean()) / 3).backward()
+    close(dfs[0][0], f0.grad.reshape(-1), 1e-6, 1e-9, "d_fake")
+    close(dfs[0][1], r0.grad.reshape(-1), 1e-6, 1e-9, "d_real")
+    loss.zero_()
+    for i in range(3):
+        ops.hinge_loss(g[f"hinge_fake_{i}"].to(dev).reshape(-1), None, 1, 1.0 / 3, loss)
+    assert abs(loss.item() - float(g["hinge_g_loss"])) < 1e-6
+    # GroupNorm + LeakyReLU fwd / bwd / param grads
+    B, HW, C, G = 2, 40, 64, 32
+    x = rnd(B, HW, C, seed=1, dev=dev, shift=0.2)
+    gamma = rnd(C, seed=2, dev=dev, dtype=torch.float32, shift=1.0, scale=0.2)
+    beta = rnd(C, seed=3, dev=dev, dtype=torch.float32, scale=0.2)
+    dy = rnd(B, HW, C, seed=4, dev=dev)
+    y, stats = ops.groupnorm_fwd(x, gamma, beta, G, 1e-5, capi.ACT_LEAKY)
+    xr = x.float().cpu().permute(0, 2, 1).requires_grad_(True)
+    gr, br = gamma.cpu().clone().requires_grad_(True), beta.cpu().clone().requires_grad_(True)
+    ref = F.leaky_relu(F.group_norm(xr, G, gr, br, 1e-5), 0.01)
+    close(y.permute(0, 2, 1), ref.detach(), 1e-2, 1e-2, "gn leaky fwd")
+    ref.backward(dy.float().cpu().permute(0, 2, 1))
+    dx = ops.groupnorm_bwd(x, dy, stats, gamma, beta, G, 1e-5, capi.ACT_LEAKY)
+    close(dx.permute(0, 2, 1), xr.grad, 1e-2, 2e-2, "gn leaky bwd")
+    dg, db = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+    ops.groupnorm_param_grad(x, dy, stats, gamma, beta, dg, db, G, 1e-5, capi.ACT_LEAKY)
+    close(dg, gr.grad, 2e-3, 2e-2, "dgamma")
+    close(db, br.grad, 2e-3, 2e-2, "dbeta")
+    # rowdot
+    M, C = 77, 64
+    xx = rnd(M, C, seed=5, dev=dev)
+    w = rnd(C, seed=6, dev=dev, dtype=torch.float32, scale=0.2)
+    bias = rnd(1, seed=7, dev=dev, dtype=torch.float32)
+    o = ops.rowdot_fwd(xx, w, bias)
+    close(o, xx.float().cpu() @ w.cpu() + bias.cpu(), 1e-5, 1e-5, "rowdot")
+    d = rnd(M, seed=8, dev=dev, dtype=torch.float32)
+    dw, dbb = torch.zeros(C, device=dev), torch.zeros(1, device=dev)
+    dxx = ops.rowdot_bwd(xx, w, d, dw, dbb)
+    close(dxx, d.cpu()[:, None] * w.cpu()[None, :], 1e-2, 1e-2, "rowdot dx")
+    close(dw, (d.cpu()[:, None] * xx.float().cpu()).sum(0), 1e-4, 1e-4, "rowdot dw")
+    close(dbb, d.cpu().sum().reshape(1), 1e-5, 1e-5, "rowdot db")
+
+
+def case_discriminator_heads(dev, dims=(64, 128), hw=(6, 3), B=2, nh=2):
+    """Discriminator heads forward / backward (parameter grads and feature grads) vs torch autograd of the
+    oracle's restatement of DiscriminatorHead (pinned to the reference source by the golden fixture)."""
+    from oracle import pcm_math as M
+    from pcm_amd.discriminator import Discriminator
+    disc = Discriminator(dims, num_h_per_head=nh, device=dev, seed=4)
+    feats, feats_ref = [], []
+    for i, (C, h) in enumerate(zip(dims, hw)):
+        f = rnd(B, h * h, C, seed=20 + i, dev=dev)
+        feats.append((f, h, h))
+        feats_ref.append(f.float().cpu().view(B, h, h, C).permute(0, 3, 1, 2).requires_grad_(True))
+    logits, tape = disc.forward(feats, save=True)
+    sd = {k: v.cpu().clone().requires_grad_(True) for k, v in disc.state_dict().items()}
+    ref_logits = []
+    for k in range(len(dims)):
+        for h in range(nh):
+            ref_logits.append(M.discriminator_head(sd, feats_ref[k], prefix=f"heads.{k}.{h}."))
+    d_logits, loss = [], 0.0
+    for i, (lg, rl) in enumerate(zip(logits, ref_logits)):
+        close(lg, rl.detach().permute(0, 2, 3, 1).reshape(-1), 3e-2, 3e-2, f"logit {i}")
+        d = rnd(lg.numel(), seed=40 + i, dev=dev, dtype=torch.float32)
+        d_logits.append(d)
+        loss = loss + (rl.permute(0, 2, 3, 1).reshape(-1) * d.cpu()).sum()
+    loss.backward()
+    disc.grads.zero_()
+    d_feats = disc.backward(d_logits, tape, param_grads=True, feature_grads=True)
+    rel = lambda a, b: float((a.double().cpu() - b.double()).norm() / (b.double().norm() + 1e-12))
+    cnt = {}
+    for k, hd in disc.heads:
+        h = cnt.get(k, 0); cnt[k] = h + 1
+        for n, t in hd.g.items():
+            v = t
+            if n in ("conv1.0.weight", "conv2.0.weight"):
+                v = v.permute(0, 3, 1, 2)
+            elif n == "conv_out.weight":
+                v = v.reshape(1, hd.C, 1, 1)
+            r = rel(v, sd[f"heads.{k}.{h}.{n}"].grad)
+            assert r < 0.1, (k, h, n, r)
+    for k, (C, h) in enumerate(zip(dims, hw)):
+        r = rel(d_feats[k].view(B, h, h, C).permute(0, 3, 1, 2), feats_ref[k].grad)
+        assert r < 0.1, ("d_feat", k, r)
+
+
+def case_teacher_input_grad(dev):
+    """Feature-tap forward (reference modified_forward) and the generator-step backward through the frozen teacher
+    down to d sample, with random cotangents on all 9 features, vs the oracle's autograd."""
+    from oracle import unet_sd15 as O
+    from pcm_amd.model import UNet, UNetWeights
+    from pcm_amd.unet_spec import UNetConfig
+    kw = dict(block_out_channels=(64, 128, 128, 128), cross_attention_dim=64, heads=2, norm_num_groups=32)
+    oc, pc = O.UNetConfig(**kw), UNetConfig(**kw)
+    sd = O.init_state_dict(oc, 0)
+    W = UNetWeights(pc, sd, dev)
+    g = torch.Generator().manual_seed(3)
+    B, Hh = 2, 8
+    x = torch.randn(B, 4, Hh, Hh, generator=g); t = torch.tensor([100, 700]); ctx = torch.randn(B, 7, 64, generator=g)
+    xr = x.clone().requires_grad_(True)
+    feats_ref = O.unet_forward(oc, sd, xr, t, ctx, return_features=True)
+    teacher = UNet(W, None)
+    feats, tape = teacher.forward(x.to(dev), t.to(dev), ctx.to(dev), features=True, save=True)
+    assert len(feats) == 9
+    d_feats, loss = [], 0.0
+    for k, ((f, H, Wd), fr) in enumerate(zip(feats, feats_ref)):
+        close(f.float().view(B, H, Wd, -1).permute(0, 3, 1, 2), fr.detach(), 3e-2, 3e-2 * float(fr.detach().abs().max()), f"feature {k}")
+        d = torch.randn(fr.shape, generator=torch.Generator().manual_seed(50 + k))
+        loss = loss + (fr * d).sum()
+        d_feats.append(d.permute(0, 2, 3, 1).reshape(B, H * Wd, -1).bfloat16().contiguous().to(dev))
+    loss.backward()
+    d_in = teacher.backward(None, tape, d_feats=d_feats, need_input_grad=True)
+    r = float((d_in.cpu() - xr.grad).norm() / xr.grad.norm())
+    assert r < 0.08, r

@@ -1,0 +1,94 @@
+"""Host-emulation end-to-end check of the adversarial step (discriminator + generator updates) on a tiny
+SD1.5-topology config against the oracle's autograd (reference: train_pcm_lora_sd15_adv.py, discriminator_sd15.py)."""
+import pytest
+import torch
+
+from emu_lib import emu_lib
+from pcm_amd import capi
+
+
+@pytest.fixture(autouse=True)
+def _use_emu():
+    capi.set_lib(emu_lib())
+    yield
+    capi.set_lib(None)
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("global_step", [0, 1])
+def test_adv_step_vs_oracle(global_step):
+    from oracle import pcm_step as OS
+    from oracle import unet_sd15 as O
+    from pcm_amd.discriminator import Discriminator
+    from pcm_amd.model import LoraState, UNetWeights
+    from pcm_amd.trainer import AdvDistiller, StepConfig
+    from pcm_amd.unet_spec import UNetConfig
+    kw = dict(block_out_channels=(64, 128), layers_per_block=1, cross_attention_dim=64, heads=2, norm_num_groups=32)   # 2-level UNet: 5 tapped features
+    oc, pc = O.UNetConfig(**kw), UNetConfig(**kw)
+    sd = O.init_state_dict(oc, 0)
+    W = UNetWeights(pc, sd, "cpu")
+    lora = LoraState(pc, 64, 8.0, "cpu", seed=1, b_std=0.05)
+    dims = (64, 128, 128, 128, 64)    # feature widths of this UNet (down x2, mid, up x2)
+    disc = Discriminator(dims, num_h_per_head=1, device="cpu", seed=2)
+    ocfg = OS.StepConfig(multiphase=2, loss_type="huber", w_min=4.0, w_max=5.0)
+    B = 2
+    inp = OS.draw_inputs(B, ocfg, seed=5, latent_hw=8, ctx_len=7, ctx_dim=64)
+    g = torch.Generator().manual_seed(9)
+    inp["noise_fake"] = torch.randn(B, 4, 8, 8, generator=g)
+    inp["noise_real"] = torch.randn(B, 4, 8, 8, generator=g)
+    inp["adv_u"] = torch.rand(B, generator=g)
+    olora = {p: (lora.A_peft(m).clone(), m.B.clone()) for p, m in lora.modules.items()}
+    dsd = disc.state_dict()
+    ref = OS.distill_step_adv(oc, sd, olora, {k.replace("heads.", "heads."): v for k, v in dsd.items()}, inp, ocfg, global_step, adv_weight=0.1)
+    # the oracle's discriminator_forward expects nh heads per feature: match num_h_per_head=1
+    cfg = StepConfig(multiphase=2, loss_type="huber", w_min=4.0, w_max=5.0, learning_rate=0.0)
+    D = AdvDistiller(W, lora, cfg, disc, adv_weight=0.1, adv_lr=0.0)
+    p_lora, p_disc = lora.params.clone(), disc.params.clone()
+    out = D.step_adv(global_step, inp["latents"], inp["prompt_embeds"], inp["uncond_prompt_embeds"], inp["noise"], inp["index"], inp["w"],
+                     inp["noise_fake"], inp["noise_real"], inp["adv_u"])
+    assert torch.equal(out["adv_timesteps"], ref["adv_timesteps"])
+    rel = lambda a, b: float((a.double() - b.double()).norm() / (b.double().norm() + 1e-6 * b.numel() ** 0.5))
+    assert rel(out["fake_adv"], ref["fake_adv"]) < 3e-2
+    if global_step % 2 == 0:
+        assert abs(out["d_loss"].item() - float(ref["d_loss"])) < 3e-2 * abs(float(ref["d_loss"]))
+        mine = disc.state_dict()
+        gstate = {}
+        cnt = {}
+        for k, hd in disc.heads:
+            h = cnt.get(k, 0); cnt[k] = h + 1
+            for n, t in hd.g.items():
+                v = t
+                if n in ("conv1.0.weight", "conv2.0.weight"):
+                    v = v.permute(0, 3, 1, 2)
+                elif n == "conv_out.weight":
+                    v = v.view(1, hd.C, 1, 1)
+                gstate[f"heads.{k}.{h}.{n}"] = v
+        num = den = 0.0
+        for n, gr in ref["head_grads"].items():
+            num += float(((gstate[n] - gr) ** 2).sum()); den += float((gr ** 2).sum())
+            assert rel(gstate[n], gr) < 0.4, (n, rel(gstate[n], gr))   # 1x1-pixel features + 4-element GN groups are bf16-noisy
+        print("d step: d_loss %.5f (oracle %.5f), head-grad rel err %.3e" % (out["d_loss"].item(), float(ref["d_loss"]), (num / den) ** 0.5))
+        # the hinge gradient is +1/n on fake rows and -1/n on real rows: every parameter gradient is a heavily
+        # cancelling sum, and on this tiny config (1x1..8x8 maps, 4-channel GN groups) bf16 rounding of the summands
+        # shows up as 10-30 % relative error; tests/kernel_cases.py::case_discriminator_heads checks the same code
+        # with non-cancelling cotangents at < 10 %.  Here: direction + magnitude.
+        mine_all = torch.cat([gstate[n].reshape(-1) for n in ref["head_grads"]])
+        ref_all = torch.cat([gr.reshape(-1) for gr in ref["head_grads"].values()])
+        cos = float((mine_all * ref_all).sum() / (mine_all.norm() * ref_all.norm()))
+        assert cos > 0.97 and (num / den) ** 0.5 < 0.25, (cos, (num / den) ** 0.5)
+        assert torch.equal(lora.params, p_lora)            # the student is untouched on discriminator steps
+    else:
+        assert abs(out["loss_cm"].item() - float(ref["loss_cm"])) < 3e-2 * abs(float(ref["loss_cm"]))
+        assert abs(out["g_loss"].item() - float(ref["g_loss"])) < 3e-2 * abs(float(ref["g_loss"]))
+        mine = torch.cat([t.reshape(-1) for m in lora.modules.values() for t in (lora.gA_peft(m), m.gB)])
+        refg = torch.cat([g_.reshape(-1) for g_ in ref["lora_grads"]])
+        print("g step: loss_cm %.5f/%.5f g_loss %.5f/%.5f lora-grad rel err %.3e" % (out["loss_cm"].item(), float(ref["loss_cm"]),
+              out["g_loss"].item(), float(ref["g_loss"]), rel(mine, refg)))
+        # with every logit on the active side of the hinge the cotangent is CONSTANT over pixels and GroupNorm's
+        # backward removes exactly that component: the adversarial part of the gradient is a near-total cancellation
+        # on this tiny config and carries ~30 % bf16 noise (measured: d loss/d fake_adv rel err 0.30 with zero hinge
+        # flips); the same code path with generic cotangents is checked at 4 % (teacher input gradient) and < 10 %
+        # (heads) in tests/kernel_cases.py / tools.  Here: losses tight, gradient direction + magnitude.
+        cos = float((mine.double() * refg.double()).sum() / (mine.double().norm() * refg.double().norm()))
+        assert cos > 0.95 and rel(mine, refg) < 0.35, (cos, rel(mine, refg))
+        assert torch.equal(disc.params, p_disc)            # the heads are untouched on generator steps

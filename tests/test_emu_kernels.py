@@ -65,3 +65,16 @@ def test_attention(B, H, Lq, Lk, d, spike):
 
 def test_lora_repack():
     K.case_lora_repack("cpu")
+
+
+def test_adv_kernels(golden):
+    K.case_adv_kernels("cpu", golden)
+
+
+def test_discriminator_heads():
+    K.case_discriminator_heads("cpu")
+
+
+@pytest.mark.slow
+def test_teacher_input_grad():
+    K.case_teacher_input_grad("cpu")

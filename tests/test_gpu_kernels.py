@@ -71,3 +71,15 @@ def test_attention(B, H, Lq, Lk, d, spike):
 
 def test_lora_repack():
     K.case_lora_repack("cuda")
+
+
+def test_adv_kernels(golden):
+    K.case_adv_kernels("cuda", golden)
+
+
+def test_discriminator_heads():
+    K.case_discriminator_heads("cuda", dims=(320, 1280), hw=(32, 8), B=2, nh=2)
+
+
+def test_teacher_input_grad():
+    K.case_teacher_input_grad("cuda")
