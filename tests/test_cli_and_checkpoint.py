@@ -54,6 +54,22 @@ def test_cli_flags_and_defaults_match_reference():
             assert ours[k] == v, (k, ours[k], v)
 
 
+def test_adv_cli_adds_adv_flags_with_reference_defaults():
+    """train_pcm_lora_sd15_adv.py:741-742 adds --adv_weight (0.1) and --adv_lr (1e-5) to the same flag set."""
+    sys.path.insert(0, PKG)
+    spec = importlib.util.spec_from_file_location("pcm_cli_adv", os.path.join(PKG, "train_pcm_lora_sd15_adv.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    a = m.parse_args(["--pretrained_teacher_model", "x"])
+    assert a.adv_weight == 0.1 and a.adv_lr == 1e-5 and a.multiphase == 8
+    a = m.parse_args(["--pretrained_teacher_model=x", "--adv_weight=0.3", "--adv_lr", "3e-5", "--loss_type=huber"])
+    assert a.adv_weight == 0.3 and a.adv_lr == 3e-5 and a.loss_type == "huber"
+    ref = "/root/reference/code/text_to_image_sd15/train_pcm_lora_sd15_adv.py"
+    if os.path.exists(ref):
+        src = open(ref).read()
+        assert re.search(r'"--adv_weight".{0,80}default=0\.1', src, re.S) and re.search(r'"--adv_lr".{0,80}default=1e-5', src, re.S)
+
+
 def test_capi_exports_every_declared_symbol():
     from pcm_amd import build as B
     from pcm_amd import capi

@@ -1,0 +1,63 @@
+"""GPU parity of the adversarial step (D and G updates) at the real SD1.5 size vs the CPU oracle (bs 1)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("global_step", [0, 1])
+def test_adv_step_full_size(global_step):
+    from oracle import pcm_step as OS
+    from oracle import unet_sd15 as O
+    from pcm_amd import capi
+    from pcm_amd.discriminator import Discriminator
+    from pcm_amd.model import LoraState, UNetWeights
+    from pcm_amd.trainer import AdvDistiller, StepConfig
+    from pcm_amd.unet_spec import UNetConfig
+    capi.set_lib(None)
+    capi.lib()
+    oc = O.UNetConfig.sd15()
+    sd = O.init_state_dict(oc, 0)
+    W = UNetWeights(UNetConfig.sd15(), sd, "cuda")
+    lora = LoraState(UNetConfig.sd15(), 64, 8.0, "cuda", seed=1, b_std=0.02)
+    disc = Discriminator(device="cuda", seed=2, num_h_per_head=1)      # 9 heads (one per feature) keeps the CPU oracle affordable
+    ocfg = OS.StepConfig(multiphase=2, loss_type="huber", w_min=4.0, w_max=5.0)
+    B = 1
+    inp = OS.draw_inputs(B, ocfg, seed=11)
+    inp["index"] = torch.tensor([30])
+    g = torch.Generator().manual_seed(9)
+    inp["noise_fake"], inp["noise_real"] = torch.randn(B, 4, 64, 64, generator=g), torch.randn(B, 4, 64, 64, generator=g)
+    inp["adv_u"] = torch.rand(B, generator=g)
+    olora = {p: (lora.A_peft(m).detach().cpu().clone(), m.B.detach().cpu().clone()) for p, m in lora.modules.items()}
+    dsd = {k: v.cpu() for k, v in disc.state_dict().items()}
+    ref = OS.distill_step_adv(oc, sd, olora, dsd, inp, ocfg, global_step, adv_weight=0.1)
+    cfg = StepConfig(multiphase=2, loss_type="huber", w_min=4.0, w_max=5.0, learning_rate=0.0)
+    D = AdvDistiller(W, lora, cfg, disc, adv_weight=0.1, adv_lr=0.0)
+    dev = {k: v.cuda() for k, v in inp.items()}
+    out = D.step_adv(global_step, dev["latents"], dev["prompt_embeds"], dev["uncond_prompt_embeds"], dev["noise"], dev["index"], dev["w"],
+                     dev["noise_fake"], dev["noise_real"], dev["adv_u"])
+    torch.cuda.synchronize()
+    rel = lambda a, b: float((a.double().cpu() - b.double()).norm() / (b.double().norm() + 1e-6 * b.numel() ** 0.5))
+    assert torch.equal(out["adv_timesteps"].cpu(), ref["adv_timesteps"])
+    assert rel(out["fake_adv"], ref["fake_adv"]) < 3e-2
+    if global_step % 2 == 0:
+        dl, rdl = out["d_loss"].item(), float(ref["d_loss"])
+        mine, refg, cnt = [], [], {}
+        for k, hd in disc.heads:
+            h = cnt.get(k, 0); cnt[k] = h + 1
+            for n, t in hd.g.items():
+                v = t.permute(0, 3, 1, 2) if n in ("conv1.0.weight", "conv2.0.weight") else t
+                mine.append(v.reshape(-1).cpu()); refg.append(ref["head_grads"][f"heads.{k}.{h}.{n}"].reshape(-1))
+        mine, refg = torch.cat(mine), torch.cat(refg)
+        cos = float((mine.double() * refg.double()).sum() / (mine.double().norm() * refg.double().norm()))
+        print("D step: d_loss %.5f / %.5f, head-grad rel %.3e cos %.4f" % (dl, rdl, rel(mine, refg), cos))
+        assert abs(dl - rdl) < 2e-2 * abs(rdl) and cos > 0.97
+    else:
+        mine = torch.cat([t.reshape(-1).cpu() for m in lora.modules.values() for t in (lora.gA_peft(m), m.gB)])
+        refg = torch.cat([g_.reshape(-1) for g_ in ref["lora_grads"]])
+        cos = float((mine.double() * refg.double()).sum() / (mine.double().norm() * refg.double().norm()))
+        print("G step: loss_cm %.5f / %.5f, g_loss %.5f / %.5f, lora-grad rel %.3e cos %.4f" % (out["loss_cm"].item(), float(ref["loss_cm"]),
+              out["g_loss"].item(), float(ref["g_loss"]), rel(mine, refg), cos))
+        assert abs(out["loss_cm"].item() - float(ref["loss_cm"])) < 2e-2 * abs(float(ref["loss_cm"]))
+        assert abs(out["g_loss"].item() - float(ref["g_loss"])) < 2e-2 * abs(float(ref["g_loss"]))
+        assert cos > 0.95
