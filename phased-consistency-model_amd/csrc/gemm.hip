@@ -16,32 +16,9 @@
 // taps / K tails fetch a 16-byte zero page.  MFMA: v_mfma_f32_32x32x16_bf16 with the WEIGHT tile
 // as the A operand, so every lane owns 4 consecutive output channels per accumulator quad
 // (8-byte bf16 stores, channel-contiguous).
-#include "pcm_common.h"
+#include "gemm_dev.h"
 
 __device__ __attribute__((aligned(16))) static const uint4 pcm_zero_page = {0u, 0u, 0u, 0u};
-
-struct SegDev {
-  const bf16_t* a;
-  const bf16_t* w;
-  int K, lda, mode, Hs, Ws, C, stride, src_mode, ktiles;
-};
-struct GemmDev {
-  SegDev seg[2];
-  int nseg, M, N, Ho, Wo;
-  const float* bias;
-  const bf16_t* rowvec;
-  int rpb;
-  const bf16_t* res;
-  int ldr;
-  void* out;
-  int ldo, out_f32, act;
-  float alpha;
-  int tiles_m, tiles_n;
-  int splitk, kt_per_split;   // split-K: blockIdx.y = K slice; raw fp32 partial tiles go to slab ws[slice][M][N]
-  float* ws;
-};
-
-__device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
 // NW waves as WGM x (NW/WGM); each wave owns a (32*TM) x (32*TN) sub-tile: block tile BM = 32*TM*WGM, BN = 32*TN*(NW/WGM)
 template <int NW, int WGM, int TM, int TN>
@@ -375,13 +352,48 @@ __global__ __launch_bounds__(256) void pcm_gemm_finalize_kernel(GemmDev g) {
 }
 
 // tile / split-K plan shared by pcm_gemm_bf16 and pcm_gemm_workspace_bytes
-struct GemmPlan { int BM, BN, tiles_m, tiles_n, splitk, kt_per_split; size_t ws_bytes; };
+struct GemmPlan { int BM, BN, tiles_m, tiles_n, splitk, kt_per_split; size_t ws_bytes; int big_fn; };
 static int g_force_bm = 0, g_force_bn = 0;
+static int g_big_mode = -1;   // -1: read PCM_GEMM_BIG once (0 = never use gemm8p, 1 = planner, 2 = wherever eligible); tuning only
+extern "C" void pcm_debug_gemm_big_mode(int mode) { g_big_mode = mode; }
+static int g_last_plan = 0;   // tests only: 1000*big_fn + splitk of the most recent pcm_gemm_bf16 launch
+extern "C" int pcm_debug_last_gemm_plan(void) { return g_last_plan; }
+static int big_mode() {
+  if (g_big_mode < 0) { const char* e = getenv("PCM_GEMM_BIG"); g_big_mode = e ? atoi(e) : 1; }
+  return g_big_mode;
+}
 // tuning hook (tools/ only): force the block tile of subsequent pcm_gemm_bf16 calls; (0,0) restores the planner
 extern "C" void pcm_debug_force_gemm_tile(int bm, int bn) { g_force_bm = bm; g_force_bn = bn; }
 
-static GemmPlan gemm_plan(int M, int N, int total_kt, bool allow_split) {
+// big_ok: the call satisfies gemm8p's preconditions (K%64==0 per segment, bf16 output with 16-B rows, < 2 GiB operands)
+static GemmPlan gemm_plan(int M, int N, int total_kt, bool allow_split, bool big_ok) {
   GemmPlan p;
+  p.big_fn = 0;
+  if (big_ok && !g_force_bm && big_mode() > 0 && M >= 256) {
+    // candidates 256x320 / 256x256 (+ split-K); pick by useful work per block-round of the 256 CUs
+    int best_fn = 0, best_s = 1; double best = 0.0;
+    for (int fn = 5; fn >= 4; fn--) {
+      const int bn = 64 * fn;
+      const long tm = (M + 255) / 256, tn = (N + bn - 1) / bn, tiles = tm * tn;
+      const double useful = ((double)M * N) / ((double)tm * 256 * tn * bn);
+      for (int s = 1; s <= 8; s++) {
+        if (s > 1 && (!allow_split || total_kt / s < 12)) break;
+        const long blocks = tiles * s, rounds = (blocks + 255) / 256;
+        double eff = useful * (double)blocks / (double)(rounds * 256);
+        if (s > 1) eff *= 0.85;                       // slab write + finalize pass
+        if (eff > best + 1e-9) { best = eff; best_fn = fn; best_s = s; }
+      }
+    }
+    const double need = big_mode() >= 2 ? 0.0 : 0.62;
+    if (best_fn && best >= need) {
+      p.big_fn = best_fn; p.BM = 256; p.BN = 64 * best_fn;
+      p.tiles_m = (M + 255) / 256; p.tiles_n = (N + p.BN - 1) / p.BN;
+      p.kt_per_split = (total_kt + best_s - 1) / best_s;
+      p.splitk = (total_kt + p.kt_per_split - 1) / p.kt_per_split;
+      p.ws_bytes = p.splitk > 1 ? (size_t)p.splitk * M * N * sizeof(float) : 0;
+      return p;
+    }
+  }
   if (g_force_bm) {
     p.splitk = 1; p.kt_per_split = total_kt; p.ws_bytes = 0; p.BM = g_force_bm; p.BN = g_force_bn;
     p.tiles_m = (M + p.BM - 1) / p.BM; p.tiles_n = (N + p.BN - 1) / p.BN;
@@ -417,9 +429,23 @@ static int gemm_total_kt(const pcm_gemm_seg* segs, int nseg) {
   for (int i = 0; i < nseg; i++) t += (segs[i].K + 63) / 64;
   return t;
 }
+static bool gemm_big_ok(const pcm_gemm_seg* segs, int nseg, const pcm_gemm_epi* e) {
+  for (int i = 0; i < nseg; i++) {
+    const pcm_gemm_seg& s = segs[i];
+    if (s.K % 64) return false;
+    const size_t a_bytes = s.mode == PCM_SEG_CONV3X3 ? (size_t)(e->M / (e->Ho * e->Wo > 0 ? e->Ho * e->Wo : 1)) * s.Hs * s.Ws * s.C * 2 : (size_t)e->M * s.lda * 2;
+    if (a_bytes >= 0x7ff00000u || (size_t)e->N * s.K * 2 >= 0x7ff00000u) return false;
+    if (s.mode == PCM_SEG_CONV3X3 && (e->Ho > 1023 || e->Wo > 1023 || e->M / (e->Ho * e->Wo) > 2047)) return false;
+  }
+  if (e->out_dtype == PCM_F32 || (e->N % 8) || (e->ldo % 8)) return false;
+  if (e->residual && ((e->ldr % 8) || (((uintptr_t)e->residual) & 15))) return false;
+  if (e->rowvec && (((uintptr_t)e->rowvec) & 15)) return false;
+  return true;
+}
 extern "C" size_t pcm_gemm_workspace_bytes(const pcm_gemm_seg* segs, int nseg, const pcm_gemm_epi* e) {
   if (!segs || !e || nseg < 1 || nseg > 2 || e->M <= 0 || e->N <= 0) return 0;
-  return gemm_plan(e->M, e->N, gemm_total_kt(segs, nseg), true).ws_bytes;
+  // the workspace is sized for the plan that would be used WITH a workspace; pcm_gemm_bf16 re-plans identically
+  return gemm_plan(e->M, e->N, gemm_total_kt(segs, nseg), true, gemm_big_ok(segs, nseg, e)).ws_bytes;
 }
 
 extern "C" int pcm_gemm_bf16(const pcm_gemm_seg* segs, int nseg, const pcm_gemm_epi* e, void* stream) {
@@ -455,13 +481,24 @@ extern "C" int pcm_gemm_bf16(const pcm_gemm_seg* segs, int nseg, const pcm_gemm_
   g.bias = e->bias; g.rowvec = (const bf16_t*)e->rowvec; g.rpb = e->rows_per_batch > 0 ? e->rows_per_batch : 1;
   g.res = (const bf16_t*)e->residual; g.ldr = e->ldr; g.out = e->out; g.ldo = e->ldo;
   g.out_f32 = e->out_dtype == PCM_F32; g.act = e->act; g.alpha = e->alpha;
-  GemmPlan pl = gemm_plan(e->M, e->N, gemm_total_kt(segs, nseg), e->workspace != nullptr);
+  GemmPlan pl = gemm_plan(e->M, e->N, gemm_total_kt(segs, nseg), e->workspace != nullptr, gemm_big_ok(segs, nseg, e));
   if (pl.splitk > 1) {
     PCM_CHECK(e->workspace_bytes >= pl.ws_bytes && PCM_ALIGNED16(e->workspace), PCM_EINVAL,
               "pcm_gemm_bf16: workspace too small (%zu < %zu) or unaligned", (size_t)e->workspace_bytes, pl.ws_bytes);
     g.ws = (float*)e->workspace;
   }
   g.tiles_m = pl.tiles_m; g.tiles_n = pl.tiles_n; g.splitk = pl.splitk; g.kt_per_split = pl.kt_per_split;
+  g_last_plan = 1000 * pl.big_fn + pl.splitk;
+  if (pl.big_fn) {
+    int rc = pcm_gemm8p_launch(g, pl.big_fn, stream);
+    if (rc) return rc;
+    if (pl.splitk > 1) {
+      long nq = (long)e->M * (e->N / 4);
+      long fb = (nq + 255) / 256; if (fb > PCM_GRID_CAP(2048)) fb = PCM_GRID_CAP(2048);
+      PCM_LAUNCH(pcm_gemm_finalize_kernel, dim3((int)fb), dim3(256), 0, stream, g);
+    }
+    return pcm_post_launch("pcm_gemm_bf16");
+  }
   dim3 grid(g.tiles_m * g.tiles_n, pl.splitk);
   size_t smem = 2 * (size_t)(pl.BM + pl.BN) * 128;
 #ifdef PCM_HOST_EMU

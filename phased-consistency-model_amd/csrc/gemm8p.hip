@@ -1,0 +1,352 @@
+// pcm_gemm8p_kernel — the large-tile member of the pcm_gemm_bf16 family (same contract as gemm.hip:
+// Linear / conv1x1 / implicit-im2col conv3x3 with an optional second K segment for the LoRA branch).
+//
+// Why a second kernel: the 4-wave 128x128 tile of gemm.hip refills (128+128) x 128 B of LDS per 2.1 MFLOP, which
+// is as many L1->LDS cycles (64 B/clk/CU) as MFMA cycles -- it tops out near 0.85 PFLOP/s.  This kernel owns a
+// 256 x (64*FN) tile per CU (FN = 5: 256x320, all of N for the 320-channel layers; FN = 4: 256x256), 8 waves as
+// 2 (M) x 4 (N), per-wave 128 x (16*FN) outputs held in 8 x FN 16x16 accumulators, BK = 64.
+//
+// Pipeline (one block per CU, so latency is hidden inside the block):
+//   * each K-tile is staged as four LDS-DMA pieces: A0 / A1 (the two 64-row halves of every wave's pixel rows) and
+//     B0 / B1 (the first 16*F0 and last 32 of every wave's channel columns); two K-tile buffers.
+//   * a K-tile is four phases, one accumulator quadrant each:  C00 = A0xB0, C01 = A0xB1, C11 = A1xB1, C10 = A1xB0.
+//     Every phase = { ds_read the operand fragments it needs; issue ONE piece of a later K-tile into the region
+//     whose last reader finished the phase before; lgkmcnt(0); barrier; MFMAs; barrier }.
+//   * pieces land two K-tiles ahead (B0: one), retired by a single counted wait per K-tile (vmcnt(6), never 0 in
+//     steady state) placed before the first barrier of phase 4, i.e. one full phase before the first read.
+//   * the two M wave-groups run one barrier apart (group 1 executes one extra barrier up front): on every SIMD one
+//     wave is in its MFMA half-phase while the other reads LDS / issues DMA.
+// Sources are addressed through raw buffer resources: per-row 32-bit byte offsets in VGPRs, the K advance in the
+// scalar offset; out-of-range rows / padding taps use an offset beyond num_records, which the hardware zero-fills.
+#include "gemm_dev.h"
+
+#define PCM_RSRC_FLAGS 0x00020000
+#define PCM_OOB 0x80000000u
+
+template <int F0>
+__global__ __launch_bounds__(512) void pcm_gemm8p_kernel(GemmDev g) {
+#if defined(__HIP_DEVICE_COMPILE__) || defined(PCM_HOST_EMU)   // the host pass only needs the launch stub (buffer-resource builtins are device-only)
+  constexpr int F1 = 2, FN = F0 + F1, WNC = 16 * FN, BN = 4 * WNC;
+  constexpr int RB0 = 64 * F0;                                         // LDS rows of B part 0 (4 waves x 16*F0)
+  constexpr int OFF_A1 = 128 * 128, OFF_B0 = 256 * 128, OFF_B1 = OFF_B0 + RB0 * 128;
+  constexpr int STAGE = (256 + BN) * 128;
+  PCM_DYN_SMEM(smem);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;        // waves w and w+4 share a SIMD: one from each M group
+  int nwg = g.tiles_m * g.tiles_n, bid = blockIdx.x;
+  {
+    int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tile_n = bid % g.tiles_n, tile_m = bid / g.tiles_n;
+  const int m0 = tile_m * 256, n0 = tile_n * BN;
+
+  // ---- loader geometry: every LDS-DMA instruction of a wave fills 8 rows x 128 B (lane -> row lane>>3, 16-B slot lane&7);
+  // this wave owns groups wave + 8j of every piece, so its swizzled source chunk is the same for all its rows.
+  const int lrow = lane >> 3;
+  const unsigned csw16 = (unsigned)(((lane & 7) ^ ((4 * (wave & 1) + (lrow >> 1)) & 7)) << 4);
+  const int HoWo = g.Ho * g.Wo;
+  auto a_tile_row = [&](int h, int j) { int r = 8 * (wave + 8 * j) + lrow; return 128 * (r >> 6) + 64 * h + (r & 63); };
+  auto b_tile_col = [&](int p, int j) {
+    const int fp = p ? F1 : F0;
+    int r = 8 * (wave + 8 * j) + lrow;
+    return WNC * (r / (16 * fp)) + (p ? 16 * F0 : 0) + r % (16 * fp);
+  };
+
+  // ---- K iterators (wave-uniform).  A pieces walk (segment, tap, 64-channel chunk); B pieces walk (segment, K-tile).
+  int total_kt = g.seg[0].ktiles + (g.nseg > 1 ? g.seg[1].ktiles : 0);
+  int kt0 = 0;
+  if (g.splitk > 1) {
+    kt0 = blockIdx.y * g.kt_per_split;
+    int kt1 = kt0 + g.kt_per_split; if (kt1 > total_kt) kt1 = total_kt;
+    total_kt = kt1 - kt0;
+  }
+  const int T = total_kt;
+  // the segment descriptors in use are held as local (SGPR) copies: no runtime-indexed kernarg access
+  int a_seg = 0, a_tap = 0, a_chunk = 0, a_nchunk, a_ntap;
+  int b_seg[2], b_kt[2];
+  SegDev ca = g.seg[0];
+  {
+    int k = kt0;
+    if (k >= g.seg[0].ktiles) { k -= g.seg[0].ktiles; a_seg = 1; ca = g.seg[1]; }
+    b_seg[0] = b_seg[1] = a_seg; b_kt[0] = b_kt[1] = k;
+    a_nchunk = (ca.mode == PCM_SEG_CONV3X3 ? ca.C : ca.K) >> 6;
+    a_ntap = ca.mode == PCM_SEG_CONV3X3 ? 9 : 1;
+    a_tap = k / a_nchunk; a_chunk = k - a_tap * a_nchunk;
+  }
+  const bf16_t* b_w[2] = {ca.w, ca.w};
+  int b_K[2] = {ca.K, ca.K}, b_nkt[2] = {ca.ktiles, ca.ktiles};
+  int a_key[2][2];          // per A row: plain -> m, conv -> b<<20 | y<<10 | x ; -1 = row beyond M
+  unsigned a_voff[2][2];    // byte offset of the row's 16-B chunk for the current (segment, tap)
+  unsigned w_voff0[F0], w_voff1[F1];
+  auto a_rekey = [&]() {
+    const SegDev& cs = ca;
+#pragma unroll
+    for (int h = 0; h < 2; h++)
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        int m = m0 + a_tile_row(h, j);
+        int key = m;
+        if (cs.mode == PCM_SEG_CONV3X3) {
+          int bb = m / HoWo, rem = m - bb * HoWo, y = rem / g.Wo, x = rem - y * g.Wo;
+          key = (bb << 20) | (y << 10) | x;
+        }
+        a_key[h][j] = m < g.M ? key : -1;
+      }
+  };
+  auto a_prepare_tap = [&]() {
+    const SegDev& cs = ca;
+    const int ty = a_tap / 3, tx = a_tap - ty * 3;
+#pragma unroll
+    for (int h = 0; h < 2; h++)
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        const int key = a_key[h][j];
+        bool ok = key >= 0;
+        unsigned off;
+        if (cs.mode == PCM_SEG_PLAIN) {
+          off = (unsigned)key * (unsigned)(cs.lda * 2);
+        } else {
+          int bb = key >> 20, y = (key >> 10) & 1023, x = key & 1023;
+          int vy = y * cs.stride + ty - 1, vx = x * cs.stride + tx - 1;
+          int sh = cs.src_mode != PCM_SRC_DIRECT;
+          ok = ok && vy >= 0 && vy < (cs.Hs << sh) && vx >= 0 && vx < (cs.Ws << sh);
+          if (cs.src_mode == PCM_SRC_ZEROINS2) ok = ok && !((vy | vx) & 1);
+          off = (unsigned)(((bb * cs.Hs + (vy >> sh)) * cs.Ws + (vx >> sh))) * (unsigned)(cs.C * 2);
+        }
+        a_voff[h][j] = ok ? off + csw16 : PCM_OOB;
+      }
+  };
+  auto w_prepare = [&](int p) {
+    if (p == 0) {
+#pragma unroll
+      for (int j = 0; j < F0; j++) { int n = n0 + b_tile_col(0, j); w_voff0[j] = n < g.N ? (unsigned)n * (unsigned)(b_K[0] * 2) + csw16 : PCM_OOB; }
+    } else {
+#pragma unroll
+      for (int j = 0; j < F1; j++) { int n = n0 + b_tile_col(1, j); w_voff1[j] = n < g.N ? (unsigned)n * (unsigned)(b_K[1] * 2) + csw16 : PCM_OOB; }
+    }
+  };
+  auto a_advance = [&]() {
+    a_chunk++;
+    if (a_chunk == a_nchunk) {
+      a_chunk = 0; a_tap++;
+      if (a_tap == a_ntap) {
+        a_tap = 0; a_seg++;
+        if (a_seg < g.nseg) {
+          ca = g.seg[1];
+          a_nchunk = (ca.mode == PCM_SEG_CONV3X3 ? ca.C : ca.K) >> 6;
+          a_ntap = ca.mode == PCM_SEG_CONV3X3 ? 9 : 1;
+          a_rekey();
+        }
+      }
+      if (a_seg < g.nseg) a_prepare_tap();
+    }
+  };
+  auto b_advance = [&](int p) {
+    b_kt[p]++;
+    if (b_kt[p] == b_nkt[p]) {
+      b_kt[p] = 0; b_seg[p]++;
+      if (b_seg[p] < g.nseg) { b_w[p] = g.seg[1].w; b_K[p] = g.seg[1].K; b_nkt[p] = g.seg[1].ktiles; w_prepare(p); }
+    }
+  };
+  auto issue_a = [&](int h, int stage) {
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)ca.a, 0, PCM_OOB, PCM_RSRC_FLAGS);
+    char* dst = smem + stage * STAGE + (h ? OFF_A1 : 0) + wave * 1024;
+    const unsigned soff = (unsigned)(a_chunk * 128);   // the tap is in the row offsets; plain segments have one tap
+#pragma unroll
+    for (int j = 0; j < 2; j++) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, PCM_AS3(dst + j * 8192), 16, a_voff[h][j], soff, 0, 0);
+  };
+  auto issue_b = [&](int p, int stage) {
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)b_w[p], 0, PCM_OOB, PCM_RSRC_FLAGS);
+    char* dst = smem + stage * STAGE + (p ? OFF_B1 : OFF_B0) + wave * 1024;
+    const unsigned soff = (unsigned)(b_kt[p] * 128);
+    if (p == 0) {
+#pragma unroll
+      for (int j = 0; j < F0; j++) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, PCM_AS3(dst + j * 8192), 16, w_voff0[j], soff, 0, 0);
+    } else {
+#pragma unroll
+      for (int j = 0; j < F1; j++) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, PCM_AS3(dst + j * 8192), 16, w_voff1[j], soff, 0, 0);
+    }
+  };
+
+  f32x4 acc[8][FN];
+#pragma unroll
+  for (int i = 0; i < 8; i++)
+#pragma unroll
+    for (int f = 0; f < FN; f++) acc[i][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- prologue: all of K-tile 0, and A0 / B1 / A1 of K-tile 1 (its B0 is issued by phase 1 of tile 0)
+  a_rekey(); a_prepare_tap(); w_prepare(0); w_prepare(1);
+  issue_b(0, 0); if (1 < T) b_advance(0);
+  issue_a(0, 0); issue_b(1, 0); issue_a(1, 0);
+  if (1 < T) {
+    b_advance(1); a_advance();
+    issue_a(0, 1); issue_b(1, 1); issue_a(1, 1);
+    if (2 < T) { b_advance(1); a_advance(); }
+    PCM_WAIT_VMCNT(6);
+  } else {
+    PCM_WAIT_VMCNT(0);
+  }
+  __builtin_amdgcn_s_barrier();
+  if (wm == 1) __builtin_amdgcn_s_barrier();   // group 1 runs one half-phase behind group 0
+
+  // fragment reads: lane (frow = lane&15, fk = lane>>4) reads row rowbase+frow, logical chunk 4*kh+fk.  Every rowbase is a
+  // multiple of 16, so the swizzle key ((row>>1)&7) depends on frow only: two per-lane offsets, the rest is uniform.
+  const int frow = lane & 15, fk = lane >> 4;
+  const int foff0 = frow * 128 + (((fk) ^ ((frow >> 1) & 7)) << 4), foff1 = frow * 128 + (((4 + fk) ^ ((frow >> 1) & 7)) << 4);
+  bf16x8 af[4][2], b0f[F0][2], b1f[F1][2];
+  auto read_a = [&](const char* base) {   // base = stage + region of the A half
+    const char* p = base + (64 * wm) * 128;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      af[i][0] = *(const bf16x8*)(p + i * 2048 + foff0);
+      af[i][1] = *(const bf16x8*)(p + i * 2048 + foff1);
+    }
+  };
+  auto read_b0 = [&](const char* base) {
+    const char* p = base + (16 * F0 * wn) * 128;
+#pragma unroll
+    for (int f = 0; f < F0; f++) {
+      b0f[f][0] = *(const bf16x8*)(p + f * 2048 + foff0);
+      b0f[f][1] = *(const bf16x8*)(p + f * 2048 + foff1);
+    }
+  };
+  auto read_b1 = [&](const char* base) {
+    const char* p = base + (16 * F1 * wn) * 128;
+#pragma unroll
+    for (int f = 0; f < F1; f++) {
+      b1f[f][0] = *(const bf16x8*)(p + f * 2048 + foff0);
+      b1f[f][1] = *(const bf16x8*)(p + f * 2048 + foff1);
+    }
+  };
+#define PCM_PHASE_SYNC_IN()                  \
+  PCM_WAIT_LGKMCNT0();                       \
+  __builtin_amdgcn_sched_barrier(0);         \
+  __builtin_amdgcn_s_barrier();              \
+  __builtin_amdgcn_sched_barrier(0);         \
+  __builtin_amdgcn_s_setprio(1)
+#define PCM_PHASE_SYNC_OUT()                 \
+  __builtin_amdgcn_s_setprio(0);             \
+  __builtin_amdgcn_sched_barrier(0);         \
+  __builtin_amdgcn_s_barrier();              \
+  __builtin_amdgcn_sched_barrier(0)
+
+  for (int t = 0; t < T; t++) {
+    const char* cur = smem + (t & 1) * STAGE;
+    const bool more1 = t + 1 < T, more2 = t + 2 < T;
+    // ---- phase 1: C00 = A0 x B0; stage B0 of tile t+1 (its region in the other buffer was last read in phase 4 of t-1)
+    read_a(cur); read_b0(cur + OFF_B0);
+    if (more1) { issue_b(0, (t + 1) & 1); if (t + 2 < T) b_advance(0); }
+    PCM_PHASE_SYNC_IN();
+#pragma unroll
+    for (int kh = 0; kh < 2; kh++)
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int f = 0; f < F0; f++) acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0f[f][kh], af[i][kh], acc[i][f], 0, 0, 0);
+    PCM_PHASE_SYNC_OUT();
+    // ---- phase 2: C01 = A0 x B1; stage A0 of tile t+2 over the A0 just consumed
+    read_b1(cur + OFF_B1);
+    if (more2) issue_a(0, t & 1);
+    PCM_PHASE_SYNC_IN();
+#pragma unroll
+    for (int kh = 0; kh < 2; kh++)
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int f = 0; f < F1; f++) acc[i][F0 + f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1f[f][kh], af[i][kh], acc[i][F0 + f], 0, 0, 0);
+    PCM_PHASE_SYNC_OUT();
+    // ---- phase 3: C11 = A1 x B1; stage B1 of tile t+2
+    read_a(cur + OFF_A1);
+    if (more2) { issue_b(1, t & 1); if (t + 3 < T) b_advance(1); }
+    PCM_PHASE_SYNC_IN();
+#pragma unroll
+    for (int kh = 0; kh < 2; kh++)
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int f = 0; f < F1; f++) acc[4 + i][F0 + f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1f[f][kh], af[i][kh], acc[4 + i][F0 + f], 0, 0, 0);
+    PCM_PHASE_SYNC_OUT();
+    // ---- phase 4: C10 = A1 x B0 (B0 fragments re-read); stage A1 of tile t+2; retire everything tile t+1 needs
+    read_b0(cur + OFF_B0);
+    if (more2) {
+      issue_a(1, t & 1);
+      if (t + 3 < T) a_advance();
+      PCM_WAIT_VMCNT(6);
+    } else {
+      PCM_WAIT_VMCNT(0);
+    }
+    PCM_PHASE_SYNC_IN();
+#pragma unroll
+    for (int kh = 0; kh < 2; kh++)
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int f = 0; f < F0; f++) acc[4 + i][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0f[f][kh], af[i][kh], acc[4 + i][f], 0, 0, 0);
+    PCM_PHASE_SYNC_OUT();
+  }
+  if (wm == 0) __builtin_amdgcn_s_barrier();   // realign the two groups
+
+  // ---- epilogue.  lane owns pixel row (lane&15) of a fragment and 4 consecutive channels 4*(lane>>4)+r
+  if (g.splitk > 1) {
+    float* slab = g.ws + (size_t)blockIdx.y * g.M * g.N;
+#pragma unroll
+    for (int i8 = 0; i8 < 8; i8++) {
+      const int m = m0 + 128 * wm + 16 * i8 + frow;
+      if (m >= g.M) continue;
+#pragma unroll
+      for (int f = 0; f < FN; f++) {
+        const int n = n0 + WNC * wn + 16 * f + 4 * fk;
+        if (n < g.N) *(float4*)(slab + (size_t)m * g.N + n) = make_float4(acc[i8][f][0], acc[i8][f][1], acc[i8][f][2], acc[i8][f][3]);
+      }
+    }
+    return;
+  }
+  // stage 64 rows x BN fp32 per pass through LDS (K-loop buffers are dead) so the global side is whole 16-B pieces of rows
+  constexpr int CH = BN / 4, C8 = BN / 8;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    __syncthreads();
+#pragma unroll
+    for (int ii = 0; ii < 2; ii++) {
+      const int lr = 32 * wm + 16 * ii + frow;
+#pragma unroll
+      for (int f = 0; f < FN; f++) {
+        const int ch = (WNC / 4) * wn + 4 * f + fk;
+        const f32x4 a = acc[2 * q + ii][f];
+        *(float4*)(smem + ((size_t)lr * CH + (ch ^ (lr & 15))) * 16) = make_float4(a[0] * g.alpha, a[1] * g.alpha, a[2] * g.alpha, a[3] * g.alpha);
+      }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 64 * C8; idx += 512) {
+      const int lr = idx / C8, c8 = idx - lr * C8;
+      const int m = m0 + 128 * (lr >> 5) + 32 * q + (lr & 31), n = n0 + 8 * c8;
+      if (m >= g.M || n >= g.N) continue;
+      const float4 lo = *(const float4*)(smem + ((size_t)lr * CH + ((2 * c8) ^ (lr & 15))) * 16);
+      const float4 hi4 = *(const float4*)(smem + ((size_t)lr * CH + ((2 * c8 + 1) ^ (lr & 15))) * 16);
+      float v[8] = {lo.x, lo.y, lo.z, lo.w, hi4.x, hi4.y, hi4.z, hi4.w};
+      pcm_epi_store8(g, m, n, v);
+    }
+  }
+#endif
+}
+
+size_t pcm_gemm8p_lds_bytes(int fn) { return 2 * (size_t)(256 + 64 * fn) * 128; }
+
+template <int F0>
+static int launch8p(const GemmDev& g, void* stream) {
+  const size_t smem = pcm_gemm8p_lds_bytes(F0 + 2);
+  dim3 grid(g.tiles_m * g.tiles_n, g.splitk);
+#ifndef PCM_HOST_EMU
+  static bool lds_ok = false;
+  if (!lds_ok) {
+    hipError_t er = hipFuncSetAttribute((const void*)pcm_gemm8p_kernel<F0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    PCM_CHECK(er == hipSuccess, PCM_EHIP, "pcm_gemm_bf16: hipFuncSetAttribute(LDS %zu): %s", smem, hipGetErrorString(er));
+    lds_ok = true;
+  }
+#endif
+  PCM_LAUNCH((pcm_gemm8p_kernel<F0>), grid, dim3(512), smem, stream, g);
+  return 0;
+}
+int pcm_gemm8p_launch(const GemmDev& g, int fn, void* stream) { return fn == 5 ? launch8p<3>(g, stream) : launch8p<2>(g, stream); }

@@ -1,0 +1,56 @@
+// Device-side argument block shared by the GEMM kernels (gemm.hip: 4-wave tiles; gemm8p.hip: 256-row phased tile).
+#pragma once
+#include "pcm_common.h"
+
+struct SegDev {
+  const bf16_t* a;
+  const bf16_t* w;
+  int K, lda, mode, Hs, Ws, C, stride, src_mode, ktiles;
+};
+struct GemmDev {
+  SegDev seg[2];
+  int nseg, M, N, Ho, Wo;
+  const float* bias;
+  const bf16_t* rowvec;
+  int rpb;
+  const bf16_t* res;
+  int ldr;
+  void* out;
+  int ldo, out_f32, act;
+  float alpha;
+  int tiles_m, tiles_n;
+  int splitk, kt_per_split;   // split-K: blockIdx.y = K slice; raw fp32 partial tiles go to slab ws[slice][M][N]
+  float* ws;
+};
+
+__device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+// fused epilogue on 8 consecutive channels of one output row (values already scaled by alpha): + bias + per-batch row
+// vector (time embedding), SiLU, + residual, one 16-byte bf16 store.  Requires the 16-B alignment the planner checks.
+__device__ __forceinline__ void pcm_epi_store8(const GemmDev& g, int m, int n, float v[8]) {
+  if (g.bias) {
+    const float4 b0 = *(const float4*)(g.bias + n), b1 = *(const float4*)(g.bias + n + 4);
+    v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+  }
+  if (g.rowvec) {
+    const uint4 t = *(const uint4*)(g.rowvec + (size_t)(m / g.rpb) * g.N + n);
+    const unsigned tw[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+    for (int e = 0; e < 4; e++) { v[2 * e] += bf2f((bf16_t)(tw[e] & 0xffff)); v[2 * e + 1] += bf2f((bf16_t)(tw[e] >> 16)); }
+  }
+  if (g.act == PCM_ACT_SILU) {
+#pragma unroll
+    for (int e = 0; e < 8; e++) v[e] = silu_f(v[e]);
+  }
+  if (g.res) {
+    const uint4 t = *(const uint4*)(g.res + (size_t)m * g.ldr + n);
+    const unsigned tw[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+    for (int e = 0; e < 4; e++) { v[2 * e] += bf2f((bf16_t)(tw[e] & 0xffff)); v[2 * e + 1] += bf2f((bf16_t)(tw[e] >> 16)); }
+  }
+  *(uint4*)((bf16_t*)g.out + (size_t)m * g.ldo + n) = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+}
+
+// 256 x (64*FN) phased kernel (gemm8p.hip).  fn = 5 -> 256x320, fn = 4 -> 256x256.  grid = (tiles_m*tiles_n, splitk)
+int pcm_gemm8p_launch(const GemmDev& g, int fn, void* stream);
+size_t pcm_gemm8p_lds_bytes(int fn);

@@ -12,6 +12,9 @@
 #define PCM_AS3(p) ((__attribute__((address_space(3))) void*)(p))
 #define PCM_EXPF(x) __expf(x)
 #define PCM_EXP2F(x) __builtin_amdgcn_exp2f(x)
+// counted waits for hand-pipelined LDS-DMA loops (hipcc never emits these for LDS-DMA -> ds_read dependences)
+#define PCM_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define PCM_WAIT_LGKMCNT0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #endif
 #include <stdint.h>
 #include <string.h>

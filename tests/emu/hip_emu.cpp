@@ -10,6 +10,7 @@ int g_block_arrived = 0, g_block_alive = 0;
 dim3 g_threadIdx, g_blockIdx, g_blockDim, g_gridDim;
 std::function<void()> g_body;
 char* g_dyn_smem = nullptr;
+bool g_lazy_dma = false;
 static const size_t STACK = 256 * 1024;
 
 void yield_to_sched() { swapcontext(&g_cur->ctx, &g_sched); }
@@ -44,6 +45,7 @@ void block_sync() {
 
 static void trampoline() {
   g_body();
+  wait_vmcnt(0);
   Fiber* f = g_cur;
   f->st = DONE;
   // a finished lane no longer takes part in rendezvous
@@ -65,6 +67,7 @@ void launch(dim3 grid, dim3 block, size_t smem, std::function<void()> body) {
   int nthreads = block.x * block.y * block.z;
   int nwaves = (nthreads + 63) / 64;
   g_body = body;
+  { const char* e = getenv("PCM_EMU_LAZY_DMA"); g_lazy_dma = e && e[0] == '1'; }
   g_blockDim = block;
   g_gridDim = grid;
   std::vector<char> dyn(smem + 64);
@@ -88,6 +91,7 @@ void launch(dim3 grid, dim3 block, size_t smem, std::function<void()> body) {
         for (int t = 0; t < nthreads; t++) {
           Fiber& f = g_fibers[t];
           f.st = RUNNABLE;
+          f.pend.clear();
           f.lin = t; f.wave = t / 64; f.lane = t % 64;
           f.tid = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
           getcontext(&f.ctx);

@@ -50,12 +50,14 @@ static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) {
 namespace pcm_emu {
 
 enum State { RUNNABLE, WAIT_WAVE, WAIT_BLOCK, DONE };
+struct DmaOp { void* dst; const void* src; int size; };   // src == nullptr: zero fill (out-of-range buffer load)
 struct Fiber {
   ucontext_t ctx;
   char* stack;
   State st;
   dim3 tid;
   int lin, wave, lane;
+  std::vector<DmaOp> pend;   // LDS-DMA issued but not yet landed (PCM_EMU_LAZY_DMA=1: lands only at s_waitcnt vmcnt / __syncthreads)
 };
 struct WaveScratch {
   // double-buffered exchange area (see hip_emu.h header comment in launch())
@@ -74,6 +76,7 @@ extern int g_block_arrived, g_block_alive;
 extern dim3 g_threadIdx, g_blockIdx, g_blockDim, g_gridDim;
 extern std::function<void()> g_body;
 extern char* g_dyn_smem;
+extern bool g_lazy_dma;
 
 void yield_to_sched();
 void wave_sync();
@@ -142,7 +145,22 @@ inline f32x4_t mfma_16x16x32_bf16(bf16x8_t a, bf16x8_t b, f32x4_t c, int, int, i
   return c;
 }
 
-// LDS-DMA: LDS dst = (first lane's ldsptr) + lane*size ; src = own gptr (offset must be 0)
+// LDS-DMA is asynchronous on the hardware: the data lands some time between the issue and the s_waitcnt vmcnt that
+// retires it.  The emulator runs the two extremes: eager (default: lands at issue) and lazy (PCM_EMU_LAZY_DMA=1: lands
+// only when a counted wait / __syncthreads retires it) -- a kernel whose results agree under both has no RAW / WAR
+// dependence on the landing time across its barrier-separated phases.
+inline void dma_do(const DmaOp& o) { if (o.src) memcpy(o.dst, o.src, o.size); else memset(o.dst, 0, o.size); }
+inline void wait_vmcnt(int n) {
+  std::vector<DmaOp>& q = g_cur->pend;
+  size_t k = 0;
+  while (q.size() - k > (size_t)n) dma_do(q[k++]);
+  if (k) q.erase(q.begin(), q.begin() + k);
+}
+inline void dma_issue(void* dst, const void* src, int size) {
+  DmaOp o{dst, src, size};
+  if (g_lazy_dma) g_cur->pend.push_back(o); else dma_do(o);
+}
+// LDS dst = (first lane's ldsptr) + lane*size ; src = own gptr (offset must be 0)
 inline void global_load_lds(const void* g, void* lds, int size, int offset, int) {
   if (offset != 0) { fprintf(stderr, "emu: global_load_lds offset!=0 unsupported\n"); abort(); }
   WaveScratch& w = wave();
@@ -150,7 +168,24 @@ inline void global_load_lds(const void* g, void* lds, int size, int offset, int)
   w.gp[bsel][l] = g;
   w.lp[bsel][l] = lds;
   wave_sync();
-  memcpy((char*)w.lp[bsel][0] + (size_t)l * size, g, size);
+  dma_issue((char*)w.lp[bsel][0] + (size_t)l * size, g, size);
+}
+// raw buffer resource: byte address = base + voffset + soffset; out of range (voffset >= num_records - soffset) reads zero
+struct BufferRsrc { const char* base; uint32_t num_records; };
+inline BufferRsrc make_buffer_rsrc(const void* p, int stride, uint32_t num_records, int) {
+  if (stride != 0) { fprintf(stderr, "emu: only raw (stride 0) buffers\n"); abort(); }
+  return BufferRsrc{(const char*)p, num_records};
+}
+inline void buffer_load_lds(BufferRsrc rs, void* lds, int size, uint32_t voff, uint32_t soff, int imm, int) {
+  if (imm != 0) { fprintf(stderr, "emu: buffer_load_lds imm offset unsupported\n"); abort(); }
+  WaveScratch& w = wave();
+  int bsel = w.gen & 1, l = lane_id();
+  w.lp[bsel][l] = lds;
+  w.u64[bsel][l] = soff;
+  wave_sync();
+  if (w.u64[bsel][0] != soff) { fprintf(stderr, "emu: buffer_load_lds soffset must be wave-uniform\n"); abort(); }
+  bool oob = soff > rs.num_records || voff >= rs.num_records - soff;
+  dma_issue((char*)w.lp[bsel][0] + (size_t)l * size, oob ? nullptr : rs.base + voff + soff, size);
 }
 
 }  // namespace pcm_emu
@@ -159,7 +194,7 @@ inline void global_load_lds(const void* g, void* lds, int size, int offset, int)
 #define blockIdx (pcm_emu::g_blockIdx)
 #define blockDim (pcm_emu::g_blockDim)
 #define gridDim (pcm_emu::g_gridDim)
-#define __syncthreads() pcm_emu::block_sync()
+#define __syncthreads() (pcm_emu::wait_vmcnt(0), pcm_emu::block_sync())
 #define __builtin_amdgcn_s_barrier() pcm_emu::block_sync()
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
@@ -170,6 +205,11 @@ inline void global_load_lds(const void* g, void* lds, int size, int offset, int)
 #define __builtin_amdgcn_readfirstlane(x) pcm_emu::shfl_idx((x), 0)
 #define PCM_AS1(p) (p)
 #define PCM_AS3(p) (p)
+typedef pcm_emu::BufferRsrc __amdgpu_buffer_rsrc_t;
+#define __builtin_amdgcn_make_buffer_rsrc(p, stride, n, flags) pcm_emu::make_buffer_rsrc((const void*)(p), stride, n, flags)
+#define __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, l, size, voff, soff, imm, aux) pcm_emu::buffer_load_lds(rs, (void*)(l), size, voff, soff, imm, aux)
+#define PCM_WAIT_VMCNT(n) pcm_emu::wait_vmcnt(n)
+#define PCM_WAIT_LGKMCNT0() ((void)0)
 
 template <typename T> static inline T __shfl_xor(T v, int m, int = 64) { return pcm_emu::shfl_idx(v, pcm_emu::lane_id() ^ m); }
 template <typename T> static inline T __shfl_down(T v, int d, int = 64) {

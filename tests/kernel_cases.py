@@ -381,3 +381,91 @@ def case_teacher_input_grad(dev):
     d_in = teacher.backward(None, tape, d_feats=d_feats, need_input_grad=True)
     r = float((d_in.cpu() - xr.grad).norm() / xr.grad.norm())
     assert r < 0.08, r
+
+
+def case_gemm_big(dev, which):
+    """The 256-row phased tile (gemm8p.hip) forced through pcm_debug_gemm_big_mode(2) on every contraction flavour
+    the UNet uses; returns (max abs err, tolerance) against torch fp32 on the same bf16-rounded operands."""
+    import torch.nn.functional as F
+    from pcm_amd import capi, ops
+
+    def rnd(*shape, seed=0, scale=1.0):
+        g = torch.Generator().manual_seed(seed)
+        return (torch.randn(*shape, generator=g) * scale).bfloat16().to(dev)
+
+    dll = capi.lib().dll
+    dll.pcm_debug_gemm_big_mode(2)
+    try:
+        if which == "plain_lora":      # 2 M tiles of 256x320, second K segment, bias + residual
+            M, N, K = 512, 320, 320
+            x, w, t, bl = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.1), rnd(M, 64, seed=3), rnd(N, 64, seed=4, scale=0.1)
+            bias = torch.randn(N, generator=torch.Generator().manual_seed(5)).to(dev)
+            res = rnd(M, N, seed=6)
+            out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+            ops.gemm([ops.Seg(x, w), ops.Seg(t, bl)], M, N, out, bias=bias, residual=res)
+            ref = x.float() @ w.float().T + t.float() @ bl.float().T + bias + res.float()
+        elif which == "ragged":         # M tail, 2 N tiles, N not a tile multiple, SiLU + alpha, single K tile
+            M, N, K = 300, 448, 64
+            x, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.2)
+            out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+            ops.gemm([ops.Seg(x, w)], M, N, out, act=capi.ACT_SILU, alpha=0.5)
+            ref = F.silu(0.5 * (x.float() @ w.float().T))
+        elif which == "two_tiles_k":    # exactly two K tiles (prologue-only pipeline), 256x256 tile
+            M, N, K = 256, 256, 128
+            x, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.2)
+            out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+            ops.gemm([ops.Seg(x, w)], M, N, out)
+            ref = x.float() @ w.float().T
+        elif which == "splitk":
+            M, N, K = 256, 320, 2048
+            x, w, t, bl = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05), rnd(M, 64, seed=3), rnd(N, 64, seed=4, scale=0.1)
+            bias = torch.randn(N, generator=torch.Generator().manual_seed(5)).to(dev)
+            out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+            ops.gemm([ops.Seg(x, w), ops.Seg(t, bl)], M, N, out, bias=bias)
+            ref = x.float() @ w.float().T + t.float() @ bl.float().T + bias
+        else:                            # conv3x3 flavours, with the LoRA branch as a plain or a conv second segment
+            stride, src_mode, lora = {"conv": (1, capi.SRC_DIRECT, "plain"), "conv_s2": (2, capi.SRC_DIRECT, None),
+                                      "conv_up": (1, capi.SRC_UPSAMPLE2, "plain"), "conv_zi": (1, capi.SRC_ZEROINS2, None),
+                                      "conv_conv": (1, capi.SRC_DIRECT, "conv")}[which]
+            Hs = {"conv": 16, "conv_s2": 32, "conv_up": 8, "conv_zi": 8, "conv_conv": 16}[which]
+            B, Ci, Co = 2, 128 if which == "conv" else 64, 320
+            x = rnd(B, Hs, Hs, Ci, seed=7)
+            w = rnd(Co, Ci, 3, 3, seed=8, scale=0.05)
+            xn = x.float().permute(0, 3, 1, 2)
+            if src_mode == capi.SRC_UPSAMPLE2:
+                xv = F.interpolate(xn, scale_factor=2.0, mode="nearest")
+            elif src_mode == capi.SRC_ZEROINS2:
+                xv = torch.zeros(B, Ci, 2 * Hs, 2 * Hs, device=dev)
+                xv[:, :, ::2, ::2] = xn
+            else:
+                xv = xn
+            ref = F.conv2d(xv, w.float(), None, stride=stride, padding=1)
+            Ho = ref.shape[2]
+            M = B * Ho * Ho
+            segs = [ops.Seg(x, w.permute(0, 2, 3, 1).reshape(Co, 9 * Ci).contiguous(), conv=dict(Hs=Hs, Ws=Hs, stride=stride, src_mode=src_mode))]
+            ref = ref.permute(0, 2, 3, 1).reshape(M, Co)
+            if lora == "plain":
+                t, bl = rnd(M, 64, seed=3), rnd(Co, 64, seed=4, scale=0.1)
+                segs.append(ops.Seg(t, bl))
+                ref = ref + t.float() @ bl.float().T
+            elif lora == "conv":
+                d = rnd(B, Hs, Hs, 64, seed=11)
+                w2 = rnd(Co, 64, 3, 3, seed=12, scale=0.05)
+                segs.append(ops.Seg(d, w2.permute(0, 2, 3, 1).reshape(Co, 576).contiguous(), conv=dict(Hs=Hs, Ws=Hs)))
+                ref = ref + F.conv2d(d.float().permute(0, 3, 1, 2), w2.float(), None, padding=1).permute(0, 2, 3, 1).reshape(M, Co)
+            temb = rnd(B, Co, seed=9)
+            out = torch.empty(M, Co, dtype=torch.bfloat16, device=dev)
+            ops.gemm(segs, M, Co, out, rowvec=temb, rows_per_batch=Ho * Ho, Ho=Ho, Wo=Ho)
+            ref = ref + temb.float().repeat_interleave(Ho * Ho, 0)
+        plan = dll.pcm_debug_last_gemm_plan()
+        assert plan >= 4000, ("big tile not taken", which, plan)
+        if which == "splitk":
+            assert plan % 1000 > 1, plan
+    finally:
+        dll.pcm_debug_gemm_big_mode(1)
+    err = (out.float() - ref).abs()
+    tol = 2e-2 + 1e-2 * ref.abs()
+    return float((err - tol).max()), float(err.max())
+
+
+GEMM_BIG_CASES = ["plain_lora", "ragged", "two_tiles_k", "splitk", "conv", "conv_s2", "conv_up", "conv_zi", "conv_conv"]

@@ -88,3 +88,14 @@ def test_split_k_plain_and_conv():
     outc = torch.empty(B * Hs * Ws, Co, dtype=torch.bfloat16)
     ops.gemm([ops.Seg(xc, wc.permute(0, 2, 3, 1).reshape(Co, -1).contiguous(), conv=dict(Hs=Hs, Ws=Ws))], B * Hs * Ws, Co, outc, Ho=Hs, Wo=Ws)
     assert torch.allclose(outc.float(), refc, rtol=2e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize("lazy_dma", ["0", "1"])
+@pytest.mark.parametrize("which", __import__("kernel_cases").GEMM_BIG_CASES)
+def test_big_tile_kernel(which, lazy_dma, monkeypatch):
+    """gemm8p (256-row phased tile, counted LDS-DMA waits).  Run with the DMA landing at issue AND only at the counted
+    wait: agreement under both rules out a dependence on the landing time (RAW too-early reads, WAR early restages)."""
+    import kernel_cases as KC
+    monkeypatch.setenv("PCM_EMU_LAZY_DMA", lazy_dma)
+    excess, err = KC.case_gemm_big("cpu", which)
+    assert excess <= 0, (which, lazy_dma, err)

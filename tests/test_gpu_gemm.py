@@ -67,3 +67,35 @@ def test_conv3x3(stride, src_mode, B, Hs, Ci, Co):
     torch.cuda.synchronize()
     err = (out - ref).abs().max().item()
     assert err < 3e-3 * max(1.0, ref.abs().max().item()), err
+
+
+@pytest.mark.parametrize("which", __import__("kernel_cases").GEMM_BIG_CASES)
+def test_big_tile_kernel(which):
+    """gemm8p (256-row phased tile) on hardware: buffer-resource zero fill, LDS-DMA above 64 KB, counted waits."""
+    import kernel_cases as KC
+    for _ in range(3):   # repeated: a landing-time race would show as run-to-run differences
+        excess, err = KC.case_gemm_big("cuda", which)
+        assert excess <= 0, (which, err)
+
+
+def test_big_tile_kernel_large_shapes_match_small_tile():
+    """Full-size SD1.5 shapes: the phased kernel must agree with the 4-wave kernel (both fp32-accumulate the same bf16 data)."""
+    from pcm_amd import capi, ops
+    dll = capi.lib().dll
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for (B, Hs, Ci, Co) in [(4, 64, 320, 320), (4, 32, 640, 640), (8, 16, 1280, 1280), (4, 32, 1280, 640)]:
+        x = torch.randn(B, Hs, Hs, Ci, device="cuda", generator=g).bfloat16()
+        w = (torch.randn(Co, 9 * Ci, device="cuda", generator=g) * 0.02).bfloat16()
+        t = torch.randn(B * Hs * Hs, 64, device="cuda", generator=g).bfloat16()
+        bl = (torch.randn(Co, 64, device="cuda", generator=g) * 0.1).bfloat16()
+        M = B * Hs * Hs
+        outs = []
+        for mode in (0, 2):
+            dll.pcm_debug_gemm_big_mode(mode)
+            out = torch.empty(M, Co, device="cuda", dtype=torch.bfloat16)
+            ops.gemm([ops.Seg(x, w, conv=dict(Hs=Hs, Ws=Hs)), ops.Seg(t, bl)], M, Co, out, Ho=Hs, Wo=Hs)
+            outs.append(out.float())
+        dll.pcm_debug_gemm_big_mode(1)
+        torch.cuda.synchronize()
+        d = (outs[0] - outs[1]).abs().max().item()
+        assert d <= 2e-2 * outs[0].abs().max().item() + 1e-3, (B, Hs, Ci, Co, d)
