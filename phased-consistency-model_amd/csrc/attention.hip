@@ -90,14 +90,17 @@ struct RowStage {
       r[i] = *(const uint4*)(src + (size_t)row * ld + 8 * c);
     }
   }
+  // full (wave-uniform): every row of the tile is valid -> no per-piece validity selects (the common case: only the last
+  // tile of a ragged sequence is partial)
   __device__ __forceinline__ void store(char* dst, int nrows_valid, int tid) const {
+    const bool full = row0_ + ROWS <= nrows_valid;
 #pragma unroll
     for (int i = 0; i < N; i++) {
       int u = tid + 256 * i;
       int rr = u / C::DG, c = u - rr * C::DG;
       if (u < ROWS * C::DG) {
         uint4 v = r[i];
-        if (row0_ + rr >= nrows_valid) v = make_uint4(0u, 0u, 0u, 0u);
+        if (!full && row0_ + rr >= nrows_valid) v = make_uint4(0u, 0u, 0u, 0u);
         *(uint4*)(dst + (rr * C::RKU + c) * 16) = v;
       }
     }
@@ -129,6 +132,7 @@ struct TransStage {
     }
   }
   __device__ __forceinline__ void store(char* dst, int nrows_valid, int tid) const {
+    const bool full = row0_ + 64 <= nrows_valid;
 #pragma unroll
     for (int i = 0; i < N; i++) {
       int u = tid + 256 * i;
@@ -138,7 +142,7 @@ struct TransStage {
         unsigned a[4], b[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-          bool ok = row0_ + 4 * rg + j < nrows_valid;
+          bool ok = full || row0_ + 4 * rg + j < nrows_valid;
           a[j] = ok ? rr[i][j].x : 0u; b[j] = ok ? rr[i][j].y : 0u;
         }
         uint2 o[4];
@@ -192,6 +196,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* q, const bf
   float m_run = -1e30f, l_run = 0.f;
   const float sc = scale * LOG2E;
   zero_pad_chunks<D, 64>(Ks, tid);
+  // head dims whose transposed V image has a spare padded row (40 -> 64, 80 -> 96): row D is set to ones, so the PV MFMA
+  // also produces the softmax denominator sum_k p[k] in accumulator row D (rescaled with O for free, no VALU row sums)
+  constexpr bool ONES = C::DV * 32 > D;
+  if (ONES && tid < 8) *(uint4*)(Vt + tr_off(D, tid)) = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
   RowStage<D, 64> kst;
   TransStage<D> vst;
   if (AttnPrefetch<D>::value) { kst.load(kb, ldk, 0, Lk, tid); vst.load(vb, ldk, 0, Lk, tid); }
@@ -218,6 +226,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* q, const bf
     }
     // online softmax in the log2 domain on RAW scores: p = exp2(s*sc - m); masks only on the tail tile
     if (kv0 + 64 > Lk) {
+      asm volatile("" ::: "memory");   // keep this a real (wave-uniform) branch: if-converted it costs 3 VALU ops per score in every tile
 #pragma unroll
       for (int t = 0; t < 2; t++)
 #pragma unroll
@@ -240,7 +249,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* q, const bf
       for (int r = 0; r < 16; r++) {
         float p = PCM_EXP2F(fmaf(s_[t][r], sc, -m_new));
         s_[t][r] = p;
-        psum += p;
+        if (!ONES) psum += p;
       }
     if (__all(m_new == m_run)) {      // running max unchanged for the whole wave: no rescale pass
       l_run += psum;
@@ -265,6 +274,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* q, const bf
       }
   }
   float l_tot = l_run + __shfl_xor(l_run, 32);
+  if constexpr (ONES) {   // accumulator row D: tile D/32, local row D%32 -> lane half (loc>>2)&1 (= 0 for 40 / 80), register (loc&3) + 4*(loc>>3)
+    constexpr int LOC = D % 32;
+    static_assert(((LOC >> 2) & 1) == 0, "ones row must sit in the low lane half");
+    l_tot = __shfl(acc_o[D / 32][(LOC & 3) + 4 * (LOC >> 3)], l31);
+  }
   float inv = 1.0f / l_tot;
   int qrow = q0 + l31;
   if (qrow < Lq) {
@@ -375,6 +389,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* q, const
         s_[t][r] = p * (dp[t][r] - dl) * scale;  // dS^T
       }
     if (kv0 + 64 > Lk) {
+      asm volatile("" ::: "memory");   // keep this a real (wave-uniform) branch: if-converted it costs 3 VALU ops per score in every tile
 #pragma unroll
       for (int t = 0; t < 2; t++)
 #pragma unroll
@@ -495,6 +510,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16_t* q, con
         s_[t][r] = p;
       }
     if (!blk_full || qq0 + 64 > Lq) {
+      asm volatile("" ::: "memory");   // real branch, see the forward kernel
 #pragma unroll
       for (int t = 0; t < 2; t++)
 #pragma unroll

@@ -179,8 +179,16 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* x, float* out
 #pragma unroll
     for (int e = 0; e < 8; e++) s[e] += f[e];
   }
+  // reduce the k pixel-lanes of the block in LDS first: one atomic per (block, channel) instead of one per thread
+  __shared__ float red[256 * 8];
 #pragma unroll
-  for (int e = 0; e < 8; e++) atomicAdd(&out[(size_t)b * C + c0 + e], s[e]);
+  for (int e = 0; e < 8; e++) red[(pl * CVL + cvl) * 8 + e] = s[e];
+  __syncthreads();
+  for (int i = threadIdx.x; i < CVL * 8; i += blockDim.x) {
+    float t = 0.f;
+    for (int j = 0; j < k; j++) t += red[j * CVL * 8 + i];
+    atomicAdd(&out[(size_t)b * C + zc * CVL * 8 + i], t);
+  }
 }
 extern "C" int pcm_colsum_bf16(const void* x, void* out, int B, int HW, int C, void* stream) {
   PCM_CHECK(x && out && (C % 8) == 0 && PCM_ALIGNED16(x), PCM_EALIGN, "pcm_colsum_bf16: C%%8, alignment");
@@ -195,6 +203,20 @@ extern "C" int pcm_colsum_bf16(const void* x, void* out, int B, int HW, int C, v
   return pcm_post_launch("pcm_colsum_bf16");
 }
 
+// Stage n fp32 weights into LDS through a per-element index map.  The global loads are issued in batches of 8 per thread
+// before any LDS store: written as a plain load/store loop hipcc waits for every load before its store, i.e. one memory
+// round trip per element per thread (45 serial round trips ~ 90 us per block for the 36x320 edge-conv weights).
+template <typename F>
+__device__ __forceinline__ void stage_weights(const float* w, float* wl, int n, F map) {
+  for (int base = 0; base < n; base += 8 * (int)blockDim.x) {
+    float r[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) { int i = base + u * (int)blockDim.x + (int)threadIdx.x; r[u] = i < n ? w[i] : 0.f; }
+#pragma unroll
+    for (int u = 0; u < 8; u++) { int i = base + u * (int)blockDim.x + (int)threadIdx.x; if (i < n) wl[map(i)] = r[u]; }
+  }
+}
+
 // ---- 4-channel edge convolutions -------------------------------------------------------
 // conv4: in NCHW fp32 [B][4][H][W] -> out NHWC bf16 [B][H][W][C0], 3x3 pad 1.
 // flip=0: w [C0][4][3][3] (conv_in).  flip=1: w [4][C0][3][3] read transposed with flipped taps
@@ -203,11 +225,12 @@ __global__ __launch_bounds__(256) void conv4_kernel(const float* x, const float*
                                                     int B, int H, int W, int C0, int flip) {
   PCM_DYN_SMEM(smem);
   float* wl = (float*)smem;  // [36][C0]
-  for (int i = threadIdx.x; i < 36 * C0; i += blockDim.x) {
-    int j = i / C0, c = i - j * C0;
-    int ci = j / 9, tap = j - ci * 9;
-    wl[i] = flip ? w[((size_t)ci * C0 + c) * 9 + (8 - tap)] : w[((size_t)c * 4 + ci) * 9 + tap];
-  }
+  stage_weights(w, wl, 36 * C0, [&](int i) {
+    int tap = i % 9, r = i / 9;
+    if (flip) { int ci = r / C0, c = r - ci * C0; return (ci * 9 + (8 - tap)) * C0 + c; }
+    int c = r >> 2, ci = r & 3;
+    return (ci * 9 + tap) * C0 + c;
+  });
   __syncthreads();
   const int CV = C0 / 8;
   long nvec = (long)B * H * W * CV;
@@ -231,14 +254,71 @@ __global__ __launch_bounds__(256) void conv4_kernel(const float* x, const float*
     *(uint4*)(y + v * 8) = ew_pack8(acc);
   }
 }
+// W % 4 == 0 variant: one item = 4 consecutive pixels of a row x 8 channels, so every staged weight vector feeds 4 pixels
+// and the 3x6 input window is loaded once; weights are staged with coalesced global reads (the scatter is on the LDS side).
+__global__ __launch_bounds__(256) void conv4x4_kernel(const float* x, const float* w, const float* bias, bf16_t* y,
+                                                      int B, int H, int W, int C0, int flip) {
+  PCM_DYN_SMEM(smem);
+  float* wl = (float*)smem;  // [36][C0]
+  stage_weights(w, wl, 36 * C0, [&](int i) {
+    int tap = i % 9, r = i / 9;
+    if (flip) { int ci = r / C0, c = r - ci * C0; return (ci * 9 + (8 - tap)) * C0 + c; }
+    int c = r >> 2, ci = r & 3;
+    return (ci * 9 + tap) * C0 + c;
+  });
+  __syncthreads();
+  const int CV = C0 / 8, WQ = W / 4;
+  const long nitem = (long)B * H * WQ * CV;
+  EW_LOOP(v, nitem) {
+    int cv = (int)(v % CV); long p = v / CV;
+    int px0 = (int)(p % WQ) * 4; long q = p / WQ;
+    int py = (int)(q % H); int b = (int)(q / H);
+    float acc[4][8];
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+#pragma unroll
+      for (int e = 0; e < 8; e++) acc[k][e] = bias ? bias[cv * 8 + e] : 0.f;
+    for (int ci = 0; ci < 4; ci++) {
+      const float* xc = x + ((size_t)b * 4 + ci) * H * W;
+#pragma unroll
+      for (int dy = 0; dy < 3; dy++) {
+        const int iy = py + dy - 1;
+        if (iy < 0 || iy >= H) continue;
+        float xr[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) { int ix = px0 + k - 1; xr[k] = (ix >= 0 && ix < W) ? xc[(size_t)iy * W + ix] : 0.f; }
+#pragma unroll
+        for (int dx = 0; dx < 3; dx++) {
+          const float4 w0 = *(const float4*)(wl + (ci * 9 + dy * 3 + dx) * C0 + cv * 8), w1 = *(const float4*)(wl + (ci * 9 + dy * 3 + dx) * C0 + cv * 8 + 4);
+          const float wr[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+          for (int k = 0; k < 4; k++)
+#pragma unroll
+            for (int e = 0; e < 8; e++) acc[k][e] += xr[k + dx] * wr[e];
+        }
+      }
+    }
+    bf16_t* yo = y + (((size_t)b * H + py) * W + px0) * C0 + cv * 8;
+#pragma unroll
+    for (int k = 0; k < 4; k++) *(uint4*)(yo + (size_t)k * C0) = ew_pack8(acc[k]);
+  }
+}
+static void conv4_launch(const float* x, const float* w, const float* bias, bf16_t* y, int B, int H, int W, int C0, int flip, void* stream) {
+  if ((W % 4) == 0) {
+    long blocks = ((long)B * H * (W / 4) * (C0 / 8) + 255) / 256; if (blocks > PCM_GRID_CAP(768)) blocks = PCM_GRID_CAP(768);
+    PCM_LAUNCH(conv4x4_kernel, dim3((int)blocks), dim3(256), 36 * C0 * 4, stream, x, w, bias, y, B, H, W, C0, flip);
+  } else {
+    PCM_LAUNCH(conv4_kernel, dim3(ew_blocks((long)B * H * W * (C0 / 8))), dim3(256), 36 * C0 * 4, stream, x, w, bias, y, B, H, W, C0, flip);
+  }
+}
 extern "C" int pcm_conv_in_fwd(const float* x, const float* w, const float* bias, void* y, int B, int H, int W, int C0, void* stream) {
   PCM_CHECK(x && w && y && (C0 % 8) == 0 && C0 <= 1024, PCM_EINVAL, "pcm_conv_in_fwd: C0%%8, C0<=1024");
-  PCM_LAUNCH(conv4_kernel, dim3(ew_blocks((long)B * H * W * (C0 / 8))), dim3(256), 36 * C0 * 4, stream, x, w, bias, (bf16_t*)y, B, H, W, C0, 0);
+  conv4_launch(x, w, bias, (bf16_t*)y, B, H, W, C0, 0, stream);
   return pcm_post_launch("pcm_conv_in_fwd");
 }
 extern "C" int pcm_conv_out_bwd(const float* dy, const float* w, void* dx, int B, int H, int W, int C0, void* stream) {
   PCM_CHECK(dy && w && dx && (C0 % 8) == 0 && C0 <= 1024, PCM_EINVAL, "pcm_conv_out_bwd: C0%%8, C0<=1024");
-  PCM_LAUNCH(conv4_kernel, dim3(ew_blocks((long)B * H * W * (C0 / 8))), dim3(256), 36 * C0 * 4, stream, dy, w, (const float*)nullptr, (bf16_t*)dx, B, H, W, C0, 1);
+  conv4_launch(dy, w, (const float*)nullptr, (bf16_t*)dx, B, H, W, C0, 1, stream);
   return pcm_post_launch("pcm_conv_out_bwd");
 }
 // conv_out: x NHWC bf16 [B][H][W][C0] -> y NCHW fp32 [B][4][H][W]; one wave per output pixel
@@ -246,10 +326,7 @@ __global__ __launch_bounds__(256) void conv_out_kernel(const bf16_t* x, const fl
                                                        int B, int H, int W, int C0) {
   PCM_DYN_SMEM(smem);
   float* wl = (float*)smem;  // [9][4][C0]
-  for (int i = threadIdx.x; i < 36 * C0; i += blockDim.x) {
-    int tap = i / (4 * C0), r = i - tap * 4 * C0, o = r / C0, c = r - o * C0;
-    wl[i] = w[((size_t)o * C0 + c) * 9 + tap];
-  }
+  stage_weights(w, wl, 36 * C0, [&](int i) { int tap = i % 9, r = i / 9; return tap * 4 * C0 + r; });   // r = o*C0 + c
   __syncthreads();
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, CV = C0 / 8;
   long npix = (long)B * H * W;
@@ -280,11 +357,75 @@ __global__ __launch_bounds__(256) void conv_out_kernel(const bf16_t* x, const fl
     }
   }
 }
+// W % 8 == 0, C0 <= 512 variant: one wave per 8 consecutive pixels of a row; lane = 8-channel group.  The 4x8 weights of a tap
+// are read from LDS once per 8 pixels; the 32 (pixel, out-channel) partial sums are reduced across the wave by a halving
+// butterfly (32 shuffles instead of 32 full wave reductions): lane l ends up with value index l>>1.
+__global__ __launch_bounds__(256) void conv_out8_kernel(const bf16_t* x, const float* w, const float* bias, float* y,
+                                                        int B, int H, int W, int C0) {
+  PCM_DYN_SMEM(smem);
+  float* wl = (float*)smem;  // [9][4][C0]
+  stage_weights(w, wl, 36 * C0, [&](int i) { int tap = i % 9, r = i / 9; return tap * 4 * C0 + r; });   // r = o*C0 + c
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, CV = C0 / 8, W8 = W / 8;
+  const long nitem = (long)B * H * W8;
+  for (long it = (long)blockIdx.x * 4 + wv; it < nitem; it += (long)gridDim.x * 4) {
+    int px0 = (int)(it % W8) * 8; long q = it / W8;
+    int py = (int)(q % H); int b = (int)(q / H);
+    float vals[32];
+#pragma unroll
+    for (int i = 0; i < 32; i++) vals[i] = 0.f;
+    for (int cv = lane; cv < CV; cv += 64) {
+#pragma unroll
+      for (int tap = 0; tap < 9; tap++) {
+        const int iy = py + tap / 3 - 1;
+        if (iy < 0 || iy >= H) continue;
+        float wr[4][8];
+#pragma unroll
+        for (int o = 0; o < 4; o++) {
+          const float4 w0 = *(const float4*)(wl + (tap * 4 + o) * C0 + cv * 8), w1 = *(const float4*)(wl + (tap * 4 + o) * C0 + cv * 8 + 4);
+          wr[o][0] = w0.x; wr[o][1] = w0.y; wr[o][2] = w0.z; wr[o][3] = w0.w; wr[o][4] = w1.x; wr[o][5] = w1.y; wr[o][6] = w1.z; wr[o][7] = w1.w;
+        }
+        const bf16_t* xr = x + (((size_t)b * H + iy) * W) * C0 + cv * 8;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          const int ix = px0 + k + tap % 3 - 1;
+          if (ix < 0 || ix >= W) continue;
+          float f[8];
+          ew_unpack8(*(const uint4*)(xr + (size_t)ix * C0), f);
+#pragma unroll
+          for (int o = 0; o < 4; o++)
+#pragma unroll
+            for (int e = 0; e < 8; e++) vals[k * 4 + o] += f[e] * wr[o][e];
+        }
+      }
+    }
+#pragma unroll
+    for (int s = 32, n = 16; n >= 1; s >>= 1, n >>= 1) {
+      const bool up = (lane & s) != 0;
+#pragma unroll
+      for (int i = 0; i < n; i++) {
+        const float lo = vals[i], hi = vals[i + n];
+        const float recv = __shfl_xor(up ? lo : hi, s);
+        vals[i] = (up ? hi : lo) + recv;
+      }
+    }
+    const float tot = vals[0] + __shfl_xor(vals[0], 1);
+    if (!(lane & 1)) {
+      const int idx = lane >> 1, k = idx >> 2, o = idx & 3;
+      y[(((size_t)b * 4 + o) * H + py) * W + px0 + k] = tot + (bias ? bias[o] : 0.f);
+    }
+  }
+}
 extern "C" int pcm_conv_out_fwd(const void* x, const float* w, const float* bias, float* y, int B, int H, int W, int C0, void* stream) {
   PCM_CHECK(x && w && y && (C0 % 8) == 0 && C0 <= 1024 && PCM_ALIGNED16(x), PCM_EINVAL, "pcm_conv_out_fwd: C0%%8, C0<=1024");
   long npix = (long)B * H * W;
-  long blocks = (npix + 3) / 4; if (blocks > PCM_GRID_CAP(2048)) blocks = PCM_GRID_CAP(2048);
-  PCM_LAUNCH(conv_out_kernel, dim3((int)blocks), dim3(256), 36 * C0 * 4, stream, (const bf16_t*)x, w, bias, y, B, H, W, C0);
+  if ((W % 8) == 0) {
+    long blocks = (npix / 8 + 3) / 4; if (blocks > PCM_GRID_CAP(768)) blocks = PCM_GRID_CAP(768);
+    PCM_LAUNCH(conv_out8_kernel, dim3((int)blocks), dim3(256), 36 * C0 * 4, stream, (const bf16_t*)x, w, bias, y, B, H, W, C0);
+  } else {
+    long blocks = (npix + 3) / 4; if (blocks > PCM_GRID_CAP(768)) blocks = PCM_GRID_CAP(768);
+    PCM_LAUNCH(conv_out_kernel, dim3((int)blocks), dim3(256), 36 * C0 * 4, stream, (const bf16_t*)x, w, bias, y, B, H, W, C0);
+  }
   return pcm_post_launch("pcm_conv_out_fwd");
 }
 

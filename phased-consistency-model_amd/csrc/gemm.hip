@@ -442,8 +442,14 @@ static bool gemm_big_ok(const pcm_gemm_seg* segs, int nseg, const pcm_gemm_epi* 
   if (e->rowvec && (((uintptr_t)e->rowvec) & 15)) return false;
   return true;
 }
+// rank-64 projection that the streaming kernel (gemm_n64.hip) takes
+static bool gemm_n64_ok(const pcm_gemm_seg* segs, int nseg, const pcm_gemm_epi* e) {
+  return big_mode() > 0 && !g_force_bm && nseg == 1 && segs[0].mode == PCM_SEG_PLAIN && e->N == 64 && (segs[0].K % 64) == 0 &&
+         e->out_dtype != PCM_F32 && !e->bias && !e->rowvec && !e->residual && e->act == PCM_ACT_NONE;
+}
 extern "C" size_t pcm_gemm_workspace_bytes(const pcm_gemm_seg* segs, int nseg, const pcm_gemm_epi* e) {
   if (!segs || !e || nseg < 1 || nseg > 2 || e->M <= 0 || e->N <= 0) return 0;
+  if (gemm_n64_ok(segs, nseg, e)) return 0;
   // the workspace is sized for the plan that would be used WITH a workspace; pcm_gemm_bf16 re-plans identically
   return gemm_plan(e->M, e->N, gemm_total_kt(segs, nseg), true, gemm_big_ok(segs, nseg, e)).ws_bytes;
 }
@@ -481,6 +487,12 @@ extern "C" int pcm_gemm_bf16(const pcm_gemm_seg* segs, int nseg, const pcm_gemm_
   g.bias = e->bias; g.rowvec = (const bf16_t*)e->rowvec; g.rpb = e->rows_per_batch > 0 ? e->rows_per_batch : 1;
   g.res = (const bf16_t*)e->residual; g.ldr = e->ldr; g.out = e->out; g.ldo = e->ldo;
   g.out_f32 = e->out_dtype == PCM_F32; g.act = e->act; g.alpha = e->alpha;
+  if (gemm_n64_ok(segs, nseg, e)) {
+    g_last_plan = 64;
+    int rc = pcm_gemm_n64_launch(g, stream);
+    if (rc) return rc;
+    return pcm_post_launch("pcm_gemm_bf16");
+  }
   GemmPlan pl = gemm_plan(e->M, e->N, gemm_total_kt(segs, nseg), e->workspace != nullptr, gemm_big_ok(segs, nseg, e));
   if (pl.splitk > 1) {
     PCM_CHECK(e->workspace_bytes >= pl.ws_bytes && PCM_ALIGNED16(e->workspace), PCM_EINVAL,

@@ -469,3 +469,17 @@ def case_gemm_big(dev, which):
 
 
 GEMM_BIG_CASES = ["plain_lora", "ragged", "two_tiles_k", "splitk", "conv", "conv_s2", "conv_up", "conv_zi", "conv_conv"]
+
+
+def case_gemm_n64(dev, M, K):
+    """Streaming rank-64 projection kernel (gemm_n64.hip) vs torch fp32; returns max abs excess over tolerance."""
+    from pcm_amd import capi, ops
+    g = torch.Generator().manual_seed(M + K)
+    x = (torch.randn(M, K, generator=g)).bfloat16().to(dev)
+    w = (torch.randn(64, K, generator=g) * 0.1).bfloat16().to(dev)
+    out = torch.empty(M, 64, dtype=torch.bfloat16, device=dev)
+    ops.gemm([ops.Seg(x, w)], M, 64, out)
+    assert capi.lib().dll.pcm_debug_last_gemm_plan() == 64
+    ref = x.float() @ w.float().T
+    err = (out.float() - ref).abs()
+    return float((err - (2e-2 + 1e-2 * ref.abs())).max())

@@ -29,6 +29,7 @@ def test_elementwise():
 
 def test_edge_convs():
     K.case_edge_convs("cpu")
+    K.case_edge_convs("cpu", B=2, H=5, W=8, C0=64)     # W%8==0: the 4-pixel conv_in and the 8-pixel conv_out kernels
 
 
 def test_timestep_embedding():
