@@ -278,9 +278,10 @@ __global__ __launch_bounds__(256) void conv4x4_kernel(const float* x, const floa
     for (int k = 0; k < 4; k++)
 #pragma unroll
       for (int e = 0; e < 8; e++) acc[k][e] = bias ? bias[cv * 8 + e] : 0.f;
+#pragma unroll 1
     for (int ci = 0; ci < 4; ci++) {
       const float* xc = x + ((size_t)b * 4 + ci) * H * W;
-#pragma unroll
+#pragma unroll 1
       for (int dy = 0; dy < 3; dy++) {
         const int iy = py + dy - 1;
         if (iy < 0 || iy >= H) continue;
@@ -375,7 +376,7 @@ __global__ __launch_bounds__(256) void conv_out8_kernel(const bf16_t* x, const f
 #pragma unroll
     for (int i = 0; i < 32; i++) vals[i] = 0.f;
     for (int cv = lane; cv < CV; cv += 64) {
-#pragma unroll
+#pragma unroll 1   // one tap at a time: fully unrolled this kernel needs 400+ VGPRs (one wave per SIMD, latency bound)
       for (int tap = 0; tap < 9; tap++) {
         const int iy = py + tap / 3 - 1;
         if (iy < 0 || iy >= H) continue;

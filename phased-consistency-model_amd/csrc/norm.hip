@@ -66,22 +66,35 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(GNArgs a) {
   int p_end = p_begin + a.ppb; if (p_end > a.HW) p_end = a.HW;
   const bf16_t* xb = a.x + (size_t)b * a.HW * a.C + c0;
   const bf16_t* dyb = MODE == 1 ? a.dy + (size_t)b * a.HW * a.C + c0 : nullptr;
-  for (int p = p_begin + pl; p < p_end; p += k) {
-    float xv[8];
-    unpack8(*(const uint4*)(xb + (size_t)p * a.C), xv);
-    if (MODE == 0) {
+  // 4 pixels per trip: the loads of a trip are issued together (clamped addresses, masked accumulation) -- with one load per
+  // thread in flight this pass ran at ~2.3 TB/s
+  for (int p = p_begin + pl; p < p_end; p += 4 * k) {
+    uint4 xr[4], dr[4];
 #pragma unroll
-      for (int e = 0; e < 8; e++) { s1[e] += xv[e]; s2[e] += xv[e] * xv[e]; }
-    } else {
-      float dv[8];
-      unpack8(*(const uint4*)(dyb + (size_t)p * a.C), dv);
+    for (int u = 0; u < 4; u++) {
+      int pp = p + u * k; if (pp > p_end - 1) pp = p_end - 1;
+      xr[u] = *(const uint4*)(xb + (size_t)pp * a.C);
+      if (MODE == 1) dr[u] = *(const uint4*)(dyb + (size_t)pp * a.C);
+    }
 #pragma unroll
-      for (int e = 0; e < 8; e++) {
-        float xh = (xv[e] - mu[e]) * rs[e];
-        float dz = dv[e];
-        dz *= gn_act_grad(xh * ga[e] + be[e], a.act);
-        float t = dz * ga[e];
-        s1[e] += t; s2[e] += t * xh;
+    for (int u = 0; u < 4; u++) {
+      if (p + u * k >= p_end) continue;
+      float xv[8];
+      unpack8(xr[u], xv);
+      if (MODE == 0) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) { s1[e] += xv[e]; s2[e] += xv[e] * xv[e]; }
+      } else {
+        float dv[8];
+        unpack8(dr[u], dv);
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+          float xh = (xv[e] - mu[e]) * rs[e];
+          float dz = dv[e];
+          dz *= gn_act_grad(xh * ga[e] + be[e], a.act);
+          float t = dz * ga[e];
+          s1[e] += t; s2[e] += t * xh;
+        }
       }
     }
   }
@@ -146,29 +159,42 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GNApply a) {
   const bf16_t* xb = a.x + (size_t)b * a.HW * a.C;
   bf16_t* yb = a.y + (size_t)b * a.HW * a.C;
   const bf16_t* dyb = MODE == 1 ? a.dy + (size_t)b * a.HW * a.C : nullptr;
-  for (size_t v = v0 + threadIdx.x; v < v1; v += blockDim.x) {
-    int c0 = (int)(v % CV) * 8;
-    float xv[8], o[8];
-    unpack8(*(const uint4*)(xb + v * 8), xv);
-    if (MODE == 0) {
+  // 4 vectors per trip, loads issued together (clamped addresses; the store is skipped for the clamped duplicates)
+  for (size_t vb = v0 + threadIdx.x; vb < v1; vb += 4 * (size_t)blockDim.x) {
+    uint4 xr[4], dr[4];
 #pragma unroll
-      for (int e = 0; e < 8; e++) {
-        float z = xv[e] * sc[c0 + e] + sh[c0 + e];
-        o[e] = gn_act(z, a.act);
-      }
-    } else {
-      float dv[8];
-      unpack8(*(const uint4*)(dyb + v * 8), dv);
-#pragma unroll
-      for (int e = 0; e < 8; e++) {
-        int c = c0 + e, g = c / a.cpg;
-        float xh = (xv[e] - gm[g]) * gr[g];
-        float dz = dv[e];
-        dz *= gn_act_grad(xh * sc[c] + sh[c], a.act);
-        o[e] = gr[g] * (dz * sc[c] - g1[g] - xh * g2[g]);
-      }
+    for (int u = 0; u < 4; u++) {
+      size_t v = vb + u * (size_t)blockDim.x; if (v > v1 - 1) v = v1 - 1;
+      xr[u] = *(const uint4*)(xb + v * 8);
+      if (MODE == 1) dr[u] = *(const uint4*)(dyb + v * 8);
     }
-    *(uint4*)(yb + v * 8) = pack8(o);
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const size_t v = vb + u * (size_t)blockDim.x;
+      if (v >= v1) continue;
+      int c0 = (int)(v % CV) * 8;
+      float xv[8], o[8];
+      unpack8(xr[u], xv);
+      if (MODE == 0) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+          float z = xv[e] * sc[c0 + e] + sh[c0 + e];
+          o[e] = gn_act(z, a.act);
+        }
+      } else {
+        float dv[8];
+        unpack8(dr[u], dv);
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+          int c = c0 + e, g = c / a.cpg;
+          float xh = (xv[e] - gm[g]) * gr[g];
+          float dz = dv[e];
+          dz *= gn_act_grad(xh * sc[c] + sh[c], a.act);
+          o[e] = gr[g] * (dz * sc[c] - g1[g] - xh * g2[g]);
+        }
+      }
+      *(uint4*)(yb + v * 8) = pack8(o);
+    }
   }
 }
 
@@ -258,48 +284,59 @@ extern "C" int pcm_groupnorm_bwd_apply(const void* x, const void* dy, const doub
 // ------------------------------------------------------------------------------------------
 // LayerNorm over the last dim: one wave per row, 16 B/lane, row kept in registers (C <= 1536*... see VPL)
 // ------------------------------------------------------------------------------------------
-template <int VPL>  // 16-byte vectors per lane: C <= 512*VPL
+template <int VPL, int R>  // 16-byte vectors per lane: C <= 512*VPL; R rows per wave with all their loads issued together
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* x, const float* gamma, const float* beta, bf16_t* y,
                                                      float* mean, float* rstd, int M, int C, float eps) {
-  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= M) return;
+  const int lane = threadIdx.x & 63, row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
+  if (row0 >= M) return;
   const int CV = C / 8;
-  float v[VPL][8];
-  float s = 0.f;
+  uint4 raw[R][VPL];
 #pragma unroll
-  for (int i = 0; i < VPL; i++) {
-    int cv = lane + 64 * i;
-    if (cv < CV) {
-      unpack8(*(const uint4*)(x + (size_t)row * C + cv * 8), v[i]);
+  for (int r = 0; r < R; r++) {
+    int row = row0 + r; if (row > M - 1) row = M - 1;
 #pragma unroll
-      for (int e = 0; e < 8; e++) s += v[i][e];
-    } else {
-#pragma unroll
-      for (int e = 0; e < 8; e++) v[i][e] = 0.f;
+    for (int i = 0; i < VPL; i++) {
+      int cv = lane + 64 * i; if (cv > CV - 1) cv = CV - 1;      // clamped (unconditional) loads; lanes beyond CV are masked below
+      raw[r][i] = *(const uint4*)(x + (size_t)row * C + cv * 8);
     }
   }
-  const float mu = wave_sum(s) / C;
-  float q = 0.f;
 #pragma unroll
-  for (int i = 0; i < VPL; i++)
-    if (lane + 64 * i < CV) {
+  for (int r = 0; r < R; r++) {
+    const int row = row0 + r;
+    if (row >= M) break;
+    float v[VPL][8];
+    float s = 0.f;
 #pragma unroll
-      for (int e = 0; e < 8; e++) { float d = v[i][e] - mu; q += d * d; }
+    for (int i = 0; i < VPL; i++) {
+      unpack8(raw[r][i], v[i]);
+      if (lane + 64 * i < CV) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) s += v[i][e];
+      }
     }
-  const float rs = rsqrtf(wave_sum(q) / C + eps);
-  if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+    const float mu = wave_sum(s) / C;
+    float q = 0.f;
 #pragma unroll
-  for (int i = 0; i < VPL; i++) {
-    int cv = lane + 64 * i;
-    if (cv < CV) {
-      float o[8];
-      float4 g0 = *(const float4*)(gamma + cv * 8), g1 = *(const float4*)(gamma + cv * 8 + 4);
-      float4 b0 = *(const float4*)(beta + cv * 8), b1 = *(const float4*)(beta + cv * 8 + 4);
-      const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-      const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+    for (int i = 0; i < VPL; i++)
+      if (lane + 64 * i < CV) {
 #pragma unroll
-      for (int e = 0; e < 8; e++) o[e] = (v[i][e] - mu) * rs * gg[e] + bb[e];
-      *(uint4*)(y + (size_t)row * C + cv * 8) = pack8(o);
+        for (int e = 0; e < 8; e++) { float d = v[i][e] - mu; q += d * d; }
+      }
+    const float rs = rsqrtf(wave_sum(q) / C + eps);
+    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+#pragma unroll
+    for (int i = 0; i < VPL; i++) {
+      int cv = lane + 64 * i;
+      if (cv < CV) {
+        float o[8];
+        float4 g0 = *(const float4*)(gamma + cv * 8), g1 = *(const float4*)(gamma + cv * 8 + 4);
+        float4 b0 = *(const float4*)(beta + cv * 8), b1 = *(const float4*)(beta + cv * 8 + 4);
+        const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+        const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+        for (int e = 0; e < 8; e++) o[e] = (v[i][e] - mu) * rs * gg[e] + bb[e];
+        *(uint4*)(y + (size_t)row * C + cv * 8) = pack8(o);
+      }
     }
   }
 }
@@ -355,10 +392,10 @@ extern "C" int pcm_layernorm_fwd(const void* x, const float* gamma, const float*
   PCM_CHECK(x && gamma && beta && y && mean && rstd && M > 0 && C > 0 && (C % 8) == 0 && C <= 2048, PCM_EINVAL,
             "pcm_layernorm_fwd: need C%%8==0, C<=2048 (M=%d C=%d)", M, C);
   PCM_CHECK(PCM_ALIGNED16(x) && PCM_ALIGNED16(y) && PCM_ALIGNED16(gamma) && PCM_ALIGNED16(beta), PCM_EALIGN, "pcm_layernorm_fwd: alignment");
-  dim3 grid((M + 3) / 4), block(256);
-  if (C <= 512) PCM_LAUNCH((ln_fwd_kernel<1>), grid, block, 0, stream, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, M, C, eps);
-  else if (C <= 1024) PCM_LAUNCH((ln_fwd_kernel<2>), grid, block, 0, stream, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, M, C, eps);
-  else PCM_LAUNCH((ln_fwd_kernel<4>), grid, block, 0, stream, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, M, C, eps);
+  dim3 block(256);
+  if (C <= 512) PCM_LAUNCH((ln_fwd_kernel<1, 4>), dim3((M + 15) / 16), block, 0, stream, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, M, C, eps);
+  else if (C <= 1024) PCM_LAUNCH((ln_fwd_kernel<2, 4>), dim3((M + 15) / 16), block, 0, stream, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, M, C, eps);
+  else PCM_LAUNCH((ln_fwd_kernel<4, 2>), dim3((M + 7) / 8), block, 0, stream, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, M, C, eps);
   return pcm_post_launch("pcm_layernorm_fwd");
 }
 

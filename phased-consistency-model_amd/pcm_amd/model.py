@@ -520,6 +520,24 @@ class UNet:
             return out, tape
         return out
 
+    @staticmethod
+    def tape_first_half(tape):
+        """Tape of the first half of the batch of a ``forward(save=True)`` call.  Every saved tensor is batch-major
+        ([B, ...] or [B*HW, ...] rows), so the first-half tape is the leading half of each tensor (views, no copies) with
+        the recorded ``B`` / ``M`` halved.  Used to run the online (grad) and the target (no-grad) forward of the
+        distillation step as ONE 2B-sample launch schedule and back-propagate through the online half only."""
+        def half(v, key=None):
+            if isinstance(v, torch.Tensor):
+                assert v.shape[0] % 2 == 0, (key, tuple(v.shape))
+                return v[: v.shape[0] // 2]
+            if isinstance(v, dict):
+                return {k: half(x, k) for k, x in v.items()}
+            if isinstance(v, int) and not isinstance(v, bool) and key in ("B", "M"):
+                assert v % 2 == 0, (key, v)
+                return v // 2
+            return v
+        return [(kind, p, half(sv)) for kind, p, sv in tape]
+
     def backward(self, d_eps, tape, d_feats=None, need_input_grad=False):
         """d_eps [B,4,H,W] fp32 -> LoRA grads accumulated in self.lora.grads (if any).
         Feature-tap tapes (``forward(features=True, save=True)``) take ``d_feats`` (list of 9 gradients, entries may

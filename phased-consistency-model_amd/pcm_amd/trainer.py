@@ -65,6 +65,7 @@ class Distiller:
         self.teacher = UNet(weights, None)
         self.world_size, self.pg = world_size, process_group
         self.step_count = 0
+        self.fuse_online_target = True    # online + target forward as one 2B-sample schedule (False: two B-sample passes)
         # optimizer step count and learning rate also live on the device, so a captured hipGraph of the
         # step stays valid while both advance
         self.step_dev = torch.zeros(1, dtype=torch.int64, device=self.device)
@@ -86,11 +87,8 @@ class Distiller:
         B = latents.shape[0]
         start_t, t_n = self.timesteps_for(index)
         noisy = ops.add_noise(latents, noise, T.acp, start_t)                                   # :1178
-        # online student forward at t_{n+k} (grad) ---------------------------------------------- :1192
-        eps_s, tape = self.student.forward(noisy, start_t, prompt_embeds, save=True)
-        model_pred, coef, end_t = ops.phase_jump(eps_s, noisy, start_t, index, T.acp, T.acp_prev, T.ddim_timesteps_prev,
-                                                 T.edges, target_mode=False)                     # :1200-1212
         # teacher cond (+ uncond) in ONE batched forward (no grad, no LoRA) --------------------- :1217-1252
+        # (scheduled first: the online forward does not depend on it, the target forward does)
         if cfg.not_apply_cfg_solver:
             eps_c = self.teacher.forward(noisy, start_t, prompt_embeds)
             eps_u = eps_c
@@ -99,8 +97,19 @@ class Distiller:
                                         torch.cat([prompt_embeds, uncond_prompt_embeds]))
             eps_c, eps_u = both[:B], both[B:]
         x_prev64, x_prev32 = ops.cfg_ddim_step(eps_c, eps_u, noisy, start_t, index, w, T.acp, T.acp_prev)   # :1254-1258
-        # target forward: same online weights (incl. LoRA) at (x_prev, t_n), no grad ------------ :1261-1268
-        eps_t = self.student.forward(x_prev32, t_n, prompt_embeds)
+        if self.fuse_online_target:
+            # online student forward at t_{n+k} (grad, :1192) and target forward at (x_prev, t_n) (same online weights incl.
+            # LoRA, no grad, :1261-1268) as ONE 2B-sample schedule: samples are independent, so each half is exactly the
+            # separate forward; the backward runs on the online half of the tape only
+            eps_st, tape2 = self.student.forward(torch.cat([noisy, x_prev32]), torch.cat([start_t, t_n]),
+                                                 torch.cat([prompt_embeds, prompt_embeds]), save=True)
+            eps_s, eps_t = eps_st[:B], eps_st[B:]
+            tape = self.student.tape_first_half(tape2)
+        else:
+            eps_s, tape = self.student.forward(noisy, start_t, prompt_embeds, save=True)
+            eps_t = self.student.forward(x_prev32, t_n, prompt_embeds)
+        model_pred, coef, end_t = ops.phase_jump(eps_s, noisy, start_t, index, T.acp, T.acp_prev, T.ddim_timesteps_prev,
+                                                 T.edges, target_mode=False)                     # :1200-1212
         target, _, _ = ops.phase_jump(eps_t, x_prev64, t_n, index, T.acp, T.acp_prev, T.ddim_timesteps_prev, T.edges,
                                       target_mode=True)                                          # :1269-1280
         loss, d_eps = ops.consistency_loss(model_pred, target, coef, cfg.loss_type == "huber", cfg.huber_c)   # :1283-1293
