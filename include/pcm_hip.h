@@ -40,6 +40,10 @@ extern "C" {
 #define PCM_ACT_NONE 0
 #define PCM_ACT_SILU 1
 #define PCM_ACT_LEAKY 2 /* LeakyReLU(0.01): DiscriminatorHead, discriminator_sd15.py:354 */
+/* GEGLU fused into the projection (diffusers GEGLU.forward: hidden, gate = proj(x).chunk(2); hidden * gelu(gate)).
+ * The weight rows (and bias) must be packed INTERLEAVED in groups of 8: [v0..v7, g0..g7, v8..v15, g8..g15, ...] (N = 2*inner
+ * rows); the output has N/2 columns (ldo >= N/2).  No residual / row vector; bf16 output only. */
+#define PCM_ACT_GEGLU 3
 
 const char* pcm_last_error(void);
 int pcm_abi_version(void);

@@ -366,10 +366,11 @@ static int big_mode() {
 extern "C" void pcm_debug_force_gemm_tile(int bm, int bn) { g_force_bm = bm; g_force_bn = bn; }
 
 // big_ok: the call satisfies gemm8p's preconditions (K%64==0 per segment, bf16 output with 16-B rows, < 2 GiB operands)
-static GemmPlan gemm_plan(int M, int N, int total_kt, bool allow_split, bool big_ok) {
+static GemmPlan gemm_plan(int M, int N, int total_kt, bool allow_split, bool big_ok, bool must_big = false) {
   GemmPlan p;
   p.big_fn = 0;
-  if (big_ok && !g_force_bm && big_mode() > 0 && M >= 256) {
+  if (must_big) allow_split = false;   // fused-GEGLU epilogue lives in gemm8p only, on complete sums
+  if (big_ok && ((!g_force_bm && big_mode() > 0 && M >= 256) || must_big)) {
     // candidates 256x320 / 256x256 (+ split-K); pick by useful work per block-round of the 256 CUs
     int best_fn = 0, best_s = 1; double best = 0.0;
     for (int fn = 5; fn >= 4; fn--) {
@@ -384,7 +385,7 @@ static GemmPlan gemm_plan(int M, int N, int total_kt, bool allow_split, bool big
         if (eff > best + 1e-9) { best = eff; best_fn = fn; best_s = s; }
       }
     }
-    const double need = big_mode() >= 2 ? 0.0 : 0.62;
+    const double need = (big_mode() >= 2 || must_big) ? 0.0 : 0.62;
     if (best_fn && best >= need) {
       p.big_fn = best_fn; p.BM = 256; p.BN = 64 * best_fn;
       p.tiles_m = (M + 255) / 256; p.tiles_n = (N + p.BN - 1) / p.BN;
@@ -451,7 +452,7 @@ extern "C" size_t pcm_gemm_workspace_bytes(const pcm_gemm_seg* segs, int nseg, c
   if (!segs || !e || nseg < 1 || nseg > 2 || e->M <= 0 || e->N <= 0) return 0;
   if (gemm_n64_ok(segs, nseg, e)) return 0;
   // the workspace is sized for the plan that would be used WITH a workspace; pcm_gemm_bf16 re-plans identically
-  return gemm_plan(e->M, e->N, gemm_total_kt(segs, nseg), true, gemm_big_ok(segs, nseg, e)).ws_bytes;
+  return gemm_plan(e->M, e->N, gemm_total_kt(segs, nseg), true, gemm_big_ok(segs, nseg, e), e->act == PCM_ACT_GEGLU).ws_bytes;
 }
 
 extern "C" int pcm_gemm_bf16(const pcm_gemm_seg* segs, int nseg, const pcm_gemm_epi* e, void* stream) {
@@ -480,7 +481,11 @@ extern "C" int pcm_gemm_bf16(const pcm_gemm_seg* segs, int nseg, const pcm_gemm_
     }
   }
   if (any_conv) PCM_CHECK(e->Ho > 0 && e->Wo > 0 && (e->M % (e->Ho * e->Wo)) == 0, PCM_EINVAL, "pcm_gemm_bf16: M must be B*Ho*Wo for conv");
-  PCM_CHECK(e->out && PCM_ALIGNED16(e->out) && (e->ldo % 4) == 0 && e->ldo >= e->N, PCM_EALIGN, "pcm_gemm_bf16: out/ldo alignment");
+  const bool geglu = e->act == PCM_ACT_GEGLU;
+  PCM_CHECK(e->out && PCM_ALIGNED16(e->out) && (e->ldo % 4) == 0 && e->ldo >= (geglu ? e->N / 2 : e->N), PCM_EALIGN, "pcm_gemm_bf16: out/ldo alignment");
+  if (geglu)
+    PCM_CHECK((e->N % 16) == 0 && (e->ldo % 8) == 0 && e->out_dtype != PCM_F32 && !e->residual && !e->rowvec && gemm_big_ok(segs, nseg, e), PCM_EUNSUPPORTED,
+              "pcm_gemm_bf16: PCM_ACT_GEGLU needs N%%16==0, K%%64==0 per segment, bf16 output, no residual / row vector");
   if (e->residual) PCM_CHECK((((uintptr_t)e->residual) & 7) == 0 && (e->ldr % 4) == 0, PCM_EALIGN, "pcm_gemm_bf16: residual alignment");
   if (e->rowvec) PCM_CHECK(e->rows_per_batch > 0, PCM_EINVAL, "pcm_gemm_bf16: rows_per_batch");
   g.nseg = nseg; g.M = e->M; g.N = e->N; g.Ho = e->Ho > 0 ? e->Ho : 1; g.Wo = e->Wo > 0 ? e->Wo : 1;
@@ -493,7 +498,7 @@ extern "C" int pcm_gemm_bf16(const pcm_gemm_seg* segs, int nseg, const pcm_gemm_
     if (rc) return rc;
     return pcm_post_launch("pcm_gemm_bf16");
   }
-  GemmPlan pl = gemm_plan(e->M, e->N, gemm_total_kt(segs, nseg), e->workspace != nullptr, gemm_big_ok(segs, nseg, e));
+  GemmPlan pl = gemm_plan(e->M, e->N, gemm_total_kt(segs, nseg), e->workspace != nullptr, gemm_big_ok(segs, nseg, e), geglu);
   if (pl.splitk > 1) {
     PCM_CHECK(e->workspace_bytes >= pl.ws_bytes && PCM_ALIGNED16(e->workspace), PCM_EINVAL,
               "pcm_gemm_bf16: workspace too small (%zu < %zu) or unaligned", (size_t)e->workspace_bytes, pl.ws_bytes);

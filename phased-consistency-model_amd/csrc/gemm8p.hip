@@ -319,6 +319,29 @@ __global__ __launch_bounds__(512) void pcm_gemm8p_kernel(GemmDev g) {
       }
     }
     __syncthreads();
+    if (g.act == PCM_ACT_GEGLU) {   // 16 packed columns = 8 values + their 8 gates -> 8 outputs
+      constexpr int C16 = BN / 16;
+      for (int idx = tid; idx < 64 * C16; idx += 512) {
+        const int lr = idx / C16, c16 = idx - lr * C16;
+        const int m = m0 + 128 * (lr >> 5) + 32 * q + (lr & 31), n = n0 + 16 * c16;
+        if (m >= g.M || n >= g.N) continue;
+        float vv[16];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+          const float4 t4 = *(const float4*)(smem + ((size_t)lr * CH + ((4 * c16 + c) ^ (lr & 15))) * 16);
+          vv[4 * c] = t4.x; vv[4 * c + 1] = t4.y; vv[4 * c + 2] = t4.z; vv[4 * c + 3] = t4.w;
+        }
+        if (g.bias) {
+#pragma unroll
+          for (int e = 0; e < 16; e++) vv[e] += g.bias[n + e];
+        }
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) o[e] = vv[e] * gelu_erf_f(vv[8 + e]);
+        *(uint4*)((bf16_t*)g.out + (size_t)m * g.ldo + (n >> 1)) = make_uint4(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]), pack_bf2(o[4], o[5]), pack_bf2(o[6], o[7]));
+      }
+      continue;
+    }
     for (int idx = tid; idx < 64 * C8; idx += 512) {
       const int lr = idx / C8, c8 = idx - lr * C8;
       const int m = m0 + 128 * (lr >> 5) + 32 * q + (lr & 31), n = n0 + 8 * c8;

@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(HERE, "lib", "libpcm_hip.so")
 
 PCM_BF16, PCM_F32 = 0, 1
-ACT_NONE, ACT_SILU, ACT_LEAKY = 0, 1, 2
+ACT_NONE, ACT_SILU, ACT_LEAKY, ACT_GEGLU = 0, 1, 2, 3
 SEG_PLAIN, SEG_CONV3X3 = 0, 1
 SRC_DIRECT, SRC_UPSAMPLE2, SRC_ZEROINS2 = 0, 1, 2
 

@@ -28,7 +28,7 @@ BF16 = torch.bfloat16
 # ----------------------------------------------------------------------------------------------
 class PackedLayer:
     """One Linear / conv1x1 / conv3x3 of the base model in MFMA operand layouts."""
-    __slots__ = ("kind", "N", "K", "C", "w_fwd", "w_bwd", "bias")
+    __slots__ = ("kind", "N", "K", "C", "w_fwd", "w_bwd", "bias", "w_geglu", "bias_geglu")
 
     def __init__(self, w, bias, device, need_bwd):
         w = w.to(device=device, dtype=torch.float32).contiguous()
@@ -42,6 +42,17 @@ class PackedLayer:
             self.kind, self.C = "lin", 0
             self.K = w.numel() // self.N
             self.w_fwd, self.w_bwd = ops.pack_linear(w.view(self.N, self.K), True, need_bwd)
+        self.w_geglu = self.bias_geglu = None
+
+    def pack_geglu(self):
+        """Extra forward operand for the fused GEGLU epilogue (PCM_ACT_GEGLU): rows interleaved [8 values, 8 gates, ...].
+        Built from the packed bf16 rows (a row permutation), used by the no-grad LoRA-free (teacher) pass."""
+        inner = self.N // 2
+        j = torch.arange(inner // 8, device=self.w_fwd.device)
+        e = torch.arange(8, device=self.w_fwd.device)
+        perm = torch.stack([(8 * j)[:, None] + e, inner + (8 * j)[:, None] + e], 1).reshape(-1)
+        self.w_geglu = self.w_fwd.view(self.N, self.K)[perm].contiguous()
+        self.bias_geglu = None if self.bias is None else self.bias[perm].contiguous()
 
 
 class UNetWeights:
@@ -71,6 +82,8 @@ class UNetWeights:
                 continue
             else:
                 self.layers[path] = PackedLayer(state_dict[k], state_dict.get(path + ".bias"), self.device, need_bwd)
+                if path.endswith("ff.net.0.proj"):
+                    self.layers[path].pack_geglu()
         self.conv_in = (state_dict["conv_in.weight"].to(**f32).contiguous(), state_dict["conv_in.bias"].to(**f32).contiguous())
         self.conv_out = (state_dict["conv_out.weight"].to(**f32).contiguous(), state_dict["conv_out.bias"].to(**f32).contiguous())
 
@@ -413,8 +426,15 @@ class UNet:
         h2 = self._attn_fwd(b + "attn2.", n2, text.view(B * Lt, -1), B, L, Lt, C, h1, sa2)
         g3, b3 = W.norms[b + "norm3"]
         n3, mu3, rs3 = ops.layernorm_fwd(h2, g3, b3)
-        hg = layer_fwd(W, lora, b + "ff.net.0.proj", n3, M, save=sf0)
-        gg = ops.geglu_fwd(hg)
+        Lff = W.layers[b + "ff.net.0.proj"]
+        if lora is None and not rec and Lff.w_geglu is not None and M >= 128:
+            # frozen no-grad pass: GEGLU applied in the projection's epilogue (the 2*inner-wide pre-activation never reaches HBM)
+            hg = None
+            gg = torch.empty(M, Lff.N // 2, dtype=BF16, device=n3.device)
+            ops.gemm([Seg(n3, Lff.w_geglu)], M, Lff.N, gg, bias=Lff.bias_geglu, act=capi.ACT_GEGLU, ldo=Lff.N // 2)
+        else:
+            hg = layer_fwd(W, lora, b + "ff.net.0.proj", n3, M, save=sf0)
+            gg = ops.geglu_fwd(hg)
         h3 = layer_fwd(W, lora, b + "ff.net.2", gg, M, save=sf2, residual=h2)
         out = layer_fwd(W, lora, p + "proj_out", h3, M, save=spo, residual=x.view(M, C))
         if rec:

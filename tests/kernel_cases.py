@@ -483,3 +483,22 @@ def case_gemm_n64(dev, M, K):
     ref = x.float() @ w.float().T
     err = (out.float() - ref).abs()
     return float((err - (2e-2 + 1e-2 * ref.abs())).max())
+
+
+def case_gemm_geglu(dev, M=300, K=128, inner=160):
+    """Projection with the GEGLU epilogue (interleaved value/gate rows) vs torch; returns max abs excess over tolerance."""
+    import torch.nn.functional as F
+    from pcm_amd import capi, ops
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(M, K, generator=g).bfloat16().to(dev)
+    w = (torch.randn(2 * inner, K, generator=g) * 0.1).bfloat16().to(dev)
+    bias = torch.randn(2 * inner, generator=g).to(dev)
+    j, e = torch.arange(inner // 8, device=dev), torch.arange(8, device=dev)
+    perm = torch.stack([(8 * j)[:, None] + e, inner + (8 * j)[:, None] + e], 1).reshape(-1)
+    out = torch.empty(M, inner, dtype=torch.bfloat16, device=dev)
+    ops.gemm([ops.Seg(x, w[perm].contiguous())], M, 2 * inner, out, bias=bias[perm].contiguous(), act=capi.ACT_GEGLU, ldo=inner)
+    assert capi.lib().dll.pcm_debug_last_gemm_plan() >= 4000
+    h = x.float() @ w.float().T + bias
+    ref = h[:, :inner] * F.gelu(h[:, inner:])
+    err = (out.float() - ref).abs()
+    return float((err - (2e-2 + 1e-2 * ref.abs())).max())

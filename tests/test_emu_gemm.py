@@ -105,3 +105,9 @@ def test_big_tile_kernel(which, lazy_dma, monkeypatch):
 def test_rank64_streaming_kernel(M, K):
     import kernel_cases as KC
     assert KC.case_gemm_n64("cpu", M, K) <= 0
+
+
+def test_fused_geglu_epilogue():
+    import kernel_cases as KC
+    assert KC.case_gemm_geglu("cpu") <= 0
+    assert KC.case_gemm_geglu("cpu", M=256, K=64, inner=128) <= 0

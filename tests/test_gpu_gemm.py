@@ -105,3 +105,10 @@ def test_big_tile_kernel_large_shapes_match_small_tile():
 def test_rank64_streaming_kernel(M, K):
     import kernel_cases as KC
     assert KC.case_gemm_n64("cuda", M, K) <= 0
+
+
+def test_fused_geglu_epilogue():
+    import kernel_cases as KC
+    assert KC.case_gemm_geglu("cuda") <= 0
+    assert KC.case_gemm_geglu("cuda", M=8192, K=1280, inner=5120) <= 0
+    assert KC.case_gemm_geglu("cuda", M=32768, K=320, inner=1280) <= 0
