@@ -69,7 +69,8 @@ def gemm(segs, M, N, out, bias=None, rowvec=None, rows_per_batch=0, residual=Non
         capi.lib().call("pcm_gemm_bf16", arr, len(segs), C.byref(e), capi.Lib.stream())
         ev1.record()
         GEMM_PROFILE.append((2.0 * M * N * sum(s.w.shape[-1] for s in segs), ev0, ev1,
-                             (M, N, tuple(s.w.shape[-1] for s in segs), "conv" if segs[0].conv else "lin")))
+                             (M, N, tuple(s.w.shape[-1] for s in segs), "conv" if segs[0].conv else "lin"),
+                             capi.lib().dll.pcm_debug_last_gemm_plan()))
         return out
     capi.lib().call("pcm_gemm_bf16", arr, len(segs), C.byref(e), capi.Lib.stream())
     return out

@@ -101,7 +101,7 @@ def test_big_tile_kernel(which, lazy_dma, monkeypatch):
     assert excess <= 0, (which, lazy_dma, err)
 
 
-@pytest.mark.parametrize("M,K", [(200, 320), (64, 1280), (130, 768), (77, 192)])
+@pytest.mark.parametrize("M,K", [(200, 320), (64, 1280), (130, 768), (77, 192), (40, 640), (33, 2560), (20, 960)])
 def test_rank64_streaming_kernel(M, K):
     import kernel_cases as KC
     assert KC.case_gemm_n64("cpu", M, K) <= 0
