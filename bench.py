@@ -181,8 +181,20 @@ def main():
             with open(os.environ["PCM_GEMM_TABLE"], "w") as f:
                 for k, (n, t, fl) in rows:
                     f.write("%-44s calls %4d  total %8.3f ms  avg %7.1f us  %7.1f TF/s\n" % (k, n, t, 1e3 * t / n, fl / t / 1e9))
+        # HBM-side bytes of the dominant kernel from the committed PMC passes (separate rocprofv3 --pmc runs, gfx950 FETCH_SIZE x2
+        # correction calibrated on a known copy): profiles/r01_e_pmc_gemm8p_traffic.json.  It is for ONE launch of the largest
+        # 64x64-resolution conv (M=131072, 320->320 + LoRA; algorithmic 186 MB): the 9 taps re-read the activation tile through
+        # the fabric (served by the 256 MB Infinity Cache, not by HBM); see DESIGN.md section 6.
+        traffic, traffic_note = None, None
+        try:
+            pj = json.load(open(os.path.join(ROOT, "profiles", "r01_e_pmc_gemm8p_traffic.json")))
+            traffic = round(pj["tap_outer_K_order (shipped)"]["traffic_MB_corrected"] * 1e6)
+            traffic_note = "bytes per launch of the M=131072 320->320 conv3x3 (+LoRA) launch of this kernel; algorithmic %.0f MB" % (
+                pj["algorithmic_MB"]["read"] + pj["algorithmic_MB"]["write"])
+        except Exception:
+            pass
         roofline = {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                    "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_note": traffic_note,
                     "kernel": "pcm_gemm8p_kernel<3> (256x320 phased tile; all its launches of one step)",
                     "launches": len(dom), "avg_launch_us": round(1e3 * d_ms / max(1, len(dom)), 1),
                     "algorithmic_tflop": round(d_fl / 1e12, 2), "kernel_ms_per_step": round(d_ms, 2),

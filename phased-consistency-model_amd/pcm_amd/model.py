@@ -84,6 +84,14 @@ class UNetWeights:
                 self.layers[path] = PackedLayer(state_dict[k], state_dict.get(path + ".bias"), self.device, need_bwd)
                 if path.endswith("ff.net.0.proj"):
                     self.layers[path].pack_geglu()
+        # self-attention q/k/v of the frozen (LoRA-free, no-grad) pass as ONE projection: rows [Wq; Wk; Wv], the
+        # activation is read once and attention reads q/k/v in place with row stride 3C
+        self.qkv = {}
+        for path in [p_ for p_ in self.layers if p_.endswith("attn1.to_q")]:
+            base = path[:-4]
+            lq, lk, lv = (self.layers[base + n] for n in ("to_q", "to_k", "to_v"))
+            if lq.bias is None and lk.bias is None and lv.bias is None and lq.K == lk.K == lv.K:
+                self.qkv[base] = torch.cat([lq.w_fwd.view(lq.N, lq.K), lk.w_fwd.view(lk.N, lk.K), lv.w_fwd.view(lv.N, lv.K)]).contiguous()
         self.conv_in = (state_dict["conv_in.weight"].to(**f32).contiguous(), state_dict["conv_in.bias"].to(**f32).contiguous())
         self.conv_out = (state_dict["conv_out.weight"].to(**f32).contiguous(), state_dict["conv_out.bias"].to(**f32).contiguous())
 
@@ -383,8 +391,14 @@ class UNet:
         d = C // Hh
         M = B * L
         sq, sk, svv, so = ({} if sv is not None else None for _ in range(4))
-        q = layer_fwd(W, lora, p + "to_q", xn, M, save=sq)
         Mk = B * Lk
+        if lora is None and sv is None and ctx is xn and p in W.qkv:
+            qkv = torch.empty(M, 3 * C, dtype=BF16, device=xn.device)
+            ops.gemm([Seg(xn, W.qkv[p])], M, 3 * C, qkv)
+            qkv = qkv.view(B, L, 3 * C)
+            o, lse = ops.attn_fwd(qkv[:, :, :C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:], Hh, d)
+            return layer_fwd(W, lora, p + "to_out.0", o.view(M, C), M, residual=resid)
+        q = layer_fwd(W, lora, p + "to_q", xn, M, save=sq)
         k = layer_fwd(W, lora, p + "to_k", ctx, Mk, save=sk)
         v = layer_fwd(W, lora, p + "to_v", ctx, Mk, save=svv)
         o, lse = ops.attn_fwd(q.view(B, L, C), k.view(B, Lk, C), v.view(B, Lk, C), Hh, d)

@@ -426,9 +426,9 @@ def case_gemm_big(dev, which):
         else:                            # conv3x3 flavours, with the LoRA branch as a plain or a conv second segment
             stride, src_mode, lora = {"conv": (1, capi.SRC_DIRECT, "plain"), "conv_s2": (2, capi.SRC_DIRECT, None),
                                       "conv_up": (1, capi.SRC_UPSAMPLE2, "plain"), "conv_zi": (1, capi.SRC_ZEROINS2, None),
-                                      "conv_conv": (1, capi.SRC_DIRECT, "conv")}[which]
-            Hs = {"conv": 16, "conv_s2": 32, "conv_up": 8, "conv_zi": 8, "conv_conv": 16}[which]
-            B, Ci, Co = 2, 128 if which == "conv" else 64, 320
+                                      "conv_conv": (1, capi.SRC_DIRECT, "conv"), "conv_splitk": (1, capi.SRC_DIRECT, "plain")}[which]
+            Hs = {"conv": 16, "conv_s2": 32, "conv_up": 8, "conv_zi": 8, "conv_conv": 16, "conv_splitk": 16}[which]
+            B, Ci, Co = (1, 256, 320) if which == "conv_splitk" else (2, 128 if which == "conv" else 64, 320)
             x = rnd(B, Hs, Hs, Ci, seed=7)
             w = rnd(Co, Ci, 3, 3, seed=8, scale=0.05)
             xn = x.float().permute(0, 3, 1, 2)
@@ -459,7 +459,7 @@ def case_gemm_big(dev, which):
             ref = ref + temb.float().repeat_interleave(Ho * Ho, 0)
         plan = dll.pcm_debug_last_gemm_plan()
         assert plan >= 4000, ("big tile not taken", which, plan)
-        if which == "splitk":
+        if which in ("splitk", "conv_splitk"):
             assert plan % 1000 > 1, plan
     finally:
         dll.pcm_debug_gemm_big_mode(1)
@@ -468,7 +468,7 @@ def case_gemm_big(dev, which):
     return float((err - tol).max()), float(err.max())
 
 
-GEMM_BIG_CASES = ["plain_lora", "ragged", "two_tiles_k", "splitk", "conv", "conv_s2", "conv_up", "conv_zi", "conv_conv"]
+GEMM_BIG_CASES = ["plain_lora", "ragged", "two_tiles_k", "splitk", "conv", "conv_s2", "conv_up", "conv_zi", "conv_conv", "conv_splitk"]
 
 
 def case_gemm_n64(dev, M, K):
