@@ -65,14 +65,29 @@ __device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {
 }
 __device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack_bf2(f, 0.f) & 0xffffu); }
 #endif
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + PCM_EXPF(-x)); }
+// Activations are evaluated per element inside HBM-bound kernels (GroupNorm+SiLU touches every activation of the UNet), so their
+// VALU cost matters: v_rcp_f32 (1 ulp) instead of the IEEE division sequence (~10 instructions), and erf by Abramowitz-Stegun
+// 7.1.26 (|error| < 1.5e-7, one exp + one rcp + 5 fma) instead of the branchy libm erff.  Results are rounded to bf16.
+#ifdef PCM_HOST_EMU
+#define PCM_RCPF(x) (1.0f / (x))
+#else
+#define PCM_RCPF(x) __builtin_amdgcn_rcpf(x)
+#endif
+__device__ __forceinline__ float silu_f(float x) { return x * PCM_RCPF(1.0f + PCM_EXPF(-x)); }
 __device__ __forceinline__ float silu_grad_f(float x) {
-  float s = 1.0f / (1.0f + PCM_EXPF(-x));
+  float s = PCM_RCPF(1.0f + PCM_EXPF(-x));
   return s * (1.0f + x * (1.0f - s));
 }
-__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float pcm_erf_f(float z) {
+  const float az = fabsf(z);
+  const float t = PCM_RCPF(1.0f + 0.3275911f * az);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float e = 1.0f - poly * PCM_EXPF(-az * az);
+  return z < 0.f ? -e : e;
+}
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + pcm_erf_f(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float gelu_erf_grad_f(float x) {
-  return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * PCM_EXPF(-0.5f * x * x);
+  return 0.5f * (1.0f + pcm_erf_f(x * 0.70710678118654752f)) + x * 0.3989422804014327f * PCM_EXPF(-0.5f * x * x);
 }
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
