@@ -416,6 +416,20 @@ def case_gemm_big(dev, which):
             out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
             ops.gemm([ops.Seg(x, w)], M, N, out)
             ref = x.float() @ w.float().T
+        elif which == "persist":        # more work items than resident blocks (8 in the emulator, 256 on the GPU): multi-item blocks
+            M, N, K = (2304, 640, 128) if dev == "cpu" else (70000, 640, 320)
+            x, w, t, bl = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.1), rnd(M, 64, seed=3), rnd(N, 64, seed=4, scale=0.1)
+            bias = torch.randn(N, generator=torch.Generator().manual_seed(5)).to(dev)
+            res = rnd(M, N, seed=6)
+            out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+            ops.gemm([ops.Seg(x, w), ops.Seg(t, bl)], M, N, out, bias=bias, residual=res)
+            ref = x.float() @ w.float().T + t.float() @ bl.float().T + bias + res.float()
+        elif which == "persist_splitk":
+            M, N, K = (1280, 320, 2048) if dev == "cpu" else (40000, 320, 2048)
+            x, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05)
+            out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+            ops.gemm([ops.Seg(x, w)], M, N, out, act=capi.ACT_SILU)
+            ref = F.silu(x.float() @ w.float().T)
         elif which == "splitk":
             M, N, K = 256, 320, 2048
             x, w, t, bl = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05), rnd(M, 64, seed=3), rnd(N, 64, seed=4, scale=0.1)
@@ -426,9 +440,12 @@ def case_gemm_big(dev, which):
         else:                            # conv3x3 flavours, with the LoRA branch as a plain or a conv second segment
             stride, src_mode, lora = {"conv": (1, capi.SRC_DIRECT, "plain"), "conv_s2": (2, capi.SRC_DIRECT, None),
                                       "conv_up": (1, capi.SRC_UPSAMPLE2, "plain"), "conv_zi": (1, capi.SRC_ZEROINS2, None),
-                                      "conv_conv": (1, capi.SRC_DIRECT, "conv"), "conv_splitk": (1, capi.SRC_DIRECT, "plain")}[which]
-            Hs = {"conv": 16, "conv_s2": 32, "conv_up": 8, "conv_zi": 8, "conv_conv": 16, "conv_splitk": 16}[which]
+                                      "conv_conv": (1, capi.SRC_DIRECT, "conv"), "conv_splitk": (1, capi.SRC_DIRECT, "plain"),
+                                      "conv_persist": (1, capi.SRC_DIRECT, "plain")}[which]
+            Hs = {"conv": 16, "conv_s2": 32, "conv_up": 8, "conv_zi": 8, "conv_conv": 16, "conv_splitk": 16, "conv_persist": 16}[which]
             B, Ci, Co = (1, 256, 320) if which == "conv_splitk" else (2, 128 if which == "conv" else 64, 320)
+            if which == "conv_persist":
+                B, Ci, Co = (9, 64, 640) if dev == "cpu" else (300, 64, 640)
             x = rnd(B, Hs, Hs, Ci, seed=7)
             w = rnd(Co, Ci, 3, 3, seed=8, scale=0.05)
             xn = x.float().permute(0, 3, 1, 2)
@@ -459,7 +476,7 @@ def case_gemm_big(dev, which):
             ref = ref + temb.float().repeat_interleave(Ho * Ho, 0)
         plan = dll.pcm_debug_last_gemm_plan()
         assert plan >= 4000, ("big tile not taken", which, plan)
-        if which in ("splitk", "conv_splitk"):
+        if which in ("splitk", "conv_splitk", "persist_splitk") and not (which == "persist_splitk" and dev != "cpu"):
             assert plan % 1000 > 1, plan
     finally:
         dll.pcm_debug_gemm_big_mode(1)
@@ -468,7 +485,7 @@ def case_gemm_big(dev, which):
     return float((err - tol).max()), float(err.max())
 
 
-GEMM_BIG_CASES = ["plain_lora", "ragged", "two_tiles_k", "splitk", "conv", "conv_s2", "conv_up", "conv_zi", "conv_conv", "conv_splitk"]
+GEMM_BIG_CASES = ["plain_lora", "ragged", "two_tiles_k", "splitk", "conv", "conv_s2", "conv_up", "conv_zi", "conv_conv", "conv_splitk", "persist", "persist_splitk", "conv_persist"]
 
 
 def case_gemm_n64(dev, M, K):
