@@ -151,6 +151,17 @@ int pcm_attn_bwd(const void* q, const void* k, const void* v, const void* o, con
                  int B, int H, int Lq, int Lk, int d, int ldq, int ldk, int ldo, float scale,
                  void* stream);
 
+/* Workspace variants.  For long sequences (Lq, Lk >= 1024, head_dim <= 80) every workgroup re-transposes each 64-row tile of the
+ * streamed operand (V in the forward; K, Q and dO in the backward); with a caller-owned workspace of pcm_attn_workspace_bytes() the
+ * transposed tile images are written ONCE (tile-major, tail rows zeroed) and the kernels stage them with plain 16-byte copies.
+ * workspace == NULL (or a sequence below the threshold: pcm_attn_workspace_bytes returns 0) is exactly pcm_attn_fwd / pcm_attn_bwd. */
+size_t pcm_attn_workspace_bytes(int B, int H, int Lq, int Lk, int d, int backward);
+int pcm_attn_fwd_ws(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int Lq, int Lk, int d, int ldq,
+                    int ldk, int ldo, float scale, void* workspace, size_t workspace_bytes, void* stream);
+int pcm_attn_bwd_ws(const void* q, const void* k, const void* v, const void* o, const void* dO, const float* lse, float* delta, void* dq,
+                    void* dk, void* dv, int B, int H, int Lq, int Lk, int d, int ldq, int ldk, int ldo, float scale, void* workspace,
+                    size_t workspace_bytes, void* stream);
+
 /* ---- small data-movement ops of the UNet wiring (discriminator_sd15.py:312-342) ---------- */
 int pcm_upsample2x_nhwc(const void* x, void* y, int B, int H, int W, int C, void* stream);
 int pcm_pool2x_sum_nhwc(const void* dy, void* dx, int B, int H, int W, int C, void* stream); /* bwd of upsample: dx[H][W] from dy[2H][2W] */

@@ -158,6 +158,66 @@ struct TransStage {
 };
 template <int D> struct AttnPrefetch { static constexpr bool value = D <= 80; };
 
+// A workgroup re-stages every 64-row tile of the streamed operand, so the 4x4 register transposes of TransStage are repeated by
+// all L/128 workgroups of a (batch, head).  With a PACKED operand (pcm_attn_pack_t: the [d][64-slot] tile images written once to
+// HBM, tile-major, tail rows zeroed) the stage is a straight 16-B copy into the swizzled LDS image.
+template <int D>
+struct PackedTStage {
+  typedef unsigned pk_u32x4 __attribute__((ext_vector_type(4)));
+  static constexpr int NCH = D * 8;                 // 16-B chunks of one tile image (D rows x 128 B)
+  static constexpr int N = (NCH + 255) / 256;
+  pk_u32x4 r[N];
+  __device__ __forceinline__ void load(const bf16_t* packed_bh, int row0, int tid) {
+    const pk_u32x4* t = (const pk_u32x4*)(packed_bh + (size_t)(row0 >> 6) * D * 64);
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      int u = tid + 256 * i;
+      u = u < NCH ? u : NCH - 1;
+      r[i] = t[u];
+    }
+  }
+  __device__ __forceinline__ void store(char* dst, int tid) const {
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      const int u = tid + 256 * i;
+      if (u < NCH) *(pk_u32x4*)(dst + tr_off(u >> 3, u & 7)) = r[i];
+    }
+  }
+};
+// one interface for both: PK selects the packed copy, otherwise the transposing register stage (separate types: a struct holding
+// both stages is not promoted to registers by hipcc and the prefetched tile ends up in scratch)
+template <int D>
+struct TransStageA : TransStage<D> {
+  __device__ __forceinline__ void load(const bf16_t* src, int ld, const bf16_t*, int row0, int nrows_valid, int tid) { TransStage<D>::load(src, ld, row0, nrows_valid, tid); }
+};
+template <int D>
+struct PackedTStageA : PackedTStage<D> {
+  __device__ __forceinline__ void load(const bf16_t*, int, const bf16_t* packed_bh, int row0, int, int tid) { PackedTStage<D>::load(packed_bh, row0, tid); }
+  __device__ __forceinline__ void store(char* dst, int, int tid) const { PackedTStage<D>::store(dst, tid); }
+};
+template <int D, bool PK> struct TStageSel { using type = TransStageA<D>; };
+template <int D> struct TStageSel<D, true> { using type = PackedTStageA<D>; };
+template <int D, bool PK> using TStage = typename TStageSel<D, PK>::type;
+
+// x [B][L][ld] (head h at columns h*D..) -> packed transposed tiles xt[(b*H+h)][tile][D][64 slots]; slot 8*chunk+e of a tile is row
+// 16*(chunk>>1) + 8*(e>>2) + 4*(chunk&1) + (e&3) (the contraction-slot order of the PV / dS MFMAs); rows >= L are zero.
+__global__ __launch_bounds__(256) void attn_pack_t_kernel(const bf16_t* x, bf16_t* xt, int H, int L, int D, int ld) {
+  const int tile = blockIdx.x, h = blockIdx.y, b = blockIdx.z, nt = gridDim.x;
+  const bf16_t* xb = x + (size_t)b * L * ld + h * D;
+  uint4* out = (uint4*)(xt + ((size_t)(b * H + h) * nt + tile) * D * 64);
+  for (int u = threadIdx.x; u < D * 8; u += blockDim.x) {
+    const int drow = u % D, chunk = u / D;     // lanes along d: the 2-byte gathers of a wave touch contiguous runs
+    unsigned w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      const int row = 64 * tile + 16 * (chunk >> 1) + 8 * (e >> 2) + 4 * (chunk & 1) + (e & 3);
+      const unsigned v = row < L ? (unsigned)xb[(size_t)row * ld + drow] : 0u;
+      w[e >> 1] |= v << (16 * (e & 1));
+    }
+    out[drow * 8 + chunk] = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+}
+
 // fragment straight from global: row-major [row][16s + 8hi ..]; zero outside [0, D) / invalid rows
 template <int D>
 __device__ __forceinline__ bf16x8 gfrag(const bf16_t* base, int ld, int row, int nrows_valid, int s, int hi) {
@@ -174,9 +234,9 @@ __device__ __forceinline__ bf16x8 pack_frag(const f32x16& p, int half) {
 }
 
 // ============================================================================ forward
-template <int D>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t* o, float* lse,
-                                                       int H, int Lq, int Lk, int ldq, int ldk, int ldo, float scale) {
+template <int D, bool PK>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* q, const bf16_t* k, const bf16_t* v, const bf16_t* vt, bf16_t* o,
+                                                       float* lse, int H, int Lq, int Lk, int ldq, int ldk, int ldo, float scale) {
   using C = AttnCfg<D>;
   __shared__ __attribute__((aligned(16))) char Ks[64 * C::RKU * 16];
   __shared__ __attribute__((aligned(16))) char Vt[C::DV * 32 * 128];
@@ -201,8 +261,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* q, const bf
   constexpr bool ONES = C::DV * 32 > D;
   if (ONES && tid < 8) *(uint4*)(Vt + tr_off(D, tid)) = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
   RowStage<D, 64> kst;
-  TransStage<D> vst;
-  if (AttnPrefetch<D>::value) { kst.load(kb, ldk, 0, Lk, tid); vst.load(vb, ldk, 0, Lk, tid); }
+  TStage<D, PK> vst;
+  const bf16_t* vtb = PK ? vt + (size_t)(b * H + h) * ((Lk + 63) >> 6) * D * 64 : nullptr;
+  if (AttnPrefetch<D>::value) { kst.load(kb, ldk, 0, Lk, tid); vst.load(vb, ldk, vtb, 0, Lk, tid); }
   for (int kv0 = 0; kv0 < Lk; kv0 += 64) {
     __syncthreads();
     if (AttnPrefetch<D>::value) {
@@ -212,7 +273,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* q, const bf
       load_transposed64<D>(Vt, vb, ldk, kv0, Lk, tid);
     }
     __syncthreads();
-    if (AttnPrefetch<D>::value && kv0 + 64 < Lk) { kst.load(kb, ldk, kv0 + 64, Lk, tid); vst.load(vb, ldk, kv0 + 64, Lk, tid); }
+    if (AttnPrefetch<D>::value && kv0 + 64 < Lk) { kst.load(kb, ldk, kv0 + 64, Lk, tid); vst.load(vb, ldk, vtb, kv0 + 64, Lk, tid); }
     f32x16 s_[2];
 #pragma unroll
     for (int t = 0; t < 2; t++) {
@@ -321,8 +382,8 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* o, const 
 }
 
 // ============================================================================ backward: dQ
-template <int D>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* q, const bf16_t* k, const bf16_t* v, const bf16_t* dO,
+template <int D, bool PK>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* q, const bf16_t* k, const bf16_t* v, const bf16_t* dO, const bf16_t* kt,
                                                           const float* lse, const float* delta, bf16_t* dq, int H, int Lq,
                                                           int Lk, int ldq, int ldk, int ldo, float scale) {
   using C = AttnCfg<D>;
@@ -353,8 +414,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* q, const
   zero_pad_chunks<D, 64>(Ks, tid);
   zero_pad_chunks<D, 64>(Vs, tid);
   RowStage<D, 64> kst, vst;
-  TransStage<D> ktst;
-  if (AttnPrefetch<D>::value) { kst.load(kb, ldk, 0, Lk, tid); vst.load(vb, ldk, 0, Lk, tid); ktst.load(kb, ldk, 0, Lk, tid); }
+  TStage<D, PK> ktst;
+  const bf16_t* ktb = PK ? kt + (size_t)(b * H + h) * ((Lk + 63) >> 6) * D * 64 : nullptr;
+  if (AttnPrefetch<D>::value) { kst.load(kb, ldk, 0, Lk, tid); vst.load(vb, ldk, 0, Lk, tid); ktst.load(kb, ldk, ktb, 0, Lk, tid); }
   for (int kv0 = 0; kv0 < Lk; kv0 += 64) {
     __syncthreads();
     if (AttnPrefetch<D>::value) {
@@ -366,7 +428,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* q, const
     }
     __syncthreads();
     if (AttnPrefetch<D>::value && kv0 + 64 < Lk) {
-      kst.load(kb, ldk, kv0 + 64, Lk, tid); vst.load(vb, ldk, kv0 + 64, Lk, tid); ktst.load(kb, ldk, kv0 + 64, Lk, tid);
+      kst.load(kb, ldk, kv0 + 64, Lk, tid); vst.load(vb, ldk, kv0 + 64, Lk, tid); ktst.load(kb, ldk, ktb, kv0 + 64, Lk, tid);
     }
     f32x16 s_[2], dp[2];
 #pragma unroll
@@ -423,9 +485,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* q, const
 }
 
 // ============================================================================ backward: dK, dV
-template <int D>
-__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16_t* q, const bf16_t* k, const bf16_t* v, const bf16_t* dO,
-                                                            const float* lse, const float* delta, bf16_t* dk, bf16_t* dv, int H,
+template <int D, bool PK>
+__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16_t* q, const bf16_t* k, const bf16_t* v, const bf16_t* dO, const bf16_t* qt,
+                                                            const bf16_t* ot, const float* lse, const float* delta, bf16_t* dk, bf16_t* dv, int H,
                                                             int Lq, int Lk, int ldq, int ldk, int ldo, float scale) {
   using C = AttnCfg<D>;
   __shared__ __attribute__((aligned(16))) char Qs[64 * C::RKU * 16];
@@ -456,11 +518,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16_t* q, con
   zero_pad_chunks<D, 64>(Qs, tid);
   zero_pad_chunks<D, 64>(Os, tid);
   RowStage<D, 64> qst, ost;
-  TransStage<D> qtst, otst;
+  TStage<D, PK> qtst, otst;
+  const bf16_t* qtb = PK ? qt + (size_t)(b * H + h) * ((Lq + 63) >> 6) * D * 64 : nullptr;
+  const bf16_t* otb = PK ? ot + (size_t)(b * H + h) * ((Lq + 63) >> 6) * D * 64 : nullptr;
   float l2r = 0.f, dlr = 0.f;
   auto stage_load = [&](int q0_) {
     qst.load(qb, ldq, q0_, Lq, tid); ost.load(dob, ldo, q0_, Lq, tid);
-    qtst.load(qb, ldq, q0_, Lq, tid); otst.load(dob, ldo, q0_, Lq, tid);
+    qtst.load(qb, ldq, qtb, q0_, Lq, tid); otst.load(dob, ldo, otb, q0_, Lq, tid);
     {
       int qr = q0_ + (tid & 63);
       if (qr >= Lq) qr = Lq - 1;
@@ -566,31 +630,87 @@ static int attn_check(const char* what, const void* q, const void* k, const void
     default: { CALL(160); } break;      \
   }
 
-extern "C" int pcm_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int Lq, int Lk,
-                            int d, int ldq, int ldk, int ldo, float scale, void* stream) {
+// Workspace for the packed transposed operands (pcm_attn_pack_t images): the forward needs V^T, the backward K^T, Q^T and dO^T.
+// 0 when the packed path is not used (short sequences: the one-off packing pass does not pay; head dims without register staging).
+static int g_attn_pack_min = 1024;
+extern "C" void pcm_debug_attn_pack_min_len(int n) { g_attn_pack_min = n; }   // tests only: exercise the packed path on short sequences
+static bool attn_use_packed(int Lq, int Lk, int d) { return d <= 80 && Lq >= g_attn_pack_min && Lk >= g_attn_pack_min; }
+static size_t attn_packed_bytes(int B, int H, int L, int d) { return (size_t)B * H * ((L + 63) / 64) * d * 128; }
+extern "C" size_t pcm_attn_workspace_bytes(int B, int H, int Lq, int Lk, int d, int backward) {
+  if (!attn_use_packed(Lq, Lk, d)) return 0;
+  return backward ? attn_packed_bytes(B, H, Lk, d) + 2 * attn_packed_bytes(B, H, Lq, d) : attn_packed_bytes(B, H, Lk, d);
+}
+static void attn_pack_launch(const void* x, void* xt, int B, int H, int L, int d, int ld, void* stream) {
+  PCM_LAUNCH(attn_pack_t_kernel, dim3((L + 63) / 64, H, B), dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)xt, H, L, d, ld);
+}
+
+extern "C" int pcm_attn_fwd_ws(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int Lq, int Lk,
+                               int d, int ldq, int ldk, int ldo, float scale, void* workspace, size_t workspace_bytes, void* stream) {
   if (int rc = attn_check("pcm_attn_fwd", q, k, v, B, H, Lq, Lk, d, ldq, ldk, ldo)) return rc;
   PCM_CHECK(o && PCM_ALIGNED16(o), PCM_EALIGN, "pcm_attn_fwd: o");
   dim3 grid((Lq + 127) / 128, H, B), block(256);
-#define FWD_CALL(DD) PCM_LAUNCH((attn_fwd_kernel<DD>), grid, block, 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse, H, Lq, Lk, ldq, ldk, ldo, scale)
+  const bool pk = workspace && attn_use_packed(Lq, Lk, d);
+  if (pk) {
+    PCM_CHECK(PCM_ALIGNED16(workspace) && workspace_bytes >= pcm_attn_workspace_bytes(B, H, Lq, Lk, d, 0), PCM_EINVAL, "pcm_attn_fwd_ws: workspace");
+    attn_pack_launch(v, workspace, B, H, Lk, d, ldk, stream);
+  }
+#define FWD_CALL(DD)                                                                                                               \
+  if (pk && AttnPrefetch<DD>::value)                                                                                               \
+    PCM_LAUNCH((attn_fwd_kernel<DD, true>), grid, block, 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,          \
+               (const bf16_t*)workspace, (bf16_t*)o, lse, H, Lq, Lk, ldq, ldk, ldo, scale);                                         \
+  else                                                                                                                             \
+    PCM_LAUNCH((attn_fwd_kernel<DD, false>), grid, block, 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,         \
+               (const bf16_t*)nullptr, (bf16_t*)o, lse, H, Lq, Lk, ldq, ldk, ldo, scale)
   ATTN_DISPATCH(d, FWD_CALL)
   return pcm_post_launch("pcm_attn_fwd");
 }
+extern "C" int pcm_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int Lq, int Lk,
+                            int d, int ldq, int ldk, int ldo, float scale, void* stream) {
+  return pcm_attn_fwd_ws(q, k, v, o, lse, B, H, Lq, Lk, d, ldq, ldk, ldo, scale, nullptr, 0, stream);
+}
 
-extern "C" int pcm_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dO, const float* lse,
-                            float* delta, void* dq, void* dk, void* dv, int B, int H, int Lq, int Lk, int d, int ldq, int ldk,
-                            int ldo, float scale, void* stream) {
+extern "C" int pcm_attn_bwd_ws(const void* q, const void* k, const void* v, const void* o, const void* dO, const float* lse,
+                               float* delta, void* dq, void* dk, void* dv, int B, int H, int Lq, int Lk, int d, int ldq, int ldk,
+                               int ldo, float scale, void* workspace, size_t workspace_bytes, void* stream) {
   if (int rc = attn_check("pcm_attn_bwd", q, k, v, B, H, Lq, Lk, d, ldq, ldk, ldo)) return rc;
   PCM_CHECK(o && dO && lse && delta && PCM_ALIGNED16(o) && PCM_ALIGNED16(dO), PCM_EALIGN, "pcm_attn_bwd: o/dO/lse/delta");
   PCM_LAUNCH(attn_delta_kernel, dim3((Lq * H + 255) / 256, B), dim3(256), 0, stream, (const bf16_t*)o, (const bf16_t*)dO, delta, H, Lq, d, ldo);
+  const bool pk = workspace && attn_use_packed(Lq, Lk, d);
+  const bf16_t *kt = nullptr, *qt = nullptr, *ot = nullptr;
+  if (pk) {
+    PCM_CHECK(PCM_ALIGNED16(workspace) && workspace_bytes >= pcm_attn_workspace_bytes(B, H, Lq, Lk, d, 1), PCM_EINVAL, "pcm_attn_bwd_ws: workspace");
+    char* w = (char*)workspace;
+    kt = (const bf16_t*)w; qt = (const bf16_t*)(w + attn_packed_bytes(B, H, Lk, d)); ot = (const bf16_t*)(w + attn_packed_bytes(B, H, Lk, d) + attn_packed_bytes(B, H, Lq, d));
+    if (dq) attn_pack_launch(k, (void*)kt, B, H, Lk, d, ldk, stream);
+    if (dk && dv) { attn_pack_launch(q, (void*)qt, B, H, Lq, d, ldq, stream); attn_pack_launch(dO, (void*)ot, B, H, Lq, d, ldo, stream); }
+  }
   if (dq) {
     dim3 grid((Lq + 127) / 128, H, B), block(256);
-#define DQ_CALL(DD) PCM_LAUNCH((attn_bwd_dq_kernel<DD>), grid, block, 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)dO, lse, delta, (bf16_t*)dq, H, Lq, Lk, ldq, ldk, ldo, scale)
+#define DQ_CALL(DD)                                                                                                                  \
+  if (pk && AttnPrefetch<DD>::value)                                                                                                 \
+    PCM_LAUNCH((attn_bwd_dq_kernel<DD, true>), grid, block, 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,         \
+               (const bf16_t*)dO, kt, lse, delta, (bf16_t*)dq, H, Lq, Lk, ldq, ldk, ldo, scale);                                      \
+  else                                                                                                                               \
+    PCM_LAUNCH((attn_bwd_dq_kernel<DD, false>), grid, block, 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,        \
+               (const bf16_t*)dO, (const bf16_t*)nullptr, lse, delta, (bf16_t*)dq, H, Lq, Lk, ldq, ldk, ldo, scale)
     ATTN_DISPATCH(d, DQ_CALL)
   }
   if (dk && dv) {
     dim3 grid((Lk + 127) / 128, H, B), block(256);
-#define DKV_CALL(DD) PCM_LAUNCH((attn_bwd_dkdv_kernel<DD>), grid, block, 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)dO, lse, delta, (bf16_t*)dk, (bf16_t*)dv, H, Lq, Lk, ldq, ldk, ldo, scale)
+#define DKV_CALL(DD)                                                                                                                 \
+  if (pk && AttnPrefetch<DD>::value)                                                                                                 \
+    PCM_LAUNCH((attn_bwd_dkdv_kernel<DD, true>), grid, block, 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,       \
+               (const bf16_t*)dO, qt, ot, lse, delta, (bf16_t*)dk, (bf16_t*)dv, H, Lq, Lk, ldq, ldk, ldo, scale);                     \
+  else                                                                                                                               \
+    PCM_LAUNCH((attn_bwd_dkdv_kernel<DD, false>), grid, block, 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,      \
+               (const bf16_t*)dO, (const bf16_t*)nullptr, (const bf16_t*)nullptr, lse, delta, (bf16_t*)dk, (bf16_t*)dv, H, Lq, Lk,    \
+               ldq, ldk, ldo, scale)
     ATTN_DISPATCH(d, DKV_CALL)
   }
   return pcm_post_launch("pcm_attn_bwd");
+}
+extern "C" int pcm_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dO, const float* lse,
+                            float* delta, void* dq, void* dk, void* dv, int B, int H, int Lq, int Lk, int d, int ldq, int ldk,
+                            int ldo, float scale, void* stream) {
+  return pcm_attn_bwd_ws(q, k, v, o, dO, lse, delta, dq, dk, dv, B, H, Lq, Lk, d, ldq, ldk, ldo, scale, nullptr, 0, stream);
 }

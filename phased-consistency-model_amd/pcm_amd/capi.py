@@ -66,6 +66,8 @@ _PROTOS = {
     "pcm_geglu_bwd": [vp, vp, vp, i32, i32, vp],
     "pcm_attn_fwd": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp],
     "pcm_attn_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp],
+    "pcm_attn_fwd_ws": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp, C.c_size_t, vp],
+    "pcm_attn_bwd_ws": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp, C.c_size_t, vp],
     "pcm_upsample2x_nhwc": [vp, vp, i32, i32, i32, i32, vp],
     "pcm_pool2x_sum_nhwc": [vp, vp, i32, i32, i32, i32, vp],
     "pcm_concat_channels": [vp, i32, vp, i32, vp, i64, vp],
@@ -117,6 +119,8 @@ class Lib:
         self.dll.pcm_abi_version.restype = C.c_int
         self.dll.pcm_gemm_workspace_bytes.restype = C.c_size_t
         self.dll.pcm_gemm_workspace_bytes.argtypes = [C.POINTER(GemmSeg), C.c_int, C.POINTER(GemmEpi)]
+        self.dll.pcm_attn_workspace_bytes.restype = C.c_size_t
+        self.dll.pcm_attn_workspace_bytes.argtypes = [C.c_int] * 6
         self.fn = {}
         for name, argt in _PROTOS.items():
             f = getattr(self.dll, name, None)

@@ -325,8 +325,10 @@ def attn_fwd(q, k, v, H, d, scale=None):
     o = torch.empty(B, Lq, H * d, dtype=BF16, device=q.device)
     lse = torch.empty(B, H, Lq, dtype=torch.float32, device=q.device)
     assert q.stride(2) == 1 and k.stride(2) == 1 and v.stride(2) == 1 and k.stride(1) == v.stride(1)
-    capi.lib().call("pcm_attn_fwd", ptr(q), ptr(k), ptr(v), ptr(o), ptr(lse), B, H, Lq, Lk, d, q.stride(1), k.stride(1),
-                    o.stride(1), scale, _stream())
+    wsb = capi.lib().dll.pcm_attn_workspace_bytes(B, H, Lq, Lk, d, 0)     # packed V^T tile images for long sequences (0: not used)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=q.device) if wsb else None
+    capi.lib().call("pcm_attn_fwd_ws", ptr(q), ptr(k), ptr(v), ptr(o), ptr(lse), B, H, Lq, Lk, d, q.stride(1), k.stride(1),
+                    o.stride(1), scale, ptr(ws), wsb, _stream())
     return o, lse
 
 
@@ -338,8 +340,10 @@ def attn_bwd(q, k, v, o, dO, lse, H, d, scale=None, need_dkv=True):
     dq = torch.empty_like(q)
     dk = torch.empty_like(k) if need_dkv else None
     dv = torch.empty_like(v) if need_dkv else None
-    capi.lib().call("pcm_attn_bwd", ptr(q), ptr(k), ptr(v), ptr(o), ptr(dO), ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv),
-                    B, H, Lq, Lk, d, q.stride(1), k.stride(1), o.stride(1), scale, _stream())
+    wsb = capi.lib().dll.pcm_attn_workspace_bytes(B, H, Lq, Lk, d, 1)     # packed K^T, Q^T, dO^T tile images
+    ws = torch.empty(wsb, dtype=torch.uint8, device=q.device) if wsb else None
+    capi.lib().call("pcm_attn_bwd_ws", ptr(q), ptr(k), ptr(v), ptr(o), ptr(dO), ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv),
+                    B, H, Lq, Lk, d, q.stride(1), k.stride(1), o.stride(1), scale, ptr(ws), wsb, _stream())
     return dq, dk, dv
 
 

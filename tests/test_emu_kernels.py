@@ -79,3 +79,16 @@ def test_discriminator_heads():
 @pytest.mark.slow
 def test_teacher_input_grad():
     K.case_teacher_input_grad("cpu")
+
+
+@pytest.mark.parametrize("B,H,Lq,Lk,d", [(1, 2, 130, 130, 40), (1, 1, 70, 200, 80)])
+def test_attention_packed_transposed_operands(B, H, Lq, Lk, d):
+    """pcm_attn_*_ws with the one-off packed V^T / K^T / Q^T / dO^T tile images (ragged tails zero-filled by the packer)."""
+    from pcm_amd import capi
+    dll = capi.lib().dll
+    dll.pcm_debug_attn_pack_min_len(64)
+    try:
+        assert dll.pcm_attn_workspace_bytes(B, H, Lq, Lk, d, 1) > 0
+        K.case_attention("cpu", B, H, Lq, Lk, d, spike=True)
+    finally:
+        dll.pcm_debug_attn_pack_min_len(1024)
