@@ -212,6 +212,12 @@ int pcm_cfg_ddim_step(const float* eps_c, const float* eps_u, const float* sampl
                       const int64_t* index, const float* w, const float* alphas_cumprod,
                       const double* acp_prev, double* x_prev, float* x_prev_f32, int B,
                       int per_sample, void* stream);
+
+/* Inference sampler step (log_validation, train_pcm_lora_sd15.py:120-145: StableDiffusionPipeline denoising loop with
+ * DDIMScheduler(timestep_spacing="trailing", clip_sample=False, set_alpha_to_one=False), eta = 0): classifier-free guidance
+ * combine (eps_u may be NULL: guidance_scale <= 1) + x_{t-1} from x_t.  alpha_* are alphas_cumprod values; fp32 throughout. */
+int pcm_sampler_ddim_step(const float* eps_c, const float* eps_u, const float* x, float alpha_t, float alpha_prev, float guidance,
+                          float* out, long n, void* stream);
 /* loss (l2 | huber, :1283-1293) forward + gradient wrt the student's eps prediction:
  * loss[0] = mean(...) (accumulated in fp64, zeroed by the call) ; d_eps = dloss/dmodel_pred * coef[b] * grad_scale */
 int pcm_consistency_loss(const float* model_pred, const float* target, const float* coef, int huber,

@@ -168,3 +168,37 @@ def discriminator_head(sd, x, prefix=""):
     h = blk("conv1", x)
     h = blk("conv2", h) + h
     return F.conv2d(h, sd[prefix + "conv_out.weight"], sd[prefix + "conv_out.bias"])
+
+
+# ----------------------------------------------------------------------------------------------
+# Inference sampler.  diffusers is not vendored under /root/reference, so this is a restatement of the pinned
+# diffusers 0.26.3 DDIMScheduler (environment.yaml:40) for the configuration log_validation builds
+# (train_pcm_lora_sd15.py:126-135): trailing spacing, clip_sample=False, set_alpha_to_one=False, eta=0, epsilon prediction.
+# PARITY UNPINNED: the reference holds no test vector for it; it is anchored on the shared alphas_cumprod table (pinned) only.
+# ----------------------------------------------------------------------------------------------
+def ddim_trailing_timesteps(num_inference_steps, num_train_timesteps=1000):
+    import numpy as np
+    return (np.round(np.arange(num_train_timesteps, 0, -num_train_timesteps / num_inference_steps)) - 1).astype(np.int64).tolist()
+
+
+def ddim_sampler_step(eps, t, sample, acp, num_inference_steps, num_train_timesteps=1000):
+    prev_t = t - num_train_timesteps // num_inference_steps
+    a_t = acp[t]
+    a_prev = acp[prev_t] if prev_t >= 0 else acp[0]
+    x0 = (sample - (1 - a_t) ** 0.5 * eps) / a_t ** 0.5
+    return a_prev ** 0.5 * x0 + (1 - a_prev) ** 0.5 * eps
+
+
+def ddim_sample(unet_fn, prompt_embeds, uncond_embeds, latents, num_inference_steps, guidance_scale, acp):
+    """StableDiffusionPipeline denoising loop: unet_fn(x, t[B], ctx) -> eps; CFG when guidance_scale > 1."""
+    import torch
+    x = latents.clone()
+    B = x.shape[0]
+    for t in ddim_trailing_timesteps(num_inference_steps):
+        tt = torch.full((B,), t, dtype=torch.int64)
+        eps = unet_fn(x, tt, prompt_embeds)
+        if guidance_scale > 1.0:
+            eps_u = unet_fn(x, tt, uncond_embeds)
+            eps = eps_u + guidance_scale * (eps - eps_u)
+        x = ddim_sampler_step(eps, t, x, acp, num_inference_steps)
+    return x

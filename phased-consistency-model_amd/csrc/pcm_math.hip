@@ -129,6 +129,27 @@ extern "C" int pcm_cfg_ddim_step(const float* eps_c, const float* eps_u, const f
   return pcm_post_launch("pcm_cfg_ddim_step");
 }
 
+// Inference: one DDIM step of the validation sampler (log_validation, train_pcm_lora_sd15.py:120-145: DDIMScheduler with
+// timestep_spacing="trailing", clip_sample=False, set_alpha_to_one=False, eta 0) fused with the pipeline's classifier-free
+// guidance combine  eps = eps_u + g (eps_c - eps_u)  (eps_u == nullptr: no guidance).
+//   x0 = (x - sqrt(1-a_t) eps) / sqrt(a_t);   x_prev = sqrt(a_prev) x0 + sqrt(1-a_prev) eps
+__global__ __launch_bounds__(256) void sampler_ddim_kernel(const float* eps_c, const float* eps_u, const float* x, float a_t, float a_prev,
+                                                           float guidance, float* out, long n) {
+  const float sa = __builtin_sqrtf(a_t), sb = __builtin_sqrtf(1.0f - a_t), pa = __builtin_sqrtf(a_prev), pb = __builtin_sqrtf(1.0f - a_prev);
+  PM_LOOP(i, n) {
+    float e = eps_c[i];
+    if (eps_u) { const float u = eps_u[i]; e = u + guidance * (e - u); }
+    const float x0 = (x[i] - sb * e) / sa;
+    out[i] = pa * x0 + pb * e;
+  }
+}
+extern "C" int pcm_sampler_ddim_step(const float* eps_c, const float* eps_u, const float* x, float alpha_t, float alpha_prev, float guidance,
+                                     float* out, long n, void* stream) {
+  PCM_CHECK(eps_c && x && out && n > 0 && alpha_t > 0.f && alpha_t <= 1.f && alpha_prev > 0.f && alpha_prev <= 1.f, PCM_EINVAL, "pcm_sampler_ddim_step: null/empty/alpha");
+  PCM_LAUNCH(sampler_ddim_kernel, dim3(pm_blocks(n)), dim3(256), 0, stream, eps_c, eps_u, x, alpha_t, alpha_prev, guidance, out, n);
+  return pcm_post_launch("pcm_sampler_ddim_step");
+}
+
 // train_pcm_lora_sd15.py:1283-1293 + d loss / d eps of the online branch
 __global__ __launch_bounds__(256) void loss_kernel(const float* mp, const float* tg, const float* coef, int huber, float hc,
                                                    double* loss, float* d_eps, float gscale, int B, int ps) {

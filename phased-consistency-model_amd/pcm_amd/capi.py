@@ -81,6 +81,7 @@ _PROTOS = {
     "pcm_timestep_embedding": [vp, vp, i32, i32, vp],
     "pcm_add_noise": [vp, vp, vp, vp, vp, i32, i32, vp],
     "pcm_phase_jump": [vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, i32, i32, vp],
+    "pcm_sampler_ddim_step": [vp, vp, vp, f32, f32, f32, vp, C.c_long, vp],
     "pcm_cfg_ddim_step": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
     "pcm_consistency_loss": [vp, vp, vp, i32, f32, vp, vp, f32, i32, i32, vp],
     "pcm_sumsq_f32": [vp, vp, i64, vp],

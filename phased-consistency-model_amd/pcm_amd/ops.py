@@ -389,3 +389,11 @@ def scale_add_rows(out, x, s1, s2):
     B = out.shape[0]
     capi.lib().call("pcm_scale_add_rows", ptr(out), ptr(x), ptr(s1), ptr(s2), B, out.numel() // B, _stream())
     return out
+
+
+def sampler_ddim_step(eps_c, eps_u, x, alpha_t, alpha_prev, guidance):
+    """One DDIM (eta 0) step of the validation sampler with the CFG combine fused; fp32 tensors of equal shape."""
+    out = torch.empty_like(x)
+    capi.lib().call("pcm_sampler_ddim_step", ptr(eps_c), ptr(eps_u), ptr(x), float(alpha_t), float(alpha_prev), float(guidance), ptr(out),
+                    x.numel(), _stream())
+    return out
