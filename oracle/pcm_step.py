@@ -55,6 +55,8 @@ def distill_step_forward(ucfg, sd, lora, inp, cfg: StepConfig):
     acp, alpha_s, sigma_s, solver = make_solver(cfg)
     latents, noise, index = inp["latents"], inp["noise"], inp["index"]
     pe, upe = inp["prompt_embeds"], inp["uncond_prompt_embeds"]
+    # SDXL added_cond_kwargs (train_pcm_lora_sdxl_adv.py:1126-1131; uncond pass swaps text_embeds, :1409-1421); absent for SD1.5
+    ac, uac = inp.get("added_cond"), inp.get("uncond_added_cond")
     bsz = latents.shape[0]
     topk = cfg.num_train_timesteps // cfg.num_ddim_timesteps                       # :1143-1146
     start_timesteps = solver.ddim_timesteps[index]                                 # :1151
@@ -67,23 +69,23 @@ def distill_step_forward(ucfg, sd, lora, inp, cfg: StepConfig):
                      M.scalings_for_boundary_conditions_target(index, edges)]
     noisy = M.add_noise(acp, latents, noise, start_timesteps)                      # :1178-1180
     w = inp["w"].reshape(bsz, 1, 1, 1).to(latents.dtype)                           # :1183-1185
-    noise_pred = unet_forward(ucfg, sd, noisy, start_timesteps, pe, lora, cfg.lora_alpha)  # :1192
+    noise_pred = unet_forward(ucfg, sd, noisy, start_timesteps, pe, lora, cfg.lora_alpha, added_cond=ac)  # :1192
     pred_x_0 = M.predicted_origin(noise_pred, start_timesteps, noisy, "epsilon", alpha_s, sigma_s)
     model_pred, end_timesteps = solver.ddim_style_multiphase_pred(pred_x_0, noise_pred, index, cfg.multiphase)
     model_pred = c_skip_start * noisy + c_out_start * model_pred                   # :1212
     with torch.no_grad():
-        cond_out = unet_forward(ucfg, sd, noisy, start_timesteps, pe)              # :1219 teacher
+        cond_out = unet_forward(ucfg, sd, noisy, start_timesteps, pe, added_cond=ac)              # :1219 teacher
         cond_x0 = M.predicted_origin(cond_out, start_timesteps, noisy, "epsilon", alpha_s, sigma_s)
         if cfg.not_apply_cfg_solver:                                               # :1233-1235
             uncond_out, uncond_x0 = cond_out, cond_x0
         else:
-            uncond_out = unet_forward(ucfg, sd, noisy, start_timesteps, upe)       # :1238
+            uncond_out = unet_forward(ucfg, sd, noisy, start_timesteps, upe, added_cond=uac if uac is not None else ac)       # :1238
             uncond_x0 = M.predicted_origin(uncond_out, start_timesteps, noisy, "epsilon", alpha_s, sigma_s)
         pred_x0 = cond_x0 + w * (cond_x0 - uncond_x0)                              # :1254
         pred_noise = cond_out + w * (cond_out - uncond_out)                        # :1255-1257
         x_prev = solver.ddim_step(pred_x0, pred_noise, index)                      # :1258
         lora_ng = None if lora is None else OrderedDict((k, (a.detach(), b.detach())) for k, (a, b) in lora.items())
-        target_noise_pred = unet_forward(ucfg, sd, x_prev.float(), timesteps, pe, lora_ng, cfg.lora_alpha)  # :1263
+        target_noise_pred = unet_forward(ucfg, sd, x_prev.float(), timesteps, pe, lora_ng, cfg.lora_alpha, added_cond=ac)  # :1263
         tx0 = M.predicted_origin(target_noise_pred, timesteps, x_prev, "epsilon", alpha_s, sigma_s)
         target, _ = solver.ddim_style_multiphase_pred(tx0, target_noise_pred, index, cfg.multiphase)
         target = c_skip * x_prev + c_out * target                                  # :1280

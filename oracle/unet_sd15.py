@@ -31,7 +31,8 @@ class UNetConfig:
 
     def __init__(self, in_channels=4, out_channels=4, block_out_channels=(320, 640, 1280, 1280),
                  layers_per_block=2, cross_attention_dim=768, heads=8, norm_num_groups=32,
-                 norm_eps=1e-5, temb_mult=4):
+                 norm_eps=1e-5, temb_mult=4, down_attn=None, transformer_depth=None, mid_depth=None,
+                 use_linear_projection=False, addition_time_embed_dim=None, projection_class_embeddings_input_dim=None):
         self.in_channels = in_channels
         self.out_channels = out_channels
         self.block_out_channels = tuple(block_out_channels)
@@ -41,10 +42,29 @@ class UNetConfig:
         self.norm_num_groups = norm_num_groups
         self.norm_eps = norm_eps
         self.time_embed_dim = block_out_channels[0] * temb_mult
+        # SDXL-style topology switches (restated from the pinned diffusers UNet2DConditionModel: the
+        # down_block_types / transformer_layers_per_block / attention_head_dim / addition_embed_type="text_time" config keys)
+        n = len(self.block_out_channels)
+        self.down_attn = tuple(down_attn) if down_attn is not None else tuple(i < n - 1 for i in range(n))
+        self.transformer_depth = tuple(transformer_depth) if transformer_depth is not None else (1,) * n
+        self.mid_depth = mid_depth if mid_depth is not None else self.transformer_depth[-1]
+        self.use_linear_projection = use_linear_projection
+        self.addition_time_embed_dim = addition_time_embed_dim
+        self.projection_class_embeddings_input_dim = projection_class_embeddings_input_dim
+
+    def heads_at(self, level):
+        return self.heads if isinstance(self.heads, int) else self.heads[level]
 
     @staticmethod
     def sd15():
         return UNetConfig()
+
+    @staticmethod
+    def sdxl():
+        """stabilityai/stable-diffusion-xl-base-1.0 unet/config.json (2 567 463 684 parameters)."""
+        return UNetConfig(block_out_channels=(320, 640, 1280), cross_attention_dim=2048, heads=(5, 10, 20),
+                          down_attn=(False, True, True), transformer_depth=(1, 2, 10), use_linear_projection=True,
+                          addition_time_embed_dim=256, projection_class_embeddings_input_dim=2816)
 
     @staticmethod
     def tiny(c=32, ctx=64, heads=2, groups=8):
@@ -64,22 +84,24 @@ def _resnet_spec(p, cin, cout, temb):
     return s
 
 
-def _attn_spec(p, c, ctx):
+def _attn_spec(p, c, ctx, depth=1, linear=False):
+    pw = (c, c) if linear else (c, c, 1, 1)
     s = [(p + "norm.weight", (c,)), (p + "norm.bias", (c,)),
-         (p + "proj_in.weight", (c, c, 1, 1)), (p + "proj_in.bias", (c,))]
-    b = p + "transformer_blocks.0."
-    s += [(b + "norm1.weight", (c,)), (b + "norm1.bias", (c,)),
-          (b + "attn1.to_q.weight", (c, c)), (b + "attn1.to_k.weight", (c, c)),
-          (b + "attn1.to_v.weight", (c, c)),
-          (b + "attn1.to_out.0.weight", (c, c)), (b + "attn1.to_out.0.bias", (c,)),
-          (b + "norm2.weight", (c,)), (b + "norm2.bias", (c,)),
-          (b + "attn2.to_q.weight", (c, c)), (b + "attn2.to_k.weight", (c, ctx)),
-          (b + "attn2.to_v.weight", (c, ctx)),
-          (b + "attn2.to_out.0.weight", (c, c)), (b + "attn2.to_out.0.bias", (c,)),
-          (b + "norm3.weight", (c,)), (b + "norm3.bias", (c,)),
-          (b + "ff.net.0.proj.weight", (8 * c, c)), (b + "ff.net.0.proj.bias", (8 * c,)),
-          (b + "ff.net.2.weight", (c, 4 * c)), (b + "ff.net.2.bias", (c,))]
-    s += [(p + "proj_out.weight", (c, c, 1, 1)), (p + "proj_out.bias", (c,))]
+         (p + "proj_in.weight", pw), (p + "proj_in.bias", (c,))]
+    for k in range(depth):
+        b = p + f"transformer_blocks.{k}."
+        s += [(b + "norm1.weight", (c,)), (b + "norm1.bias", (c,)),
+              (b + "attn1.to_q.weight", (c, c)), (b + "attn1.to_k.weight", (c, c)),
+              (b + "attn1.to_v.weight", (c, c)),
+              (b + "attn1.to_out.0.weight", (c, c)), (b + "attn1.to_out.0.bias", (c,)),
+              (b + "norm2.weight", (c,)), (b + "norm2.bias", (c,)),
+              (b + "attn2.to_q.weight", (c, c)), (b + "attn2.to_k.weight", (c, ctx)),
+              (b + "attn2.to_v.weight", (c, ctx)),
+              (b + "attn2.to_out.0.weight", (c, c)), (b + "attn2.to_out.0.bias", (c,)),
+              (b + "norm3.weight", (c,)), (b + "norm3.bias", (c,)),
+              (b + "ff.net.0.proj.weight", (8 * c, c)), (b + "ff.net.0.proj.bias", (8 * c,)),
+              (b + "ff.net.2.weight", (c, 4 * c)), (b + "ff.net.2.bias", (c,))]
+    s += [(p + "proj_out.weight", pw), (p + "proj_out.bias", (c,))]
     return s
 
 
@@ -112,33 +134,38 @@ def param_spec(cfg):
     s = [("conv_in.weight", (boc[0], cfg.in_channels, 3, 3)), ("conv_in.bias", (boc[0],)),
          ("time_embedding.linear_1.weight", (temb, boc[0])), ("time_embedding.linear_1.bias", (temb,)),
          ("time_embedding.linear_2.weight", (temb, temb)), ("time_embedding.linear_2.bias", (temb,))]
+    if cfg.addition_time_embed_dim:
+        pin = cfg.projection_class_embeddings_input_dim
+        s += [("add_embedding.linear_1.weight", (temb, pin)), ("add_embedding.linear_1.bias", (temb,)),
+              ("add_embedding.linear_2.weight", (temb, temb)), ("add_embedding.linear_2.bias", (temb,))]
+    lin = cfg.use_linear_projection
     cin = boc[0]
     for i in range(n):
         cout = boc[i]
-        has_attn = i < n - 1
+        has_attn = cfg.down_attn[i]
         for j in range(cfg.layers_per_block):
             s += _resnet_spec(f"down_blocks.{i}.resnets.{j}.", cin if j == 0 else cout, cout, temb)
         if has_attn:
             for j in range(cfg.layers_per_block):
-                s += _attn_spec(f"down_blocks.{i}.attentions.{j}.", cout, ctx)
+                s += _attn_spec(f"down_blocks.{i}.attentions.{j}.", cout, ctx, cfg.transformer_depth[i], lin)
         if i < n - 1:
             s += [(f"down_blocks.{i}.downsamplers.0.conv.weight", (cout, cout, 3, 3)),
                   (f"down_blocks.{i}.downsamplers.0.conv.bias", (cout,))]
         cin = cout
     c = boc[-1]
     s += _resnet_spec("mid_block.resnets.0.", c, c, temb)
-    s += _attn_spec("mid_block.attentions.0.", c, ctx)
+    s += _attn_spec("mid_block.attentions.0.", c, ctx, cfg.mid_depth, lin)
     s += _resnet_spec("mid_block.resnets.1.", c, c, temb)
     rin = up_resnet_in_channels(cfg)
     rev = list(reversed(boc))
     for i in range(n):
         cout = rev[i]
-        has_attn = i > 0
+        has_attn = cfg.down_attn[n - 1 - i]
         for j in range(cfg.layers_per_block + 1):
             s += _resnet_spec(f"up_blocks.{i}.resnets.{j}.", rin[i][j], cout, temb)
         if has_attn:
             for j in range(cfg.layers_per_block + 1):
-                s += _attn_spec(f"up_blocks.{i}.attentions.{j}.", cout, ctx)
+                s += _attn_spec(f"up_blocks.{i}.attentions.{j}.", cout, ctx, cfg.transformer_depth[n - 1 - i], lin)
         if i < n - 1:
             s += [(f"up_blocks.{i}.upsamplers.0.conv.weight", (cout, cout, 3, 3)),
                   (f"up_blocks.{i}.upsamplers.0.conv.bias", (cout,))]
@@ -248,9 +275,8 @@ class _Net:
             x = self.conv(p + "conv_shortcut", x)
         return x + h
 
-    def attention(self, p, x, ctx):
+    def attention(self, p, x, ctx, H):
         B, L, C = x.shape
-        H = self.cfg.heads
         q = self.linear(p + "to_q", x)
         k = self.linear(p + "to_k", ctx)
         v = self.linear(p + "to_v", ctx)
@@ -262,24 +288,32 @@ class _Net:
         o = (s @ v).transpose(1, 2).reshape(B, L, C)
         return self.linear(p + "to_out.0", o)
 
-    def transformer(self, p, x, ctx):
+    def transformer(self, p, x, ctx, depth=1, heads=None):
+        heads = heads if heads is not None else self.cfg.heads_at(0)
         B, C, Hh, Ww = x.shape
         r = x
-        h = self.conv(p + "proj_in", self.gn(p + "norm", x, 1e-6))
-        h = h.permute(0, 2, 3, 1).reshape(B, Hh * Ww, C)
-        b = p + "transformer_blocks.0."
-        n = self.ln(b + "norm1", h)
-        h = h + self.attention(b + "attn1.", n, n)
-        h = h + self.attention(b + "attn2.", self.ln(b + "norm2", h), ctx)
-        n = self.ln(b + "norm3", h)
-        a, g = self.linear(b + "ff.net.0.proj", n).chunk(2, dim=-1)
-        h = h + self.linear(b + "ff.net.2", a * F.gelu(g))
+        h = self.gn(p + "norm", x, 1e-6)
+        if self.cfg.use_linear_projection:       # Transformer2DModel: reshape first, then a Linear proj_in
+            h = self.linear(p + "proj_in", h.permute(0, 2, 3, 1).reshape(B, Hh * Ww, C))
+        else:
+            h = self.conv(p + "proj_in", h).permute(0, 2, 3, 1).reshape(B, Hh * Ww, C)
+        for k in range(depth):
+            b = p + f"transformer_blocks.{k}."
+            n = self.ln(b + "norm1", h)
+            h = h + self.attention(b + "attn1.", n, n, heads)
+            h = h + self.attention(b + "attn2.", self.ln(b + "norm2", h), ctx, heads)
+            n = self.ln(b + "norm3", h)
+            a, g = self.linear(b + "ff.net.0.proj", n).chunk(2, dim=-1)
+            h = h + self.linear(b + "ff.net.2", a * F.gelu(g))
+        if self.cfg.use_linear_projection:
+            h = self.linear(p + "proj_out", h).reshape(B, Hh, Ww, C).permute(0, 3, 1, 2)
+            return h + r
         h = h.reshape(B, Hh, Ww, C).permute(0, 3, 1, 2)
         return self.conv(p + "proj_out", h) + r
 
 
 def unet_forward(cfg, sd, sample, timesteps, encoder_hidden_states, lora=None, lora_alpha=8.0,
-                 return_features=False):
+                 return_features=False, added_cond=None):
     """UNet2DConditionModel.forward(sample, timestep, encoder_hidden_states).sample in fp32.
     ``return_features`` mimics discriminator_sd15.py modified_forward (features after every down
     block, mid, every up block; no conv_norm_out/conv_out)."""
@@ -288,29 +322,36 @@ def unet_forward(cfg, sd, sample, timesteps, encoder_hidden_states, lora=None, l
     n = len(boc)
     t_emb = timestep_embedding(timesteps, boc[0]).to(sample.dtype)
     emb = net.linear("time_embedding.linear_2", F.silu(net.linear("time_embedding.linear_1", t_emb)))
+    if cfg.addition_time_embed_dim:
+        # addition_embed_type="text_time" (get_aug_embed): emb += add_embedding(cat(text_embeds, add_time_proj(time_ids.flatten())))
+        B = sample.shape[0]
+        tid = timestep_embedding(added_cond["time_ids"].flatten(), cfg.addition_time_embed_dim).reshape(B, -1).to(sample.dtype)
+        add_in = torch.cat([added_cond["text_embeds"].to(sample.dtype), tid], dim=-1)
+        emb = emb + net.linear("add_embedding.linear_2", F.silu(net.linear("add_embedding.linear_1", add_in)))
     h = net.conv("conv_in", sample)
     skips = [h]
     feats = []
     for i in range(n):
         for j in range(cfg.layers_per_block):
             h = net.resnet(f"down_blocks.{i}.resnets.{j}.", h, emb)
-            if i < n - 1:
-                h = net.transformer(f"down_blocks.{i}.attentions.{j}.", h, encoder_hidden_states)
+            if cfg.down_attn[i]:
+                h = net.transformer(f"down_blocks.{i}.attentions.{j}.", h, encoder_hidden_states, cfg.transformer_depth[i], cfg.heads_at(i))
             skips.append(h)
         if i < n - 1:
             h = net.conv(f"down_blocks.{i}.downsamplers.0.conv", h, stride=2)
             skips.append(h)
         feats.append(h)
     h = net.resnet("mid_block.resnets.0.", h, emb)
-    h = net.transformer("mid_block.attentions.0.", h, encoder_hidden_states)
+    h = net.transformer("mid_block.attentions.0.", h, encoder_hidden_states, cfg.mid_depth, cfg.heads_at(n - 1))
     h = net.resnet("mid_block.resnets.1.", h, emb)
     feats.append(h)
     for i in range(n):
         for j in range(cfg.layers_per_block + 1):
             h = torch.cat([h, skips.pop()], dim=1)
             h = net.resnet(f"up_blocks.{i}.resnets.{j}.", h, emb)
-            if i > 0:
-                h = net.transformer(f"up_blocks.{i}.attentions.{j}.", h, encoder_hidden_states)
+            if cfg.down_attn[n - 1 - i]:
+                h = net.transformer(f"up_blocks.{i}.attentions.{j}.", h, encoder_hidden_states, cfg.transformer_depth[n - 1 - i],
+                                    cfg.heads_at(n - 1 - i))
         if i < n - 1:
             h = F.interpolate(h, scale_factor=2.0, mode="nearest")
             h = net.conv(f"up_blocks.{i}.upsamplers.0.conv", h)

@@ -386,8 +386,8 @@ class UNet:
         return d_x.view(B, H * Wd, Cin)
 
     # ---- transformer (Transformer2DModel with one BasicTransformerBlock) ----
-    def _attn_fwd(self, p, xn, ctx, B, L, Lk, C, resid, sv):
-        W, lora, Hh = self.W, self.lora, self.cfg.heads
+    def _attn_fwd(self, p, xn, ctx, B, L, Lk, C, resid, sv, Hh):
+        W, lora = self.W, self.lora
         d = C // Hh
         M = B * L
         sq, sk, svv, so = ({} if sv is not None else None for _ in range(4))
@@ -407,9 +407,9 @@ class UNet:
             sv.update(sq=sq, sk=sk, sv=svv, so=so, q=q, k=k, v=v, o=o, lse=lse, L=L, Lk=Lk)
         return out
 
-    def _attn_bwd(self, p, d_out, sv, B, C, need_dctx):
+    def _attn_bwd(self, p, d_out, sv, B, C, need_dctx, Hh):
         """returns (d_xn [M,C], d_ctx or None)"""
-        W, lora, Hh = self.W, self.lora, self.cfg.heads
+        W, lora = self.W, self.lora
         d, L, Lk = C // Hh, sv["L"], sv["Lk"]
         d_o = layer_bwd(W, lora, p + "to_out.0", d_out, sv["so"])
         dq, dk, dv = ops.attn_bwd(sv["q"].view(B, L, C), sv["k"].view(B, Lk, C), sv["v"].view(B, Lk, C), sv["o"],
@@ -423,63 +423,74 @@ class UNet:
             layer_bwd(W, lora, p + "to_v", dv.view(B * Lk, C), sv["sv"], need_dx=False)
         return d_xn
 
-    def transformer_fwd(self, p, x, text, B, H, Wd, tape):
+    def transformer_fwd(self, p, x, text, B, H, Wd, tape, depth=1, heads=None):
+        """Transformer2DModel: GroupNorm -> proj_in -> ``depth`` BasicTransformerBlocks -> proj_out + input residual."""
         W, lora = self.W, self.lora
+        heads = heads if heads is not None else self.cfg.heads_at(0)
         C, L, M = x.shape[-1], H * Wd, B * H * Wd
         Lt = text.shape[1]
         rec = tape is not None
-        sgn, spi, sa1, sa2, sf0, sf2, spo = ({} if rec else None for _ in range(7))
+        sgn, spi, spo = ({} if rec else None for _ in range(3))
         n = self._gn(p + "norm", x, capi.ACT_NONE, 1e-6, sgn)
         h = layer_fwd(W, lora, p + "proj_in", n.view(M, C), M, save=spi)
-        b = p + "transformer_blocks.0."
-        g1, b1 = W.norms[b + "norm1"]
-        n1, mu1, rs1 = ops.layernorm_fwd(h, g1, b1)
-        h1 = self._attn_fwd(b + "attn1.", n1, n1, B, L, L, C, h, sa1)
-        g2, b2 = W.norms[b + "norm2"]
-        n2, mu2, rs2 = ops.layernorm_fwd(h1, g2, b2)
-        h2 = self._attn_fwd(b + "attn2.", n2, text.view(B * Lt, -1), B, L, Lt, C, h1, sa2)
-        g3, b3 = W.norms[b + "norm3"]
-        n3, mu3, rs3 = ops.layernorm_fwd(h2, g3, b3)
-        Lff = W.layers[b + "ff.net.0.proj"]
-        if lora is None and not rec and Lff.w_geglu is not None and M >= 128:
-            # frozen no-grad pass: GEGLU applied in the projection's epilogue (the 2*inner-wide pre-activation never reaches HBM)
-            hg = None
-            gg = torch.empty(M, Lff.N // 2, dtype=BF16, device=n3.device)
-            ops.gemm([Seg(n3, Lff.w_geglu)], M, Lff.N, gg, bias=Lff.bias_geglu, act=capi.ACT_GEGLU, ldo=Lff.N // 2)
-        else:
-            hg = layer_fwd(W, lora, b + "ff.net.0.proj", n3, M, save=sf0)
-            gg = ops.geglu_fwd(hg)
-        h3 = layer_fwd(W, lora, b + "ff.net.2", gg, M, save=sf2, residual=h2)
-        out = layer_fwd(W, lora, p + "proj_out", h3, M, save=spo, residual=x.view(M, C))
+        blocks = []
+        for k in range(depth):
+            b = p + f"transformer_blocks.{k}."
+            sa1, sa2, sf0, sf2 = ({} if rec else None for _ in range(4))
+            g1, b1 = W.norms[b + "norm1"]
+            n1, mu1, rs1 = ops.layernorm_fwd(h, g1, b1)
+            h1 = self._attn_fwd(b + "attn1.", n1, n1, B, L, L, C, h, sa1, heads)
+            g2, b2 = W.norms[b + "norm2"]
+            n2, mu2, rs2 = ops.layernorm_fwd(h1, g2, b2)
+            h2 = self._attn_fwd(b + "attn2.", n2, text.view(B * Lt, -1), B, L, Lt, C, h1, sa2, heads)
+            g3, b3 = W.norms[b + "norm3"]
+            n3, mu3, rs3 = ops.layernorm_fwd(h2, g3, b3)
+            Lff = W.layers[b + "ff.net.0.proj"]
+            if lora is None and not rec and Lff.w_geglu is not None and M >= 128:
+                # frozen no-grad pass: GEGLU applied in the projection's epilogue (the 2*inner-wide pre-activation never reaches HBM)
+                hg = None
+                gg = torch.empty(M, Lff.N // 2, dtype=BF16, device=n3.device)
+                ops.gemm([Seg(n3, Lff.w_geglu)], M, Lff.N, gg, bias=Lff.bias_geglu, act=capi.ACT_GEGLU, ldo=Lff.N // 2)
+            else:
+                hg = layer_fwd(W, lora, b + "ff.net.0.proj", n3, M, save=sf0)
+                gg = ops.geglu_fwd(hg)
+            h3 = layer_fwd(W, lora, b + "ff.net.2", gg, M, save=sf2, residual=h2)
+            if rec:
+                blocks.append(dict(sa1=sa1, sa2=sa2, sf0=sf0, sf2=sf2, h=h, mu1=mu1, rs1=rs1, h1=h1, mu2=mu2, rs2=rs2, h2=h2, mu3=mu3,
+                                   rs3=rs3, hg=hg))
+            h = h3
+        out = layer_fwd(W, lora, p + "proj_out", h, M, save=spo, residual=x.view(M, C))
         if rec:
-            tape.append(("transformer", p, dict(sgn=sgn, spi=spi, sa1=sa1, sa2=sa2, sf0=sf0, sf2=sf2, spo=spo, B=B, H=H, W=Wd, C=C,
-                                                h=h, mu1=mu1, rs1=rs1, h1=h1, mu2=mu2, rs2=rs2, h2=h2, mu3=mu3, rs3=rs3, hg=hg)))
+            tape.append(("transformer", p, dict(sgn=sgn, spi=spi, spo=spo, B=B, H=H, W=Wd, C=C, heads=heads,
+                                                **{f"blk{k}": blocks[k] for k in range(depth)})))
         return out.view(B, L, C)
 
     def transformer_bwd(self, p, d_out, sv):
         W, lora = self.W, self.lora
-        B, H, Wd, C = sv["B"], sv["H"], sv["W"], sv["C"]
+        B, H, Wd, C, heads = sv["B"], sv["H"], sv["W"], sv["C"], sv["heads"]
         M = B * H * Wd
         d_out = d_out.view(M, C)
-        b = p + "transformer_blocks.0."
-        d_h3 = layer_bwd(W, lora, p + "proj_out", d_out, sv["spo"])                      # residual r: + d_out at the end
-        # ff: h3 = h2 + ff2(geglu(ff0(LN3(h2))))
-        d_gg = layer_bwd(W, lora, b + "ff.net.2", d_h3, sv["sf2"])
-        d_hg = ops.geglu_bwd(sv["hg"], d_gg)
-        d_n3 = layer_bwd(W, lora, b + "ff.net.0.proj", d_hg, sv["sf0"])
-        d_h2 = ops.layernorm_bwd(sv["h2"], d_n3, W.norms[b + "norm3"][0], sv["mu3"], sv["rs3"], dres=d_h3)
-        # attn2: h2 = h1 + attn2(LN2(h1), text)
-        d_n2 = self._attn_bwd(b + "attn2.", d_h2, sv["sa2"], B, C, need_dctx=False)
-        d_h1 = ops.layernorm_bwd(sv["h1"], d_n2, W.norms[b + "norm2"][0], sv["mu2"], sv["rs2"], dres=d_h2)
-        # attn1: h1 = h + attn1(LN1(h))
-        d_n1 = self._attn_bwd(b + "attn1.", d_h1, sv["sa1"], B, C, need_dctx=True)
-        d_h = ops.layernorm_bwd(sv["h"], d_n1, W.norms[b + "norm1"][0], sv["mu1"], sv["rs1"], dres=d_h1)
+        d_h = layer_bwd(W, lora, p + "proj_out", d_out, sv["spo"])                       # residual r: + d_out at the end
+        depth = sum(1 for k in sv if k.startswith("blk"))
+        for k in reversed(range(depth)):
+            b, bs = p + f"transformer_blocks.{k}.", sv[f"blk{k}"]
+            # ff: h3 = h2 + ff2(geglu(ff0(LN3(h2))))
+            d_gg = layer_bwd(W, lora, b + "ff.net.2", d_h, bs["sf2"])
+            d_hg = ops.geglu_bwd(bs["hg"], d_gg)
+            d_n3 = layer_bwd(W, lora, b + "ff.net.0.proj", d_hg, bs["sf0"])
+            d_h2 = ops.layernorm_bwd(bs["h2"], d_n3, W.norms[b + "norm3"][0], bs["mu3"], bs["rs3"], dres=d_h)
+            # attn2: h2 = h1 + attn2(LN2(h1), text)
+            d_n2 = self._attn_bwd(b + "attn2.", d_h2, bs["sa2"], B, C, False, heads)
+            d_h1 = ops.layernorm_bwd(bs["h1"], d_n2, W.norms[b + "norm2"][0], bs["mu2"], bs["rs2"], dres=d_h2)
+            # attn1: h1 = h + attn1(LN1(h))
+            d_n1 = self._attn_bwd(b + "attn1.", d_h1, bs["sa1"], B, C, True, heads)
+            d_h = ops.layernorm_bwd(bs["h"], d_n1, W.norms[b + "norm1"][0], bs["mu1"], bs["rs1"], dres=d_h1)
         d_n = layer_bwd(W, lora, p + "proj_in", d_h, sv["spi"])
         d_x = self._gn_bwd(p + "norm", d_n.view(B, H * Wd, C), capi.ACT_NONE, 1e-6, sv["sgn"])
         return ops.add(d_x.view(M, C), d_out).view(B, H * Wd, C)
 
     # ---- whole network ----
-    def forward(self, sample, timesteps, encoder_hidden_states, save=False, features=False):
+    def forward(self, sample, timesteps, encoder_hidden_states, save=False, features=False, added_cond=None):
         """``features=True`` is the reference's ``modified_forward`` (discriminator_sd15.py:16-345): returns the 9
         hidden states after every down block, the mid block and every up block (no conv_norm_out / conv_out)."""
         cfg, W, lora = self.cfg, self.W, self.lora
@@ -489,15 +500,29 @@ class UNet:
         text = encoder_hidden_states if encoder_hidden_states.dtype == BF16 else ops.cast_bf16(encoder_hidden_states.contiguous())
         t_emb = ops.timestep_embedding(timesteps, boc[0])
         e1 = layer_fwd(W, None, "time_embedding.linear_1", t_emb, B, act=capi.ACT_SILU)
-        emb_act = layer_fwd(W, None, "time_embedding.linear_2", e1, B, act=capi.ACT_SILU)  # silu(emb): only use of emb
+        if cfg.addition_time_embed_dim:
+            # SDXL "text_time" conditioning (added_cond_kwargs, train_pcm_lora_sdxl_adv.py:1113-1131): emb = time_emb +
+            # add_embedding([pooled text embeds | sinusoid(6 time ids)]); everything upstream of silu(emb) is frozen
+            assert added_cond is not None, "this UNet needs added_cond={'text_embeds': [B,P], 'time_ids': [B,6]}"
+            emb_t = layer_fwd(W, None, "time_embedding.linear_2", e1, B)
+            ids = added_cond["time_ids"].to(torch.int64).reshape(-1)
+            tid = ops.timestep_embedding(ids, cfg.addition_time_embed_dim).view(B, -1)
+            te = added_cond["text_embeds"]
+            te = te if te.dtype == BF16 else ops.cast_bf16(te.contiguous())
+            add_in = torch.cat([te, tid], dim=1).contiguous()
+            a1 = layer_fwd(W, None, "add_embedding.linear_1", add_in, B, act=capi.ACT_SILU)
+            emb = layer_fwd(W, None, "add_embedding.linear_2", a1, B, residual=emb_t)
+            emb_act = ops.silu(emb)
+        else:
+            emb_act = layer_fwd(W, None, "time_embedding.linear_2", e1, B, act=capi.ACT_SILU)  # silu(emb): only use of emb
         h = ops.conv_in_fwd(sample.contiguous(), W.conv_in[0], W.conv_in[1], boc[0])
         skips = [(h, H, Wd)]
         feats = []
         for i in range(n):
             for j in range(cfg.layers_per_block):
                 h = self.resnet_fwd(f"down_blocks.{i}.resnets.{j}.", h, emb_act, B, H, Wd, tape)
-                if i < n - 1:
-                    h = self.transformer_fwd(f"down_blocks.{i}.attentions.{j}.", h, text, B, H, Wd, tape)
+                if cfg.down_attn[i]:
+                    h = self.transformer_fwd(f"down_blocks.{i}.attentions.{j}.", h, text, B, H, Wd, tape, cfg.transformer_depth[i], cfg.heads_at(i))
                 skips.append((h, H, Wd))
             if i < n - 1:
                 geo = Geo(H, Wd, stride=2)
@@ -513,7 +538,7 @@ class UNet:
                 if save:
                     tape.append(("feat", None, dict(k=len(feats) - 1)))
         h = self.resnet_fwd("mid_block.resnets.0.", h, emb_act, B, H, Wd, tape)
-        h = self.transformer_fwd("mid_block.attentions.0.", h, text, B, H, Wd, tape)
+        h = self.transformer_fwd("mid_block.attentions.0.", h, text, B, H, Wd, tape, cfg.mid_depth, cfg.heads_at(n - 1))
         h = self.resnet_fwd("mid_block.resnets.1.", h, emb_act, B, H, Wd, tape)
         if features:
             feats.append((h, H, Wd))
@@ -527,8 +552,9 @@ class UNet:
                 if save:
                     tape.append(("cat", None, dict(Ch=Ch, skip_index=len(skips))))
                 h = self.resnet_fwd(f"up_blocks.{i}.resnets.{j}.", h, emb_act, B, H, Wd, tape)
-                if i > 0:
-                    h = self.transformer_fwd(f"up_blocks.{i}.attentions.{j}.", h, text, B, H, Wd, tape)
+                if cfg.up_attn(i):
+                    lv = cfg.up_level(i)
+                    h = self.transformer_fwd(f"up_blocks.{i}.attentions.{j}.", h, text, B, H, Wd, tape, cfg.transformer_depth[lv], cfg.heads_at(lv))
             if i < n - 1:
                 geo = Geo(H, Wd, stride=1, src_mode=capi.SRC_UPSAMPLE2)   # nearest-2x fused into the conv loader
                 sv = {} if save else None

@@ -81,8 +81,13 @@ class Distiller:
         t = torch.clamp(start - self.tables.topk, min=0)
         return start, t
 
-    def forward_backward(self, latents, prompt_embeds, uncond_prompt_embeds, noise, index, w, backward=True):
-        """Everything of the step before the gradient exchange: returns a dict of device tensors."""
+    def forward_backward(self, latents, prompt_embeds, uncond_prompt_embeds, noise, index, w, backward=True, added_cond=None,
+                         uncond_added_cond=None):
+        """Everything of the step before the gradient exchange: returns a dict of device tensors.
+        ``added_cond`` / ``uncond_added_cond``: SDXL ``added_cond_kwargs`` ({'text_embeds': [B,1280], 'time_ids': [B,6]},
+        train_pcm_lora_sdxl_adv.py:1113-1131, :1409-1421) for UNets with text_time conditioning; None for SD1.5."""
+        def cat2(a, b_):
+            return None if a is None else {k: torch.cat([a[k], (b_ if b_ is not None else a)[k]]) for k in a}
         cfg, T = self.cfg, self.tables
         B = latents.shape[0]
         start_t, t_n = self.timesteps_for(index)
@@ -90,11 +95,11 @@ class Distiller:
         # teacher cond (+ uncond) in ONE batched forward (no grad, no LoRA) --------------------- :1217-1252
         # (scheduled first: the online forward does not depend on it, the target forward does)
         if cfg.not_apply_cfg_solver:
-            eps_c = self.teacher.forward(noisy, start_t, prompt_embeds)
+            eps_c = self.teacher.forward(noisy, start_t, prompt_embeds, added_cond=added_cond)
             eps_u = eps_c
         else:
             both = self.teacher.forward(torch.cat([noisy, noisy]), torch.cat([start_t, start_t]),
-                                        torch.cat([prompt_embeds, uncond_prompt_embeds]))
+                                        torch.cat([prompt_embeds, uncond_prompt_embeds]), added_cond=cat2(added_cond, uncond_added_cond))
             eps_c, eps_u = both[:B], both[B:]
         x_prev64, x_prev32 = ops.cfg_ddim_step(eps_c, eps_u, noisy, start_t, index, w, T.acp, T.acp_prev)   # :1254-1258
         if self.fuse_online_target:
@@ -102,12 +107,12 @@ class Distiller:
             # LoRA, no grad, :1261-1268) as ONE 2B-sample schedule: samples are independent, so each half is exactly the
             # separate forward; the backward runs on the online half of the tape only
             eps_st, tape2 = self.student.forward(torch.cat([noisy, x_prev32]), torch.cat([start_t, t_n]),
-                                                 torch.cat([prompt_embeds, prompt_embeds]), save=True)
+                                                 torch.cat([prompt_embeds, prompt_embeds]), save=True, added_cond=cat2(added_cond, None))
             eps_s, eps_t = eps_st[:B], eps_st[B:]
             tape = self.student.tape_first_half(tape2)
         else:
-            eps_s, tape = self.student.forward(noisy, start_t, prompt_embeds, save=True)
-            eps_t = self.student.forward(x_prev32, t_n, prompt_embeds)
+            eps_s, tape = self.student.forward(noisy, start_t, prompt_embeds, save=True, added_cond=added_cond)
+            eps_t = self.student.forward(x_prev32, t_n, prompt_embeds, added_cond=added_cond)
         model_pred, coef, end_t = ops.phase_jump(eps_s, noisy, start_t, index, T.acp, T.acp_prev, T.ddim_timesteps_prev,
                                                  T.edges, target_mode=False)                     # :1200-1212
         target, _, _ = ops.phase_jump(eps_t, x_prev64, t_n, index, T.acp, T.acp_prev, T.ddim_timesteps_prev, T.edges,
@@ -123,11 +128,13 @@ class Distiller:
         self.student.backward(d_eps, tape)                                                       # :1296
         return out
 
-    def step(self, latents, prompt_embeds, uncond_prompt_embeds, noise, index, w, lr=None, update=True):
+    def step(self, latents, prompt_embeds, uncond_prompt_embeds, noise, index, w, lr=None, update=True, added_cond=None,
+             uncond_added_cond=None):
         """One distillation step on this rank's batch (eager launches).  All inputs are device tensors:
         latents/noise [B,4,H,W] fp32, prompt embeds [B,77,768], index [B] int64, w [B] fp32.
         Returns a dict of device tensors (no host sync)."""
-        out = self.forward_backward(latents, prompt_embeds, uncond_prompt_embeds, noise, index, w, backward=update)
+        out = self.forward_backward(latents, prompt_embeds, uncond_prompt_embeds, noise, index, w, backward=update, added_cond=added_cond,
+                                    uncond_added_cond=uncond_added_cond)
         if not update:
             return out
         if lr is not None:

@@ -75,3 +75,86 @@ def test_unet_forward_backward_vs_oracle():
             assert rel < 0.15, (p, rel)
     print("grad rel err: global %.3e worst module %.3e" % ((num / den) ** 0.5, worst))
     assert (num / den) ** 0.5 < 0.05
+
+
+def test_sdxl_topology_forward_backward_vs_oracle():
+    """the SDXL UNet wiring (no attention at level 0, transformer depth > 1, per-level head counts with 64-wide heads,
+    Linear proj_in/proj_out, text_time added conditioning) on a narrow config; plus the full-size parameter count."""
+    import math
+    from oracle import unet_sd15 as O
+    from pcm_amd.model import LoraState, UNet, UNetWeights
+    from pcm_amd.unet_spec import UNetConfig, param_spec
+    assert sum(math.prod(s) for _, s in param_spec(UNetConfig.sdxl())) == 2567463684
+    assert [k for k, _ in param_spec(UNetConfig.sdxl())] == [k for k, _ in O.param_spec(O.UNetConfig.sdxl())]
+    kw = dict(block_out_channels=(64, 128, 128), cross_attention_dim=64, heads=(1, 2, 2), down_attn=(False, True, True),
+              transformer_depth=(1, 2, 2), use_linear_projection=True, addition_time_embed_dim=32, projection_class_embeddings_input_dim=64 + 6 * 32,
+              layers_per_block=1)
+    oc, pc = O.UNetConfig(**kw), UNetConfig(**kw)
+    sd = O.init_state_dict(oc, 0)
+    B, Hh = 2, 8
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(B, 4, Hh, Hh, generator=g)
+    t = torch.tensor([19, 759])
+    ctx = torch.randn(B, 7, 64, generator=g)
+    added = dict(text_embeds=torch.randn(B, 64, generator=g), time_ids=torch.tensor([[1024, 1024, 0, 0, 1024, 1024], [512, 768, 16, 32, 1024, 1024]]))
+    d_eps = torch.randn(B, 4, Hh, Hh, generator=g)
+    W = UNetWeights(pc, sd, "cpu")
+    lora = LoraState(pc, 64, 8.0, "cpu", seed=1, b_std=0.05)
+    olora = {p: (lora.A_peft(m).clone().requires_grad_(True), m.B.clone().requires_grad_(True)) for p, m in lora.modules.items()}
+    assert set(olora) == {p for p, _ in O.lora_target_modules(oc)}
+    ref_t = O.unet_forward(oc, sd, x, t, ctx, added_cond=added)
+    ref_s = O.unet_forward(oc, sd, x, t, ctx, olora, 8.0, added_cond=added)
+    out_t = UNet(W, None).forward(x, t, ctx, added_cond=added)
+    student = UNet(W, lora)
+    out_s, tape = student.forward(x, t, ctx, save=True, added_cond=added)
+    scale = ref_t.abs().max().item()
+    err_t, err_s = (out_t - ref_t).abs().max().item(), (out_s - ref_s.detach()).abs().max().item()
+    print("sdxl-topology fwd err teacher %.3e student %.3e (scale %.3e)" % (err_t, err_s, scale))
+    assert err_t < 0.03 * scale and err_s < 0.03 * scale
+    # the added conditioning must matter (otherwise the test would not see a wiring error)
+    other = dict(added, time_ids=added["time_ids"] * 0 + 7)
+    assert (O.unet_forward(oc, sd, x, t, ctx, added_cond=other) - ref_t).abs().max().item() > 10 * err_t
+    (ref_s * d_eps).sum().backward()
+    lora.zero_grad()
+    student.backward(d_eps, tape)
+    num = den = 0.0
+    for p, m in lora.modules.items():
+        for got, ref in ((lora.gA_peft(m), olora[p][0].grad), (m.gB, olora[p][1].grad)):
+            ref = ref.view_as(got)
+            num += float(((got - ref) ** 2).sum()); den += float((ref ** 2).sum())
+    print("sdxl-topology LoRA grad rel err %.3e" % (num / den) ** 0.5)
+    assert (num / den) ** 0.5 < 0.08
+
+
+def test_sdxl_topology_distillation_step_vs_oracle():
+    """One PCM distillation step with SDXL-style added conditioning (cond + uncond pooled embeds) through the Distiller."""
+    from oracle import pcm_step as OS
+    from oracle import unet_sd15 as O
+    from pcm_amd.model import LoraState, UNetWeights
+    from pcm_amd.trainer import Distiller, StepConfig
+    from pcm_amd.unet_spec import UNetConfig
+    kw = dict(block_out_channels=(64, 128), cross_attention_dim=64, heads=(1, 2), down_attn=(False, True), transformer_depth=(1, 2),
+              use_linear_projection=True, addition_time_embed_dim=32, projection_class_embeddings_input_dim=64 + 6 * 32, layers_per_block=1)
+    oc, pc = O.UNetConfig(**kw), UNetConfig(**kw)
+    sd = O.init_state_dict(oc, 0)
+    W = UNetWeights(pc, sd, "cpu")
+    lora = LoraState(pc, 64, 8.0, "cpu", seed=1, b_std=0.05)
+    olora = {p: (lora.A_peft(m).clone().requires_grad_(True), m.B.clone().requires_grad_(True)) for p, m in lora.modules.items()}
+    ocfg = OS.StepConfig(multiphase=2, loss_type="huber", w_min=4.0, w_max=5.0)
+    B = 2
+    inp = OS.draw_inputs(B, ocfg, seed=7, latent_hw=8, ctx_len=7, ctx_dim=64)
+    g = torch.Generator().manual_seed(3)
+    tids = torch.tensor([[1024, 1024, 0, 0, 1024, 1024]] * B)
+    inp["added_cond"] = dict(text_embeds=torch.randn(B, 64, generator=g), time_ids=tids)
+    inp["uncond_added_cond"] = dict(text_embeds=torch.zeros(B, 64), time_ids=tids)       # zero uncond pooled embeds (sdxl_adv.py:1216-1221)
+    ref = OS.distill_step_forward(oc, sd, olora, inp, ocfg)
+    cfg = StepConfig(multiphase=2, loss_type="huber", w_min=4.0, w_max=5.0)
+    D = Distiller(W, lora, cfg)
+    out = D.forward_backward(inp["latents"], inp["prompt_embeds"], inp["uncond_prompt_embeds"], inp["noise"], inp["index"], inp["w"],
+                             backward=False, added_cond=inp["added_cond"], uncond_added_cond=inp["uncond_added_cond"])
+    for k in ("noise_pred", "uncond_teacher_output", "x_prev", "target"):
+        r = ref[k].detach().float()
+        rel = float((out[k].float() - r).norm() / r.norm())
+        print(k, "%.3e" % rel)
+        assert rel < 3e-2, (k, rel)
+    assert abs(float(out["loss"]) - float(ref["loss"])) < 5e-2 * abs(float(ref["loss"]))

@@ -1,0 +1,59 @@
+"""GPU parity of the SDXL UNet wiring on a narrow config: forward, LoRA backward and one distillation step with
+added conditioning vs the CPU oracle."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfgs():
+    from oracle import unet_sd15 as O
+    from pcm_amd.unet_spec import UNetConfig
+    kw = dict(block_out_channels=(64, 128, 128), cross_attention_dim=64, heads=(1, 2, 2), down_attn=(False, True, True),
+              transformer_depth=(1, 2, 3), use_linear_projection=True, addition_time_embed_dim=32,
+              projection_class_embeddings_input_dim=64 + 6 * 32)
+    return O.UNetConfig(**kw), UNetConfig(**kw)
+
+
+def test_sdxl_topology_step_vs_oracle():
+    from oracle import pcm_step as OS
+    from oracle import unet_sd15 as O
+    from pcm_amd import capi
+    from pcm_amd.model import LoraState, UNetWeights
+    from pcm_amd.trainer import Distiller, StepConfig
+    capi.set_lib(None)
+    capi.lib()
+    oc, pc = _cfgs()
+    sd = O.init_state_dict(oc, 0)
+    W = UNetWeights(pc, sd, "cuda")
+    lora = LoraState(pc, 64, 8.0, "cuda", seed=1, b_std=0.05)
+    olora = {p: (lora.A_peft(m).detach().cpu().clone().requires_grad_(True), m.B.detach().cpu().clone().requires_grad_(True))
+             for p, m in lora.modules.items()}
+    ocfg = OS.StepConfig(multiphase=4, loss_type="huber", w_min=6.0, w_max=7.0, num_ddim_timesteps=40)
+    B = 2
+    inp = OS.draw_inputs(B, ocfg, seed=7, latent_hw=32, ctx_len=77, ctx_dim=64)
+    g = torch.Generator().manual_seed(3)
+    tids = torch.tensor([[1024, 1024, 0, 0, 1024, 1024]] * B)
+    inp["added_cond"] = dict(text_embeds=torch.randn(B, 64, generator=g), time_ids=tids)
+    inp["uncond_added_cond"] = dict(text_embeds=torch.zeros(B, 64), time_ids=tids)
+    ref = OS.distill_step_forward(oc, sd, olora, inp, ocfg)
+    ref["loss"].backward()
+    cfg = StepConfig(multiphase=4, loss_type="huber", w_min=6.0, w_max=7.0, num_ddim_timesteps=40)
+    D = Distiller(W, lora, cfg)
+    cu = lambda v: {k: x.cuda() for k, x in v.items()} if isinstance(v, dict) else v.cuda()
+    out = D.forward_backward(*(cu(inp[k]) for k in ("latents", "prompt_embeds", "uncond_prompt_embeds", "noise", "index", "w")),
+                             added_cond=cu(inp["added_cond"]), uncond_added_cond=cu(inp["uncond_added_cond"]))
+    torch.cuda.synchronize()
+    for k in ("noise_pred", "uncond_teacher_output", "x_prev", "target"):
+        r = ref[k].detach().float()
+        rel = float((out[k].float().cpu() - r).norm() / r.norm())
+        assert rel < 3e-2, (k, rel)
+    assert abs(float(out["loss"]) - float(ref["loss"])) < 5e-2 * abs(float(ref["loss"]))
+    num = den = 0.0
+    for p, m in lora.modules.items():
+        for got, rg in ((lora.gA_peft(m), olora[p][0].grad), (m.gB, olora[p][1].grad)):
+            rg = rg.view_as(got)
+            num += float(((got.cpu() - rg) ** 2).sum()); den += float((rg ** 2).sum())
+    rel = (num / den) ** 0.5
+    print("sdxl-topology step: loss %.5f / %.5f, LoRA grad rel err %.3e" % (float(out["loss"]), float(ref["loss"]), rel))
+    assert rel < 0.1
