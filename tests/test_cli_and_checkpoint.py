@@ -70,6 +70,30 @@ def test_adv_cli_adds_adv_flags_with_reference_defaults():
         assert re.search(r'"--adv_weight".{0,80}default=0\.1', src, re.S) and re.search(r'"--adv_lr".{0,80}default=1e-5', src, re.S)
 
 
+def test_sdxl_cli_flag_surface_matches_reference():
+    """train_pcm_lora_sdxl_adv.py: the SD1.5 flag set + 4 extra flags, with the SDXL script's own defaults (resolution 1024, w_min 3, multiphase 4)."""
+    sys.path.insert(0, PKG)
+    spec = importlib.util.spec_from_file_location("pcm_cli_sdxl", os.path.join(PKG, "train_pcm_lora_sdxl_adv.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    ours = vars(m.parse_args(["--pretrained_teacher_model", "x"]))
+    ref_path = "/root/reference/code/text_to_image_sdxl/train_pcm_lora_sdxl_adv.py"
+    if os.path.exists(ref_path):
+        tree = ast.parse(open(ref_path).read())
+        fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "parse_args"][0]
+        ref = {}
+        for node in ast.walk(fn):
+            if isinstance(node, ast.Call) and getattr(node.func, "attr", "") == "add_argument":
+                kw = {k.arg: k.value for k in node.keywords}
+                ref[node.args[0].value.lstrip("-")] = ast.literal_eval(kw["default"]) if "default" in kw else (False if "action" in kw else None)
+        assert len(ref) == 55
+        for k, v in ref.items():
+            assert k in ours, k
+            if k != "pretrained_teacher_model":
+                assert ours[k] == v, (k, ours[k], v)
+    assert ours["resolution"] == 1024 and ours["multiphase"] == 4 and ours["adv_weight"] == 0.1
+
+
 def test_capi_exports_every_declared_symbol():
     from pcm_amd import build as B
     from pcm_amd import capi
