@@ -157,11 +157,13 @@ def kohya_key(peft_key, prefix="lora_unet"):
 
 def discriminator_head(sd, x, prefix=""):
     """discriminator_sd15.py:348-368 — conv3x3→GN(32)→LeakyReLU(0.01), conv3x3→GN→LeakyReLU
-    (+ skip), conv1x1→1; ``sd`` uses the nn.Sequential key names (conv1.0/conv1.1/conv2.0/...)."""
+    (+ skip), conv1x1→1; ``sd`` uses the nn.Sequential key names (conv1.0/conv1.1/conv2.0/...).
+    discriminator_sdxl.py:348-369 is the same head with 1x1 convs ("to save memory"): the kernel size is read off the weight."""
     F = torch.nn.functional
 
     def blk(name, h):
-        h = F.conv2d(h, sd[prefix + name + ".0.weight"], sd[prefix + name + ".0.bias"], padding=1)
+        w = sd[prefix + name + ".0.weight"]
+        h = F.conv2d(h, w, sd[prefix + name + ".0.bias"], padding=w.shape[-1] // 2)
         h = F.group_norm(h, 32, sd[prefix + name + ".1.weight"], sd[prefix + name + ".1.bias"], 1e-5)
         return F.leaky_relu(h, 0.01)
 

@@ -151,9 +151,10 @@ def distill_step(ucfg, sd, lora, inp, cfg: StepConfig, opt_state, step):
 # ---------------------------------------------------------------------------------------------
 # adversarial variant (train_pcm_lora_sd15_adv.py:1288-1431; discriminator_sd15.py:348-434)
 # ---------------------------------------------------------------------------------------------
-def discriminator_forward(ucfg, sd, disc_sd, sample, timestep, ehs, n_feats=9, nh=None):
-    """Discriminator._forward (discriminator_sd15.py:395-402): teacher features -> 36 head outputs."""
-    feats = unet_forward(ucfg, sd, sample, timestep, ehs, return_features=True)
+def discriminator_forward(ucfg, sd, disc_sd, sample, timestep, ehs, n_feats=9, nh=None, added_cond=None, taps=True):
+    """Discriminator._forward (discriminator_sd15.py:395-402): teacher features -> 36 head outputs.
+    ``taps="down_mid"``: the SDXL discriminator (discriminator_sdxl.py:395-411: 4 features, down blocks + mid)."""
+    feats = unet_forward(ucfg, sd, sample, timestep, ehs, return_features=taps, added_cond=added_cond)
     outs = []
     for k, f in enumerate(feats):
         h = 0
@@ -163,7 +164,7 @@ def discriminator_forward(ucfg, sd, disc_sd, sample, timestep, ehs, n_feats=9, n
     return outs
 
 
-def distill_step_adv(ucfg, sd, lora, disc_sd, inp, cfg: StepConfig, global_step, adv_weight=0.1):
+def distill_step_adv(ucfg, sd, lora, disc_sd, inp, cfg: StepConfig, global_step, adv_weight=0.1, taps=True):
     """One step of the adversarial trainer up to (and including) the backward; no optimizer update.
     inp additionally carries noise_fake, noise_real [B,4,H,W] and adv_u [B] in [0,1).
     Even global_step -> dict(d_loss, head_grads{name: grad}); odd -> dict(loss_cm, g_loss, lora_grads[list])."""
@@ -178,20 +179,20 @@ def distill_step_adv(ucfg, sd, lora, disc_sd, inp, cfg: StepConfig, global_step,
     span = cfg.num_train_timesteps // cfg.multiphase
     adv_t = end_t + torch.clamp((inp["adv_u"] * span).long(), max=span - 1)                     # :1288-1298
     fake_adv = M.noise_travel(acp, model_pred.float(), inp["noise_fake"], end_t, adv_t)         # :1303-1305
-    pe = inp["prompt_embeds"]
+    pe, ac = inp["prompt_embeds"], inp.get("added_cond")
     res = dict(model_pred=model_pred.detach(), target=target.detach(), adv_timesteps=adv_t, fake_adv=fake_adv.detach())
     if global_step % 2 == 0:
         real_adv = M.noise_travel(acp, target.float(), inp["noise_real"], end_t, adv_t)         # :1379-1381
         dsd = {k: v.detach().clone().requires_grad_(True) for k, v in disc_sd.items()}
-        fake_o = discriminator_forward(ucfg, sd, dsd, fake_adv.detach().float(), adv_t, pe)
-        real_o = discriminator_forward(ucfg, sd, dsd, real_adv.detach().float(), adv_t, pe)
+        fake_o = discriminator_forward(ucfg, sd, dsd, fake_adv.detach().float(), adv_t, pe, added_cond=ac, taps=taps)
+        real_o = discriminator_forward(ucfg, sd, dsd, real_adv.detach().float(), adv_t, pe, added_cond=ac, taps=taps)
         loss = M.hinge_d_loss(fake_o, real_o, 1.0)
         names = list(dsd)
         grads = torch.autograd.grad(loss, [dsd[n] for n in names])
         res.update(d_loss=loss.detach(), head_grads=dict(zip(names, grads)), real_adv=real_adv.detach())
         return res
     loss_cm = M.consistency_loss(model_pred, target, cfg.loss_type, cfg.huber_c)
-    fake_o = discriminator_forward(ucfg, sd, disc_sd, fake_adv.float(), adv_t, pe)
+    fake_o = discriminator_forward(ucfg, sd, disc_sd, fake_adv.float(), adv_t, pe, added_cond=ac, taps=taps)
     g_loss = M.hinge_g_loss(fake_o, 1.0)
     loss = loss_cm + adv_weight * g_loss                                                         # :1414-1422
     grads = torch.autograd.grad(loss, leaves, allow_unused=True)

@@ -345,6 +345,8 @@ def unet_forward(cfg, sd, sample, timesteps, encoder_hidden_states, lora=None, l
     h = net.transformer("mid_block.attentions.0.", h, encoder_hidden_states, cfg.mid_depth, cfg.heads_at(n - 1))
     h = net.resnet("mid_block.resnets.1.", h, emb)
     feats.append(h)
+    if return_features == "down_mid":      # discriminator_sdxl.py:311: "do not use up blocks to save memory"
+        return feats
     for i in range(n):
         for j in range(cfg.layers_per_block + 1):
             h = torch.cat([h, skips.pop()], dim=1)

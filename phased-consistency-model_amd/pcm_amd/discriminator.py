@@ -19,6 +19,7 @@ from .ops import Seg
 
 BF16 = torch.bfloat16
 ADAPTER_DIMS = (320, 640, 1280, 1280, 1280, 1280, 1280, 640, 320)   # discriminator_sd15.py:377
+ADAPTER_DIMS_SDXL = (320, 640, 1280, 1280)                            # discriminator_sdxl.py:377-386 (down blocks + mid only)
 
 
 class Head:
@@ -26,14 +27,19 @@ class Head:
 
 
 class Discriminator:
-    def __init__(self, adapter_channel_dims=ADAPTER_DIMS, num_h_per_head=4, device="cuda", seed=2, groups=32):
+    def __init__(self, adapter_channel_dims=ADAPTER_DIMS, num_h_per_head=4, device="cuda", seed=2, groups=32, ksize=3, taps=True):
+        """``ksize`` 3: the SD1.5 heads (conv3x3); 1: the SDXL heads (discriminator_sdxl.py:348-369, "1x1 to save memory").
+        ``taps``: feature mode handed to ``UNet.forward(features=...)`` (True: 9 taps; "down_mid": the 4 SDXL taps)."""
+        assert ksize in (1, 3)
         self.dims, self.nh, self.device, self.G = tuple(adapter_channel_dims), num_h_per_head, torch.device(device), groups
+        self.ksize, self.taps = ksize, taps
         self.head_num = len(self.dims)
         layout, total = [], 0
         for k, C in enumerate(self.dims):
             for h in range(num_h_per_head):
-                names = OrderedDict([("conv1.0.weight", (C, 3, 3, C)), ("conv1.0.bias", (C,)), ("conv1.1.weight", (C,)),
-                                     ("conv1.1.bias", (C,)), ("conv2.0.weight", (C, 3, 3, C)), ("conv2.0.bias", (C,)),
+                wshape = (C, 3, 3, C) if ksize == 3 else (C, C)
+                names = OrderedDict([("conv1.0.weight", wshape), ("conv1.0.bias", (C,)), ("conv1.1.weight", (C,)),
+                                     ("conv1.1.bias", (C,)), ("conv2.0.weight", wshape), ("conv2.0.bias", (C,)),
                                      ("conv2.1.weight", (C,)), ("conv2.1.bias", (C,)), ("conv_out.weight", (C,)),
                                      ("conv_out.bias", (1,))])
                 offs = {}
@@ -58,24 +64,27 @@ class Discriminator:
             hd.g = {n: self.grads[o:o + math.prod(shp)].view(shp) for n, (o, shp) in offs.items()}
             # torch default init of nn.Conv2d / nn.GroupNorm (DiscriminatorHead.__init__, :349-362)
             for cv in ("conv1.0", "conv2.0"):
-                bound = 1.0 / math.sqrt(9 * C)
-                w = (torch.rand(C, C, 3, 3, generator=g) * 2 - 1) * bound
-                hd.p[cv + ".weight"].copy_(w.permute(0, 2, 3, 1).to(self.device))
+                bound = 1.0 / math.sqrt(ksize * ksize * C)
+                w = (torch.rand(C, C, ksize, ksize, generator=g) * 2 - 1) * bound
+                hd.p[cv + ".weight"].copy_((w.permute(0, 2, 3, 1) if ksize == 3 else w.view(C, C)).to(self.device))
                 hd.p[cv + ".bias"].copy_(((torch.rand(C, generator=g) * 2 - 1) * bound).to(self.device))
             for gn in ("conv1.1", "conv2.1"):
                 hd.p[gn + ".weight"].fill_(1.0)
             bound = 1.0 / math.sqrt(C)
             hd.p["conv_out.weight"].copy_(((torch.rand(C, generator=g) * 2 - 1) * bound).to(self.device))
             hd.p["conv_out.bias"].copy_(((torch.rand(1, generator=g) * 2 - 1) * bound).to(self.device))
-            hd.wf = {cv: torch.empty(C, 9 * C, dtype=BF16, device=self.device) for cv in ("conv1.0", "conv2.0")}
-            hd.wb = {cv: torch.empty(C, 9 * C, dtype=BF16, device=self.device) for cv in ("conv1.0", "conv2.0")}
+            hd.wf = {cv: torch.empty(C, ksize * ksize * C, dtype=BF16, device=self.device) for cv in ("conv1.0", "conv2.0")}
+            hd.wb = {cv: torch.empty(C, ksize * ksize * C, dtype=BF16, device=self.device) for cv in ("conv1.0", "conv2.0")}
             self.heads.append((k, hd))
         self.repack()
 
     def repack(self):
         for _, hd in self.heads:
             for cv in ("conv1.0", "conv2.0"):
-                ops.pack_conv3x3(hd.p[cv + ".weight"], True, True, 1.0, hd.wf[cv], hd.wb[cv], khwc=True)
+                if self.ksize == 3:
+                    ops.pack_conv3x3(hd.p[cv + ".weight"], True, True, 1.0, hd.wf[cv], hd.wb[cv], khwc=True)
+                else:
+                    ops.pack_linear(hd.p[cv + ".weight"], True, True, 1.0, hd.wf[cv], hd.wb[cv])
 
     def state_dict(self):
         """reference names / torch layouts: heads.{k}.{h}.conv1.0.weight [C,C,3,3], ... conv_out.weight [1,C,1,1]"""
@@ -86,7 +95,7 @@ class Discriminator:
             for n, t in hd.p.items():
                 v = t.detach().clone()
                 if n in ("conv1.0.weight", "conv2.0.weight"):
-                    v = v.permute(0, 3, 1, 2).contiguous()
+                    v = v.permute(0, 3, 1, 2).contiguous() if self.ksize == 3 else v.view(hd.C, hd.C, 1, 1)
                 elif n == "conv_out.weight":
                     v = v.view(1, hd.C, 1, 1)
                 out[f"heads.{k}.{h}.{n}"] = v
@@ -99,7 +108,7 @@ class Discriminator:
             cnt[k] = h + 1
             for n, t in hd.p.items():
                 v = sd[f"heads.{k}.{h}.{n}"].to(self.device)
-                if n in ("conv1.0.weight", "conv2.0.weight"):
+                if n in ("conv1.0.weight", "conv2.0.weight") and self.ksize == 3:
                     v = v.permute(0, 2, 3, 1)
                 t.copy_(v.reshape(t.shape))
         self.repack()
@@ -112,12 +121,12 @@ class Discriminator:
             f, H, W = feats[k]
             B, C = f.shape[0], hd.C
             M = B * H * W
-            geo = dict(Hs=H, Ws=W)
+            geo = dict(Hs=H, Ws=W) if self.ksize == 3 else None
             a1 = torch.empty(M, C, dtype=BF16, device=f.device)
-            ops.gemm([Seg(f, hd.wf["conv1.0"], conv=geo)], M, C, a1, bias=hd.p["conv1.0.bias"], Ho=H, Wo=W)
+            ops.gemm([Seg(f if geo else f.reshape(M, C), hd.wf["conv1.0"], conv=geo)], M, C, a1, bias=hd.p["conv1.0.bias"], Ho=H, Wo=W)
             n1, st1 = ops.groupnorm_fwd(a1.view(B, H * W, C), hd.p["conv1.1.weight"], hd.p["conv1.1.bias"], self.G, 1e-5, capi.ACT_LEAKY)
             a2 = torch.empty(M, C, dtype=BF16, device=f.device)
-            ops.gemm([Seg(n1, hd.wf["conv2.0"], conv=geo)], M, C, a2, bias=hd.p["conv2.0.bias"], Ho=H, Wo=W)
+            ops.gemm([Seg(n1 if geo else n1.reshape(M, C), hd.wf["conv2.0"], conv=geo)], M, C, a2, bias=hd.p["conv2.0.bias"], Ho=H, Wo=W)
             n2, st2 = ops.groupnorm_fwd(a2.view(B, H * W, C), hd.p["conv2.1.weight"], hd.p["conv2.1.bias"], self.G, 1e-5, capi.ACT_LEAKY)
             h2 = ops.add(n2, n1)                                                         # x = conv2(x) + x   (:366)
             logits.append(ops.rowdot_fwd(h2, hd.p["conv_out.weight"], hd.p["conv_out.bias"]))
@@ -132,7 +141,7 @@ class Discriminator:
         for (k, hd), dl, sv in zip(self.heads, d_logits, tape):
             B, H, W, C = sv["B"], sv["H"], sv["W"], hd.C
             M = B * H * W
-            geo = dict(Hs=H, Ws=W)
+            geo = dict(Hs=H, Ws=W) if self.ksize == 3 else None
             wg = dict(Hs=H, Ws=W, Ho=H, Wo=W)
             if param_grads:
                 d_h2 = ops.rowdot_bwd(sv["h2"], hd.p["conv_out.weight"], dl, hd.g["conv_out.weight"], hd.g["conv_out.bias"])
@@ -148,7 +157,7 @@ class Discriminator:
             if param_grads:
                 self._conv_param_grads(hd, "conv2.0", sv["n1"], d_a2.view(M, C), M, wg)
             d_n1 = torch.empty(M, C, dtype=BF16, device=dl.device)                     # dgrad(conv2) + skip branch
-            ops.gemm([Seg(d_a2, hd.wb["conv2.0"], conv=geo)], M, C, d_n1, residual=d_h2.view(M, C), Ho=H, Wo=W)
+            ops.gemm([Seg(d_a2 if geo else d_a2.reshape(M, C), hd.wb["conv2.0"], conv=geo)], M, C, d_n1, residual=d_h2.view(M, C), Ho=H, Wo=W)
             gam1, bet1 = hd.p["conv1.1.weight"], hd.p["conv1.1.bias"]
             a1 = sv["a1"].view(B, H * W, C)
             if param_grads:
@@ -158,7 +167,7 @@ class Discriminator:
                 self._conv_param_grads(hd, "conv1.0", sv["f"], d_a1.view(M, C), M, wg)
             if feature_grads:
                 d_f = torch.empty(M, C, dtype=BF16, device=dl.device)
-                ops.gemm([Seg(d_a1, hd.wb["conv1.0"], conv=geo)], M, C, d_f, residual=None if d_feats[k] is None else d_feats[k].view(M, C),
+                ops.gemm([Seg(d_a1 if geo else d_a1.reshape(M, C), hd.wb["conv1.0"], conv=geo)], M, C, d_f, residual=None if d_feats[k] is None else d_feats[k].view(M, C),
                          Ho=H, Wo=W)                                                   # 4 heads share one feature: sum in the epilogue
                 d_feats[k] = d_f.view(B, H * W, C)
         return d_feats
@@ -167,6 +176,12 @@ class Discriminator:
         """full conv3x3 weight gradient dW[co][tap][ci] = sum_m dy[m][co] * im2col(x)[m][(tap,ci)] as Cout/64 launches of
         the rank-64 wgrad kernel (64 output channels each), bias gradient = pixel sum of dy."""
         C = hd.C
+        if self.ksize == 1:      # dW[co][ci] = sum_m dy[m][co] * x[m][ci]: plain rank-64 wgrad per 64 output channels
+            gW = hd.g[name + ".weight"].view(C, C)
+            for co in range(0, C, 64):
+                ops.lora_wgrad(x.reshape(M, C), dy[:, co:co + 64], gW[co:co + 64], 1.0, M, G=C, g_stride=1, r_stride=C, lds=C)
+            capi.lib().call("pcm_colsum_bf16", ops.ptr(dy), ops.ptr(hd.g[name + ".bias"]), 1, M, C, capi.Lib.stream())
+            return
         gW = hd.g[name + ".weight"].view(C, 9 * C)
         for co in range(0, C, 64):
             ops.lora_wgrad(x, dy[:, co:co + 64], gW[co:co + 64], 1.0, M, conv=wg, g_stride=1, r_stride=9 * C, lds=C)

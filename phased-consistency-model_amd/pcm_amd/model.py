@@ -544,6 +544,11 @@ class UNet:
             feats.append((h, H, Wd))
             if save:
                 tape.append(("feat", None, dict(k=len(feats) - 1)))
+            if features == "down_mid":     # SDXL discriminator taps (discriminator_sdxl.py:311): stop after the mid block
+                if save:
+                    tape.append(("feats_end", None, dict(B=B, H=H, W=Wd)))
+                    return feats, tape
+                return feats
         for i in range(n):
             for j in range(cfg.layers_per_block + 1):
                 s, _, _ = skips.pop()

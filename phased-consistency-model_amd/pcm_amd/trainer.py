@@ -233,42 +233,47 @@ class AdvDistiller(Distiller):
         self.adv_lr_dev = torch.full((1,), float(adv_lr), dtype=torch.float32, device=self.device)
 
     def step_adv(self, global_step, latents, prompt_embeds, uncond_prompt_embeds, noise, index, w, noise_fake, noise_real, adv_u,
-                 lr=None):
+                 lr=None, added_cond=None, uncond_added_cond=None):
         """adv_u [B] in [0,1): adv_timesteps = end_timesteps + floor(adv_u * (T // multiphase))   (:1288-1298)."""
         cfg, T, disc = self.cfg, self.tables, self.disc
         B = latents.shape[0]
+        ac, uac, taps = added_cond, uncond_added_cond, getattr(disc, "taps", True)
+
+        def cat2(a, b_):
+            return None if a is None else {k: torch.cat([a[k], (b_ if b_ is not None else a)[k]]) for k in a}
         is_d = (global_step % 2 == 0)                                                           # :1375 / :1399
         start_t, t_n = self.timesteps_for(index)
         noisy = ops.add_noise(latents, noise, T.acp, start_t)
         if is_d:     # the student forward is not back-propagated on discriminator steps: no tape
-            eps_s, tape = self.student.forward(noisy, start_t, prompt_embeds), None
+            eps_s, tape = self.student.forward(noisy, start_t, prompt_embeds, added_cond=ac), None
         else:
-            eps_s, tape = self.student.forward(noisy, start_t, prompt_embeds, save=True)
+            eps_s, tape = self.student.forward(noisy, start_t, prompt_embeds, save=True, added_cond=ac)
         model_pred, coef, end_t = ops.phase_jump(eps_s, noisy, start_t, index, T.acp, T.acp_prev, T.ddim_timesteps_prev, T.edges, target_mode=False)
         span = cfg.num_train_timesteps // cfg.multiphase
         adv_t = end_t + torch.clamp((adv_u * span).long(), max=span - 1)
         fake_adv, sr = ops.noise_travel(model_pred, noise_fake, T.acp, end_t, adv_t)            # :1303-1305
         if cfg.not_apply_cfg_solver:
-            eps_c = self.teacher.forward(noisy, start_t, prompt_embeds)
+            eps_c = self.teacher.forward(noisy, start_t, prompt_embeds, added_cond=ac)
             eps_u = eps_c
         else:
-            both = self.teacher.forward(torch.cat([noisy, noisy]), torch.cat([start_t, start_t]), torch.cat([prompt_embeds, uncond_prompt_embeds]))
+            both = self.teacher.forward(torch.cat([noisy, noisy]), torch.cat([start_t, start_t]), torch.cat([prompt_embeds, uncond_prompt_embeds]),
+                                        added_cond=cat2(ac, uac))
             eps_c, eps_u = both[:B], both[B:]
         x_prev64, x_prev32 = ops.cfg_ddim_step(eps_c, eps_u, noisy, start_t, index, w, T.acp, T.acp_prev)
-        eps_t = self.student.forward(x_prev32, t_n, prompt_embeds)
+        eps_t = self.student.forward(x_prev32, t_n, prompt_embeds, added_cond=ac)
         target, _, _ = ops.phase_jump(eps_t, x_prev64, t_n, index, T.acp, T.acp_prev, T.ddim_timesteps_prev, T.edges, target_mode=True)
         out = dict(model_pred=model_pred, target=target, end_timesteps=end_t, adv_timesteps=adv_t, fake_adv=fake_adv, is_d=is_d)
         if is_d:
             real_adv, _ = ops.noise_travel(target, noise_real, T.acp, end_t, adv_t)             # :1379-1381
             feats = self.teacher.forward(torch.cat([fake_adv, real_adv]), torch.cat([adv_t, adv_t]),
-                                         torch.cat([prompt_embeds, prompt_embeds]), features=True)
+                                         torch.cat([prompt_embeds, prompt_embeds]), features=taps, added_cond=cat2(ac, None))
             logits, dtape = disc.forward(feats, save=True)
             disc.grads.zero_()
             out["d_loss"] = disc.d_loss_backward(logits, dtape, B)                              # :1383-1391
             out["real_adv"] = real_adv
             self._disc_optimizer_step()
             return out
-        feats, utape = self.teacher.forward(fake_adv, adv_t, prompt_embeds, features=True, save=True)
+        feats, utape = self.teacher.forward(fake_adv, adv_t, prompt_embeds, features=taps, save=True, added_cond=ac)
         logits, dtape = disc.forward(feats, save=True)
         g_loss, d_feats = disc.g_loss_backward(logits, dtape, grad_scale=self.adv_weight)       # :1414-1421
         d_fake = self.teacher.backward(None, utape, d_feats=d_feats, need_input_grad=True)

@@ -4,8 +4,9 @@
 Takes the launch line of code/text_to_image_sdxl/train_pcm_lora_sdxl_adv.py (its 55 flags: the SD1.5 set + --adv_weight, --adv_lr,
 --train_shards_path_or_url, --use_fix_crop_and_size; reference defaults resolution 1024, w_min 3, multiphase 4).  The consistency
 distillation step (same math as SD1.5 with ``added_cond_kwargs``: pooled text embeds + 6 time ids, zero unconditional embeds,
-:1113-1131, :1216-1221, :1300-1460) runs on the generalised UNet; the SDXL discriminator (discriminator_sdxl.py) is NOT implemented
-yet, so this entry point requires ``--adv_weight 0`` and says so loudly otherwise.
+:1113-1131, :1216-1221, :1300-1460) runs on the generalised UNet.  ``--adv_weight`` > 0 (reference default 0.1) adds the SDXL latent
+discriminator (discriminator_sdxl.py: teacher features after the three down blocks and the mid block, one 1x1-conv head each) with the
+even/odd D/G alternation of :1483-1529; ``--adv_weight 0`` is pure phased-consistency distillation.
 
 Data: ``--latents_dir`` shards with ``latents`` [N,4,128,128], ``prompt_embeds`` [N,77,2048], ``pooled_prompt_embeds`` [N,1280]
 (VAE / the two CLIP encoders are upstream of the path), or ``--synthetic_data``."""
@@ -89,11 +90,9 @@ class SdxlSource:
 def main(args):
     from pcm_amd import capi, checkpoint as ck
     from pcm_amd.model import LoraState, UNetWeights
-    from pcm_amd.trainer import Distiller, StepConfig
+    from pcm_amd.discriminator import ADAPTER_DIMS_SDXL, Discriminator
+    from pcm_amd.trainer import AdvDistiller, Distiller, StepConfig
     from pcm_amd.unet_spec import UNetConfig, random_state_dict
-    if args.adv_weight != 0:
-        raise SystemExit("pcm_amd: the SDXL discriminator (discriminator_sdxl.py) is not implemented yet; run with --adv_weight 0 "
-                         "(pure phased-consistency distillation)")
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     local_rank = max(args.local_rank, 0)
     logging.basicConfig(format="%(asctime)s - %(levelname)s - %(name)s - %(message)s", level=logging.INFO if rank == 0 else logging.WARNING)
@@ -115,13 +114,20 @@ def main(args):
                      loss_type=args.loss_type, huber_c=args.huber_c, learning_rate=args.learning_rate, adam_beta1=args.adam_beta1,
                      adam_beta2=args.adam_beta2, adam_weight_decay=args.adam_weight_decay, adam_epsilon=args.adam_epsilon,
                      max_grad_norm=args.max_grad_norm, lora_rank=args.lora_rank, not_apply_cfg_solver=args.not_apply_cfg_solver)
-    D = Distiller(W, lora, cfg, world_size=world)
+    adv = args.adv_weight != 0
+    if adv:
+        disc = Discriminator(ADAPTER_DIMS_SDXL, num_h_per_head=1, device=device, seed=(args.seed or 0) + 1, ksize=1, taps="down_mid")
+        if world > 1:
+            torch.distributed.broadcast(disc.params, src=0); disc.repack()
+        D = AdvDistiller(W, lora, cfg, disc, adv_weight=args.adv_weight, adv_lr=args.adv_lr, world_size=world)
+    else:
+        D = Distiller(W, lora, cfg, world_size=world)
     src = SdxlSource(args, rank, world, device)
     if args.max_train_steps is None:
         args.max_train_steps = args.num_train_epochs * len(src)
     if rank == 0:
         os.makedirs(os.path.join(args.output_dir, args.logging_dir), exist_ok=True)
-    global_step = 0
+    global_step = gen_steps = 0
     if args.resume_from_checkpoint:
         path = os.path.basename(args.resume_from_checkpoint) if args.resume_from_checkpoint != "latest" else ck.latest_checkpoint(args.output_dir)
         if path is not None:
@@ -135,13 +141,27 @@ def main(args):
         noise = torch.randn(latents.shape, generator=src.g, device=device)
         index = torch.randint(0, args.num_ddim_timesteps, (B,), generator=src.g, device=device)
         w = ((args.w_max - args.w_min) * torch.rand((B,), generator=cpu_gen) + args.w_min).to(device)
-        lr = base.lr_at(args, global_step)
+        ac = dict(text_embeds=pooled, time_ids=src.time_ids)
         t0 = time.time()
-        out = D.step(latents, pe, src.uncond, noise, index, w, lr=lr, added_cond=dict(text_embeds=pooled, time_ids=src.time_ids),
-                     uncond_added_cond=uac)
+        if adv:
+            lr = base.lr_at(args, gen_steps)                       # the lr schedule advances on generator steps only (:1527)
+            rn = lambda: torch.randn(latents.shape, generator=src.g, device=device)
+            out = D.step_adv(global_step, latents, pe, src.uncond, noise, index, w, rn(), rn(), torch.rand(B, generator=src.g, device=device),
+                             lr=lr, added_cond=ac, uncond_added_cond=uac)
+            gen_steps += 0 if out["is_d"] else 1
+        else:
+            lr = base.lr_at(args, global_step)
+            out = D.step(latents, pe, src.uncond, noise, index, w, lr=lr, added_cond=ac, uncond_added_cond=uac)
         global_step += 1
         if rank == 0:
-            rec = {"step": global_step, "loss": float(out["loss"].item()), "lr": lr, "grad_norm": D.grad_norm(), "sec": time.time() - t0}
+            if adv:
+                rec = {"step": global_step, "lr": lr, "sec": time.time() - t0}
+                if out["is_d"]:
+                    rec["d_loss"] = float(out["d_loss"].item())
+                else:
+                    rec["loss_cm"], rec["g_loss"] = float(out["loss_cm"].item()), float(out["g_loss"].item())
+            else:
+                rec = {"step": global_step, "loss": float(out["loss"].item()), "lr": lr, "grad_norm": D.grad_norm(), "sec": time.time() - t0}
             logf.write(json.dumps(rec) + "\n"); logf.flush()
             if global_step % 10 == 0 or global_step <= 2:
                 logger.info("%s", rec)

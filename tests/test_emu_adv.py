@@ -16,7 +16,19 @@ def _use_emu():
 
 @pytest.mark.slow
 @pytest.mark.parametrize("global_step", [0, 1])
+def test_sdxl_adv_step_vs_oracle(global_step):
+    """SDXL adversarial step (discriminator_sdxl.py: taps after the down blocks + mid only, one 1x1-conv head per tap; added
+    conditioning through every UNet call) on a narrow SDXL-topology config."""
+    _run_adv(global_step, sdxl=True)
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("global_step", [0, 1])
 def test_adv_step_vs_oracle(global_step):
+    _run_adv(global_step, sdxl=False)
+
+
+def _run_adv(global_step, sdxl):
     from oracle import pcm_step as OS
     from oracle import unet_sd15 as O
     from pcm_amd.discriminator import Discriminator
@@ -24,12 +36,19 @@ def test_adv_step_vs_oracle(global_step):
     from pcm_amd.trainer import AdvDistiller, StepConfig
     from pcm_amd.unet_spec import UNetConfig
     kw = dict(block_out_channels=(64, 128), layers_per_block=1, cross_attention_dim=64, heads=2, norm_num_groups=32)   # 2-level UNet: 5 tapped features
+    if sdxl:
+        kw = dict(block_out_channels=(64, 128), layers_per_block=1, cross_attention_dim=64, heads=(1, 2), norm_num_groups=32, down_attn=(False, True),
+                  transformer_depth=(1, 2), use_linear_projection=True, addition_time_embed_dim=32, projection_class_embeddings_input_dim=64 + 6 * 32)
     oc, pc = O.UNetConfig(**kw), UNetConfig(**kw)
     sd = O.init_state_dict(oc, 0)
     W = UNetWeights(pc, sd, "cpu")
     lora = LoraState(pc, 64, 8.0, "cpu", seed=1, b_std=0.05)
     dims = (64, 128, 128, 128, 64)    # feature widths of this UNet (down x2, mid, up x2)
     disc = Discriminator(dims, num_h_per_head=1, device="cpu", seed=2)
+    taps = True
+    if sdxl:
+        taps = "down_mid"
+        disc = Discriminator((64, 128, 128), num_h_per_head=1, device="cpu", seed=2, ksize=1, taps=taps)
     ocfg = OS.StepConfig(multiphase=2, loss_type="huber", w_min=4.0, w_max=5.0)
     B = 2
     inp = OS.draw_inputs(B, ocfg, seed=5, latent_hw=8, ctx_len=7, ctx_dim=64)
@@ -37,15 +56,20 @@ def test_adv_step_vs_oracle(global_step):
     inp["noise_fake"] = torch.randn(B, 4, 8, 8, generator=g)
     inp["noise_real"] = torch.randn(B, 4, 8, 8, generator=g)
     inp["adv_u"] = torch.rand(B, generator=g)
+    ac = uac = None
+    if sdxl:
+        tids = torch.tensor([[1024, 1024, 0, 0, 1024, 1024]] * B)
+        ac = inp["added_cond"] = dict(text_embeds=torch.randn(B, 64, generator=g), time_ids=tids)
+        uac = inp["uncond_added_cond"] = dict(text_embeds=torch.zeros(B, 64), time_ids=tids)
     olora = {p: (lora.A_peft(m).clone(), m.B.clone()) for p, m in lora.modules.items()}
     dsd = disc.state_dict()
-    ref = OS.distill_step_adv(oc, sd, olora, {k.replace("heads.", "heads."): v for k, v in dsd.items()}, inp, ocfg, global_step, adv_weight=0.1)
+    ref = OS.distill_step_adv(oc, sd, olora, {k.replace("heads.", "heads."): v for k, v in dsd.items()}, inp, ocfg, global_step, adv_weight=0.1, taps=taps)
     # the oracle's discriminator_forward expects nh heads per feature: match num_h_per_head=1
     cfg = StepConfig(multiphase=2, loss_type="huber", w_min=4.0, w_max=5.0, learning_rate=0.0)
     D = AdvDistiller(W, lora, cfg, disc, adv_weight=0.1, adv_lr=0.0)
     p_lora, p_disc = lora.params.clone(), disc.params.clone()
     out = D.step_adv(global_step, inp["latents"], inp["prompt_embeds"], inp["uncond_prompt_embeds"], inp["noise"], inp["index"], inp["w"],
-                     inp["noise_fake"], inp["noise_real"], inp["adv_u"])
+                     inp["noise_fake"], inp["noise_real"], inp["adv_u"], added_cond=ac, uncond_added_cond=uac)
     assert torch.equal(out["adv_timesteps"], ref["adv_timesteps"])
     rel = lambda a, b: float((a.double() - b.double()).norm() / (b.double().norm() + 1e-6 * b.numel() ** 0.5))
     assert rel(out["fake_adv"], ref["fake_adv"]) < 3e-2
@@ -59,7 +83,7 @@ def test_adv_step_vs_oracle(global_step):
             for n, t in hd.g.items():
                 v = t
                 if n in ("conv1.0.weight", "conv2.0.weight"):
-                    v = v.permute(0, 3, 1, 2)
+                    v = v.permute(0, 3, 1, 2) if disc.ksize == 3 else v.view(hd.C, hd.C, 1, 1)
                 elif n == "conv_out.weight":
                     v = v.view(1, hd.C, 1, 1)
                 gstate[f"heads.{k}.{h}.{n}"] = v
