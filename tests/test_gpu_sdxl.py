@@ -58,3 +58,60 @@ def test_sdxl_topology_step_vs_oracle():
     ratio = float(mine.norm() / refg.norm())
     print("sdxl-topology step: loss %.5f / %.5f, LoRA grad cos %.4f norm ratio %.3f" % (float(out["loss"]), float(ref["loss"]), cos, ratio))
     assert cos > 0.93 and 0.85 < ratio < 1.15
+
+
+@pytest.mark.parametrize("global_step", [0, 1])
+def test_sdxl_adv_step_vs_oracle(global_step):
+    """SDXL adversarial D / G step (1x1-conv heads on the down + mid taps, added conditioning) on the GPU vs the oracle."""
+    from oracle import pcm_step as OS
+    from oracle import unet_sd15 as O
+    from pcm_amd import capi
+    from pcm_amd.discriminator import Discriminator
+    from pcm_amd.model import LoraState, UNetWeights
+    from pcm_amd.trainer import AdvDistiller, StepConfig
+    capi.set_lib(None)
+    capi.lib()
+    oc, pc = _cfgs()
+    sd = O.init_state_dict(oc, 0)
+    W = UNetWeights(pc, sd, "cuda")
+    lora = LoraState(pc, 64, 8.0, "cuda", seed=1, b_std=0.05)
+    disc = Discriminator((64, 128, 128, 128), num_h_per_head=1, device="cuda", seed=2, ksize=1, taps="down_mid")
+    olora = {p: (lora.A_peft(m).detach().cpu().clone(), m.B.detach().cpu().clone()) for p, m in lora.modules.items()}
+    dsd = {k: v.cpu() for k, v in disc.state_dict().items()}
+    ocfg = OS.StepConfig(multiphase=4, loss_type="huber", w_min=6.0, w_max=7.0, num_ddim_timesteps=40)
+    B = 2
+    inp = OS.draw_inputs(B, ocfg, seed=7, latent_hw=32, ctx_len=77, ctx_dim=64)
+    g = torch.Generator().manual_seed(3)
+    tids = torch.tensor([[1024, 1024, 0, 0, 1024, 1024]] * B)
+    inp["added_cond"] = dict(text_embeds=torch.randn(B, 64, generator=g), time_ids=tids)
+    inp["uncond_added_cond"] = dict(text_embeds=torch.zeros(B, 64), time_ids=tids)
+    inp["noise_fake"], inp["noise_real"] = torch.randn(B, 4, 32, 32, generator=g), torch.randn(B, 4, 32, 32, generator=g)
+    inp["adv_u"] = torch.rand(B, generator=g)
+    ref = OS.distill_step_adv(oc, sd, olora, dsd, inp, ocfg, global_step, adv_weight=0.1, taps="down_mid")
+    cfg = StepConfig(multiphase=4, loss_type="huber", w_min=6.0, w_max=7.0, num_ddim_timesteps=40, learning_rate=0.0)
+    D = AdvDistiller(W, lora, cfg, disc, adv_weight=0.1, adv_lr=0.0)
+    cu = lambda v: {k: x.cuda() for k, x in v.items()} if isinstance(v, dict) else v.cuda()
+    out = D.step_adv(global_step, *(cu(inp[k]) for k in ("latents", "prompt_embeds", "uncond_prompt_embeds", "noise", "index", "w", "noise_fake",
+                                                           "noise_real", "adv_u")), added_cond=cu(inp["added_cond"]), uncond_added_cond=cu(inp["uncond_added_cond"]))
+    torch.cuda.synchronize()
+    assert torch.equal(out["adv_timesteps"].cpu(), ref["adv_timesteps"])
+    if global_step % 2 == 0:
+        dl, rdl = out["d_loss"].item(), float(ref["d_loss"])
+        mine, refg, cnt = [], [], {}
+        for k, hd in disc.heads:
+            h = cnt.get(k, 0); cnt[k] = h + 1
+            for n, t in hd.g.items():
+                mine.append(t.reshape(-1).cpu()); refg.append(ref["head_grads"][f"heads.{k}.{h}.{n}"].reshape(-1))
+        mine, refg = torch.cat(mine).double(), torch.cat(refg).double()
+        cos = float((mine * refg).sum() / (mine.norm() * refg.norm()))
+        print("sdxl D step: d_loss %.5f / %.5f, head-grad cos %.4f" % (dl, rdl, cos))
+        assert abs(dl - rdl) < 3e-2 * abs(rdl) and cos > 0.95
+    else:
+        mine = torch.cat([t.reshape(-1).cpu() for m in lora.modules.values() for t in (lora.gA_peft(m), m.gB)]).double()
+        refg = torch.cat([g_.reshape(-1) for g_ in ref["lora_grads"]]).double()
+        cos = float((mine * refg).sum() / (mine.norm() * refg.norm()))
+        print("sdxl G step: loss_cm %.5f / %.5f, g_loss %.5f / %.5f, lora-grad cos %.4f" % (out["loss_cm"].item(), float(ref["loss_cm"]),
+              out["g_loss"].item(), float(ref["g_loss"]), cos))
+        assert abs(out["loss_cm"].item() - float(ref["loss_cm"])) < 5e-2 * abs(float(ref["loss_cm"]))
+        assert abs(out["g_loss"].item() - float(ref["g_loss"])) < 3e-2 * abs(float(ref["g_loss"]))
+        assert cos > 0.93
