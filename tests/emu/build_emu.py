@@ -24,7 +24,7 @@ def build(force=False):
     for s in srcs:
         o = os.path.join(HERE, "build", os.path.basename(s) + ".o")
         objs.append(o)
-        cmd = [CLANG, "-x", "c++", "-DPCM_HOST_EMU", "-I", HERE, "-O1", "-g", "-std=c++17", "-fPIC",
+        cmd = [CLANG, "-x", "c++", "-DPCM_HOST_EMU", "-I", HERE, "-O2", "-std=c++17", "-fPIC",
                "-Wno-unused-value", "-Wno-deprecated-declarations", "-Wno-psabi", "-c", s, "-o", o]
         procs.append((s, subprocess.Popen(cmd)))
     for s, p in procs:

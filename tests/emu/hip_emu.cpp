@@ -4,7 +4,33 @@
 namespace pcm_emu {
 std::vector<Fiber> g_fibers;
 std::vector<WaveScratch> g_waves;
-ucontext_t g_sched;
+void* g_sched_sp = nullptr;
+}  // namespace pcm_emu
+// Minimal SysV x86-64 context switch (callee-saved registers + stack pointer).  swapcontext() also saves / restores the signal mask
+// with a system call per switch; a wave-collective does one switch per lane, so that syscall dominated the emulator's run time.
+asm(R"(
+.text
+.globl pcm_ctx_switch
+.type pcm_ctx_switch,@function
+pcm_ctx_switch:
+  pushq %rbp
+  pushq %rbx
+  pushq %r12
+  pushq %r13
+  pushq %r14
+  pushq %r15
+  movq %rsp, (%rdi)
+  movq %rsi, %rsp
+  popq %r15
+  popq %r14
+  popq %r13
+  popq %r12
+  popq %rbx
+  popq %rbp
+  ret
+.size pcm_ctx_switch,.-pcm_ctx_switch
+)");
+namespace pcm_emu {
 Fiber* g_cur = nullptr;
 int g_block_arrived = 0, g_block_alive = 0;
 dim3 g_threadIdx, g_blockIdx, g_blockDim, g_gridDim;
@@ -13,7 +39,7 @@ char* g_dyn_smem = nullptr;
 bool g_lazy_dma = false;
 static const size_t STACK = 256 * 1024;
 
-void yield_to_sched() { swapcontext(&g_cur->ctx, &g_sched); }
+void yield_to_sched() { pcm_ctx_switch(&g_cur->sp, g_sched_sp); }
 
 void wave_sync() {
   Fiber* f = g_cur;
@@ -60,7 +86,8 @@ static void trampoline() {
     g_block_arrived = 0;
     for (auto& o : g_fibers) if (o.st == WAIT_BLOCK) o.st = RUNNABLE;
   }
-  swapcontext(&f->ctx, &g_sched);
+  pcm_ctx_switch(&f->sp, g_sched_sp);
+  __builtin_trap();   // a finished fiber is never resumed
 }
 
 void launch(dim3 grid, dim3 block, size_t smem, std::function<void()> body) {
@@ -94,11 +121,14 @@ void launch(dim3 grid, dim3 block, size_t smem, std::function<void()> body) {
           f.pend.clear();
           f.lin = t; f.wave = t / 64; f.lane = t % 64;
           f.tid = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
-          getcontext(&f.ctx);
-          f.ctx.uc_stack.ss_sp = f.stack;
-          f.ctx.uc_stack.ss_size = STACK;
-          f.ctx.uc_link = &g_sched;
-          makecontext(&f.ctx, trampoline, 0);
+          // fresh stack: [top-8] dummy return address, [top-16] entry point popped by the switch's `ret` (so the entry sees
+          // rsp = 16n + 8 like after a call), six zeroed callee-saved slots below
+          uintptr_t top = ((uintptr_t)f.stack + STACK) & ~(uintptr_t)15;
+          void** sp = (void**)top;
+          *--sp = nullptr;
+          *--sp = (void*)&trampoline;
+          for (int r = 0; r < 6; r++) *--sp = nullptr;
+          f.sp = (void*)sp;
         }
         int done = 0;
         while (done < nthreads) {
@@ -109,7 +139,7 @@ void launch(dim3 grid, dim3 block, size_t smem, std::function<void()> body) {
             progressed = true;
             g_cur = &f;
             g_threadIdx = f.tid;
-            swapcontext(&g_sched, &f.ctx);
+            pcm_ctx_switch(&g_sched_sp, f.sp);
             if (f.st == DONE) done++;
           }
           if (!progressed) {

@@ -4,11 +4,10 @@
 // The shipped library is built by hipcc for gfx950 and never sees this header
 // (csrc/pcm_common.h includes it only under -DPCM_HOST_EMU, which only tests/emu/build_emu.py sets).
 //
-// Model: one block at a time; every thread of the block is a ucontext fiber; __syncthreads and
+// Model: one block at a time; every thread of the block is a fiber (own stack, hand-rolled x86-64 context switch); __syncthreads and
 // wave-collectives (shuffles, MFMA, global_load_lds) are cooperative rendezvous points.
 // MFMA fragment layouts follow /opt/skills/guides/cdna_hip_programming.md §3.
 #pragma once
-#include <ucontext.h>
 
 #include <cmath>
 #include <cstdint>
@@ -52,7 +51,7 @@ namespace pcm_emu {
 enum State { RUNNABLE, WAIT_WAVE, WAIT_BLOCK, DONE };
 struct DmaOp { void* dst; const void* src; int size; };   // src == nullptr: zero fill (out-of-range buffer load)
 struct Fiber {
-  ucontext_t ctx;
+  void* sp;        // saved stack pointer while the fiber is switched out
   char* stack;
   State st;
   dim3 tid;
@@ -70,7 +69,8 @@ struct WaveScratch {
 
 extern std::vector<Fiber> g_fibers;
 extern std::vector<WaveScratch> g_waves;
-extern ucontext_t g_sched;
+extern void* g_sched_sp;
+extern "C" void pcm_ctx_switch(void** save_sp, void* to_sp);
 extern Fiber* g_cur;
 extern int g_block_arrived, g_block_alive;
 extern dim3 g_threadIdx, g_blockIdx, g_blockDim, g_gridDim;
