@@ -119,6 +119,12 @@ int pcm_groupnorm_apply(const void* x, const double* stats, const float* gamma, 
 int pcm_groupnorm_bwd_stats(const void* x, const void* dy, const double* stats, const float* gamma,
                             const float* beta, double* bstats, int B, int HW, int C, int G,
                             float eps, int act, void* stream);
+
+/* Same two reductions, but ACCUMULATING into a buffer the caller has already zeroed (e.g. one slice of an arena cleared by a single
+ * memset per network pass: the SD1.5 step runs 180 GroupNorm statistics passes). */
+int pcm_groupnorm_stats_acc(const void* x, double* stats, int B, int HW, int C, int G, void* stream);
+int pcm_groupnorm_bwd_stats_acc(const void* x, const void* dy, const double* stats, const float* gamma, const float* beta, double* bstats,
+                                int B, int HW, int C, int G, float eps, int act, void* stream);
 int pcm_groupnorm_bwd_apply(const void* x, const void* dy, const double* stats, const double* bstats,
                             const float* gamma, const float* beta, void* dx, int B, int HW, int C,
                             int G, float eps, int act, void* stream);

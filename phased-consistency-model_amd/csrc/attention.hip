@@ -202,21 +202,32 @@ template <int D, bool PK> using TStage = typename TStageSel<D, PK>::type;
 // x [B][L][ld] (head h at columns h*D..) -> packed transposed tiles xt[(b*H+h)][tile][D][64 slots]; slot 8*chunk+e of a tile is row
 // 16*(chunk>>1) + 8*(e>>2) + 4*(chunk&1) + (e&3) (the contraction-slot order of the PV / dS MFMAs); rows >= L are zero.
 __global__ __launch_bounds__(256) void attn_pack_t_kernel(const bf16_t* x, bf16_t* xt, int H, int L, int D, int ld) {
-  const int tile = blockIdx.x, h = blockIdx.y, b = blockIdx.z, nt = gridDim.x;
-  const bf16_t* xb = x + (size_t)b * L * ld + h * D;
-  uint4* out = (uint4*)(xt + ((size_t)(b * H + h) * nt + tile) * D * 64);
-  for (int u = threadIdx.x; u < D * 8; u += blockDim.x) {
-    const int drow = u % D, chunk = u / D;     // lanes along d: the 2-byte gathers of a wave touch contiguous runs
+  // one block = one 64-row tile of ALL heads: coalesced 16-B row loads into LDS, transposed 2-byte reads out of LDS, 16-B tile-image stores
+  PCM_DYN_SMEM(sm);
+  const int tile = blockIdx.x, b = blockIdx.y, nt = gridDim.x, HD = H * D, CV = HD / 8, RS = HD + 8;   // RS: padded LDS row (elements)
+  bf16_t* t = (bf16_t*)sm;
+  const bf16_t* xb = x + (size_t)b * L * ld;
+  for (int u = threadIdx.x; u < 64 * CV; u += blockDim.x) {
+    const int r = u / CV, c = u - r * CV, row = 64 * tile + r;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (row < L) v = *(const uint4*)(xb + (size_t)row * ld + 8 * c);
+    *(uint4*)(t + r * RS + 8 * c) = v;
+  }
+  __syncthreads();
+  for (int u = threadIdx.x; u < HD * 8; u += blockDim.x) {
+    const int col = u % HD, chunk = u / HD;                 // lanes along the columns: conflict-free 2-byte LDS reads
+    const int h = col / D, drow = col - h * D;
     unsigned w[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
     for (int e = 0; e < 8; e++) {
-      const int row = 64 * tile + 16 * (chunk >> 1) + 8 * (e >> 2) + 4 * (chunk & 1) + (e & 3);
-      const unsigned v = row < L ? (unsigned)xb[(size_t)row * ld + drow] : 0u;
-      w[e >> 1] |= v << (16 * (e & 1));
+      const int r = 16 * (chunk >> 1) + 8 * (e >> 2) + 4 * (chunk & 1) + (e & 3);
+      w[e >> 1] |= (unsigned)t[r * RS + col] << (16 * (e & 1));
     }
+    uint4* out = (uint4*)(xt + ((size_t)(b * H + h) * nt + tile) * D * 64);
     out[drow * 8 + chunk] = make_uint4(w[0], w[1], w[2], w[3]);
   }
 }
+
 
 // fragment straight from global: row-major [row][16s + 8hi ..]; zero outside [0, D) / invalid rows
 template <int D>
@@ -641,7 +652,11 @@ extern "C" size_t pcm_attn_workspace_bytes(int B, int H, int Lq, int Lk, int d, 
   return backward ? attn_packed_bytes(B, H, Lk, d) + 2 * attn_packed_bytes(B, H, Lq, d) : attn_packed_bytes(B, H, Lk, d);
 }
 static void attn_pack_launch(const void* x, void* xt, int B, int H, int L, int d, int ld, void* stream) {
-  PCM_LAUNCH(attn_pack_t_kernel, dim3((L + 63) / 64, H, B), dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)xt, H, L, d, ld);
+#ifndef PCM_HOST_EMU
+  static bool lds_ok = false;      // tiles of 640-channel tensors need 83 KB of dynamic LDS
+  if (!lds_ok) { hipFuncSetAttribute((const void*)attn_pack_t_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); lds_ok = true; }
+#endif
+  PCM_LAUNCH(attn_pack_t_kernel, dim3((L + 63) / 64, B), dim3(256), 64 * (size_t)(H * d + 8) * 2, stream, (const bf16_t*)x, (bf16_t*)xt, H, L, d, ld);
 }
 
 extern "C" int pcm_attn_fwd_ws(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int Lq, int Lk,

@@ -205,7 +205,7 @@ static int gn_check(const char* what, int B, int HW, int C, int G) {
 }
 
 template <int MODE>
-static int gn_stats_launch(const char* what, GNArgs a, int B, void* stream) {
+static int gn_stats_launch(const char* what, GNArgs a, int B, void* stream, bool zero = true) {
   int CV = a.C / 8;
   int split = 1;
   // channel split so a block's slice has <= 256 vectors and whole groups
@@ -222,7 +222,7 @@ static int gn_stats_launch(const char* what, GNArgs a, int B, void* stream) {
   int maxchunks = (a.HW + k - 1) / k; if (chunks > maxchunks) chunks = maxchunks; if (chunks < 1) chunks = 1;
   a.ppb = (a.HW + chunks - 1) / chunks;
   chunks = (a.HW + a.ppb - 1) / a.ppb;
-  hipMemsetAsync(a.out, 0, sizeof(double) * 2 * B * a.G, (hipStream_t)stream);
+  if (zero) hipMemsetAsync(a.out, 0, sizeof(double) * 2 * B * a.G, (hipStream_t)stream);
   PCM_LAUNCH((gn_stats_kernel<MODE>), dim3(chunks, B, split), dim3(threads), 0, stream, a);
   return pcm_post_launch(what);
 }
@@ -245,6 +245,27 @@ extern "C" int pcm_groupnorm_bwd_stats(const void* x, const void* dy, const doub
   a.x = (const bf16_t*)x; a.dy = (const bf16_t*)dy; a.stats = stats; a.gamma = gamma; a.beta = beta;
   a.out = bstats; a.HW = HW; a.C = C; a.G = G; a.cpg = C / G; a.eps = eps; a.act = act;
   return gn_stats_launch<1>("pcm_groupnorm_bwd_stats", a, B, stream);
+}
+
+// _acc variants: the caller hands in an ALREADY ZEROED statistics buffer (one memset for a whole arena of layers instead of one per call)
+extern "C" int pcm_groupnorm_stats_acc(const void* x, double* stats, int B, int HW, int C, int G, void* stream) {
+  if (int rc = gn_check("pcm_groupnorm_stats", B, HW, C, G)) return rc;
+  PCM_CHECK(x && stats && PCM_ALIGNED16(x), PCM_EALIGN, "pcm_groupnorm_stats: x must be 16-byte aligned");
+  GNArgs a; memset(&a, 0, sizeof(a));
+  a.x = (const bf16_t*)x; a.out = stats; a.HW = HW; a.C = C; a.G = G; a.cpg = C / G;
+  return gn_stats_launch<0>("pcm_groupnorm_stats_acc", a, B, stream, false);
+}
+
+extern "C" int pcm_groupnorm_bwd_stats_acc(const void* x, const void* dy, const double* stats, const float* gamma,
+                                       const float* beta, double* bstats, int B, int HW, int C, int G,
+                                       float eps, int act, void* stream) {
+  if (int rc = gn_check("pcm_groupnorm_bwd_stats", B, HW, C, G)) return rc;
+  PCM_CHECK(x && dy && stats && gamma && beta && bstats && PCM_ALIGNED16(x) && PCM_ALIGNED16(dy), PCM_EALIGN,
+            "pcm_groupnorm_bwd_stats: null/unaligned argument");
+  GNArgs a; memset(&a, 0, sizeof(a));
+  a.x = (const bf16_t*)x; a.dy = (const bf16_t*)dy; a.stats = stats; a.gamma = gamma; a.beta = beta;
+  a.out = bstats; a.HW = HW; a.C = C; a.G = G; a.cpg = C / G; a.eps = eps; a.act = act;
+  return gn_stats_launch<1>("pcm_groupnorm_bwd_stats_acc", a, B, stream, false);
 }
 
 template <int MODE>

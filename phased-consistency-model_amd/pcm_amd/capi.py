@@ -51,8 +51,10 @@ _PROTOS = {
     "pcm_gemm_bf16": [C.POINTER(GemmSeg), i32, C.POINTER(GemmEpi), vp],
     "pcm_lora_wgrad_bf16": [C.POINTER(WgradArgs), vp],
     "pcm_groupnorm_stats": [vp, vp, i32, i32, i32, i32, vp],
+    "pcm_groupnorm_stats_acc": [vp, vp, i32, i32, i32, i32, vp],
     "pcm_groupnorm_apply": [vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp],
     "pcm_groupnorm_bwd_stats": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp],
+    "pcm_groupnorm_bwd_stats_acc": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp],
     "pcm_groupnorm_bwd_apply": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp],
     "pcm_groupnorm_param_grad": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp],
     "pcm_rowdot_fwd": [vp, vp, vp, vp, i64, i32, vp],

@@ -323,18 +323,19 @@ class UNet:
 
     def __init__(self, weights: UNetWeights, lora: LoraState = None):
         self.W, self.lora, self.cfg = weights, lora, weights.cfg
+        self._arena = None      # per-pass arena of pre-zeroed GroupNorm statistics (ops.StatArena)
 
     # ---- norm helpers ----
     def _gn(self, path, x, act, eps, save):
         g, b = self.W.norms[path]
-        y, stats = ops.groupnorm_fwd(x, g, b, self.cfg.norm_num_groups, eps, act)
+        y, stats = ops.groupnorm_fwd(x, g, b, self.cfg.norm_num_groups, eps, act, arena=self._arena)
         if save is not None:
             save["gn_x"], save["gn_stats"] = x, stats
         return y
 
     def _gn_bwd(self, path, dy, act, eps, saved):
         g, b = self.W.norms[path]
-        return ops.groupnorm_bwd(saved["gn_x"], dy, saved["gn_stats"], g, b, self.cfg.norm_num_groups, eps, act)
+        return ops.groupnorm_bwd(saved["gn_x"], dy, saved["gn_stats"], g, b, self.cfg.norm_num_groups, eps, act, arena=self._arena)
 
     # ---- resnet ----
     def resnet_fwd(self, p, x, emb_act, B, H, Wd, tape):
@@ -496,6 +497,7 @@ class UNet:
         cfg, W, lora = self.cfg, self.W, self.lora
         B, _, H, Wd = sample.shape
         boc, n = cfg.block_out_channels, len(cfg.block_out_channels)
+        self._arena = ops.StatArena(sample.device, slots=sum(1 for k in W.norms if "transformer_blocks" not in k) + 2, per_slot=B * cfg.norm_num_groups * 2)
         tape = [] if save else None
         text = encoder_hidden_states if encoder_hidden_states.dtype == BF16 else ops.cast_bf16(encoder_hidden_states.contiguous())
         t_emb = ops.timestep_embedding(timesteps, boc[0])
@@ -609,6 +611,9 @@ class UNet:
         be None) instead of d_eps.  ``need_input_grad`` also back-propagates through the first resnet and conv_in and
         returns d sample [B,4,H,W] fp32 (the generator step's path through the frozen teacher, sd15_adv.py:1414-1424)."""
         W, lora, cfg = self.W, self.lora, self.cfg
+        B0 = tape[-1][2]["B"]
+        self._arena = ops.StatArena(d_eps.device if d_eps is not None else self.W.conv_in[0].device,
+                                    slots=sum(1 for k in W.norms if "transformer_blocks" not in k) + 2, per_slot=B0 * cfg.norm_num_groups * 2)
         kind, _, sv = tape[-1]
         if kind == "out":
             d_hn = ops.conv_out_bwd(d_eps.contiguous(), W.conv_out[0], cfg.block_out_channels[0])
