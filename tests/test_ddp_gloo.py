@@ -64,3 +64,64 @@ def test_two_rank_allreduce_and_step(tmp_path):
     clip_grad_norm_(gm, 1.0)
     adamw_step([ref_p], gm, {}, 1, OC(lr=1e-3, adam_weight_decay=1e-2))
     assert torch.allclose(p0, ref_p, rtol=1e-5, atol=1e-7)
+
+
+def _step_worker(rank, world, port, outdir):
+    """Full distillation step (fused online+target forward, LoRA backward, all-reduce, clip + AdamW) of a tiny UNet on this rank's shard."""
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "phased-consistency-model_amd"), os.path.join(ROOT, "tests")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    if world > 1:
+        torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    from emu_lib import emu_lib
+    from oracle import pcm_step as OS
+    from oracle import unet_sd15 as O
+    from pcm_amd import capi
+    from pcm_amd.model import LoraState, UNetWeights
+    from pcm_amd.trainer import Distiller, StepConfig
+    from pcm_amd.unet_spec import UNetConfig
+    capi.set_lib(emu_lib())
+    kw = dict(block_out_channels=(64, 64), layers_per_block=1, cross_attention_dim=64, heads=2)
+    sd = O.init_state_dict(O.UNetConfig(**kw), 0)
+    W = UNetWeights(UNetConfig(**kw), sd, "cpu")
+    lora = LoraState(UNetConfig(**kw), 64, 8.0, "cpu", seed=5, b_std=0.02)
+    cfg = StepConfig(multiphase=2, learning_rate=1e-3, w_min=4.0, w_max=5.0)
+    D = Distiller(W, lora, cfg, world_size=world)
+    inp = OS.draw_inputs(4, OS.StepConfig(multiphase=2), seed=11, latent_hw=8, ctx_len=7, ctx_dim=64)       # the GLOBAL batch of 4
+    n = 4 // world
+    sl = slice(rank * n, (rank + 1) * n)                                                                      # this rank's shard
+    out = D.step(*(inp[k][sl].contiguous() for k in ("latents", "prompt_embeds", "uncond_prompt_embeds", "noise", "index", "w")))
+    torch.save((lora.params.clone(), float(out["loss"])), os.path.join(outdir, f"w{world}r{rank}.pt"))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+def test_two_rank_full_step_matches_single_process_on_the_global_batch(tmp_path):
+    """Data-parallel semantics end to end: 2 ranks x 2 samples (gradient SUM all-reduce, 1/world folded into AdamW) must land on the same
+    LoRA parameters as 1 process x 4 samples -- the per-sample mean of the loss makes the two gradients equal up to bf16 noise."""
+    ctx = mp.get_context("spawn")
+    ps = [ctx.Process(target=_step_worker, args=(r, 2, 29741, str(tmp_path))) for r in range(2)]
+    ps.append(ctx.Process(target=_step_worker, args=(0, 1, 29742, str(tmp_path))))
+    for p in ps:
+        p.start()
+    for p in ps:
+        p.join(600)
+        assert p.exitcode == 0
+    (p0, l0), (p1, l1) = (torch.load(os.path.join(str(tmp_path), f"w2r{r}.pt")) for r in range(2))
+    ps1, l_single = torch.load(os.path.join(str(tmp_path), "w1r0.pt"))
+    assert torch.equal(p0, p1), "ranks diverged"
+    assert abs((l0 + l1) / 2 - l_single) < 2e-2 * abs(l_single)          # mean of shard losses = loss of the global batch
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "phased-consistency-model_amd"), os.path.join(ROOT, "tests")]
+    from emu_lib import emu_lib
+    from pcm_amd import capi
+    from pcm_amd.model import LoraState
+    from pcm_amd.unet_spec import UNetConfig
+    capi.set_lib(emu_lib())
+    try:
+        init = LoraState(UNetConfig(block_out_channels=(64, 64), layers_per_block=1, cross_attention_dim=64, heads=2), 64, 8.0, "cpu", seed=5, b_std=0.02).params.clone()
+    finally:
+        capi.set_lib(None)
+    u2, u1 = (p0 - init).double(), (ps1 - init).double()
+    cos = float((u2 * u1).sum() / (u2.norm() * u1.norm()))
+    print("update cosine 2-rank vs single %.4f, norm ratio %.3f" % (cos, float(u2.norm() / u1.norm())))
+    assert cos > 0.9 and 0.8 < float(u2.norm() / u1.norm()) < 1.25
