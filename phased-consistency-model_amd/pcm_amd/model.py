@@ -12,6 +12,7 @@ Mirrors diffusers' ``UNet2DConditionModel.forward(sample, timestep, encoder_hidd
 (train_pcm_lora_sd15.py:866-885).
 """
 import math
+import os
 from collections import OrderedDict
 
 import torch
@@ -86,12 +87,14 @@ class UNetWeights:
                     self.layers[path].pack_geglu()
         # self-attention q/k/v of the frozen (LoRA-free, no-grad) pass as ONE projection: rows [Wq; Wk; Wv], the
         # activation is read once and attention reads q/k/v in place with row stride 3C
-        self.qkv = {}
+        self.qkv, self.qkv_bwd = {}, {}
         for path in [p_ for p_ in self.layers if p_.endswith("attn1.to_q")]:
             base = path[:-4]
             lq, lk, lv = (self.layers[base + n] for n in ("to_q", "to_k", "to_v"))
             if lq.bias is None and lk.bias is None and lv.bias is None and lq.K == lk.K == lv.K:
                 self.qkv[base] = torch.cat([lq.w_fwd.view(lq.N, lq.K), lk.w_fwd.view(lk.N, lk.K), lv.w_fwd.view(lv.N, lv.K)]).contiguous()
+                if need_bwd and lq.N == lk.N == lv.N:   # dgrad operand of the fused projection: [K][3N] = [Wq^T | Wk^T | Wv^T]
+                    self.qkv_bwd[base] = torch.cat([lq.w_bwd.view(lq.K, lq.N), lk.w_bwd.view(lk.K, lk.N), lv.w_bwd.view(lv.K, lv.N)], dim=1).contiguous()
         self.conv_in = (state_dict["conv_in.weight"].to(**f32).contiguous(), state_dict["conv_in.bias"].to(**f32).contiguous())
         self.conv_out = (state_dict["conv_out.weight"].to(**f32).contiguous(), state_dict["conv_out.bias"].to(**f32).contiguous())
 
@@ -101,6 +104,15 @@ class UNetWeights:
 # ----------------------------------------------------------------------------------------------
 class LoraModule:
     __slots__ = ("path", "kind", "N", "K", "C", "r", "A", "B", "gA", "gB", "A_fwd", "A_bwd", "Bs_fwd", "Bs_bwd")
+
+
+# debug hook: PCM_LORA_QKV=0 runs the self-attention q/k/v LoRA projections as three separate layers (A/B measurement)
+FUSE_LORA_QKV = os.environ.get("PCM_LORA_QKV", "1") != "0"
+
+
+class LoraQKV:
+    """concatenated operands of one self-attention's to_q/to_k/to_v LoRA factors (see LoraState.__init__)."""
+    __slots__ = ("K", "N", "r3", "q", "k", "v", "A_cat_fwd", "A_cat_bwd", "Bs_cat_fwd", "Bs_cat_bwd")
 
 
 class LoraState:
@@ -178,7 +190,37 @@ class LoraState:
             else:
                 descs.append((oa, o_af, o_ab, r, m.K, m.K, m.K, r, 1.0))               # A [r][K] -> copy + A^T [K][r]
             descs.append((ob, o_bf, o_bb, m.N, r, r, r, m.N, self.scaling))             # s*B [N][r] -> copy + transpose [r][N]
+        # self-attention q/k/v triples additionally get CONCATENATED operands, so the three rank-64 down-projections
+        # are one [M,C]x[C,192] GEMM and the three up-projections ride the fused QKV GEMM as one block-diagonal K=192
+        # segment (the off-diagonal blocks stay at the zeros this buffer is created with):
+        #   A_cat_fwd [3r][C], A_cat_bwd [C][3r], Bs_cat_fwd [3N][3r] (block-diag), Bs_cat_bwd [3r][3N] (block-diag)
+        offs = {path: (oa, ob) for path, shp, oa, ob in layout}
+        qkv_layout = []
+        for path in list(offs):
+            if not path.endswith("attn1.to_q"):
+                continue
+            p = path[:-len("to_q")]
+            trio = [self.modules.get(p + n) for n in ("to_q", "to_k", "to_v")]
+            if any(t is None or t.kind != "lin" or t.K != trio[0].K or t.N != trio[0].N for t in trio):
+                continue
+            Kc, Nc = trio[0].K, trio[0].N
+            o_caf, o_cab, o_cbf, o_cbb = alloc(3 * r * Kc), alloc(Kc * 3 * r), alloc(3 * Nc * 3 * r), alloc(3 * r * 3 * Nc)
+            qkv_layout.append((p, Kc, Nc, o_caf, o_cab, o_cbf, o_cbb))
+            for j, t in enumerate(trio):
+                oa_j, ob_j = offs[t.path]
+                descs.append((oa_j, o_caf + j * r * Kc, o_cab + j * r, r, Kc, Kc, Kc, 3 * r, 1.0))
+                descs.append((ob_j, o_cbf + j * Nc * 3 * r + j * r, o_cbb + j * r * 3 * Nc + j * Nc, Nc, r, r, 3 * r, 3 * Nc, self.scaling))
         self.operands = torch.zeros(ototal, dtype=BF16, device=self.device)
+        self.qkv = {}
+        for p, Kc, Nc, o_caf, o_cab, o_cbf, o_cbb in qkv_layout:
+            f = LoraQKV()
+            f.K, f.N, f.r3 = Kc, Nc, 3 * r
+            f.q, f.k, f.v = (self.modules[p + n] for n in ("to_q", "to_k", "to_v"))
+            f.A_cat_fwd = self.operands[o_caf:o_caf + 3 * r * Kc].view(3 * r, Kc)
+            f.A_cat_bwd = self.operands[o_cab:o_cab + Kc * 3 * r].view(Kc, 3 * r)
+            f.Bs_cat_fwd = self.operands[o_cbf:o_cbf + 9 * Nc * r].view(3 * Nc, 3 * r)
+            f.Bs_cat_bwd = self.operands[o_cbb:o_cbb + 9 * Nc * r].view(3 * r, 3 * Nc)
+            self.qkv[p] = f
         for m, o_af, o_ab, o_bf, o_bb in layout2:
             if m.kind == "conv3":
                 m.A_fwd, m.A_bwd = self.operands[o_af:o_af + r * m.K].view(r, m.K), self.operands[o_ab:o_ab + m.K * r].view(m.C, 9 * r)
@@ -399,6 +441,20 @@ class UNet:
             qkv = qkv.view(B, L, 3 * C)
             o, lse = ops.attn_fwd(qkv[:, :, :C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:], Hh, d)
             return layer_fwd(W, lora, p + "to_out.0", o.view(M, C), M, residual=resid)
+        fq = lora.qkv.get(p) if (lora is not None and FUSE_LORA_QKV and ctx is xn and p in W.qkv and (sv is None or p in W.qkv_bwd)) else None
+        if fq is not None:
+            # LoRA self-attention: the three rank-64 down-projections as one N=192 GEMM, then ONE QKV GEMM whose second
+            # K-segment is the block-diagonal s*B operand; attention reads q/k/v in place (row stride 3C)
+            t3 = torch.empty(M, fq.r3, dtype=BF16, device=xn.device)
+            ops.gemm([Seg(xn, fq.A_cat_fwd)], M, fq.r3, t3)
+            qkv = torch.empty(M, 3 * C, dtype=BF16, device=xn.device)
+            ops.gemm([Seg(xn, W.qkv[p]), Seg(t3, fq.Bs_cat_fwd)], M, 3 * C, qkv)
+            q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
+            o, lse = ops.attn_fwd(q.unflatten(0, (B, L)), k.unflatten(0, (B, L)), v.unflatten(0, (B, L)), Hh, d)
+            out = layer_fwd(W, lora, p + "to_out.0", o.view(M, C), M, save=so, residual=resid)
+            if sv is not None:
+                sv.update(fused=True, x=xn, t3=t3, so=so, q=q, k=k, v=v, o=o, lse=lse, L=L, Lk=Lk)
+            return out
         q = layer_fwd(W, lora, p + "to_q", xn, M, save=sq)
         k = layer_fwd(W, lora, p + "to_k", ctx, Mk, save=sk)
         v = layer_fwd(W, lora, p + "to_v", ctx, Mk, save=svv)
@@ -413,6 +469,21 @@ class UNet:
         W, lora = self.W, self.lora
         d, L, Lk = C // Hh, sv["L"], sv["Lk"]
         d_o = layer_bwd(W, lora, p + "to_out.0", d_out, sv["so"])
+        if sv.get("fused"):
+            fq, M, r = lora.qkv[p], B * L, lora.rank
+            q, k, v, x, t3 = sv["q"], sv["k"], sv["v"], sv["x"], sv["t3"]
+            d3 = torch.empty(M, 3 * C, dtype=BF16, device=d_o.device)        # [dq | dk | dv], written in place by attention
+            dq, dk, dv = d3[:, :C], d3[:, C:2 * C], d3[:, 2 * C:]
+            ops.attn_bwd(q.unflatten(0, (B, L)), k.unflatten(0, (B, L)), v.unflatten(0, (B, L)), sv["o"], d_o.view(B, L, C),
+                         sv["lse"], Hh, d, out=(dq, dk, dv))
+            u3 = torch.empty(M, fq.r3, dtype=BF16, device=d_o.device)
+            ops.gemm([Seg(d3, fq.Bs_cat_bwd)], M, fq.r3, u3)                  # u_j = d_j (s B_j): block-diagonal operand
+            for j, (lm, dj) in enumerate(((fq.q, dq), (fq.k, dk), (fq.v, dv))):
+                ops.lora_wgrad(dj, t3[:, j * r:(j + 1) * r], lm.gB, lora.scaling, M, G=C, g_stride=r, r_stride=1, ldb=3 * C, lds=fq.r3)
+                ops.lora_wgrad(x, u3[:, j * r:(j + 1) * r], lm.gA, 1.0, M, G=fq.K, g_stride=1, r_stride=fq.K, lds=fq.r3)
+            d_xn = torch.empty(M, fq.K, dtype=BF16, device=d_o.device)
+            ops.gemm([Seg(d3, W.qkv_bwd[p]), Seg(u3, fq.A_cat_bwd)], M, fq.K, d_xn)
+            return d_xn
         dq, dk, dv = ops.attn_bwd(sv["q"].view(B, L, C), sv["k"].view(B, Lk, C), sv["v"].view(B, Lk, C), sv["o"],
                                   d_o.view(B, L, C), sv["lse"], Hh, d)
         d_xn = layer_bwd(W, lora, p + "to_q", dq.view(B * L, C), sv["sq"])

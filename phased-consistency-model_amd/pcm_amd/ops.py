@@ -356,14 +356,24 @@ def attn_fwd(q, k, v, H, d, scale=None):
     return o, lse
 
 
-def attn_bwd(q, k, v, o, dO, lse, H, d, scale=None, need_dkv=True):
+def attn_bwd(q, k, v, o, dO, lse, H, d, scale=None, need_dkv=True, out=None):
+    """q/k/v may be column slices of a wider row (unit inner stride; dq shares q's row stride, dk/dv share k's).
+    ``out`` = (dq, dk, dv) preallocated with those strides, e.g. slices of one [.., 3C] buffer."""
     B, Lq, Lk = q.shape[0], q.shape[1], k.shape[1]
     scale = scale if scale is not None else d ** -0.5
-    assert q.is_contiguous() and k.is_contiguous() and v.is_contiguous() and o.is_contiguous() and dO.is_contiguous()
+    assert q.stride(2) == 1 and k.stride(2) == 1 and v.stride(2) == 1 and k.stride(1) == v.stride(1)
+    assert q.stride(0) == Lq * q.stride(1) and k.stride(0) == Lk * k.stride(1) and v.stride(0) == Lk * v.stride(1)
+    assert o.is_contiguous() and dO.is_contiguous()
     delta = torch.empty(B, H, Lq, dtype=torch.float32, device=q.device)
-    dq = torch.empty_like(q)
-    dk = torch.empty_like(k) if need_dkv else None
-    dv = torch.empty_like(v) if need_dkv else None
+    if out is not None:
+        dq, dk, dv = out
+        for g_, s_ in ((dq, q), (dk, k), (dv, v)):
+            assert g_.shape[-1] == s_.shape[-1] and g_.stride(-1) == 1 and g_.stride(-2) == s_.stride(1), "attn_bwd: gradient strides must match"
+    else:
+        dq = torch.empty(q.shape, dtype=q.dtype, device=q.device) if q.is_contiguous() else None
+        assert dq is not None and (not need_dkv or (k.is_contiguous() and v.is_contiguous())), "attn_bwd: strided q/k/v need out="
+        dk = torch.empty_like(k) if need_dkv else None
+        dv = torch.empty_like(v) if need_dkv else None
     wsb = capi.lib().dll.pcm_attn_workspace_bytes(B, H, Lq, Lk, d, 1)     # packed K^T, Q^T, dO^T tile images
     ws = torch.empty(wsb, dtype=torch.uint8, device=q.device) if wsb else None
     capi.lib().call("pcm_attn_bwd_ws", ptr(q), ptr(k), ptr(v), ptr(o), ptr(dO), ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv),

@@ -56,6 +56,8 @@ def test_unet_forward_backward_vs_oracle():
     out_t = teacher.forward(x, t, ctx)
     student = UNet(W, lora)
     out_s, tape = student.forward(x, t, ctx, save=True)
+    # the self-attention q/k/v LoRA projections ran as the fused (concatenated / block-diagonal operand) schedule
+    assert lora.qkv and all(sv["blk0"]["sa1"].get("fused") for kind, _, sv in tape if kind == "transformer")
     scale = ref_t.abs().max().item()
     err_t = (out_t - ref_t).abs().max().item()
     err_s = (out_s - ref_s.detach()).abs().max().item()
