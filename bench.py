@@ -117,9 +117,14 @@ def main():
 
     use_graph = not args.no_graph
     if use_graph:
-        D.capture(B)
-        torch.cuda.synchronize()
-        log("step captured into hipGraphs")
+        try:
+            D.capture(B)
+            torch.cuda.synchronize()
+            log("step captured into hipGraphs")
+        except RuntimeError as e:      # same launches issued eagerly: slower on the host side, identical device work
+            log("hipGraph capture failed (%s); falling back to eager launches" % str(e).splitlines()[0])
+            use_graph = False
+            D._graph = None
 
     def run(b, eager=False):
         f = D.step if (eager or not use_graph) else D.step_graphed
@@ -127,7 +132,10 @@ def main():
 
     def sync():
         if world > 1:
-            torch.distributed.barrier()
+            if torch.distributed.get_backend() == "nccl":
+                torch.distributed.barrier(device_ids=[local_rank])
+            else:
+                torch.distributed.barrier()
         torch.cuda.synchronize()
 
     log("rank %d: batches ready" % rank)

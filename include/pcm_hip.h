@@ -125,6 +125,13 @@ int pcm_groupnorm_bwd_stats(const void* x, const void* dy, const double* stats, 
 int pcm_groupnorm_stats_acc(const void* x, double* stats, int B, int HW, int C, int G, void* stream);
 int pcm_groupnorm_bwd_stats_acc(const void* x, const void* dy, const double* stats, const float* gamma, const float* beta, double* bstats,
                                 int B, int HW, int C, int G, float eps, int act, void* stream);
+/* Contention-free form of the two reductions (the one the UNet runner uses): every workgroup writes its partial sums into the
+ * caller's `workspace` and a second, tiny launch adds them up into stats[b][g] (written, not accumulated).  Same-address fp64
+ * atomics cost ~0.5 us each on MI355X and serialize per (b, g), which bounds the atomic form to ~2 workgroups per CU. */
+size_t pcm_groupnorm_workspace_bytes(int B, int HW, int C, int G);
+int pcm_groupnorm_stats_ws(const void* x, double* stats, int B, int HW, int C, int G, void* workspace, size_t workspace_bytes, void* stream);
+int pcm_groupnorm_bwd_stats_ws(const void* x, const void* dy, const double* stats, const float* gamma, const float* beta, double* bstats,
+                               int B, int HW, int C, int G, float eps, int act, void* workspace, size_t workspace_bytes, void* stream);
 int pcm_groupnorm_bwd_apply(const void* x, const void* dy, const double* stats, const double* bstats,
                             const float* gamma, const float* beta, void* dx, int B, int HW, int C,
                             int G, float eps, int act, void* stream);

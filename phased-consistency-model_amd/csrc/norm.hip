@@ -16,6 +16,7 @@ struct GNArgs {
   const float* gamma;
   const float* beta;
   double* out;
+  double* part;   // != nullptr: contention-free mode, partial sums [b][chunk][g][2] instead of atomics into out
   int HW, C, G, cpg, CVL, csplit, ppb, act;
   float eps;
 };
@@ -39,26 +40,32 @@ __device__ __forceinline__ float gn_act_grad(float z, int act) {
 
 template <int MODE>
 __global__ __launch_bounds__(256) void gn_stats_kernel(GNArgs a) {
-  __shared__ float red[2][2560];  // per-channel partials of this block's channel slice
-  __shared__ float gconst[2][32];
+  __shared__ float red[2][2048];                                   // per-channel sums of this block's channel slice (<= 256 vectors)
+  __shared__ __attribute__((aligned(16))) float4 pbuf[4][256];     // per-thread partials, [float4 index][thread]: conflict-free b128 traffic
   const int b = blockIdx.y, zc = blockIdx.z;      // batch, channel split
   const int cvl = threadIdx.x % a.CVL, pl = threadIdx.x / a.CVL, k = blockDim.x / a.CVL;
   const int c0 = (zc * a.CVL + cvl) * 8;          // first channel of this thread's vector
   const int Cl = a.CVL * 8;                        // channels in this block's slice
-  for (int i = threadIdx.x; i < Cl; i += blockDim.x) { red[0][i] = 0.f; red[1][i] = 0.f; }
   float ga[8], be[8], mu[8], rs[8];
   if (MODE == 1) {
-    const double n = (double)a.HW * a.cpg;
-#pragma unroll
-    for (int e = 0; e < 8; e++) {
-      int c = c0 + e, g = c / a.cpg;
+    __shared__ float gconst[2][32];                // mean / rstd of the groups of this slice (fp64 math once per group, not per thread)
+    const int gl0 = Cl / a.cpg;
+    if ((int)threadIdx.x < gl0) {
+      const int g = zc * gl0 + threadIdx.x;
+      const double n = (double)a.HW * a.cpg;
       double s = a.stats[((size_t)b * a.G + g) * 2], ss = a.stats[((size_t)b * a.G + g) * 2 + 1];
       double m = s / n, var = ss / n - m * m;
-      mu[e] = (float)m; rs[e] = (float)(1.0 / sqrt((var > 0 ? var : 0) + (double)a.eps));
+      gconst[0][threadIdx.x] = (float)m;
+      gconst[1][threadIdx.x] = (float)(1.0 / sqrt((var > 0 ? var : 0) + (double)a.eps));
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      int c = c0 + e, gloc = (cvl * 8 + e) / a.cpg;
+      mu[e] = gconst[0][gloc]; rs[e] = gconst[1][gloc];
       ga[e] = a.gamma[c]; be[e] = a.beta[c];
     }
   }
-  __syncthreads();
   float s1[8], s2[8];
 #pragma unroll
   for (int e = 0; e < 8; e++) { s1[e] = 0.f; s2[e] = 0.f; }
@@ -66,18 +73,19 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(GNArgs a) {
   int p_end = p_begin + a.ppb; if (p_end > a.HW) p_end = a.HW;
   const bf16_t* xb = a.x + (size_t)b * a.HW * a.C + c0;
   const bf16_t* dyb = MODE == 1 ? a.dy + (size_t)b * a.HW * a.C + c0 : nullptr;
-  // 4 pixels per trip: the loads of a trip are issued together (clamped addresses, masked accumulation) -- with one load per
-  // thread in flight this pass ran at ~2.3 TB/s
-  for (int p = p_begin + pl; p < p_end; p += 4 * k) {
-    uint4 xr[4], dr[4];
+  // several pixels per trip: the loads of a trip are issued together (clamped addresses, masked accumulation) -- with one load
+  // per thread in flight this pass ran at ~2.3 TB/s
+  constexpr int U = MODE == 0 ? 8 : 4;   // 8 x 16 B in flight per thread either way
+  for (int p = p_begin + pl; p < p_end; p += U * k) {
+    uint4 xr[U], dr[MODE == 1 ? U : 1];
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
+    for (int u = 0; u < U; u++) {
       int pp = p + u * k; if (pp > p_end - 1) pp = p_end - 1;
       xr[u] = *(const uint4*)(xb + (size_t)pp * a.C);
       if (MODE == 1) dr[u] = *(const uint4*)(dyb + (size_t)pp * a.C);
     }
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
+    for (int u = 0; u < U; u++) {
       if (p + u * k >= p_end) continue;
       float xv[8];
       unpack8(xr[u], xv);
@@ -98,17 +106,61 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(GNArgs a) {
       }
     }
   }
-#pragma unroll
-  for (int e = 0; e < 8; e++) { atomicAdd(&red[0][cvl * 8 + e], s1[e]); atomicAdd(&red[1][cvl * 8 + e], s2[e]); }
+  // block reduction over the k pixel lanes of each channel vector, without LDS atomics (256 threads x 16 ds_add_f32 with k-way
+  // address conflicts cost ~3 us per block and bounded the whole pass by the LDS pipe): every thread parks its 16 sums as 4 float4,
+  // then CVL*4 (vector, float4) pairs are summed over the pixel lanes
+  pbuf[0][threadIdx.x] = make_float4(s1[0], s1[1], s1[2], s1[3]);
+  pbuf[1][threadIdx.x] = make_float4(s1[4], s1[5], s1[6], s1[7]);
+  pbuf[2][threadIdx.x] = make_float4(s2[0], s2[1], s2[2], s2[3]);
+  pbuf[3][threadIdx.x] = make_float4(s2[4], s2[5], s2[6], s2[7]);
+  __syncthreads();
+  for (int t2 = threadIdx.x; t2 < 4 * a.CVL; t2 += blockDim.x) {
+    const int cv2 = t2 % a.CVL, j = t2 / a.CVL;
+    float4 acc4 = pbuf[j][cv2];
+    for (int q = 1; q < k; q++) {
+      float4 v = pbuf[j][q * a.CVL + cv2];
+      acc4.x += v.x; acc4.y += v.y; acc4.z += v.z; acc4.w += v.w;
+    }
+    *(float4*)&red[j >> 1][cv2 * 8 + 4 * (j & 1)] = acc4;
+  }
   __syncthreads();
   const int gl = Cl / a.cpg;  // groups in this slice
   if ((int)threadIdx.x < gl) {
     float t1 = 0.f, t2 = 0.f;
     for (int i = 0; i < a.cpg; i++) { t1 += red[0][threadIdx.x * a.cpg + i]; t2 += red[1][threadIdx.x * a.cpg + i]; }
     int g = zc * gl + threadIdx.x;
-    atomicAdd(&a.out[((size_t)b * a.G + g) * 2], (double)t1);
-    atomicAdd(&a.out[((size_t)b * a.G + g) * 2 + 1], (double)t2);
+    if (a.part) {   // exactly one block owns (b, chunk, g)
+      double* pp = a.part + (((size_t)b * gridDim.x + blockIdx.x) * a.G + g) * 2;
+      pp[0] = (double)t1; pp[1] = (double)t2;
+    } else {
+      atomicAdd(&a.out[((size_t)b * a.G + g) * 2], (double)t1);
+      atomicAdd(&a.out[((size_t)b * a.G + g) * 2 + 1], (double)t2);
+    }
   }
+}
+
+// stats[b][i] = sum over chunks of part[b][chunk][i], i in [0, 2G): one 256-thread block per sample, 4 chunk lanes per output with
+// all of a lane's loads issued together (the partials were just written by other XCDs, every load is a trip to memory)
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const double* part, double* out, int nchunks, int n2g) {
+  __shared__ double sm[4][64];
+  const int b = blockIdx.x, i = threadIdx.x & 63, lane = threadIdx.x >> 6;
+  double acc = 0.0;
+  if (i < n2g) {
+    const double* p = part + (size_t)b * nchunks * n2g + i;
+    for (int c0 = lane; c0 < nchunks; c0 += 32) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        int ch = c0 + 4 * u;
+        v[u] = p[(size_t)(ch < nchunks ? ch : c0) * n2g];
+        if (ch >= nchunks) v[u] = 0.0;
+      }
+      acc += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    }
+  }
+  sm[lane][i] = acc;
+  __syncthreads();
+  if (lane == 0 && i < n2g) out[(size_t)b * n2g + i] = (sm[0][i] + sm[1][i]) + (sm[2][i] + sm[3][i]);
 }
 
 // apply.  MODE 0: y = act(xhat*gamma+beta).  MODE 1: dx = rstd*(dz*gamma - g1/n - xhat*g2/n)
@@ -126,7 +178,14 @@ struct GNApply {
 
 template <int MODE>
 __global__ __launch_bounds__(256) void gn_apply_kernel(GNApply a) {
-  __shared__ float sc[2560], sh[2560];     // per-channel scale / shift (MODE0) or gamma*rstd / beta... (MODE1)
+  // per-channel constants in LDS.  MODE 0: y = act(x*sc + sh) with sc = rstd*gamma, sh = beta - mean*sc.
+  // MODE 1: with z = x*sc + sh, dz = dy*act'(z), R = rstd^2*g2, Q = rstd*g1 - R*mean:  dx = sc*dz - Q - R*x
+  // (algebraically rstd*(dz*gamma - g1 - xhat*g2)); no per-element group lookup or division is left in the stream.
+  PCM_DYN_SMEM(smem_raw);
+  float* sc = (float*)smem_raw;
+  float* sh = sc + a.C;
+  float* qq = sh + a.C;
+  float* rq = qq + a.C;
   __shared__ float gm[32], gr[32], g1[32], g2[32];
   const int b = blockIdx.y;
   const double n = (double)a.HW * a.cpg;
@@ -144,56 +203,58 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GNApply a) {
   __syncthreads();
   for (int c = threadIdx.x; c < a.C; c += blockDim.x) {
     int g = c / a.cpg;
-    if (MODE == 0) {
-      float s_ = gr[g] * a.gamma[c];
-      sc[c] = s_; sh[c] = a.beta[c] - gm[g] * s_;
-    } else {
-      sc[c] = a.gamma[c]; sh[c] = a.beta[c];
+    float s_ = gr[g] * a.gamma[c];
+    sc[c] = s_; sh[c] = a.beta[c] - gm[g] * s_;
+    if (MODE == 1) {
+      float R = gr[g] * gr[g] * g2[g];
+      rq[c] = R; qq[c] = gr[g] * g1[g] - R * gm[g];
     }
   }
   __syncthreads();
   const int CV = a.C / 8;
-  const size_t nvec = (size_t)a.HW * CV;
-  const size_t v0 = (size_t)blockIdx.x * a.vec_per_block;
-  size_t v1 = v0 + a.vec_per_block; if (v1 > nvec) v1 = nvec;
+  const int nvec = a.HW * CV;
+  const int v0 = blockIdx.x * a.vec_per_block;
+  int v1 = v0 + a.vec_per_block; if (v1 > nvec) v1 = nvec;
   const bf16_t* xb = a.x + (size_t)b * a.HW * a.C;
   bf16_t* yb = a.y + (size_t)b * a.HW * a.C;
   const bf16_t* dyb = MODE == 1 ? a.dy + (size_t)b * a.HW * a.C : nullptr;
+  // channel-vector index of this thread's vector, advanced incrementally (stride 256 vectors): one modulo per thread
+  const int cstep = 256 % CV;
+  int cv = (v0 + (int)threadIdx.x) % CV;
   // 4 vectors per trip, loads issued together (clamped addresses; the store is skipped for the clamped duplicates)
-  for (size_t vb = v0 + threadIdx.x; vb < v1; vb += 4 * (size_t)blockDim.x) {
+  for (int vb = v0 + threadIdx.x; vb < v1; vb += 4 * 256) {
     uint4 xr[4], dr[4];
 #pragma unroll
     for (int u = 0; u < 4; u++) {
-      size_t v = vb + u * (size_t)blockDim.x; if (v > v1 - 1) v = v1 - 1;
-      xr[u] = *(const uint4*)(xb + v * 8);
-      if (MODE == 1) dr[u] = *(const uint4*)(dyb + v * 8);
+      int v = vb + u * 256; if (v > v1 - 1) v = v1 - 1;
+      xr[u] = *(const uint4*)(xb + (size_t)v * 8);
+      if (MODE == 1) dr[u] = *(const uint4*)(dyb + (size_t)v * 8);
     }
 #pragma unroll
     for (int u = 0; u < 4; u++) {
-      const size_t v = vb + u * (size_t)blockDim.x;
+      const int v = vb + u * 256;
+      const int c0 = cv * 8;
+      cv += cstep; if (cv >= CV) cv -= CV;
       if (v >= v1) continue;
-      int c0 = (int)(v % CV) * 8;
-      float xv[8], o[8];
+      float xv[8], o[8], scv[8], shv[8];
       unpack8(xr[u], xv);
+      *(float4*)&scv[0] = *(const float4*)&sc[c0]; *(float4*)&scv[4] = *(const float4*)&sc[c0 + 4];
+      *(float4*)&shv[0] = *(const float4*)&sh[c0]; *(float4*)&shv[4] = *(const float4*)&sh[c0 + 4];
       if (MODE == 0) {
 #pragma unroll
-        for (int e = 0; e < 8; e++) {
-          float z = xv[e] * sc[c0 + e] + sh[c0 + e];
-          o[e] = gn_act(z, a.act);
-        }
+        for (int e = 0; e < 8; e++) o[e] = gn_act(fmaf(xv[e], scv[e], shv[e]), a.act);
       } else {
-        float dv[8];
+        float dv[8], qv[8], rv[8];
         unpack8(dr[u], dv);
+        *(float4*)&qv[0] = *(const float4*)&qq[c0]; *(float4*)&qv[4] = *(const float4*)&qq[c0 + 4];
+        *(float4*)&rv[0] = *(const float4*)&rq[c0]; *(float4*)&rv[4] = *(const float4*)&rq[c0 + 4];
 #pragma unroll
         for (int e = 0; e < 8; e++) {
-          int c = c0 + e, g = c / a.cpg;
-          float xh = (xv[e] - gm[g]) * gr[g];
-          float dz = dv[e];
-          dz *= gn_act_grad(xh * sc[c] + sh[c], a.act);
-          o[e] = gr[g] * (dz * sc[c] - g1[g] - xh * g2[g]);
+          float dz = dv[e] * gn_act_grad(fmaf(xv[e], scv[e], shv[e]), a.act);
+          o[e] = fmaf(scv[e], dz, -fmaf(rv[e], xv[e], qv[e]));
         }
       }
-      *(uint4*)(yb + v * 8) = pack8(o);
+      *(uint4*)(yb + (size_t)v * 8) = pack8(o);
     }
   }
 }
@@ -204,11 +265,10 @@ static int gn_check(const char* what, int B, int HW, int C, int G) {
   return PCM_OK;
 }
 
-template <int MODE>
-static int gn_stats_launch(const char* what, GNArgs a, int B, void* stream, bool zero = true) {
+// launch geometry of the statistics pass: channel split so a block's slice has <= 256 vectors and whole groups; `target` blocks
+static int gn_stats_geometry(const char* what, GNArgs& a, int B, int target, int* split_, int* chunks_, int* threads_) {
   int CV = a.C / 8;
   int split = 1;
-  // channel split so a block's slice has <= 256 vectors and whole groups
   while (CV / split > 256 || (CV % split) != 0 || ((a.C / split) % a.cpg) != 0) {
     split++;
     PCM_CHECK(split <= a.G, PCM_EUNSUPPORTED, "%s: cannot split C=%d over groups of %d", what, a.C, a.cpg);
@@ -216,15 +276,66 @@ static int gn_stats_launch(const char* what, GNArgs a, int B, void* stream, bool
   a.CVL = CV / split; a.csplit = split;
   PCM_CHECK(a.CVL * 8 <= 2560, PCM_EUNSUPPORTED, "%s: channel slice too large", what);
   int k = 256 / a.CVL; if (k < 1) k = 1;
-  int threads = a.CVL * k;
-  // each block ends with LDS + fp64 global atomics: ~2 blocks per CU, long pixel runs per thread
-  int chunks = (PCM_GRID_CAP(512) + B * split - 1) / (B * split);
+  int chunks = (target + B * split - 1) / (B * split);
   int maxchunks = (a.HW + k - 1) / k; if (chunks > maxchunks) chunks = maxchunks; if (chunks < 1) chunks = 1;
   a.ppb = (a.HW + chunks - 1) / chunks;
   chunks = (a.HW + a.ppb - 1) / a.ppb;
+  *split_ = split; *chunks_ = chunks; *threads_ = a.CVL * k;
+  return PCM_OK;
+}
+
+// atomic mode: each block ends with LDS + fp64 global atomics (same-address fp64 atomics serialize at ~0.5 us each on this part):
+// ~2 blocks per CU, long pixel runs per thread.  Workspace mode: no atomics, any batch size gets ~1024 blocks (measured flat from 512 to 2048).
+static int g_gn_target_ws = 1024;
+extern "C" void pcm_debug_gn_target(int blocks) { g_gn_target_ws = blocks > 0 ? blocks : 1024; }   // tuning hook (tools/gn_probe.py)
+#define GN_TARGET_ATOMIC PCM_GRID_CAP(512)
+#define GN_TARGET_WS PCM_GRID_CAP(g_gn_target_ws)
+
+template <int MODE>
+static int gn_stats_launch(const char* what, GNArgs a, int B, void* stream, bool zero = true, void* ws = nullptr, size_t ws_bytes = 0) {
+  int split, chunks, threads;
+  if (int rc = gn_stats_geometry(what, a, B, ws ? GN_TARGET_WS : GN_TARGET_ATOMIC, &split, &chunks, &threads)) return rc;
+  if (ws) {
+    PCM_CHECK(ws_bytes >= sizeof(double) * 2 * a.G * (size_t)B * chunks && ((uintptr_t)ws % 8) == 0, PCM_EINVAL, "%s: workspace too small", what);
+    a.part = (double*)ws;
+    PCM_LAUNCH((gn_stats_kernel<MODE>), dim3(chunks, B, split), dim3(threads), 0, stream, a);
+    PCM_LAUNCH(gn_finalize_kernel, dim3(B), dim3(256), 0, stream, (const double*)ws, a.out, chunks, 2 * a.G);
+    return pcm_post_launch(what);
+  }
+  a.part = nullptr;
   if (zero) hipMemsetAsync(a.out, 0, sizeof(double) * 2 * B * a.G, (hipStream_t)stream);
   PCM_LAUNCH((gn_stats_kernel<MODE>), dim3(chunks, B, split), dim3(threads), 0, stream, a);
   return pcm_post_launch(what);
+}
+
+extern "C" size_t pcm_groupnorm_workspace_bytes(int B, int HW, int C, int G) {
+  if (B <= 0 || HW <= 0 || C <= 0 || G <= 0 || G > 32 || (C % G) || (C % 8)) return 0;
+  GNArgs a; memset(&a, 0, sizeof(a));
+  a.HW = HW; a.C = C; a.G = G; a.cpg = C / G;
+  int split, chunks, threads;
+  if (gn_stats_geometry("pcm_groupnorm_workspace_bytes", a, B, GN_TARGET_WS, &split, &chunks, &threads)) return 0;
+  return sizeof(double) * 2 * G * (size_t)B * chunks;
+}
+
+extern "C" int pcm_groupnorm_stats_ws(const void* x, double* stats, int B, int HW, int C, int G, void* workspace, size_t workspace_bytes,
+                                      void* stream) {
+  if (int rc = gn_check("pcm_groupnorm_stats_ws", B, HW, C, G)) return rc;
+  PCM_CHECK(x && stats && workspace && PCM_ALIGNED16(x), PCM_EALIGN, "pcm_groupnorm_stats_ws: null/unaligned argument");
+  GNArgs a; memset(&a, 0, sizeof(a));
+  a.x = (const bf16_t*)x; a.out = stats; a.HW = HW; a.C = C; a.G = G; a.cpg = C / G;
+  return gn_stats_launch<0>("pcm_groupnorm_stats_ws", a, B, stream, false, workspace, workspace_bytes);
+}
+
+extern "C" int pcm_groupnorm_bwd_stats_ws(const void* x, const void* dy, const double* stats, const float* gamma, const float* beta,
+                                          double* bstats, int B, int HW, int C, int G, float eps, int act, void* workspace,
+                                          size_t workspace_bytes, void* stream) {
+  if (int rc = gn_check("pcm_groupnorm_bwd_stats_ws", B, HW, C, G)) return rc;
+  PCM_CHECK(x && dy && stats && gamma && beta && bstats && workspace && PCM_ALIGNED16(x) && PCM_ALIGNED16(dy), PCM_EALIGN,
+            "pcm_groupnorm_bwd_stats_ws: null/unaligned argument");
+  GNArgs a; memset(&a, 0, sizeof(a));
+  a.x = (const bf16_t*)x; a.dy = (const bf16_t*)dy; a.stats = stats; a.gamma = gamma; a.beta = beta;
+  a.out = bstats; a.HW = HW; a.C = C; a.G = G; a.cpg = C / G; a.eps = eps; a.act = act;
+  return gn_stats_launch<1>("pcm_groupnorm_bwd_stats_ws", a, B, stream, false, workspace, workspace_bytes);
 }
 
 extern "C" int pcm_groupnorm_stats(const void* x, double* stats, int B, int HW, int C, int G, void* stream) {
@@ -275,7 +386,7 @@ static int gn_apply_launch(const char* what, GNApply a, int B, void* stream) {
   int cap = (PCM_GRID_CAP(4096) + B - 1) / B; if (blocks > cap) blocks = cap; if (blocks < 1) blocks = 1;
   a.vec_per_block = (int)((nvec + blocks - 1) / blocks);
   blocks = (int)((nvec + a.vec_per_block - 1) / a.vec_per_block);
-  PCM_LAUNCH((gn_apply_kernel<MODE>), dim3(blocks, B), dim3(256), 0, stream, a);
+  PCM_LAUNCH((gn_apply_kernel<MODE>), dim3(blocks, B), dim3(256), (MODE == 1 ? 4 : 2) * a.C * sizeof(float), stream, a);
   return pcm_post_launch(what);
 }
 

@@ -52,6 +52,8 @@ _PROTOS = {
     "pcm_lora_wgrad_bf16": [C.POINTER(WgradArgs), vp],
     "pcm_groupnorm_stats": [vp, vp, i32, i32, i32, i32, vp],
     "pcm_groupnorm_stats_acc": [vp, vp, i32, i32, i32, i32, vp],
+    "pcm_groupnorm_stats_ws": [vp, vp, i32, i32, i32, i32, vp, C.c_size_t, vp],
+    "pcm_groupnorm_bwd_stats_ws": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp, C.c_size_t, vp],
     "pcm_groupnorm_apply": [vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp],
     "pcm_groupnorm_bwd_stats": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp],
     "pcm_groupnorm_bwd_stats_acc": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp],
@@ -124,6 +126,8 @@ class Lib:
         self.dll.pcm_gemm_workspace_bytes.argtypes = [C.POINTER(GemmSeg), C.c_int, C.POINTER(GemmEpi)]
         self.dll.pcm_attn_workspace_bytes.restype = C.c_size_t
         self.dll.pcm_attn_workspace_bytes.argtypes = [C.c_int] * 6
+        self.dll.pcm_groupnorm_workspace_bytes.restype = C.c_size_t
+        self.dll.pcm_groupnorm_workspace_bytes.argtypes = [C.c_int] * 4
         self.fn = {}
         for name, argt in _PROTOS.items():
             f = getattr(self.dll, name, None)

@@ -448,7 +448,7 @@ class UNet:
             t3 = torch.empty(M, fq.r3, dtype=BF16, device=xn.device)
             ops.gemm([Seg(xn, fq.A_cat_fwd)], M, fq.r3, t3)
             qkv = torch.empty(M, 3 * C, dtype=BF16, device=xn.device)
-            ops.gemm([Seg(xn, W.qkv[p]), Seg(t3, fq.Bs_cat_fwd)], M, 3 * C, qkv)
+            ops.gemm([Seg(xn, W.qkv[p]), Seg(t3, fq.Bs_cat_fwd, k_algo=lora.rank)], M, 3 * C, qkv)
             q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
             o, lse = ops.attn_fwd(q.unflatten(0, (B, L)), k.unflatten(0, (B, L)), v.unflatten(0, (B, L)), Hh, d)
             out = layer_fwd(W, lora, p + "to_out.0", o.view(M, C), M, save=so, residual=resid)
@@ -477,7 +477,7 @@ class UNet:
             ops.attn_bwd(q.unflatten(0, (B, L)), k.unflatten(0, (B, L)), v.unflatten(0, (B, L)), sv["o"], d_o.view(B, L, C),
                          sv["lse"], Hh, d, out=(dq, dk, dv))
             u3 = torch.empty(M, fq.r3, dtype=BF16, device=d_o.device)
-            ops.gemm([Seg(d3, fq.Bs_cat_bwd)], M, fq.r3, u3)                  # u_j = d_j (s B_j): block-diagonal operand
+            ops.gemm([Seg(d3, fq.Bs_cat_bwd, k_algo=C)], M, fq.r3, u3)                  # u_j = d_j (s B_j): block-diagonal operand
             for j, (lm, dj) in enumerate(((fq.q, dq), (fq.k, dk), (fq.v, dv))):
                 ops.lora_wgrad(dj, t3[:, j * r:(j + 1) * r], lm.gB, lora.scaling, M, G=C, g_stride=r, r_stride=1, ldb=3 * C, lds=fq.r3)
                 ops.lora_wgrad(x, u3[:, j * r:(j + 1) * r], lm.gA, 1.0, M, G=fq.K, g_stride=1, r_stride=fq.K, lds=fq.r3)
@@ -568,8 +568,8 @@ class UNet:
         cfg, W, lora = self.cfg, self.W, self.lora
         B, _, H, Wd = sample.shape
         boc, n = cfg.block_out_channels, len(cfg.block_out_channels)
-        self._arena = ops.StatArena(sample.device, slots=sum(1 for k in W.norms if "transformer_blocks" not in k) + 2, per_slot=B * cfg.norm_num_groups * 2)
         tape = [] if save else None
+        self._arena = ops.StatArena.for_pass(sample.device, W, B, cfg.norm_num_groups)
         text = encoder_hidden_states if encoder_hidden_states.dtype == BF16 else ops.cast_bf16(encoder_hidden_states.contiguous())
         t_emb = ops.timestep_embedding(timesteps, boc[0])
         e1 = layer_fwd(W, None, "time_embedding.linear_1", t_emb, B, act=capi.ACT_SILU)
@@ -682,9 +682,7 @@ class UNet:
         be None) instead of d_eps.  ``need_input_grad`` also back-propagates through the first resnet and conv_in and
         returns d sample [B,4,H,W] fp32 (the generator step's path through the frozen teacher, sd15_adv.py:1414-1424)."""
         W, lora, cfg = self.W, self.lora, self.cfg
-        B0 = tape[-1][2]["B"]
-        self._arena = ops.StatArena(d_eps.device if d_eps is not None else self.W.conv_in[0].device,
-                                    slots=sum(1 for k in W.norms if "transformer_blocks" not in k) + 2, per_slot=B0 * cfg.norm_num_groups * 2)
+        self._arena = ops.StatArena.for_pass(d_eps.device if d_eps is not None else self.W.conv_in[0].device, W, tape[-1][2]["B"], cfg.norm_num_groups)
         kind, _, sv = tape[-1]
         if kind == "out":
             d_hn = ops.conv_out_bwd(d_eps.contiguous(), W.conv_out[0], cfg.block_out_channels[0])

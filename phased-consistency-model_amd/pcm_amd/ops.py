@@ -22,10 +22,13 @@ def _chk(t, dtype=None):
 class Seg:
     """One K-segment of pcm_gemm_bf16."""
 
-    def __init__(self, a, w, conv=None, lda=None):
+    def __init__(self, a, w, conv=None, lda=None, k_algo=None):
         """plain: a [M, K] (row stride lda), w [N, K].  conv: a NHWC [B,Hs,Ws,C], w [N, 9*C],
-        conv = dict(Hs, Ws, stride=1, src_mode=SRC_DIRECT)."""
+        conv = dict(Hs, Ws, stride=1, src_mode=SRC_DIRECT).  ``k_algo``: contraction length that is algorithmically
+        needed per output when ``w`` carries structural zeros (block-diagonal operands); only the flop accounting of
+        the bench's roofline leg reads it, so padded zeros are never counted as useful work."""
         self.a, self.w, self.conv, self.lda = a, w, conv, lda
+        self.k_algo = k_algo if k_algo is not None else w.shape[-1]
 
     def fill(self, s: GemmSeg):
         s.a, s.w = ptr(self.a), ptr(self.w)
@@ -68,7 +71,7 @@ def gemm(segs, M, N, out, bias=None, rowvec=None, rows_per_batch=0, residual=Non
         ev0.record()
         capi.lib().call("pcm_gemm_bf16", arr, len(segs), C.byref(e), capi.Lib.stream())
         ev1.record()
-        GEMM_PROFILE.append((2.0 * M * N * sum(s.w.shape[-1] for s in segs), ev0, ev1,
+        GEMM_PROFILE.append((2.0 * M * N * sum(s.k_algo for s in segs), ev0, ev1,
                              (M, N, tuple(s.w.shape[-1] for s in segs), "conv" if segs[0].conv else "lin"),
                              capi.lib().dll.pcm_debug_last_gemm_plan()))
         return out
@@ -80,12 +83,26 @@ def _stream():
     return capi.Lib.stream()
 
 
+# GroupNorm statistics.  Two forms of the same reduction (kernel table): fp64 atomics into a pre-zeroed slice (one memset per
+# network pass through StatArena) or per-workgroup partials + a finalize launch.  Same-address fp64 atomics serialize at ~0.5 us each
+# on MI355X and a launch issues ~512/B of them per (sample, group): from B >= 16 that chain is shorter than the extra launch
+# (measured 22.5 vs 24.2 us at [32,4096,320]); below it (sampler, SDXL small batches) the partials form wins.
+GN_ATOMIC_MIN_BATCH = 16
+
+
 class StatArena:
     """Pre-zeroed fp64 slices for GroupNorm statistics: ONE memset per network pass instead of one per GroupNorm call."""
 
     def __init__(self, device, slots=96, per_slot=64 * 32 * 2):
         self.buf = torch.zeros(slots * per_slot, dtype=torch.float64, device=device)
         self.per_slot, self.used = per_slot, 0
+
+    @classmethod
+    def for_pass(cls, device, W, B, G):
+        """arena for one UNet pass over batch B (None when the partials form is used instead)."""
+        if B < GN_ATOMIC_MIN_BATCH:
+            return None
+        return cls(device, slots=sum(1 for k in W.norms if "transformer_blocks" not in k) + 2, per_slot=B * G * 2)
 
     def take(self, B, G):
         n = B * G * 2
@@ -94,6 +111,12 @@ class StatArena:
         s = self.buf[self.used * self.per_slot: self.used * self.per_slot + n].view(B, G, 2)
         self.used += 1
         return s
+
+
+def _gn_workspace(x, B, HW, Cc, G):
+    n = capi.lib().dll.pcm_groupnorm_workspace_bytes(B, HW, Cc, G)
+    assert n > 0, "pcm_groupnorm_workspace_bytes: unsupported shape"
+    return torch.empty(n // 8, dtype=torch.float64, device=x.device), n
 
 
 def groupnorm_fwd(x, gamma, beta, G, eps, act, arena=None):
@@ -106,7 +129,8 @@ def groupnorm_fwd(x, gamma, beta, G, eps, act, arena=None):
         L.call("pcm_groupnorm_stats_acc", ptr(x), ptr(stats), B, HW, Cc, G, _stream())
     else:
         stats = torch.empty(B, G, 2, dtype=torch.float64, device=x.device)
-        L.call("pcm_groupnorm_stats", ptr(x), ptr(stats), B, HW, Cc, G, _stream())
+        ws, n = _gn_workspace(x, B, HW, Cc, G)
+        L.call("pcm_groupnorm_stats_ws", ptr(x), ptr(stats), B, HW, Cc, G, ptr(ws), n, _stream())
     L.call("pcm_groupnorm_apply", ptr(x), ptr(stats), ptr(gamma), ptr(beta), ptr(y), B, HW, Cc, G, eps, act, _stream())
     return y, stats
 
@@ -120,7 +144,8 @@ def groupnorm_bwd(x, dy, stats, gamma, beta, G, eps, act, arena=None):
         L.call("pcm_groupnorm_bwd_stats_acc", ptr(x), ptr(dy), ptr(stats), ptr(gamma), ptr(beta), ptr(bstats), B, HW, Cc, G, eps, act, _stream())
     else:
         bstats = torch.empty(B, G, 2, dtype=torch.float64, device=x.device)
-        L.call("pcm_groupnorm_bwd_stats", ptr(x), ptr(dy), ptr(stats), ptr(gamma), ptr(beta), ptr(bstats), B, HW, Cc, G, eps, act, _stream())
+        ws, n = _gn_workspace(x, B, HW, Cc, G)
+        L.call("pcm_groupnorm_bwd_stats_ws", ptr(x), ptr(dy), ptr(stats), ptr(gamma), ptr(beta), ptr(bstats), B, HW, Cc, G, eps, act, ptr(ws), n, _stream())
     L.call("pcm_groupnorm_bwd_apply", ptr(x), ptr(dy), ptr(stats), ptr(bstats), ptr(gamma), ptr(beta), ptr(dx), B, HW, Cc, G, eps, act, _stream())
     return dx
 

@@ -165,9 +165,10 @@ class Distiller:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self._g_fb, self._g_opt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._g_fb):
+        # thread_local: the RCCL watchdog thread of a multi-rank job may query its events while this thread captures
+        with torch.cuda.graph(self._g_fb, capture_error_mode="thread_local"):
             self._static_out = self.forward_backward(**self._static)
-        with torch.cuda.graph(self._g_opt, pool=self._g_fb.pool()):
+        with torch.cuda.graph(self._g_opt, pool=self._g_fb.pool(), capture_error_mode="thread_local"):
             self._optimizer_apply()
         for dst, src in zip((lo.params, lo.exp_avg, lo.exp_avg_sq, self.step_dev, self.lr_dev), saved):
             dst.copy_(src)

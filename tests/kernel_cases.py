@@ -31,6 +31,14 @@ def case_groupnorm(dev, B, HW, C, G, act, eps=1e-5):
     ref.backward(dy.float().cpu().permute(0, 2, 1))
     dx = ops.groupnorm_bwd(x, dy, stats, gamma, beta, G, eps, act)
     close(dx.permute(0, 2, 1), xr.grad, 1e-2, 2e-2, "gn bwd")
+    # the atomic form of the two reductions (pre-zeroed arena slices; the runner uses it from batch 16 up) gives the same numbers
+    arena = ops.StatArena(x.device, slots=2, per_slot=B * G * 2)
+    y2, stats2 = ops.groupnorm_fwd(x, gamma, beta, G, eps, act, arena=arena)
+    dx2 = ops.groupnorm_bwd(x, dy, stats2, gamma, beta, G, eps, act, arena=arena)
+    assert arena.used == 2
+    close(stats2, stats, 1e-5, 1e-3, "gn stats atomic vs partials")
+    close(y2, y, 1e-6, 1e-2, "gn fwd atomic vs partials")
+    close(dx2, dx, 1e-6, 2e-2, "gn bwd atomic vs partials")
 
 
 def case_layernorm(dev, M, C):

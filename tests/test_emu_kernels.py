@@ -13,7 +13,8 @@ def _use_emu():
     capi.set_lib(None)
 
 
-@pytest.mark.parametrize("B,HW,C,G,act", [(2, 40, 320, 32, 1), (1, 9, 64, 8, 0), (2, 16, 2560, 32, 1), (1, 30, 960, 32, 1)])
+@pytest.mark.parametrize("B,HW,C,G,act", [(2, 40, 320, 32, 1), (1, 9, 64, 8, 0), (2, 16, 2560, 32, 1), (1, 30, 960, 32, 1), (1, 300, 64, 8, 1),
+                                            (3, 70, 640, 32, 0)])
 def test_groupnorm(B, HW, C, G, act):
     K.case_groupnorm("cpu", B, HW, C, G, act)
 
