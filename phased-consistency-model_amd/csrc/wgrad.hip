@@ -128,6 +128,13 @@ __global__ __launch_bounds__(256) void pcm_wgrad_kernel(WgDev a) {
   }
 }
 
+static int g_wg_target = 512, g_wg_minchunks = 4, g_wg_auto = 1;
+extern "C" void pcm_debug_wgrad_grid(int target_blocks, int min_chunks) {   // tuning hook (tools/wgrad_probe.py); 0, 0 = shipped rule
+  g_wg_auto = (target_blocks <= 0 && min_chunks <= 0) ? 1 : 0;
+  g_wg_target = target_blocks > 0 ? target_blocks : 512;
+  g_wg_minchunks = min_chunks > 0 ? min_chunks : 4;
+}
+
 extern "C" int pcm_lora_wgrad_bf16(const pcm_wgrad_args* p, void* stream) {
   PCM_CHECK(p && p->big && p->small_ && p->out && p->M > 0 && p->G > 0, PCM_EINVAL, "pcm_lora_wgrad_bf16: null/empty");
   PCM_CHECK(PCM_ALIGNED16(p->big) && PCM_ALIGNED16(p->small_) && (p->lds_ % 8) == 0 && p->lds_ >= 64, PCM_EALIGN,
@@ -147,9 +154,19 @@ extern "C" int pcm_lora_wgrad_bf16(const pcm_wgrad_args* p, void* stream) {
   }
   int tiles_g = (p->G + 63) / 64;
   int chunks = (p->M + 127) / 128;
-  // every block ends with 4096 fp32 atomics: split M only as far as needed to fill the chip (~2 blocks/CU)
-  int msplit = (PCM_GRID_CAP(512) + tiles_g - 1) / tiles_g;
-  if (msplit > (chunks + 3) / 4) msplit = (chunks + 3) / 4;
+  // M split.  Every block ends with 4096 fp32 atomics, i.e. msplit*G*256 B of atomic traffic against M*G*2 B of operand reads:
+  // (1) split as far as needed for ~2 blocks per CU (>= 4 chunks per block), (2) go on to ~8 blocks per CU only while the atomics
+  // stay below ~8 % of the reads (msplit <= M/1536).  Measured (tools/wgrad_probe.py, bs 16): 64x64x960 conv dA 385 -> 290 us,
+  // 64x64x320 131 -> 113 us, [65536 x 2560] dB 115 -> 98 us; shapes with M <= 4096 keep the first rule.
+  auto cdiv = [](int x, int y) { return (x + y - 1) / y; };
+  int msplit = cdiv(PCM_GRID_CAP(g_wg_target), tiles_g);
+  if (msplit > cdiv(chunks, g_wg_minchunks)) msplit = cdiv(chunks, g_wg_minchunks);
+  if (g_wg_auto) {
+    int extra = cdiv(PCM_GRID_CAP(2048), tiles_g);
+    if (extra > p->M / 1536) extra = p->M / 1536;
+    if (extra > cdiv(chunks, 2)) extra = cdiv(chunks, 2);
+    if (extra > msplit) msplit = extra;
+  }
   if (msplit > chunks) msplit = chunks;
   if (msplit < 1) msplit = 1;
   a.m_per_block = ((chunks + msplit - 1) / msplit) * 128;
