@@ -63,42 +63,75 @@ extern "C" int pcm_pool2x_sum_nhwc(const void* dy, void* dx, int B, int H, int W
 }
 
 // ---- concat / split ----
-__global__ __launch_bounds__(256) void concat_kernel(const uint4* a, int CVa, const uint4* b, int CVb, uint4* out, long rows) {
-  int CV = CVa + CVb;
-  long nvec = rows * CV;
-  EW_LOOP(v, nvec) {
-    int cv = (int)(v % CV); long r = v / CV;
-    out[v] = cv < CVa ? a[r * CVa + cv] : b[r * CVb + (cv - CVa)];
+// Row/column walker for the [rows][CV] vector grids below: a thread visits vectors v, v+S, v+2S, ... (S = grid size); the
+// (row, column) pair is advanced incrementally -- one 32-bit division per thread instead of a 64-bit div+mod per vector --
+// and EW_U vectors are fetched per trip so their loads are in flight together.
+#define EW_U 4
+struct EwWalk {
+  unsigned v, r, c, S, sr, sc, CV, nvec;
+  __device__ __forceinline__ EwWalk(unsigned rows, unsigned CV_) {
+    CV = CV_; nvec = rows * CV_; S = gridDim.x * blockDim.x; sr = S / CV_; sc = S - sr * CV_;
+    v = blockIdx.x * blockDim.x + threadIdx.x; r = v / CV_; c = v - r * CV_;
+  }
+  __device__ __forceinline__ void step() { v += S; c += sc; r += sr; if (c >= CV) { c -= CV; r++; } }
+};
+static inline int ew_blocks_u(long nvec) { return ew_blocks((nvec + EW_U - 1) / EW_U); }   // EW_U vectors per thread and trip
+static inline bool ew_fits32(long rows, long CV) { return rows > 0 && CV > 0 && rows * CV < (1L << 31) - (1L << 22); }
+
+__global__ __launch_bounds__(256) void concat_kernel(const uint4* a, int CVa, const uint4* b, int CVb, uint4* out, int rows) {
+  EwWalk w(rows, CVa + CVb);
+  while (w.v < w.nvec) {
+    uint4 val[EW_U]; unsigned vv[EW_U];
+#pragma unroll
+    for (int u = 0; u < EW_U; u++) {
+      vv[u] = w.v;
+      if (w.v < w.nvec) val[u] = (int)w.c < CVa ? a[(size_t)w.r * CVa + w.c] : b[(size_t)w.r * CVb + (w.c - CVa)];
+      w.step();
+    }
+#pragma unroll
+    for (int u = 0; u < EW_U; u++)
+      if (vv[u] < w.nvec) out[vv[u]] = val[u];
   }
 }
-__global__ __launch_bounds__(256) void split_kernel(const uint4* in, uint4* a, int CVa, uint4* b, int CVb, long rows, int acc_a) {
-  int CV = CVa + CVb;
-  long nvec = rows * CV;
-  EW_LOOP(v, nvec) {
-    int cv = (int)(v % CV); long r = v / CV;
-    uint4 val = in[v];
-    if (cv < CVa) {
-      if (acc_a) {
-        float f[8], g[8];
-        ew_unpack8(val, f); ew_unpack8(a[r * CVa + cv], g);
+__global__ __launch_bounds__(256) void split_kernel(const uint4* in, uint4* a, int CVa, uint4* b, int CVb, int rows, int acc_a) {
+  EwWalk w(rows, CVa + CVb);
+  while (w.v < w.nvec) {
+    uint4 val[EW_U], old[EW_U]; unsigned rr[EW_U], cc[EW_U]; bool ok[EW_U];
 #pragma unroll
-        for (int e = 0; e < 8; e++) f[e] += g[e];
-        val = ew_pack8(f);
+    for (int u = 0; u < EW_U; u++) {
+      rr[u] = w.r; cc[u] = w.c; ok[u] = w.v < w.nvec;
+      if (ok[u]) {
+        val[u] = in[w.v];
+        if (acc_a && (int)w.c < CVa) old[u] = a[(size_t)w.r * CVa + w.c];
       }
-      a[r * CVa + cv] = val;
-    } else {
-      b[r * CVb + (cv - CVa)] = val;
+      w.step();
+    }
+#pragma unroll
+    for (int u = 0; u < EW_U; u++) {
+      if (!ok[u]) continue;
+      if ((int)cc[u] < CVa) {
+        if (acc_a) {
+          float f[8], g[8];
+          ew_unpack8(val[u], f); ew_unpack8(old[u], g);
+#pragma unroll
+          for (int e = 0; e < 8; e++) f[e] += g[e];
+          val[u] = ew_pack8(f);
+        }
+        a[(size_t)rr[u] * CVa + cc[u]] = val[u];
+      } else {
+        b[(size_t)rr[u] * CVb + (cc[u] - CVa)] = val[u];
+      }
     }
   }
 }
 extern "C" int pcm_concat_channels(const void* a, int Ca, const void* b, int Cb, void* out, long rows, void* stream) {
-  PCM_CHECK(a && b && out && (Ca % 8) == 0 && (Cb % 8) == 0, PCM_EINVAL, "pcm_concat_channels: C%%8");
-  PCM_LAUNCH(concat_kernel, dim3(ew_blocks(rows * ((Ca + Cb) / 8))), dim3(256), 0, stream, (const uint4*)a, Ca / 8, (const uint4*)b, Cb / 8, (uint4*)out, rows);
+  PCM_CHECK(a && b && out && (Ca % 8) == 0 && (Cb % 8) == 0 && ew_fits32(rows, (Ca + Cb) / 8), PCM_EINVAL, "pcm_concat_channels: C%%8, rows*C/8 < 2^31");
+  PCM_LAUNCH(concat_kernel, dim3(ew_blocks_u(rows * ((Ca + Cb) / 8))), dim3(256), 0, stream, (const uint4*)a, Ca / 8, (const uint4*)b, Cb / 8, (uint4*)out, (int)rows);
   return pcm_post_launch("pcm_concat_channels");
 }
 extern "C" int pcm_split_channels(const void* in, void* a, int Ca, void* b, int Cb, long rows, int accumulate_a, void* stream) {
-  PCM_CHECK(in && a && b && (Ca % 8) == 0 && (Cb % 8) == 0, PCM_EINVAL, "pcm_split_channels: C%%8");
-  PCM_LAUNCH(split_kernel, dim3(ew_blocks(rows * ((Ca + Cb) / 8))), dim3(256), 0, stream, (const uint4*)in, (uint4*)a, Ca / 8, (uint4*)b, Cb / 8, rows, accumulate_a);
+  PCM_CHECK(in && a && b && (Ca % 8) == 0 && (Cb % 8) == 0 && ew_fits32(rows, (Ca + Cb) / 8), PCM_EINVAL, "pcm_split_channels: C%%8, rows*C/8 < 2^31");
+  PCM_LAUNCH(split_kernel, dim3(ew_blocks_u(rows * ((Ca + Cb) / 8))), dim3(256), 0, stream, (const uint4*)in, (uint4*)a, Ca / 8, (uint4*)b, Cb / 8, (int)rows, accumulate_a);
   return pcm_post_launch("pcm_split_channels");
 }
 
@@ -132,37 +165,58 @@ extern "C" int pcm_silu_bf16(const void* x, void* y, long n, void* stream) {
   return pcm_post_launch("pcm_silu_bf16");
 }
 // hg [M][2*C4]: h = cols [0,C4), g = cols [C4, 2*C4)
-__global__ __launch_bounds__(256) void geglu_fwd_kernel(const uint4* hg, uint4* out, long M, int CV4) {
-  long nvec = M * CV4;
-  EW_LOOP(v, nvec) {
-    int cv = (int)(v % CV4); long r = v / CV4;
-    float h[8], g[8];
-    ew_unpack8(hg[r * 2 * CV4 + cv], h); ew_unpack8(hg[r * 2 * CV4 + CV4 + cv], g);
+__global__ __launch_bounds__(256) void geglu_fwd_kernel(const uint4* hg, uint4* out, int M, int CV4) {
+  EwWalk w(M, CV4);
+  while (w.v < w.nvec) {
+    uint4 hr[EW_U], gr[EW_U]; unsigned vv[EW_U];
 #pragma unroll
-    for (int e = 0; e < 8; e++) h[e] *= gelu_erf_f(g[e]);
-    out[v] = ew_pack8(h);
+    for (int u = 0; u < EW_U; u++) {
+      vv[u] = w.v;
+      if (w.v < w.nvec) { const uint4* p = hg + (size_t)w.r * 2 * CV4 + w.c; hr[u] = p[0]; gr[u] = p[CV4]; }
+      w.step();
+    }
+#pragma unroll
+    for (int u = 0; u < EW_U; u++) {
+      if (vv[u] >= w.nvec) continue;
+      float h[8], g[8];
+      ew_unpack8(hr[u], h); ew_unpack8(gr[u], g);
+#pragma unroll
+      for (int e = 0; e < 8; e++) h[e] *= gelu_erf_f(g[e]);
+      out[vv[u]] = ew_pack8(h);
+    }
   }
 }
-__global__ __launch_bounds__(256) void geglu_bwd_kernel(const uint4* hg, const uint4* dout, uint4* dhg, long M, int CV4) {
-  long nvec = M * CV4;
-  EW_LOOP(v, nvec) {
-    int cv = (int)(v % CV4); long r = v / CV4;
-    float h[8], g[8], d[8], dh[8], dg[8];
-    ew_unpack8(hg[r * 2 * CV4 + cv], h); ew_unpack8(hg[r * 2 * CV4 + CV4 + cv], g); ew_unpack8(dout[v], d);
+__global__ __launch_bounds__(256) void geglu_bwd_kernel(const uint4* hg, const uint4* dout, uint4* dhg, int M, int CV4) {
+  EwWalk w(M, CV4);
+  while (w.v < w.nvec) {
+    uint4 hr[EW_U], gr[EW_U], dr[EW_U]; unsigned rr[EW_U], cc[EW_U]; bool ok[EW_U];
 #pragma unroll
-    for (int e = 0; e < 8; e++) { dh[e] = d[e] * gelu_erf_f(g[e]); dg[e] = d[e] * h[e] * gelu_erf_grad_f(g[e]); }
-    dhg[r * 2 * CV4 + cv] = ew_pack8(dh);
-    dhg[r * 2 * CV4 + CV4 + cv] = ew_pack8(dg);
+    for (int u = 0; u < EW_U; u++) {
+      rr[u] = w.r; cc[u] = w.c; ok[u] = w.v < w.nvec;
+      if (ok[u]) { const uint4* p = hg + (size_t)w.r * 2 * CV4 + w.c; hr[u] = p[0]; gr[u] = p[CV4]; dr[u] = dout[w.v]; }
+      w.step();
+    }
+#pragma unroll
+    for (int u = 0; u < EW_U; u++) {
+      if (!ok[u]) continue;
+      float h[8], g[8], d[8], dh[8], dg[8];
+      ew_unpack8(hr[u], h); ew_unpack8(gr[u], g); ew_unpack8(dr[u], d);
+#pragma unroll
+      for (int e = 0; e < 8; e++) { dh[e] = d[e] * gelu_erf_f(g[e]); dg[e] = d[e] * h[e] * gelu_erf_grad_f(g[e]); }
+      uint4* q = dhg + (size_t)rr[u] * 2 * CV4 + cc[u];
+      q[0] = ew_pack8(dh);
+      q[CV4] = ew_pack8(dg);
+    }
   }
 }
 extern "C" int pcm_geglu_fwd(const void* hg, void* out, int M, int C4, void* stream) {
-  PCM_CHECK(hg && out && (C4 % 8) == 0, PCM_EINVAL, "pcm_geglu_fwd: C4%%8");
-  PCM_LAUNCH(geglu_fwd_kernel, dim3(ew_blocks((long)M * (C4 / 8))), dim3(256), 0, stream, (const uint4*)hg, (uint4*)out, (long)M, C4 / 8);
+  PCM_CHECK(hg && out && (C4 % 8) == 0 && ew_fits32(M, C4 / 8), PCM_EINVAL, "pcm_geglu_fwd: C4%%8, M*C4/8 < 2^31");
+  PCM_LAUNCH(geglu_fwd_kernel, dim3(ew_blocks_u((long)M * (C4 / 8))), dim3(256), 0, stream, (const uint4*)hg, (uint4*)out, M, C4 / 8);
   return pcm_post_launch("pcm_geglu_fwd");
 }
 extern "C" int pcm_geglu_bwd(const void* hg, const void* dout, void* dhg, int M, int C4, void* stream) {
-  PCM_CHECK(hg && dout && dhg && (C4 % 8) == 0, PCM_EINVAL, "pcm_geglu_bwd: C4%%8");
-  PCM_LAUNCH(geglu_bwd_kernel, dim3(ew_blocks((long)M * (C4 / 8))), dim3(256), 0, stream, (const uint4*)hg, (const uint4*)dout, (uint4*)dhg, (long)M, C4 / 8);
+  PCM_CHECK(hg && dout && dhg && (C4 % 8) == 0 && ew_fits32(M, C4 / 8), PCM_EINVAL, "pcm_geglu_bwd: C4%%8, M*C4/8 < 2^31");
+  PCM_LAUNCH(geglu_bwd_kernel, dim3(ew_blocks_u((long)M * (C4 / 8))), dim3(256), 0, stream, (const uint4*)hg, (const uint4*)dout, (uint4*)dhg, M, C4 / 8);
   return pcm_post_launch("pcm_geglu_bwd");
 }
 

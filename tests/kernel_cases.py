@@ -84,6 +84,25 @@ def case_elementwise(dev):
     do = rnd(5, 64, seed=7, dev=dev)
     refg.backward(do.float().cpu())
     close(ops.geglu_bwd(hg, do), hr.grad, 1e-2, 2e-2, "geglu bwd")
+    # larger grids: several trips of the batched row/column walker per thread, ragged tail, odd column counts
+    a, b = rnd(301, 72, seed=13, dev=dev), rnd(301, 40, seed=14, dev=dev)
+    cat = ops.concat_channels(a, b)
+    assert torch.equal(cat.cpu(), torch.cat([a.cpu(), b.cpu()], -1))
+    acc = rnd(301, 72, seed=15, dev=dev)
+    acc0 = acc.clone()
+    a2, b2 = ops.split_channels(cat, 72, a_out=acc, accumulate_a=True)
+    assert torch.equal(b2.cpu(), b.cpu())
+    close(a2, acc0.float().cpu() + a.float().cpu(), 1e-2, 1e-2, "split acc (large)")
+    a3, b3 = ops.split_channels(cat, 72)
+    assert torch.equal(a3.cpu(), a.cpu()) and torch.equal(b3.cpu(), b.cpu())
+    hg = rnd(203, 2 * 104, seed=16, dev=dev)
+    hr = hg.float().cpu().requires_grad_(True)
+    h, g = hr.chunk(2, -1)
+    refg = h * F.gelu(g)
+    close(ops.geglu_fwd(hg), refg.detach(), 1e-2, 1e-2, "geglu (large)")
+    do = rnd(203, 104, seed=17, dev=dev)
+    refg.backward(do.float().cpu())
+    close(ops.geglu_bwd(hg, do), hr.grad, 1e-2, 2e-2, "geglu bwd (large)")
     xs = rnd(2, 37, 320, seed=8, dev=dev)
     close(ops.colsum(xs), xs.float().cpu().sum(1), 1e-4, 1e-3, "colsum")
     close(ops.cast_f32(ops.cast_bf16(xs.float())), xs, 0, 0, "cast")
