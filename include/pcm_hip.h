@@ -231,6 +231,28 @@ int pcm_cfg_ddim_step(const float* eps_c, const float* eps_u, const float* sampl
  * combine (eps_u may be NULL: guidance_scale <= 1) + x_{t-1} from x_t.  alpha_* are alphas_cumprod values; fp32 throughout. */
 int pcm_sampler_ddim_step(const float* eps_c, const float* eps_u, const float* x, float alpha_t, float alpha_prev, float guidance,
                           float* out, long n, void* stream);
+/* ---- flow-matching PCM math of the SD3 variant (paths under code/text_to_image_sd3/) ----------------------
+ * Tables as the reference's EulerSolver builds them (train_pcm_lora_sd3.py:158-175): sigmas float32 [E], sigmas_prev FLOAT64 [E]
+ * (np.asarray over python floats), so every result that touches sigma_prev is float64, like the reference's. */
+/* train_pcm_lora_sd3.py:1291,:1301   noisy = sigmas[index] * noise + (1 - sigmas[index]) * x   (float32) */
+int pcm_fm_add_noise(const float* x, const float* noise, const float* sigmas, const int64_t* index, float* out, int B,
+                     int per_sample, void* stream);
+/* EulerSolver.euler_style_multiphase_pred (:192-230): edges = floor(linspace(0, E, multiphase, endpoint=False)) on the device;
+ * end = last edge <= index[b]; out = sample + (sigmas_prev[end] - (target_mode ? sigmas_prev[index] : sigmas[index])) * model_pred
+ * (float64; out_f32 optional copy; end_index optional [B]).  sample is float32 (noisy input, :1313) or float64 (x_prev, :1368). */
+int pcm_fm_phase_jump(const void* sample, int sample_f64, const float* model_pred, const int64_t* index, const float* sigmas,
+                      const double* sigmas_prev, const int64_t* edges, int n_edges, int target_mode, double* out,
+                      float* out_f32, int64_t* end_index, int B, int per_sample, void* stream);
+/* teacher CFG with the fixed w (:1334, :1352-1354; uncond may be NULL: --not_apply_cfg_solver) + EulerSolver.euler_step (:184-190):
+ * x_prev = sample + (sigmas_prev[index] - sigmas[index]) * (cond + w * (cond - uncond))   (float64 + optional float32 copy) */
+int pcm_fm_cfg_euler_step(const float* cond, const float* uncond, const float* sample, const int64_t* index, float w,
+                          const float* sigmas, const double* sigmas_prev, double* x_prev, float* x_prev_f32, int B,
+                          int per_sample, void* stream);
+/* Inference: one step of PCMFMDeterministicScheduler.step (pcm_fm_deterministic_scheduler.py:225-233; noise == NULL) or
+ * PCMFMStochasticScheduler.step (pcm_fm_stochastic_scheduler.py:225-233; noise = the step's randn_like draw), float32. */
+int pcm_fm_sampler_step(const float* model_output, const float* sample, float sigma, float sigma_next, const float* noise,
+                        float* out, long n, void* stream);
+
 /* loss (l2 | huber, :1283-1293) forward + gradient wrt the student's eps prediction:
  * loss[0] = mean(...) (accumulated in fp64, zeroed by the call) ; d_eps = dloss/dmodel_pred * coef[b] * grad_scale */
 int pcm_consistency_loss(const float* model_pred, const float* target, const float* coef, int huber,

@@ -13,6 +13,9 @@ Slices used (reference file:line):
   scheduling_ddpm_modified.py:500-554  DDPMScheduler.add_noise / .noise_travel (method bodies
                                   lifted and bound to a stub that carries ``alphas_cumprod``)
   discriminator_sd15.py:348-434   DiscriminatorHead, Discriminator.d_loss/g_loss
+  text_to_image_sd3/train_pcm_lora_sd3.py:153-230  extract_into_tensor, EulerSolver (flow-matching PCM math)
+  text_to_image_sd3/pcm_fm_{deterministic,stochastic}_scheduler.py:35-242  the two sampler classes (bases and the
+                                  config decorator stripped; ``self.config`` supplied by a stub)
 """
 import ast
 import os
@@ -23,6 +26,7 @@ import torch
 
 REF_ROOT = "/root/reference"
 SD15_DIR = os.path.join(REF_ROOT, "code", "text_to_image_sd15")
+SD3_DIR = os.path.join(REF_ROOT, "code", "text_to_image_sd3")
 
 
 def available() -> bool:
@@ -93,3 +97,44 @@ def kohya_rename(peft_key: str, prefix: str = "lora_unet") -> str:
     k = k.replace("lora_B", "lora_up")
     k = k.replace(".", "_", k.count(".") - 2)
     return k
+
+
+def sd3_train_namespace():
+    """EulerSolver + extract_into_tensor of train_pcm_lora_sd3.py:153-230 as live objects."""
+    return _slice(os.path.join(SD3_DIR, "train_pcm_lora_sd3.py"), ["extract_into_tensor", "EulerSolver"])
+
+
+def sd3_flow_sigmas(num_train_timesteps=1000, shift=3.0):
+    """The sigma table the reference hands to EulerSolver: ``noise_scheduler.sigmas.numpy()[::-1]`` (train_pcm_lora_sd3.py:961-965).
+    diffusers' FlowMatchEulerDiscreteScheduler is not vendored; its constructor's table is the same expression the reference's own
+    samplers build at pcm_fm_deterministic_scheduler.py:47-52 (float32 linspace 1..N reversed, /N, shift*s/(1+(shift-1)*s));
+    shift = 3.0 is the SD3-medium scheduler config."""
+    t = np.linspace(1, num_train_timesteps, num_train_timesteps, dtype=np.float32)[::-1].copy()
+    sig = torch.from_numpy(t).to(torch.float32) / num_train_timesteps
+    sig = shift * sig / (1 + (shift - 1) * sig)
+    return sig.numpy()[::-1]
+
+
+def sd3_sampler_class(kind="deterministic"):
+    """PCMFMDeterministicScheduler / PCMFMStochasticScheduler with diffusers' mixins and config decorator stripped."""
+    import typing
+    fname = "pcm_fm_%s_scheduler.py" % kind
+    cname = "PCMFM%sScheduler" % kind.capitalize()
+    path = os.path.join(SD3_DIR, fname)
+    tree = ast.parse(open(path).read())
+    cls = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == cname][0]
+    cls.bases, cls.keywords = [], []
+    for n in cls.body:
+        if isinstance(n, ast.FunctionDef):
+            n.decorator_list = [d for d in n.decorator_list if not (isinstance(d, ast.Name) and d.id == "register_to_config")]
+    ns = {"torch": torch, "np": np, "Optional": typing.Optional, "Tuple": typing.Tuple, "Union": typing.Union,
+          cname + "Output": object}
+    exec(compile(ast.Module(body=[cls], type_ignores=[]), path, "exec"), ns)
+    base = ns[cname]
+
+    class Sampler(base):
+        def __init__(self, num_train_timesteps=1000, shift=1.0, pcm_timesteps=50):
+            self.config = types.SimpleNamespace(num_train_timesteps=num_train_timesteps, shift=shift, pcm_timesteps=pcm_timesteps)
+            super().__init__(num_train_timesteps, shift, pcm_timesteps)
+    Sampler.__name__ = cname
+    return Sampler

@@ -19,3 +19,10 @@ def pytest_configure(config):
 def golden():
     from safetensors.torch import load_file
     return load_file(os.path.join(ROOT, "tests", "golden", "pcm_math_golden.safetensors"))
+
+
+@pytest.fixture(scope="session")
+def golden_fm():
+    """flow-matching (SD3 variant) PCM math + samplers, tests/golden/make_golden_sd3.py"""
+    from safetensors.torch import load_file
+    return load_file(os.path.join(ROOT, "tests", "golden", "pcm_fm_golden.safetensors"))

@@ -1,5 +1,6 @@
 """Kernel parity cases shared by the host-emulation (CPU) and the GPU test files.  Every case
 compares the C-ABI op against plain torch fp32 evaluated on the SAME bf16-rounded inputs."""
+import pytest
 import torch
 import torch.nn.functional as F
 
@@ -546,3 +547,56 @@ def case_gemm_geglu(dev, M=300, K=128, inner=160):
     ref = h[:, :inner] * F.gelu(h[:, inner:])
     err = (out.float() - ref).abs()
     return float((err - (2e-2 + 1e-2 * ref.abs())).max())
+
+
+def case_pcm_fm_math(dev, g):
+    """flow-matching PCM math + samplers of the SD3 variant: BIT-EXACT against the reference's own source
+    (tests/golden/pcm_fm_golden.safetensors, generated by tests/golden/make_golden_sd3.py)."""
+    from pcm_amd import fm
+    sol = fm.EulerSolver(fm.flow_sigmas(1000, 3.0), 1000, 50, device=dev)
+    for k in ("euler_timesteps", "euler_timesteps_prev", "sigmas", "sigmas_prev"):
+        assert getattr(sol, k).dtype == g[k].dtype and torch.equal(getattr(sol, k).cpu(), g[k]), k
+    idx = g["index"].to(dev)
+    t, tp = sol.timesteps(idx)
+    assert torch.equal(t.cpu(), g["timesteps"]) and torch.equal(tp.cpu(), g["timesteps_prev"])
+    noisy = sol.add_noise(g["x"].to(dev), g["noise"].to(dev), idx)
+    assert torch.equal(noisy.cpu(), g["noisy"]), "fm add_noise"
+    pred = g["pred"].to(dev)
+    for M in (1, 2, 4, 8):
+        for tgt, name in ((False, "online"), (True, "target")):
+            xp, end = sol.euler_style_multiphase_pred(noisy, pred, idx, M, tgt)
+            assert xp.dtype == torch.float64 and torch.equal(xp.cpu(), g[f"{name}_{M}_x"]), (name, M)
+            assert torch.equal(end.cpu(), g[f"{name}_{M}_end"]), (name, M)
+    xp, xp32 = sol.euler_step(noisy, g["cond"].to(dev), idx, g["uncond"].to(dev), 3)
+    assert torch.equal(xp.cpu(), g["euler_step"]) and torch.equal(xp32.cpu(), g["euler_step"].float()), "fm cfg + euler_step"
+    xn, _ = sol.euler_step(noisy, g["teacher"].to(dev), idx, None)                       # --not_apply_cfg_solver: teacher used as is
+    assert torch.equal(xn.cpu(), g["euler_step"])
+    for M in (1, 4):
+        ct, end = sol.euler_style_multiphase_pred(xp, pred, idx, M, True)                  # float64 sample
+        assert torch.equal(ct.cpu(), g[f"chain_target_{M}_x"]) and torch.equal(end.cpu(), g[f"chain_target_{M}_end"]), M
+    # huber loss through the step's loss kernel (same expression as the SD1.5 trainer): value parity
+    B = idx.shape[0]
+    loss = torch.zeros(1, dtype=torch.float64, device=dev)
+    d = torch.empty_like(noisy)
+    a, b = g["online_4_x"].float().to(dev).contiguous(), g["target_4_x"].float().to(dev).contiguous()
+    ones = torch.ones(B, dtype=torch.float32, device=dev)
+    capi.lib().call("pcm_consistency_loss", ops.ptr(a), ops.ptr(b), ops.ptr(ones), 1, 0.001, ops.ptr(loss), ops.ptr(d), 1.0, B, a.numel() // B, capi.Lib.stream())
+    ref_d = (a - b).cpu() / torch.sqrt((a - b).cpu() ** 2 + 0.001 ** 2) / a.numel()
+    close(d, ref_d, 1e-4, 1e-9, "fm huber grad")
+    assert abs(float(loss) - float(g["huber_loss"])) <= 2e-6 * abs(float(g["huber_loss"])), (float(loss), float(g["huber_loss"]))
+    # samplers
+    for stochastic in (False, True):
+        kind = "stochastic" if stochastic else "deterministic"
+        for steps in (1, 2, 4, 8):
+            sm = fm.PCMFMSampler(1000, 3.0, 100, stochastic=stochastic)
+            sm.set_timesteps(steps, device=dev)
+            assert torch.equal(sm.timesteps.cpu(), g[f"sampler_timesteps_{steps}"]) and torch.equal(sm.sigmas_, g[f"sampler_sigmas_{steps}"])
+            lat = g[f"{kind}_{steps}_x0"].to(dev)
+            for i, tt in enumerate(sm.timesteps):
+                nz = g[f"{kind}_{steps}_noise{i}"].to(dev) if stochastic else None
+                lat = sm.step(g[f"{kind}_{steps}_v{i}"].to(dev), tt, lat, noise=nz)
+                assert torch.equal(lat.cpu(), g[f"{kind}_{steps}_x{i + 1}"]), (kind, steps, i)
+    with pytest.raises(ValueError):
+        sm2 = fm.PCMFMSampler(1000, 3.0, 100)
+        sm2.set_timesteps(2)
+        sm2.step(g["pred"][:1].to(dev), 3, g["x"][:1].to(dev))
