@@ -231,6 +231,28 @@ int pcm_cfg_ddim_step(const float* eps_c, const float* eps_u, const float* sampl
  * combine (eps_u may be NULL: guidance_scale <= 1) + x_{t-1} from x_t.  alpha_* are alphas_cumprod values; fp32 throughout. */
 int pcm_sampler_ddim_step(const float* eps_c, const float* eps_u, const float* x, float alpha_t, float alpha_prev, float guidance,
                           float* out, long n, void* stream);
+/* ---- MMDiT block pieces of the SD3 variant.  The transformer is diffusers' SD3Transformer2DModel (un-vendored
+ * dependency, pinned by code/text_to_image_sd3/environment.sd3.yaml); its call order is witnessed in-repo by the copied forward at
+ * code/text_to_image_sd3/discriminator_sd3.py:73-137 (pos_embed -> time_text_embed -> context_embedder -> JointTransformerBlocks ->
+ * norm_out -> proj_out -> unpatchify). ---------------------------------------------------------------------------------------- */
+/* AdaLayerNormZero / AdaLayerNormContinuous: LayerNorm without affine, then y = xhat * gamma[b] + beta[b] (gamma = 1 + scale, beta = shift,
+ * fp32 [B][C]; rows_per_batch consecutive rows share one pair).  bwd: input gradient only (+ optional accumulate of dres). */
+int pcm_layernorm_mod_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int M, int C,
+                          float eps, int rows_per_batch, void* stream);
+int pcm_layernorm_mod_bwd(const void* x, const void* dy, const float* gamma, const float* mean, const float* rstd, const void* dres,
+                          void* dx, int M, int C, int rows_per_batch, void* stream);
+/* gated residual of the adaLN-Zero block: out = (res ? res : 0) + gate[b] * y   (bf16 [M][C], gate fp32 [B][C]) */
+int pcm_rowgate_fma(const void* y, const float* gate, const void* res, void* out, int M, int C, int rows_per_batch, void* stream);
+/* FeedForward(activation_fn="gelu-approximate") */
+int pcm_gelu_tanh_fwd(const void* x, void* y, long n, void* stream);
+int pcm_gelu_tanh_bwd(const void* x, const void* dy, void* dx, long n, void* stream);
+/* PatchEmbed's Conv2d(k=2, s=2) as a GEMM: fp32 NCHW image -> bf16 token rows [B*(H/2)*(W/2)][4C], column order 0 = (c,p,q) (conv weight),
+ * 1 = (p,q,c) (the unpatchify einsum "nhwpqc->nchpwq", discriminator_sd3.py:112-131); and the inverse for order 1 in fp32. */
+int pcm_patchify2x2(const float* img, void* tokens, int B, int C, int H, int W, int order, void* stream);
+int pcm_unpatchify2x2(const float* tokens, float* img, int B, int C, int H, int W, void* stream);
+/* sinusoidal projection of FLOAT timesteps (sigma * 1000, train_pcm_lora_sd3.py:1295-1300), flip_sin_to_cos, shift 0 -> bf16 [B][dim] */
+int pcm_timestep_embedding_f32(const float* t, void* out, int B, int dim, void* stream);
+
 /* ---- flow-matching PCM math of the SD3 variant (paths under code/text_to_image_sd3/) ----------------------
  * Tables as the reference's EulerSolver builds them (train_pcm_lora_sd3.py:158-175): sigmas float32 [E], sigmas_prev FLOAT64 [E]
  * (np.asarray over python floats), so every result that touches sigma_prev is float64, like the reference's. */

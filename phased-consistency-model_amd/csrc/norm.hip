@@ -418,7 +418,7 @@ extern "C" int pcm_groupnorm_bwd_apply(const void* x, const void* dy, const doub
 // ------------------------------------------------------------------------------------------
 template <int VPL, int R>  // 16-byte vectors per lane: C <= 512*VPL; R rows per wave with all their loads issued together
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* x, const float* gamma, const float* beta, bf16_t* y,
-                                                     float* mean, float* rstd, int M, int C, float eps) {
+                                                     float* mean, float* rstd, int M, int C, float eps, int rpb) {
   const int lane = threadIdx.x & 63, row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
   if (row0 >= M) return;
   const int CV = C / 8;
@@ -461,8 +461,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* x, const floa
       int cv = lane + 64 * i;
       if (cv < CV) {
         float o[8];
-        float4 g0 = *(const float4*)(gamma + cv * 8), g1 = *(const float4*)(gamma + cv * 8 + 4);
-        float4 b0 = *(const float4*)(beta + cv * 8), b1 = *(const float4*)(beta + cv * 8 + 4);
+        const size_t po = (rpb > 0 ? (size_t)(row / rpb) * C : 0) + cv * 8;   // rpb > 0: per-sample affine rows (adaLN modulation)
+        float4 g0 = *(const float4*)(gamma + po), g1 = *(const float4*)(gamma + po + 4);
+        float4 b0 = *(const float4*)(beta + po), b1 = *(const float4*)(beta + po + 4);
         const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
         const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
@@ -476,7 +477,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* x, const floa
 // dx = rstd * (dy*g - mean(dy*g) - xhat * mean(dy*g*xhat)) (+ dres)
 template <int VPL>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* x, const bf16_t* dy, const float* gamma, const float* mean,
-                                                     const float* rstd, const bf16_t* dres, bf16_t* dx, int M, int C) {
+                                                     const float* rstd, const bf16_t* dres, bf16_t* dx, int M, int C, int rpb) {
   const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
   const int CV = C / 8;
@@ -490,7 +491,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* x, const bf16
       float xv[8], dv[8];
       unpack8(*(const uint4*)(x + (size_t)row * C + cv * 8), xv);
       unpack8(*(const uint4*)(dy + (size_t)row * C + cv * 8), dv);
-      float4 g0 = *(const float4*)(gamma + cv * 8), g1 = *(const float4*)(gamma + cv * 8 + 4);
+      const size_t po = (rpb > 0 ? (size_t)(row / rpb) * C : 0) + cv * 8;
+      float4 g0 = *(const float4*)(gamma + po), g1 = *(const float4*)(gamma + po + 4);
       const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
 #pragma unroll
       for (int e = 0; e < 8; e++) {
@@ -519,28 +521,48 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* x, const bf16
   }
 }
 
-extern "C" int pcm_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean,
-                                 float* rstd, int M, int C, float eps, void* stream) {
-  PCM_CHECK(x && gamma && beta && y && mean && rstd && M > 0 && C > 0 && (C % 8) == 0 && C <= 2048, PCM_EINVAL,
-            "pcm_layernorm_fwd: need C%%8==0, C<=2048 (M=%d C=%d)", M, C);
-  PCM_CHECK(PCM_ALIGNED16(x) && PCM_ALIGNED16(y) && PCM_ALIGNED16(gamma) && PCM_ALIGNED16(beta), PCM_EALIGN, "pcm_layernorm_fwd: alignment");
+static int ln_fwd_launch(const char* what, const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int M,
+                         int C, float eps, int rpb, void* stream) {
+  PCM_CHECK(x && gamma && beta && y && mean && rstd && M > 0 && C > 0 && (C % 8) == 0 && C <= 2048 && rpb >= 0, PCM_EINVAL,
+            "%s: need C%%8==0, C<=2048 (M=%d C=%d)", what, M, C);
+  PCM_CHECK(PCM_ALIGNED16(x) && PCM_ALIGNED16(y) && PCM_ALIGNED16(gamma) && PCM_ALIGNED16(beta), PCM_EALIGN, "%s: alignment", what);
   dim3 block(256);
-  if (C <= 512) PCM_LAUNCH((ln_fwd_kernel<1, 4>), dim3((M + 15) / 16), block, 0, stream, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, M, C, eps);
-  else if (C <= 1024) PCM_LAUNCH((ln_fwd_kernel<2, 4>), dim3((M + 15) / 16), block, 0, stream, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, M, C, eps);
-  else PCM_LAUNCH((ln_fwd_kernel<4, 2>), dim3((M + 7) / 8), block, 0, stream, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, M, C, eps);
-  return pcm_post_launch("pcm_layernorm_fwd");
+  if (C <= 512) PCM_LAUNCH((ln_fwd_kernel<1, 4>), dim3((M + 15) / 16), block, 0, stream, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, M, C, eps, rpb);
+  else if (C <= 1024) PCM_LAUNCH((ln_fwd_kernel<2, 4>), dim3((M + 15) / 16), block, 0, stream, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, M, C, eps, rpb);
+  else PCM_LAUNCH((ln_fwd_kernel<4, 2>), dim3((M + 7) / 8), block, 0, stream, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, M, C, eps, rpb);
+  return pcm_post_launch(what);
+}
+static int ln_bwd_launch(const char* what, const void* x, const void* dy, const float* gamma, const float* mean, const float* rstd,
+                         const void* dres, void* dx, int M, int C, int rpb, void* stream) {
+  PCM_CHECK(x && dy && gamma && mean && rstd && dx && M > 0 && C > 0 && (C % 8) == 0 && C <= 2048 && rpb >= 0, PCM_EINVAL,
+            "%s: need C%%8==0, C<=2048 (M=%d C=%d)", what, M, C);
+  PCM_CHECK(PCM_ALIGNED16(x) && PCM_ALIGNED16(dy) && PCM_ALIGNED16(dx) && PCM_ALIGNED16(gamma) && (!dres || PCM_ALIGNED16(dres)), PCM_EALIGN, "%s: alignment", what);
+  dim3 grid((M + 3) / 4), block(256);
+  if (C <= 512) PCM_LAUNCH((ln_bwd_kernel<1>), grid, block, 0, stream, (const bf16_t*)x, (const bf16_t*)dy, gamma, mean, rstd, (const bf16_t*)dres, (bf16_t*)dx, M, C, rpb);
+  else if (C <= 1024) PCM_LAUNCH((ln_bwd_kernel<2>), grid, block, 0, stream, (const bf16_t*)x, (const bf16_t*)dy, gamma, mean, rstd, (const bf16_t*)dres, (bf16_t*)dx, M, C, rpb);
+  else PCM_LAUNCH((ln_bwd_kernel<4>), grid, block, 0, stream, (const bf16_t*)x, (const bf16_t*)dy, gamma, mean, rstd, (const bf16_t*)dres, (bf16_t*)dx, M, C, rpb);
+  return pcm_post_launch(what);
 }
 
+extern "C" int pcm_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean,
+                                 float* rstd, int M, int C, float eps, void* stream) {
+  return ln_fwd_launch("pcm_layernorm_fwd", x, gamma, beta, y, mean, rstd, M, C, eps, 0, stream);
+}
 extern "C" int pcm_layernorm_bwd(const void* x, const void* dy, const float* gamma, const float* mean, const float* rstd,
                                  const void* dres, void* dx, int M, int C, void* stream) {
-  PCM_CHECK(x && dy && gamma && mean && rstd && dx && M > 0 && C > 0 && (C % 8) == 0 && C <= 2048, PCM_EINVAL,
-            "pcm_layernorm_bwd: need C%%8==0, C<=2048 (M=%d C=%d)", M, C);
-  PCM_CHECK(PCM_ALIGNED16(x) && PCM_ALIGNED16(dy) && PCM_ALIGNED16(dx) && PCM_ALIGNED16(gamma) && (!dres || PCM_ALIGNED16(dres)), PCM_EALIGN, "pcm_layernorm_bwd: alignment");
-  dim3 grid((M + 3) / 4), block(256);
-  if (C <= 512) PCM_LAUNCH((ln_bwd_kernel<1>), grid, block, 0, stream, (const bf16_t*)x, (const bf16_t*)dy, gamma, mean, rstd, (const bf16_t*)dres, (bf16_t*)dx, M, C);
-  else if (C <= 1024) PCM_LAUNCH((ln_bwd_kernel<2>), grid, block, 0, stream, (const bf16_t*)x, (const bf16_t*)dy, gamma, mean, rstd, (const bf16_t*)dres, (bf16_t*)dx, M, C);
-  else PCM_LAUNCH((ln_bwd_kernel<4>), grid, block, 0, stream, (const bf16_t*)x, (const bf16_t*)dy, gamma, mean, rstd, (const bf16_t*)dres, (bf16_t*)dx, M, C);
-  return pcm_post_launch("pcm_layernorm_bwd");
+  return ln_bwd_launch("pcm_layernorm_bwd", x, dy, gamma, mean, rstd, dres, dx, M, C, 0, stream);
+}
+// adaLN (AdaLayerNormZero / AdaLayerNormContinuous of the MMDiT blocks): LayerNorm without learned affine followed by a per-SAMPLE
+// modulation y = xhat * gamma[b] + beta[b] with gamma = 1 + scale, beta = shift ([B][C] fp32, rows_per_batch rows share one pair)
+extern "C" int pcm_layernorm_mod_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int M, int C,
+                                     float eps, int rows_per_batch, void* stream) {
+  PCM_CHECK(rows_per_batch > 0 && (M % rows_per_batch) == 0, PCM_EINVAL, "pcm_layernorm_mod_fwd: M must be B*rows_per_batch");
+  return ln_fwd_launch("pcm_layernorm_mod_fwd", x, gamma, beta, y, mean, rstd, M, C, eps, rows_per_batch, stream);
+}
+extern "C" int pcm_layernorm_mod_bwd(const void* x, const void* dy, const float* gamma, const float* mean, const float* rstd, const void* dres,
+                                     void* dx, int M, int C, int rows_per_batch, void* stream) {
+  PCM_CHECK(rows_per_batch > 0 && (M % rows_per_batch) == 0, PCM_EINVAL, "pcm_layernorm_mod_bwd: M must be B*rows_per_batch");
+  return ln_bwd_launch("pcm_layernorm_mod_bwd", x, dy, gamma, mean, rstd, dres, dx, M, C, rows_per_batch, stream);
 }
 
 // ---- GroupNorm affine-parameter gradients (discriminator heads: their norms ARE trainable) ----

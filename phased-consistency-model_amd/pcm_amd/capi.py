@@ -86,6 +86,14 @@ _PROTOS = {
     "pcm_add_noise": [vp, vp, vp, vp, vp, i32, i32, vp],
     "pcm_phase_jump": [vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, i32, i32, vp],
     "pcm_sampler_ddim_step": [vp, vp, vp, f32, f32, f32, vp, C.c_long, vp],
+    "pcm_layernorm_mod_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, f32, i32, vp],
+    "pcm_layernorm_mod_bwd": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
+    "pcm_rowgate_fma": [vp, vp, vp, vp, i32, i32, i32, vp],
+    "pcm_gelu_tanh_fwd": [vp, vp, C.c_long, vp],
+    "pcm_gelu_tanh_bwd": [vp, vp, vp, C.c_long, vp],
+    "pcm_patchify2x2": [vp, vp, i32, i32, i32, i32, i32, vp],
+    "pcm_unpatchify2x2": [vp, vp, i32, i32, i32, i32, vp],
+    "pcm_timestep_embedding_f32": [vp, vp, i32, i32, vp],
     "pcm_fm_add_noise": [vp, vp, vp, vp, vp, i32, i32, vp],
     "pcm_fm_phase_jump": [vp, i32, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, i32, i32, vp],
     "pcm_fm_cfg_euler_step": [vp, vp, vp, vp, f32, vp, vp, vp, vp, i32, i32, vp],

@@ -259,6 +259,65 @@ def timestep_embedding(t, dim):
     return out
 
 
+# ---- MMDiT (SD3 variant) block pieces ----
+def layernorm_mod_fwd(x, gamma, beta, rows_per_batch, eps=1e-6):
+    """adaLN: LayerNorm(no affine) then per-sample y = xhat * gamma[b] + beta[b]; gamma/beta fp32 [B, C]."""
+    M, Cc = x.numel() // x.shape[-1], x.shape[-1]
+    y = torch.empty_like(x)
+    mean = torch.empty(M, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(M, dtype=torch.float32, device=x.device)
+    capi.lib().call("pcm_layernorm_mod_fwd", ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(rstd), M, Cc, eps, rows_per_batch, _stream())
+    return y, mean, rstd
+
+
+def layernorm_mod_bwd(x, dy, gamma, mean, rstd, rows_per_batch, dres=None):
+    M, Cc = x.numel() // x.shape[-1], x.shape[-1]
+    dx = torch.empty_like(x)
+    capi.lib().call("pcm_layernorm_mod_bwd", ptr(x), ptr(dy), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(dx), M, Cc, rows_per_batch, _stream())
+    return dx
+
+
+def rowgate_fma(y, gate, rows_per_batch, res=None):
+    """(res or 0) + gate[b] * y ; y/res bf16 [M, C], gate fp32 [B, C]."""
+    M, Cc = y.numel() // y.shape[-1], y.shape[-1]
+    out = torch.empty_like(y)
+    capi.lib().call("pcm_rowgate_fma", ptr(y), ptr(gate), ptr(res), ptr(out), M, Cc, rows_per_batch, _stream())
+    return out
+
+
+def gelu_tanh_fwd(x):
+    y = torch.empty_like(x)
+    capi.lib().call("pcm_gelu_tanh_fwd", ptr(x), ptr(y), x.numel(), _stream())
+    return y
+
+
+def gelu_tanh_bwd(x, dy):
+    dx = torch.empty_like(x)
+    capi.lib().call("pcm_gelu_tanh_bwd", ptr(x), ptr(dy), ptr(dx), x.numel(), _stream())
+    return dx
+
+
+def patchify2x2(img, order):
+    """fp32 [B,C,H,W] -> bf16 [B*(H/2)*(W/2), 4C]; order 0 = (c,p,q) columns, 1 = (p,q,c)."""
+    B, Cc, H, W = img.shape
+    out = torch.empty(B * (H // 2) * (W // 2), 4 * Cc, dtype=BF16, device=img.device)
+    capi.lib().call("pcm_patchify2x2", ptr(img), ptr(out), B, Cc, H, W, order, _stream())
+    return out
+
+
+def unpatchify2x2(tokens, B, Cc, H, W):
+    """fp32 [B*(H/2)*(W/2), 4C] in (p,q,c) column order -> fp32 [B,C,H,W]."""
+    img = torch.empty(B, Cc, H, W, dtype=torch.float32, device=tokens.device)
+    capi.lib().call("pcm_unpatchify2x2", ptr(tokens), ptr(img), B, Cc, H, W, _stream())
+    return img
+
+
+def timestep_embedding_f32(t, dim):
+    out = torch.empty(t.shape[0], dim, dtype=BF16, device=t.device)
+    capi.lib().call("pcm_timestep_embedding_f32", ptr(t), ptr(out), t.shape[0], dim, _stream())
+    return out
+
+
 def cast_bf16(x):
     y = torch.empty(x.shape, dtype=BF16, device=x.device)
     capi.lib().call("pcm_cast_f32_bf16", ptr(x), ptr(y), x.numel(), _stream())

@@ -1,5 +1,7 @@
 """Kernel parity cases shared by the host-emulation (CPU) and the GPU test files.  Every case
 compares the C-ABI op against plain torch fp32 evaluated on the SAME bf16-rounded inputs."""
+import math
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -600,3 +602,53 @@ def case_pcm_fm_math(dev, g):
         sm2 = fm.PCMFMSampler(1000, 3.0, 100)
         sm2.set_timesteps(2)
         sm2.step(g["pred"][:1].to(dev), 3, g["x"][:1].to(dev))
+
+
+def case_mmdit_ops(dev):
+    """element-wise pieces of the MMDiT blocks (SD3 variant) against plain torch fp32."""
+    B, L, C = 3, 13, 192
+    x = rnd(B * L, C, seed=1, dev=dev, shift=0.2)
+    dy = rnd(B * L, C, seed=2, dev=dev)
+    scale = rnd(B, C, seed=3, dev=dev, dtype=torch.float32, scale=0.3)
+    shift = rnd(B, C, seed=4, dev=dev, dtype=torch.float32, scale=0.3)
+    gamma = (1.0 + scale).contiguous()
+    y, mean, rstd = ops.layernorm_mod_fwd(x, gamma, shift, L, eps=1e-6)
+    xr = x.float().cpu().view(B, L, C).requires_grad_(True)
+    ref = F.layer_norm(xr, (C,), eps=1e-6) * (1 + scale.cpu()[:, None, :]) + shift.cpu()[:, None, :]
+    close(y.view(B, L, C), ref.detach(), 1e-2, 1e-2, "adaLN fwd")
+    ref.backward(dy.float().cpu().view(B, L, C))
+    dres = rnd(B * L, C, seed=5, dev=dev)
+    dx = ops.layernorm_mod_bwd(x, dy, gamma, mean, rstd, L, dres=dres)
+    close(dx.view(B, L, C), xr.grad + dres.float().cpu().view(B, L, C), 1e-2, 2e-2, "adaLN bwd")
+    gate = rnd(B, C, seed=6, dev=dev, dtype=torch.float32)
+    res = rnd(B * L, C, seed=7, dev=dev)
+    out = ops.rowgate_fma(dy, gate, L, res=res)
+    close(out.view(B, L, C), res.float().cpu().view(B, L, C) + gate.cpu()[:, None, :] * dy.float().cpu().view(B, L, C), 1e-2, 1e-2, "gate fma")
+    out = ops.rowgate_fma(dy, gate, L)
+    close(out.view(B, L, C), gate.cpu()[:, None, :] * dy.float().cpu().view(B, L, C), 1e-2, 1e-2, "gate mul")
+    h = rnd(257, 136, seed=8, dev=dev, scale=1.5)
+    hr = h.float().cpu().requires_grad_(True)
+    refg = F.gelu(hr, approximate="tanh")
+    close(ops.gelu_tanh_fwd(h), refg.detach(), 1e-2, 1e-2, "gelu tanh")
+    dh = rnd(257, 136, seed=9, dev=dev)
+    refg.backward(dh.float().cpu())
+    close(ops.gelu_tanh_bwd(h, dh), hr.grad, 1e-2, 2e-2, "gelu tanh bwd")
+    # patchify: order 0 == Conv2d(k=2, s=2) im2col, order 1 == inverse of the unpatchify einsum
+    Bi, Ci, H, W = 2, 16, 6, 10
+    img = rnd(Bi, Ci, H, W, seed=10, dev=dev, dtype=torch.float32)
+    tok0 = ops.patchify2x2(img, 0)
+    refu = F.unfold(img.cpu().to(torch.bfloat16).float(), kernel_size=2, stride=2).transpose(1, 2).reshape(Bi * (H // 2) * (W // 2), 4 * Ci)
+    assert torch.equal(tok0.float().cpu(), refu), "patchify (c,p,q)"
+    tok1 = ops.patchify2x2(img, 1)
+    back = ops.unpatchify2x2(tok1.float(), Bi, Ci, H, W)
+    assert torch.equal(back.cpu(), img.cpu().to(torch.bfloat16).float()), "patchify (p,q,c) / unpatchify roundtrip"
+    tk = rnd(Bi * (H // 2) * (W // 2), 4 * Ci, seed=11, dev=dev, dtype=torch.float32)
+    hs = tk.cpu().reshape(Bi, H // 2, W // 2, 2, 2, Ci)
+    refimg = torch.einsum("nhwpqc->nchpwq", hs).reshape(Bi, Ci, H, W)                     # discriminator_sd3.py:112-131
+    assert torch.equal(ops.unpatchify2x2(tk, Bi, Ci, H, W).cpu(), refimg), "unpatchify einsum"
+    t = torch.tensor([999.97, 500.25, 3.0, 57.7], device=dev)
+    emb = ops.timestep_embedding_f32(t, 256)
+    half = 128
+    fr = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half)
+    arg = t.cpu()[:, None] * fr[None, :]
+    close(emb, torch.cat([torch.cos(arg), torch.sin(arg)], -1), 1e-2, 1e-2, "timestep f32")

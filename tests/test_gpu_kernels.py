@@ -44,6 +44,10 @@ def test_pcm_math_bit_exact_vs_reference_golden(golden):
     K.case_pcm_math("cuda", golden)
 
 
+def test_mmdit_ops():
+    K.case_mmdit_ops("cuda")
+
+
 def test_pcm_fm_math_bit_exact_vs_reference_golden(golden_fm):
     K.case_pcm_fm_math("cuda", golden_fm)
 
