@@ -37,7 +37,7 @@ def kohya_state_dict(peft_sd, lora_alpha, prefix="lora_unet", dtype=torch.float1
 
 def adapter_config(lora):
     """The fields peft 0.9 writes for LoraConfig(r, target_modules) (:866-884)."""
-    return {"peft_type": "LORA", "task_type": None, "base_model_name_or_path": None, "r": lora.rank,
+    return {"peft_type": "LORA", "task_type": None, "base_model_name_or_path": None, "r": lora.real_rank,
             "lora_alpha": lora.alpha, "lora_dropout": 0.0, "bias": "none", "fan_in_fan_out": False,
             "init_lora_weights": True, "inference_mode": True, "target_modules": list(LORA_TARGETS),
             "modules_to_save": None, "rank_pattern": {}, "alpha_pattern": {}, "use_rslora": False, "revision": None,

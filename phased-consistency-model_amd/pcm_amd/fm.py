@@ -8,7 +8,7 @@ with the arithmetic in the HIP kernels of csrc/pcm_fm_math.hip (bit-exact agains
 vectors of tests/golden/pcm_fm_golden.safetensors).  The tables are built once on the host exactly as the reference builds
 them -- including ``sigmas_prev`` being float64 -- and live on the device; no per-step numpy / H2D traffic.
 
-The MMDiT transformer itself (SD3Transformer2DModel) is not part of this round.
+The transformer these expressions wrap is pcm_amd/mmdit.py; the step that strings them together is pcm_amd/trainer_sd3.py.
 """
 import numpy as np
 import torch
@@ -71,8 +71,9 @@ class EulerSolver:
                         ptr(xp), ptr(xp32), B, s.numel() // B, _stream())
         return xp, xp32
 
-    def euler_style_multiphase_pred(self, sample, model_pred, timestep_index, multiphase, is_target=False):
-        """:192-230 -> (x float64, timestep_index_end); ``sample`` float32 (noisy input) or float64 (x_prev)."""
+    def euler_style_multiphase_pred(self, sample, model_pred, timestep_index, multiphase, is_target=False, with_f32=False):
+        """:192-230 -> (x float64, timestep_index_end); ``sample`` float32 (noisy input) or float64 (x_prev).
+        ``with_f32``: also return the float32 copy the loss consumes (``.float()``, :1376) -> (x64, end, x32)."""
         B = sample.shape[0]
         s = sample.contiguous()
         assert s.dtype in (torch.float32, torch.float64)
@@ -80,10 +81,11 @@ class EulerSolver:
         e = self.edges(multiphase)
         out = torch.empty(s.shape, dtype=torch.float64, device=s.device)
         end = torch.empty(B, dtype=torch.int64, device=s.device)
+        out32 = torch.empty(s.shape, dtype=torch.float32, device=s.device) if with_f32 else None
         capi.lib().call("pcm_fm_phase_jump", ptr(s), 1 if s.dtype == torch.float64 else 0, ptr(p), ptr(timestep_index), ptr(self.sigmas),
-                        ptr(self.sigmas_prev), ptr(e), int(e.numel()), 1 if is_target else 0, ptr(out), None, ptr(end), B,
+                        ptr(self.sigmas_prev), ptr(e), int(e.numel()), 1 if is_target else 0, ptr(out), ptr(out32), ptr(end), B,
                         s.numel() // B, _stream())
-        return out, end
+        return (out, end, out32) if with_f32 else (out, end)
 
 
 class PCMFMSampler:

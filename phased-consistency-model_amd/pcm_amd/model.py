@@ -120,12 +120,19 @@ class LoraState:
     (+ grads + Adam moments), plus the bf16 operand copies the kernels read.
     scaling = lora_alpha / r (peft default lora_alpha = 8; LoraConfig at :866 does not set it)."""
 
-    def __init__(self, cfg: UNetConfig, rank=64, lora_alpha=8.0, device="cuda", seed=1, b_std=0.0):
-        if rank != 64:
-            raise ValueError("pcm_amd: the HIP LoRA kernels are built for rank 64 (reference recipe --lora_rank=64)")
-        self.cfg, self.rank, self.alpha, self.scaling = cfg, rank, lora_alpha, lora_alpha / rank
+    def __init__(self, cfg, rank=64, lora_alpha=8.0, device="cuda", seed=1, b_std=0.0, targets=None, init="kaiming"):
+        """``targets``: [(module path, weight shape)] (default: the UNet's 14 patterns for ``cfg``).  ``rank`` <= 64: the HIP LoRA
+        kernels are rank-64; a smaller rank (SD3 recipe: 32) is stored ZERO-PADDED to 64 -- the padded rows of A / columns of B get
+        exactly zero gradients (t_pad = x A_pad^T = 0, u_pad = dy B_pad = 0) and AdamW leaves exact zeros at zero, so the padded
+        factors ARE the rank-``rank`` factors; checkpoints carry the real rank.  ``init``: "kaiming" (peft default, SD1.5/SDXL
+        recipes) or "gaussian" (init_lora_weights="gaussian", train_pcm_lora_sd3.py:977: A ~ N(0, 1/r))."""
+        if not (0 < rank <= 64):
+            raise ValueError("pcm_amd: the HIP LoRA kernels are built for rank <= 64 (reference recipes: 64, SD3 32)")
+        self.real_rank = rank
+        rank = 64
+        self.cfg, self.rank, self.alpha, self.scaling = cfg, rank, lora_alpha, lora_alpha / self.real_rank
         self.device = torch.device(device)
-        targets = lora_target_modules(cfg)
+        targets = targets if targets is not None else lora_target_modules(cfg)
         total = 0
         layout = []
         for path, shp in targets:
@@ -157,14 +164,20 @@ class LoraState:
             m.B = self.params[ob:ob + shp[0] * rank].view(b_shape)
             m.gA = self.grads[oa:oa + rank * ain].view(a_shape)
             m.gB = self.grads[ob:ob + shp[0] * rank].view(b_shape)
-            # peft init: kaiming_uniform_(A, a=sqrt(5)) == U(+-1/sqrt(fan_in)); B = 0
+            # peft init: kaiming_uniform_(A, a=sqrt(5)) == U(+-1/sqrt(fan_in)) or N(0, 1/r) ("gaussian"); B = 0
             bound = 1.0 / math.sqrt(ain)
+            rr = self.real_rank
+
+            def draw(shape):
+                if init == "gaussian":
+                    return torch.randn(shape, generator=g) / rr
+                return (torch.rand(shape, generator=g) * 2 - 1) * bound
             if m.kind == "conv3":   # draw in peft shape [r, C, 3, 3] (same RNG stream as peft order), store permuted
-                m.A.copy_(((torch.rand((rank, shp[1], 3, 3), generator=g) * 2 - 1) * bound).permute(0, 2, 3, 1).to(self.device))
+                m.A[:rr].copy_(draw((rr, shp[1], 3, 3)).permute(0, 2, 3, 1).to(self.device))
             else:
-                m.A.copy_(((torch.rand(a_shape, generator=g) * 2 - 1) * bound).to(self.device))
+                m.A[:rr].copy_(draw((rr,) + tuple(a_shape[1:])).to(self.device))
             if b_std > 0:
-                m.B.copy_((torch.randn(b_shape, generator=g) * b_std).to(self.device))
+                m.B[:, :rr].copy_((torch.randn((b_shape[0], rr) + tuple(b_shape[2:]), generator=g) * b_std).to(self.device))
             self.modules[path] = m
         # bf16 MFMA operand copies of every factor in ONE flat buffer, refreshed by ONE segmented-pack launch
         import ctypes as C
@@ -260,16 +273,18 @@ class LoraState:
     # ---- checkpoint formats (train_pcm_lora_sd15.py:52-72, :918-944, :1374-1382) ----
     def peft_state_dict(self):
         out = OrderedDict()
+        rr = self.real_rank
         for p, m in self.modules.items():
-            out[f"base_model.model.{p}.lora_A.weight"] = self.A_peft(m).detach().clone()
-            out[f"base_model.model.{p}.lora_B.weight"] = m.B.detach().clone()
+            out[f"base_model.model.{p}.lora_A.weight"] = self.A_peft(m)[:rr].detach().clone()
+            out[f"base_model.model.{p}.lora_B.weight"] = m.B[:, :rr].detach().clone()
         return out
 
     def load_peft_state_dict(self, sd):
+        rr = self.real_rank
         for p, m in self.modules.items():
             a = sd[f"base_model.model.{p}.lora_A.weight"].to(self.device)
-            m.A.copy_(a.permute(0, 2, 3, 1) if m.kind == "conv3" else a.view_as(m.A))
-            m.B.copy_(sd[f"base_model.model.{p}.lora_B.weight"].to(self.device).view_as(m.B))
+            m.A[:rr].copy_(a.permute(0, 2, 3, 1) if m.kind == "conv3" else a.view_as(m.A[:rr]))
+            m.B[:, :rr].copy_(sd[f"base_model.model.{p}.lora_B.weight"].to(self.device).view_as(m.B[:, :rr]))
         self.repack()
 
 

@@ -1,0 +1,101 @@
+"""MMDiT / SD3-step parity cases shared by the host-emulation (CPU) and the GPU test files."""
+import torch
+
+
+def run_case(dev):
+    from oracle import mmdit_sd3 as O
+    from pcm_amd.mmdit import MMDiT, MMDiTWeights, sd3_lora_state
+    from pcm_amd.mmdit_spec import MMDiTConfig
+    kw = dict(sample_size=16, num_layers=3, attention_head_dim=64, num_attention_heads=2, joint_attention_dim=96, caption_projection_dim=128,
+              pooled_projection_dim=64, pos_embed_max_size=12)
+    oc, pc = O.MMDiTConfig(**kw), MMDiTConfig(**kw)
+    sd = O.init_state_dict(oc, 0)
+    B, H, Wd, Lc = 2, 8, 12, 7
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(B, 16, H, Wd, generator=g)
+    t = torch.tensor([901.25, 57.5])
+    ctx = torch.randn(B, Lc, 96, generator=g)
+    pooled = torch.randn(B, 64, generator=g)
+    d_out = torch.randn(B, 16, H, Wd, generator=g)
+    W = MMDiTWeights(pc, {k: v.to(dev) for k, v in sd.items()}, dev)
+    lora = sd3_lora_state(pc, 32, 8.0, dev, seed=1, b_std=0.1)
+    assert lora.real_rank == 32 and lora.rank == 64 and abs(lora.scaling - 0.25) < 1e-12
+    olora = {p: (m.A[:32].detach().cpu().clone().requires_grad_(True), m.B[:, :32].detach().cpu().clone().requires_grad_(True)) for p, m in lora.modules.items()}
+    assert set(olora) == {p for p, _ in O.lora_target_modules(oc)}
+    assert all(float(m.A[32:].abs().max()) == 0.0 and float(m.B[:, 32:].abs().max()) == 0.0 for m in lora.modules.values())
+    ref_t = O.mmdit_forward(oc, sd, x, t, ctx, pooled)
+    ref_s = O.mmdit_forward(oc, sd, x, t, ctx, pooled, olora, 8.0)
+    xd, td, cd, pd = x.to(dev), t.to(dev), ctx.to(dev), pooled.to(dev)
+    out_t = MMDiT(W, None).forward(xd, td, cd, pd)
+    student = MMDiT(W, lora)
+    out_s, tape = student.forward(xd, td, cd, pd, save=True)
+    scale = ref_t.abs().max().item()
+    err_t = (out_t.cpu() - ref_t).abs().max().item()
+    err_s = (out_s.cpu() - ref_s.detach()).abs().max().item()
+    effect = (ref_s - ref_t).abs().max().item()
+    print("fwd err teacher %.3e student %.3e (scale %.3e), lora effect %.3e" % (err_t, err_s, scale, effect))
+    assert err_t < 0.03 * scale and err_s < 0.03 * scale
+    assert effect > 5 * err_s, "LoRA branch not exercised"
+    (ref_s * d_out).sum().backward()
+    lora.zero_grad()
+    student.backward(d_out.to(dev), tape)
+    num = den = 0.0
+    worst = 0.0
+    for p, m in lora.modules.items():
+        assert float(m.gA[32:].abs().max()) == 0.0 and float(m.gB[:, 32:].abs().max()) == 0.0, "padded LoRA ranks must get exactly zero gradient"
+        for got, ref in ((m.gA[:32].cpu(), olora[p][0].grad), (m.gB[:, :32].cpu(), olora[p][1].grad)):
+            num += float(((got - ref) ** 2).sum())
+            den += float((ref ** 2).sum())
+            rel = float((got - ref).norm() / (ref.norm() + 1e-12))
+            worst = max(worst, rel)
+            assert rel < 0.15, (p, rel)
+    print("grad rel err: global %.3e worst module %.3e" % ((num / den) ** 0.5, worst))
+    assert (num / den) ** 0.5 < 0.05
+
+
+def run_step_case(dev, not_apply_cfg_solver=False):
+    """one SD3 PCM distillation step (train_pcm_lora_sd3.py:1270-1390) through SD3Distiller vs the oracle step."""
+    from oracle import mmdit_sd3 as O
+    from oracle import pcm_step_sd3 as OS
+    from pcm_amd.mmdit import MMDiTWeights, sd3_lora_state
+    from pcm_amd.mmdit_spec import MMDiTConfig
+    from pcm_amd.trainer_sd3 import SD3Distiller, SD3StepConfig
+    kw = dict(sample_size=16, num_layers=2, attention_head_dim=64, num_attention_heads=2, joint_attention_dim=96, caption_projection_dim=128,
+              pooled_projection_dim=64, pos_embed_max_size=12)
+    oc, pc = O.MMDiTConfig(**kw), MMDiTConfig(**kw)
+    sd = O.init_state_dict(oc, 0)
+    W = MMDiTWeights(pc, {k: v.to(dev) for k, v in sd.items()}, dev)
+    lora = sd3_lora_state(pc, 32, 8.0, dev, seed=1, b_std=0.1)
+    olora = {p: (m.A[:32].detach().cpu().clone().requires_grad_(True), m.B[:, :32].detach().cpu().clone().requires_grad_(True)) for p, m in lora.modules.items()}
+    B, H, Wd, Lc = 4, 8, 8, 5
+    g = torch.Generator().manual_seed(5)
+    x0 = torch.randn(B, 16, H, Wd, generator=g)
+    noise = torch.randn(B, 16, H, Wd, generator=g)
+    pe, upe = torch.randn(B, Lc, 96, generator=g), torch.randn(B, Lc, 96, generator=g)
+    pp, upp = torch.randn(B, 64, generator=g), torch.randn(B, 64, generator=g)
+    index = torch.tensor([0, 49, 13, 30])
+    ref = OS.distill_step_sd3(oc, sd, olora, x0, pe, pp, upe, upp, noise, index, multiphase=4, not_apply_cfg_solver=not_apply_cfg_solver)
+    ref["loss"].backward()
+    cfg = SD3StepConfig(multiphase=4, not_apply_cfg_solver=not_apply_cfg_solver)
+    D = SD3Distiller(W, lora, cfg)
+    p0 = lora.params.clone()
+    out = D.step(*(t.to(dev) for t in (x0, pe, pp, upe, upp, noise, index)))
+    assert torch.equal(out["end_index"].cpu(), ref["end_index"])
+    assert torch.equal(out["noisy_model_input"].cpu(), ref["noisy_model_input"])                     # reference-owned math: bit-exact
+    for k in ("model_output", "cond_teacher_output", "x_prev", "target", "model_pred"):
+        a, b = out[k].double().cpu(), ref[k].detach().double()
+        err = (a - b).abs().max().item()
+        assert err < 0.04 * b.abs().max().item(), (k, err, b.abs().max().item())
+    rl = float(ref["loss"].detach())
+    assert abs(float(out["loss"]) - rl) < 5e-2 * abs(rl), (float(out["loss"]), rl)
+    num = den = 0.0
+    for p, m in lora.modules.items():
+        for got, r in ((m.gA[:32].cpu(), olora[p][0].grad), (m.gB[:, :32].cpu(), olora[p][1].grad)):
+            num += float(((got - r) ** 2).sum())
+            den += float((r ** 2).sum())
+    print("loss %.5f (oracle %.5f), LoRA grad rel err %.3e" % (float(out["loss"]), rl, (num / den) ** 0.5))
+    assert (num / den) ** 0.5 < 0.08
+    assert not torch.equal(lora.params, p0) and D.step_count == 1                                      # AdamW applied
+    assert float(lora.params.view(-1)[:0].numel()) == 0
+    for m in lora.modules.values():                                                                    # padded ranks stay exactly zero
+        assert float(m.A[32:].abs().max()) == 0.0 and float(m.B[:, 32:].abs().max()) == 0.0

@@ -1,0 +1,43 @@
+"""SD3 transformer (MMDiT) on the host emulator vs the CPU oracle.  The same cases run on the GPU in
+tests/test_gpu_mmdit.py."""
+import math
+
+import pytest
+import torch
+
+from emu_lib import emu_lib
+from pcm_amd import capi
+
+
+@pytest.fixture(autouse=True)
+def _use_emu():
+    capi.set_lib(emu_lib())
+    yield
+    capi.set_lib(None)
+
+
+def test_spec_counts():
+    """the enumeration reproduces the published SD3-medium size and the reference's LoRA placement."""
+    from oracle import mmdit_sd3 as O
+    from pcm_amd import mmdit_spec as P
+    oc, pc = O.MMDiTConfig.sd3_medium(), P.MMDiTConfig.sd3_medium()
+    assert O.param_spec(oc) == P.param_spec(pc)
+    assert sum(math.prod(s) for _, s in P.param_spec(pc)) == 2_028_328_000
+    lt = P.lora_target_modules(pc)
+    assert lt == O.lora_target_modules(oc) and len(lt) == 24 * 6 + 1 and lt[-1][0] == "proj_out"
+    assert not any("add_" in p or "context" in p for p, _ in lt)
+    assert torch.equal(O.sincos_pos_embed(oc)[:, :7], P.sincos_pos_embed(pc)[:, :7])
+
+
+from mmdit_cases import run_case, run_step_case  # noqa: E402
+
+
+@pytest.mark.slow
+def test_mmdit_forward_backward_vs_oracle():
+    run_case("cpu")
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("nocfg", [False, True])
+def test_sd3_distillation_step_vs_oracle(nocfg):
+    run_step_case("cpu", nocfg)

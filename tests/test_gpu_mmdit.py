@@ -1,0 +1,16 @@
+"""SD3 variant on the MI355X: MMDiT forward / backward and one PCM distillation step vs the CPU oracle (same cases as
+tests/test_emu_mmdit.py, through the real HIP library)."""
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_mmdit_forward_backward_vs_oracle():
+    from mmdit_cases import run_case
+    run_case("cuda")
+
+
+@pytest.mark.parametrize("nocfg", [False, True])
+def test_sd3_distillation_step_vs_oracle(nocfg):
+    from mmdit_cases import run_step_case
+    run_step_case("cuda", nocfg)
