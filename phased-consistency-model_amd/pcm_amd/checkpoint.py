@@ -56,6 +56,28 @@ def save_lora(lora, output_dir, kohya=True):
         save_file(kohya_state_dict(sd, lora.alpha), os.path.join(output_dir, "pcm_lora_kohya_converted.safetensors"))
 
 
+def save_lora_sd3(lora, output_dir):
+    """``StableDiffusion3Pipeline.save_lora_weights(output_dir, transformer_lora_layers=get_peft_model_state_dict(transformer))``
+    (train_pcm_lora_sd3.py:1010-1012, :1495-1500): ``pytorch_lora_weights.safetensors`` with ``transformer.<module>.lora_A|B.weight``
+    keys, at the real LoRA rank.  The peft adapter dir is written beside it for resuming."""
+    os.makedirs(output_dir, exist_ok=True)
+    sd = peft_state_dict(lora)
+    save_file(sd, os.path.join(output_dir, "adapter_model.safetensors"))
+    save_file({"transformer." + k[len("base_model.model."):]: v for k, v in sd.items()}, os.path.join(output_dir, "pytorch_lora_weights.safetensors"))
+
+
+def load_transformer_state_dict(pretrained_dir):
+    """diffusers SD3 layout: <dir>/transformer/diffusion_pytorch_model*.safetensors (possibly sharded)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(pretrained_dir, "transformer", "diffusion_pytorch_model*.safetensors")))
+    if not files:
+        raise FileNotFoundError(f"no transformer/diffusion_pytorch_model*.safetensors under {pretrained_dir}")
+    sd = {}
+    for f in files:
+        sd.update(load_file(f))
+    return sd
+
+
 def load_lora(lora, input_dir):
     lora.load_peft_state_dict(load_file(os.path.join(input_dir, "adapter_model.safetensors")))
 

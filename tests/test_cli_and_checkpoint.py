@@ -148,3 +148,59 @@ def test_lr_schedule_constant_ignores_warmup():
     cli = load_cli()
     a = cli.parse_args(["--pretrained_teacher_model", "x", "--learning_rate", "5e-6", "--lr_warmup_steps", "500"])
     assert cli.lr_at(a, 0) == 5e-6 and cli.lr_at(a, 10000) == 5e-6
+
+
+def test_sd3_cli_flag_surface_matches_reference():
+    """train_pcm_lora_sd3.py: every flag of the reference's SD3 parser with the reference's default, and run.sh's launch line parses."""
+    sys.path.insert(0, PKG)
+    spec = importlib.util.spec_from_file_location("pcm_cli_sd3", os.path.join(PKG, "train_pcm_lora_sd3.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    ours = vars(m.parse_args(["--pretrained_teacher_model", "x"]))
+    ref_path = "/root/reference/code/text_to_image_sd3/train_pcm_lora_sd3.py"
+    if os.path.exists(ref_path):
+        tree = ast.parse(open(ref_path).read())
+        fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "parse_args"][0]
+        ref = {}
+        for node in ast.walk(fn):
+            if isinstance(node, ast.Call) and getattr(node.func, "attr", "") == "add_argument":
+                kw = {k.arg: k.value for k in node.keywords}
+                ref[node.args[0].value.lstrip("-")] = ast.literal_eval(kw["default"]) if "default" in kw else (False if "action" in kw else None)
+        assert len(ref) >= 60
+        for k, v in ref.items():
+            assert k in ours, k
+            if k != "pretrained_teacher_model":
+                assert ours[k] == v, (k, ours[k], v)
+    a = m.parse_args(["--pretrained_teacher_model=/x", "--output_dir=o", "--tracker_project_nam=p", "--mixed_precision=fp16", "--resolution=1024",
+                      "--lora_rank=32", "--learning_rate=5e-6", "--loss_type=huber", "--adam_weight_decay=1e-3", "--max_train_steps=20000",
+                      "--dataloader_num_workers=16", "--w_min=4", "--w_max=5", "--validation_steps=1000", "--checkpointing_steps=2000",
+                      "--checkpoints_total_limit=10", "--train_batch_size=2", "--enable_xformers_memory_efficient_attention",
+                      "--gradient_accumulation_steps=1", "--use_8bit_adam", "--resume_from_checkpoint=latest", "--seed=453645634",
+                      "--report_to=wandb", "--num_euler_timesteps=100", "--multiphase=2"])
+    assert a.lora_rank == 32 and a.num_euler_timesteps == 100 and a.multiphase == 2 and a.tracker_project_name == "p"
+
+
+def test_sd3_checkpoint_format(tmp_path):
+    """StableDiffusion3Pipeline.save_lora_weights layout at the REAL rank (the kernels' padding to 64 never reaches a file)."""
+    from emu_lib import emu_lib
+    from pcm_amd import capi, checkpoint as ck
+    from pcm_amd.mmdit import sd3_lora_state
+    from pcm_amd.mmdit_spec import MMDiTConfig
+    from safetensors.torch import load_file
+    capi.set_lib(emu_lib())
+    try:
+        cfg = MMDiTConfig(sample_size=16, num_layers=2, num_attention_heads=2, joint_attention_dim=96, caption_projection_dim=128,
+                          pooled_projection_dim=64, pos_embed_max_size=12)
+        lora = sd3_lora_state(cfg, 32, 8.0, "cpu", seed=3, b_std=0.01)
+        ck.save_lora_sd3(lora, str(tmp_path))
+        sd = load_file(str(tmp_path / "pytorch_lora_weights.safetensors"))
+        assert len(sd) == 2 * (2 * 6 + 1)
+        assert sd["transformer.transformer_blocks.0.attn.to_q.lora_A.weight"].shape == (32, 128)
+        assert sd["transformer.transformer_blocks.1.ff.net.0.proj.lora_B.weight"].shape == (512, 32)
+        assert sd["transformer.proj_out.lora_B.weight"].shape == (64, 32)
+        assert not any("add_" in k or "context" in k for k in sd)
+        lora2 = sd3_lora_state(cfg, 32, 8.0, "cpu", seed=99)
+        ck.load_lora(lora2, str(tmp_path))
+        assert torch.equal(lora2.params, lora.params)
+    finally:
+        capi.set_lib(None)
