@@ -271,9 +271,10 @@ int pcm_fm_cfg_euler_step(const float* cond, const float* uncond, const float* s
                           const float* sigmas, const double* sigmas_prev, double* x_prev, float* x_prev_f32, int B,
                           int per_sample, void* stream);
 /* Inference: one step of PCMFMDeterministicScheduler.step (pcm_fm_deterministic_scheduler.py:225-233; noise == NULL) or
- * PCMFMStochasticScheduler.step (pcm_fm_stochastic_scheduler.py:225-233; noise = the step's randn_like draw), float32. */
-int pcm_fm_sampler_step(const float* model_output, const float* sample, float sigma, float sigma_next, const float* noise,
-                        float* out, long n, void* stream);
+ * PCMFMStochasticScheduler.step (pcm_fm_stochastic_scheduler.py:225-233; noise = the step's randn_like draw), float32, optionally
+ * fused with the pipeline's guidance combine v = v_u + guidance * (v_c - v_u) (model_output_uncond may be NULL). */
+int pcm_fm_sampler_step(const float* model_output, const float* model_output_uncond, float guidance, const float* sample, float sigma,
+                        float sigma_next, const float* noise, float* out, long n, void* stream);
 
 /* loss (l2 | huber, :1283-1293) forward + gradient wrt the student's eps prediction:
  * loss[0] = mean(...) (accumulated in fp64, zeroed by the call) ; d_eps = dloss/dmodel_pred * coef[b] * grad_scale */

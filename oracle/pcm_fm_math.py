@@ -117,3 +117,20 @@ class PCMFMSampler:
             prev = sample + derivative * (self.sigmas_[self.step_index + 1] - sigma)
         self.step_index += 1
         return prev.to(model_output.dtype)
+
+
+def fm_sample(model_fn, prompt_embeds, pooled, uncond_embeds, uncond_pooled, latents, num_inference_steps, guidance_scale, shift=3.0,
+              pcm_timesteps=100, stochastic=False, noises=None):
+    """StableDiffusion3Pipeline's denoising loop around the PCM sampler (train_pcm_lora_sd3.py:1433-1470): CFG as
+    uncond + g * (text - uncond) when guidance_scale > 1.  ``model_fn(x, t, ctx, pooled)`` -> velocity prediction."""
+    sm = PCMFMSampler(1000, shift, pcm_timesteps, stochastic=stochastic)
+    sm.set_timesteps(num_inference_steps)
+    x = latents
+    for i, t in enumerate(sm.timesteps):
+        tt = t.expand(x.shape[0])
+        v = model_fn(x, tt, prompt_embeds, pooled)
+        if guidance_scale > 1.0 and uncond_embeds is not None:
+            u = model_fn(x, tt, uncond_embeds, uncond_pooled)
+            v = u + guidance_scale * (v - u)
+        x = sm.step(v, x, None if noises is None else noises[i])
+    return x

@@ -91,16 +91,19 @@ extern "C" int pcm_fm_cfg_euler_step(const float* cond, const float* uncond, con
 }
 
 // Inference: one step of the PCM flow-matching samplers (pcm_fm_deterministic_scheduler.py:225-233 /
-// pcm_fm_stochastic_scheduler.py:225-233), float32:
+// pcm_fm_stochastic_scheduler.py:225-233), float32, optionally preceded by the pipeline's classifier-free guidance combine
+// v = v_u + g * (v_c - v_u) (StableDiffusion3Pipeline's denoising loop; v_u == nullptr: no guidance):
 //   denoised = x - v * sigma
 //   deterministic: x' = x + ((x - denoised) / sigma) * (sigma_next - sigma)        (noise == nullptr)
 //   stochastic:    x' = (1 - sigma_next) * denoised + sigma_next * noise
-__global__ __launch_bounds__(256) void fm_sampler_kernel(const float* v, const float* x, float sigma, float sigma_next, const float* noise,
-                                                         float* out, long n) {
+__global__ __launch_bounds__(256) void fm_sampler_kernel(const float* v, const float* vu, float guidance, const float* x, float sigma,
+                                                         float sigma_next, const float* noise, float* out, long n) {
   const float dt = sigma_next - sigma, om = 1.0f - sigma_next;
   FM_LOOP(i, n) {
     const float xs = x[i];
-    const float vs = v[i] * sigma;
+    float vv = v[i];
+    if (vu) { const float u = vu[i]; const float d = vv - u; const float gd = guidance * d; vv = u + gd; }
+    const float vs = vv * sigma;
     const float den = xs - vs;
     if (noise) {
       const float a = om * den;
@@ -114,9 +117,9 @@ __global__ __launch_bounds__(256) void fm_sampler_kernel(const float* v, const f
     }
   }
 }
-extern "C" int pcm_fm_sampler_step(const float* model_output, const float* sample, float sigma, float sigma_next, const float* noise,
-                                   float* out, long n, void* stream) {
+extern "C" int pcm_fm_sampler_step(const float* model_output, const float* model_output_uncond, float guidance, const float* sample, float sigma,
+                                   float sigma_next, const float* noise, float* out, long n, void* stream) {
   PCM_CHECK(model_output && sample && out && n > 0 && sigma > 0.f && sigma_next >= 0.f, PCM_EINVAL, "pcm_fm_sampler_step: null/empty/sigma");
-  PCM_LAUNCH(fm_sampler_kernel, dim3(fm_blocks(n)), dim3(256), 0, stream, model_output, sample, sigma, sigma_next, noise, out, n);
+  PCM_LAUNCH(fm_sampler_kernel, dim3(fm_blocks(n)), dim3(256), 0, stream, model_output, model_output_uncond, guidance, sample, sigma, sigma_next, noise, out, n);
   return pcm_post_launch("pcm_fm_sampler_step");
 }

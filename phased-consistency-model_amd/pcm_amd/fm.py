@@ -113,7 +113,7 @@ class PCMFMSampler:
     def step_index(self):
         return self._step_index
 
-    def step(self, model_output, timestep, sample, generator=None, noise=None):
+    def step(self, model_output, timestep, sample, generator=None, noise=None, model_output_uncond=None, guidance_scale=1.0):
         """one sampler update; ``timestep`` is accepted for interface parity (the scheduler walks its own step index, like the
         reference after the first call).  Stochastic: ``noise`` (or a draw from ``generator``) stands for the reference's
         ``torch.randn_like(denoised)``."""
@@ -127,8 +127,9 @@ class PCMFMSampler:
         if self.stochastic:
             nz = noise if noise is not None else torch.randn(x.shape, generator=generator, device=x.device, dtype=torch.float32)
             nz = nz.float().contiguous()
+        vu = model_output_uncond.float().contiguous() if model_output_uncond is not None else None   # fused CFG combine
         out = torch.empty_like(x)
-        capi.lib().call("pcm_fm_sampler_step", ptr(v), ptr(x), sigma, sigma_next, ptr(nz), ptr(out), x.numel(), _stream())
+        capi.lib().call("pcm_fm_sampler_step", ptr(v), ptr(vu), float(guidance_scale), ptr(x), sigma, sigma_next, ptr(nz), ptr(out), x.numel(), _stream())
         self._step_index += 1
         return out.to(model_output.dtype)
 

@@ -598,6 +598,15 @@ def case_pcm_fm_math(dev, g):
                 nz = g[f"{kind}_{steps}_noise{i}"].to(dev) if stochastic else None
                 lat = sm.step(g[f"{kind}_{steps}_v{i}"].to(dev), tt, lat, noise=nz)
                 assert torch.equal(lat.cpu(), g[f"{kind}_{steps}_x{i + 1}"]), (kind, steps, i)
+    # fused guidance combine of the sampler step
+    sm3 = fm.PCMFMSampler(1000, 3.0, 100)
+    sm3.set_timesteps(2, device=dev)
+    vc, vu, x3 = g["cond"][:2].to(dev), g["uncond"][:2].to(dev), g["x"][:2].to(dev)
+    got = sm3.step(vc, sm3.timesteps[0], x3, model_output_uncond=vu, guidance_scale=1.7)
+    sm4 = fm.PCMFMSampler(1000, 3.0, 100)
+    sm4.set_timesteps(2, device=dev)
+    vcomb = (vu.cpu() + 1.7 * (vc.cpu() - vu.cpu())).to(dev)
+    close(got, sm4.step(vcomb, sm4.timesteps[0], x3).cpu(), 1e-6, 1e-6, "fm sampler cfg")
     with pytest.raises(ValueError):
         sm2 = fm.PCMFMSampler(1000, 3.0, 100)
         sm2.set_timesteps(2)

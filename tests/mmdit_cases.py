@@ -99,3 +99,47 @@ def run_step_case(dev, not_apply_cfg_solver=False):
     assert float(lora.params.view(-1)[:0].numel()) == 0
     for m in lora.modules.values():                                                                    # padded ranks stay exactly zero
         assert float(m.A[32:].abs().max()) == 0.0 and float(m.B[:, 32:].abs().max()) == 0.0
+
+
+def run_sampler_case(dev):
+    """few-step latent sampling with the SD3 student (deterministic + guidance, stochastic) vs the oracle loop."""
+    from oracle import mmdit_sd3 as O
+    from oracle import pcm_fm_math as FM
+    from pcm_amd.mmdit import MMDiT, MMDiTWeights, sd3_lora_state
+    from pcm_amd.mmdit_spec import MMDiTConfig
+    from pcm_amd.sampler_sd3 import PCMFMLatentSampler
+    kw = dict(sample_size=16, num_layers=2, attention_head_dim=64, num_attention_heads=2, joint_attention_dim=96, caption_projection_dim=128,
+              pooled_projection_dim=64, pos_embed_max_size=12)
+    oc, pc = O.MMDiTConfig(**kw), MMDiTConfig(**kw)
+    sd = O.init_state_dict(oc, 0)
+    W = MMDiTWeights(pc, {k: v.to(dev) for k, v in sd.items()}, dev, need_bwd=False)
+    lora = sd3_lora_state(pc, 32, 8.0, dev, seed=1, b_std=0.1)
+    olora = {p: (m.A[:32].detach().cpu().clone(), m.B[:, :32].detach().cpu().clone()) for p, m in lora.modules.items()}
+    B, H, Wd, Lc = 2, 8, 8, 5
+    g = torch.Generator().manual_seed(21)
+    lat = torch.randn(B, 16, H, Wd, generator=g)
+    pe, un = torch.randn(B, Lc, 96, generator=g), torch.randn(B, Lc, 96, generator=g)
+    pp, unp = torch.randn(B, 64, generator=g), torch.randn(B, 64, generator=g)
+
+    def model_fn(x, t, c, p):
+        with torch.no_grad():
+            return O.mmdit_forward(oc, sd, x, t, c, p, olora, 8.0)
+    m = MMDiT(W, lora)
+    to = lambda *ts: (t.to(dev) for t in ts)   # noqa: E731
+    for steps, gs in ((1, 1.0), (4, 1.0), (2, 1.5)):
+        ref = FM.fm_sample(model_fn, pe, pp, un, unp, lat, steps, gs)
+        a, b, c, d, e = to(pe, pp, un, unp, lat)
+        got = PCMFMLatentSampler(m).sample(a, b, c, d, steps, gs, latents=e)
+        err = (got.cpu() - ref).abs().max().item()
+        assert err < 0.05 * ref.abs().max().item(), (steps, gs, err, ref.abs().max().item())
+    noises = [torch.randn(B, 16, H, Wd, generator=g) for _ in range(3)]
+    ref = FM.fm_sample(model_fn, pe, pp, None, None, lat, 3, 1.0, stochastic=True, noises=noises)
+    # same noise through the product sampler: drive the scheduler by hand
+    from pcm_amd.fm import PCMFMSampler
+    sch = PCMFMSampler(1000, 3.0, 100, stochastic=True)
+    sch.set_timesteps(3, device=dev)
+    a, b, x = (*to(pe, pp), lat.to(dev))
+    for i, t in enumerate(sch.timesteps):
+        x = sch.step(m.forward(x, t.expand(B).contiguous(), a, b), t, x, noise=noises[i].to(dev))
+    err = (x.cpu() - ref).abs().max().item()
+    assert err < 0.05 * ref.abs().max().item(), ("stochastic", err)

@@ -29,7 +29,7 @@ def test_spec_counts():
     assert torch.equal(O.sincos_pos_embed(oc)[:, :7], P.sincos_pos_embed(pc)[:, :7])
 
 
-from mmdit_cases import run_case, run_step_case  # noqa: E402
+from mmdit_cases import run_case, run_sampler_case, run_step_case  # noqa: E402
 
 
 @pytest.mark.slow
@@ -41,3 +41,8 @@ def test_mmdit_forward_backward_vs_oracle():
 @pytest.mark.parametrize("nocfg", [False, True])
 def test_sd3_distillation_step_vs_oracle(nocfg):
     run_step_case("cpu", nocfg)
+
+
+@pytest.mark.slow
+def test_sd3_latent_sampler_vs_oracle():
+    run_sampler_case("cpu")

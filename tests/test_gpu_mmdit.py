@@ -14,3 +14,8 @@ def test_mmdit_forward_backward_vs_oracle():
 def test_sd3_distillation_step_vs_oracle(nocfg):
     from mmdit_cases import run_step_case
     run_step_case("cuda", nocfg)
+
+
+def test_sd3_latent_sampler_vs_oracle():
+    from mmdit_cases import run_sampler_case
+    run_sampler_case("cuda")
