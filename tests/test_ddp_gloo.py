@@ -125,3 +125,58 @@ def test_two_rank_full_step_matches_single_process_on_the_global_batch(tmp_path)
     cos = float((u2 * u1).sum() / (u2.norm() * u1.norm()))
     print("update cosine 2-rank vs single %.4f, norm ratio %.3f" % (cos, float(u2.norm() / u1.norm())))
     assert cos > 0.9 and 0.8 < float(u2.norm() / u1.norm()) < 1.25
+
+
+def _sd3_step_worker(rank, world, port, outdir):
+    """SD3 variant: one SD3Distiller step of a tiny MMDiT on this rank's shard of a global batch of 4."""
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "phased-consistency-model_amd"), os.path.join(ROOT, "tests")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    if world > 1:
+        torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    from emu_lib import emu_lib
+    from oracle import mmdit_sd3 as O
+    from pcm_amd import capi
+    from pcm_amd.mmdit import MMDiTWeights, sd3_lora_state
+    from pcm_amd.mmdit_spec import MMDiTConfig
+    from pcm_amd.trainer_sd3 import SD3Distiller, SD3StepConfig
+    capi.set_lib(emu_lib())
+    kw = dict(sample_size=16, num_layers=2, attention_head_dim=64, num_attention_heads=2, joint_attention_dim=96, caption_projection_dim=128,
+              pooled_projection_dim=64, pos_embed_max_size=12)
+    sd = O.init_state_dict(O.MMDiTConfig(**kw), 0)
+    pc = MMDiTConfig(**kw)
+    W = MMDiTWeights(pc, sd, "cpu")
+    lora = sd3_lora_state(pc, 32, 8.0, "cpu", seed=5, b_std=0.05)
+    init = lora.params.clone()
+    D = SD3Distiller(W, lora, SD3StepConfig(multiphase=2, learning_rate=1e-3), world_size=world)
+    g = torch.Generator().manual_seed(77)
+    G, H, Lc = 4, 8, 5
+    x0, noise = torch.randn(G, 16, H, H, generator=g), torch.randn(G, 16, H, H, generator=g)
+    pe, un = torch.randn(G, Lc, 96, generator=g), torch.randn(1, Lc, 96, generator=g).expand(G, -1, -1)
+    pp, unp = torch.randn(G, 64, generator=g), torch.randn(1, 64, generator=g).expand(G, -1)
+    index = torch.tensor([3, 41, 17, 28])
+    n = G // world
+    sl = slice(rank * n, (rank + 1) * n)
+    out = D.step(*(t[sl].contiguous() for t in (x0, pe, pp, un, unp, noise, index)))
+    torch.save((lora.params.clone(), init, float(out["loss"])), os.path.join(outdir, f"s{world}r{rank}.pt"))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+def test_sd3_two_rank_step_matches_single_process_on_the_global_batch(tmp_path):
+    ctx = mp.get_context("spawn")
+    ps = [ctx.Process(target=_sd3_step_worker, args=(r, 2, 29751, str(tmp_path))) for r in range(2)]
+    ps.append(ctx.Process(target=_sd3_step_worker, args=(0, 1, 29752, str(tmp_path))))
+    for p in ps:
+        p.start()
+    for p in ps:
+        p.join(600)
+        assert p.exitcode == 0
+    (p0, init, l0), (p1, _, l1) = (torch.load(os.path.join(str(tmp_path), f"s2r{r}.pt")) for r in range(2))
+    ps1, _, l_single = torch.load(os.path.join(str(tmp_path), "s1r0.pt"))
+    assert torch.equal(p0, p1), "ranks diverged"
+    assert abs((l0 + l1) / 2 - l_single) < 2e-2 * abs(l_single)
+    u2, u1 = (p0 - init).double(), (ps1 - init).double()
+    cos = float((u2 * u1).sum() / (u2.norm() * u1.norm()))
+    print("SD3 update cosine 2-rank vs single %.4f, norm ratio %.3f" % (cos, float(u2.norm() / u1.norm())))
+    assert cos > 0.9 and 0.8 < float(u2.norm() / u1.norm()) < 1.25
