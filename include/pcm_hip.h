@@ -247,9 +247,14 @@ int pcm_rowgate_fma(const void* y, const float* gate, const void* res, void* out
 int pcm_gelu_tanh_fwd(const void* x, void* y, long n, void* stream);
 int pcm_gelu_tanh_bwd(const void* x, const void* dy, void* dx, long n, void* stream);
 /* PatchEmbed's Conv2d(k=2, s=2) as a GEMM: fp32 NCHW image -> bf16 token rows [B*(H/2)*(W/2)][4C], column order 0 = (c,p,q) (conv weight),
- * 1 = (p,q,c) (the unpatchify einsum "nhwpqc->nchpwq", discriminator_sd3.py:112-131); and the inverse for order 1 in fp32. */
+ * 1 = (p,q,c) (the unpatchify einsum "nhwpqc->nchpwq", discriminator_sd3.py:112-131); and the inverse (fp32 tokens -> fp32 image). */
 int pcm_patchify2x2(const float* img, void* tokens, int B, int C, int H, int W, int order, void* stream);
-int pcm_unpatchify2x2(const float* tokens, float* img, int B, int C, int H, int W, void* stream);
+int pcm_unpatchify2x2(const float* tokens, float* img, int B, int C, int H, int W, int order, void* stream);
+/* gradients of the per-sample modulation vectors (adaLN projections with LoRA, train_pcm_lora_sd3_adv.py:992-1015): per sample b,
+ * out_a[b][c] = sum_l dy * u with u = (x - mean[row]) * rstd[row] (mean != NULL: d(1+scale)) or u = x (mean == NULL: d gate);
+ * out_b[b][c] = sum_l dy (d shift; optional).  x, dy bf16 [B*L][C]; outputs fp32 [B][C], zeroed by the call. */
+int pcm_mod_grad(const void* x, const void* dy, const float* mean, const float* rstd, float* out_a, float* out_b, int B, int L, int C,
+                 void* stream);
 /* sinusoidal projection of FLOAT timesteps (sigma * 1000, train_pcm_lora_sd3.py:1295-1300), flip_sin_to_cos, shift 0 -> bf16 [B][dim] */
 int pcm_timestep_embedding_f32(const float* t, void* out, int B, int dim, void* stream);
 

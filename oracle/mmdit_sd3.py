@@ -88,16 +88,21 @@ def buffer_spec(cfg: MMDiTConfig):
 
 
 LORA_SUFFIXES = ("to_k", "to_q", "to_v", "to_out.0", "proj_in", "proj_out", "ff.net.0.proj", "ff.net.2")   # train_pcm_lora_sd3.py:978-987
+# train_pcm_lora_sd3_adv.py:992-1015 (verbatim, incl. the three leading-dot entries that peft's suffix rule can never match)
+LORA_SUFFIXES_ADV = ("to_k", "to_q", "to_v", ".add_q_proj", ".add_k_proj", ".add_v_proj", "to_add_out", "to_out.0", "proj_in", "proj_out",
+                     "ff.net.0.proj", "ff.net.2", "ff_context.net.0.proj", "ff_context.net.2", "norm1.linear", "norm1_context.linear",
+                     "context_embedder", "text_embedder.linear_1", "text_embedder.linear_2", "timestep_embedder.linear_1",
+                     "timestep_embedder.linear_2", "pos_embed.proj")
 
 
-def lora_target_modules(cfg: MMDiTConfig):
-    """[(module path, weight shape)] in module order -- peft's suffix rule on the Linear modules of param_spec."""
+def lora_target_modules(cfg: MMDiTConfig, targets=LORA_SUFFIXES):
+    """[(module path, weight shape)] in module order -- peft 0.9's rule ``name == t or name.endswith("." + t)``."""
     out = []
     for k, shp in param_spec(cfg):
-        if not k.endswith(".weight") or len(shp) != 2:
+        if not k.endswith(".weight"):
             continue
         name = k[:-len(".weight")]
-        if any(name == t or name.endswith("." + t) for t in LORA_SUFFIXES):
+        if any(name == t or name.endswith("." + t) for t in targets):
             out.append((name, shp))
     return out
 
@@ -135,7 +140,7 @@ def _lin(sd, name, x, lora=None, alpha=8.0):
     y = F.linear(x, sd[name + ".weight"], sd[name + ".bias"])
     if lora is not None and name in lora:
         A, Bm = lora[name]
-        y = y + (alpha / A.shape[0]) * F.linear(F.linear(x, A), Bm)
+        y = y + (alpha / A.shape[0]) * F.linear(F.linear(x, A.reshape(A.shape[0], -1)), Bm.reshape(Bm.shape[0], -1))
     return y
 
 
@@ -161,12 +166,17 @@ def mmdit_forward(cfg: MMDiTConfig, sd, hidden_states, timestep, encoder_hidden_
     p, D, nh = cfg.patch_size, cfg.inner_dim, cfg.num_attention_heads
     hp, wp = H // p, W // p
     L = dict(lora=lora, alpha=lora_alpha)
-    x = F.conv2d(hidden_states, sd["pos_embed.proj.weight"], sd["pos_embed.proj.bias"], stride=p).flatten(2).transpose(1, 2)
+    x = F.conv2d(hidden_states, sd["pos_embed.proj.weight"], sd["pos_embed.proj.bias"], stride=p)
+    if lora is not None and "pos_embed.proj" in lora:      # peft Conv2d LoRA: lora_A = Conv2d(16, r, k=p, s=p), lora_B = Conv2d(r, D, 1)
+        A, Bm = lora["pos_embed.proj"]
+        r = A.shape[0]
+        x = x + (lora_alpha / r) * F.conv2d(F.conv2d(hidden_states, A.reshape(r, cfg.in_channels, p, p), stride=p), Bm.reshape(-1, r, 1, 1))
+    x = x.flatten(2).transpose(1, 2)
     x = x + crop_pos_embed(cfg, sd, hp, wp)
-    te = _lin(sd, "time_text_embed.timestep_embedder.linear_2", F.silu(_lin(sd, "time_text_embed.timestep_embedder.linear_1", timestep_proj(timestep))))
-    pe = _lin(sd, "time_text_embed.text_embedder.linear_2", F.silu(_lin(sd, "time_text_embed.text_embedder.linear_1", pooled_projections)))
+    te = _lin(sd, "time_text_embed.timestep_embedder.linear_2", F.silu(_lin(sd, "time_text_embed.timestep_embedder.linear_1", timestep_proj(timestep), **L)), **L)
+    pe = _lin(sd, "time_text_embed.text_embedder.linear_2", F.silu(_lin(sd, "time_text_embed.text_embedder.linear_1", pooled_projections, **L)), **L)
     temb = te + pe
-    c = _lin(sd, "context_embedder", encoder_hidden_states)
+    c = _lin(sd, "context_embedder", encoder_hidden_states, **L)
     semb = F.silu(temb)
     feats = []
 
@@ -175,17 +185,17 @@ def mmdit_forward(cfg: MMDiTConfig, sd, hidden_states, timestep, encoder_hidden_
     for i in range(cfg.num_layers):
         b = f"transformer_blocks.{i}."
         last = i == cfg.num_layers - 1
-        sh_a, sc_a, g_a, sh_m, sc_m, g_m = _lin(sd, b + "norm1.linear", semb).chunk(6, dim=1)
+        sh_a, sc_a, g_a, sh_m, sc_m, g_m = _lin(sd, b + "norm1.linear", semb, **L).chunk(6, dim=1)
         xn = ln(x) * (1 + sc_a[:, None]) + sh_a[:, None]
         if last:
-            csc, csh = _lin(sd, b + "norm1_context.linear", semb).chunk(2, dim=1)
+            csc, csh = _lin(sd, b + "norm1_context.linear", semb, **L).chunk(2, dim=1)
             cn = ln(c) * (1 + csc[:, None]) + csh[:, None]
         else:
-            csh_a, csc_a, cg_a, csh_m, csc_m, cg_m = _lin(sd, b + "norm1_context.linear", semb).chunk(6, dim=1)
+            csh_a, csc_a, cg_a, csh_m, csc_m, cg_m = _lin(sd, b + "norm1_context.linear", semb, **L).chunk(6, dim=1)
             cn = ln(c) * (1 + csc_a[:, None]) + csh_a[:, None]
-        q = torch.cat([_lin(sd, b + "attn.to_q", xn, **L), _lin(sd, b + "attn.add_q_proj", cn)], 1)
-        k = torch.cat([_lin(sd, b + "attn.to_k", xn, **L), _lin(sd, b + "attn.add_k_proj", cn)], 1)
-        v = torch.cat([_lin(sd, b + "attn.to_v", xn, **L), _lin(sd, b + "attn.add_v_proj", cn)], 1)
+        q = torch.cat([_lin(sd, b + "attn.to_q", xn, **L), _lin(sd, b + "attn.add_q_proj", cn, **L)], 1)
+        k = torch.cat([_lin(sd, b + "attn.to_k", xn, **L), _lin(sd, b + "attn.add_k_proj", cn, **L)], 1)
+        v = torch.cat([_lin(sd, b + "attn.to_v", xn, **L), _lin(sd, b + "attn.add_v_proj", cn, **L)], 1)
 
         def heads(t):
             return t.view(B, -1, nh, cfg.attention_head_dim).transpose(1, 2)
@@ -197,9 +207,9 @@ def mmdit_forward(cfg: MMDiTConfig, sd, hidden_states, timestep, encoder_hidden_
         ff = _lin(sd, b + "ff.net.2", F.gelu(_lin(sd, b + "ff.net.0.proj", xn2, **L), approximate="tanh"), **L)
         x = x + g_m[:, None] * ff
         if not last:
-            c = c + cg_a[:, None] * _lin(sd, b + "attn.to_add_out", oc)
+            c = c + cg_a[:, None] * _lin(sd, b + "attn.to_add_out", oc, **L)
             cn2 = ln(c) * (1 + csc_m[:, None]) + csh_m[:, None]
-            c = c + cg_m[:, None] * _lin(sd, b + "ff_context.net.2", F.gelu(_lin(sd, b + "ff_context.net.0.proj", cn2), approximate="tanh"))
+            c = c + cg_m[:, None] * _lin(sd, b + "ff_context.net.2", F.gelu(_lin(sd, b + "ff_context.net.0.proj", cn2, **L), approximate="tanh"), **L)
         feats.append(x)
     sc, sh = _lin(sd, "norm_out.linear", semb).chunk(2, dim=1)
     x = ln(x) * (1 + sc[:, None]) + sh[:, None]

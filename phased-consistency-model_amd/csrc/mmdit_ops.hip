@@ -50,6 +50,66 @@ extern "C" int pcm_rowgate_fma(const void* y, const float* gate, const void* res
   return pcm_post_launch("pcm_rowgate_fma");
 }
 
+// Gradients of the per-sample modulation vectors (needed when the adaLN projections norm1(.context).linear carry LoRA factors,
+// train_pcm_lora_sd3_adv.py:992-1015): column reductions over the rows of each sample,
+//   out_a[b][c] = sum_l dy[b,l,c] * u[b,l,c],   u = (x - mean[row]) * rstd[row]  (LayerNorm scale: d gamma)  or  u = x (gate: d gate)
+//   out_b[b][c] = sum_l dy[b,l,c]                (LayerNorm shift: d beta; optional)
+// thread -> fixed 8-channel vector, strided over rows; block reduction through a float4 LDS image; fp32 atomics into the zeroed outputs.
+__global__ __launch_bounds__(256) void mod_grad_kernel(const bf16_t* x, const bf16_t* dy, const float* mean, const float* rstd, float* out_a,
+                                                       float* out_b, int L, int C, int CVL, int rpb_blk) {
+  __shared__ __attribute__((aligned(16))) float4 pbuf[4][256];
+  const int b = blockIdx.y, zc = blockIdx.z;
+  const int cvl = threadIdx.x % CVL, pl = threadIdx.x / CVL, k = blockDim.x / CVL;
+  const int c0 = (zc * CVL + cvl) * 8;
+  const int l_begin = blockIdx.x * rpb_blk;
+  int l_end = l_begin + rpb_blk; if (l_end > L) l_end = L;
+  float sa[8], sb[8];
+#pragma unroll
+  for (int e = 0; e < 8; e++) { sa[e] = 0.f; sb[e] = 0.f; }
+  for (int l = l_begin + pl; l < l_end; l += k) {
+    const size_t row = (size_t)b * L + l;
+    float xv[8], dv[8];
+    mm_unpack8(*(const uint4*)(x + row * C + c0), xv);
+    mm_unpack8(*(const uint4*)(dy + row * C + c0), dv);
+    float mu = 0.f, rs = 1.f;
+    if (mean) { mu = mean[row]; rs = rstd[row]; }
+#pragma unroll
+    for (int e = 0; e < 8; e++) { sa[e] += dv[e] * ((xv[e] - mu) * rs); sb[e] += dv[e]; }
+  }
+  pbuf[0][threadIdx.x] = make_float4(sa[0], sa[1], sa[2], sa[3]);
+  pbuf[1][threadIdx.x] = make_float4(sa[4], sa[5], sa[6], sa[7]);
+  pbuf[2][threadIdx.x] = make_float4(sb[0], sb[1], sb[2], sb[3]);
+  pbuf[3][threadIdx.x] = make_float4(sb[4], sb[5], sb[6], sb[7]);
+  __syncthreads();
+  for (int t2 = threadIdx.x; t2 < 4 * CVL; t2 += blockDim.x) {
+    const int cv2 = t2 % CVL, j = t2 / CVL;
+    if (j >= 2 && !out_b) continue;
+    float4 acc = pbuf[j][cv2];
+    for (int q = 1; q < k; q++) {
+      const float4 v = pbuf[j][q * CVL + cv2];
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    float* o = (j < 2 ? out_a : out_b) + (size_t)b * C + (zc * CVL + cv2) * 8 + 4 * (j & 1);
+    atomicAdd(o + 0, acc.x); atomicAdd(o + 1, acc.y); atomicAdd(o + 2, acc.z); atomicAdd(o + 3, acc.w);
+  }
+}
+extern "C" int pcm_mod_grad(const void* x, const void* dy, const float* mean, const float* rstd, float* out_a, float* out_b, int B, int L, int C,
+                            void* stream) {
+  PCM_CHECK(x && dy && out_a && B > 0 && L > 0 && C > 0 && (C % 8) == 0 && (!mean == !rstd), PCM_EINVAL, "pcm_mod_grad: null/empty, C%%8");
+  PCM_CHECK(PCM_ALIGNED16(x) && PCM_ALIGNED16(dy), PCM_EALIGN, "pcm_mod_grad: alignment");
+  const int CV = C / 8;
+  int split = 1;
+  while (CV / split > 256 || (CV % split) != 0) split++;
+  const int CVL = CV / split, k = 256 / CVL > 0 ? 256 / CVL : 1;
+  int chunks = (PCM_GRID_CAP(1024) + B * split - 1) / (B * split);
+  const int maxc = (L + k - 1) / k; if (chunks > maxc) chunks = maxc; if (chunks < 1) chunks = 1;
+  const int rpb = (L + chunks - 1) / chunks; chunks = (L + rpb - 1) / rpb;
+  hipMemsetAsync(out_a, 0, sizeof(float) * (size_t)B * C, (hipStream_t)stream);
+  if (out_b) hipMemsetAsync(out_b, 0, sizeof(float) * (size_t)B * C, (hipStream_t)stream);
+  PCM_LAUNCH(mod_grad_kernel, dim3(chunks, B, split), dim3(CVL * k), 0, stream, (const bf16_t*)x, (const bf16_t*)dy, mean, rstd, out_a, out_b, L, C, CVL, rpb);
+  return pcm_post_launch("pcm_mod_grad");
+}
+
 // FeedForward(activation_fn="gelu-approximate"): y = 0.5 x (1 + tanh(k (x + 0.044715 x^3))), k = sqrt(2/pi)
 __device__ __forceinline__ float gelu_tanh_f(float x) {
   const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
@@ -106,14 +166,14 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* img, bf16_t*
     tok[i] = f2bf(img[(((size_t)b * C + c) * H + 2 * hp + p) * W + 2 * wp + q]);
   }
 }
-__global__ __launch_bounds__(256) void unpatchify_kernel(const float* tok, float* img, int B, int C, int H, int W) {
+__global__ __launch_bounds__(256) void unpatchify_kernel(const float* tok, float* img, int B, int C, int H, int W, int order) {
   const int Hp = H / 2, Wp = W / 2, K = 4 * C;
   const long n = (long)B * C * H * W;
   MM_LOOP(i, n) {
     const int w = (int)(i % W); long t = i / W;
     const int h = (int)(t % H); t /= H;
     const int c = (int)(t % C); const int b = (int)(t / C);
-    const int k = ((h & 1) * 2 + (w & 1)) * C + c;
+    const int k = order == 0 ? c * 4 + (h & 1) * 2 + (w & 1) : ((h & 1) * 2 + (w & 1)) * C + c;
     img[i] = tok[(((size_t)b * Hp + (h >> 1)) * Wp + (w >> 1)) * K + k];
   }
 }
@@ -123,9 +183,10 @@ extern "C" int pcm_patchify2x2(const float* img, void* tokens, int B, int C, int
   PCM_LAUNCH(patchify_kernel, dim3(mm_blocks((long)B * C * H * W)), dim3(256), 0, stream, img, (bf16_t*)tokens, B, C, H, W, order);
   return pcm_post_launch("pcm_patchify2x2");
 }
-extern "C" int pcm_unpatchify2x2(const float* tokens, float* img, int B, int C, int H, int W, void* stream) {
-  PCM_CHECK(img && tokens && B > 0 && C > 0 && H > 0 && W > 0 && (H % 2) == 0 && (W % 2) == 0, PCM_EINVAL, "pcm_unpatchify2x2: even H, W");
-  PCM_LAUNCH(unpatchify_kernel, dim3(mm_blocks((long)B * C * H * W)), dim3(256), 0, stream, tokens, img, B, C, H, W);
+extern "C" int pcm_unpatchify2x2(const float* tokens, float* img, int B, int C, int H, int W, int order, void* stream) {
+  PCM_CHECK(img && tokens && B > 0 && C > 0 && H > 0 && W > 0 && (H % 2) == 0 && (W % 2) == 0 && (order == 0 || order == 1), PCM_EINVAL,
+            "pcm_unpatchify2x2: even H, W; order 0|1");
+  PCM_LAUNCH(unpatchify_kernel, dim3(mm_blocks((long)B * C * H * W)), dim3(256), 0, stream, tokens, img, B, C, H, W, order);
   return pcm_post_launch("pcm_unpatchify2x2");
 }
 

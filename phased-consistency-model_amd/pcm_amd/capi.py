@@ -92,7 +92,8 @@ _PROTOS = {
     "pcm_gelu_tanh_fwd": [vp, vp, C.c_long, vp],
     "pcm_gelu_tanh_bwd": [vp, vp, vp, C.c_long, vp],
     "pcm_patchify2x2": [vp, vp, i32, i32, i32, i32, i32, vp],
-    "pcm_unpatchify2x2": [vp, vp, i32, i32, i32, i32, vp],
+    "pcm_unpatchify2x2": [vp, vp, i32, i32, i32, i32, i32, vp],
+    "pcm_mod_grad": [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
     "pcm_timestep_embedding_f32": [vp, vp, i32, i32, vp],
     "pcm_fm_add_noise": [vp, vp, vp, vp, vp, i32, i32, vp],
     "pcm_fm_phase_jump": [vp, i32, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, i32, i32, vp],

@@ -11,6 +11,13 @@ from collections import OrderedDict
 import torch
 
 LORA_TARGETS_SD3 = ("to_k", "to_q", "to_v", "to_out.0", "proj_in", "proj_out", "ff.net.0.proj", "ff.net.2")
+# the adversarial trainers' list (train_pcm_lora_sd3_adv.py:992-1015, 22 entries; the stochastic script drops "pos_embed.proj").
+# peft 0.9 matches ``name == t or name.endswith("." + t)``: the three entries written with a LEADING DOT (".add_q_proj", ...) can
+# never match, so add_q/k/v_proj stay unadapted -- kept verbatim, the quirk is part of the behaviour.
+LORA_TARGETS_SD3_ADV = ("to_k", "to_q", "to_v", ".add_q_proj", ".add_k_proj", ".add_v_proj", "to_add_out", "to_out.0", "proj_in", "proj_out",
+                        "ff.net.0.proj", "ff.net.2", "ff_context.net.0.proj", "ff_context.net.2", "norm1.linear", "norm1_context.linear",
+                        "context_embedder", "text_embedder.linear_1", "text_embedder.linear_2", "timestep_embedder.linear_1",
+                        "timestep_embedder.linear_2", "pos_embed.proj")
 
 
 class MMDiTConfig:
@@ -69,16 +76,17 @@ def buffer_spec(cfg: MMDiTConfig):
     return [("pos_embed.pos_embed", (1, cfg.pos_embed_max_size ** 2, cfg.inner_dim))]
 
 
-def lora_target_modules(cfg: MMDiTConfig):
-    """[(module path, weight shape)] -- peft's rule ``name == t or name.endswith('.' + t)`` over the Linear modules: the image
-    stream's to_q/k/v/to_out.0 and ff of every block plus the final proj_out (145 modules at 24 layers); the context stream's
-    add_*_proj / to_add_out / ff_context do not match."""
+def lora_target_modules(cfg: MMDiTConfig, targets=LORA_TARGETS_SD3):
+    """[(module path, weight shape)] -- peft's rule ``name == t or name.endswith('.' + t)`` over the Linear / Conv2d modules.
+    Default list (train_pcm_lora_sd3.py:978-987): the image stream's to_q/k/v/to_out.0 and ff of every block plus the final proj_out
+    (145 modules at 24 layers).  ``LORA_TARGETS_SD3_ADV``: additionally the context stream's to_add_out / ff_context, the adaLN
+    projections norm1(.context).linear, context_embedder, the four time/text embedder linears and the patch-embedding conv."""
     out = []
     for k, shp in param_spec(cfg):
-        if not k.endswith(".weight") or len(shp) != 2:
+        if not k.endswith(".weight"):
             continue
         name = k[:-len(".weight")]
-        if any(name == t or name.endswith("." + t) for t in LORA_TARGETS_SD3):
+        if any(name == t or name.endswith("." + t) for t in targets):
             out.append((name, shp))
     return out
 

@@ -154,9 +154,9 @@ class LoraState:
             if len(shp) == 4 and shp[-1] == 3:
                 m.kind, m.C, m.K = "conv3", shp[1], 9 * shp[1]
                 a_shape, b_shape = (rank, 3, 3, shp[1]), (shp[0], rank, 1, 1)   # INTERNAL layout [r][kh][kw][ci]
-            elif len(shp) == 4:
-                m.kind, m.C, m.K = "lin", 0, shp[1]
-                a_shape, b_shape = (rank, shp[1], 1, 1), (shp[0], rank, 1, 1)
+            elif len(shp) == 4:     # 1x1 conv, or a k x k / stride k patch conv run as a GEMM over flattened (c, kh, kw) patches
+                m.kind, m.C, m.K = "lin", 0, ain
+                a_shape, b_shape = (rank,) + tuple(shp[1:]), (shp[0], rank, 1, 1)
             else:
                 m.kind, m.C, m.K = "lin", 0, shp[1]
                 a_shape, b_shape = (rank, shp[1]), (shp[0], rank)

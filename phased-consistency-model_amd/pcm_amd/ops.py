@@ -305,11 +305,21 @@ def patchify2x2(img, order):
     return out
 
 
-def unpatchify2x2(tokens, B, Cc, H, W):
-    """fp32 [B*(H/2)*(W/2), 4C] in (p,q,c) column order -> fp32 [B,C,H,W]."""
+def unpatchify2x2(tokens, B, Cc, H, W, order=1):
+    """fp32 [B*(H/2)*(W/2), 4C] (column order 1 = (p,q,c), 0 = (c,p,q)) -> fp32 [B,C,H,W]."""
     img = torch.empty(B, Cc, H, W, dtype=torch.float32, device=tokens.device)
-    capi.lib().call("pcm_unpatchify2x2", ptr(tokens), ptr(img), B, Cc, H, W, _stream())
+    capi.lib().call("pcm_unpatchify2x2", ptr(tokens), ptr(img), B, Cc, H, W, order, _stream())
     return img
+
+
+def mod_grad(x, dy, B, mean=None, rstd=None, want_b=True):
+    """per-sample column reductions for the adaLN parameter gradients: (sum_l dy*u, sum_l dy), u = xhat (mean given) or x."""
+    Cc = x.shape[-1]
+    L = x.numel() // Cc // B
+    a = torch.empty(B, Cc, dtype=torch.float32, device=x.device)
+    b = torch.empty(B, Cc, dtype=torch.float32, device=x.device) if want_b else None
+    capi.lib().call("pcm_mod_grad", ptr(x), ptr(dy), ptr(mean), ptr(rstd), ptr(a), ptr(b), B, L, Cc, _stream())
+    return a, b
 
 
 def timestep_embedding_f32(t, dim):

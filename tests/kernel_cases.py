@@ -655,6 +655,18 @@ def case_mmdit_ops(dev):
     hs = tk.cpu().reshape(Bi, H // 2, W // 2, 2, 2, Ci)
     refimg = torch.einsum("nhwpqc->nchpwq", hs).reshape(Bi, Ci, H, W)                     # discriminator_sd3.py:112-131
     assert torch.equal(ops.unpatchify2x2(tk, Bi, Ci, H, W).cpu(), refimg), "unpatchify einsum"
+    tk0 = rnd(Bi * (H // 2) * (W // 2), 4 * Ci, seed=12, dev=dev, dtype=torch.float32)
+    ref0 = F.fold(tk0.cpu().reshape(Bi, (H // 2) * (W // 2), 4 * Ci).transpose(1, 2), (H, W), kernel_size=2, stride=2)
+    assert torch.equal(ops.unpatchify2x2(tk0, Bi, Ci, H, W, order=0).cpu(), ref0), "unpatchify (c,p,q)"
+    # modulation-vector gradients
+    ga, gb = ops.mod_grad(x, dy, B, mean, rstd)
+    xh = ((x.float().cpu().view(B, L, C) - mean.cpu().view(B, L, 1)) * rstd.cpu().view(B, L, 1))
+    dyf = dy.float().cpu().view(B, L, C)
+    close(ga, (dyf * xh).sum(1), 1e-3, 1e-3, "mod grad scale")
+    close(gb, dyf.sum(1), 1e-3, 1e-3, "mod grad shift")
+    gg, none = ops.mod_grad(x, dy, B, want_b=False)
+    assert none is None
+    close(gg, (dyf * x.float().cpu().view(B, L, C)).sum(1), 1e-3, 1e-3, "mod grad gate")
     t = torch.tensor([999.97, 500.25, 3.0, 57.7], device=dev)
     emb = ops.timestep_embedding_f32(t, 256)
     half = 128

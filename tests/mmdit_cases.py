@@ -2,10 +2,11 @@
 import torch
 
 
-def run_case(dev):
+def run_case(dev, adv_targets=False):
+    """``adv_targets``: the adversarial trainers' 22-entry LoRA list (context stream, adaLN projections, embedders, patch conv)."""
     from oracle import mmdit_sd3 as O
     from pcm_amd.mmdit import MMDiT, MMDiTWeights, sd3_lora_state
-    from pcm_amd.mmdit_spec import MMDiTConfig
+    from pcm_amd.mmdit_spec import LORA_TARGETS_SD3_ADV, MMDiTConfig
     kw = dict(sample_size=16, num_layers=3, attention_head_dim=64, num_attention_heads=2, joint_attention_dim=96, caption_projection_dim=128,
               pooled_projection_dim=64, pos_embed_max_size=12)
     oc, pc = O.MMDiTConfig(**kw), MMDiTConfig(**kw)
@@ -18,10 +19,16 @@ def run_case(dev):
     pooled = torch.randn(B, 64, generator=g)
     d_out = torch.randn(B, 16, H, Wd, generator=g)
     W = MMDiTWeights(pc, {k: v.to(dev) for k, v in sd.items()}, dev)
-    lora = sd3_lora_state(pc, 32, 8.0, dev, seed=1, b_std=0.1)
+    if adv_targets:
+        lora = sd3_lora_state(pc, 32, 8.0, dev, seed=1, b_std=0.05, targets=LORA_TARGETS_SD3_ADV, init="kaiming")
+        expect = {p for p, _ in O.lora_target_modules(oc, O.LORA_SUFFIXES_ADV)}
+        assert "pos_embed.proj" in expect and "transformer_blocks.0.norm1.linear" in expect and not any("add_q_proj" in p for p in expect)
+    else:
+        lora = sd3_lora_state(pc, 32, 8.0, dev, seed=1, b_std=0.1)
+        expect = {p for p, _ in O.lora_target_modules(oc)}
     assert lora.real_rank == 32 and lora.rank == 64 and abs(lora.scaling - 0.25) < 1e-12
     olora = {p: (m.A[:32].detach().cpu().clone().requires_grad_(True), m.B[:, :32].detach().cpu().clone().requires_grad_(True)) for p, m in lora.modules.items()}
-    assert set(olora) == {p for p, _ in O.lora_target_modules(oc)}
+    assert set(olora) == expect
     assert all(float(m.A[32:].abs().max()) == 0.0 and float(m.B[:, 32:].abs().max()) == 0.0 for m in lora.modules.values())
     ref_t = O.mmdit_forward(oc, sd, x, t, ctx, pooled)
     ref_s = O.mmdit_forward(oc, sd, x, t, ctx, pooled, olora, 8.0)
@@ -44,11 +51,12 @@ def run_case(dev):
     for p, m in lora.modules.items():
         assert float(m.gA[32:].abs().max()) == 0.0 and float(m.gB[:, 32:].abs().max()) == 0.0, "padded LoRA ranks must get exactly zero gradient"
         for got, ref in ((m.gA[:32].cpu(), olora[p][0].grad), (m.gB[:, :32].cpu(), olora[p][1].grad)):
+            ref = ref.view_as(got)
             num += float(((got - ref) ** 2).sum())
             den += float((ref ** 2).sum())
             rel = float((got - ref).norm() / (ref.norm() + 1e-12))
             worst = max(worst, rel)
-            assert rel < 0.15, (p, rel)
+            assert rel < (0.3 if adv_targets else 0.15), (p, rel)
     print("grad rel err: global %.3e worst module %.3e" % ((num / den) ** 0.5, worst))
     assert (num / den) ** 0.5 < 0.05
 

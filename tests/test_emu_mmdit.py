@@ -46,3 +46,10 @@ def test_sd3_distillation_step_vs_oracle(nocfg):
 @pytest.mark.slow
 def test_sd3_latent_sampler_vs_oracle():
     run_sampler_case("cpu")
+
+
+@pytest.mark.slow
+def test_mmdit_full_lora_list_forward_backward_vs_oracle():
+    """the adversarial trainers' LoRA placement: gradients through the context stream, the adaLN modulation vectors, the
+    time / text embedders, context_embedder and the patch-embedding conv."""
+    run_case("cpu", adv_targets=True)

@@ -19,3 +19,8 @@ def test_sd3_distillation_step_vs_oracle(nocfg):
 def test_sd3_latent_sampler_vs_oracle():
     from mmdit_cases import run_sampler_case
     run_sampler_case("cuda")
+
+
+def test_mmdit_full_lora_list_forward_backward_vs_oracle():
+    from mmdit_cases import run_case
+    run_case("cuda", adv_targets=True)
