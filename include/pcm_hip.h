@@ -275,6 +275,11 @@ int pcm_fm_phase_jump(const void* sample, int sample_f64, const float* model_pre
 int pcm_fm_cfg_euler_step(const float* cond, const float* uncond, const float* sample, const int64_t* index, float w,
                           const float* sigmas, const double* sigmas_prev, double* x_prev, float* x_prev_f32, int B,
                           int per_sample, void* stream);
+/* adversarial trainers, train_pcm_lora_sd3_adv.py:1413-1445: x_adv = ((1 - s_adv) * x + (s_adv - s_end) * noise) / (1 - s_end) with
+ * s_* = sigmas_prev[end_index | adv_index]; float64 in (model_pred / target and the reference's randn_like are float64), float64 and / or
+ * float32 out; ratio[b] = (1 - s_adv) / (1 - s_end) (optional, the generator step's chain-rule factor). */
+int pcm_fm_noise_travel(const double* x, const double* noise, const double* sigmas_prev, const int64_t* end_index,
+                        const int64_t* adv_index, double* out, float* out_f32, float* ratio, int B, int per_sample, void* stream);
 /* Inference: one step of PCMFMDeterministicScheduler.step (pcm_fm_deterministic_scheduler.py:225-233; noise == NULL) or
  * PCMFMStochasticScheduler.step (pcm_fm_stochastic_scheduler.py:225-233; noise = the step's randn_like draw), float32, optionally
  * fused with the pipeline's guidance combine v = v_u + guidance * (v_c - v_u) (model_output_uncond may be NULL). */

@@ -79,6 +79,13 @@ def fm_cfg(cond, uncond, w=3):
     return cond + w * (cond - uncond)
 
 
+def fm_noise_travel(solver, x, noise, end_index, adv_index):
+    """train_pcm_lora_sd3_adv.py:1413-1445 -- re-noise from sigma_prev[end_index] to sigma_prev[adv_index] (float64)."""
+    s_end = extract_into_tensor(solver.sigmas_prev, end_index, x.shape)
+    s_adv = extract_into_tensor(solver.sigmas_prev, adv_index, x.shape)
+    return ((1 - s_adv) * x + (s_adv - s_end) * noise) / (1 - s_end)
+
+
 def huber_loss(model_pred, target, huber_c=0.001):
     """train_pcm_lora_sd3.py:1374-1379."""
     return torch.mean(torch.sqrt((model_pred.float() - target.float()) ** 2 + huber_c ** 2) - huber_c)

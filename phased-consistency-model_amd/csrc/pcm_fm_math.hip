@@ -90,6 +90,33 @@ extern "C" int pcm_fm_cfg_euler_step(const float* cond, const float* uncond, con
   return pcm_post_launch("pcm_fm_cfg_euler_step");
 }
 
+// Adversarial trainers (train_pcm_lora_sd3_adv.py:1413-1445): re-noise a phase-edge sample from sigma_end to sigma_adv,
+//   x_adv = ((1 - sigma_adv) * x + (sigma_adv - sigma_end) * noise) / (1 - sigma_end),  sigma_* = sigmas_prev[end_index | adv_index]
+// in float64 (x = model_pred / target and the reference's randn_like(x) are float64); float32 copy = the ``.float()`` handed to the
+// discriminator; ratio[b] = (1 - sigma_adv) / (1 - sigma_end) = d x_adv / d x for the generator step's chain rule.
+__global__ __launch_bounds__(256) void fm_noise_travel_kernel(const double* x, const double* noise, const double* sigmas_prev, const int64_t* end_index,
+                                                              const int64_t* adv_index, double* out, float* out32, float* ratio, int B, int ps) {
+  long n = (long)B * ps;
+  FM_LOOP(i, n) {
+    const int b = (int)(i / ps);
+    const double se = sigmas_prev[end_index[b]], sa = sigmas_prev[adv_index[b]];
+    const double oma = 1.0 - sa, ome = 1.0 - se, dse = sa - se;
+    const double t1 = oma * x[i];
+    const double t2 = dse * noise[i];
+    const double r = (t1 + t2) / ome;
+    if (out) out[i] = r;
+    if (out32) out32[i] = (float)r;
+    if (ratio && i == (long)b * ps) ratio[b] = (float)(oma / ome);
+  }
+}
+extern "C" int pcm_fm_noise_travel(const double* x, const double* noise, const double* sigmas_prev, const int64_t* end_index,
+                                   const int64_t* adv_index, double* out, float* out_f32, float* ratio, int B, int per_sample, void* stream) {
+  PCM_CHECK(x && noise && sigmas_prev && end_index && adv_index && (out || out_f32) && B > 0 && per_sample > 0, PCM_EINVAL, "pcm_fm_noise_travel: null/empty");
+  PCM_LAUNCH(fm_noise_travel_kernel, dim3(fm_blocks((long)B * per_sample)), dim3(256), 0, stream, x, noise, sigmas_prev, end_index, adv_index, out,
+             out_f32, ratio, B, per_sample);
+  return pcm_post_launch("pcm_fm_noise_travel");
+}
+
 // Inference: one step of the PCM flow-matching samplers (pcm_fm_deterministic_scheduler.py:225-233 /
 // pcm_fm_stochastic_scheduler.py:225-233), float32, optionally preceded by the pipeline's classifier-free guidance combine
 // v = v_u + g * (v_c - v_u) (StableDiffusion3Pipeline's denoising loop; v_u == nullptr: no guidance):

@@ -98,6 +98,7 @@ _PROTOS = {
     "pcm_fm_add_noise": [vp, vp, vp, vp, vp, i32, i32, vp],
     "pcm_fm_phase_jump": [vp, i32, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, i32, i32, vp],
     "pcm_fm_cfg_euler_step": [vp, vp, vp, vp, f32, vp, vp, vp, vp, i32, i32, vp],
+    "pcm_fm_noise_travel": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
     "pcm_fm_sampler_step": [vp, vp, f32, vp, f32, f32, vp, vp, C.c_long, vp],
     "pcm_cfg_ddim_step": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
     "pcm_consistency_loss": [vp, vp, vp, i32, f32, vp, vp, f32, i32, i32, vp],

@@ -88,6 +88,21 @@ class EulerSolver:
         return (out, end, out32) if with_f32 else (out, end)
 
 
+def _noise_travel(solver, x64, noise64, end_index, adv_index):
+    B = x64.shape[0]
+    x, nz = x64.double().contiguous(), noise64.double().contiguous()
+    out = torch.empty_like(x)
+    out32 = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    ratio = torch.empty(B, dtype=torch.float32, device=x.device)
+    capi.lib().call("pcm_fm_noise_travel", ptr(x), ptr(nz), ptr(solver.sigmas_prev), ptr(end_index), ptr(adv_index), ptr(out), ptr(out32),
+                    ptr(ratio), B, x.numel() // B, _stream())
+    return out, out32, ratio
+
+
+EulerSolver.noise_travel = _noise_travel
+EulerSolver.noise_travel.__doc__ = """train_pcm_lora_sd3_adv.py:1436-1445 -> (x_adv float64, float32 copy, ratio[B] = d x_adv / d x)."""
+
+
 class PCMFMSampler:
     """PCMFMDeterministicScheduler / PCMFMStochasticScheduler (pcm_fm_*_scheduler.py:35-242): same constructor arguments,
     ``set_timesteps`` and ``step``; the scheduler's sigma tables stay on the host (a handful of scalars), the update runs in

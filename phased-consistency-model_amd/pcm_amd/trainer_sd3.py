@@ -91,3 +91,84 @@ class SD3Distiller(Distiller):
 
     def capture(self, *a, **k):
         raise NotImplementedError("SD3Distiller: hipGraph capture is not wired for this variant yet (eager launches)")
+
+
+class SD3AdvDistiller(SD3Distiller):
+    """PCM-LoRA + latent adversarial consistency for SD3 (reference: train_pcm_lora_sd3_adv.py:1330-1520, discriminator_sd3.py).
+    Even ``global_step``: discriminator (heads) update only; odd: student update with loss_cm + adv_weight * g_loss.
+    The discriminator = the frozen teacher transformer's per-block image-stream states + one 1x1-conv head per block
+    (``pcm_amd.discriminator.Discriminator([D] * num_layers, num_h_per_head=1, ksize=1)``)."""
+
+    def __init__(self, weights, lora, cfg, discriminator, adv_weight=0.1, adv_lr=1e-5, loss_type="huber", world_size=1, process_group=None):
+        super().__init__(weights, lora, cfg, world_size, process_group)
+        self.disc, self.adv_weight, self.adv_lr, self.loss_type = discriminator, adv_weight, adv_lr, loss_type
+        self.adv_lr_dev = torch.full((1,), float(adv_lr), dtype=torch.float32, device=self.device)
+        assert discriminator.head_num == weights.cfg.num_layers and discriminator.ksize == 1 and discriminator.nh == 1
+
+    def _feats(self, runner_out, H, W):
+        return [(f, H // 2, W // 2) for f in runner_out]
+
+    def step_adv(self, global_step, model_input, prompt_embeds, pooled_prompt_embeds, uncond_prompt_embeds, uncond_pooled_prompt_embeds, noise,
+                 index, noise_fake, noise_real, adv_u, lr=None):
+        """adv_u [B] in [0,1): adv_index = end_index + floor(adv_u * (E // multiphase)) (the reference's per-sample randint, :1413-1422);
+        noise_fake / noise_real float64 [B,16,H,W] (its two randn_like draws, :1436-1445)."""
+        cfg, S, disc = self.cfg, self.solver, self.disc
+        B, _, H, Wd = model_input.shape
+        is_d = (global_step % 2 == 0)
+        timesteps, timesteps_prev = S.timesteps(index, cfg.num_train_timesteps)
+        noisy = S.add_noise(model_input, noise, index)
+        if cfg.not_apply_cfg_solver:
+            cond = self.teacher.forward(noisy, timesteps, prompt_embeds, pooled_prompt_embeds)
+            x_prev64, x_prev32 = S.euler_step(noisy, cond, index, None)
+        else:
+            both = self.teacher.forward(torch.cat([noisy, noisy]), torch.cat([timesteps, timesteps]),
+                                        torch.cat([prompt_embeds, uncond_prompt_embeds]), torch.cat([pooled_prompt_embeds, uncond_pooled_prompt_embeds]))
+            x_prev64, x_prev32 = S.euler_step(noisy, both[:B], index, both[B:], cfg.w)
+        if is_d:        # the student forward is not back-propagated on discriminator steps: no tape
+            pred, tape = self.student.forward(noisy, timesteps, prompt_embeds, pooled_prompt_embeds), None
+        else:
+            pred, tape = self.student.forward(noisy, timesteps, prompt_embeds, pooled_prompt_embeds, save=True)
+        model_pred64, end_index, model_pred32 = S.euler_style_multiphase_pred(noisy, pred, index, cfg.multiphase, with_f32=True)
+        target_pred = self.student.forward(x_prev32, timesteps_prev.float(), prompt_embeds, pooled_prompt_embeds)
+        target64, _, target32 = S.euler_style_multiphase_pred(x_prev64, target_pred, index, cfg.multiphase, True, with_f32=True)
+        span = cfg.num_euler_timesteps // cfg.multiphase
+        adv_index = end_index + torch.clamp((adv_u * span).long(), max=span - 1)                           # :1413-1422
+        t_adv = (S.sigmas_prev[adv_index] * cfg.num_train_timesteps).float()                               # :1430-1435
+        _, fake32, ratio = S.noise_travel(model_pred64, noise_fake, end_index, adv_index)                  # :1441-1445
+        out = dict(model_pred=model_pred64, target=target64, end_index=end_index, adv_index=adv_index, fake_adv=fake32, is_d=is_d)
+        if is_d:
+            _, real32, _ = S.noise_travel(target64, noise_real, end_index, adv_index)                      # :1436-1440
+            feats = self.teacher.forward(torch.cat([fake32, real32]), torch.cat([t_adv, t_adv]), torch.cat([prompt_embeds, prompt_embeds]),
+                                         torch.cat([pooled_prompt_embeds, pooled_prompt_embeds]), features=True)
+            logits, dtape = disc.forward(self._feats(feats, H, Wd), save=True)
+            disc.grads.zero_()
+            out["d_loss"] = disc.d_loss_backward(logits, dtape, B)                                         # :1446-1466
+            out["real_adv"] = real32
+            self._disc_optimizer_step()
+            return out
+        feats, utape = self.teacher.forward(fake32, t_adv, prompt_embeds, pooled_prompt_embeds, features=True, save=True)
+        logits, dtape = disc.forward(self._feats(feats, H, Wd), save=True)
+        g_loss, d_feats = disc.g_loss_backward(logits, dtape, grad_scale=self.adv_weight)                  # :1492-1500
+        d_fake = self.teacher.backward(None, utape, d_feats=d_feats, need_input_grad=True)
+        coef = (S.sigmas_prev[end_index] - S.sigmas[index].double()).float().contiguous()                  # d model_pred / d pred
+        loss_cm, d_pred = ops.consistency_loss(model_pred32, target32, coef, self.loss_type == "huber", cfg.huber_c)   # :1468-1481
+        ops.scale_add_rows(d_pred, d_fake, ratio, coef)        # d fake_adv / d model_pred = ratio; d model_pred / d pred = coef
+        out.update(loss_cm=loss_cm, g_loss=g_loss, d_fake_adv=d_fake, d_pred=d_pred)
+        self.lora.zero_grad()
+        self.student.backward(d_pred, tape)
+        if lr is not None:
+            self.lr_dev.fill_(float(lr))
+        self.optimizer_step()
+        out["grad_sumsq"] = self.lora.gradsq
+        return out
+
+    def _disc_optimizer_step(self):
+        """adv_optimizer (train_pcm_lora_sd3_adv.py:1150-1156): AdamW(lr=adv_lr, betas=(0, 0.999)) over the heads, global-norm clip (:1459-1462)."""
+        cfg, d = self.cfg, self.disc
+        if self.world_size > 1:
+            torch.distributed.all_reduce(d.grads, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+        d.step_dev += 1
+        ops.sumsq(d.grads, d.gradsq)
+        ops.adamw_clip_step(d.params, d.grads, d.exp_avg, d.exp_avg_sq, d.gradsq, cfg.max_grad_norm, self.adv_lr, 0.0, 0.999,
+                            cfg.adam_epsilon, cfg.adam_weight_decay, 1, 1.0 / self.world_size, step_dev=d.step_dev, lr_dev=self.adv_lr_dev)
+        d.repack()

@@ -61,6 +61,16 @@ def main():
     for M in (1, 4):
         xp, te = solver.euler_style_multiphase_pred(out["euler_step"], pred, index, M, True)
         out[f"chain_target_{M}_x"], out[f"chain_target_{M}_end"] = xp, te
+    # adversarial trainers' re-noising (train_pcm_lora_sd3_adv.py:1413-1445; the expression is inline in the training loop, so it is
+    # evaluated here verbatim on the reference's own tables / extract_into_tensor rather than sliced as a function)
+    end_index = out["online_4_end"]
+    adv_index = end_index + torch.randint(0, 50 // 4, (B,), generator=g)
+    adv_noise = torch.randn(shape, generator=g, dtype=torch.float64)
+    sigmas_end = ext(solver.sigmas_prev, end_index, x.shape)
+    sigmas_adv = ext(solver.sigmas_prev, adv_index, x.shape)
+    out["adv_index"], out["adv_noise"] = adv_index, adv_noise
+    out["timesteps_adv"] = (sigmas_adv * 1000).squeeze([1, 2, 3])
+    out["fake_adv"] = ((1 - sigmas_adv) * out["online_4_x"] + (sigmas_adv - sigmas_end) * adv_noise) / (1 - sigmas_end)
     # :1374-1379 loss
     a, b = out["online_4_x"], out["target_4_x"]
     out["huber_loss"] = torch.mean(torch.sqrt((a.float() - b.float()) ** 2 + 0.001 ** 2) - 0.001).reshape(1)

@@ -576,6 +576,12 @@ def case_pcm_fm_math(dev, g):
     for M in (1, 4):
         ct, end = sol.euler_style_multiphase_pred(xp, pred, idx, M, True)                  # float64 sample
         assert torch.equal(ct.cpu(), g[f"chain_target_{M}_x"]) and torch.equal(end.cpu(), g[f"chain_target_{M}_end"]), M
+    # adversarial trainers' re-noising of the phase-edge prediction
+    fa64, fa32, ratio = sol.noise_travel(g["online_4_x"].to(dev), g["adv_noise"].to(dev), g["online_4_end"].to(dev), g["adv_index"].to(dev))
+    assert torch.equal(fa64.cpu(), g["fake_adv"]) and torch.equal(fa32.cpu(), g["fake_adv"].float()), "fm noise travel"
+    sp = g["sigmas_prev"]
+    close(ratio, ((1 - sp[g["adv_index"]]) / (1 - sp[g["online_4_end"]])).float(), 1e-6, 0, "fm noise travel ratio")
+    assert torch.equal((sol.sigmas_prev[g["adv_index"].to(dev)] * 1000).cpu(), g["timesteps_adv"])
     # huber loss through the step's loss kernel (same expression as the SD1.5 trainer): value parity
     B = idx.shape[0]
     loss = torch.zeros(1, dtype=torch.float64, device=dev)

@@ -151,3 +151,79 @@ def run_sampler_case(dev):
         x = sch.step(m.forward(x, t.expand(B).contiguous(), a, b), t, x, noise=noises[i].to(dev))
     err = (x.cpu() - ref).abs().max().item()
     assert err < 0.05 * ref.abs().max().item(), ("stochastic", err)
+
+
+def run_adv_case(dev, global_step):
+    """one adversarial SD3 step (train_pcm_lora_sd3_adv.py:1330-1520) with the trainers' 22-entry LoRA list: even = discriminator
+    update (head gradients vs oracle autograd), odd = generator update (loss_cm + adv_weight * g_loss -> LoRA gradients)."""
+    from oracle import mmdit_sd3 as O
+    from oracle import pcm_step_sd3 as OS
+    from pcm_amd.discriminator import Discriminator
+    from pcm_amd.mmdit import MMDiTWeights, sd3_lora_state
+    from pcm_amd.mmdit_spec import LORA_TARGETS_SD3_ADV, MMDiTConfig
+    from pcm_amd.trainer_sd3 import SD3AdvDistiller, SD3StepConfig
+    kw = dict(sample_size=16, num_layers=2, attention_head_dim=64, num_attention_heads=2, joint_attention_dim=96, caption_projection_dim=128,
+              pooled_projection_dim=64, pos_embed_max_size=12)
+    oc, pc = O.MMDiTConfig(**kw), MMDiTConfig(**kw)
+    sd = O.init_state_dict(oc, 0)
+    W = MMDiTWeights(pc, {k: v.to(dev) for k, v in sd.items()}, dev)
+    lora = sd3_lora_state(pc, 32, 8.0, dev, seed=1, b_std=0.05, targets=LORA_TARGETS_SD3_ADV, init="kaiming")
+    olora = {p: (m.A[:32].detach().cpu().clone().requires_grad_(True), m.B[:, :32].detach().cpu().clone().requires_grad_(True)) for p, m in lora.modules.items()}
+    disc = Discriminator([128] * 2, num_h_per_head=1, device=dev, seed=4, ksize=1)
+    dsd = {k: v.detach().cpu().clone() for k, v in disc.state_dict().items()}
+    B, H, Wd, Lc = 4, 8, 8, 5
+    g = torch.Generator().manual_seed(5)
+    x0 = torch.randn(B, 16, H, Wd, generator=g)
+    noise = torch.randn(B, 16, H, Wd, generator=g)
+    pe, upe = torch.randn(B, Lc, 96, generator=g), torch.randn(B, Lc, 96, generator=g)
+    pp, upp = torch.randn(B, 64, generator=g), torch.randn(B, 64, generator=g)
+    nf = torch.randn(B, 16, H, Wd, generator=g, dtype=torch.float64)
+    nr = torch.randn(B, 16, H, Wd, generator=g, dtype=torch.float64)
+    index = torch.tensor([0, 49, 13, 30])
+    adv_u = torch.tensor([0.0, 0.99, 0.5, 0.26])
+    span = 50 // 4
+    off = torch.clamp((adv_u * span).long(), max=span - 1)
+    ref = OS.distill_step_sd3_adv(oc, sd, olora, dsd, x0, pe, pp, upe, upp, noise, index, off, nf, nr, global_step, multiphase=4, adv_weight=0.1)
+    D = SD3AdvDistiller(W, lora, SD3StepConfig(multiphase=4), disc, adv_weight=0.1, adv_lr=1e-5)
+    p0, d0 = lora.params.clone(), disc.params.clone()
+    out = D.step_adv(global_step, *(t.to(dev) for t in (x0, pe, pp, upe, upp, noise, index, nf, nr, adv_u)))
+    assert torch.equal(out["adv_index"].cpu(), ref["adv_index"])
+    fa = ref["fake_adv"].detach().float()
+    assert (out["fake_adv"].cpu() - fa).abs().max().item() < 0.04 * fa.abs().max().item()
+    if global_step % 2 == 0:
+        rl = float(ref["d_loss"])
+        assert abs(float(out["d_loss"]) - rl) < 3e-2 * abs(rl), (float(out["d_loss"]), rl)
+        got = {}
+        cnt = {}
+        for k, hd in disc.heads:
+            h = cnt.get(k, 0)
+            cnt[k] = h + 1
+            for n, t in hd.g.items():
+                v = t.detach().cpu().clone()
+                got[f"heads.{k}.{h}.{n}"] = v
+        num = den = 0.0
+        for n, gref in ref["head_grads"].items():
+            a, b = got[n].reshape(-1), gref.reshape(-1)
+            num += float(((a - b) ** 2).sum())
+            den += float((b ** 2).sum())
+        mine_all = torch.cat([got[n].reshape(-1) for n in ref["head_grads"]])
+        ref_all = torch.cat([gr.reshape(-1) for gr in ref["head_grads"].values()])
+        cos = float((mine_all * ref_all).sum() / (mine_all.norm() * ref_all.norm()))
+        print("d_loss %.5f (oracle %.5f), head grad rel err %.3e cos %.4f" % (float(out["d_loss"]), rl, (num / den) ** 0.5, cos))
+        # the hinge cotangent is +-1/n per logit: every head-parameter gradient is a heavily cancelling sum, so bf16 rounding of the
+        # summands shows as ~10 % relative error on this tiny config (same criterion as tests/test_emu_adv.py): direction + magnitude
+        assert cos > 0.97 and (num / den) ** 0.5 < 0.25, (cos, (num / den) ** 0.5)
+        assert torch.equal(lora.params, p0) and not torch.equal(disc.params, d0)          # only the heads moved
+        return
+    ref["loss"].backward()
+    rl, rg = float(ref["loss_cm"].detach()), float(ref["g_loss"].detach()) / 0.1      # out["g_loss"] is the unweighted hinge term
+    assert abs(float(out["loss_cm"]) - rl) < 5e-2 * abs(rl) and abs(float(out["g_loss"]) - rg) < 5e-2 * abs(rg), (float(out["loss_cm"]), rl, float(out["g_loss"]), rg)
+    num = den = 0.0
+    for p, m in lora.modules.items():
+        for got, r in ((m.gA[:32].cpu(), olora[p][0].grad), (m.gB[:, :32].cpu(), olora[p][1].grad)):
+            r = r.view_as(got)
+            num += float(((got - r) ** 2).sum())
+            den += float((r ** 2).sum())
+    print("loss_cm %.5f (%.5f) g_loss %.5f (%.5f), LoRA grad rel err %.3e" % (float(out["loss_cm"]), rl, float(out["g_loss"]), rg, (num / den) ** 0.5))
+    assert (num / den) ** 0.5 < 0.1
+    assert not torch.equal(lora.params, p0) and torch.equal(disc.params, d0)              # only the student moved

@@ -29,7 +29,7 @@ def test_spec_counts():
     assert torch.equal(O.sincos_pos_embed(oc)[:, :7], P.sincos_pos_embed(pc)[:, :7])
 
 
-from mmdit_cases import run_case, run_sampler_case, run_step_case  # noqa: E402
+from mmdit_cases import run_adv_case, run_case, run_sampler_case, run_step_case  # noqa: E402
 
 
 @pytest.mark.slow
@@ -53,3 +53,9 @@ def test_mmdit_full_lora_list_forward_backward_vs_oracle():
     """the adversarial trainers' LoRA placement: gradients through the context stream, the adaLN modulation vectors, the
     time / text embedders, context_embedder and the patch-embedding conv."""
     run_case("cpu", adv_targets=True)
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("global_step", [0, 1])
+def test_sd3_adversarial_step_vs_oracle(global_step):
+    run_adv_case("cpu", global_step)

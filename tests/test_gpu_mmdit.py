@@ -24,3 +24,9 @@ def test_sd3_latent_sampler_vs_oracle():
 def test_mmdit_full_lora_list_forward_backward_vs_oracle():
     from mmdit_cases import run_case
     run_case("cuda", adv_targets=True)
+
+
+@pytest.mark.parametrize("global_step", [0, 1])
+def test_sd3_adversarial_step_vs_oracle(global_step):
+    from mmdit_cases import run_adv_case
+    run_adv_case("cuda", global_step)
