@@ -204,3 +204,31 @@ def test_sd3_checkpoint_format(tmp_path):
         assert torch.equal(lora2.params, lora.params)
     finally:
         capi.set_lib(None)
+
+
+def test_sd3_adv_cli_flags_and_lora_lists():
+    sys.path.insert(0, PKG)
+    mods = {}
+    for name in ("train_pcm_lora_sd3_adv", "train_pcm_lora_sd3_adv_stochastic"):
+        spec = importlib.util.spec_from_file_location("pcm_cli_" + name, os.path.join(PKG, name + ".py"))
+        m = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(m)
+        mods[name] = m
+    a = mods["train_pcm_lora_sd3_adv"].parse_args(["--pretrained_teacher_model=x", "--lora_rank=32", "--num_euler_timesteps=100", "--multiphase=2",
+                                                    "--adv_weight=0.2", "--adv_lr", "2e-5", "--loss_type=huber"])
+    assert a.adv_weight == 0.2 and a.adv_lr == 2e-5 and a.multiphase == 2 and a.loss_type == "huber"
+    d = mods["train_pcm_lora_sd3_adv"].parse_args(["--pretrained_teacher_model=x"])
+    assert d.adv_weight == 0.1 and d.adv_lr == 1e-5                                     # train_pcm_lora_sd3_adv.py:640-641
+    adv = mods["train_pcm_lora_sd3_adv"]
+    adv.STOCHASTIC = False
+    det = adv.lora_targets()
+    adv.STOCHASTIC = True
+    sto = adv.lora_targets()
+    adv.STOCHASTIC = False
+    assert len(det) == 22 and "pos_embed.proj" in det and "pos_embed.proj" not in sto and len(sto) == 21
+    ref_path = "/root/reference/code/text_to_image_sd3/train_pcm_lora_sd3_adv.py"
+    if os.path.exists(ref_path):          # the list is the reference's, verbatim
+        src = open(ref_path).read()
+        blk = src[src.index("target_modules=[\n", src.index("transformer_lora_config = LoraConfig(")):]        # (a commented one-line list precedes it)
+        blk = blk[:blk.index("]")]
+        assert tuple(re.findall(r'"([^"]+)"', blk)) == det
