@@ -68,7 +68,7 @@ def test_wgrad_conv(stride, src_mode):
     K.case_wgrad_conv("cpu", 2, 6, 5, 64, stride, src_mode)
 
 
-@pytest.mark.parametrize("B,H,Lq,Lk,d,spike", [(1, 2, 100, 77, 40, False), (2, 1, 70, 130, 80, True), (1, 1, 40, 64, 160, False), (1, 1, 300, 330, 40, True)])
+@pytest.mark.parametrize("B,H,Lq,Lk,d,spike", [(1, 2, 100, 77, 40, False), (2, 1, 70, 130, 80, True), (1, 1, 40, 64, 160, False), (1, 1, 300, 330, 40, True), (1, 2, 90, 90, 64, True)])
 def test_attention(B, H, Lq, Lk, d, spike):
     K.case_attention("cpu", B, H, Lq, Lk, d, spike)
 
@@ -90,7 +90,7 @@ def test_teacher_input_grad():
     K.case_teacher_input_grad("cpu")
 
 
-@pytest.mark.parametrize("B,H,Lq,Lk,d", [(1, 2, 130, 130, 40), (1, 1, 70, 200, 80)])
+@pytest.mark.parametrize("B,H,Lq,Lk,d", [(1, 2, 130, 130, 40), (1, 1, 70, 200, 80), (1, 2, 154, 154, 64)])
 def test_attention_packed_transposed_operands(B, H, Lq, Lk, d):
     """pcm_attn_*_ws with the one-off packed V^T / K^T / Q^T / dO^T tile images (ragged tails zero-filled by the packer)."""
     from pcm_amd import capi
