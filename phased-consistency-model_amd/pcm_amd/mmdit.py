@@ -11,11 +11,17 @@ token-axis concat / split of the two streams around attention and the [B, 6D] mo
 
 First version of this path: no fused QKV, no hipGraph capture; measured next round.
 """
+import os
+
 import torch
 
 from . import capi, ops
 from .mmdit_spec import MMDiTConfig, buffer_spec, lora_target_modules, param_spec
 from .model import BF16, LoraState, PackedLayer, layer_bwd, layer_fwd
+from .ops import Seg
+
+# debug hook: PCM_MMDIT_QKV=0 runs the six q/k/v projections of a block as separate layers (A/B measurement)
+FUSE_QKV = os.environ.get("PCM_MMDIT_QKV", "1") != "0"
 
 
 class MMDiTWeights:
@@ -43,6 +49,18 @@ class MMDiTWeights:
             self.layers[path] = PackedLayer(state_dict[k], state_dict[path + ".bias"], self.device, bwd)
         self.pos_embed = state_dict["pos_embed.pos_embed"].to(self.device, torch.float32).reshape(cfg.pos_embed_max_size, cfg.pos_embed_max_size, cfg.inner_dim)
         self._pos_cache = {}
+        # q/k/v of each stream as ONE projection: rows [Wq; Wk; Wv] (+ concatenated bias), the normalised activation is read once and
+        # attention reads q/k/v in place with row stride 3D; dgrad operand [K][3N] = [Wq^T | Wk^T | Wv^T]
+        self.qkv_bias, self.cqkv, self.cqkv_bias, self.cqkv_bwd = {}, {}, {}, {}
+        for i in range(cfg.num_layers):
+            pa = f"transformer_blocks.{i}.attn."
+            for names, wf, wb, bs in ((("to_q", "to_k", "to_v"), self.qkv, self.qkv_bwd, self.qkv_bias),
+                                      (("add_q_proj", "add_k_proj", "add_v_proj"), self.cqkv, self.cqkv_bwd, self.cqkv_bias)):
+                Ls = [self.layers[pa + n] for n in names]
+                wf[pa] = torch.cat([l.w_fwd.view(l.N, l.K) for l in Ls]).contiguous()
+                bs[pa] = torch.cat([l.bias for l in Ls]).contiguous()
+                if all(l.w_bwd is not None for l in Ls):
+                    wb[pa] = torch.cat([l.w_bwd.view(l.K, l.N) for l in Ls], dim=1).contiguous()
 
     def pos_crop(self, hp, wp):
         """centre crop of the positional table for an hp x wp token grid, bf16 [hp*wp, D] (cached)."""
@@ -79,6 +97,22 @@ class MMDiT:
         self.mod_lora = self.emb_lora or any(p.endswith("norm1.linear") or p.endswith("norm1_context.linear") for p in mods)
         self.ctx_in_lora = "context_embedder" in mods
         self.pos_lora = "pos_embed.proj" in mods
+
+    def _fusable(self, pa, save):
+        """q/k/v of block ``pa`` can run as fused projections: the context-stream projections carry no LoRA (true for both reference
+        lists) and the image stream's three either all do (concatenated operands exist) or none does."""
+        if not FUSE_QKV:
+            return False
+        W, lora = self.W, self.lora
+        if save and (pa not in W.qkv_bwd or pa not in W.cqkv_bwd):
+            return False
+        if lora is None:
+            return True
+        mods = lora.modules
+        if any((pa + n) in mods for n in ("add_q_proj", "add_k_proj", "add_v_proj")):
+            return False
+        have = [(pa + n) in mods for n in ("to_q", "to_k", "to_v")]
+        return (all(have) and pa in lora.qkv) or not any(have)
 
     @staticmethod
     def _aff(scale, shift):
@@ -147,12 +181,31 @@ class MMDiT:
             cn, cmu1, crs1 = ops.layernorm_mod_fwd(c, cgam_a, csh_a, Lc)
             sq, sk, sv, so, sf0, sf2 = (S() for _ in range(6))
             cq, ck, cv, co, cf0, cf2 = (S() for _ in range(6))
-            q = torch.cat([layer_fwd(W, lora, b + "attn.to_q", xn, Mx, save=sq).view(B, Lx, D),
-                           layer_fwd(W, lora, b + "attn.add_q_proj", cn, Mc, save=cq).view(B, Lc, D)], 1)
-            k = torch.cat([layer_fwd(W, lora, b + "attn.to_k", xn, Mx, save=sk).view(B, Lx, D),
-                           layer_fwd(W, lora, b + "attn.add_k_proj", cn, Mc, save=ck).view(B, Lc, D)], 1)
-            v = torch.cat([layer_fwd(W, lora, b + "attn.to_v", xn, Mx, save=sv).view(B, Lx, D),
-                           layer_fwd(W, lora, b + "attn.add_v_proj", cn, Mc, save=cv).view(B, Lc, D)], 1)
+            pa = b + "attn."
+            fuse = self._fusable(pa, save)
+            fq = t3 = None
+            if fuse:
+                # both streams' q/k/v as one projection each; LoRA (image stream): concatenated rank-192 down-projection + block-diagonal
+                # s*B K-segment (LoraState.qkv); one token-axis concat of the [., 3D] rows instead of three
+                segs = [Seg(xn, W.qkv[pa])]
+                fq = lora.qkv.get(pa) if lora is not None else None
+                if fq is not None:
+                    t3 = torch.empty(Mx, fq.r3, dtype=BF16, device=xn.device)
+                    ops.gemm([Seg(xn, fq.A_cat_fwd)], Mx, fq.r3, t3)
+                    segs.append(Seg(t3, fq.Bs_cat_fwd, k_algo=lora.rank))
+                qkv_x = torch.empty(Mx, 3 * D, dtype=BF16, device=xn.device)
+                ops.gemm(segs, Mx, 3 * D, qkv_x, bias=W.qkv_bias[pa])
+                qkv_c = torch.empty(Mc, 3 * D, dtype=BF16, device=xn.device)
+                ops.gemm([Seg(cn, W.cqkv[pa])], Mc, 3 * D, qkv_c, bias=W.cqkv_bias[pa])
+                j3 = torch.cat([qkv_x.view(B, Lx, 3 * D), qkv_c.view(B, Lc, 3 * D)], 1)
+                q, k, v = j3[:, :, :D], j3[:, :, D:2 * D], j3[:, :, 2 * D:]
+            else:
+                q = torch.cat([layer_fwd(W, lora, b + "attn.to_q", xn, Mx, save=sq).view(B, Lx, D),
+                               layer_fwd(W, lora, b + "attn.add_q_proj", cn, Mc, save=cq).view(B, Lc, D)], 1)
+                k = torch.cat([layer_fwd(W, lora, b + "attn.to_k", xn, Mx, save=sk).view(B, Lx, D),
+                               layer_fwd(W, lora, b + "attn.add_k_proj", cn, Mc, save=ck).view(B, Lc, D)], 1)
+                v = torch.cat([layer_fwd(W, lora, b + "attn.to_v", xn, Mx, save=sv).view(B, Lx, D),
+                               layer_fwd(W, lora, b + "attn.add_v_proj", cn, Mc, save=cv).view(B, Lc, D)], 1)
             o, lse = ops.attn_fwd(q, k, v, nh, hd)
             ox = o[:, :Lx].contiguous().view(Mx, D)
             a_x = layer_fwd(W, lora, b + "attn.to_out.0", ox, Mx, save=so)
@@ -164,7 +217,7 @@ class MMDiT:
             if save:
                 rec.update(x=x, c=c, gam_a=gam_a, g_a=g_a, gam_m=gam_m, g_m=g_m, mu1=mu1, rs1=rs1, cgam_a=cgam_a, cmu1=cmu1, crs1=crs1,
                            sq=sq, sk=sk, sv=sv, so=so, sf0=sf0, sf2=sf2, cq=cq, ck=ck, cv=cv, q=q, k=k, v=v, o=o, lse=lse,
-                           x1=x1, mu2=mu2, rs2=rs2, h=h, last=last, sm=sm, smc=smc)
+                           x1=x1, mu2=mu2, rs2=rs2, h=h, last=last, sm=sm, smc=smc, fuse=fuse, xn=xn, cn=cn, t3=t3)
                 if self.mod_lora:
                     rec.update(a_x=a_x, f_x=f_x)
             if not last:
@@ -265,10 +318,30 @@ class MMDiT:
                     cdg_a, _ = ops.mod_grad(r["a_c"], d_c1, B, want_b=False)
                     cparts = (cdg_a, cdsh_m, cdgam_m, cdg_m)
             d_o = torch.cat([d_ox.view(B, Lx, D), d_oc], 1)
-            dq, dk, dv = ops.attn_bwd(r["q"], r["k"], r["v"], r["o"], d_o, r["lse"], nh, hd)
-            d_xn = layer_bwd(W, lora, b + "attn.to_q", dq[:, :Lx].contiguous().view(Mx, D), r["sq"])
-            d_xn = layer_bwd(W, lora, b + "attn.to_k", dk[:, :Lx].contiguous().view(Mx, D), r["sk"], residual=d_xn)
-            d_xn = layer_bwd(W, lora, b + "attn.to_v", dv[:, :Lx].contiguous().view(Mx, D), r["sv"], residual=d_xn)
+            pa = b + "attn."
+            if r["fuse"]:
+                d3 = torch.empty(B, Lx + Lc, 3 * D, dtype=BF16, device=d_o.device)      # [dq | dk | dv], written in place by attention
+                ops.attn_bwd(r["q"], r["k"], r["v"], r["o"], d_o, r["lse"], nh, hd, out=(d3[:, :, :D], d3[:, :, D:2 * D], d3[:, :, 2 * D:]))
+                d3x = d3[:, :Lx].contiguous().view(Mx, 3 * D)
+                segs = [Seg(d3x, W.qkv_bwd[pa])]
+                fq = lora.qkv.get(pa) if lora is not None else None
+                if fq is not None:
+                    rk, t3, xn_ = lora.rank, r["t3"], r["xn"]
+                    u3 = torch.empty(Mx, fq.r3, dtype=BF16, device=d_o.device)
+                    ops.gemm([Seg(d3x, fq.Bs_cat_bwd, k_algo=D)], Mx, fq.r3, u3)
+                    for jj, lm in enumerate((fq.q, fq.k, fq.v)):
+                        ops.lora_wgrad(d3x[:, jj * D:(jj + 1) * D], t3[:, jj * rk:(jj + 1) * rk], lm.gB, lora.scaling, Mx, G=D, g_stride=rk, r_stride=1,
+                                       ldb=3 * D, lds=fq.r3)
+                        ops.lora_wgrad(xn_, u3[:, jj * rk:(jj + 1) * rk], lm.gA, 1.0, Mx, G=fq.K, g_stride=1, r_stride=fq.K, lds=fq.r3)
+                    segs.append(Seg(u3, fq.A_cat_bwd))
+                d_xn = torch.empty(Mx, D, dtype=BF16, device=d_o.device)
+                ops.gemm(segs, Mx, D, d_xn)
+                dq = dk = dv = None
+            else:
+                dq, dk, dv = ops.attn_bwd(r["q"], r["k"], r["v"], r["o"], d_o, r["lse"], nh, hd)
+                d_xn = layer_bwd(W, lora, b + "attn.to_q", dq[:, :Lx].contiguous().view(Mx, D), r["sq"])
+                d_xn = layer_bwd(W, lora, b + "attn.to_k", dk[:, :Lx].contiguous().view(Mx, D), r["sk"], residual=d_xn)
+                d_xn = layer_bwd(W, lora, b + "attn.to_v", dv[:, :Lx].contiguous().view(Mx, D), r["sv"], residual=d_xn)
             d_x = ops.layernorm_mod_bwd(r["x"], d_xn, r["gam_a"], r["mu1"], r["rs1"], Lx, dres=d_x1)
             if self.mod_lora:
                 dgam_a, dsh_a = ops.mod_grad(r["x"], d_xn, B, r["mu1"], r["rs1"])
@@ -277,9 +350,13 @@ class MMDiT:
             # upstream of the modulation) is adapted
             need_dc = i > 0 or self.ctx_in_lora or self.mod_lora
             if need_dc:
-                d_cn = layer_bwd(W, lora, b + "attn.add_q_proj", dq[:, Lx:].contiguous().view(Mc, D), r["cq"])
-                d_cn = layer_bwd(W, lora, b + "attn.add_k_proj", dk[:, Lx:].contiguous().view(Mc, D), r["ck"], residual=d_cn)
-                d_cn = layer_bwd(W, lora, b + "attn.add_v_proj", dv[:, Lx:].contiguous().view(Mc, D), r["cv"], residual=d_cn)
+                if r["fuse"]:
+                    d_cn = torch.empty(Mc, D, dtype=BF16, device=d_o.device)
+                    ops.gemm([Seg(d3[:, Lx:].contiguous().view(Mc, 3 * D), W.cqkv_bwd[pa])], Mc, D, d_cn)
+                else:
+                    d_cn = layer_bwd(W, lora, b + "attn.add_q_proj", dq[:, Lx:].contiguous().view(Mc, D), r["cq"])
+                    d_cn = layer_bwd(W, lora, b + "attn.add_k_proj", dk[:, Lx:].contiguous().view(Mc, D), r["ck"], residual=d_cn)
+                    d_cn = layer_bwd(W, lora, b + "attn.add_v_proj", dv[:, Lx:].contiguous().view(Mc, D), r["cv"], residual=d_cn)
                 d_c = ops.layernorm_mod_bwd(r["c"], d_cn, r["cgam_a"], r["cmu1"], r["crs1"], Lc, dres=d_c1)
                 if self.mod_lora:
                     cdgam_a, cdsh_a = ops.mod_grad(r["c"], d_cn, B, r["cmu1"], r["crs1"])

@@ -210,7 +210,7 @@ class LoraState:
         offs = {path: (oa, ob) for path, shp, oa, ob in layout}
         qkv_layout = []
         for path in list(offs):
-            if not path.endswith("attn1.to_q"):
+            if not (path.endswith("attn1.to_q") or path.endswith("attn.to_q")):     # UNet self-attention / MMDiT joint attention (image stream)
                 continue
             p = path[:-len("to_q")]
             trio = [self.modules.get(p + n) for n in ("to_q", "to_k", "to_v")]

@@ -36,6 +36,8 @@ def run_case(dev, adv_targets=False):
     out_t = MMDiT(W, None).forward(xd, td, cd, pd)
     student = MMDiT(W, lora)
     out_s, tape = student.forward(xd, td, cd, pd, save=True)
+    from pcm_amd import mmdit as _mm
+    assert all(r["fuse"] == _mm.FUSE_QKV for r in tape[:-1])        # the fused q/k/v schedule is the one that ran (unless switched off)
     scale = ref_t.abs().max().item()
     err_t = (out_t.cpu() - ref_t).abs().max().item()
     err_s = (out_s.cpu() - ref_s.detach()).abs().max().item()

@@ -59,3 +59,11 @@ def test_mmdit_full_lora_list_forward_backward_vs_oracle():
 @pytest.mark.parametrize("global_step", [0, 1])
 def test_sd3_adversarial_step_vs_oracle(global_step):
     run_adv_case("cpu", global_step)
+
+
+@pytest.mark.slow
+def test_mmdit_unfused_qkv_schedule(monkeypatch):
+    """PCM_MMDIT_QKV=0 debug path: the six q/k/v projections as separate layers give the same parity."""
+    from pcm_amd import mmdit
+    monkeypatch.setattr(mmdit, "FUSE_QKV", False)
+    run_case("cpu", adv_targets=True)
