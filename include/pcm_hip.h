@@ -183,6 +183,9 @@ int pcm_split_channels(const void* in, void* a, int Ca, void* b, int Cb, long ro
 int pcm_add_bf16(const void* a, const void* b, void* out, long n, void* stream);
 int pcm_colsum_bf16(const void* x, void* out /*fp32 [B][C], zeroed by the call*/, int B, int HW, int C, void* stream); /* d(time_emb_proj out) */
 int pcm_silu_bf16(const void* x, void* y, long n, void* stream);
+/* dx = dy * silu'(x): backward of the SiLU on the conditioning vector (silu(temb), and between the two embedder linears) when the
+ * SD3 adversarial trainers' LoRA list adapts the conditioning path (train_pcm_lora_sd3_adv.py:992-1015) */
+int pcm_silu_bwd_bf16(const void* x, const void* dy, void* dx, long n, void* stream);
 
 /* conv_in (4->C0, NCHW fp32 latent in, NHWC bf16 out) and conv_out (C0->4, NHWC bf16 in, NCHW fp32
  * out) + its input gradient — UNet2DConditionModel.conv_in / conv_out, not LoRA targets. */

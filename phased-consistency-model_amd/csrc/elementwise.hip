@@ -154,6 +154,21 @@ __global__ __launch_bounds__(256) void silu_kernel(const uint4* a, uint4* o, lon
     o[v] = ew_pack8(f);
   }
 }
+// dx = dy * silu'(x)
+__global__ __launch_bounds__(256) void silu_bwd_kernel(const uint4* x, const uint4* dy, uint4* dx, long nvec) {
+  EW_LOOP(v, nvec) {
+    float f[8], d[8];
+    ew_unpack8(x[v], f); ew_unpack8(dy[v], d);
+#pragma unroll
+    for (int e = 0; e < 8; e++) d[e] *= silu_grad_f(f[e]);
+    dx[v] = ew_pack8(d);
+  }
+}
+extern "C" int pcm_silu_bwd_bf16(const void* x, const void* dy, void* dx, long n, void* stream) {
+  PCM_CHECK(x && dy && dx && (n % 8) == 0, PCM_EINVAL, "pcm_silu_bwd_bf16: n%%8");
+  PCM_LAUNCH(silu_bwd_kernel, dim3(ew_blocks(n / 8)), dim3(256), 0, stream, (const uint4*)x, (const uint4*)dy, (uint4*)dx, n / 8);
+  return pcm_post_launch("pcm_silu_bwd_bf16");
+}
 extern "C" int pcm_add_bf16(const void* a, const void* b, void* out, long n, void* stream) {
   PCM_CHECK(a && b && out && (n % 8) == 0, PCM_EINVAL, "pcm_add_bf16: n%%8");
   PCM_LAUNCH(add_kernel, dim3(ew_blocks(n / 8)), dim3(256), 0, stream, (const uint4*)a, (const uint4*)b, (uint4*)out, n / 8);

@@ -79,6 +79,7 @@ _PROTOS = {
     "pcm_add_bf16": [vp, vp, vp, i64, vp],
     "pcm_colsum_bf16": [vp, vp, i32, i32, i32, vp],
     "pcm_silu_bf16": [vp, vp, i64, vp],
+    "pcm_silu_bwd_bf16": [vp, vp, vp, i64, vp],
     "pcm_conv_in_fwd": [vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "pcm_conv_out_fwd": [vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "pcm_conv_out_bwd": [vp, vp, vp, i32, i32, i32, i32, vp],

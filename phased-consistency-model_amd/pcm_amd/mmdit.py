@@ -6,10 +6,12 @@
 Wiring: the reference's copied forward, discriminator_sd3.py:73-137; block internals = diffusers' JointTransformerBlock (see
 oracle/mmdit_sd3.py for the restated semantics and what pins them).  Every contraction runs in ``pcm_gemm_bf16`` (LoRA as the
 second K-segment, rank 32 zero-padded to the kernels' 64), joint attention in the flash kernels with 64-wide heads, adaLN in
-``pcm_layernorm_mod_*``, gates in ``pcm_rowgate_fma``, tanh-GELU in ``pcm_gelu_tanh_*``.  torch is used for memory only: the
-token-axis concat / split of the two streams around attention and the [B, 6D] modulation slices.
+``pcm_layernorm_mod_*``, gates in ``pcm_rowgate_fma``, tanh-GELU in ``pcm_gelu_tanh_*``, the adaLN parameter gradients in
+``pcm_mod_grad``.  What torch does here is memory movement and bookkeeping on per-sample vectors: the token-axis concat / split of the
+two streams around attention, slicing the [B, 6, D] modulation outputs into (1 + scale, shift, gate) rows, stacking their gradients
+back, and the fp32 running sum of the [B, D] conditioning gradient over the blocks.
 
-First version of this path: no fused QKV, no hipGraph capture; measured next round.
+First version of this path: q/k/v fused per stream, no hipGraph capture; measured next round.
 """
 import os
 
@@ -117,12 +119,6 @@ class MMDiT:
     @staticmethod
     def _aff(scale, shift):
         return (1.0 + scale).contiguous(), shift.contiguous()
-
-    @staticmethod
-    def _silu_grad(z):
-        """d silu(z) / dz on a small fp32 tensor (conditioning path, [B, D])."""
-        sg = torch.sigmoid(z)
-        return sg * (1.0 + z * (1.0 - sg))
 
     def forward(self, hidden_states, timestep, encoder_hidden_states, pooled_projections, save=False, features=False):
         """-> [B,16,H,W] fp32 (``.sample``).  ``save``: also the tape for ``backward``.  ``features``: return the image-stream
@@ -370,13 +366,12 @@ class MMDiT:
         if d_c is not None and self.ctx_in_lora:
             layer_bwd(W, lora, "context_embedder", d_c, fin["sctx"], need_dx=False)
         if d_semb is not None and self.emb_lora:
-            d_temb = d_semb * self._silu_grad(fin["temb"].float())
+            d_temb = ops.silu_bwd(fin["temb"], d_semb.to(BF16).contiguous())          # semb = silu(temb), temb = te + pe
             for name in ("timestep_embedder", "text_embedder"):
                 _, s1, s2, z1 = fin["emb"][name]
                 pre = "time_text_embed." + name
-                d_h1 = layer_bwd(W, lora, pre + ".linear_2", d_temb.to(BF16).contiguous(), s2).float()
-                d_z1 = (d_h1 * self._silu_grad(z1.float())).to(BF16).contiguous()
-                layer_bwd(W, lora, pre + ".linear_1", d_z1, s1, need_dx=False)
+                d_h1 = layer_bwd(W, lora, pre + ".linear_2", d_temb, s2)
+                layer_bwd(W, lora, pre + ".linear_1", ops.silu_bwd(z1, d_h1), s1, need_dx=False)
         if d_x is None:
             return None
         if not (need_input_grad or self.pos_lora):

@@ -224,6 +224,12 @@ def silu(x):
     return y
 
 
+def silu_bwd(x, dy):
+    dx = torch.empty_like(x)
+    capi.lib().call("pcm_silu_bwd_bf16", ptr(x), ptr(dy), ptr(dx), x.numel(), _stream())
+    return dx
+
+
 def colsum(x):
     """x [B, HW, C] bf16 -> fp32 [B, C]"""
     B, HW, Cc = x.shape

@@ -79,6 +79,9 @@ def case_elementwise(dev):
     close(a2, acc0.float().cpu() + a.float().cpu(), 1e-2, 1e-2, "split acc")
     close(ops.add(a, acc0), a.float().cpu() + acc0.float().cpu(), 1e-2, 1e-2, "add")
     close(ops.silu(a), F.silu(a.float().cpu()), 1e-2, 1e-2, "silu")
+    ar = a.float().cpu().requires_grad_(True)
+    F.silu(ar).backward(acc0.float().cpu())
+    close(ops.silu_bwd(a, acc0), ar.grad, 1e-2, 1e-2, "silu bwd")
     hg = rnd(5, 128, seed=6, dev=dev)
     hr = hg.float().cpu().requires_grad_(True)
     h, g = hr.chunk(2, -1)
