@@ -89,8 +89,56 @@ class SD3Distiller(Distiller):
         out["grad_sumsq"] = self.lora.gradsq
         return out
 
-    def capture(self, *a, **k):
-        raise NotImplementedError("SD3Distiller: hipGraph capture is not wired for this variant yet (eager launches)")
+    # ---- hipGraph replay (same scheme as Distiller.capture: forward+backward and the optimizer as two graphs around the eager
+    # gradient all-reduce).  NOT yet exercised on hardware: the CLIs launch eagerly; tools/sd3_step_probe.py tries it behind a guard. ----
+    def capture(self, B, H=128, W=128, ctx_len=154):
+        dev, mc = self.device, self.W.cfg
+        f32 = dict(dtype=torch.float32, device=dev)
+        self._static = dict(model_input=torch.zeros(B, mc.in_channels, H, W, **f32), prompt_embeds=torch.zeros(B, ctx_len, mc.joint_attention_dim, **f32),
+                            pooled_prompt_embeds=torch.zeros(B, mc.pooled_projection_dim, **f32),
+                            uncond_prompt_embeds=torch.zeros(B, ctx_len, mc.joint_attention_dim, **f32),
+                            uncond_pooled_prompt_embeds=torch.zeros(B, mc.pooled_projection_dim, **f32),
+                            noise=torch.zeros(B, mc.in_channels, H, W, **f32), index=torch.zeros(B, dtype=torch.int64, device=dev))
+        lo = self.lora
+        saved = [t.clone() for t in (lo.params, lo.exp_avg, lo.exp_avg_sq, self.step_dev, self.lr_dev)]
+        if self.ema is not None:
+            saved.append(self.ema.clone())
+        count = self.step_count
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                      # warm-up: lazy init, allocator pools
+            self.forward_backward(**self._static)
+            self._optimizer_apply()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self._g_fb, self._g_opt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._g_fb, capture_error_mode="thread_local"):
+            self._static_out = self.forward_backward(**self._static)
+        with torch.cuda.graph(self._g_opt, pool=self._g_fb.pool(), capture_error_mode="thread_local"):
+            self._optimizer_apply()
+        for dst, src in zip((lo.params, lo.exp_avg, lo.exp_avg_sq, self.step_dev, self.lr_dev), saved):
+            dst.copy_(src)
+        if self.ema is not None:
+            self.ema.copy_(saved[-1])
+        self.step_count = count
+        lo.repack()
+        self._static_out["grad_sumsq"] = lo.gradsq
+        self._graph = True
+
+    def step_graphed(self, model_input, prompt_embeds, pooled_prompt_embeds, uncond_prompt_embeds, uncond_pooled_prompt_embeds, noise, index, lr=None):
+        """Same as step() through the captured graphs; returned tensors are the graph's static outputs."""
+        st = self._static
+        for k, v in (("model_input", model_input), ("prompt_embeds", prompt_embeds), ("pooled_prompt_embeds", pooled_prompt_embeds),
+                     ("uncond_prompt_embeds", uncond_prompt_embeds), ("uncond_pooled_prompt_embeds", uncond_pooled_prompt_embeds),
+                     ("noise", noise), ("index", index)):
+            st[k].copy_(v)
+        if lr is not None:
+            self.lr_dev.fill_(float(lr))
+        self._g_fb.replay()
+        self.all_reduce_grads()
+        self.step_count += 1
+        self._g_opt.replay()
+        return self._static_out
 
 
 class SD3AdvDistiller(SD3Distiller):

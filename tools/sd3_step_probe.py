@@ -1,6 +1,6 @@
 """Full-size SD3-medium (2.03 B-parameter MMDiT, 128x128x16 latents -> 4096 image tokens + 154 text tokens, LoRA r=32) PCM distillation
 step on one MI355X with random-init weights and synthetic conditioning: checks that every layer shape of BASELINE.json configs[4] runs
-and times the step (eager launches).   python tools/sd3_step_probe.py [batch] [adv]
+and times the step (eager launches).   python tools/sd3_step_probe.py [batch] [adv|graph]
 "adv": the adversarial trainer (22-entry LoRA list + 24 discriminator heads), one discriminator and one generator step per iteration."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -51,3 +51,13 @@ for it in range(3):
               float(out["grad_sumsq"]), torch.cuda.max_memory_allocated() / 1e9), flush=True)
         assert torch.isfinite(out["loss"]).all()
 print("images/sec (eager launches, bs %d%s): %.2f" % (B, ", D+G pair" if adv else "", B / (time.time() - t1)))
+if not adv and len(sys.argv) > 2 and sys.argv[2] == "graph":
+    try:
+        D.capture(B)
+        for it in range(3):
+            torch.cuda.synchronize(); t1 = time.time()
+            out = D.step_graphed(lat, pe, pp, un, unp, nz, idx)
+            torch.cuda.synchronize()
+            print("graphed step %d: %.1f ms, loss %.5f" % (it, 1e3 * (time.time() - t1), float(out["loss"])), flush=True)
+    except Exception as e:       # first hardware run of this path
+        print("hipGraph capture of the SD3 step failed:", repr(e)[:300])
