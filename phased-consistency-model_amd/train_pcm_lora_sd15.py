@@ -32,7 +32,7 @@ logger = logging.getLogger("pcm_amd")
 IGNORED = ["pretrained_vae_model_name_or_path", "teacher_revision", "revision", "cache_dir", "center_crop", "random_flip",
            "dataloader_num_workers", "max_train_samples", "scale_lr", "use_8bit_adam", "proportion_empty_prompts",
            "allow_tf32", "cast_teacher_unet", "enable_xformers_memory_efficient_attention", "gradient_checkpointing",
-           "push_to_hub", "hub_token", "hub_model_id", "validation_steps", "resolution"]
+           "push_to_hub", "hub_token", "hub_model_id", "validation_steps"]
 
 
 def parse_args(argv=None):
@@ -105,6 +105,7 @@ class LatentSource:
 
     def __init__(self, args, rank, world, device):
         self.bs, self.device = args.train_batch_size, device
+        self.hw = args.resolution // 8                      # VAE downsampling factor: synthetic latents follow --resolution
         self.g = torch.Generator(device=device).manual_seed((args.seed or 0) + rank)
         self.shards, self.uncond = None, None
         if args.latents_dir:
@@ -132,7 +133,7 @@ class LatentSource:
         if self.shards:
             idx = torch.randint(0, self.lat.shape[0], (self.bs,), generator=self.g, device=self.device)
             return self.lat[idx].contiguous(), self.pe[idx].contiguous()
-        return (torch.randn(self.bs, 4, 64, 64, generator=self.g, device=self.device),
+        return (torch.randn(self.bs, 4, self.hw, self.hw, generator=self.g, device=self.device),
                 torch.randn(self.bs, 77, 768, generator=self.g, device=self.device))
 
 
@@ -170,7 +171,7 @@ def main(args):
         logger.info("--mixed_precision=fp16 requested: this build computes in bf16 MFMA / fp32 accumulate (no GradScaler needed)")
     if args.gradient_accumulation_steps != 1:
         raise SystemExit("pcm_amd: --gradient_accumulation_steps != 1 is not implemented (reference recipes use 1)")
-    ignored = [k for k in IGNORED if getattr(args, k) not in (None, False, 0, 8, 200, 512)]
+    ignored = [k for k in IGNORED if getattr(args, k) not in (None, False, 0, 8, 200)]
     if ignored:
         logger.info("flags accepted for CLI compatibility and ignored: %s", ", ".join(ignored))
     if world > 1:
