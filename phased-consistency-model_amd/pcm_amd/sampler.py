@@ -35,7 +35,9 @@ class DDIMTrailingSampler:
 
     @torch.no_grad()
     def sample(self, prompt_embeds, uncond_embeds=None, num_inference_steps=4, guidance_scale=1.0, latents=None, generator=None,
-               height=64, width=64):
+               height=64, width=64, added_cond=None, uncond_added_cond=None):
+        """``added_cond`` / ``uncond_added_cond``: SDXL ``added_cond_kwargs`` ({'text_embeds': [B,1280], 'time_ids': [B,6]}) for the
+        positive / negative branch (StableDiffusionXLPipeline, the SDXL script's log_validation, train_pcm_lora_sdxl_adv.py:160-222)."""
         B, dev = prompt_embeds.shape[0], prompt_embeds.device
         if latents is None:
             latents = torch.randn(B, 4, height, width, generator=generator, device=dev, dtype=torch.float32)   # init_noise_sigma = 1
@@ -45,10 +47,14 @@ class DDIMTrailingSampler:
         for t in trailing_timesteps(num_inference_steps, self.T):
             tt = torch.full((B,), t, dtype=torch.int64, device=dev)
             if cfg:   # [uncond; cond] as one 2B forward (the pipeline concatenates them the same way)
-                both = self.unet.forward(torch.cat([x, x]), torch.cat([tt, tt]), torch.cat([uncond_embeds, prompt_embeds]))
+                ac2 = None
+                if added_cond is not None:
+                    un = uncond_added_cond if uncond_added_cond is not None else added_cond
+                    ac2 = {k: torch.cat([un[k], added_cond[k]]) for k in added_cond}
+                both = self.unet.forward(torch.cat([x, x]), torch.cat([tt, tt]), torch.cat([uncond_embeds, prompt_embeds]), added_cond=ac2)
                 eps_u, eps_c = both[:B].contiguous(), both[B:].contiguous()
             else:
-                eps_u, eps_c = None, self.unet.forward(x, tt, prompt_embeds)
+                eps_u, eps_c = None, self.unet.forward(x, tt, prompt_embeds, added_cond=added_cond)
             prev = t - skip
             a_prev = self.acp[prev] if prev >= 0 else self.final_alpha
             x = ops.sampler_ddim_step(eps_c, eps_u, x, self.acp[t], a_prev, guidance_scale)

@@ -60,3 +60,38 @@ def test_sampling_loop_vs_oracle(guidance):
     rel = float((out - ref).norm() / ref.norm())
     print("sampled latents rel err %.3e (guidance %.1f)" % (rel, guidance))
     assert rel < (3e-2 if guidance == 1.0 else 8e-2)
+
+
+def test_sdxl_sampling_loop_with_added_conditioning_vs_oracle():
+    """the SDXL script's validation loop: same DDIM-trailing sampler, UNet with text_time added conditioning, zero negative embeds."""
+    from oracle import pcm_math as PM
+    from oracle import unet_sd15 as O
+    from pcm_amd.model import LoraState, UNet, UNetWeights
+    from pcm_amd.sampler import DDIMTrailingSampler
+    from pcm_amd.unet_spec import UNetConfig
+    kw = dict(block_out_channels=(64, 128), cross_attention_dim=64, heads=(1, 2), down_attn=(False, True), transformer_depth=(1, 2),
+              use_linear_projection=True, addition_time_embed_dim=32, projection_class_embeddings_input_dim=64 + 6 * 32, layers_per_block=1)
+    oc, pc = O.UNetConfig(**kw), UNetConfig(**kw)
+    sd = O.init_state_dict(oc, 0)
+    W = UNetWeights(pc, sd, "cpu")
+    lora = LoraState(pc, 64, 8.0, "cpu", seed=1, b_std=0.05)
+    olora = {p: (lora.A_peft(m).clone(), m.B.clone()) for p, m in lora.modules.items()}
+    g = torch.Generator().manual_seed(6)
+    B = 2
+    lat = torch.randn(B, 4, 8, 8, generator=g)
+    ctx, unc = torch.randn(B, 7, 64, generator=g), torch.zeros(B, 7, 64)
+    tids = torch.tensor([[1024, 1024, 0, 0, 1024, 1024]] * B)
+    ac = dict(text_embeds=torch.randn(B, 64, generator=g), time_ids=tids)
+    uac = dict(text_embeds=torch.zeros(B, 64), time_ids=tids)
+    acp = PM.sd15_alphas_cumprod()
+
+    def unet_fn(x, t, c):      # the oracle loop calls the positive branch with ctx and the negative one with unc
+        return O.unet_forward(oc, sd, x, t, c, olora, 8.0, added_cond=ac if c is ctx else uac)
+    for guidance in (1.0, 5.0):
+        with torch.no_grad():
+            ref = PM.ddim_sample(unet_fn, ctx, unc, lat, 2, guidance, acp)
+        out = DDIMTrailingSampler(UNet(W, lora)).sample(ctx, unc, num_inference_steps=2, guidance_scale=guidance, latents=lat,
+                                                        added_cond=ac, uncond_added_cond=uac)
+        rel = float((out - ref).norm() / ref.norm())
+        print("SDXL sampled latents rel err %.3e (guidance %.1f)" % (rel, guidance))
+        assert rel < (3e-2 if guidance == 1.0 else 8e-2)
