@@ -102,6 +102,7 @@ def load_state(distiller, input_dir):
     with open(os.path.join(input_dir, "trainer_state.json")) as f:
         st = json.load(f)
     distiller.step_count = st["optimizer_step"]
+    distiller.step_dev.fill_(st["optimizer_step"])      # the AdamW kernel reads its bias-correction step from device memory
     return st["global_step"]
 
 

@@ -232,3 +232,38 @@ def test_sd3_adv_cli_flags_and_lora_lists():
         blk = src[src.index("target_modules=[\n", src.index("transformer_lora_config = LoraConfig(")):]        # (a commented one-line list precedes it)
         blk = blk[:blk.index("]")]
         assert tuple(re.findall(r'"([^"]+)"', blk)) == det
+
+
+def test_resume_restores_adam_step_and_moments(tmp_path):
+    """checkpoint-N -> a fresh trainer -> the next optimizer step must equal the uninterrupted run (moments AND the bias-correction
+    step, which lives in device memory for graph replay)."""
+    from emu_lib import emu_lib
+    from pcm_amd import capi, checkpoint as ck
+    from pcm_amd.model import LoraState
+    from pcm_amd.trainer import Distiller, StepConfig
+    from pcm_amd.unet_spec import UNetConfig
+    capi.set_lib(emu_lib())
+    try:
+        cfg = UNetConfig(block_out_channels=(64, 64), layers_per_block=1, cross_attention_dim=64, heads=2)
+
+        def bare(seed):
+            lora = LoraState(cfg, 64, 8.0, "cpu", seed=seed, b_std=0.01)
+            D = Distiller.__new__(Distiller)       # optimizer half only
+            D.lora, D.cfg, D.world_size, D.pg, D.step_count, D.ema = lora, StepConfig(learning_rate=1e-3), 1, None, 0, None
+            D.step_dev = torch.zeros(1, dtype=torch.int64)
+            D.lr_dev = torch.full((1,), 1e-3)
+            return D
+        g = torch.Generator().manual_seed(0)
+        grads = [torch.randn(bare(5).lora.numel, generator=g) * 1e-3 for _ in range(4)]
+        A = bare(5)
+        for i in range(3):
+            A.lora.grads.copy_(grads[i]); A.optimizer_step()
+        ck.save_state(A, str(tmp_path / "checkpoint-3"), 3)
+        A.lora.grads.copy_(grads[3]); A.optimizer_step()
+        Bd = bare(99)                                # different init: everything must come from the checkpoint
+        assert ck.load_state(Bd, str(tmp_path / "checkpoint-3")) == 3
+        assert Bd.step_count == 3 and int(Bd.step_dev) == 3
+        Bd.lora.grads.copy_(grads[3]); Bd.optimizer_step()
+        assert torch.allclose(Bd.lora.params, A.lora.params, rtol=0, atol=1e-7), float((Bd.lora.params - A.lora.params).abs().max())
+    finally:
+        capi.set_lib(None)
