@@ -154,6 +154,22 @@ def lr_at(args, step):
             return args.learning_rate * step / max(1, w)
         prog = (step - w) / max(1, args.max_train_steps - w)
         return args.learning_rate * max(0.0, 0.5 * (1.0 + math.cos(math.pi * prog)))
+    if args.lr_scheduler == "cosine_with_restarts":      # diffusers get_cosine_with_hard_restarts_schedule_with_warmup (--lr_num_cycles)
+        w = args.lr_warmup_steps
+        if step < w:
+            return args.learning_rate * step / max(1, w)
+        prog = (step - w) / max(1, args.max_train_steps - w)
+        if prog >= 1.0:
+            return 0.0
+        return args.learning_rate * max(0.0, 0.5 * (1.0 + math.cos(math.pi * ((getattr(args, "lr_num_cycles", 1) * prog) % 1.0))))
+    if args.lr_scheduler == "polynomial":                 # diffusers get_polynomial_decay_schedule_with_warmup (--lr_power, lr_end 1e-7)
+        w, lr_end, power = args.lr_warmup_steps, 1e-7, getattr(args, "lr_power", 1.0)
+        if step < w:
+            return args.learning_rate * step / max(1, w)
+        if step > args.max_train_steps:
+            return lr_end
+        pct = 1 - (step - w) / max(1, args.max_train_steps - w)
+        return (args.learning_rate - lr_end) * pct ** power + lr_end
     raise ValueError(f"unsupported --lr_scheduler {args.lr_scheduler}")
 
 

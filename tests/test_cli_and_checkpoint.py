@@ -267,3 +267,19 @@ def test_resume_restores_adam_step_and_moments(tmp_path):
         assert torch.allclose(Bd.lora.params, A.lora.params, rtol=0, atol=1e-7), float((Bd.lora.params - A.lora.params).abs().max())
     finally:
         capi.set_lib(None)
+
+
+def test_lr_schedules_restarts_and_polynomial():
+    """the two extra schedules the SD3 parser exposes knobs for (--lr_num_cycles, --lr_power), against the closed forms of diffusers' get_scheduler."""
+    import math
+    import types
+    cli = load_cli()
+    a = types.SimpleNamespace(learning_rate=1e-4, lr_warmup_steps=10, max_train_steps=110, lr_num_cycles=2, lr_power=2.0, lr_scheduler="cosine_with_restarts")
+    assert cli.lr_at(a, 5) == 1e-4 * 0.5                                   # warm-up
+    assert abs(cli.lr_at(a, 10) - 1e-4) < 1e-12                            # start of cycle 1
+    assert abs(cli.lr_at(a, 35) - 1e-4 * 0.5 * (1 + math.cos(math.pi * 0.5))) < 1e-12
+    assert abs(cli.lr_at(a, 60) - 1e-4) < 1e-12                            # hard restart at half of the decay span
+    assert cli.lr_at(a, 110) == 0.0
+    a.lr_scheduler = "polynomial"
+    assert abs(cli.lr_at(a, 60) - ((1e-4 - 1e-7) * 0.5 ** 2 + 1e-7)) < 1e-15
+    assert abs(cli.lr_at(a, 110) - 1e-7) < 1e-15 and cli.lr_at(a, 500) == 1e-7
