@@ -84,7 +84,10 @@ def load_lora(lora, input_dir):
 
 def save_state(distiller, output_dir, global_step):
     """checkpoint-N directory: adapter + diffusers LoRA (the reference's save hook) + optimizer state."""
-    save_lora(distiller.lora, output_dir, kohya=False)
+    if type(getattr(getattr(distiller, "W", None), "cfg", None)).__name__ == "MMDiTConfig":
+        save_lora_sd3(distiller.lora, output_dir)          # SD3: the transformer save hook's layout (train_pcm_lora_sd3.py:997-1012)
+    else:
+        save_lora(distiller.lora, output_dir, kohya=False)
     lo = distiller.lora
     save_file({"exp_avg": lo.exp_avg.detach().cpu(), "exp_avg_sq": lo.exp_avg_sq.detach().cpu()},
               os.path.join(output_dir, "optimizer.safetensors"))
