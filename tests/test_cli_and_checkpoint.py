@@ -283,3 +283,71 @@ def test_lr_schedules_restarts_and_polynomial():
     a.lr_scheduler = "polynomial"
     assert abs(cli.lr_at(a, 60) - ((1e-4 - 1e-7) * 0.5 ** 2 + 1e-7)) < 1e-15
     assert abs(cli.lr_at(a, 110) - 1e-7) < 1e-15 and cli.lr_at(a, 500) == 1e-7
+
+
+def _load(name):
+    sys.path.insert(0, PKG)
+    spec = importlib.util.spec_from_file_location("pcm_cli_" + name, os.path.join(PKG, name + ".py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_latent_shard_sources_rank_sharding_and_shapes(tmp_path):
+    """--latents_dir shards of the three trainers: files are dealt round-robin to ranks, batches are drawn from the rank's own
+    shards only, the unconditional embeddings come from the shards (SD1.5 / SD3) or are zeros (SDXL, :1216-1221)."""
+    from safetensors.torch import save_file
+    dev = torch.device("cpu")
+    g = torch.Generator().manual_seed(0)
+    # ---- SD1.5
+    d15 = tmp_path / "sd15"
+    d15.mkdir()
+    for i in range(4):
+        t = {"latents": torch.full((3, 4, 8, 8), float(i)), "prompt_embeds": torch.randn(3, 77, 768, generator=g)}
+        if i == 1:
+            t["uncond_prompt_embeds"] = torch.full((77, 768), 7.0)
+        save_file(t, str(d15 / f"shard{i}.safetensors"))
+    cli = load_cli()
+    a = cli.parse_args(["--pretrained_teacher_model", "x", "--latents_dir", str(d15), "--train_batch_size", "5", "--seed", "3"])
+    for rank in range(2):
+        src = cli.LatentSource(a, rank, 2, dev)
+        lat, pe = src.batch()
+        assert lat.shape == (5, 4, 8, 8) and pe.shape == (5, 77, 768) and len(src) == 6 // 5
+        assert set(lat[:, 0, 0, 0].tolist()) <= ({0.0, 2.0} if rank == 0 else {1.0, 3.0})        # shards rank::world
+        assert src.uncond.shape == (5, 77, 768)
+        assert (rank == 1) == bool((src.uncond == 7.0).all())                                  # found in rank 1's shard only
+    with pytest.raises(SystemExit):
+        cli.LatentSource(cli.parse_args(["--pretrained_teacher_model", "x"]), 0, 1, dev)       # neither shards nor --synthetic_data
+    with pytest.raises(FileNotFoundError):
+        cli.LatentSource(a, 5, 8, dev)                                                          # more ranks than shards
+    s = cli.LatentSource(cli.parse_args(["--pretrained_teacher_model", "x", "--synthetic_data", "--resolution", "256", "--train_batch_size", "2"]), 0, 1, dev)
+    assert s.batch()[0].shape == (2, 4, 32, 32)
+    # ---- SDXL
+    dxl = tmp_path / "sdxl"
+    dxl.mkdir()
+    save_file({"latents": torch.randn(4, 4, 16, 16, generator=g), "prompt_embeds": torch.randn(4, 77, 2048, generator=g),
+               "pooled_prompt_embeds": torch.randn(4, 1280, generator=g)}, str(dxl / "a.safetensors"))
+    xl = _load("train_pcm_lora_sdxl_adv")
+    ax = xl.parse_args(["--pretrained_teacher_model", "x", "--latents_dir", str(dxl), "--train_batch_size", "2", "--resolution", "128"])
+    sx = xl.SdxlSource(ax, 0, 1, dev)
+    lat, pe, pp = sx.batch()
+    assert lat.shape == (2, 4, 16, 16) and pe.shape == (2, 77, 2048) and pp.shape == (2, 1280)
+    assert float(sx.uncond.abs().max()) == 0.0 and float(sx.uncond_pooled.abs().max()) == 0.0 and sx.time_ids.tolist()[0] == [128, 128, 0, 0, 128, 128]
+    # ---- SD3
+    d3 = tmp_path / "sd3"
+    d3.mkdir()
+    save_file({"latents": torch.randn(4, 16, 8, 8, generator=g), "prompt_embeds": torch.randn(4, 20, 96, generator=g),
+               "pooled_prompt_embeds": torch.randn(4, 64, generator=g), "uncond_prompt_embeds": torch.full((20, 96), 2.0),
+               "uncond_pooled_prompt_embeds": torch.full((64,), 3.0)}, str(d3 / "a.safetensors"))
+    s3 = _load("train_pcm_lora_sd3")
+    from pcm_amd.mmdit_spec import MMDiTConfig
+    mc = MMDiTConfig(sample_size=16, num_layers=1, num_attention_heads=2, joint_attention_dim=96, caption_projection_dim=128, pooled_projection_dim=64,
+                     pos_embed_max_size=12)
+    a3 = s3.parse_args(["--pretrained_teacher_model", "x", "--latents_dir", str(d3), "--train_batch_size", "3"])
+    src3 = s3.SD3Source(a3, 0, 1, dev, mc)
+    lat, pe, pp = src3.batch()
+    assert lat.shape == (3, 16, 8, 8) and pe.shape == (3, 20, 96) and pp.shape == (3, 64)
+    assert src3.uncond.shape == (3, 20, 96) and bool((src3.uncond == 2.0).all()) and bool((src3.uncond_pooled == 3.0).all())
+    syn = s3.SD3Source(s3.parse_args(["--pretrained_teacher_model", "x", "--synthetic_data", "--resolution", "128", "--train_batch_size", "2"]), 0, 1, dev, mc)
+    lat, pe, pp = syn.batch()
+    assert lat.shape == (2, 16, 16, 16) and pe.shape == (2, 154, 96) and pp.shape == (2, 64)
