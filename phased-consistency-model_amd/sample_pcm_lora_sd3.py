@@ -22,6 +22,7 @@ def parse_args(argv=None):
     p = argparse.ArgumentParser(description=__doc__.split("\n")[0])
     p.add_argument("--pretrained_teacher_model", required=True, help="diffusers SD3 directory, or 'random'")
     p.add_argument("--num_layers", type=int, default=None, help="(random weights) MMDiT depth, default 24")
+    p.add_argument("--tiny_model", action="store_true", help="(random weights) a 128-wide MMDiT for smoke tests of the CLI itself")
     p.add_argument("--lora_dir", default=None)
     p.add_argument("--lora_rank", type=int, default=32)
     p.add_argument("--prompt_embeds", default=None)
@@ -44,14 +45,11 @@ def main(args):
     from pcm_amd.mmdit import MMDiT, MMDiTWeights, sd3_lora_state
     from pcm_amd.mmdit_spec import MMDiTConfig, random_state_dict
     from pcm_amd.sampler_sd3 import PCMFMLatentSampler
+    import train_pcm_lora_sd3 as tr
     capi.lib()
-    dev = torch.device("cuda", 0)
-    if args.pretrained_teacher_model == "random":
-        cfg = MMDiTConfig(num_layers=args.num_layers) if args.num_layers else MMDiTConfig.sd3_medium()
-        sd = random_state_dict(cfg, 0, dev)
-    else:
-        cfg = MMDiTConfig.sd3_medium()
-        sd = ck.load_transformer_state_dict(args.pretrained_teacher_model)
+    dev = tr.pick_device(0)
+    cfg = tr.model_config(args)
+    sd = random_state_dict(cfg, 0, dev) if args.pretrained_teacher_model == "random" else ck.load_transformer_state_dict(args.pretrained_teacher_model)
     W = MMDiTWeights(cfg, sd, dev, need_bwd=False)
     del sd
     lora = sd3_lora_state(cfg, args.lora_rank, 8.0, dev, seed=args.seed)

@@ -93,6 +93,7 @@ def parse_args(argv=None):
     p.add_argument("--latents_dir", type=str, default=None, help="safetensors shards of precomputed latents / prompt embeds")
     p.add_argument("--synthetic_data", action="store_true", help="seeded N(0,1) latents / prompt embeds")
     p.add_argument("--ema_rate", type=float, default=None, help="enable the reference's (dead) update_ema on a shadow copy")
+    p.add_argument("--tiny_model", action="store_true", help="(with random weights) a narrow UNet of the same topology for smoke tests of the CLI itself")
     args = p.parse_args(argv)
     env_local_rank = int(os.environ.get("LOCAL_RANK", -1))      # :730-732
     if env_local_rank != -1 and env_local_rank != args.local_rank:
@@ -123,8 +124,8 @@ class LatentSource:
         elif not args.synthetic_data:
             raise SystemExit("pcm_amd: give --latents_dir or --synthetic_data (VAE/CLIP encoding is out of scope, see --help)")
         if self.uncond is None:
-            self.uncond = torch.randn(77, 768, generator=self.g, device=device)
-        self.uncond = self.uncond.expand(self.bs, 77, 768).contiguous()
+            self.uncond = torch.randn(77, 768, generator=self.g, device=device) if not self.shards else torch.zeros_like(self.pe[0])
+        self.uncond = self.uncond.expand(self.bs, *self.uncond.shape[-2:]).contiguous()
 
     def __len__(self):
         return (self.lat.shape[0] // self.bs) if self.shards else 10 ** 9
@@ -135,6 +136,30 @@ class LatentSource:
             return self.lat[idx].contiguous(), self.pe[idx].contiguous()
         return (torch.randn(self.bs, 4, self.hw, self.hw, generator=self.g, device=self.device),
                 torch.randn(self.bs, 77, 768, generator=self.g, device=self.device))
+
+
+def pick_device(local_rank):
+    """cuda:<local_rank>; PCM_CLI_DEVICE=cpu (tests: the CLI end to end on the host emulator, which the test installs as the library)."""
+    if os.environ.get("PCM_CLI_DEVICE") == "cpu":
+        return torch.device("cpu")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    return dev
+
+
+def unet_config(args, kind="sd15"):
+    """the trainer's UNet: SD1.5 / SDXL, or with --tiny_model (random weights only) a narrow config of the same topology."""
+    from pcm_amd.unet_spec import UNetConfig
+    tiny = getattr(args, "tiny_model", False) and args.pretrained_teacher_model == "random"
+    if kind == "sdxl":
+        if tiny:
+            return UNetConfig(block_out_channels=(64, 128), cross_attention_dim=64, heads=(1, 2), down_attn=(False, True),
+                              transformer_depth=(1, 2), use_linear_projection=True, addition_time_embed_dim=32,
+                              projection_class_embeddings_input_dim=64 + 6 * 32, layers_per_block=1)
+        return UNetConfig.sdxl()
+    if tiny:
+        return UNetConfig(block_out_channels=(64, 128), layers_per_block=1, cross_attention_dim=64, heads=2)
+    return UNetConfig.sd15()
 
 
 def lr_at(args, step):
@@ -194,12 +219,11 @@ def main(args):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         torch.distributed.init_process_group("nccl", rank=rank, world_size=world)
-    device = torch.device("cuda", local_rank)
-    torch.cuda.set_device(device)
+    device = pick_device(local_rank)
     capi.lib()
     if args.seed is not None:
         torch.manual_seed(args.seed + rank)                       # set_seed(seed + process_index), :795-797
-    ucfg = UNetConfig.sd15()
+    ucfg = unet_config(args)
     if args.pretrained_teacher_model == "random":
         sd = random_state_dict(ucfg, seed=0, device=device)
     else:

@@ -52,15 +52,16 @@ def main(args):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         torch.distributed.init_process_group("nccl", rank=rank, world_size=world)
-    device = torch.device("cuda", local_rank)
-    torch.cuda.set_device(device)
+    device = base.pick_device(local_rank)
     capi.lib()
-    ucfg = UNetConfig.sd15()
+    ucfg = base.unet_config(args)
     sd = random_state_dict(ucfg, 0, device) if args.pretrained_teacher_model == "random" else ck.load_unet_state_dict(args.pretrained_teacher_model)
     W = UNetWeights(ucfg, sd, device)
     del sd
     lora = LoraState(ucfg, args.lora_rank, 8.0, device, seed=(args.seed or 0))
-    disc = Discriminator(device=device, seed=(args.seed or 0) + 1)
+    b = tuple(ucfg.block_out_channels)                            # feature taps: every down-block output, mid, every up-block output
+    dims = b + (b[-1],) + b[::-1] if getattr(args, "tiny_model", False) else None          # (SD1.5: discriminator_sd15.py:377)
+    disc = Discriminator(**(dict(adapter_channel_dims=dims) if dims else {}), device=device, seed=(args.seed or 0) + 1)
     if world > 1:
         torch.distributed.broadcast(lora.params, src=0); lora.repack()
         torch.distributed.broadcast(disc.params, src=0); disc.repack()

@@ -101,6 +101,7 @@ def parse_args(argv=None):
     p.add_argument("--latents_dir", type=str, default=None, help="safetensors shards of precomputed latents / text embeddings")
     p.add_argument("--synthetic_data", action="store_true", help="seeded N(0,1) latents / embeddings")
     p.add_argument("--num_layers", type=int, default=None, help="(with --pretrained_teacher_model random) MMDiT depth, default 24")
+    p.add_argument("--tiny_model", action="store_true", help="(with random weights) a 128-wide MMDiT for smoke tests of the CLI itself")
     args = p.parse_args(argv)
     env_local_rank = int(os.environ.get("LOCAL_RANK", -1))
     if env_local_rank != -1 and env_local_rank != args.local_rank:
@@ -152,6 +153,25 @@ class SD3Source:
         return r(self.bs, self.cin, self.hw, self.hw), r(self.bs, self.Lc, self.jd), r(self.bs, self.pd)
 
 
+def pick_device(local_rank):
+    """cuda:<local_rank>; PCM_CLI_DEVICE=cpu (tests: the CLI end to end on the host emulator, which the test installs as the library)."""
+    if os.environ.get("PCM_CLI_DEVICE") == "cpu":
+        return torch.device("cpu")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    return dev
+
+
+def model_config(args):
+    from pcm_amd.mmdit_spec import MMDiTConfig
+    if args.pretrained_teacher_model != "random":
+        return MMDiTConfig.sd3_medium()
+    if getattr(args, "tiny_model", False):
+        return MMDiTConfig(sample_size=16, num_layers=args.num_layers or 2, num_attention_heads=2, joint_attention_dim=96, caption_projection_dim=128,
+                           pooled_projection_dim=64, pos_embed_max_size=16)
+    return MMDiTConfig(num_layers=args.num_layers) if args.num_layers else MMDiTConfig.sd3_medium()
+
+
 def main(args):
     from pcm_amd import capi, checkpoint as ck
     from pcm_amd.mmdit import MMDiTWeights, sd3_lora_state
@@ -170,16 +190,14 @@ def main(args):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         torch.distributed.init_process_group("nccl", rank=rank, world_size=world)
-    device = torch.device("cuda", local_rank)
-    torch.cuda.set_device(device)
+    device = pick_device(local_rank)
     capi.lib()
     if args.seed is not None:
         torch.manual_seed(args.seed + rank)
+    mcfg = model_config(args)
     if args.pretrained_teacher_model == "random":
-        mcfg = MMDiTConfig(num_layers=args.num_layers) if args.num_layers else MMDiTConfig.sd3_medium()
         sd = random_state_dict(mcfg, seed=0, device=device)
     else:
-        mcfg = MMDiTConfig.sd3_medium()
         sd = ck.load_transformer_state_dict(args.pretrained_teacher_model)
     W = MMDiTWeights(mcfg, sd, device)
     del sd

@@ -70,16 +70,14 @@ def main(args):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         torch.distributed.init_process_group("nccl", rank=rank, world_size=world)
-    device = torch.device("cuda", local_rank)
-    torch.cuda.set_device(device)
+    device = sd3.pick_device(local_rank)
     capi.lib()
     if args.seed is not None:
         torch.manual_seed(args.seed + rank)
+    mcfg = sd3.model_config(args)
     if args.pretrained_teacher_model == "random":
-        mcfg = MMDiTConfig(num_layers=args.num_layers) if args.num_layers else MMDiTConfig.sd3_medium()
         sd = random_state_dict(mcfg, seed=0, device=device)
     else:
-        mcfg = MMDiTConfig.sd3_medium()
         sd = ck.load_transformer_state_dict(args.pretrained_teacher_model)
     W = MMDiTWeights(mcfg, sd, device)
     del sd

@@ -73,8 +73,9 @@ class SdxlSource:
             raise SystemExit("pcm_amd: give --latents_dir or --synthetic_data (VAE / text encoders are out of scope)")
         r = args.resolution
         self.time_ids = torch.tensor([[r, r, 0, 0, r, r]] * self.bs, device=device)                       # :1115-1122
-        self.uncond = torch.zeros(self.bs, 77, 2048, device=device)                                        # zero uncond embeds, :1216-1221
-        self.uncond_pooled = torch.zeros(self.bs, 1280, device=device)
+        pe_shape, pp_dim = ((77, 2048), 1280) if not self.data else (tuple(self.data["prompt_embeds"].shape[1:]), self.data["pooled_prompt_embeds"].shape[1])
+        self.uncond = torch.zeros(self.bs, *pe_shape, device=device)                                       # zero uncond embeds, :1216-1221
+        self.uncond_pooled = torch.zeros(self.bs, pp_dim, device=device)
 
     def __len__(self):
         return (self.data["latents"].shape[0] // self.bs) if self.data else 10 ** 9
@@ -100,10 +101,9 @@ def main(args):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         torch.distributed.init_process_group("nccl", rank=rank, world_size=world)
-    device = torch.device("cuda", local_rank)
-    torch.cuda.set_device(device)
+    device = base.pick_device(local_rank)
     capi.lib()
-    ucfg = UNetConfig.sdxl()
+    ucfg = base.unet_config(args, "sdxl")
     sd = random_state_dict(ucfg, 0, device) if args.pretrained_teacher_model == "random" else ck.load_unet_state_dict(args.pretrained_teacher_model)
     W = UNetWeights(ucfg, sd, device)
     del sd
@@ -116,7 +116,9 @@ def main(args):
                      max_grad_norm=args.max_grad_norm, lora_rank=args.lora_rank, not_apply_cfg_solver=args.not_apply_cfg_solver)
     adv = args.adv_weight != 0
     if adv:
-        disc = Discriminator(ADAPTER_DIMS_SDXL, num_h_per_head=1, device=device, seed=(args.seed or 0) + 1, ksize=1, taps="down_mid")
+        b = ucfg.block_out_channels
+        dims = ADAPTER_DIMS_SDXL if not getattr(args, "tiny_model", False) else tuple(b) + (b[-1],)            # down-block outputs + mid
+        disc = Discriminator(dims, num_h_per_head=1, device=device, seed=(args.seed or 0) + 1, ksize=1, taps="down_mid")
         if world > 1:
             torch.distributed.broadcast(disc.params, src=0); disc.repack()
         D = AdvDistiller(W, lora, cfg, disc, adv_weight=args.adv_weight, adv_lr=args.adv_lr, world_size=world)

@@ -351,3 +351,106 @@ def test_latent_shard_sources_rank_sharding_and_shapes(tmp_path):
     syn = s3.SD3Source(s3.parse_args(["--pretrained_teacher_model", "x", "--synthetic_data", "--resolution", "128", "--train_batch_size", "2"]), 0, 1, dev, mc)
     lat, pe, pp = syn.batch()
     assert lat.shape == (2, 16, 16, 16) and pe.shape == (2, 154, 96) and pp.shape == (2, 64)
+
+
+@pytest.mark.slow
+def test_sd3_clis_end_to_end_on_the_emulator(tmp_path, monkeypatch):
+    """train_pcm_lora_sd3.py (train, checkpoint, resume, final LoRA file), train_pcm_lora_sd3_adv.py (one D and one G step) and
+    sample_pcm_lora_sd3.py (loads the trained LoRA) run as programs: PCM_CLI_DEVICE=cpu + the host emulator as the library."""
+    from emu_lib import emu_lib
+    from pcm_amd import capi
+    from safetensors.torch import load_file, save_file
+    g = torch.Generator().manual_seed(0)
+    shards = tmp_path / "shards"
+    shards.mkdir()
+    save_file({"latents": torch.randn(6, 16, 8, 8, generator=g), "prompt_embeds": torch.randn(6, 5, 96, generator=g),
+               "pooled_prompt_embeds": torch.randn(6, 64, generator=g), "uncond_prompt_embeds": torch.randn(5, 96, generator=g),
+               "uncond_pooled_prompt_embeds": torch.randn(64, generator=g)}, str(shards / "a.safetensors"))
+    monkeypatch.setenv("PCM_CLI_DEVICE", "cpu")
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    capi.set_lib(emu_lib())
+    try:
+        out = tmp_path / "out"
+        common = ["--pretrained_teacher_model", "random", "--tiny_model", "--latents_dir", str(shards), "--train_batch_size", "2", "--lora_rank", "32",
+                  "--learning_rate", "1e-3", "--num_euler_timesteps", "20", "--multiphase", "2", "--seed", "1", "--output_dir", str(out)]
+        tr = _load("train_pcm_lora_sd3")
+        tr.main(tr.parse_args(common + ["--max_train_steps", "3", "--checkpointing_steps", "2"]))
+        assert (out / "checkpoint-2" / "optimizer.safetensors").exists() and (out / "checkpoint-2" / "pytorch_lora_weights.safetensors").exists()
+        sd = load_file(str(out / "pytorch_lora_weights.safetensors"))
+        assert sd["transformer.transformer_blocks.0.attn.to_q.lora_A.weight"].shape == (32, 128)
+        assert float(sd["transformer.transformer_blocks.0.attn.to_q.lora_B.weight"].abs().max()) > 0          # B left zero init: it trained
+        log = [json.loads(l) for l in open(out / "logs" / "text2image-fine-tune.jsonl")]
+        assert [r["step"] for r in log] == [1, 2, 3] and all(r["loss"] > 0 for r in log)
+        tr.main(tr.parse_args(common + ["--max_train_steps", "4", "--resume_from_checkpoint", "latest"]))           # resumes at 2, runs 3..4
+        log = [json.loads(l) for l in open(out / "logs" / "text2image-fine-tune.jsonl")]
+        assert [r["step"] for r in log] == [1, 2, 3, 3, 4]
+        # sampler CLI with the trained adapter
+        pe = tmp_path / "pe.safetensors"
+        save_file({"prompt_embeds": torch.randn(2, 5, 96, generator=g), "pooled_prompt_embeds": torch.randn(2, 64, generator=g),
+                   "uncond_prompt_embeds": torch.randn(5, 96, generator=g), "uncond_pooled_prompt_embeds": torch.randn(64, generator=g)}, str(pe))
+        sm = _load("sample_pcm_lora_sd3")
+        lat_path = tmp_path / "lat.safetensors"
+        sm.main(sm.parse_args(["--pretrained_teacher_model", "random", "--tiny_model", "--lora_dir", str(out), "--prompt_embeds", str(pe),
+                               "--num_inference_steps", "2", "--guidance_scale", "1.5", "--resolution", "64", "--output", str(lat_path)]))
+        lat = load_file(str(lat_path))["latents"]
+        assert lat.shape == (2, 16, 8, 8) and bool(torch.isfinite(lat).all())
+        # adversarial trainer: one discriminator and one generator step
+        adv = _load("train_pcm_lora_sd3_adv")
+        out2 = tmp_path / "out_adv"
+        adv.main(adv.parse_args([a if a != str(out) else str(out2) for a in common] + ["--max_train_steps", "2", "--loss_type", "huber"]))
+        log = [json.loads(l) for l in open(out2 / "logs" / "text2image-fine-tune.jsonl")]
+        assert "d_loss" in log[0] and "loss_cm" in log[1] and "g_loss" in log[1]
+        sd = load_file(str(out2 / "pytorch_lora_weights.safetensors"))
+        assert "transformer.pos_embed.proj.lora_A.weight" in sd and sd["transformer.pos_embed.proj.lora_A.weight"].shape == (32, 16, 2, 2)
+        assert "transformer.transformer_blocks.0.norm1.linear.lora_B.weight" in sd
+    finally:
+        capi.set_lib(None)
+
+
+@pytest.mark.slow
+def test_unet_clis_end_to_end_on_the_emulator(tmp_path, monkeypatch):
+    """train_pcm_lora_sd15.py, train_pcm_lora_sd15_adv.py and train_pcm_lora_sdxl_adv.py as programs on a narrow UNet
+    (--tiny_model, PCM_CLI_DEVICE=cpu + the host emulator as the library): step loop, logs, checkpoints, final LoRA files."""
+    from emu_lib import emu_lib
+    from pcm_amd import capi
+    from safetensors.torch import load_file, save_file
+    g = torch.Generator().manual_seed(0)
+    d15, dxl = tmp_path / "s15", tmp_path / "sxl"
+    d15.mkdir(); dxl.mkdir()
+    save_file({"latents": torch.randn(6, 4, 8, 8, generator=g), "prompt_embeds": torch.randn(6, 7, 64, generator=g),
+               "uncond_prompt_embeds": torch.randn(7, 64, generator=g)}, str(d15 / "a.safetensors"))
+    save_file({"latents": torch.randn(6, 4, 8, 8, generator=g), "prompt_embeds": torch.randn(6, 7, 64, generator=g),
+               "pooled_prompt_embeds": torch.randn(6, 64, generator=g)}, str(dxl / "a.safetensors"))
+    monkeypatch.setenv("PCM_CLI_DEVICE", "cpu")
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    capi.set_lib(emu_lib())
+    try:
+        def args(out, shards, extra):
+            return ["--pretrained_teacher_model", "random", "--tiny_model", "--latents_dir", str(shards), "--train_batch_size", "1", "--learning_rate", "1e-3",
+                    "--multiphase", "2", "--seed", "1", "--output_dir", str(out)] + extra
+        import time as _t
+        _t0 = _t.time()
+        cli = load_cli()
+        o1 = tmp_path / "o1"
+        cli.main(cli.parse_args(args(o1, d15, ["--max_train_steps", "2", "--checkpointing_steps", "2", "--loss_type", "huber"])))
+        assert (o1 / "checkpoint-2" / "trainer_state.json").exists()
+        sd = load_file(str(o1 / "adapter_model.safetensors"))
+        assert any(k.endswith("conv1.lora_A.weight") and v.shape[0] == 64 for k, v in sd.items())
+        assert (o1 / "pcm_lora_kohya_converted.safetensors").exists() and (o1 / "unet_lora" / "pytorch_lora_weights.safetensors").exists()
+        log = [json.loads(l) for l in open(o1 / "logs" / "text2image-fine-tune.jsonl")]
+        assert [r["step"] for r in log] == [1, 2] and all(r["loss"] > 0 and r["grad_norm"] > 0 for r in log)
+        print("sd15 base cli %.1f s" % (_t.time() - _t0)); _t0 = _t.time()
+        adv = _load("train_pcm_lora_sd15_adv")
+        o2 = tmp_path / "o2"
+        adv.main(adv.parse_args(args(o2, d15, ["--max_train_steps", "2"])))
+        log = [json.loads(l) for l in open(o2 / "logs" / "text2image-fine-tune.jsonl")]
+        assert "d_loss" in log[0] and "loss_cm" in log[1]
+        print("sd15 adv cli %.1f s" % (_t.time() - _t0)); _t0 = _t.time()
+        xl = _load("train_pcm_lora_sdxl_adv")
+        o3 = tmp_path / "o3"
+        xl.main(xl.parse_args(args(o3, dxl, ["--max_train_steps", "2", "--resolution", "64", "--adv_weight", "0"])))   # (adv SDXL step: tests/test_emu_adv.py)
+        log = [json.loads(l) for l in open(o3 / "logs" / "text2image-fine-tune.jsonl")]
+        assert len(log) == 2 and (o3 / "adapter_model.safetensors").exists()
+        print("sdxl adv cli %.1f s" % (_t.time() - _t0))
+    finally:
+        capi.set_lib(None)
