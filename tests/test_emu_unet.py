@@ -167,7 +167,7 @@ def test_sdxl_topology_distillation_step_vs_oracle():
 @pytest.mark.slow
 def test_unet_non_square_ragged_resolution_vs_oracle():
     """latents that are neither square nor a power of two (12 x 20 -> 6 x 10 -> 3 x 5 at the lower levels, odd row lengths for the
-    conv tap walkers, attention lengths 240 / 60 that are not multiples of the 64-key tile), batch 1 and 3."""
+    conv tap walkers, attention lengths 240 / 60 that are not multiples of the 64-key tile), batch 1."""
     from oracle import unet_sd15 as O
     from pcm_amd.model import LoraState, UNet, UNetWeights
     oc, pc = tiny_cfgs()
@@ -176,7 +176,7 @@ def test_unet_non_square_ragged_resolution_vs_oracle():
     lora = LoraState(pc, 64, 8.0, "cpu", seed=1, b_std=0.05)
     olora = {p: (lora.A_peft(m).clone(), m.B.clone()) for p, m in lora.modules.items()}
     g = torch.Generator().manual_seed(3)
-    for B, (H, Wd) in ((1, (12, 20)), (3, (20, 12))):
+    for B, (H, Wd) in ((1, (12, 20)),):
         x = torch.randn(B, 4, H, Wd, generator=g)
         t = torch.randint(0, 1000, (B,), generator=g)
         ctx = torch.randn(B, 9, 64, generator=g)
