@@ -20,6 +20,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 def parse_args(argv=None):
     p = argparse.ArgumentParser(description=__doc__.split("\n")[0])
     p.add_argument("--pretrained_teacher_model", required=True, help="diffusers SD1.5 directory, or 'random'")
+    p.add_argument("--tiny_model", action="store_true", help="(random weights) a narrow UNet of the same topology for smoke tests of the CLI itself")
     p.add_argument("--lora_dir", default=None)
     p.add_argument("--lora_rank", type=int, default=64)
     p.add_argument("--prompt_embeds", default=None)
@@ -39,9 +40,10 @@ def main(args):
     from pcm_amd.model import LoraState, UNet, UNetWeights
     from pcm_amd.sampler import DDIMTrailingSampler
     from pcm_amd.unet_spec import UNetConfig, random_state_dict
+    import train_pcm_lora_sd15 as tr
     capi.lib()
-    dev = torch.device("cuda", 0)
-    cfg = UNetConfig.sd15()
+    dev = tr.pick_device(0)
+    cfg = tr.unet_config(args)
     sd = random_state_dict(cfg, 0, dev) if args.pretrained_teacher_model == "random" else ck.load_unet_state_dict(args.pretrained_teacher_model)
     W = UNetWeights(cfg, sd, dev, need_bwd=False)
     lora = LoraState(cfg, args.lora_rank, 8.0, dev, seed=args.seed)

@@ -21,6 +21,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 def parse_args(argv=None):
     p = argparse.ArgumentParser(description=__doc__.split("\n")[0])
     p.add_argument("--pretrained_teacher_model", required=True, help="diffusers SDXL directory, or 'random'")
+    p.add_argument("--tiny_model", action="store_true", help="(random weights) a narrow UNet of the same topology for smoke tests of the CLI itself")
     p.add_argument("--lora_dir", default=None)
     p.add_argument("--lora_rank", type=int, default=64)
     p.add_argument("--prompt_embeds", default=None)
@@ -40,9 +41,10 @@ def main(args):
     from pcm_amd.model import LoraState, UNet, UNetWeights
     from pcm_amd.sampler import DDIMTrailingSampler
     from pcm_amd.unet_spec import UNetConfig, random_state_dict
+    import train_pcm_lora_sd15 as tr
     capi.lib()
-    dev = torch.device("cuda", 0)
-    cfg = UNetConfig.sdxl()
+    dev = tr.pick_device(0)
+    cfg = tr.unet_config(args, "sdxl")
     sd = random_state_dict(cfg, 0, dev) if args.pretrained_teacher_model == "random" else ck.load_unet_state_dict(args.pretrained_teacher_model)
     W = UNetWeights(cfg, sd, dev, need_bwd=False)
     del sd
@@ -61,7 +63,7 @@ def main(args):
         unp = unp.to(dev, torch.float32).expand(B, -1).contiguous() if unp is not None else torch.zeros_like(pp)
     else:
         B = max(1, args.synthetic_prompts)
-        pe, pp = torch.randn(B, 77, cfg.cross_attention_dim, generator=g, device=dev), torch.randn(B, 1280, generator=g, device=dev)
+        pe, pp = torch.randn(B, 77, cfg.cross_attention_dim, generator=g, device=dev), torch.randn(B, cfg.projection_class_embeddings_input_dim - 6 * cfg.addition_time_embed_dim, generator=g, device=dev)
         un, unp = torch.zeros_like(pe), torch.zeros_like(pp)           # force_zeros_for_empty_prompt
     tids = torch.tensor([[R, R, 0, 0, R, R]] * B, device=dev)
     hw = R // 8

@@ -439,6 +439,14 @@ def test_unet_clis_end_to_end_on_the_emulator(tmp_path, monkeypatch):
         assert (o1 / "pcm_lora_kohya_converted.safetensors").exists() and (o1 / "unet_lora" / "pytorch_lora_weights.safetensors").exists()
         log = [json.loads(l) for l in open(o1 / "logs" / "text2image-fine-tune.jsonl")]
         assert [r["step"] for r in log] == [1, 2] and all(r["loss"] > 0 and r["grad_norm"] > 0 for r in log)
+        sm = _load("sample_pcm_lora_sd15")                      # sampler CLI with the adapter just trained
+        sm.main(sm.parse_args(["--pretrained_teacher_model", "random", "--tiny_model", "--lora_dir", str(o1), "--synthetic_prompts", "1",
+                               "--num_inference_steps", "2", "--guidance_scale", "2.0", "--resolution", "64", "--output", str(tmp_path / "l15.safetensors")]))
+        assert load_file(str(tmp_path / "l15.safetensors"))["latents"].shape == (1, 4, 8, 8)
+        smx = _load("sample_pcm_lora_sdxl")
+        smx.main(smx.parse_args(["--pretrained_teacher_model", "random", "--tiny_model", "--synthetic_prompts", "1", "--num_inference_steps", "1",
+                                 "--resolution", "64", "--output", str(tmp_path / "lxl.safetensors")]))
+        assert bool(torch.isfinite(load_file(str(tmp_path / "lxl.safetensors"))["latents"]).all())
         print("sd15 base cli %.1f s" % (_t.time() - _t0)); _t0 = _t.time()
         adv = _load("train_pcm_lora_sd15_adv")
         o2 = tmp_path / "o2"
