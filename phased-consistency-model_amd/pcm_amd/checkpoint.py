@@ -78,6 +78,35 @@ def load_transformer_state_dict(pretrained_dir):
     return sd
 
 
+def sd3_lora_from_file(cfg, path, device, lora_alpha=8.0, scale=1.0):
+    """LoRA state for the SD3 transformer inferred FROM a LoRA file: ``pytorch_lora_weights.safetensors`` (``transformer.<module>.lora_A|B
+    .weight``, what the trainers and StableDiffusion3Pipeline.save_lora_weights write and ``pipe.load_lora_weights`` of
+    code/text_to_image_sd3/sd3_test.py:13-20 reads) or a peft ``adapter_model.safetensors``.  Module set and rank come from the file, so
+    adapters of the base trainer (8 suffixes) and of the adversarial trainers (22-entry list) both load.  ``scale``: sd3_test.py's ``alpha``
+    (every tensor multiplied by sqrt(alpha))."""
+    from .mmdit import sd3_lora_state  # noqa: F401  (documented entry point; the state is built directly below)
+    from .mmdit_spec import param_spec
+    from .model import LoraState
+    raw = load_file(path)
+    norm = {}
+    for k, v in raw.items():
+        for pre in ("transformer.", "base_model.model."):
+            if k.startswith(pre):
+                k = k[len(pre):]
+        norm[k] = v
+    have = {k[:-len(".lora_A.weight")] for k in norm if k.endswith(".lora_A.weight")}
+    shapes = [(k[:-len(".weight")], shp) for k, shp in param_spec(cfg) if k.endswith(".weight")]
+    targets = [(p_, shp) for p_, shp in shapes if p_ in have]
+    unknown = have - {p_ for p_, _ in targets}
+    if unknown or not targets:
+        raise KeyError(f"{path}: LoRA modules not in the SD3 transformer: {sorted(unknown)[:3]}" if unknown else f"{path}: no lora_A tensors")
+    rank = int(norm[targets[0][0] + ".lora_A.weight"].shape[0])
+    lora = LoraState(cfg, rank, lora_alpha, device, targets=targets, init="gaussian")
+    f = float(scale) ** 0.5
+    lora.load_peft_state_dict({f"base_model.model.{p_}.lora_{ab}.weight": norm[f"{p_}.lora_{ab}.weight"].float() * f for p_, _ in targets for ab in "AB"})
+    return lora
+
+
 def load_lora(lora, input_dir):
     lora.load_peft_state_dict(load_file(os.path.join(input_dir, "adapter_model.safetensors")))
 

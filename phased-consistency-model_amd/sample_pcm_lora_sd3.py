@@ -23,7 +23,9 @@ def parse_args(argv=None):
     p.add_argument("--pretrained_teacher_model", required=True, help="diffusers SD3 directory, or 'random'")
     p.add_argument("--num_layers", type=int, default=None, help="(random weights) MMDiT depth, default 24")
     p.add_argument("--tiny_model", action="store_true", help="(random weights) a 128-wide MMDiT for smoke tests of the CLI itself")
-    p.add_argument("--lora_dir", default=None)
+    p.add_argument("--lora_dir", default=None, help="trainer output directory (reads its pytorch_lora_weights.safetensors)")
+    p.add_argument("--lora_file", default=None, help="a LoRA safetensors file (diffusers 'transformer.*' or peft keys); module set and rank are read from it")
+    p.add_argument("--lora_scale", type=float, default=1.0, help="sd3_test.py's alpha: LoRA tensors are multiplied by sqrt(alpha)")
     p.add_argument("--lora_rank", type=int, default=32)
     p.add_argument("--prompt_embeds", default=None)
     p.add_argument("--synthetic_prompts", type=int, default=0)
@@ -52,9 +54,11 @@ def main(args):
     sd = random_state_dict(cfg, 0, dev) if args.pretrained_teacher_model == "random" else ck.load_transformer_state_dict(args.pretrained_teacher_model)
     W = MMDiTWeights(cfg, sd, dev, need_bwd=False)
     del sd
-    lora = sd3_lora_state(cfg, args.lora_rank, 8.0, dev, seed=args.seed)
-    if args.lora_dir:
-        ck.load_lora(lora, args.lora_dir)
+    lora_file = args.lora_file or (os.path.join(args.lora_dir, "pytorch_lora_weights.safetensors") if args.lora_dir else None)
+    if lora_file:
+        lora = ck.sd3_lora_from_file(cfg, lora_file, dev, scale=args.lora_scale)
+    else:
+        lora = sd3_lora_state(cfg, args.lora_rank, 8.0, dev, seed=args.seed)          # B = 0: the teacher
     g = torch.Generator(device=dev).manual_seed(args.seed)
     un = unp = None
     if args.prompt_embeds:

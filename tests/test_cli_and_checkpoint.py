@@ -403,6 +403,16 @@ def test_sd3_clis_end_to_end_on_the_emulator(tmp_path, monkeypatch):
         sd = load_file(str(out2 / "pytorch_lora_weights.safetensors"))
         assert "transformer.pos_embed.proj.lora_A.weight" in sd and sd["transformer.pos_embed.proj.lora_A.weight"].shape == (32, 16, 2, 2)
         assert "transformer.transformer_blocks.0.norm1.linear.lora_B.weight" in sd
+        # the sampler reads module set and rank from the file: the 22-entry adapter of the adversarial trainer loads as well
+        sm.main(sm.parse_args(["--pretrained_teacher_model", "random", "--tiny_model", "--lora_file", str(out2 / "pytorch_lora_weights.safetensors"),
+                               "--lora_scale", "1.0", "--prompt_embeds", str(pe), "--num_inference_steps", "1", "--resolution", "64", "--output", str(lat_path)]))
+        from pcm_amd import checkpoint as ck
+        from pcm_amd.mmdit_spec import MMDiTConfig
+        tcfg = tr.model_config(tr.parse_args(["--pretrained_teacher_model", "random", "--tiny_model"]))
+        lo = ck.sd3_lora_from_file(tcfg, str(out2 / "pytorch_lora_weights.safetensors"), "cpu", scale=4.0)
+        assert lo.real_rank == 32 and "pos_embed.proj" in lo.modules and len(lo.modules) == len(sd) // 2
+        m0 = lo.modules["transformer_blocks.0.attn.to_q"]
+        assert torch.allclose(m0.A[:32], 2.0 * sd["transformer.transformer_blocks.0.attn.to_q.lora_A.weight"])       # sqrt(alpha) on every tensor
     finally:
         capi.set_lib(None)
 
