@@ -78,6 +78,43 @@ def load_transformer_state_dict(pretrained_dir):
     return sd
 
 
+def unet_lora_from_file(cfg, path, device, lora_alpha=8.0, scale=1.0):
+    """LoRA state for the UNet inferred FROM a LoRA file in any of the three formats the reference handles: kohya-ss
+    (``lora_unet_<module_with_underscores>.lora_down|lora_up.weight`` + ``.alpha``: what get_module_kohya_state_dict writes,
+    train_pcm_lora_sd15.py:52-72, and what demo/app.py loads), peft (``base_model.model.<module>.lora_A|B.weight``) or diffusers
+    (``unet.<...>``).  Rank comes from the file, ``lora_alpha`` from the kohya ``.alpha`` entries when present."""
+    from .model import LoraState
+    from .unet_spec import lora_target_modules
+    raw = load_file(path)
+    all_targets = lora_target_modules(cfg)
+    norm, alpha = {}, None
+    if any(k.startswith("lora_unet_") for k in raw):
+        inv = {"lora_unet_" + p_.replace(".", "_"): p_ for p_, _ in all_targets}
+        for k, v in raw.items():
+            mod, _, leaf = k.partition(".")
+            if leaf == "alpha":
+                alpha = float(v)
+                continue
+            if mod not in inv:
+                raise KeyError(f"{path}: {mod} is not a LoRA-targeted module of this UNet")
+            norm[inv[mod] + (".lora_A.weight" if leaf.startswith("lora_down") else ".lora_B.weight")] = v
+    else:
+        for k, v in raw.items():
+            for pre in ("unet.", "base_model.model."):
+                if k.startswith(pre):
+                    k = k[len(pre):]
+            norm[k] = v
+    have = {k[:-len(".lora_A.weight")] for k in norm if k.endswith(".lora_A.weight")}
+    targets = [(p_, shp) for p_, shp in all_targets if p_ in have]
+    if not targets or have - {p_ for p_, _ in targets}:
+        raise KeyError(f"{path}: no (or unknown) LoRA modules for this UNet: {sorted(have - {p_ for p_, _ in targets})[:3]}")
+    rank = int(norm[targets[0][0] + ".lora_A.weight"].shape[0])
+    lora = LoraState(cfg, rank, alpha if alpha is not None else lora_alpha, device, targets=targets)
+    f = float(scale) ** 0.5
+    lora.load_peft_state_dict({f"base_model.model.{p_}.lora_{ab}.weight": norm[f"{p_}.lora_{ab}.weight"].float() * f for p_, _ in targets for ab in "AB"})
+    return lora
+
+
 def sd3_lora_from_file(cfg, path, device, lora_alpha=8.0, scale=1.0):
     """LoRA state for the SD3 transformer inferred FROM a LoRA file: ``pytorch_lora_weights.safetensors`` (``transformer.<module>.lora_A|B
     .weight``, what the trainers and StableDiffusion3Pipeline.save_lora_weights write and ``pipe.load_lora_weights`` of

@@ -22,7 +22,8 @@ def parse_args(argv=None):
     p = argparse.ArgumentParser(description=__doc__.split("\n")[0])
     p.add_argument("--pretrained_teacher_model", required=True, help="diffusers SDXL directory, or 'random'")
     p.add_argument("--tiny_model", action="store_true", help="(random weights) a narrow UNet of the same topology for smoke tests of the CLI itself")
-    p.add_argument("--lora_dir", default=None)
+    p.add_argument("--lora_dir", default=None, help="trainer output directory (peft adapter_model.safetensors)")
+    p.add_argument("--lora_file", default=None, help="a LoRA safetensors file: kohya-ss (lora_unet_*), peft or diffusers (unet.*) keys; rank / alpha read from it")
     p.add_argument("--lora_rank", type=int, default=64)
     p.add_argument("--prompt_embeds", default=None)
     p.add_argument("--synthetic_prompts", type=int, default=0)
@@ -48,9 +49,12 @@ def main(args):
     sd = random_state_dict(cfg, 0, dev) if args.pretrained_teacher_model == "random" else ck.load_unet_state_dict(args.pretrained_teacher_model)
     W = UNetWeights(cfg, sd, dev, need_bwd=False)
     del sd
-    lora = LoraState(cfg, args.lora_rank, 8.0, dev, seed=args.seed)
-    if args.lora_dir:
-        ck.load_lora(lora, args.lora_dir)
+    if args.lora_file:
+        lora = ck.unet_lora_from_file(cfg, args.lora_file, dev)
+    else:
+        lora = LoraState(cfg, args.lora_rank, 8.0, dev, seed=args.seed)
+        if args.lora_dir:
+            ck.load_lora(lora, args.lora_dir)
     g = torch.Generator(device=dev).manual_seed(args.seed)
     R = args.resolution
     if args.prompt_embeds:

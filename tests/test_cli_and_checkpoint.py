@@ -140,6 +140,12 @@ def test_checkpoint_formats_roundtrip(tmp_path):
         lora2 = LoraState(cfg, 64, 8.0, "cpu", seed=99)
         ck.load_lora(lora2, str(tmp_path))
         assert torch.equal(lora2.params, lora.params)
+        # the three on-disk formats load back through the format-sniffing reader (kohya is fp16: compare at that precision)
+        for name, tol in (("adapter_model.safetensors", 0.0), (os.path.join("unet_lora", "pytorch_lora_weights.safetensors"), 0.0),
+                          ("pcm_lora_kohya_converted.safetensors", 2e-3)):
+            l3 = ck.unet_lora_from_file(cfg, str(tmp_path / name), "cpu")
+            assert l3.real_rank == 64 and l3.alpha == 8.0 and set(l3.modules) == set(lora.modules)
+            assert float((l3.params - lora.params).abs().max()) <= tol * float(lora.params.abs().max()), name
     finally:
         capi.set_lib(None)
 
