@@ -8,8 +8,14 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "phased-consistency-model_amd", "csrc")
-OUT = os.path.join(HERE, "libpcm_emu.so")
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+# PCM_EMU_ASAN=1: AddressSanitizer build (separate objects / library).  Run the kernel tests under it with
+#   LD_PRELOAD=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so) ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0 \
+#   PCM_EMU_ASAN=1 python -m pytest tests/test_emu_kernels.py
+# torch's CPU allocator goes through the intercepted malloc, so every tensor gets redzones: out-of-bounds reads / writes of a kernel
+# (tails, halos, clamped loads) that the GPU would silently tolerate or fault on are reported with the kernel's source line.
+ASAN = os.environ.get("PCM_EMU_ASAN") == "1"
+OUT = os.path.join(HERE, "libpcm_emu_asan.so" if ASAN else "libpcm_emu.so")
 
 
 def build(force=False):
@@ -22,15 +28,17 @@ def build(force=False):
     procs = []
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
     for s in srcs:
-        o = os.path.join(HERE, "build", os.path.basename(s) + ".o")
+        o = os.path.join(HERE, "build", os.path.basename(s) + (".asan.o" if ASAN else ".o"))
         objs.append(o)
-        cmd = [CLANG, "-x", "c++", "-DPCM_HOST_EMU", "-I", HERE, "-O2", "-std=c++17", "-fPIC",
+        cmd = [CLANG, "-x", "c++", "-DPCM_HOST_EMU", "-I", HERE, "-O1" if ASAN else "-O2", "-std=c++17", "-fPIC",
                "-Wno-unused-value", "-Wno-deprecated-declarations", "-Wno-psabi", "-c", s, "-o", o]
+        if ASAN:
+            cmd[1:1] = ["-fsanitize=address", "-fno-omit-frame-pointer", "-g", "-shared-libasan"]
         procs.append((s, subprocess.Popen(cmd)))
     for s, p in procs:
         if p.wait() != 0:
             raise RuntimeError("emu compile failed: " + s)
-    subprocess.check_call([CLANG, "-shared", "-o", OUT] + objs)
+    subprocess.check_call([CLANG, "-shared", "-o", OUT] + (["-fsanitize=address", "-shared-libasan"] if ASAN else []) + objs)
     return OUT
 
 
