@@ -15,7 +15,10 @@ CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 # torch's CPU allocator goes through the intercepted malloc, so every tensor gets redzones: out-of-bounds reads / writes of a kernel
 # (tails, halos, clamped loads) that the GPU would silently tolerate or fault on are reported with the kernel's source line.
 ASAN = os.environ.get("PCM_EMU_ASAN") == "1"
-OUT = os.path.join(HERE, "libpcm_emu_asan.so" if ASAN else "libpcm_emu.so")
+# PCM_EMU_UBSAN=1: -fsanitize=alignment,bounds (LD_PRELOAD libclang_rt.ubsan_standalone-x86_64.so, UBSAN_OPTIONS=halt_on_error=1):
+# under-aligned vector accesses (hip_emu.h gives float4 / uint4 their 16-byte alignment) and out-of-range constant-size array indices
+UBSAN = os.environ.get("PCM_EMU_UBSAN") == "1"
+OUT = os.path.join(HERE, "libpcm_emu_asan.so" if ASAN else ("libpcm_emu_ubsan.so" if UBSAN else "libpcm_emu.so"))
 
 
 def build(force=False):
@@ -28,17 +31,20 @@ def build(force=False):
     procs = []
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
     for s in srcs:
-        o = os.path.join(HERE, "build", os.path.basename(s) + (".asan.o" if ASAN else ".o"))
+        o = os.path.join(HERE, "build", os.path.basename(s) + (".asan.o" if ASAN else (".ubsan.o" if UBSAN else ".o")))
         objs.append(o)
         cmd = [CLANG, "-x", "c++", "-DPCM_HOST_EMU", "-I", HERE, "-O1" if ASAN else "-O2", "-std=c++17", "-fPIC",
                "-Wno-unused-value", "-Wno-deprecated-declarations", "-Wno-psabi", "-c", s, "-o", o]
         if ASAN:
             cmd[1:1] = ["-fsanitize=address", "-fno-omit-frame-pointer", "-g", "-shared-libasan"]
+        elif UBSAN:
+            cmd[1:1] = ["-fsanitize=alignment,bounds", "-fno-sanitize-recover=alignment,bounds", "-g", "-shared-libsan"]
         procs.append((s, subprocess.Popen(cmd)))
     for s, p in procs:
         if p.wait() != 0:
             raise RuntimeError("emu compile failed: " + s)
-    subprocess.check_call([CLANG, "-shared", "-o", OUT] + (["-fsanitize=address", "-shared-libasan"] if ASAN else []) + objs)
+    san = ["-fsanitize=address", "-shared-libasan"] if ASAN else (["-fsanitize=alignment,bounds", "-shared-libsan"] if UBSAN else [])
+    subprocess.check_call([CLANG, "-shared", "-o", OUT] + san + objs)
     return OUT
 
 

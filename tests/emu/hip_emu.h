@@ -29,11 +29,14 @@ struct dim3 {
   unsigned x, y, z;
   dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
 };
-struct float2 { float x, y; };
-struct float4 { float x, y, z, w; };
-struct uint2 { unsigned x, y; };
-struct uint4 { unsigned x, y, z, w; };
-struct int4 { int x, y, z, w; };
+// HIP's vector types carry their natural alignment (float4 / uint4: 16 B, float2 / uint2: 8 B): a misaligned 16-byte lane access is
+// a fault (or a split access) on the GPU.  With the same alignment here, -fsanitize=alignment (PCM_EMU_UBSAN=1 in build_emu.py)
+// reports every under-aligned vector load / store of a kernel with its source line.
+struct alignas(8) float2 { float x, y; };
+struct alignas(16) float4 { float x, y, z, w; };
+struct alignas(8) uint2 { unsigned x, y; };
+struct alignas(16) uint4 { unsigned x, y, z, w; };
+struct alignas(16) int4 { int x, y, z, w; };
 static inline float4 make_float4(float a, float b, float c, float d) { return {a, b, c, d}; }
 static inline float2 make_float2(float a, float b) { return {a, b}; }
 static inline uint4 make_uint4(unsigned a, unsigned b, unsigned c, unsigned d) { return {a, b, c, d}; }
