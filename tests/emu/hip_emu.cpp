@@ -37,6 +37,7 @@ dim3 g_threadIdx, g_blockIdx, g_blockDim, g_gridDim;
 std::function<void()> g_body;
 char* g_dyn_smem = nullptr;
 bool g_lazy_dma = false;
+int g_wave_order = 0;
 static const size_t STACK = 256 * 1024;
 
 void yield_to_sched() { pcm_ctx_switch(&g_cur->sp, g_sched_sp); }
@@ -95,6 +96,7 @@ void launch(dim3 grid, dim3 block, size_t smem, std::function<void()> body) {
   int nwaves = (nthreads + 63) / 64;
   g_body = body;
   { const char* e = getenv("PCM_EMU_LAZY_DMA"); g_lazy_dma = e && e[0] == '1'; }
+  { const char* e = getenv("PCM_EMU_ORDER"); g_wave_order = e ? atoi(e) : 0; }
   g_blockDim = block;
   g_gridDim = grid;
   std::vector<char> dyn(smem + 64);
@@ -133,7 +135,16 @@ void launch(dim3 grid, dim3 block, size_t smem, std::function<void()> body) {
         int done = 0;
         while (done < nthreads) {
           bool progressed = false;
-          for (int t = 0; t < nthreads; t++) {
+          for (int ti = 0; ti < 64 * nwaves; ti++) {
+            // wave visiting order (PCM_EMU_ORDER): the hardware runs the waves of a block concurrently, so a kernel may not depend on
+            // which wave reaches a point first; 0 = ascending (default), 1 = descending, 2 = odd waves first.  A missing barrier between
+            // one wave's LDS writes and another wave's reads shows up as a result that changes with the order.
+            const int w_ = ti / 64, l_ = ti % 64;
+            int wv = w_;
+            if (g_wave_order == 1) wv = nwaves - 1 - w_;
+            else if (g_wave_order == 2) wv = (2 * w_ + 1 < nwaves) ? 2 * w_ + 1 : 2 * (w_ - nwaves / 2);
+            const int t = wv * 64 + l_;
+            if (t >= nthreads) continue;
             Fiber& f = g_fibers[t];
             if (f.st != RUNNABLE) continue;
             progressed = true;
