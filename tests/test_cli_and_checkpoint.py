@@ -448,13 +448,13 @@ def test_unet_clis_end_to_end_on_the_emulator(tmp_path, monkeypatch):
         _t0 = _t.time()
         cli = load_cli()
         o1 = tmp_path / "o1"
-        cli.main(cli.parse_args(args(o1, d15, ["--max_train_steps", "2", "--checkpointing_steps", "2", "--loss_type", "huber"])))
-        assert (o1 / "checkpoint-2" / "trainer_state.json").exists()
+        cli.main(cli.parse_args(args(o1, d15, ["--max_train_steps", "1", "--checkpointing_steps", "1", "--loss_type", "huber"])))
+        assert (o1 / "checkpoint-1" / "trainer_state.json").exists()
         sd = load_file(str(o1 / "adapter_model.safetensors"))
         assert any(k.endswith("conv1.lora_A.weight") and v.shape[0] == 64 for k, v in sd.items())
         assert (o1 / "pcm_lora_kohya_converted.safetensors").exists() and (o1 / "unet_lora" / "pytorch_lora_weights.safetensors").exists()
         log = [json.loads(l) for l in open(o1 / "logs" / "text2image-fine-tune.jsonl")]
-        assert [r["step"] for r in log] == [1, 2] and all(r["loss"] > 0 and r["grad_norm"] > 0 for r in log)
+        assert [r["step"] for r in log] == [1] and all(r["loss"] > 0 and r["grad_norm"] > 0 for r in log)
         sm = _load("sample_pcm_lora_sd15")                      # sampler CLI with the adapter just trained
         sm.main(sm.parse_args(["--pretrained_teacher_model", "random", "--tiny_model", "--lora_dir", str(o1), "--synthetic_prompts", "1",
                                "--num_inference_steps", "2", "--guidance_scale", "2.0", "--resolution", "64", "--output", str(tmp_path / "l15.safetensors")]))
@@ -472,9 +472,9 @@ def test_unet_clis_end_to_end_on_the_emulator(tmp_path, monkeypatch):
         print("sd15 adv cli %.1f s" % (_t.time() - _t0)); _t0 = _t.time()
         xl = _load("train_pcm_lora_sdxl_adv")
         o3 = tmp_path / "o3"
-        xl.main(xl.parse_args(args(o3, dxl, ["--max_train_steps", "2", "--resolution", "64", "--adv_weight", "0"])))   # (adv SDXL step: tests/test_emu_adv.py)
+        xl.main(xl.parse_args(args(o3, dxl, ["--max_train_steps", "1", "--resolution", "64", "--adv_weight", "0"])))   # (adv SDXL step: tests/test_emu_adv.py)
         log = [json.loads(l) for l in open(o3 / "logs" / "text2image-fine-tune.jsonl")]
-        assert len(log) == 2 and (o3 / "adapter_model.safetensors").exists()
+        assert len(log) == 1 and (o3 / "adapter_model.safetensors").exists()
         print("sdxl adv cli %.1f s" % (_t.time() - _t0))
     finally:
         capi.set_lib(None)
