@@ -682,3 +682,48 @@ def case_mmdit_ops(dev):
     fr = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half)
     arg = t.cpu()[:, None] * fr[None, :]
     close(emb, torch.cat([torch.cos(arg), torch.sin(arg)], -1), 1e-2, 1e-2, "timestep f32")
+
+
+def case_pcm_math_random_shapes(dev):
+    """reference-owned math on shapes / parameters the golden fixture does not hold: ragged per-sample sizes (not multiples of the
+    256-thread block), batch 1, every multiphase from 1 to the number of solver steps, other solver step counts and schedule shifts.
+    BIT-EXACT against the oracle restatements (which are pinned bit-exactly to the reference's source)."""
+    import numpy as np
+    from oracle import pcm_fm_math as FM
+    from oracle import pcm_math as PM
+    from pcm_amd import fm
+    g = torch.Generator().manual_seed(2024)
+    # ---- flow matching (SD3 variant)
+    for B, shape, E, shift in ((1, (16, 5, 7), 20, 3.0), (3, (16, 2, 2), 50, 1.0), (5, (4, 9, 3), 100, 3.0), (2, (16, 16, 16), 50, 2.0)):
+        osol = FM.EulerSolver(FM.flow_sigmas(1000, shift), 1000, E)
+        sol = fm.EulerSolver(fm.flow_sigmas(1000, shift), 1000, E, device=dev)
+        assert torch.equal(sol.sigmas.cpu(), osol.sigmas) and torch.equal(sol.sigmas_prev.cpu(), osol.sigmas_prev)
+        x, nz, pr, c, u = (torch.randn(B, *shape, generator=g) for _ in range(5))
+        idx = torch.randint(0, E, (B,), generator=g)
+        idx[0] = E - 1
+        noisy = FM.fm_add_noise(osol, x, nz, idx)
+        got = sol.add_noise(x.to(dev), nz.to(dev), idx.to(dev))
+        assert torch.equal(got.cpu(), noisy)
+        xp = osol.euler_step(noisy, FM.fm_cfg(c, u, 3), idx)
+        gp, gp32 = sol.euler_step(got, c.to(dev), idx.to(dev), u.to(dev), 3)
+        assert torch.equal(gp.cpu(), xp) and torch.equal(gp32.cpu(), xp.float())
+        for M in sorted({1, 2, 3, 7, E}):
+            for tgt, smp, gsmp in ((False, noisy, got), (True, xp, gp)):
+                a, ea = osol.euler_style_multiphase_pred(smp, pr, idx, M, tgt)
+                b, eb = sol.euler_style_multiphase_pred(gsmp, pr.to(dev), idx.to(dev), M, tgt)
+                assert torch.equal(b.cpu(), a) and torch.equal(eb.cpu(), ea), (B, shape, E, M, tgt)
+        end = ea
+        adv = torch.minimum(end + torch.randint(0, max(1, E // 7), (B,), generator=g), torch.full((B,), E - 1))
+        n64 = torch.randn(B, *shape, generator=g, dtype=torch.float64)
+        ra = FM.fm_noise_travel(osol, a, n64, end, adv)
+        rb, rb32, _ = sol.noise_travel(b, n64.to(dev), end.to(dev), adv.to(dev))
+        assert torch.equal(rb.cpu(), ra) and torch.equal(rb32.cpu(), ra.float())
+    # ---- DDPM side (SD1.5 / SDXL): add_noise and noise_travel on ragged shapes
+    acp = PM.sd15_alphas_cumprod()
+    for B, shape in ((1, (4, 5, 7)), (3, (4, 3, 3)), (2, (4, 17, 9))):
+        x, nz = torch.randn(B, *shape, generator=g), torch.randn(B, *shape, generator=g)
+        t = torch.randint(0, 1000, (B,), generator=g)
+        t2 = torch.minimum(t + torch.randint(0, 250, (B,), generator=g), torch.full((B,), 999))
+        assert torch.equal(ops.add_noise(x.to(dev), nz.to(dev), acp.to(dev), t.to(dev)).cpu(), PM.add_noise(acp, x, nz, t))
+        got, _ = ops.noise_travel(x.to(dev), nz.to(dev), acp.to(dev), t.to(dev), t2.to(dev))
+        assert torch.equal(got.cpu(), PM.noise_travel(acp, x, nz, t, t2))

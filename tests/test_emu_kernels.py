@@ -45,6 +45,10 @@ def test_pcm_fm_math_bit_exact_vs_reference_golden(golden_fm):
     K.case_pcm_fm_math("cpu", golden_fm)
 
 
+def test_pcm_math_random_shapes_bit_exact_vs_oracle():
+    K.case_pcm_math_random_shapes("cpu")
+
+
 def test_mmdit_ops():
     K.case_mmdit_ops("cpu")
 

@@ -44,6 +44,10 @@ def test_pcm_math_bit_exact_vs_reference_golden(golden):
     K.case_pcm_math("cuda", golden)
 
 
+def test_pcm_math_random_shapes_bit_exact_vs_oracle():
+    K.case_pcm_math_random_shapes("cuda")
+
+
 def test_mmdit_ops():
     K.case_mmdit_ops("cuda")
 
