@@ -1,9 +1,12 @@
 """Host-emulation (CPU) runs of the kernel parity cases: index math of every kernel at small sizes."""
+import ctypes
+
 import pytest
+import torch
 
 import kernel_cases as K
 from emu_lib import emu_lib
-from pcm_amd import capi
+from pcm_amd import capi, ops
 
 
 @pytest.fixture(autouse=True)
@@ -105,3 +108,39 @@ def test_attention_packed_transposed_operands(B, H, Lq, Lk, d):
         K.case_attention("cpu", B, H, Lq, Lk, d, spike=True)
     finally:
         dll.pcm_debug_attn_pack_min_len(1024)
+
+
+def test_abi_rejects_bad_arguments_with_a_message():
+    """error behaviour of the boundary: a bad call returns a non-zero code and leaves a message naming the entry point
+    (capi raises PcmError with it); nothing is launched."""
+    L, S = capi.lib(), capi.Lib.stream
+    p = ops.ptr
+    bf = torch.zeros(64, 64, dtype=torch.bfloat16)
+    f32 = torch.zeros(64, 64)
+    f64 = torch.zeros(64, 64, dtype=torch.float64)
+    idx = torch.zeros(4, dtype=torch.int64)
+    cases = [
+        ("pcm_groupnorm_stats", (p(bf), p(f64), 1, 64, 60, 32, S())),                                   # C % G != 0
+        ("pcm_layernorm_fwd", (p(bf), p(f32), p(f32), p(bf), p(f32), p(f32), 1, 4096, 1e-5, S())),      # C > 2048
+        ("pcm_layernorm_mod_fwd", (p(bf), p(f32), p(f32), p(bf), p(f32), p(f32), 64, 64, 1e-6, 48, S())),  # M not B * rows_per_batch
+        ("pcm_rowgate_fma", (p(bf), p(f32), None, p(bf), 64, 64, 48, S())),
+        ("pcm_attn_fwd", (p(bf), p(bf), p(bf), p(bf), p(f32), 1, 1, 64, 64, 64, 60, 64, 64, 0.125, S())),   # ld % 8 != 0
+        ("pcm_patchify2x2", (p(f32), p(bf), 1, 4, 3, 4, 0, S())),                                        # odd H
+        ("pcm_unpatchify2x2", (p(f32), p(f32), 1, 4, 4, 4, 2, S())),                                     # order not in {0, 1}
+        ("pcm_fm_sampler_step", (p(f32), None, 1.0, p(f32), 0.0, 0.0, None, p(f32), 64, S())),           # sigma must be > 0 (division)
+        ("pcm_fm_phase_jump", (p(f32), 0, p(f32), p(idx), p(f32), p(f64), p(idx), 0, 0, p(f64), None, None, 4, 16, S())),   # no phase edges
+        ("pcm_gelu_tanh_fwd", (p(bf), p(bf), 12, S())),                                                   # n % 8 != 0
+        ("pcm_mod_grad", (p(bf), p(bf), p(f32), None, p(f32), None, 1, 64, 64, S())),                    # mean without rstd
+        ("pcm_geglu_fwd", (p(bf), p(bf), 4, 12, S())),
+        ("pcm_concat_channels", (p(bf), 12, p(bf), 8, p(bf), 4, S())),
+    ]
+    for name, args in cases:
+        with pytest.raises(capi.PcmError) as ei:
+            L.call(name, *args)
+        assert name.replace("_fwd", "") .split("pcm_")[1][:6] in str(ei.value) or "pcm_" in str(ei.value), (name, str(ei.value))
+    a = capi.WgradArgs()
+    a.big, a.small_, a.out, a.M, a.G, a.lds_, a.ldb, a.mode = p(bf), p(bf), p(f32), 64, 64, 32, 64, capi.SEG_PLAIN      # small ld < 64
+    with pytest.raises(capi.PcmError, match="pcm_lora_wgrad_bf16"):
+        L.call("pcm_lora_wgrad_bf16", ctypes.byref(a), S())
+    with pytest.raises(capi.PcmError, match="not exported"):
+        L.call("pcm_no_such_entry")
