@@ -153,6 +153,14 @@ class SD3Source:
         return r(self.bs, self.cin, self.hw, self.hw), r(self.bs, self.Lc, self.jd), r(self.bs, self.pd)
 
 
+def apply_scale_lr(args, world):
+    """--scale_lr (train_pcm_lora_sd3.py:1061-1067; the SDXL script has the same block at :1166-1172, the SD1.5 script defines the
+    flag but never reads it): lr *= gradient_accumulation_steps * train_batch_size * num_processes."""
+    if getattr(args, "scale_lr", False):
+        args.learning_rate = args.learning_rate * args.gradient_accumulation_steps * args.train_batch_size * world
+    return args.learning_rate
+
+
 def pick_device(local_rank):
     """cuda:<local_rank>; PCM_CLI_DEVICE=cpu (tests: the CLI end to end on the host emulator, which the test installs as the library)."""
     if os.environ.get("PCM_CLI_DEVICE") == "cpu":
@@ -186,6 +194,7 @@ def main(args):
         raise SystemExit("pcm_amd: --gradient_accumulation_steps != 1 is not implemented (reference recipes use 1)")
     if args.optimizer.lower() != "adamw":
         raise SystemExit("pcm_amd: only --optimizer AdamW (the reference recipes') is implemented")
+    apply_scale_lr(args, world)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)

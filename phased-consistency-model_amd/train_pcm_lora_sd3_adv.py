@@ -66,6 +66,7 @@ def main(args):
         raise SystemExit("pcm_amd: --gradient_accumulation_steps != 1 is not implemented (reference recipes use 1)")
     if args.optimizer.lower() != "adamw":
         raise SystemExit("pcm_amd: only --optimizer AdamW (the reference recipes') is implemented")
+    sd3.apply_scale_lr(args, world)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)

@@ -96,6 +96,8 @@ def main(args):
     from pcm_amd.unet_spec import UNetConfig, random_state_dict
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     local_rank = max(args.local_rank, 0)
+    if args.scale_lr:            # train_pcm_lora_sdxl_adv.py:1166-1172 (unlike the SD1.5 script, which never reads the flag)
+        args.learning_rate = args.learning_rate * args.gradient_accumulation_steps * args.train_batch_size * world
     logging.basicConfig(format="%(asctime)s - %(levelname)s - %(name)s - %(message)s", level=logging.INFO if rank == 0 else logging.WARNING)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -478,3 +478,21 @@ def test_unet_clis_end_to_end_on_the_emulator(tmp_path, monkeypatch):
         print("sdxl adv cli %.1f s" % (_t.time() - _t0))
     finally:
         capi.set_lib(None)
+
+
+def test_scale_lr_semantics_per_script():
+    """--scale_lr multiplies lr by accumulation * batch * processes in the SD3 and SDXL scripts; the SD1.5 script defines the flag
+    and never reads it (kept as is)."""
+    s3 = _load("train_pcm_lora_sd3")
+    a = s3.parse_args(["--pretrained_teacher_model", "x", "--scale_lr", "--learning_rate", "1e-6", "--train_batch_size", "4"])
+    assert abs(s3.apply_scale_lr(a, 8) - 1e-6 * 1 * 4 * 8) < 1e-18 and abs(a.learning_rate - 3.2e-5) < 1e-18
+    b = s3.parse_args(["--pretrained_teacher_model", "x", "--learning_rate", "1e-6"])
+    assert s3.apply_scale_lr(b, 8) == 1e-6
+    for ref, uses in (("/root/reference/code/text_to_image_sd15/train_pcm_lora_sd15.py", False),
+                      ("/root/reference/code/text_to_image_sdxl/train_pcm_lora_sdxl_adv.py", True),
+                      ("/root/reference/code/text_to_image_sd3/train_pcm_lora_sd3.py", True)):
+        if os.path.exists(ref):
+            assert ("if args.scale_lr" in open(ref).read()) == uses, ref
+    import inspect
+    xl = _load("train_pcm_lora_sdxl_adv")
+    assert "args.scale_lr" in inspect.getsource(xl.main) and "scale_lr" not in inspect.getsource(load_cli().main)
