@@ -162,6 +162,14 @@ def unet_config(args, kind="sd15"):
     return UNetConfig.sd15()
 
 
+def sched_step(step, world):
+    """Scheduler position after ``step`` optimizer steps.  The SD1.5 / SDXL scripts build the schedule with the raw
+    ``lr_warmup_steps`` / ``max_train_steps`` (:1026-1031) and hand it to ``accelerator.prepare``: accelerate's AcceleratedScheduler
+    (0.27.2, split_batches=False) then advances it ``num_processes`` times per optimizer step, so every non-constant schedule runs
+    ``world`` times faster on ``world`` GPUs.  (The SD3 scripts multiply both counts by num_processes, which cancels this.)"""
+    return step * world
+
+
 def lr_at(args, step):
     """get_scheduler(args.lr_scheduler, ...) (:1026-1031): 'constant' ignores warmup (App. A.6)."""
     if args.lr_scheduler == "constant":
@@ -264,7 +272,7 @@ def main(args):
         noise = torch.randn(latents.shape, generator=src.g, device=device)                                      # :1139
         index = torch.randint(0, args.num_ddim_timesteps, (latents.shape[0],), generator=src.g, device=device)  # :1147
         w = ((args.w_max - args.w_min) * torch.rand((latents.shape[0],), generator=cpu_gen) + args.w_min).to(device)  # :1183 CPU RNG
-        lr = lr_at(args, global_step)
+        lr = lr_at(args, sched_step(global_step, world))
         out = D.step(latents, pe, src.uncond, noise, index, w, lr=lr)
         global_step += 1
         if rank == 0:

@@ -496,3 +496,21 @@ def test_scale_lr_semantics_per_script():
     import inspect
     xl = _load("train_pcm_lora_sdxl_adv")
     assert "args.scale_lr" in inspect.getsource(xl.main) and "scale_lr" not in inspect.getsource(load_cli().main)
+
+
+def test_scheduler_position_follows_accelerate_per_script():
+    """non-constant schedules: the SD1.5 / SDXL scripts' schedulers advance num_processes times per optimizer step (accelerate's
+    AcceleratedScheduler on a schedule built with raw step counts); the SD3 scripts pre-multiply the counts, so theirs does not."""
+    import inspect
+    import types
+    cli = load_cli()
+    assert cli.sched_step(10, 1) == 10 and cli.sched_step(10, 8) == 80
+    a = types.SimpleNamespace(learning_rate=1e-4, lr_warmup_steps=80, max_train_steps=1000, lr_scheduler="constant_with_warmup")
+    assert abs(cli.lr_at(a, cli.sched_step(9, 8)) - 1e-4 * 73 / 80) < 1e-12          # 8 GPUs: warm-up over after 10 optimizer steps
+    assert cli.lr_at(a, cli.sched_step(10, 8)) == 1e-4
+    assert "sched_step" in inspect.getsource(cli.main) and "sched_step" in inspect.getsource(_load("train_pcm_lora_sd15_adv").main)
+    assert "sched_step" in inspect.getsource(_load("train_pcm_lora_sdxl_adv").main)
+    assert "sched_step" not in inspect.getsource(_load("train_pcm_lora_sd3").main)
+    for ref, mult in (("/root/reference/code/text_to_image_sd15/train_pcm_lora_sd15.py", False), ("/root/reference/code/text_to_image_sd3/train_pcm_lora_sd3.py", True)):
+        if os.path.exists(ref):
+            assert ("num_warmup_steps=args.lr_warmup_steps * accelerator.num_processes" in open(ref).read()) == mult
