@@ -82,7 +82,7 @@ class Distiller:
         return start, t
 
     def forward_backward(self, latents, prompt_embeds, uncond_prompt_embeds, noise, index, w, backward=True, added_cond=None,
-                         uncond_added_cond=None):
+                         uncond_added_cond=None, grad_scale=1.0, zero_grad=True):
         """Everything of the step before the gradient exchange: returns a dict of device tensors.
         ``added_cond`` / ``uncond_added_cond``: SDXL ``added_cond_kwargs`` ({'text_embeds': [B,1280], 'time_ids': [B,6]},
         train_pcm_lora_sdxl_adv.py:1113-1131, :1409-1421) for UNets with text_time conditioning; None for SD1.5."""
@@ -117,25 +117,29 @@ class Distiller:
                                                  T.edges, target_mode=False)                     # :1200-1212
         target, _, _ = ops.phase_jump(eps_t, x_prev64, t_n, index, T.acp, T.acp_prev, T.ddim_timesteps_prev, T.edges,
                                       target_mode=True)                                          # :1269-1280
-        loss, d_eps = ops.consistency_loss(model_pred, target, coef, cfg.loss_type == "huber", cfg.huber_c)   # :1283-1293
+        loss, d_eps = ops.consistency_loss(model_pred, target, coef, cfg.loss_type == "huber", cfg.huber_c, grad_scale=grad_scale)   # :1283-1293
         out = dict(loss=loss, noisy_model_input=noisy, noise_pred=eps_s, model_pred=model_pred, cond_teacher_output=eps_c,
                    uncond_teacher_output=eps_u, x_prev=x_prev64, target_noise_pred=eps_t, target=target,
                    start_timesteps=start_t, timesteps=t_n, end_timesteps=end_t)
         if not backward:
             out["tape"], out["d_eps"] = tape, d_eps
             return out
-        self.lora.zero_grad()
+        if zero_grad:
+            self.lora.zero_grad()
         self.student.backward(d_eps, tape)                                                       # :1296
         return out
 
     def step(self, latents, prompt_embeds, uncond_prompt_embeds, noise, index, w, lr=None, update=True, added_cond=None,
-             uncond_added_cond=None):
+             uncond_added_cond=None, accum=None):
         """One distillation step on this rank's batch (eager launches).  All inputs are device tensors:
         latents/noise [B,4,H,W] fp32, prompt embeds [B,77,768], index [B] int64, w [B] fp32.
-        Returns a dict of device tensors (no host sync)."""
+        Returns a dict of device tensors (no host sync).
+        ``accum=(i, k)``: micro-batch i of k under ``--gradient_accumulation_steps k`` (``accelerator.accumulate``, :1120): the loss
+        gradient is scaled by 1/k, gradients add up over the k calls, and exchange + clip + AdamW run with the last one only."""
+        i, k = accum if accum is not None else (0, 1)
         out = self.forward_backward(latents, prompt_embeds, uncond_prompt_embeds, noise, index, w, backward=update, added_cond=added_cond,
-                                    uncond_added_cond=uncond_added_cond)
-        if not update:
+                                    uncond_added_cond=uncond_added_cond, grad_scale=1.0 / k, zero_grad=(i == 0))
+        if not update or i < k - 1:
             return out
         if lr is not None:
             self.lr_dev.fill_(float(lr))

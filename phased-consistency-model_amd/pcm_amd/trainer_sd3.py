@@ -41,7 +41,7 @@ class SD3Distiller(Distiller):
         self.ema = lora.params.clone() if cfg.ema_rate is not None else None
 
     def forward_backward(self, model_input, prompt_embeds, pooled_prompt_embeds, uncond_prompt_embeds, uncond_pooled_prompt_embeds, noise,
-                         index, backward=True):
+                         index, backward=True, grad_scale=1.0, zero_grad=True):
         cfg, S = self.cfg, self.solver
         B = model_input.shape[0]
         timesteps, timesteps_prev = S.timesteps(index, cfg.num_train_timesteps)                               # :1291-1300
@@ -64,24 +64,27 @@ class SD3Distiller(Distiller):
         target64, _, target32 = S.euler_style_multiphase_pred(x_prev64, target_pred, index, cfg.multiphase, True, with_f32=True)
         # d model_pred / d pred = sigma_prev[end] - sigma[index]  (per sample)
         coef = (S.sigmas_prev[end_index] - S.sigmas[index].double()).float().contiguous()
-        loss, d_pred = ops.consistency_loss(model_pred32, target32, coef, True, cfg.huber_c)                      # :1374-1379
+        loss, d_pred = ops.consistency_loss(model_pred32, target32, coef, True, cfg.huber_c, grad_scale=grad_scale)   # :1374-1379
         out = dict(loss=loss, noisy_model_input=noisy, model_output=pred, model_pred=model_pred64, cond_teacher_output=cond,
                    uncond_teacher_output=uncond, x_prev=x_prev64, target_pred=target_pred, target=target64, timesteps=timesteps,
                    timesteps_prev=timesteps_prev, end_index=end_index)
         if not backward:
             out["tape"], out["d_pred"] = tape, d_pred
             return out
-        self.lora.zero_grad()
+        if zero_grad:
+            self.lora.zero_grad()
         self.student.backward(d_pred, tape)                                                                    # :1381
         return out
 
     def step(self, model_input, prompt_embeds, pooled_prompt_embeds, uncond_prompt_embeds, uncond_pooled_prompt_embeds, noise, index,
-             lr=None, update=True):
+             lr=None, update=True, accum=None):
         """One distillation step on this rank's batch; all inputs device tensors (latents/noise [B,16,H,W] fp32, prompt embeds
-        [B,Lc,4096], pooled [B,2048], index [B] int64).  Returns device tensors (no host sync)."""
+        [B,Lc,4096], pooled [B,2048], index [B] int64).  Returns device tensors (no host sync).  ``accum=(i, k)``: micro-batch i of k
+        (``--gradient_accumulation_steps``, ``accelerator.accumulate``, :1267-1268)."""
+        i, k = accum if accum is not None else (0, 1)
         out = self.forward_backward(model_input, prompt_embeds, pooled_prompt_embeds, uncond_prompt_embeds, uncond_pooled_prompt_embeds,
-                                    noise, index, backward=update)
-        if not update:
+                                    noise, index, backward=update, grad_scale=1.0 / k, zero_grad=(i == 0))
+        if not update or i < k - 1:
             return out
         if lr is not None:
             self.lr_dev.fill_(float(lr))

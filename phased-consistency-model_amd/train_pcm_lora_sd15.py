@@ -218,8 +218,8 @@ def main(args):
                         level=logging.INFO if rank == 0 else logging.WARNING)
     if args.mixed_precision == "fp16":
         logger.info("--mixed_precision=fp16 requested: this build computes in bf16 MFMA / fp32 accumulate (no GradScaler needed)")
-    if args.gradient_accumulation_steps != 1:
-        raise SystemExit("pcm_amd: --gradient_accumulation_steps != 1 is not implemented (reference recipes use 1)")
+    if args.gradient_accumulation_steps < 1:
+        raise SystemExit("pcm_amd: --gradient_accumulation_steps must be >= 1")
     ignored = [k for k in IGNORED if getattr(args, k) not in (None, False, 0, 8, 200)]
     if ignored:
         logger.info("flags accepted for CLI compatibility and ignored: %s", ", ".join(ignored))
@@ -268,12 +268,14 @@ def main(args):
     cpu_gen = torch.Generator().manual_seed((args.seed or 0) + rank)
     t_last = time.time()
     while global_step < args.max_train_steps:
-        latents, pe = src.batch()
-        noise = torch.randn(latents.shape, generator=src.g, device=device)                                      # :1139
-        index = torch.randint(0, args.num_ddim_timesteps, (latents.shape[0],), generator=src.g, device=device)  # :1147
-        w = ((args.w_max - args.w_min) * torch.rand((latents.shape[0],), generator=cpu_gen) + args.w_min).to(device)  # :1183 CPU RNG
         lr = lr_at(args, sched_step(global_step, world))
-        out = D.step(latents, pe, src.uncond, noise, index, w, lr=lr)
+        ga = args.gradient_accumulation_steps
+        for micro in range(ga):                                # accelerator.accumulate(unet), :1120: one optimizer step per ga batches
+            latents, pe = src.batch()
+            noise = torch.randn(latents.shape, generator=src.g, device=device)                                      # :1139
+            index = torch.randint(0, args.num_ddim_timesteps, (latents.shape[0],), generator=src.g, device=device)  # :1147
+            w = ((args.w_max - args.w_min) * torch.rand((latents.shape[0],), generator=cpu_gen) + args.w_min).to(device)  # :1183 CPU RNG
+            out = D.step(latents, pe, src.uncond, noise, index, w, lr=lr, accum=(micro, ga))
         global_step += 1
         if rank == 0:
             loss = float(out["loss"].item())                       # the reference's only per-step host sync (:1367)

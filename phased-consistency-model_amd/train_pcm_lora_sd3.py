@@ -190,8 +190,8 @@ def main(args):
     local_rank = max(args.local_rank, 0)
     logging.basicConfig(format="%(asctime)s - %(levelname)s - %(name)s - %(message)s", datefmt="%m/%d/%Y %H:%M:%S",
                         level=logging.INFO if rank == 0 else logging.WARNING)
-    if args.gradient_accumulation_steps != 1:
-        raise SystemExit("pcm_amd: --gradient_accumulation_steps != 1 is not implemented (reference recipes use 1)")
+    if args.gradient_accumulation_steps < 1:
+        raise SystemExit("pcm_amd: --gradient_accumulation_steps must be >= 1")
     if args.optimizer.lower() != "adamw":
         raise SystemExit("pcm_amd: only --optimizer AdamW (the reference recipes') is implemented")
     apply_scale_lr(args, world)
@@ -236,11 +236,13 @@ def main(args):
     logger.info("***** Running training *****  world=%d  per-GPU batch=%d  total steps=%d", world, args.train_batch_size, args.max_train_steps)
     t_last = time.time()
     while global_step < args.max_train_steps:
-        latents, pe, pp = src.batch()
-        noise = torch.randn(latents.shape, generator=src.g, device=device)                                            # :1281
-        index = torch.randint(0, args.num_euler_timesteps, (latents.shape[0],), generator=src.g, device=device)       # :1285-1287
         lr = base.lr_at(args, global_step)
-        out = D.step(latents, pe, pp, src.uncond, src.uncond_pooled, noise, index, lr=lr)
+        ga = args.gradient_accumulation_steps
+        for micro in range(ga):                                # accelerator.accumulate(transformer), :1267-1268
+            latents, pe, pp = src.batch()
+            noise = torch.randn(latents.shape, generator=src.g, device=device)                                            # :1281
+            index = torch.randint(0, args.num_euler_timesteps, (latents.shape[0],), generator=src.g, device=device)       # :1285-1287
+            out = D.step(latents, pe, pp, src.uncond, src.uncond_pooled, noise, index, lr=lr, accum=(micro, ga))
         global_step += 1
         if rank == 0:
             loss = float(out["loss"].item())

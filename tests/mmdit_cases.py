@@ -231,3 +231,36 @@ def run_adv_case(dev, global_step):
     print("loss_cm %.5f (%.5f) g_loss %.5f (%.5f), LoRA grad rel err %.3e" % (float(out["loss_cm"]), rl, float(out["g_loss"]), rg, (num / den) ** 0.5))
     assert (num / den) ** 0.5 < 0.15
     assert not torch.equal(lora.params, p0) and torch.equal(disc.params, d0)              # only the student moved
+
+
+def run_accumulation_case(dev):
+    """--gradient_accumulation_steps 2: two micro-batches of 2 (gradient scaled by 1/2 each, one exchange + AdamW at the end) land on the
+    same LoRA parameters as one step on the 4 samples."""
+    from oracle import mmdit_sd3 as O
+    from pcm_amd.mmdit import MMDiTWeights, sd3_lora_state
+    from pcm_amd.mmdit_spec import MMDiTConfig
+    from pcm_amd.trainer_sd3 import SD3Distiller, SD3StepConfig
+    kw = dict(sample_size=16, num_layers=2, attention_head_dim=64, num_attention_heads=2, joint_attention_dim=96, caption_projection_dim=128,
+              pooled_projection_dim=64, pos_embed_max_size=12)
+    sd = O.init_state_dict(O.MMDiTConfig(**kw), 0)
+    pc = MMDiTConfig(**kw)
+    W = MMDiTWeights(pc, {k: v.to(dev) for k, v in sd.items()}, dev)
+    g = torch.Generator().manual_seed(9)
+    G, H, Lc = 4, 8, 5
+    ts = [torch.randn(G, 16, H, H, generator=g), torch.randn(G, Lc, 96, generator=g), torch.randn(G, 64, generator=g),
+          torch.randn(G, Lc, 96, generator=g), torch.randn(G, 64, generator=g), torch.randn(G, 16, H, H, generator=g), torch.tensor([3, 41, 17, 28])]
+    res = []
+    for mode in ("single", "accum"):
+        lora = sd3_lora_state(pc, 32, 8.0, dev, seed=5, b_std=0.05)
+        init = lora.params.clone()
+        D = SD3Distiller(W, lora, SD3StepConfig(multiphase=2, learning_rate=1e-3))
+        if mode == "single":
+            D.step(*(t.to(dev) for t in ts))
+        else:
+            for i in range(2):
+                out = D.step(*(t[2 * i:2 * i + 2].contiguous().to(dev) for t in ts), accum=(i, 2))
+                assert (D.step_count == 1) == (i == 1)                      # the optimizer runs with the last micro-batch only
+        res.append((lora.params - init).double().cpu())
+    u1, u2 = res
+    cos = float((u1 * u2).sum() / (u1.norm() * u2.norm()))
+    assert cos > 0.98 and 0.9 < float(u2.norm() / u1.norm()) < 1.1, (cos, float(u2.norm() / u1.norm()))
