@@ -47,6 +47,8 @@ def main(args):
     from pcm_amd.unet_spec import UNetConfig, random_state_dict
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     local_rank = max(args.local_rank, 0)
+    if args.gradient_accumulation_steps != 1:
+        raise SystemExit("pcm_amd: --gradient_accumulation_steps != 1 is not implemented for this trainer (reference recipes use 1)")
     logging.basicConfig(format="%(asctime)s - %(levelname)s - %(name)s - %(message)s", level=logging.INFO if rank == 0 else logging.WARNING)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
