@@ -30,7 +30,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 logger = logging.getLogger("pcm_amd")
 IGNORED = ["pretrained_vae_model_name_or_path", "teacher_revision", "revision", "cache_dir", "center_crop", "random_flip",
-           "dataloader_num_workers", "max_train_samples", "scale_lr", "use_8bit_adam", "proportion_empty_prompts",
+           "dataloader_num_workers", "max_train_samples", "scale_lr", "use_8bit_adam",
            "allow_tf32", "cast_teacher_unet", "enable_xformers_memory_efficient_attention", "gradient_checkpointing",
            "push_to_hub", "hub_token", "hub_model_id", "validation_steps"]
 
@@ -106,6 +106,9 @@ class LatentSource:
 
     def __init__(self, args, rank, world, device):
         self.bs, self.device = args.train_batch_size, device
+        self.p_empty = float(getattr(args, "proportion_empty_prompts", 0) or 0)
+        if not 0.0 <= self.p_empty <= 1.0:
+            raise ValueError("`--proportion_empty_prompts` must be in the range [0, 1].")        # :733-734
         self.hw = args.resolution // 8                      # VAE downsampling factor: synthetic latents follow --resolution
         self.g = torch.Generator(device=device).manual_seed((args.seed or 0) + rank)
         self.shards, self.uncond = None, None
@@ -133,9 +136,14 @@ class LatentSource:
     def batch(self):
         if self.shards:
             idx = torch.randint(0, self.lat.shape[0], (self.bs,), generator=self.g, device=self.device)
-            return self.lat[idx].contiguous(), self.pe[idx].contiguous()
-        return (torch.randn(self.bs, 4, self.hw, self.hw, generator=self.g, device=self.device),
-                torch.randn(self.bs, 77, 768, generator=self.g, device=self.device))
+            lat, pe = self.lat[idx].contiguous(), self.pe[idx].contiguous()
+        else:
+            lat = torch.randn(self.bs, 4, self.hw, self.hw, generator=self.g, device=self.device)
+            pe = torch.randn(self.bs, 77, 768, generator=self.g, device=self.device)
+        if self.p_empty > 0:        # caption dropout (:740-746): the caption becomes "" -> its encoding is the unconditional embedding
+            drop = torch.rand(self.bs, generator=self.g, device=self.device) < self.p_empty
+            pe = torch.where(drop[:, None, None], self.uncond, pe)
+        return lat, pe
 
 
 def pick_device(local_rank):

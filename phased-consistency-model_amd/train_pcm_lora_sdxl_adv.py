@@ -60,6 +60,9 @@ class SdxlSource:
 
     def __init__(self, args, rank, world, device):
         self.bs, self.device, self.hw = args.train_batch_size, device, args.resolution // 8
+        if float(getattr(args, "proportion_empty_prompts", 0) or 0) > 0:
+            raise SystemExit("pcm_amd: --proportion_empty_prompts needs the two text encoders' output for the empty caption, which is upstream "
+                             "of this path: drop the captions when the embedding shards are written")
         self.g = torch.Generator(device=device).manual_seed((args.seed or 0) + rank)
         self.data = None
         if args.latents_dir:

@@ -328,6 +328,14 @@ def test_latent_shard_sources_rank_sharding_and_shapes(tmp_path):
         cli.LatentSource(a, 5, 8, dev)                                                          # more ranks than shards
     s = cli.LatentSource(cli.parse_args(["--pretrained_teacher_model", "x", "--synthetic_data", "--resolution", "256", "--train_batch_size", "2"]), 0, 1, dev)
     assert s.batch()[0].shape == (2, 4, 32, 32)
+    # caption dropout: a dropped caption's embedding IS the unconditional one
+    ad = cli.parse_args(["--pretrained_teacher_model", "x", "--latents_dir", str(d15), "--train_batch_size", "64", "--proportion_empty_prompts", "0.5", "--seed", "3"])
+    sdrop = cli.LatentSource(ad, 1, 2, dev)
+    _, pe = sdrop.batch()
+    frac = float((pe == 7.0).all(dim=(1, 2)).float().mean())
+    assert 0.25 < frac < 0.75, frac
+    with pytest.raises(ValueError):
+        cli.LatentSource(cli.parse_args(["--pretrained_teacher_model", "x", "--synthetic_data", "--proportion_empty_prompts", "1.5"]), 0, 1, dev)
     # ---- SDXL
     dxl = tmp_path / "sdxl"
     dxl.mkdir()
