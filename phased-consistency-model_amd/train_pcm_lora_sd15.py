@@ -30,7 +30,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 logger = logging.getLogger("pcm_amd")
 IGNORED = ["pretrained_vae_model_name_or_path", "teacher_revision", "revision", "cache_dir", "center_crop", "random_flip",
-           "dataloader_num_workers", "max_train_samples", "scale_lr", "use_8bit_adam",
+           "dataloader_num_workers", "scale_lr", "use_8bit_adam",
            "allow_tf32", "cast_teacher_unet", "enable_xformers_memory_efficient_attention", "gradient_checkpointing",
            "push_to_hub", "hub_token", "hub_model_id", "validation_steps"]
 
@@ -123,6 +123,9 @@ class LatentSource:
             for d in data:
                 if "uncond_prompt_embeds" in d:
                     self.uncond = d["uncond_prompt_embeds"].float().to(device)
+            if getattr(args, "max_train_samples", None):            # debugging knob of the reference's parser: truncate the training set
+                n = max(1, args.max_train_samples // world)
+                self.lat, self.pe = self.lat[:n], self.pe[:n]
             self.shards = True
         elif not args.synthetic_data:
             raise SystemExit("pcm_amd: give --latents_dir or --synthetic_data (VAE/CLIP encoding is out of scope, see --help)")

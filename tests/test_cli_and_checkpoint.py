@@ -322,6 +322,8 @@ def test_latent_shard_sources_rank_sharding_and_shapes(tmp_path):
         assert set(lat[:, 0, 0, 0].tolist()) <= ({0.0, 2.0} if rank == 0 else {1.0, 3.0})        # shards rank::world
         assert src.uncond.shape == (5, 77, 768)
         assert (rank == 1) == bool((src.uncond == 7.0).all())                                  # found in rank 1's shard only
+    at = cli.parse_args(["--pretrained_teacher_model", "x", "--latents_dir", str(d15), "--train_batch_size", "2", "--max_train_samples", "4"])
+    assert cli.LatentSource(at, 0, 2, dev).lat.shape[0] == 2                                   # 4 samples over 2 ranks
     with pytest.raises(SystemExit):
         cli.LatentSource(cli.parse_args(["--pretrained_teacher_model", "x"]), 0, 1, dev)       # neither shards nor --synthetic_data
     with pytest.raises(FileNotFoundError):
