@@ -63,7 +63,7 @@ def main(args):
     lora = LoraState(ucfg, args.lora_rank, 8.0, device, seed=(args.seed or 0))
     b = tuple(ucfg.block_out_channels)                            # feature taps: every down-block output, mid, every up-block output
     dims = b + (b[-1],) + b[::-1] if getattr(args, "tiny_model", False) else None          # (SD1.5: discriminator_sd15.py:377)
-    disc = Discriminator(**(dict(adapter_channel_dims=dims) if dims else {}), device=device, seed=(args.seed or 0) + 1)
+    disc = Discriminator(**(dict(adapter_channel_dims=dims, num_h_per_head=1) if dims else {}), device=device, seed=(args.seed or 0) + 1)
     if world > 1:
         torch.distributed.broadcast(lora.params, src=0); lora.repack()
         torch.distributed.broadcast(disc.params, src=0); disc.repack()
