@@ -72,3 +72,17 @@ def test_mmdit_unfused_qkv_schedule(monkeypatch):
 @pytest.mark.slow
 def test_gradient_accumulation_matches_the_full_batch_step():
     run_accumulation_case("cpu")
+
+
+@pytest.mark.slow
+def test_property_case_on_a_narrow_config():
+    """the checks the GPU suite applies to SD3-medium at full size (tests/test_gpu_zz_sd3_fullsize.py), on the emulator."""
+    from mmdit_cases import run_property_case
+    from oracle import mmdit_sd3 as O
+    from pcm_amd.mmdit import MMDiTWeights, sd3_lora_state
+    from pcm_amd.mmdit_spec import MMDiTConfig
+    kw = dict(sample_size=16, num_layers=3, attention_head_dim=64, num_attention_heads=2, joint_attention_dim=96, caption_projection_dim=128,
+              pooled_projection_dim=64, pos_embed_max_size=12)
+    pc = MMDiTConfig(**kw)
+    W = MMDiTWeights(pc, O.init_state_dict(O.MMDiTConfig(**kw), 0), "cpu")
+    run_property_case("cpu", pc, W, sd3_lora_state(pc, 32, 8.0, "cpu", seed=1), 8, 5)
