@@ -1,0 +1,45 @@
+"""SDXL at its real size (2.57 B-parameter UNet, 128x128x4 latents, text_time added conditioning) on the MI355X through size-independent
+properties: finite output, batch independence of the UNet, B = 0 LoRA == teacher, one distillation step (tools/sdxl_step_probe.py is the
+timing companion: bs 4, 261 ms/step, `profiles/r01_g_sdxl_step_probe.json`).  Runs near the end of the GPU suite."""
+import pytest
+import torch
+
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(600)]
+
+
+def test_sdxl_full_size_properties():
+    from pcm_amd import capi
+    from pcm_amd.model import LoraState, UNet, UNetWeights
+    from pcm_amd.trainer import Distiller, StepConfig
+    from pcm_amd.unet_spec import UNetConfig, random_state_dict
+    capi.lib()
+    dev = torch.device("cuda", 0)
+    cfg = UNetConfig.sdxl()
+    sd = random_state_dict(cfg, 0, dev)
+    W = UNetWeights(cfg, sd, dev)
+    del sd
+    torch.cuda.empty_cache()
+    lora = LoraState(cfg, 64, 8.0, dev, seed=1)                                  # B = 0 (peft init)
+    g = torch.Generator(device=dev).manual_seed(0)
+    r = lambda *s: torch.randn(*s, generator=g, device=dev)   # noqa: E731
+    B = 2
+    x, t, ctx = r(B, 4, 128, 128), torch.tensor([999, 259], device=dev), r(B, 77, 2048)
+    tids = torch.tensor([[1024, 1024, 0, 0, 1024, 1024]] * B, device=dev)
+    ac = dict(text_embeds=r(B, 1280), time_ids=tids)
+
+    def rel(a, b):
+        return float((a - b).norm() / b.norm())
+    teacher = UNet(W, None)
+    out = teacher.forward(x, t, ctx, added_cond=ac)
+    assert out.shape == (B, 4, 128, 128) and bool(torch.isfinite(out).all()) and float(out.abs().max()) > 0
+    solo = teacher.forward(x[1:], t[1:], ctx[1:], added_cond={k: v[1:] for k, v in ac.items()})
+    assert rel(solo[0], out[1]) < 5e-2, rel(solo[0], out[1])                     # no cross-sample coupling
+    assert rel(UNet(W, lora).forward(x, t, ctx, added_cond=ac), out) < 5e-2       # B = 0: the student is the teacher
+    D = Distiller(W, lora, StepConfig(multiphase=4, num_ddim_timesteps=40, w_min=6.0, w_max=7.0, learning_rate=2e-6, adam_weight_decay=0.0, loss_type="huber"))
+    uac = dict(text_embeds=torch.zeros(B, 1280, device=dev), time_ids=tids)
+    p0 = lora.params.clone()
+    res = D.step(x, ctx, torch.zeros(B, 77, 2048, device=dev), r(B, 4, 128, 128), torch.tensor([3, 31], device=dev),
+                 6.0 + torch.rand(B, generator=g, device=dev), added_cond=ac, uncond_added_cond=uac)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(res["loss"]).all()) and float(res["grad_sumsq"]) > 0 and not torch.equal(lora.params, p0)
+    print("SDXL full-size step: loss %.5f, peak %.1f GB" % (float(res["loss"]), torch.cuda.max_memory_allocated() / 1e9))
