@@ -201,12 +201,14 @@ template <int D, bool PK> using TStage = typename TStageSel<D, PK>::type;
 
 // x [B][L][ld] (head h at columns h*D..) -> packed transposed tiles xt[(b*H+h)][tile][D][64 slots]; slot 8*chunk+e of a tile is row
 // 16*(chunk>>1) + 8*(e>>2) + 4*(chunk&1) + (e&3) (the contraction-slot order of the PV / dS MFMAs); rows >= L are zero.
-__global__ __launch_bounds__(256) void attn_pack_t_kernel(const bf16_t* x, bf16_t* xt, int H, int L, int D, int ld) {
-  // one block = one 64-row tile of ALL heads: coalesced 16-B row loads into LDS, transposed 2-byte reads out of LDS, 16-B tile-image stores
+__global__ __launch_bounds__(256) void attn_pack_t_kernel(const bf16_t* x, bf16_t* xt, int H, int L, int D, int ld, int HG) {
+  // one block = one 64-row tile of a GROUP of HG heads (blockIdx.z; the group is sized by the launcher so that the LDS image stays under
+  // 64 KB for any H*D): coalesced 16-B row loads into LDS, transposed 2-byte reads out of LDS, 16-B tile-image stores
   PCM_DYN_SMEM(sm);
-  const int tile = blockIdx.x, b = blockIdx.y, nt = gridDim.x, HD = H * D, CV = HD / 8, RS = HD + 8;   // RS: padded LDS row (elements)
+  const int tile = blockIdx.x, b = blockIdx.y, nt = gridDim.x, h0 = blockIdx.z * HG;
+  const int nh = (H - h0 < HG ? H - h0 : HG), HD = nh * D, CV = HD / 8, RS = HG * D + 8;   // RS: padded LDS row (elements)
   bf16_t* t = (bf16_t*)sm;
-  const bf16_t* xb = x + (size_t)b * L * ld;
+  const bf16_t* xb = x + (size_t)b * L * ld + h0 * D;
   for (int u = threadIdx.x; u < 64 * CV; u += blockDim.x) {
     const int r = u / CV, c = u - r * CV, row = 64 * tile + r;
     uint4 v = make_uint4(0u, 0u, 0u, 0u);
@@ -216,14 +218,14 @@ __global__ __launch_bounds__(256) void attn_pack_t_kernel(const bf16_t* x, bf16_
   __syncthreads();
   for (int u = threadIdx.x; u < HD * 8; u += blockDim.x) {
     const int col = u % HD, chunk = u / HD;                 // lanes along the columns: conflict-free 2-byte LDS reads
-    const int h = col / D, drow = col - h * D;
+    const int hl = col / D, drow = col - hl * D;
     unsigned w[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
     for (int e = 0; e < 8; e++) {
       const int r = 16 * (chunk >> 1) + 8 * (e >> 2) + 4 * (chunk & 1) + (e & 3);
       w[e >> 1] |= (unsigned)t[r * RS + col] << (16 * (e & 1));
     }
-    uint4* out = (uint4*)(xt + ((size_t)(b * H + h) * nt + tile) * D * 64);
+    uint4* out = (uint4*)(xt + ((size_t)(b * H + h0 + hl) * nt + tile) * D * 64);
     out[drow * 8 + chunk] = make_uint4(w[0], w[1], w[2], w[3]);
   }
 }
@@ -651,12 +653,16 @@ extern "C" size_t pcm_attn_workspace_bytes(int B, int H, int Lq, int Lk, int d, 
   if (!attn_use_packed(Lq, Lk, d)) return 0;
   return backward ? attn_packed_bytes(B, H, Lk, d) + 2 * attn_packed_bytes(B, H, Lq, d) : attn_packed_bytes(B, H, Lk, d);
 }
-static void attn_pack_launch(const void* x, void* xt, int B, int H, int L, int d, int ld, void* stream) {
-#ifndef PCM_HOST_EMU
-  static bool lds_ok = false;      // tiles of 640-channel tensors need 83 KB of dynamic LDS
-  if (!lds_ok) { hipFuncSetAttribute((const void*)attn_pack_t_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); lds_ok = true; }
-#endif
-  PCM_LAUNCH(attn_pack_t_kernel, dim3((L + 63) / 64, B), dim3(256), 64 * (size_t)(H * d + 8) * 2, stream, (const bf16_t*)x, (bf16_t*)xt, H, L, d, ld);
+// heads per pack block: the LDS image of a block is 64 rows x (HG*d + 8) bf16; HG*d <= 504 keeps it at <= 64 KB (no opt-in attribute,
+// two blocks per CU) for every head count -- SDXL level 2 (20 x 64) and SD3 (24 x 64) run as 3 / 4 head groups
+static int attn_pack_heads_per_block(int H, int d) { int hg = 504 / d; return hg < 1 ? 1 : (hg > H ? H : hg); }
+static int attn_pack_launch(const void* x, void* xt, int B, int H, int L, int d, int ld, void* stream) {
+  const int HG = attn_pack_heads_per_block(H, d);
+  const size_t smem = 64 * (size_t)(HG * d + 8) * 2;
+  PCM_CHECK(smem <= 64 * 1024 && (d % 8) == 0, PCM_EUNSUPPORTED, "pcm_attn: packed operand path: head_dim %d needs %zu B of LDS per tile", d, smem);
+  PCM_CHECK(B <= 65535 && (H + HG - 1) / HG <= 65535, PCM_EUNSUPPORTED, "pcm_attn: batch %d exceeds the grid limit", B);
+  PCM_LAUNCH(attn_pack_t_kernel, dim3((L + 63) / 64, B, (H + HG - 1) / HG), dim3(256), smem, stream, (const bf16_t*)x, (bf16_t*)xt, H, L, d, ld, HG);
+  return PCM_OK;
 }
 
 extern "C" int pcm_attn_fwd_ws(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int Lq, int Lk,
@@ -667,7 +673,7 @@ extern "C" int pcm_attn_fwd_ws(const void* q, const void* k, const void* v, void
   const bool pk = workspace && attn_use_packed(Lq, Lk, d);
   if (pk) {
     PCM_CHECK(PCM_ALIGNED16(workspace) && workspace_bytes >= pcm_attn_workspace_bytes(B, H, Lq, Lk, d, 0), PCM_EINVAL, "pcm_attn_fwd_ws: workspace");
-    attn_pack_launch(v, workspace, B, H, Lk, d, ldk, stream);
+    if (int rc = attn_pack_launch(v, workspace, B, H, Lk, d, ldk, stream)) return rc;
   }
 #define FWD_CALL(DD)                                                                                                               \
   if (pk && AttnPrefetch<DD>::value)                                                                                               \
@@ -696,8 +702,11 @@ extern "C" int pcm_attn_bwd_ws(const void* q, const void* k, const void* v, cons
     PCM_CHECK(PCM_ALIGNED16(workspace) && workspace_bytes >= pcm_attn_workspace_bytes(B, H, Lq, Lk, d, 1), PCM_EINVAL, "pcm_attn_bwd_ws: workspace");
     char* w = (char*)workspace;
     kt = (const bf16_t*)w; qt = (const bf16_t*)(w + attn_packed_bytes(B, H, Lk, d)); ot = (const bf16_t*)(w + attn_packed_bytes(B, H, Lk, d) + attn_packed_bytes(B, H, Lq, d));
-    if (dq) attn_pack_launch(k, (void*)kt, B, H, Lk, d, ldk, stream);
-    if (dk && dv) { attn_pack_launch(q, (void*)qt, B, H, Lq, d, ldq, stream); attn_pack_launch(dO, (void*)ot, B, H, Lq, d, ldo, stream); }
+    if (dq) { if (int rc = attn_pack_launch(k, (void*)kt, B, H, Lk, d, ldk, stream)) return rc; }
+    if (dk && dv) {
+      if (int rc = attn_pack_launch(q, (void*)qt, B, H, Lq, d, ldq, stream)) return rc;
+      if (int rc = attn_pack_launch(dO, (void*)ot, B, H, Lq, d, ldo, stream)) return rc;
+    }
   }
   if (dq) {
     dim3 grid((Lq + 127) / 128, H, B), block(256);

@@ -518,9 +518,6 @@ extern "C" int pcm_gemm_bf16(const pcm_gemm_seg* segs, int nseg, const pcm_gemm_
   }
   dim3 grid(g.tiles_m * g.tiles_n, pl.splitk);
   size_t smem = 2 * (size_t)(pl.BM + pl.BN) * 128;
-#ifdef PCM_HOST_EMU
-#define PCM_GEMM_LAUNCH(NW, WGM, TM, TN) PCM_LAUNCH((pcm_gemm_kernel<NW, WGM, TM, TN>), grid, dim3(64 * NW), smem, stream, g)
-#else
   // tiles above 64 KB of dynamic LDS need the per-function cap raised once
 #define PCM_GEMM_LAUNCH(NW, WGM, TM, TN)                                                                          \
   do {                                                                                                             \
@@ -533,7 +530,6 @@ extern "C" int pcm_gemm_bf16(const pcm_gemm_seg* segs, int nseg, const pcm_gemm_
     }                                                                                                              \
     PCM_LAUNCH((pcm_gemm_kernel<NW, WGM, TM, TN>), grid, dim3(64 * NW), smem, stream, g);                          \
   } while (0)
-#endif
   if (pl.BM == 256 && pl.BN == 128) PCM_GEMM_LAUNCH(8, 4, 2, 2);
   else if (pl.BM == 128 && pl.BN == 128) PCM_GEMM_LAUNCH(4, 2, 2, 2);
   else if (pl.BM == 256 && pl.BN == 64) PCM_GEMM_LAUNCH(4, 4, 2, 2);

@@ -361,14 +361,12 @@ template <int F0>
 static int launch8p(const GemmDev& g, void* stream) {
   const size_t smem = pcm_gemm8p_lds_bytes(F0 + 2);
   dim3 grid(g.tiles_m * g.tiles_n, g.splitk);
-#ifndef PCM_HOST_EMU
   static bool lds_ok = false;
   if (!lds_ok) {
     hipError_t er = hipFuncSetAttribute((const void*)pcm_gemm8p_kernel<F0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     PCM_CHECK(er == hipSuccess, PCM_EHIP, "pcm_gemm_bf16: hipFuncSetAttribute(LDS %zu): %s", smem, hipGetErrorString(er));
     lds_ok = true;
   }
-#endif
   PCM_LAUNCH((pcm_gemm8p_kernel<F0>), grid, dim3(512), smem, stream, g);
   return 0;
 }

@@ -1,5 +1,7 @@
 // TEST INFRASTRUCTURE ONLY — fiber scheduler for tests/emu/hip_emu.h
 #include "hip_emu.h"
+#include <algorithm>
+#include <map>
 
 namespace pcm_emu {
 std::vector<Fiber> g_fibers;
@@ -91,7 +93,31 @@ static void trampoline() {
   __builtin_trap();   // a finished fiber is never resumed
 }
 
-void launch(dim3 grid, dim3 block, size_t smem, std::function<void()> body) {
+// gfx950 launch limits (MI355X_MICROARCH.md): 160 KiB of LDS per CU / workgroup, of which a kernel may use more than 64 KiB of DYNAMIC
+// LDS only after hipFuncSetAttribute(MaxDynamicSharedMemorySize) raised its limit; 1024 threads per block; grid.y/z <= 65535.
+// (static __shared__ arrays are host statics here and not counted: tests/test_codeobj_limits.py checks them on the gfx950 code object.)
+hipError_t g_last_error = 0;
+static std::map<const void*, size_t> g_max_dyn;
+static const size_t LDS_PER_CU = 160 * 1024, LDS_DEFAULT_DYN = 64 * 1024;
+hipError_t set_max_dyn_lds(const void* fn, int bytes) {
+  if (bytes < 0 || (size_t)bytes > LDS_PER_CU) return hipErrorInvalidValue;
+  g_max_dyn[fn] = (size_t)bytes;
+  return 0;
+}
+
+void launch(const void* fn, dim3 grid, dim3 block, size_t smem, std::function<void()> body) {
+  {
+    auto it = g_max_dyn.find(fn);
+    const size_t lim = it == g_max_dyn.end() ? LDS_DEFAULT_DYN : std::max(it->second, LDS_DEFAULT_DYN);
+    const unsigned long nthr = (unsigned long)block.x * block.y * block.z;
+    if (smem > lim || smem > LDS_PER_CU || nthr == 0 || nthr > 1024 || grid.x == 0 || grid.y == 0 || grid.z == 0 || grid.y > 65535 ||
+        grid.z > 65535 || grid.x > 2147483647u) {
+      fprintf(stderr, "pcm_emu: launch REJECTED (gfx950 limits): dynamic LDS %zu B (limit %zu), block %lu, grid (%u,%u,%u)\n", smem, lim, nthr,
+              grid.x, grid.y, grid.z);
+      g_last_error = hipErrorInvalidValue;
+      return;
+    }
+  }
   int nthreads = block.x * block.y * block.z;
   int nwaves = (nthreads + 63) / 64;
   g_body = body;
@@ -163,3 +189,12 @@ void launch(dim3 grid, dim3 block, size_t smem, std::function<void()> body) {
   g_cur = nullptr;
 }
 }  // namespace pcm_emu
+
+// self-test hook for tests/test_emu_kernels.py::test_emulator_enforces_launch_limits: launch an empty kernel with the given dynamic LDS
+// request / block size (optionally after raising the kernel's dynamic-LDS cap) and return what hipGetLastError would report
+static void emu_empty_kernel() {}
+extern "C" int pcm_emu_try_launch(long dyn_lds, int block, int gy, long raise_cap_to) {
+  if (raise_cap_to >= 0) { if (hipFuncSetAttribute((const void*)emu_empty_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)raise_cap_to)) return -1; }
+  PCM_LAUNCH(emu_empty_kernel, dim3(1, gy), dim3(block), (size_t)dyn_lds, nullptr);
+  return hipGetLastError();
+}

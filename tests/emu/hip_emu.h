@@ -45,8 +45,16 @@ static inline uint2 make_uint2(unsigned a, unsigned b) { return {a, b}; }
 typedef void* hipStream_t;
 typedef int hipError_t;
 #define hipSuccess 0
-static inline hipError_t hipGetLastError() { return 0; }
-static inline const char* hipGetErrorString(hipError_t) { return "emu"; }
+// launch-limit model (gfx950): a launch that the hardware would reject is NOT run and leaves hipErrorInvalidValue for hipGetLastError,
+// exactly like a real launch -- the C ABI then reports rc = PCM_EHIP "HIP launch error: invalid argument"
+#define hipErrorInvalidValue 1
+#define hipFuncAttributeMaxDynamicSharedMemorySize 8
+namespace pcm_emu { extern hipError_t g_last_error; hipError_t set_max_dyn_lds(const void* fn, int bytes); }
+static inline hipError_t hipGetLastError() { hipError_t e = pcm_emu::g_last_error; pcm_emu::g_last_error = 0; return e; }
+static inline const char* hipGetErrorString(hipError_t e) { return e == hipErrorInvalidValue ? "invalid argument" : "emu"; }
+static inline hipError_t hipFuncSetAttribute(const void* fn, int attr, int value) {
+  return attr == hipFuncAttributeMaxDynamicSharedMemorySize ? pcm_emu::set_max_dyn_lds(fn, value) : hipErrorInvalidValue;
+}
 static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return 0; }
 
 namespace pcm_emu {
@@ -84,7 +92,7 @@ extern bool g_lazy_dma;
 void yield_to_sched();
 void wave_sync();
 void block_sync();
-void launch(dim3 grid, dim3 block, size_t smem, std::function<void()> body);
+void launch(const void* fn, dim3 grid, dim3 block, size_t smem, std::function<void()> body);
 
 inline int lane_id() { return g_cur->lane; }
 inline WaveScratch& wave() { return g_waves[g_cur->wave]; }
@@ -243,5 +251,5 @@ static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4);
 static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
 
 #define PCM_LAUNCH(kern, grid, block, smem, stream, ...) \
-  pcm_emu::launch((grid), (block), (smem), [=]() { kern(__VA_ARGS__); })
+  pcm_emu::launch((const void*)(kern), (grid), (block), (smem), [=]() { kern(__VA_ARGS__); })
 #define PCM_DYN_SMEM(name) char* name = pcm_emu::g_dyn_smem

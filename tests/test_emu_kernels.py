@@ -97,7 +97,25 @@ def test_teacher_input_grad():
     K.case_teacher_input_grad("cpu")
 
 
-@pytest.mark.parametrize("B,H,Lq,Lk,d", [(1, 2, 130, 130, 40), (1, 1, 70, 200, 80), (1, 2, 154, 154, 64)])
+def test_emulator_enforces_launch_limits():
+    """The emulator refuses what a gfx950 CU refuses (round-1 bug class: a 164 864 B dynamic-LDS request passed every CPU test):
+    > 64 KB of dynamic LDS without the per-kernel attribute, > 160 KB at all, > 1024 threads, grid.y > 65535."""
+    from pcm_amd import capi
+    dll = capi.lib().dll
+    import ctypes
+    f = dll.pcm_emu_try_launch
+    f.argtypes = [ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_long]
+    assert f(65536, 256, 1, -1) == 0
+    assert f(65537, 256, 1, -1) != 0                 # needs hipFuncSetAttribute first
+    assert f(0, 2048, 1, -1) != 0 and f(0, 256, 70000, -1) != 0
+    assert f(0, 256, 1, 163841) == -1                # the attribute itself is bounded by the 160 KiB of a CU
+    assert f(163840, 256, 1, 163840) == 0
+    assert f(164864, 256, 1, -1) != 0                # the round-1 SDXL request (64 rows x (1280 + 8) bf16)
+
+
+# (1, 20, .., 64) / (1, 24, .., 64): SDXL level-2 and SD3 widths (H*d = 1280 / 1536: several head groups per pack block row); d = 32 wide
+@pytest.mark.parametrize("B,H,Lq,Lk,d", [(1, 2, 130, 130, 40), (1, 1, 70, 200, 80), (1, 2, 154, 154, 64), (1, 20, 70, 70, 64),
+                                         (1, 24, 130, 100, 64), (1, 17, 70, 70, 32)])
 def test_attention_packed_transposed_operands(B, H, Lq, Lk, d):
     """pcm_attn_*_ws with the one-off packed V^T / K^T / Q^T / dO^T tile images (ragged tails zero-filled by the packer)."""
     from pcm_amd import capi

@@ -76,7 +76,10 @@ def test_wgrad_conv(stride, src_mode, C):
 
 @pytest.mark.parametrize("B,H,Lq,Lk,d,spike", [(1, 8, 1024, 1024, 40, False), (2, 8, 256, 77, 80, False),
                                                (2, 8, 256, 256, 160, True), (1, 8, 64, 64, 160, False),
-                                               (1, 2, 4096, 4096, 40, True), (1, 8, 4096, 77, 40, False)])
+                                               (1, 2, 4096, 4096, 40, True), (1, 8, 4096, 77, 40, False),
+                                               # SDXL level 2 / level 1, SD3 joint tokens (ragged), d = 32: packed path at H*d >= 1280
+                                               (1, 20, 1024, 1024, 64, True), (1, 10, 2176, 2176, 64, False),
+                                               (1, 24, 1178, 1178, 64, True), (1, 40, 1024, 1024, 32, False)])
 def test_attention(B, H, Lq, Lk, d, spike):
     K.case_attention("cuda", B, H, Lq, Lk, d, spike)
 
