@@ -356,6 +356,8 @@ struct GemmPlan { int BM, BN, tiles_m, tiles_n, splitk, kt_per_split; size_t ws_
 static int g_force_bm = 0, g_force_bn = 0;
 static int g_big_mode = -1;   // -1: read PCM_GEMM_BIG once (0 = never use gemm8p, 1 = planner, 2 = wherever eligible); tuning only
 extern "C" void pcm_debug_gemm_big_mode(int mode) { g_big_mode = mode; }
+static int g_ablate = 0;      // see PCM_ABL in gemm_dev.h (no effect in the product build)
+extern "C" void pcm_debug_gemm_ablate(int mask) { g_ablate = mask; }
 static int g_last_plan = 0;   // tests only: 1000*big_fn + splitk of the most recent pcm_gemm_bf16 launch
 extern "C" int pcm_debug_last_gemm_plan(void) { return g_last_plan; }
 static int big_mode() {
@@ -491,7 +493,7 @@ extern "C" int pcm_gemm_bf16(const pcm_gemm_seg* segs, int nseg, const pcm_gemm_
   g.nseg = nseg; g.M = e->M; g.N = e->N; g.Ho = e->Ho > 0 ? e->Ho : 1; g.Wo = e->Wo > 0 ? e->Wo : 1;
   g.bias = e->bias; g.rowvec = (const bf16_t*)e->rowvec; g.rpb = e->rows_per_batch > 0 ? e->rows_per_batch : 1;
   g.res = (const bf16_t*)e->residual; g.ldr = e->ldr; g.out = e->out; g.ldo = e->ldo;
-  g.out_f32 = e->out_dtype == PCM_F32; g.act = e->act; g.alpha = e->alpha;
+  g.out_f32 = e->out_dtype == PCM_F32; g.act = e->act; g.alpha = e->alpha; g.dbg = g_ablate;
   if (gemm_n64_ok(segs, nseg, e)) {
     g_last_plan = 64;
     int rc = pcm_gemm_n64_launch(g, stream);

@@ -21,7 +21,15 @@ struct GemmDev {
   int tiles_m, tiles_n;
   int splitk, kt_per_split;   // split-K: blockIdx.y = K slice; raw fp32 partial tiles go to slab ws[slice][M][N]
   float* ws;
+  int dbg;                    // ablation mask: only read by -DPCM_ABLATE builds (tools/probes/build_ablate.py), 0 otherwise
 };
+// timing ablations for tools/gemm8p_ablate.py (results are wrong by construction): 1 = no global stores in the epilogue, 2 = no epilogue,
+// 4 = no MFMAs, 8 = no LDS-DMA after the prologue.  Compiled out of the product library.
+#ifdef PCM_ABLATE
+#define PCM_ABL(bit) (g.dbg & (bit))
+#else
+#define PCM_ABL(bit) 0
+#endif
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 

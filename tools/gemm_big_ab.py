@@ -21,6 +21,12 @@ shapes = [(65536, 320, (320, 64), "lin", 0), (131072, 320, (320,), "lin", 0), (1
           (8192, 1280, (11520,), "conv", 16), (1024, 1280, (11520, 64), "conv", 8), (65536, 320, (5760, 64), "conv", 64), (32768, 640, (5760,), "conv", 32),
           (4096, 1280, (23040, 64), "conv", 16), (65536, 320, (8640, 64), "conv", 64), (65536, 640, (5760, 64), "conv", 64), (16384, 1280, (11520, 64), "conv", 32),
           (8192, 8192, (8192,), "lin", 0)]
+if os.environ.get("AB_SET") == "lin2b":   # the short-K Linear shapes of the 2B-sample forward passes (round-2 table, gpurun_out/b/gemm_table.txt)
+    shapes = [(131072, 2560, (320, 64), "lin", 0), (131072, 2560, (320,), "lin", 0), (131072, 320, (320, 64), "lin", 0), (131072, 320, (320,), "lin", 0),
+              (32768, 5120, (640, 64), "lin", 0), (8192, 1280, (1280, 64), "lin", 0), (32768, 640, (640, 64), "lin", 0), (8192, 10240, (1280, 64), "lin", 0),
+              (131072, 960, (320, 192), "lin", 0), (16384, 640, (640, 64), "lin", 0), (131072, 320, (1280, 64), "lin", 0), (65536, 320, (320, 64), "lin", 0),
+              (4096, 1280, (1280, 64), "lin", 0), (8192, 1280, (5120, 64), "lin", 0), (32768, 640, (2560, 64), "lin", 0), (32768, 1920, (640, 192), "lin", 0),
+              (65536, 1280, (320, 64), "lin", 0), (65536, 320, (2560, 64), "lin", 0), (8192, 3840, (1280, 192), "lin", 0), (16384, 2560, (640, 64), "lin", 0)]
 only = os.environ.get("AB_ONLY")
 for (M, N, Ks, kind, Hs) in shapes:
     segs = []
