@@ -164,10 +164,9 @@ int pcm_attn_bwd(const void* q, const void* k, const void* v, const void* o, con
                  int B, int H, int Lq, int Lk, int d, int ldq, int ldk, int ldo, float scale,
                  void* stream);
 
-/* Workspace variants.  For long sequences (Lq, Lk >= 1024, head_dim <= 80) every workgroup re-transposes each 64-row tile of the
- * streamed operand (V in the forward; K, Q and dO in the backward); with a caller-owned workspace of pcm_attn_workspace_bytes() the
- * transposed tile images are written ONCE (tile-major, tail rows zeroed) and the kernels stage them with plain 16-byte copies.
- * workspace == NULL (or a sequence below the threshold: pcm_attn_workspace_bytes returns 0) is exactly pcm_attn_fwd / pcm_attn_bwd. */
+/* Workspace variants (ABI kept from round 1, when the k-along-rows operands V^T / K^T / Q^T / dO^T were pre-transposed into a caller
+ * workspace).  The kernels now read those operands with LDS transpose reads (ds_read_b64_tr_b16) straight out of the row-major tiles:
+ * pcm_attn_workspace_bytes returns 0 for every shape and the *_ws calls ignore `workspace`; they are exactly pcm_attn_fwd / pcm_attn_bwd. */
 size_t pcm_attn_workspace_bytes(int B, int H, int Lq, int Lk, int d, int backward);
 int pcm_attn_fwd_ws(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int Lq, int Lk, int d, int ldq,
                     int ldk, int ldo, float scale, void* workspace, size_t workspace_bytes, void* stream);

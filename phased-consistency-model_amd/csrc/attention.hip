@@ -6,8 +6,9 @@
 //   lane holds 16+16 scores of ONE query row: row max/sum need a single cross-half shuffle.
 //   P^T feeds the second MFMA (O^T = V^T P^T) straight from the accumulator registers: the MFMA
 //   contraction slot (hi, e) of step ss is DEFINED as key 16ss + 8(e>>2) + 4hi + (e&3) — exactly
-//   what the lane already holds — and the V tile is staged transposed into LDS in that same key
-//   order (8x8 register transposes), so no permlane / LDS round trip for P.
+//   what the lane already holds — and the V^T operand is read in that same key order out of the
+//   ROW-MAJOR V tile by LDS transpose reads (ds_read_b64_tr_b16: 4 consecutive keys of one column
+//   per read), so no permlane / LDS round trip for P and no transposed copy of V anywhere.
 // dK/dV kernel: a workgroup owns 128 key rows and streams 64-query tiles with the roles swapped
 //   (S = Q K^T, lane = one key), the same slot trick on the query index.
 // head_dim 40 is padded to 48 for QK^T (K-step 16) and to 64 for the PV tile (32-row output tiles);
@@ -15,6 +16,19 @@
 #include "pcm_common.h"
 
 #define LOG2E 1.4426950408889634f
+// timing ablations of the forward kernel (tools/attn_ablate.py, -DPCM_ABLATE builds only; results are wrong by construction):
+// 1 = no exp (p = scaled score), 2 = no global loads / LDS restage inside the loop, 4 = no PV MFMAs, 8 = no QK^T MFMAs, 16 = no barriers
+#ifdef PCM_ABLATE
+static int g_attn_ablate = 0;
+extern "C" void pcm_debug_attn_ablate(int m) { g_attn_ablate = m; }
+#define ATTN_DBG_PARAM , int dbg
+#define ATTN_DBG_ARG , g_attn_ablate
+#define ATTN_ABL(bit) (dbg & (bit))
+#else
+#define ATTN_DBG_PARAM
+#define ATTN_DBG_ARG
+#define ATTN_ABL(bit) 0
+#endif
 
 template <int D>
 struct AttnCfg {
@@ -25,9 +39,10 @@ struct AttnCfg {
   static constexpr int DG = D / 8;               // 8-wide column groups
 };
 
-// row-major tile image: [rows][RKU*16 B]; chunk c of row r at (r*RKU + c)*16
-// transposed tile image: [d rows][64 slots] bf16 = 8 chunks of 16 B, XOR-swizzled
-__device__ __forceinline__ int tr_off(int drow, int chunk) { return drow * 128 + ((chunk ^ ((drow >> 1) & 7)) << 4); }
+// row-major tile image: [rows][RKU*16 B]; chunk c of row r at (r*RKU + c)*16.  Both MFMA operand orientations come out of it:
+//   * k along the columns (S^T = K Q^T): one ds_read_b128 per fragment;
+//   * k along the ROWS (O^T = V^T P^T, dQ^T = K^T dS^T, dV^T = dO^T P, dK^T = Q^T dS): two ds_read_b64_tr_b16 per fragment
+//     (tr_frag below) -- no transposed copy of the tile in LDS, no transposing stage, no packed-operand pre-pass.
 
 // load a [rows x D] row-major tile (row stride ld elements) into the padded row-major LDS image
 template <int D, int ROWS>
@@ -40,34 +55,33 @@ __device__ __forceinline__ void load_rowmajor(char* dst, const bf16_t* src, int 
     *(uint4*)(dst + (r * C::RKU + c) * 16) = v;
   }
 }
+// pad chunks (columns D .. 16*DK16-1 of every row; the spare chunk of the odd row stride too): zero, or with ``ones`` a 1.0 in column D
+// (the tile then carries a ones COLUMN, i.e. a ones row of its transpose: see the forward kernel)
 template <int D, int ROWS>
-__device__ __forceinline__ void zero_pad_chunks(char* dst, int tid) {
+__device__ __forceinline__ void fill_pad_chunks(char* dst, int tid, bool ones) {
   using C = AttnCfg<D>;
-  constexpr int NP = C::KCH - C::DG;
-  if (NP > 0)
-    for (int u = tid; u < ROWS * NP; u += 256) {
-      int r = u / NP, c = C::DG + (u - r * NP);
-      *(uint4*)(dst + (r * C::RKU + c) * 16) = make_uint4(0u, 0u, 0u, 0u);
-    }
-}
-// load a [64 x D] tile TRANSPOSED into the [d][64-slot] image; slot (ss, hi, e) <-> row 16ss+8(e>>2)+4hi+(e&3)
-template <int D>
-__device__ __forceinline__ void load_transposed64(char* dst, const bf16_t* src, int ld, int row0, int nrows_valid, int tid) {
-  using C = AttnCfg<D>;
-  if (tid < 8 * C::DG) {
-    int sh = tid & 7, dg = tid >> 3;  // sh = 2*ss + hi
-    int ss = sh >> 1, hi = sh & 1;
-    uint4 rr[8], oo[8];
-#pragma unroll
-    for (int e = 0; e < 8; e++) {
-      int r = row0 + 16 * ss + 8 * (e >> 2) + 4 * hi + (e & 3);
-      rr[e] = r < nrows_valid ? *(const uint4*)(src + (size_t)r * ld + 8 * dg) : make_uint4(0u, 0u, 0u, 0u);
-    }
-    transpose8x8_bf16(rr, oo);
-#pragma unroll
-    for (int dd = 0; dd < 8; dd++) *(uint4*)(dst + tr_off(8 * dg + dd, sh)) = oo[dd];
+  constexpr int NP = C::RKU - C::DG;
+  for (int u = tid; u < ROWS * NP; u += 256) {
+    int r = u / NP, c = C::DG + (u - r * NP);
+    *(uint4*)(dst + (r * C::RKU + c) * 16) = make_uint4((ones && c == C::DG) ? 0x00003f80u : 0u, 0u, 0u, 0u);
   }
 }
+// fragment with the contraction index along the tile ROWS: A[i = column 32*it + (lane&31)][k], k-slot (hi, e) of step ss = tile row
+// 16ss + 8(e>>2) + 4hi + (e&3).  Per 16-lane group g = lane>>4 (columns 32it + 16(g&1) .., hi = g>>1) source lane 4j+q addresses the quad
+// (row 16ss + 4hi + j, columns +4q..+3) and receives its own column's 4 rows (pcm_common.h PCM_DS_READ_TR16); rows +8 give e = 4..7.
+template <int D>
+struct TrFrag {
+  using C = AttnCfg<D>;
+  int base;
+  __device__ __forceinline__ TrFrag(int lane) {
+    const int s = lane & 15, j = s >> 2, q = s & 3, g = lane >> 4;
+    base = (4 * (g >> 1) + j) * (C::RKU * 16) + (16 * (g & 1) + 4 * q) * 2;
+  }
+  __device__ __forceinline__ bf16x8 get(const char* tile, int it, int ss) const {
+    const char* p = tile + base + 16 * ss * (C::RKU * 16) + 64 * it;
+    return pcm_join4(PCM_DS_READ_TR16(p), PCM_DS_READ_TR16(p + 8 * (C::RKU * 16)));
+  }
+};
 // ---- register staging (issue the NEXT tile's global loads before computing on the current tile;
 // the LDS write happens after the next barrier, so L2/HBM latency hides under the MFMA phase) ----
 // Loads are UNCONDITIONAL from clamped addresses (a predicated load + zero select makes hipcc wait
@@ -106,130 +120,10 @@ struct RowStage {
     }
   }
 };
-// transposing stage in 4x4 blocks: a unit = 4 consecutive rows x 4 columns (4 x 8-B loads, 8 VGPRs),
-// transposed in registers and written as 4 x ds_write_b64.  Row group rg = rows 4rg..4rg+3 maps to
-// slot chunk 2*ss+hi with ss = rg>>2, hi = rg&1 and element half (rg>>1)&1 (same slot order as above).
-template <int D>
-struct TransStage {
-  using C = AttnCfg<D>;
-  static constexpr int DQ = D / 4;
-  static constexpr int N = (16 * DQ + 255) / 256;
-  uint2 rr[N][4];
-  int row0_;
-  __device__ __forceinline__ void load(const bf16_t* src, int ld, int row0, int nrows_valid, int tid) {
-    row0_ = row0;
-#pragma unroll
-    for (int i = 0; i < N; i++) {
-      int u = tid + 256 * i;
-      if (u >= 16 * DQ) u = 16 * DQ - 1;
-      int dq = u % DQ, rg = u / DQ;
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        int r = row0 + 4 * rg + j;
-        if (r >= nrows_valid) r = nrows_valid - 1;
-        rr[i][j] = *(const uint2*)(src + (size_t)r * ld + 4 * dq);
-      }
-    }
-  }
-  __device__ __forceinline__ void store(char* dst, int nrows_valid, int tid) const {
-    const bool full = row0_ + 64 <= nrows_valid;
-#pragma unroll
-    for (int i = 0; i < N; i++) {
-      int u = tid + 256 * i;
-      if (u < 16 * DQ) {
-        int dq = u % DQ, rg = u / DQ;
-        int chunk = 2 * (rg >> 2) + (rg & 1), half = (rg >> 1) & 1;
-        unsigned a[4], b[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-          bool ok = full || row0_ + 4 * rg + j < nrows_valid;
-          a[j] = ok ? rr[i][j].x : 0u; b[j] = ok ? rr[i][j].y : 0u;
-        }
-        uint2 o[4];
-        o[0] = make_uint2((a[0] & 0xffffu) | (a[1] << 16), (a[2] & 0xffffu) | (a[3] << 16));
-        o[1] = make_uint2((a[0] >> 16) | (a[1] & 0xffff0000u), (a[2] >> 16) | (a[3] & 0xffff0000u));
-        o[2] = make_uint2((b[0] & 0xffffu) | (b[1] << 16), (b[2] & 0xffffu) | (b[3] << 16));
-        o[3] = make_uint2((b[0] >> 16) | (b[1] & 0xffff0000u), (b[2] >> 16) | (b[3] & 0xffff0000u));
-#pragma unroll
-        for (int c = 0; c < 4; c++) *(uint2*)(dst + tr_off(4 * dq + c, chunk) + 8 * half) = o[c];
-      }
-    }
-  }
-};
 template <int D> struct AttnPrefetch { static constexpr bool value = D <= 80; };
-
-// A workgroup re-stages every 64-row tile of the streamed operand, so the 4x4 register transposes of TransStage are repeated by
-// all L/128 workgroups of a (batch, head).  With a PACKED operand (pcm_attn_pack_t: the [d][64-slot] tile images written once to
-// HBM, tile-major, tail rows zeroed) the stage is a straight 16-B copy into the swizzled LDS image.
-template <int D>
-struct PackedTStage {
-  typedef unsigned pk_u32x4 __attribute__((ext_vector_type(4)));
-  static constexpr int NCH = D * 8;                 // 16-B chunks of one tile image (D rows x 128 B)
-  static constexpr int N = (NCH + 255) / 256;
-  pk_u32x4 r[N];
-  __device__ __forceinline__ void load(const bf16_t* packed_bh, int row0, int tid) {
-    const pk_u32x4* t = (const pk_u32x4*)(packed_bh + (size_t)(row0 >> 6) * D * 64);
-#pragma unroll
-    for (int i = 0; i < N; i++) {
-      int u = tid + 256 * i;
-      u = u < NCH ? u : NCH - 1;
-      r[i] = t[u];
-    }
-  }
-  __device__ __forceinline__ void store(char* dst, int tid) const {
-#pragma unroll
-    for (int i = 0; i < N; i++) {
-      const int u = tid + 256 * i;
-      if (u < NCH) *(pk_u32x4*)(dst + tr_off(u >> 3, u & 7)) = r[i];
-    }
-  }
-};
-// one interface for both: PK selects the packed copy, otherwise the transposing register stage (separate types: a struct holding
-// both stages is not promoted to registers by hipcc and the prefetched tile ends up in scratch)
-template <int D>
-struct TransStageA : TransStage<D> {
-  __device__ __forceinline__ void load(const bf16_t* src, int ld, const bf16_t*, int row0, int nrows_valid, int tid) { TransStage<D>::load(src, ld, row0, nrows_valid, tid); }
-};
-template <int D>
-struct PackedTStageA : PackedTStage<D> {
-  __device__ __forceinline__ void load(const bf16_t*, int, const bf16_t* packed_bh, int row0, int, int tid) { PackedTStage<D>::load(packed_bh, row0, tid); }
-  __device__ __forceinline__ void store(char* dst, int, int tid) const { PackedTStage<D>::store(dst, tid); }
-};
-template <int D, bool PK> struct TStageSel { using type = TransStageA<D>; };
-template <int D> struct TStageSel<D, true> { using type = PackedTStageA<D>; };
-template <int D, bool PK> using TStage = typename TStageSel<D, PK>::type;
-
-// x [B][L][ld] (head h at columns h*D..) -> packed transposed tiles xt[(b*H+h)][tile][D][64 slots]; slot 8*chunk+e of a tile is row
-// 16*(chunk>>1) + 8*(e>>2) + 4*(chunk&1) + (e&3) (the contraction-slot order of the PV / dS MFMAs); rows >= L are zero.
-__global__ __launch_bounds__(256) void attn_pack_t_kernel(const bf16_t* x, bf16_t* xt, int H, int L, int D, int ld, int HG) {
-  // one block = one 64-row tile of a GROUP of HG heads (blockIdx.z; the group is sized by the launcher so that the LDS image stays under
-  // 64 KB for any H*D): coalesced 16-B row loads into LDS, transposed 2-byte reads out of LDS, 16-B tile-image stores
-  PCM_DYN_SMEM(sm);
-  const int tile = blockIdx.x, b = blockIdx.y, nt = gridDim.x, h0 = blockIdx.z * HG;
-  const int nh = (H - h0 < HG ? H - h0 : HG), HD = nh * D, CV = HD / 8, RS = HG * D + 8;   // RS: padded LDS row (elements)
-  bf16_t* t = (bf16_t*)sm;
-  const bf16_t* xb = x + (size_t)b * L * ld + h0 * D;
-  for (int u = threadIdx.x; u < 64 * CV; u += blockDim.x) {
-    const int r = u / CV, c = u - r * CV, row = 64 * tile + r;
-    uint4 v = make_uint4(0u, 0u, 0u, 0u);
-    if (row < L) v = *(const uint4*)(xb + (size_t)row * ld + 8 * c);
-    *(uint4*)(t + r * RS + 8 * c) = v;
-  }
-  __syncthreads();
-  for (int u = threadIdx.x; u < HD * 8; u += blockDim.x) {
-    const int col = u % HD, chunk = u / HD;                 // lanes along the columns: conflict-free 2-byte LDS reads
-    const int hl = col / D, drow = col - hl * D;
-    unsigned w[4] = {0u, 0u, 0u, 0u};
-#pragma unroll
-    for (int e = 0; e < 8; e++) {
-      const int r = 16 * (chunk >> 1) + 8 * (e >> 2) + 4 * (chunk & 1) + (e & 3);
-      w[e >> 1] |= (unsigned)t[r * RS + col] << (16 * (e & 1));
-    }
-    uint4* out = (uint4*)(xt + ((size_t)(b * H + h0 + hl) * nt + tile) * D * 64);
-    out[drow * 8 + chunk] = make_uint4(w[0], w[1], w[2], w[3]);
-  }
-}
-
+// LDS bytes of one row-major tile; the k-along-rows reads of the last 32-column group run up to 32*DV columns wide, i.e. past the end
+// of short rows into the next row (finite data feeding accumulator rows >= D that are never stored) -- 64 B of slack behind the last row
+template <int D> struct TileBytes { static constexpr int value = 64 * AttnCfg<D>::RKU * 16 + 64; };
 
 // fragment straight from global: row-major [row][16s + 8hi ..]; zero outside [0, D) / invalid rows
 template <int D>
@@ -247,12 +141,12 @@ __device__ __forceinline__ bf16x8 pack_frag(const f32x16& p, int half) {
 }
 
 // ============================================================================ forward
-template <int D, bool PK>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* q, const bf16_t* k, const bf16_t* v, const bf16_t* vt, bf16_t* o,
-                                                       float* lse, int H, int Lq, int Lk, int ldq, int ldk, int ldo, float scale) {
+template <int D>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t* o,
+                                                       float* lse, int H, int Lq, int Lk, int ldq, int ldk, int ldo, float scale ATTN_DBG_PARAM) {
   using C = AttnCfg<D>;
-  __shared__ __attribute__((aligned(16))) char Ks[64 * C::RKU * 16];
-  __shared__ __attribute__((aligned(16))) char Vt[C::DV * 32 * 128];
+  __shared__ __attribute__((aligned(16))) char Ks[TileBytes<D>::value];
+  __shared__ __attribute__((aligned(16))) char Vs[TileBytes<D>::value];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 128 + wave * 32;
   const bf16_t* qb = q + (size_t)b * Lq * ldq + h * D;
@@ -268,25 +162,24 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* q, const bf
     for (int r = 0; r < 16; r++) acc_o[i][r] = 0.f;
   float m_run = -1e30f, l_run = 0.f;
   const float sc = scale * LOG2E;
-  zero_pad_chunks<D, 64>(Ks, tid);
-  // head dims whose transposed V image has a spare padded row (40 -> 64, 80 -> 96): row D is set to ones, so the PV MFMA
-  // also produces the softmax denominator sum_k p[k] in accumulator row D (rescaled with O for free, no VALU row sums)
-  constexpr bool ONES = C::DV * 32 > D;
-  if (ONES && tid < 8) *(uint4*)(Vt + tr_off(D, tid)) = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
-  RowStage<D, 64> kst;
-  TStage<D, PK> vst;
-  const bf16_t* vtb = PK ? vt + (size_t)(b * H + h) * ((Lk + 63) >> 6) * D * 64 : nullptr;
-  if (AttnPrefetch<D>::value) { kst.load(kb, ldk, 0, Lk, tid); vst.load(vb, ldk, vtb, 0, Lk, tid); }
+  // head dims with a padded column (40 -> 48, 80 -> 96): column D of the V tile is set to ones, so the PV MFMA (V^T P^T) also
+  // produces the softmax denominator sum_k p[k] in accumulator row D (rescaled with O for free, no VALU row sums)
+  constexpr bool ONES = C::DV * 32 > D && C::RKU > C::DG;
+  fill_pad_chunks<D, 64>(Ks, tid, false);
+  fill_pad_chunks<D, 64>(Vs, tid, ONES);
+  const TrFrag<D> trf(lane);
+  RowStage<D, 64> kst, vst;
+  if (AttnPrefetch<D>::value) { kst.load(kb, ldk, 0, Lk, tid); vst.load(vb, ldk, 0, Lk, tid); }
   for (int kv0 = 0; kv0 < Lk; kv0 += 64) {
-    __syncthreads();
+    if (!ATTN_ABL(16)) __syncthreads();
     if (AttnPrefetch<D>::value) {
-      kst.store(Ks, Lk, tid); vst.store(Vt, Lk, tid);
+      if (!ATTN_ABL(2) || kv0 == 0) { kst.store(Ks, Lk, tid); vst.store(Vs, Lk, tid); }
     } else {
       load_rowmajor<D, 64>(Ks, kb, ldk, kv0, Lk, tid);
-      load_transposed64<D>(Vt, vb, ldk, kv0, Lk, tid);
+      load_rowmajor<D, 64>(Vs, vb, ldk, kv0, Lk, tid);
     }
-    __syncthreads();
-    if (AttnPrefetch<D>::value && kv0 + 64 < Lk) { kst.load(kb, ldk, kv0 + 64, Lk, tid); vst.load(vb, ldk, vtb, kv0 + 64, Lk, tid); }
+    if (!ATTN_ABL(16)) __syncthreads();
+    if (AttnPrefetch<D>::value && kv0 + 64 < Lk && !ATTN_ABL(2)) { kst.load(kb, ldk, kv0 + 64, Lk, tid); vst.load(vb, ldk, kv0 + 64, Lk, tid); }
     f32x16 s_[2];
 #pragma unroll
     for (int t = 0; t < 2; t++) {
@@ -295,6 +188,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* q, const bf
 #pragma unroll
       for (int s = 0; s < C::DK16; s++) {
         bf16x8 kf = *(const bf16x8*)(Ks + ((32 * t + l31) * C::RKU + 2 * s + hi) * 16);
+        if (ATTN_ABL(8)) { s_[t][s] += (float)kf[0]; continue; }
         s_[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], s_[t], 0, 0, 0);
       }
     }
@@ -321,7 +215,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* q, const bf
     for (int t = 0; t < 2; t++)
 #pragma unroll
       for (int r = 0; r < 16; r++) {
-        float p = PCM_EXP2F(fmaf(s_[t][r], sc, -m_new));
+        float p = ATTN_ABL(1) ? fmaf(s_[t][r], sc, -m_new) : PCM_EXP2F(fmaf(s_[t][r], sc, -m_new));
         s_[t][r] = p;
         if (!ONES) psum += p;
       }
@@ -343,7 +237,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* q, const bf
     for (int i = 0; i < C::DV; i++)
 #pragma unroll
       for (int ss = 0; ss < 4; ss++) {
-        bf16x8 vf = *(const bf16x8*)(Vt + tr_off(32 * i + l31, 2 * ss + hi));
+        bf16x8 vf = trf.get(Vs, i, ss);
+        if (ATTN_ABL(4)) { acc_o[i][ss] += (float)vf[0] + (float)pf[ss][0]; continue; }
         acc_o[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[ss], acc_o[i], 0, 0, 0);
       }
   }
@@ -395,14 +290,13 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* o, const 
 }
 
 // ============================================================================ backward: dQ
-template <int D, bool PK>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* q, const bf16_t* k, const bf16_t* v, const bf16_t* dO, const bf16_t* kt,
+template <int D>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* q, const bf16_t* k, const bf16_t* v, const bf16_t* dO,
                                                           const float* lse, const float* delta, bf16_t* dq, int H, int Lq,
                                                           int Lk, int ldq, int ldk, int ldo, float scale) {
   using C = AttnCfg<D>;
-  __shared__ __attribute__((aligned(16))) char Ks[64 * C::RKU * 16];
-  __shared__ __attribute__((aligned(16))) char Vs[64 * C::RKU * 16];
-  __shared__ __attribute__((aligned(16))) char Kt[C::DV * 32 * 128];
+  __shared__ __attribute__((aligned(16))) char Ks[TileBytes<D>::value];
+  __shared__ __attribute__((aligned(16))) char Vs[TileBytes<D>::value];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 128 + wave * 32;
   const bf16_t* qb = q + (size_t)b * Lq * ldq + h * D;
@@ -424,24 +318,22 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* q, const
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[i][r] = 0.f;
   const float sc = scale * LOG2E;
-  zero_pad_chunks<D, 64>(Ks, tid);
-  zero_pad_chunks<D, 64>(Vs, tid);
+  fill_pad_chunks<D, 64>(Ks, tid, false);
+  fill_pad_chunks<D, 64>(Vs, tid, false);
+  const TrFrag<D> trf(lane);
   RowStage<D, 64> kst, vst;
-  TStage<D, PK> ktst;
-  const bf16_t* ktb = PK ? kt + (size_t)(b * H + h) * ((Lk + 63) >> 6) * D * 64 : nullptr;
-  if (AttnPrefetch<D>::value) { kst.load(kb, ldk, 0, Lk, tid); vst.load(vb, ldk, 0, Lk, tid); ktst.load(kb, ldk, ktb, 0, Lk, tid); }
+  if (AttnPrefetch<D>::value) { kst.load(kb, ldk, 0, Lk, tid); vst.load(vb, ldk, 0, Lk, tid); }
   for (int kv0 = 0; kv0 < Lk; kv0 += 64) {
     __syncthreads();
     if (AttnPrefetch<D>::value) {
-      kst.store(Ks, Lk, tid); vst.store(Vs, Lk, tid); ktst.store(Kt, Lk, tid);
+      kst.store(Ks, Lk, tid); vst.store(Vs, Lk, tid);
     } else {
       load_rowmajor<D, 64>(Ks, kb, ldk, kv0, Lk, tid);
       load_rowmajor<D, 64>(Vs, vb, ldk, kv0, Lk, tid);
-      load_transposed64<D>(Kt, kb, ldk, kv0, Lk, tid);
     }
     __syncthreads();
     if (AttnPrefetch<D>::value && kv0 + 64 < Lk) {
-      kst.load(kb, ldk, kv0 + 64, Lk, tid); vst.load(vb, ldk, kv0 + 64, Lk, tid); ktst.load(kb, ldk, ktb, kv0 + 64, Lk, tid);
+      kst.load(kb, ldk, kv0 + 64, Lk, tid); vst.load(vb, ldk, kv0 + 64, Lk, tid);
     }
     f32x16 s_[2], dp[2];
 #pragma unroll
@@ -480,7 +372,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* q, const
     for (int i = 0; i < C::DV; i++)
 #pragma unroll
       for (int ss = 0; ss < 4; ss++) {
-        bf16x8 ktf = *(const bf16x8*)(Kt + tr_off(32 * i + l31, 2 * ss + hi));
+        bf16x8 ktf = trf.get(Ks, i, ss);
         acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf, df[ss], acc[i], 0, 0, 0);
       }
   }
@@ -498,15 +390,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* q, const
 }
 
 // ============================================================================ backward: dK, dV
-template <int D, bool PK>
-__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16_t* q, const bf16_t* k, const bf16_t* v, const bf16_t* dO, const bf16_t* qt,
-                                                            const bf16_t* ot, const float* lse, const float* delta, bf16_t* dk, bf16_t* dv, int H,
+template <int D>
+__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16_t* q, const bf16_t* k, const bf16_t* v, const bf16_t* dO,
+                                                            const float* lse, const float* delta, bf16_t* dk, bf16_t* dv, int H,
                                                             int Lq, int Lk, int ldq, int ldk, int ldo, float scale) {
   using C = AttnCfg<D>;
-  __shared__ __attribute__((aligned(16))) char Qs[64 * C::RKU * 16];
-  __shared__ __attribute__((aligned(16))) char Os[64 * C::RKU * 16];
-  __shared__ __attribute__((aligned(16))) char Qt[C::DV * 32 * 128];
-  __shared__ __attribute__((aligned(16))) char Ot[C::DV * 32 * 128];
+  __shared__ __attribute__((aligned(16))) char Qs[TileBytes<D>::value];
+  __shared__ __attribute__((aligned(16))) char Os[TileBytes<D>::value];
   __shared__ float L2s[64], dls[64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y, kv0 = blockIdx.x * 128 + wave * 32;
@@ -528,16 +418,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16_t* q, con
   const float sc = scale * LOG2E;
   const bool kv_ok = (kv0 + l31) < Lk;
   const bool blk_full = ((int)blockIdx.x * 128 + 128) <= Lk;
-  zero_pad_chunks<D, 64>(Qs, tid);
-  zero_pad_chunks<D, 64>(Os, tid);
+  fill_pad_chunks<D, 64>(Qs, tid, false);
+  fill_pad_chunks<D, 64>(Os, tid, false);
+  const TrFrag<D> trf(lane);
   RowStage<D, 64> qst, ost;
-  TStage<D, PK> qtst, otst;
-  const bf16_t* qtb = PK ? qt + (size_t)(b * H + h) * ((Lq + 63) >> 6) * D * 64 : nullptr;
-  const bf16_t* otb = PK ? ot + (size_t)(b * H + h) * ((Lq + 63) >> 6) * D * 64 : nullptr;
   float l2r = 0.f, dlr = 0.f;
   auto stage_load = [&](int q0_) {
     qst.load(qb, ldq, q0_, Lq, tid); ost.load(dob, ldo, q0_, Lq, tid);
-    qtst.load(qb, ldq, qtb, q0_, Lq, tid); otst.load(dob, ldo, otb, q0_, Lq, tid);
     {
       int qr = q0_ + (tid & 63);
       if (qr >= Lq) qr = Lq - 1;
@@ -549,13 +436,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16_t* q, con
   for (int qq0 = 0; qq0 < Lq; qq0 += 64) {
     __syncthreads();
     if (AttnPrefetch<D>::value) {
-      qst.store(Qs, Lq, tid); ost.store(Os, Lq, tid); qtst.store(Qt, Lq, tid); otst.store(Ot, Lq, tid);
+      qst.store(Qs, Lq, tid); ost.store(Os, Lq, tid);
       if (tid < 64) { L2s[tid] = l2r; dls[tid] = dlr; }
     } else {
       load_rowmajor<D, 64>(Qs, qb, ldq, qq0, Lq, tid);
       load_rowmajor<D, 64>(Os, dob, ldo, qq0, Lq, tid);
-      load_transposed64<D>(Qt, qb, ldq, qq0, Lq, tid);
-      load_transposed64<D>(Ot, dob, ldo, qq0, Lq, tid);
       if (tid < 64) {
         int qr = qq0 + tid;
         L2s[tid] = qr < Lq ? lse[((size_t)b * H + h) * Lq + qr] : 0.f;
@@ -603,8 +488,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16_t* q, con
     for (int i = 0; i < C::DV; i++)
 #pragma unroll
       for (int ss = 0; ss < 4; ss++) {
-        bf16x8 otf = *(const bf16x8*)(Ot + tr_off(32 * i + l31, 2 * ss + hi));
-        bf16x8 qtf = *(const bf16x8*)(Qt + tr_off(32 * i + l31, 2 * ss + hi));
+        bf16x8 otf = trf.get(Os, i, ss);
+        bf16x8 qtf = trf.get(Qs, i, ss);
         acc_v[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(otf, pf[ss], acc_v[i], 0, 0, 0);  // dV^T[d][kv]
         acc_k[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf, df[ss], acc_k[i], 0, 0, 0);  // dK^T[d][kv]
       }
@@ -643,45 +528,21 @@ static int attn_check(const char* what, const void* q, const void* k, const void
     default: { CALL(160); } break;      \
   }
 
-// Workspace for the packed transposed operands (pcm_attn_pack_t images): the forward needs V^T, the backward K^T, Q^T and dO^T.
-// 0 when the packed path is not used (short sequences: the one-off packing pass does not pay; head dims without register staging).
-static int g_attn_pack_min = 1024;
-extern "C" void pcm_debug_attn_pack_min_len(int n) { g_attn_pack_min = n; }   // tests only: exercise the packed path on short sequences
-static bool attn_use_packed(int Lq, int Lk, int d) { return d <= 80 && Lq >= g_attn_pack_min && Lk >= g_attn_pack_min; }
-static size_t attn_packed_bytes(int B, int H, int L, int d) { return (size_t)B * H * ((L + 63) / 64) * d * 128; }
-extern "C" size_t pcm_attn_workspace_bytes(int B, int H, int Lq, int Lk, int d, int backward) {
-  if (!attn_use_packed(Lq, Lk, d)) return 0;
-  return backward ? attn_packed_bytes(B, H, Lk, d) + 2 * attn_packed_bytes(B, H, Lq, d) : attn_packed_bytes(B, H, Lk, d);
-}
-// heads per pack block: the LDS image of a block is 64 rows x (HG*d + 8) bf16; HG*d <= 504 keeps it at <= 64 KB (no opt-in attribute,
-// two blocks per CU) for every head count -- SDXL level 2 (20 x 64) and SD3 (24 x 64) run as 3 / 4 head groups
-static int attn_pack_heads_per_block(int H, int d) { int hg = 504 / d; return hg < 1 ? 1 : (hg > H ? H : hg); }
-static int attn_pack_launch(const void* x, void* xt, int B, int H, int L, int d, int ld, void* stream) {
-  const int HG = attn_pack_heads_per_block(H, d);
-  const size_t smem = 64 * (size_t)(HG * d + 8) * 2;
-  PCM_CHECK(smem <= 64 * 1024 && (d % 8) == 0, PCM_EUNSUPPORTED, "pcm_attn: packed operand path: head_dim %d needs %zu B of LDS per tile", d, smem);
-  PCM_CHECK(B <= 65535 && (H + HG - 1) / HG <= 65535, PCM_EUNSUPPORTED, "pcm_attn: batch %d exceeds the grid limit", B);
-  PCM_LAUNCH(attn_pack_t_kernel, dim3((L + 63) / 64, B, (H + HG - 1) / HG), dim3(256), smem, stream, (const bf16_t*)x, (bf16_t*)xt, H, L, d, ld, HG);
-  return PCM_OK;
-}
+// The packed-operand pre-pass of round 1 is gone (the k-along-rows operands are LDS transpose reads of the row-major tiles), so no call
+// needs a workspace any more; the *_ws entry points and the size query stay in the ABI and accept / report an unused workspace.
+extern "C" void pcm_debug_attn_pack_min_len(int) {}
+extern "C" size_t pcm_attn_workspace_bytes(int, int, int, int, int, int) { return 0; }
 
 extern "C" int pcm_attn_fwd_ws(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int Lq, int Lk,
                                int d, int ldq, int ldk, int ldo, float scale, void* workspace, size_t workspace_bytes, void* stream) {
+  (void)workspace; (void)workspace_bytes;
   if (int rc = attn_check("pcm_attn_fwd", q, k, v, B, H, Lq, Lk, d, ldq, ldk, ldo)) return rc;
   PCM_CHECK(o && PCM_ALIGNED16(o), PCM_EALIGN, "pcm_attn_fwd: o");
+  PCM_CHECK(B <= 65535 && H <= 65535, PCM_EUNSUPPORTED, "pcm_attn_fwd: batch / head count beyond the grid limit");
   dim3 grid((Lq + 127) / 128, H, B), block(256);
-  const bool pk = workspace && attn_use_packed(Lq, Lk, d);
-  if (pk) {
-    PCM_CHECK(PCM_ALIGNED16(workspace) && workspace_bytes >= pcm_attn_workspace_bytes(B, H, Lq, Lk, d, 0), PCM_EINVAL, "pcm_attn_fwd_ws: workspace");
-    if (int rc = attn_pack_launch(v, workspace, B, H, Lk, d, ldk, stream)) return rc;
-  }
-#define FWD_CALL(DD)                                                                                                               \
-  if (pk && AttnPrefetch<DD>::value)                                                                                               \
-    PCM_LAUNCH((attn_fwd_kernel<DD, true>), grid, block, 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,          \
-               (const bf16_t*)workspace, (bf16_t*)o, lse, H, Lq, Lk, ldq, ldk, ldo, scale);                                         \
-  else                                                                                                                             \
-    PCM_LAUNCH((attn_fwd_kernel<DD, false>), grid, block, 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,         \
-               (const bf16_t*)nullptr, (bf16_t*)o, lse, H, Lq, Lk, ldq, ldk, ldo, scale)
+#define FWD_CALL(DD)                                                                                                        \
+  PCM_LAUNCH((attn_fwd_kernel<DD>), grid, block, 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse, \
+             H, Lq, Lk, ldq, ldk, ldo, scale ATTN_DBG_ARG)
   ATTN_DISPATCH(d, FWD_CALL)
   return pcm_post_launch("pcm_attn_fwd");
 }
@@ -693,42 +554,23 @@ extern "C" int pcm_attn_fwd(const void* q, const void* k, const void* v, void* o
 extern "C" int pcm_attn_bwd_ws(const void* q, const void* k, const void* v, const void* o, const void* dO, const float* lse,
                                float* delta, void* dq, void* dk, void* dv, int B, int H, int Lq, int Lk, int d, int ldq, int ldk,
                                int ldo, float scale, void* workspace, size_t workspace_bytes, void* stream) {
+  (void)workspace; (void)workspace_bytes;
   if (int rc = attn_check("pcm_attn_bwd", q, k, v, B, H, Lq, Lk, d, ldq, ldk, ldo)) return rc;
   PCM_CHECK(o && dO && lse && delta && PCM_ALIGNED16(o) && PCM_ALIGNED16(dO), PCM_EALIGN, "pcm_attn_bwd: o/dO/lse/delta");
+  PCM_CHECK(B <= 65535 && H <= 65535, PCM_EUNSUPPORTED, "pcm_attn_bwd: batch / head count beyond the grid limit");
   PCM_LAUNCH(attn_delta_kernel, dim3((Lq * H + 255) / 256, B), dim3(256), 0, stream, (const bf16_t*)o, (const bf16_t*)dO, delta, H, Lq, d, ldo);
-  const bool pk = workspace && attn_use_packed(Lq, Lk, d);
-  const bf16_t *kt = nullptr, *qt = nullptr, *ot = nullptr;
-  if (pk) {
-    PCM_CHECK(PCM_ALIGNED16(workspace) && workspace_bytes >= pcm_attn_workspace_bytes(B, H, Lq, Lk, d, 1), PCM_EINVAL, "pcm_attn_bwd_ws: workspace");
-    char* w = (char*)workspace;
-    kt = (const bf16_t*)w; qt = (const bf16_t*)(w + attn_packed_bytes(B, H, Lk, d)); ot = (const bf16_t*)(w + attn_packed_bytes(B, H, Lk, d) + attn_packed_bytes(B, H, Lq, d));
-    if (dq) { if (int rc = attn_pack_launch(k, (void*)kt, B, H, Lk, d, ldk, stream)) return rc; }
-    if (dk && dv) {
-      if (int rc = attn_pack_launch(q, (void*)qt, B, H, Lq, d, ldq, stream)) return rc;
-      if (int rc = attn_pack_launch(dO, (void*)ot, B, H, Lq, d, ldo, stream)) return rc;
-    }
-  }
   if (dq) {
     dim3 grid((Lq + 127) / 128, H, B), block(256);
-#define DQ_CALL(DD)                                                                                                                  \
-  if (pk && AttnPrefetch<DD>::value)                                                                                                 \
-    PCM_LAUNCH((attn_bwd_dq_kernel<DD, true>), grid, block, 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,         \
-               (const bf16_t*)dO, kt, lse, delta, (bf16_t*)dq, H, Lq, Lk, ldq, ldk, ldo, scale);                                      \
-  else                                                                                                                               \
-    PCM_LAUNCH((attn_bwd_dq_kernel<DD, false>), grid, block, 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,        \
-               (const bf16_t*)dO, (const bf16_t*)nullptr, lse, delta, (bf16_t*)dq, H, Lq, Lk, ldq, ldk, ldo, scale)
+#define DQ_CALL(DD)                                                                                                          \
+  PCM_LAUNCH((attn_bwd_dq_kernel<DD>), grid, block, 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)dO, \
+             lse, delta, (bf16_t*)dq, H, Lq, Lk, ldq, ldk, ldo, scale)
     ATTN_DISPATCH(d, DQ_CALL)
   }
   if (dk && dv) {
     dim3 grid((Lk + 127) / 128, H, B), block(256);
-#define DKV_CALL(DD)                                                                                                                 \
-  if (pk && AttnPrefetch<DD>::value)                                                                                                 \
-    PCM_LAUNCH((attn_bwd_dkdv_kernel<DD, true>), grid, block, 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,       \
-               (const bf16_t*)dO, qt, ot, lse, delta, (bf16_t*)dk, (bf16_t*)dv, H, Lq, Lk, ldq, ldk, ldo, scale);                     \
-  else                                                                                                                               \
-    PCM_LAUNCH((attn_bwd_dkdv_kernel<DD, false>), grid, block, 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,      \
-               (const bf16_t*)dO, (const bf16_t*)nullptr, (const bf16_t*)nullptr, lse, delta, (bf16_t*)dk, (bf16_t*)dv, H, Lq, Lk,    \
-               ldq, ldk, ldo, scale)
+#define DKV_CALL(DD)                                                                                                         \
+  PCM_LAUNCH((attn_bwd_dkdv_kernel<DD>), grid, block, 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)dO, \
+             lse, delta, (bf16_t*)dk, (bf16_t*)dv, H, Lq, Lk, ldq, ldk, ldo, scale)
     ATTN_DISPATCH(d, DKV_CALL)
   }
   return pcm_post_launch("pcm_attn_bwd");

@@ -267,7 +267,7 @@ extern "C" int pcm_colsum_bf16(const void* x, void* out, int B, int HW, int C, v
   int chunks = (PCM_GRID_CAP(1024) + B * split - 1) / (B * split);
   int maxc = (HW + k - 1) / k; if (chunks > maxc) chunks = maxc; if (chunks < 1) chunks = 1;
   int ppb = (HW + chunks - 1) / chunks; chunks = (HW + ppb - 1) / ppb;
-  hipMemsetAsync(out, 0, sizeof(float) * (size_t)B * C, (hipStream_t)stream);
+  pcm_zero_async(out, sizeof(float) * (size_t)B * C, stream);
   PCM_LAUNCH(colsum_kernel, dim3(chunks, B, split), dim3(CVL * k), 0, stream, (const bf16_t*)x, (float*)out, HW, C, CVL, ppb);
   return pcm_post_launch("pcm_colsum_bf16");
 }

@@ -104,8 +104,8 @@ extern "C" int pcm_mod_grad(const void* x, const void* dy, const float* mean, co
   int chunks = (PCM_GRID_CAP(1024) + B * split - 1) / (B * split);
   const int maxc = (L + k - 1) / k; if (chunks > maxc) chunks = maxc; if (chunks < 1) chunks = 1;
   const int rpb = (L + chunks - 1) / chunks; chunks = (L + rpb - 1) / rpb;
-  hipMemsetAsync(out_a, 0, sizeof(float) * (size_t)B * C, (hipStream_t)stream);
-  if (out_b) hipMemsetAsync(out_b, 0, sizeof(float) * (size_t)B * C, (hipStream_t)stream);
+  pcm_zero_async(out_a, sizeof(float) * (size_t)B * C, stream);
+  if (out_b) pcm_zero_async(out_b, sizeof(float) * (size_t)B * C, stream);
   PCM_LAUNCH(mod_grad_kernel, dim3(chunks, B, split), dim3(CVL * k), 0, stream, (const bf16_t*)x, (const bf16_t*)dy, mean, rstd, out_a, out_b, L, C, CVL, rpb);
   return pcm_post_launch("pcm_mod_grad");
 }

@@ -303,7 +303,7 @@ static int gn_stats_launch(const char* what, GNArgs a, int B, void* stream, bool
     return pcm_post_launch(what);
   }
   a.part = nullptr;
-  if (zero) hipMemsetAsync(a.out, 0, sizeof(double) * 2 * B * a.G, (hipStream_t)stream);
+  if (zero) pcm_zero_async(a.out, sizeof(double) * 2 * B * a.G, stream);
   PCM_LAUNCH((gn_stats_kernel<MODE>), dim3(chunks, B, split), dim3(threads), 0, stream, a);
   return pcm_post_launch(what);
 }

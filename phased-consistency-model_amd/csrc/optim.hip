@@ -18,7 +18,7 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* g, double* out,
 }
 extern "C" int pcm_sumsq_f32(const float* g, double* out, long n, void* stream) {
   PCM_CHECK(g && out && n > 0, PCM_EINVAL, "pcm_sumsq_f32: null/empty");
-  hipMemsetAsync(out, 0, sizeof(double), (hipStream_t)stream);
+  pcm_zero_async(out, sizeof(double), stream);
   PCM_LAUNCH(sumsq_kernel, dim3(op_blocks(n)), dim3(256), 0, stream, g, out, n);
   return pcm_post_launch("pcm_sumsq_f32");
 }

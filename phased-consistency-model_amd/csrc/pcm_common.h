@@ -28,6 +28,17 @@
 #include "../../include/pcm_hip.h"
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
+// ds_read_b64_tr_b16 (gfx950 LDS transpose read).  Lane mapping measured on MI355X (tools/probes/trread.hip): inside each 16-lane
+// group, result lane i receives element (i & 3) of the 8-byte row addressed by SOURCE lane 4*j + (i >> 2), for j = 0..3.  I.e. source
+// lanes 4j..4j+3 address the four 4-element quads of row j of a 4 x 16 block and lane i gets column i: the k-strided operand of an
+// MFMA (8 consecutive k for one row / column) comes out of a row-major LDS tile with two of these reads.  Addresses must be 8-B aligned.
+#ifdef PCM_HOST_EMU
+#define PCM_DS_READ_TR16(p) pcm_emu::ds_read_tr16_b64((const void*)(p))
+#else
+#define PCM_DS_READ_TR16(p) __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(p))
+#endif
+__device__ __forceinline__ bf16x8 pcm_join4(bf16x4 a, bf16x4 b) { return bf16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]}; }
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short bf16_t;
@@ -43,6 +54,7 @@ void pcm_set_error(const char* fmt, ...);
   } while (0)
 #define PCM_ALIGNED16(p) ((((uintptr_t)(p)) & 15) == 0)
 int pcm_post_launch(const char* what);
+void pcm_zero_async(void* p, size_t bytes, void* stream);   // zero fill as a kernel launch (runtime.hip: why not hipMemsetAsync)
 
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((unsigned)h) << 16); }
 #ifdef PCM_HOST_EMU

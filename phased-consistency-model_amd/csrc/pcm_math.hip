@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void loss_kernel(const float* mp, const float*
 extern "C" int pcm_consistency_loss(const float* model_pred, const float* target, const float* coef, int huber, float huber_c,
                                     double* loss, float* d_eps, float grad_scale, int B, int per_sample, void* stream) {
   PCM_CHECK(model_pred && target && loss && B > 0 && per_sample > 0 && (!d_eps || coef), PCM_EINVAL, "pcm_consistency_loss: null/empty");
-  hipMemsetAsync(loss, 0, sizeof(double), (hipStream_t)stream);
+  pcm_zero_async(loss, sizeof(double), stream);
   PCM_LAUNCH(loss_kernel, dim3(pm_blocks((long)B * per_sample)), dim3(256), 0, stream, model_pred, target, coef, huber, huber_c, loss, d_eps, grad_scale, B, per_sample);
   return pcm_post_launch("pcm_consistency_loss");
 }

@@ -23,5 +23,17 @@ int pcm_post_launch(const char* what) {
   return PCM_OK;
 }
 
+// Zero fill as a KERNEL.  hipMemsetAsync inside a captured hipGraph becomes a memset node; on this stack (ROCm 7.2) replays of a graph with
+// such nodes in front of atomic accumulations gave wrong sums from the second replay on (tests/test_gpu_bench_config.py: graph vs eager),
+// so every "zero, then accumulate" sequence of the library clears with this launch instead (bytes must be a multiple of 4).
+__global__ __launch_bounds__(256) void pcm_zero_kernel(unsigned* p, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = 0u;
+}
+void pcm_zero_async(void* p, size_t bytes, void* stream) {
+  const long n = (long)(bytes / 4);
+  long b = (n + 255) / 256; if (b > PCM_GRID_CAP(1024)) b = PCM_GRID_CAP(1024); if (b < 1) b = 1;
+  PCM_LAUNCH(pcm_zero_kernel, dim3((unsigned)b), dim3(256), 0, stream, (unsigned*)p, n);
+}
+
 extern "C" const char* pcm_last_error(void) { return g_err; }
 extern "C" int pcm_abi_version(void) { return 1; }

@@ -9,13 +9,7 @@
 // with ((row ^ (row>>3)) & 15) — conflict-free for both the transposed writes and the
 // ds_read_b128 MFMA fragment reads.  Block = 64 cols of Big x 64 ranks, 128 rows of m per step,
 // split over M across workgroups, fp32 atomics into the flat gradient buffer.
-#include "pcm_common.h"
-
-struct WgDev {
-  const bf16_t* big; int ldb, G, mode, Hs, Ws, C, stride, src_mode, Ho, Wo;
-  const bf16_t* small_; int lds_, M;
-  float* out; long g_stride, r_stride; int out_conv; float alpha; int m_per_block; int swap;
-};
+#include "wgrad_dev.h"
 
 __device__ __forceinline__ int wg_off(int row, int chunk) { return row * 256 + ((chunk ^ ((row ^ (row >> 3)) & 15)) << 4); }
 
@@ -151,6 +145,11 @@ extern "C" int pcm_lora_wgrad_bf16(const pcm_wgrad_args* p, void* stream) {
   } else {
     PCM_CHECK(p->mode == PCM_SEG_PLAIN && (p->G % 8) == 0 && (p->ldb % 8) == 0 && p->ldb >= p->G && !p->out_conv, PCM_EINVAL,
               "pcm_lora_wgrad_bf16: plain view needs G%%8==0, ldb%%8==0");
+  }
+  {   // LDS-DMA + transpose-read kernels (wgrad_tr.hip) for the plain and the stride-1 3x3 views; everything else stays here
+    const int rc = pcm_wgrad_tr_launch(a, stream);
+    if (rc == 0) return pcm_post_launch("pcm_lora_wgrad_bf16");
+    if (rc < 0) return rc;
   }
   int tiles_g = (p->G + 63) / 64;
   int chunks = (p->M + 127) / 128;

@@ -1,0 +1,14 @@
+// Device-side argument block of the LoRA weight-gradient kernels (wgrad.hip: register-transposing kernel for every geometry;
+// wgrad_tr.hip: LDS-DMA + transpose-read kernels for the plain and the stride-1 3x3 views).
+#pragma once
+#include "pcm_common.h"
+
+struct WgDev {
+  const bf16_t* big; int ldb, G, mode, Hs, Ws, C, stride, src_mode, Ho, Wo;
+  const bf16_t* small_; int lds_, M;
+  float* out; long g_stride, r_stride; int out_conv; float alpha; int m_per_block; int swap;
+};
+
+
+// returns 0 when a transpose-read kernel took the call, 1 when the geometry is not one of theirs (caller falls back), < 0 on error
+int pcm_wgrad_tr_launch(const WgDev& a, void* stream);

@@ -1,0 +1,253 @@
+// LoRA weight gradients with LDS-DMA staging and LDS transpose reads (gfx950 ds_read_b64_tr_b16):
+//     G[g][r] += alpha * sum_m Big[m][g] * Small[m][r]            (same contract as wgrad.hip)
+// The contraction index m is the ROW index of both operands.  wgrad.hip transposes 8x8 blocks in registers on the way into LDS; here the
+// tiles go into LDS row-major exactly as they sit in HBM (buffer_load ... lds, 16 B per lane, no VGPR round trip, two stages in
+// flight) and BOTH MFMA operands are read k-along-the-rows with two transpose reads per fragment (pcm_common.h PCM_DS_READ_TR16).
+//
+//  pcm_wgrad_tr_kernel       plain view: block = 128 columns of Big x 64 ranks, 64 rows of m per stage, 4 waves x (32 g x 64 r).
+//                            Small is re-read once per 128 Big columns (wgrad.hip: once per 64).
+//  pcm_wgrad_tr_conv_kernel  3x3 / stride 1 / pad 1 view (dA of the conv LoRA factors): out[tap][c][r] = sum_p x[p][c] u[p - off(tap)][r].
+//                            wgrad.hip walks the 9 taps as 9 im2col column blocks: x is staged 9 times and u 9*C/64 times.  Here a block
+//                            owns 64 input channels x 64 ranks x ALL 9 taps (9 accumulator tiles per wave): per 64-pixel stage it stages
+//                            the x tile ONCE plus a zero-padded (rows+2) x (width+2) window of u, and the 9 shifted u operands are
+//                            transpose reads of that window at 9 scalar offsets (image borders = the window's zero frame, written by
+//                            the DMA itself through out-of-range buffer offsets).
+// LDS images carry an XOR swizzle on the 16-B chunk index so that the 4 rows x 32 B quads of a transpose read fall on distinct banks;
+// the DMA writes LDS linearly, so the swizzle is applied to the SOURCE chunk a lane fetches (guide rule 21).
+#include <stdlib.h>
+
+#include "wgrad_dev.h"
+
+#define WT_RSRC_FLAGS 0x00020000
+#define WT_OOB 0x80000000u
+
+// ------------------------------------------------------------------------------------------------ plain view
+template <bool SWAP>
+__global__ __launch_bounds__(256) void pcm_wgrad_tr_kernel(WgDev a) {
+#if defined(__HIP_DEVICE_COMPILE__) || defined(PCM_HOST_EMU)
+  constexpr int BIGB = 64 * 256, SMB = 64 * 128, STAGE = BIGB + SMB;   // Big tile [64][128] bf16, Small tile [64][64] bf16
+  PCM_DYN_SMEM(smem);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g0 = blockIdx.x * 128;
+  const int m_begin = blockIdx.y * a.m_per_block;
+  int m_end = m_begin + a.m_per_block; if (m_end > a.M) m_end = a.M;
+  const int nst = (m_end - m_begin + 63) >> 6;
+  // ---- DMA geometry.  Big: one instruction = 4 rows x 16 chunks (lane -> row lane>>4, LDS chunk lane&15); Small: 8 rows x 8 chunks.
+  // LDS chunk position p of row r holds source chunk p ^ swz(r): swz = (r&3)<<2 for the 256-B rows, ((r>>1)&1)<<2 for the 128-B rows.
+  const int b_rl = lane >> 4, b_c = (lane & 15) ^ ((b_rl & 3) << 2);
+  const int s_rl = lane >> 3, s_c = (lane & 7) ^ (((s_rl >> 1) & 1) << 2);
+  const bool b_colok = g0 + 8 * b_c < a.G;
+  const unsigned b_coloff = (unsigned)(g0 + 8 * b_c) * 2u, s_coloff = (unsigned)s_c * 16u;
+  const unsigned ldb2 = (unsigned)a.ldb * 2u, lds2 = (unsigned)a.lds_ * 2u;
+  auto issue = [&](int st, int buf) {
+    const int m0 = m_begin + 64 * st;
+    __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)a.big, 0, WT_OOB, WT_RSRC_FLAGS);
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.small_, 0, WT_OOB, WT_RSRC_FLAGS);
+    char* base = smem + buf * STAGE;
+#pragma unroll
+    for (int jj = 0; jj < 4; jj++) {
+      const int t = wave + 4 * jj, row = m0 + 4 * t + b_rl;
+      const unsigned voff = (row < m_end && b_colok) ? (unsigned)row * ldb2 + b_coloff : WT_OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, PCM_AS3(base + t * 1024), 16, voff, 0, 0, 0);
+    }
+#pragma unroll
+    for (int jj = 0; jj < 2; jj++) {
+      const int t = wave + 4 * jj, row = m0 + 8 * t + s_rl;
+      const unsigned voff = row < m_end ? (unsigned)row * lds2 + s_coloff : WT_OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, PCM_AS3(base + BIGB + t * 1024), 16, voff, 0, 0, 0);
+    }
+  };
+  // ---- transpose-read geometry: 16-lane group gq = lane>>4 -> column half cb = gq&1, k half kg = gq>>1; source lane 4j+q of the group
+  // addresses the quad (row 8kg + j [+4 for the second read], columns 4q..4q+3 of the group's 16 columns)
+  const int sl = lane & 15, j = sl >> 2, q = sl & 3, gq = lane >> 4, cb = gq & 1, kg = gq >> 1;
+  const int a_chunk = (4 * wave + 2 * cb + (q >> 1)) ^ (j << 2);
+  const int a_base = (8 * kg + j) * 256 + a_chunk * 16 + 8 * (q & 1);
+  const int jb = (j >> 1) & 1;
+  int b_base[2];
+#pragma unroll
+  for (int rt = 0; rt < 2; rt++) b_base[rt] = (8 * kg + j) * 128 + (((4 * rt + 2 * cb + (q >> 1)) ^ (jb << 2)) * 16) + 8 * (q & 1);
+  f32x16 acc[2];
+#pragma unroll
+  for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[rt][r] = 0.f;
+
+  issue(0, 0);
+  for (int st = 0; st < nst; st++) {
+    if (st + 1 < nst) { issue(st + 1, (st + 1) & 1); PCM_WAIT_VMCNT(6); } else { PCM_WAIT_VMCNT(0); }
+    __builtin_amdgcn_s_barrier();            // every wave's pieces of stage st have landed
+    const char* B = smem + (st & 1) * STAGE;
+    const char* S = B + BIGB;
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {
+      const bf16x8 af = pcm_join4(PCM_DS_READ_TR16(B + a_base + (16 * ks) * 256), PCM_DS_READ_TR16(B + a_base + (16 * ks + 4) * 256));
+#pragma unroll
+      for (int rt = 0; rt < 2; rt++) {
+        const bf16x8 bf = pcm_join4(PCM_DS_READ_TR16(S + b_base[rt] + (16 * ks) * 128), PCM_DS_READ_TR16(S + b_base[rt] + (16 * ks + 4) * 128));
+        acc[rt] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf, af, acc[rt], 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[rt], 0, 0, 0);
+      }
+    }
+    PCM_WAIT_LGKMCNT0();
+    __builtin_amdgcn_s_barrier();            // reads of this buffer are done before stage st+2 is issued into it
+  }
+  const int l31 = lane & 31, hi = lane >> 5;
+#pragma unroll
+  for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+      const int ii = (e & 3) + 8 * (e >> 2) + 4 * hi;
+      const int g = g0 + 32 * wave + (SWAP ? l31 : ii), r = 32 * rt + (SWAP ? ii : l31);
+      if (g < a.G) atomicAdd(a.out + (size_t)g * a.g_stride + (size_t)r * a.r_stride, acc[rt][e] * a.alpha);
+    }
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------ 3x3 / stride 1 view
+// stage = 64 consecutive pixels of one image: Wt = min(W, 64) columns x R = 64/Wt rows at (y0, x0); u window = (R+2) x (Wt+2) entries of
+// 128 B, entry (ry, cx) <-> pixel (y0 - 1 + ry, x0 - 1 + cx), zero outside the image.  LDS: x tile 8 KB + window 28 KB, two stages.
+__global__ __launch_bounds__(256) void pcm_wgrad_tr_conv_kernel(WgDev a) {
+#if defined(__HIP_DEVICE_COMPILE__) || defined(PCM_HOST_EMU)
+  constexpr int XB = 64 * 128, UB = 28 * 1024, STAGE = XB + UB;
+  PCM_DYN_SMEM(smem);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wc = wave & 1, wr = wave >> 1;
+  const int c0 = blockIdx.x * 64;
+  const int W = a.Wo, H = a.Ho, HW = H * W, C = a.C;
+  const int Wt = W < 64 ? W : 64, R = 64 / Wt, WP = Wt + 2, E = (R + 2) * WP;
+  const int lw = 31 - __builtin_clz((unsigned)Wt);
+  const int st_begin = blockIdx.y * (a.m_per_block >> 6);
+  int st_end = st_begin + (a.m_per_block >> 6);
+  if (st_end > (a.M >> 6)) st_end = a.M >> 6;
+  const int nst = st_end - st_begin, spi = HW >> 6;       // stages per image
+  // ---- DMA geometry
+  const int x_rl = lane >> 3;
+  int u_ry[7], u_cx[7];
+#pragma unroll
+  for (int jj = 0; jj < 7; jj++) {
+    const int e = 8 * (wave + 4 * jj) + (lane >> 3);
+    u_ry[jj] = e < E ? e / WP : -4096;        // entries beyond the window: always out of range (zero fill keeps the wait counts uniform)
+    u_cx[jj] = e < E ? e - (e / WP) * WP : 0;
+  }
+  const unsigned u_coloff = (unsigned)(lane & 7) * 16u, lds2 = (unsigned)a.lds_ * 2u, c2 = (unsigned)C * 2u;
+  auto issue = [&](int sti, int buf) {
+    const int sg = st_begin + sti, bimg = sg / spi, pix0 = (sg - bimg * spi) << 6;
+    const int y0 = pix0 / W, x0 = pix0 - y0 * W;
+    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.big, 0, WT_OOB, WT_RSRC_FLAGS);
+    __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc((void*)a.small_, 0, WT_OOB, WT_RSRC_FLAGS);
+    char* base = smem + buf * STAGE;
+#pragma unroll
+    for (int jj = 0; jj < 2; jj++) {          // x tile: 8 pixels x 8 chunks per instruction, chunk swizzle ((row>>1)&1)<<2
+      const int t = wave + 4 * jj, rl = 8 * t + x_rl;
+      const int c = (lane & 7) ^ (((rl >> 1) & 1) << 2);
+      const unsigned voff = (unsigned)(bimg * HW + pix0 + rl) * c2 + (unsigned)(c0 + 8 * c) * 2u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, PCM_AS3(base + t * 1024), 16, voff, 0, 0, 0);
+    }
+#pragma unroll
+    for (int jj = 0; jj < 7; jj++) {          // u window: 8 entries x 8 chunks per instruction, linear
+      const int t = wave + 4 * jj;
+      const int y = y0 - 1 + u_ry[jj], x = x0 - 1 + u_cx[jj];
+      const bool ok = y >= 0 && y < H && x >= 0 && x < W;
+      const unsigned voff = ok ? (unsigned)(bimg * HW + y * W + x) * lds2 + u_coloff : WT_OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ru, PCM_AS3(base + XB + t * 1024), 16, voff, 0, 0, 0);
+    }
+  };
+  // ---- transpose-read geometry (see the plain kernel); pixel quads never straddle an image row (Wt % 4 == 0)
+  const int sl = lane & 15, j = sl >> 2, q = sl & 3, gq = lane >> 4, cb = gq & 1, kg = gq >> 1;
+  const int x_base = (8 * kg + j) * 128 + (((4 * wc + 2 * cb + (q >> 1)) ^ (((j >> 1) & 1) << 2)) * 16) + 8 * (q & 1);
+  int u_base[4][2];                            // [k-step][read]: byte offset of entry (yl, xl + j) of the un-shifted tap (ty, tx) = (2, 2)
+#pragma unroll
+  for (int ks = 0; ks < 4; ks++)
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int pl = 16 * ks + 8 * kg + 4 * h, yl = pl >> lw, xl = pl & (Wt - 1);
+      u_base[ks][h] = (yl * WP + xl + j) * 128 + (32 * wr + 16 * cb + 4 * q) * 2;
+    }
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; t++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
+
+  if (nst > 0) issue(0, 0);
+  for (int st = 0; st < nst; st++) {
+    if (st + 1 < nst) { issue(st + 1, (st + 1) & 1); PCM_WAIT_VMCNT(9); } else { PCM_WAIT_VMCNT(0); }
+    __builtin_amdgcn_s_barrier();
+    const char* X = smem + (st & 1) * STAGE;
+    const char* U = X + XB;
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {
+      const bf16x8 xf = pcm_join4(PCM_DS_READ_TR16(X + x_base + (16 * ks) * 128), PCM_DS_READ_TR16(X + x_base + (16 * ks + 4) * 128));
+#pragma unroll
+      for (int t = 0; t < 9; t++) {
+        const int toff = ((2 - t / 3) * WP + (2 - t % 3)) * 128;       // wave-uniform: entry of pixel p - off(tap) relative to tap (2,2)
+        const bf16x8 uf = pcm_join4(PCM_DS_READ_TR16(U + u_base[ks][0] + toff), PCM_DS_READ_TR16(U + u_base[ks][1] + toff));
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uf, xf, acc[t], 0, 0, 0);      // D[i = r][j = c]
+      }
+    }
+    PCM_WAIT_LGKMCNT0();
+    __builtin_amdgcn_s_barrier();
+  }
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int c = c0 + 32 * wc + l31;
+#pragma unroll
+  for (int t = 0; t < 9; t++)
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+      const int r = 32 * wr + (e & 3) + 8 * (e >> 2) + 4 * hi;
+      atomicAdd(a.out + (size_t)(t * C + c) * a.g_stride + (size_t)r * a.r_stride, acc[t][e] * a.alpha);
+    }
+#endif
+}
+
+static int g_wgtr_mode = -1;     // -1: PCM_WGRAD_TR env (default 1); 0 = always wgrad.hip (A/B, tests)
+extern "C" void pcm_debug_wgrad_tr(int mode) { g_wgtr_mode = mode; }
+static long g_wgtr_count[2] = {0, 0};   // tests: launches taken by the plain / conv kernel
+extern "C" long pcm_debug_wgrad_tr_count(int conv) { return g_wgtr_count[conv ? 1 : 0]; }
+static int g_wgtr_blocks = 512;
+extern "C" void pcm_debug_wgrad_tr_blocks(int n) { g_wgtr_blocks = n > 0 ? n : 512; }
+
+int pcm_wgrad_tr_launch(const WgDev& a0, void* stream) {
+  if (g_wgtr_mode < 0) { const char* e = getenv("PCM_WGRAD_TR"); g_wgtr_mode = e ? atoi(e) : 1; }
+  if (!g_wgtr_mode || a0.out_conv) return 1;
+  WgDev a = a0;
+  const bool conv = a.mode == PCM_SEG_CONV3X3;
+  if ((size_t)a.M * a.lds_ * 2 >= 0x7ff00000u) return 1;
+  auto cdiv = [](long x, long y) { return (int)((x + y - 1) / y); };
+  if (!conv) {
+    if ((size_t)a.M * a.ldb * 2 >= 0x7ff00000u) return 1;
+    const int tiles_g = cdiv(a.G, 128), stages = cdiv(a.M, 64);
+    // split over M: ~g_wgtr_blocks blocks (two per CU), at least 4 stages per block so that the 8192 fp32 atomics a block ends with stay small
+    int msplit = cdiv(PCM_GRID_CAP(g_wgtr_blocks), tiles_g);
+    if (msplit > cdiv(stages, 4)) msplit = cdiv(stages, 4);
+    if (msplit < 1) msplit = 1;
+    a.m_per_block = cdiv(stages, msplit) * 64;
+    msplit = cdiv(a.M, a.m_per_block);
+    const size_t smem = 2 * (64 * 256 + 64 * 128);
+    if (a.swap) PCM_LAUNCH((pcm_wgrad_tr_kernel<true>), dim3(tiles_g, msplit), dim3(256), smem, stream, a);
+    else PCM_LAUNCH((pcm_wgrad_tr_kernel<false>), dim3(tiles_g, msplit), dim3(256), smem, stream, a);
+    g_wgtr_count[0]++;
+    return 0;
+  }
+  const int W = a.Wo, HW = a.Ho * a.Wo;
+  const bool wok = W >= 64 ? (W % 64) == 0 : (W >= 4 && (W & (W - 1)) == 0);
+  if (a.stride != 1 || a.src_mode != PCM_SRC_DIRECT || a.Hs != a.Ho || a.Ws != a.Wo || !wok || (HW % 64) || (a.C % 64) || !a.swap) return 1;
+  if ((size_t)a.M * a.C * 2 >= 0x7ff00000u) return 1;
+  const int tiles_c = a.C / 64, stages = a.M / 64;
+  int msplit = cdiv(PCM_GRID_CAP(g_wgtr_blocks), tiles_c);
+  if (msplit > cdiv(stages, 2)) msplit = cdiv(stages, 2);
+  if (msplit < 1) msplit = 1;
+  a.m_per_block = cdiv(stages, msplit) * 64;
+  msplit = cdiv(a.M, a.m_per_block);
+  const size_t smem = 2 * (64 * 128 + 28 * 1024);
+  static bool lds_ok = false;
+  if (!lds_ok) {
+    hipError_t er = hipFuncSetAttribute((const void*)pcm_wgrad_tr_conv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    PCM_CHECK(er == hipSuccess, PCM_EHIP, "pcm_lora_wgrad_bf16: hipFuncSetAttribute(LDS %zu): %s", smem, hipGetErrorString(er));
+    lds_ok = true;
+  }
+  PCM_LAUNCH(pcm_wgrad_tr_conv_kernel, dim3(tiles_c, msplit), dim3(256), smem, stream, a);
+  g_wgtr_count[1]++;
+  return 0;
+}

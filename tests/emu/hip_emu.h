@@ -156,6 +156,20 @@ inline f32x4_t mfma_16x16x32_bf16(bf16x8_t a, bf16x8_t b, f32x4_t c, int, int, i
   return c;
 }
 
+// ds_read_b64_tr_b16: see csrc/pcm_common.h (mapping measured on MI355X with tools/probes/trread.hip)
+typedef short bf16x4_t __attribute__((ext_vector_type(4)));
+inline bf16x4_t ds_read_tr16_b64(const void* p) {
+  if (((uintptr_t)p) & 7) { fprintf(stderr, "emu: ds_read_b64_tr_b16 address not 8-byte aligned (the hardware returns the aligned address's data)\n"); abort(); }
+  WaveScratch& w = wave();
+  int bsel = w.gen & 1, l = lane_id();
+  w.gp[bsel][l] = p;
+  wave_sync();
+  const int g0 = l & ~15, i = l & 15;
+  bf16x4_t out;
+  for (int j = 0; j < 4; j++) out[j] = ((const short*)w.gp[bsel][g0 + 4 * j + (i >> 2)])[i & 3];
+  return out;
+}
+
 // LDS-DMA is asynchronous on the hardware: the data lands some time between the issue and the s_waitcnt vmcnt that
 // retires it.  The emulator runs the two extremes: eager (default: lands at issue) and lazy (PCM_EMU_LAZY_DMA=1: lands
 // only when a counted wait / __syncthreads retires it) -- a kernel whose results agree under both has no RAW / WAR

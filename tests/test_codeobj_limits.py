@@ -49,7 +49,7 @@ def meta():
 
 
 def test_every_kernel_fits_a_gfx950_cu(meta):
-    assert len(meta) > 100, len(meta)
+    assert len(meta) > 80, len(meta)
     bad = []
     for name, f in meta.items():
         lds, vg, ag = f["group_segment_fixed_size"], f["vgpr_count"], f["agpr_count"]
@@ -67,7 +67,6 @@ def test_every_kernel_fits_a_gfx950_cu(meta):
 # kernels that are launched with dynamic LDS: their (static + largest dynamic request) must fit the 160 KiB of a CU.
 # The dynamic sizes restate the launchers' formulas at their maxima.
 DYN = {
-    "attn_pack_t_kernel": 64 * 1024,                    # attn_pack_launch: PCM_CHECK(smem <= 64 KB)
     "pcm_gemm8p_kernel": 2 * (256 + 64 * 5) * 128,      # pcm_gemm8p_lds_bytes(5)
     "pcm_gemm_kernel": 2 * (256 + 128) * 128,           # 256x128 tile
     "pcm_gemm_n64_kernel": 64 * 32 * 10 * 2,

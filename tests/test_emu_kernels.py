@@ -75,6 +75,31 @@ def test_wgrad_conv(stride, src_mode):
     K.case_wgrad_conv("cpu", 2, 6, 5, 64, stride, src_mode)
 
 
+# geometries the LDS-DMA + transpose-read kernels take (wgrad_tr.hip): 8x8 (8 image rows per 64-pixel stage), 16x16 (4 rows), 64-wide
+# (one row per stage, two channel tiles), 128-wide (two stages per image row); the plain cases above cover the plain kernel incl. ragged M
+@pytest.mark.parametrize("B,H,W,C", [(2, 8, 8, 64), (1, 16, 16, 128), (1, 2, 64, 64), (1, 1, 128, 64), (3, 4, 16, 64)])
+def test_wgrad_conv_transpose_read_kernel(B, H, W, C):
+    import ctypes
+    from pcm_amd import capi
+    cnt = capi.lib().dll.pcm_debug_wgrad_tr_count
+    cnt.restype = ctypes.c_long
+    n0 = cnt(1)
+    K.case_wgrad_conv("cpu", B, H, W, C, 1, 0)
+    assert cnt(1) == n0 + 1      # the khwc-layout call took the transpose-read kernel (the peft-layout call stays on wgrad.hip)
+
+
+def test_wgrad_transpose_read_matches_register_transposing_kernel():
+    """A/B of the two implementations of the same contract on one ragged plain shape (both must agree with the reference)."""
+    from pcm_amd import capi
+    dll = capi.lib().dll
+    for mode in (0, 1):
+        dll.pcm_debug_wgrad_tr(mode)
+        try:
+            K.case_wgrad_plain("cpu", 333, 200, 136)
+        finally:
+            dll.pcm_debug_wgrad_tr(1)
+
+
 @pytest.mark.parametrize("B,H,Lq,Lk,d,spike", [(1, 2, 100, 77, 40, False), (2, 1, 70, 130, 80, True), (1, 1, 40, 64, 160, False), (1, 1, 300, 330, 40, True), (1, 2, 90, 90, 64, True)])
 def test_attention(B, H, Lq, Lk, d, spike):
     K.case_attention("cpu", B, H, Lq, Lk, d, spike)
@@ -113,19 +138,14 @@ def test_emulator_enforces_launch_limits():
     assert f(164864, 256, 1, -1) != 0                # the round-1 SDXL request (64 rows x (1280 + 8) bf16)
 
 
-# (1, 20, .., 64) / (1, 24, .., 64): SDXL level-2 and SD3 widths (H*d = 1280 / 1536: several head groups per pack block row); d = 32 wide
+# wide-head shapes: SDXL level-2 and SD3 widths (H*d = 1280 / 1536), d = 32; ragged tails on both sequence axes.  (Round 1 packed transposed
+# operand images for these -- the LDS over-subscription that broke the full-size GPU tests; the operands are LDS transpose reads now.)
 @pytest.mark.parametrize("B,H,Lq,Lk,d", [(1, 2, 130, 130, 40), (1, 1, 70, 200, 80), (1, 2, 154, 154, 64), (1, 20, 70, 70, 64),
                                          (1, 24, 130, 100, 64), (1, 17, 70, 70, 32)])
-def test_attention_packed_transposed_operands(B, H, Lq, Lk, d):
-    """pcm_attn_*_ws with the one-off packed V^T / K^T / Q^T / dO^T tile images (ragged tails zero-filled by the packer)."""
+def test_attention_wide_heads_and_ragged_tiles(B, H, Lq, Lk, d):
     from pcm_amd import capi
-    dll = capi.lib().dll
-    dll.pcm_debug_attn_pack_min_len(64)
-    try:
-        assert dll.pcm_attn_workspace_bytes(B, H, Lq, Lk, d, 1) > 0
-        K.case_attention("cpu", B, H, Lq, Lk, d, spike=True)
-    finally:
-        dll.pcm_debug_attn_pack_min_len(1024)
+    assert capi.lib().dll.pcm_attn_workspace_bytes(B, H, Lq, Lk, d, 1) == 0     # no call needs a workspace any more
+    K.case_attention("cpu", B, H, Lq, Lk, d, spike=True)
 
 
 def test_abi_rejects_bad_arguments_with_a_message():
