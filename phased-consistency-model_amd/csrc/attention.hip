@@ -82,6 +82,25 @@ struct TrFrag {
     return pcm_join4(PCM_DS_READ_TR16(p), PCM_DS_READ_TR16(p + 8 * (C::RKU * 16)));
   }
 };
+// The four k-steps of one 32-column group (one accumulator tile of the k-along-rows MFMAs), issued as 8 untracked transpose reads: they
+// can be put in flight long before their MFMAs (forward: before the softmax) and cost the wave no wait until wait() / use.
+template <int D>
+struct TrQuad {
+  using C = AttnCfg<D>;
+  bf16x4 lo[4], hi[4];
+  template <int IT>
+  __device__ __forceinline__ void issue(const char* tile, const TrFrag<D>& f) {
+    const char* p = tile + f.base;
+#define TRQ_STEP(SS)                                                          \
+  PCM_TR16_ISSUE(lo[SS], p, 16 * SS * (C::RKU * 16) + 64 * IT);               \
+  PCM_TR16_ISSUE(hi[SS], p, 16 * SS * (C::RKU * 16) + 64 * IT + 8 * (C::RKU * 16));
+    TRQ_STEP(0) TRQ_STEP(1) TRQ_STEP(2) TRQ_STEP(3)
+#undef TRQ_STEP
+  }
+  __device__ __forceinline__ void wait() { PCM_TR16_WAIT8(lo[0], hi[0], lo[1], hi[1], lo[2], hi[2], lo[3], hi[3]); }
+  __device__ __forceinline__ void keep() { PCM_TR16_KEEP8(lo[0], hi[0], lo[1], hi[1], lo[2], hi[2], lo[3], hi[3]); }
+  __device__ __forceinline__ bf16x8 frag(int ss) const { return pcm_join4(lo[ss], hi[ss]); }
+};
 // ---- register staging (issue the NEXT tile's global loads before computing on the current tile;
 // the LDS write happens after the next barrier, so L2/HBM latency hides under the MFMA phase) ----
 // Loads are UNCONDITIONAL from clamped addresses (a predicated load + zero select makes hipcc wait
@@ -192,6 +211,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* q, const bf
         s_[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], s_[t], 0, 0, 0);
       }
     }
+    // V^T fragments of this tile: in flight under the softmax (head dims whose 4*DV fragments fit the register budget)
+    constexpr bool V_EARLY = D <= 80;
+    TrQuad<D> vq[V_EARLY ? C::DV : 1];
+    if constexpr (V_EARLY) pcm_static_for<0, C::DV>([&](auto it) { vq[decltype(it)::value].template issue<decltype(it)::value>(Vs, trf); });
     // online softmax in the log2 domain on RAW scores: p = exp2(s*sc - m); masks only on the tail tile
     if (kv0 + 64 > Lk) {
       asm volatile("" ::: "memory");   // keep this a real (wave-uniform) branch: if-converted it costs 3 VALU ops per score in every tile
@@ -233,14 +256,17 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* q, const bf
     bf16x8 pf[4];
 #pragma unroll
     for (int ss = 0; ss < 4; ss++) pf[ss] = pack_frag(s_[ss >> 1], ss & 1);
+    if constexpr (V_EARLY) {
+      vq[0].wait();
+      pcm_static_for<1, C::DV>([&](auto it) { vq[decltype(it)::value].keep(); });
+    }
+    pcm_static_for<0, C::DV>([&](auto it) {
+      constexpr int i = decltype(it)::value;
+      TrQuad<D>& v4 = vq[V_EARLY ? i : 0];
+      if constexpr (!V_EARLY) { v4.template issue<i>(Vs, trf); v4.wait(); }
 #pragma unroll
-    for (int i = 0; i < C::DV; i++)
-#pragma unroll
-      for (int ss = 0; ss < 4; ss++) {
-        bf16x8 vf = trf.get(Vs, i, ss);
-        if (ATTN_ABL(4)) { acc_o[i][ss] += (float)vf[0] + (float)pf[ss][0]; continue; }
-        acc_o[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[ss], acc_o[i], 0, 0, 0);
-      }
+      for (int ss = 0; ss < 4; ss++) acc_o[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v4.frag(ss), pf[ss], acc_o[i], 0, 0, 0);
+    });
   }
   float l_tot = l_run + __shfl_xor(l_run, 32);
   if constexpr (ONES) {   // accumulator row D: tile D/32, local row D%32 -> lane half (loc>>2)&1 (= 0 for 40 / 80), register (loc&3) + 4*(loc>>3)
@@ -368,13 +394,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* q, const
     bf16x8 df[4];
 #pragma unroll
     for (int ss = 0; ss < 4; ss++) df[ss] = pack_frag(s_[ss >> 1], ss & 1);
+    // K^T fragments: the tile of accumulator row group i+1 is in flight while group i multiplies
+    TrQuad<D> kq[2];
+    kq[0].template issue<0>(Ks, trf);
+    pcm_static_for<0, C::DV>([&](auto it) {
+      constexpr int i = decltype(it)::value;
+      TrQuad<D>& k4 = kq[i & 1];
+      k4.wait();
+      if constexpr (i + 1 < C::DV) kq[(i + 1) & 1].template issue<i + 1>(Ks, trf);
 #pragma unroll
-    for (int i = 0; i < C::DV; i++)
-#pragma unroll
-      for (int ss = 0; ss < 4; ss++) {
-        bf16x8 ktf = trf.get(Ks, i, ss);
-        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf, df[ss], acc[i], 0, 0, 0);
-      }
+      for (int ss = 0; ss < 4; ss++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k4.frag(ss), df[ss], acc[i], 0, 0, 0);
+    });
   }
   if (qrow < Lq) {
     bf16_t* orow = dq + ((size_t)b * Lq + qrow) * ldq + h * D;
@@ -484,15 +514,23 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16_t* q, con
     bf16x8 pf[4], df[4];
 #pragma unroll
     for (int ss = 0; ss < 4; ss++) { pf[ss] = pack_frag(s_[ss >> 1], ss & 1); df[ss] = pack_frag(dp[ss >> 1], ss & 1); }
+    // dO^T and Q^T fragments, one 32-row accumulator group at a time: dO^T(i), Q^T(i) in flight while the previous group multiplies
+    TrQuad<D> oq, qq;
+    oq.template issue<0>(Os, trf);
+    qq.template issue<0>(Qs, trf);
+    pcm_static_for<0, C::DV>([&](auto it) {
+      constexpr int i = decltype(it)::value;
+      oq.wait(); qq.keep();
+      bf16x8 of[4], qf4[4];
 #pragma unroll
-    for (int i = 0; i < C::DV; i++)
+      for (int ss = 0; ss < 4; ss++) { of[ss] = oq.frag(ss); qf4[ss] = qq.frag(ss); }
+      if constexpr (i + 1 < C::DV) { oq.template issue<i + 1>(Os, trf); qq.template issue<i + 1>(Qs, trf); }
 #pragma unroll
       for (int ss = 0; ss < 4; ss++) {
-        bf16x8 otf = trf.get(Os, i, ss);
-        bf16x8 qtf = trf.get(Qs, i, ss);
-        acc_v[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(otf, pf[ss], acc_v[i], 0, 0, 0);  // dV^T[d][kv]
-        acc_k[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf, df[ss], acc_k[i], 0, 0, 0);  // dK^T[d][kv]
+        acc_v[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(of[ss], pf[ss], acc_v[i], 0, 0, 0);   // dV^T[d][kv]
+        acc_k[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf4[ss], df[ss], acc_k[i], 0, 0, 0);  // dK^T[d][kv]
       }
+    });
   }
   if (kv_ok) {
     bf16_t* krow = dk + ((size_t)b * Lk + kv0 + l31) * ldk + h * D;

@@ -18,6 +18,8 @@
 #endif
 #include <stdint.h>
 #include <string.h>
+
+#include <type_traits>
 // grid-stride kernels: cap of the launch grid (the host emulator runs blocks serially, keep it small there)
 #ifdef PCM_HOST_EMU
 #define PCM_GRID_CAP(n) 4
@@ -27,6 +29,11 @@
 
 #include "../../include/pcm_hip.h"
 
+// compile-time loop: f(std::integral_constant<int, I>) for I in [I0, N) -- indices usable as asm immediates / register-array subscripts
+template <int I, int N, typename F>
+__device__ __forceinline__ void pcm_static_for(F&& f) {
+  if constexpr (I < N) { f(std::integral_constant<int, I>{}); pcm_static_for<I + 1, N>(f); }
+}
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef short bf16x4 __attribute__((ext_vector_type(4)));
 // ds_read_b64_tr_b16 (gfx950 LDS transpose read).  Lane mapping measured on MI355X (tools/probes/trread.hip): inside each 16-lane
@@ -37,6 +44,25 @@ typedef short bf16x4 __attribute__((ext_vector_type(4)));
 #define PCM_DS_READ_TR16(p) pcm_emu::ds_read_tr16_b64((const void*)(p))
 #else
 #define PCM_DS_READ_TR16(p) __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(p))
+#endif
+// The builtin form above is tracked by hipcc like any LDS read -- including against pending LDS-DMA writes: in a loop that keeps
+// buffer_load...lds pieces in flight across its barriers hipcc puts s_waitcnt vmcnt(0) in front of the first builtin read and drains the
+// prefetch (measured on wgrad_tr.hip).  PCM_TR16_ISSUE is the same instruction as inline asm (guide section 5.7): hipcc neither counts
+// nor waits for it, so (1) it can be issued EARLY (e.g. the V^T fragments of an attention tile before the softmax) and (2) it does not
+// drain the DMA queue; the destination is valid only after PCM_TR16_WAITn(...) naming every destination (data dependence for the
+// consumers).  ``imm`` must be a compile-time constant < 65536 (pcm_static_for gives loop indices as constants).
+#ifdef PCM_HOST_EMU
+#define PCM_TR16_ISSUE(dst, base, imm) (dst) = pcm_emu::ds_read_tr16_b64((const char*)(base) + (imm))
+#define PCM_TR16_WAIT8(a, b, c, d, e, f, g, h) ((void)0)
+#define PCM_TR16_KEEP8(a, b, c, d, e, f, g, h) ((void)0)
+#define PCM_TR16_WAIT4(a, b, c, d) ((void)0)
+#define PCM_TR16_WAIT2(a, b) ((void)0)
+#else
+#define PCM_TR16_ISSUE(dst, base, imm) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"((unsigned)(size_t)(base)), "n"(imm))
+#define PCM_TR16_WAIT8(a, b, c, d, e, f, g, h) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h))
+#define PCM_TR16_KEEP8(a, b, c, d, e, f, g, h) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h))
+#define PCM_TR16_WAIT4(a, b, c, d) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
+#define PCM_TR16_WAIT2(a, b) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b))
 #endif
 __device__ __forceinline__ bf16x8 pcm_join4(bf16x4 a, bf16x4 b) { return bf16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]}; }
 typedef float f32x16 __attribute__((ext_vector_type(16)));

@@ -79,12 +79,26 @@ __global__ __launch_bounds__(256) void pcm_wgrad_tr_kernel(WgDev a) {
     __builtin_amdgcn_s_barrier();            // every wave's pieces of stage st have landed
     const char* B = smem + (st & 1) * STAGE;
     const char* S = B + BIGB;
+    // all 24 transpose reads of the stage as untracked asm reads (the builtin form makes hipcc drain the DMA queue: pcm_common.h), one wait
+    bf16x4 alo[4], ahi[4], blo[2][4], bhi[2][4];
+    const char* pa = B + a_base;
+    const char* pb0 = S + b_base[0];
+    const char* pb1 = S + b_base[1];
+#define WT_KS(KS)                                                                                                   \
+  PCM_TR16_ISSUE(alo[KS], pa, (16 * KS) * 256); PCM_TR16_ISSUE(ahi[KS], pa, (16 * KS + 4) * 256);                    \
+  PCM_TR16_ISSUE(blo[0][KS], pb0, (16 * KS) * 128); PCM_TR16_ISSUE(bhi[0][KS], pb0, (16 * KS + 4) * 128);            \
+  PCM_TR16_ISSUE(blo[1][KS], pb1, (16 * KS) * 128); PCM_TR16_ISSUE(bhi[1][KS], pb1, (16 * KS + 4) * 128);
+    WT_KS(0) WT_KS(1) WT_KS(2) WT_KS(3)
+#undef WT_KS
+    PCM_TR16_WAIT8(alo[0], ahi[0], alo[1], ahi[1], alo[2], ahi[2], alo[3], ahi[3]);
+    PCM_TR16_KEEP8(blo[0][0], bhi[0][0], blo[0][1], bhi[0][1], blo[0][2], bhi[0][2], blo[0][3], bhi[0][3]);
+    PCM_TR16_KEEP8(blo[1][0], bhi[1][0], blo[1][1], bhi[1][1], blo[1][2], bhi[1][2], blo[1][3], bhi[1][3]);
 #pragma unroll
     for (int ks = 0; ks < 4; ks++) {
-      const bf16x8 af = pcm_join4(PCM_DS_READ_TR16(B + a_base + (16 * ks) * 256), PCM_DS_READ_TR16(B + a_base + (16 * ks + 4) * 256));
+      const bf16x8 af = pcm_join4(alo[ks], ahi[ks]);
 #pragma unroll
       for (int rt = 0; rt < 2; rt++) {
-        const bf16x8 bf = pcm_join4(PCM_DS_READ_TR16(S + b_base[rt] + (16 * ks) * 128), PCM_DS_READ_TR16(S + b_base[rt] + (16 * ks + 4) * 128));
+        const bf16x8 bf = pcm_join4(blo[rt][ks], bhi[rt][ks]);
         acc[rt] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf, af, acc[rt], 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[rt], 0, 0, 0);
       }
     }
@@ -164,6 +178,9 @@ __global__ __launch_bounds__(256) void pcm_wgrad_tr_conv_kernel(WgDev a) {
       const int pl = 16 * ks + 8 * kg + 4 * h, yl = pl >> lw, xl = pl & (Wt - 1);
       u_base[ks][h] = (yl * WP + xl + j) * 128 + (32 * wr + 16 * cb + 4 * q) * 2;
     }
+  int toff[9];                                 // wave-uniform: entry of pixel p - off(tap) relative to tap (2, 2), in bytes
+#pragma unroll
+  for (int t = 0; t < 9; t++) toff[t] = ((2 - t / 3) * WP + (2 - t % 3)) * 128;
   f32x16 acc[9];
 #pragma unroll
   for (int t = 0; t < 9; t++)
@@ -176,16 +193,35 @@ __global__ __launch_bounds__(256) void pcm_wgrad_tr_conv_kernel(WgDev a) {
     __builtin_amdgcn_s_barrier();
     const char* X = smem + (st & 1) * STAGE;
     const char* U = X + XB;
-#pragma unroll
-    for (int ks = 0; ks < 4; ks++) {
-      const bf16x8 xf = pcm_join4(PCM_DS_READ_TR16(X + x_base + (16 * ks) * 128), PCM_DS_READ_TR16(X + x_base + (16 * ks + 4) * 128));
-#pragma unroll
-      for (int t = 0; t < 9; t++) {
-        const int toff = ((2 - t / 3) * WP + (2 - t % 3)) * 128;       // wave-uniform: entry of pixel p - off(tap) relative to tap (2,2)
-        const bf16x8 uf = pcm_join4(PCM_DS_READ_TR16(U + u_base[ks][0] + toff), PCM_DS_READ_TR16(U + u_base[ks][1] + toff));
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uf, xf, acc[t], 0, 0, 0);      // D[i = r][j = c]
-      }
-    }
+    // 12 pipeline steps per stage = 4 k-steps x 3 tap rows: step n waits for its own fragments (x of the k-step + 3 shifted u), puts the
+    // fragments of step n+1 in flight (untracked asm reads, double-buffered registers) and multiplies -- LDS latency under 3 MFMAs
+    bf16x4 xlo[2], xhi[2], ulo[2][3], uhi[2][3];
+    const char* px = X + x_base;
+#define WC_ISSUE(N)                                                                                                  \
+  {                                                                                                                  \
+    constexpr int KS = (N) / 3, G = (N) % 3, BU = (N) & 1;                                                           \
+    if (G == 0) { PCM_TR16_ISSUE(xlo[KS & 1], px, (16 * KS) * 128); PCM_TR16_ISSUE(xhi[KS & 1], px, (16 * KS + 4) * 128); } \
+    const char* q0 = U + u_base[KS][0];                                                                              \
+    const char* q1 = U + u_base[KS][1];                                                                              \
+    PCM_TR16_ISSUE(ulo[BU][0], q0 + toff[3 * G + 0], 0); PCM_TR16_ISSUE(uhi[BU][0], q1 + toff[3 * G + 0], 0);         \
+    PCM_TR16_ISSUE(ulo[BU][1], q0 + toff[3 * G + 1], 0); PCM_TR16_ISSUE(uhi[BU][1], q1 + toff[3 * G + 1], 0);         \
+    PCM_TR16_ISSUE(ulo[BU][2], q0 + toff[3 * G + 2], 0); PCM_TR16_ISSUE(uhi[BU][2], q1 + toff[3 * G + 2], 0);         \
+  }
+#define WC_STEP(N)                                                                                                   \
+  {                                                                                                                  \
+    constexpr int KS = (N) / 3, G = (N) % 3, BU = (N) & 1;                                                           \
+    PCM_TR16_WAIT8(xlo[KS & 1], xhi[KS & 1], ulo[BU][0], uhi[BU][0], ulo[BU][1], uhi[BU][1], ulo[BU][2], uhi[BU][2]); \
+    const bf16x8 xf = pcm_join4(xlo[KS & 1], xhi[KS & 1]);                                                           \
+    const bf16x8 u0 = pcm_join4(ulo[BU][0], uhi[BU][0]), u1 = pcm_join4(ulo[BU][1], uhi[BU][1]), u2 = pcm_join4(ulo[BU][2], uhi[BU][2]); \
+    if ((N) + 1 < 12) WC_ISSUE(((N) + 1) % 12)                                                                       \
+    acc[3 * G + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u0, xf, acc[3 * G + 0], 0, 0, 0);   /* D[i = r][j = c] */ \
+    acc[3 * G + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u1, xf, acc[3 * G + 1], 0, 0, 0);                       \
+    acc[3 * G + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u2, xf, acc[3 * G + 2], 0, 0, 0);                       \
+  }
+    WC_ISSUE(0)
+    WC_STEP(0) WC_STEP(1) WC_STEP(2) WC_STEP(3) WC_STEP(4) WC_STEP(5) WC_STEP(6) WC_STEP(7) WC_STEP(8) WC_STEP(9) WC_STEP(10) WC_STEP(11)
+#undef WC_ISSUE
+#undef WC_STEP
     PCM_WAIT_LGKMCNT0();
     __builtin_amdgcn_s_barrier();
   }
@@ -205,8 +241,8 @@ static int g_wgtr_mode = -1;     // -1: PCM_WGRAD_TR env (default 1); 0 = always
 extern "C" void pcm_debug_wgrad_tr(int mode) { g_wgtr_mode = mode; }
 static long g_wgtr_count[2] = {0, 0};   // tests: launches taken by the plain / conv kernel
 extern "C" long pcm_debug_wgrad_tr_count(int conv) { return g_wgtr_count[conv ? 1 : 0]; }
-static int g_wgtr_blocks = 512;
-extern "C" void pcm_debug_wgrad_tr_blocks(int n) { g_wgtr_blocks = n > 0 ? n : 512; }
+static int g_wgtr_blocks = 512, g_wgtr_auto = 1;      // tuning hook: n > 0 forces ~n blocks, 0 restores the shipped rule
+extern "C" void pcm_debug_wgrad_tr_blocks(int n) { g_wgtr_auto = n <= 0; g_wgtr_blocks = n > 0 ? n : 512; }
 
 int pcm_wgrad_tr_launch(const WgDev& a0, void* stream) {
   if (g_wgtr_mode < 0) { const char* e = getenv("PCM_WGRAD_TR"); g_wgtr_mode = e ? atoi(e) : 1; }
@@ -218,9 +254,14 @@ int pcm_wgrad_tr_launch(const WgDev& a0, void* stream) {
   if (!conv) {
     if ((size_t)a.M * a.ldb * 2 >= 0x7ff00000u) return 1;
     const int tiles_g = cdiv(a.G, 128), stages = cdiv(a.M, 64);
-    // split over M: ~g_wgtr_blocks blocks (two per CU), at least 4 stages per block so that the 8192 fp32 atomics a block ends with stay small
-    int msplit = cdiv(PCM_GRID_CAP(g_wgtr_blocks), tiles_g);
-    if (msplit > cdiv(stages, 4)) msplit = cdiv(stages, 4);
+    // split over M.  A block ends with 8192 fp32 atomics (32 KB) against 24 KB of operand reads per stage, and the L2 atomic units, not
+    // HBM, bound the launch once the atomics pass ~10 % of the reads: measured (MI355X, tools/gpu_job_f.sh) M = 65536 x G = 320 best at
+    // 128..256 blocks (17 us; 512: 23.5), G = 2560 at ~1024 (71 us), so: msplit = M / 1024 rows, but at least ~128 blocks in all.
+    int msplit = a.M / 1024;
+    if (msplit * tiles_g < 128) msplit = cdiv(128, tiles_g);
+    if (!g_wgtr_auto) msplit = cdiv(PCM_GRID_CAP(g_wgtr_blocks), tiles_g);
+    if (msplit * tiles_g > PCM_GRID_CAP(2048)) msplit = cdiv(PCM_GRID_CAP(2048), tiles_g);
+    if (msplit > cdiv(stages, 2)) msplit = cdiv(stages, 2);
     if (msplit < 1) msplit = 1;
     a.m_per_block = cdiv(stages, msplit) * 64;
     msplit = cdiv(a.M, a.m_per_block);
@@ -232,10 +273,13 @@ int pcm_wgrad_tr_launch(const WgDev& a0, void* stream) {
   }
   const int W = a.Wo, HW = a.Ho * a.Wo;
   const bool wok = W >= 64 ? (W % 64) == 0 : (W >= 4 && (W & (W - 1)) == 0);
+  if (a.M < 4096) return 1;   // few stages per block: staging the 28 KB window per 64 pixels costs more than wgrad.hip's 9 passes (8x8x1280: 24 vs 17 us)
   if (a.stride != 1 || a.src_mode != PCM_SRC_DIRECT || a.Hs != a.Ho || a.Ws != a.Wo || !wok || (HW % 64) || (a.C % 64) || !a.swap) return 1;
   if ((size_t)a.M * a.C * 2 >= 0x7ff00000u) return 1;
   const int tiles_c = a.C / 64, stages = a.M / 64;
-  int msplit = cdiv(PCM_GRID_CAP(g_wgtr_blocks), tiles_c);
+  // a block ends with 36864 fp32 atomics (9 taps x 64 x 64): measured best at 128..256 blocks for every UNet level (64x64x320: 80 us at
+  // 128..256 blocks, 100 at 512, 216 at 2048; 16x16x1280: 32 us at 128, 58 at 512) -- ~160 blocks, never less than 2 stages per block
+  int msplit = cdiv(g_wgtr_auto ? 160 : PCM_GRID_CAP(g_wgtr_blocks), tiles_c);
   if (msplit > cdiv(stages, 2)) msplit = cdiv(stages, 2);
   if (msplit < 1) msplit = 1;
   a.m_per_block = cdiv(stages, msplit) * 64;

@@ -325,6 +325,40 @@ def layer_fwd(W: UNetWeights, lora, path, x, M, geo=None, save=None, rowvec=None
     return y
 
 
+class WgradSide:
+    """LoRA weight-gradient launches on a SIDE stream.  The backward's critical path is the input-gradient chain (dgrad GEMMs, attention,
+    norms); the weight gradients hang off it as leaves (they only feed the flat gradient buffer) and are latency / atomics bound, so they
+    run beside the chain: fork after the operands exist, join once at the end of the backward.  Works under hipGraph capture (the side
+    stream is forked from the capturing stream, so its launches become parallel branches of the same graph).  Operand tensors are kept
+    alive until the join: the caching allocator must not hand their memory to a later main-stream allocation while the side stream reads."""
+
+    def __init__(self):
+        self.stream, self.keep = torch.cuda.Stream(), []
+
+    def run(self, fn, *tensors):
+        self.stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.stream):
+            fn()
+        self.keep.extend(tensors)
+
+    def join(self):
+        torch.cuda.current_stream().wait_stream(self.stream)
+        self.keep.clear()
+
+
+_SIDE = None      # set by UNet.backward for the duration of one backward pass (None: weight gradients inline, e.g. host emulation)
+# opt-in (PCM_WGRAD_SIDE=1): measured neutral on one MI355X at bs 16 (126.1 ms/step inline vs 127.0 with the side stream: the dgrad GEMM
+# blocks own a CU's whole LDS, so the weight-gradient blocks only find room between launches, and a multi-branch hipGraph enqueues slower)
+WGRAD_SIDE_STREAM = os.environ.get("PCM_WGRAD_SIDE", "0") == "1"
+
+
+def _wgrad(fn, *tensors):
+    if _SIDE is not None:
+        _SIDE.run(fn, *tensors)
+    else:
+        fn()
+
+
 def layer_bwd(W: UNetWeights, lora, path, dy, saved, need_dx=True, residual=None):
     """dy [M, N] -> dx ([M_in, K] or NHWC of the source); accumulates LoRA grads.  ``residual`` is
     added to dx in the GEMM epilogue."""
@@ -335,12 +369,15 @@ def layer_bwd(W: UNetWeights, lora, path, dy, saved, need_dx=True, residual=None
     if lm is not None:
         u = torch.empty(M, lm.r, dtype=BF16, device=dy.device)
         ops.gemm([Seg(dy, lm.Bs_bwd)], M, lm.r, u)                      # u = dy (sB)   [M, r]
-        ops.lora_wgrad(dy, t, lm.gB, lora.scaling, M, G=L.N, g_stride=lm.r, r_stride=1)   # dB = s dy^T t
-        if L.kind == "conv3":
-            ops.lora_wgrad(x, u, lm.gA, 1.0, M, conv=dict(Hs=geo.Hs, Ws=geo.Ws, Ho=geo.Ho, Wo=geo.Wo, stride=geo.stride,
-                                                          src_mode=geo.src_mode), g_stride=1, r_stride=L.K)
-        else:
-            ops.lora_wgrad(x, u, lm.gA, 1.0, M, G=L.K, g_stride=1, r_stride=L.K)          # dA = u^T x
+
+        def wg():
+            ops.lora_wgrad(dy, t, lm.gB, lora.scaling, M, G=L.N, g_stride=lm.r, r_stride=1)   # dB = s dy^T t
+            if L.kind == "conv3":
+                ops.lora_wgrad(x, u, lm.gA, 1.0, M, conv=dict(Hs=geo.Hs, Ws=geo.Ws, Ho=geo.Ho, Wo=geo.Wo, stride=geo.stride,
+                                                              src_mode=geo.src_mode), g_stride=1, r_stride=L.K)
+            else:
+                ops.lora_wgrad(x, u, lm.gA, 1.0, M, G=L.K, g_stride=1, r_stride=L.K)          # dA = u^T x
+        _wgrad(wg, dy, t, x, u)
     if not need_dx:
         return None
     if L.kind == "conv3":
@@ -381,6 +418,7 @@ class UNet:
     def __init__(self, weights: UNetWeights, lora: LoraState = None):
         self.W, self.lora, self.cfg = weights, lora, weights.cfg
         self._arena = None      # per-pass arena of pre-zeroed GroupNorm statistics (ops.StatArena)
+        self._side = None       # WgradSide of this runner's backward passes
 
     # ---- norm helpers ----
     def _gn(self, path, x, act, eps, save):
@@ -493,9 +531,11 @@ class UNet:
                          sv["lse"], Hh, d, out=(dq, dk, dv))
             u3 = torch.empty(M, fq.r3, dtype=BF16, device=d_o.device)
             ops.gemm([Seg(d3, fq.Bs_cat_bwd, k_algo=C)], M, fq.r3, u3)                  # u_j = d_j (s B_j): block-diagonal operand
-            for j, (lm, dj) in enumerate(((fq.q, dq), (fq.k, dk), (fq.v, dv))):
-                ops.lora_wgrad(dj, t3[:, j * r:(j + 1) * r], lm.gB, lora.scaling, M, G=C, g_stride=r, r_stride=1, ldb=3 * C, lds=fq.r3)
-                ops.lora_wgrad(x, u3[:, j * r:(j + 1) * r], lm.gA, 1.0, M, G=fq.K, g_stride=1, r_stride=fq.K, lds=fq.r3)
+            def wg():
+                for j, (lm, dj) in enumerate(((fq.q, dq), (fq.k, dk), (fq.v, dv))):
+                    ops.lora_wgrad(dj, t3[:, j * r:(j + 1) * r], lm.gB, lora.scaling, M, G=C, g_stride=r, r_stride=1, ldb=3 * C, lds=fq.r3)
+                    ops.lora_wgrad(x, u3[:, j * r:(j + 1) * r], lm.gA, 1.0, M, G=fq.K, g_stride=1, r_stride=fq.K, lds=fq.r3)
+            _wgrad(wg, d3, t3, x, u3)
             d_xn = torch.empty(M, fq.K, dtype=BF16, device=d_o.device)
             ops.gemm([Seg(d3, W.qkv_bwd[p]), Seg(u3, fq.A_cat_bwd)], M, fq.K, d_xn)
             return d_xn
@@ -696,6 +736,21 @@ class UNet:
         Feature-tap tapes (``forward(features=True, save=True)``) take ``d_feats`` (list of 9 gradients, entries may
         be None) instead of d_eps.  ``need_input_grad`` also back-propagates through the first resnet and conv_in and
         returns d sample [B,4,H,W] fp32 (the generator step's path through the frozen teacher, sd15_adv.py:1414-1424)."""
+        global _SIDE
+        W, lora, cfg = self.W, self.lora, self.cfg
+        dev_ = d_eps.device if d_eps is not None else self.W.conv_in[0].device
+        if lora is not None and WGRAD_SIDE_STREAM and dev_.type == "cuda":
+            if self._side is None:
+                self._side = WgradSide()
+            _SIDE = self._side
+        try:
+            return self._backward(d_eps, tape, d_feats, need_input_grad)
+        finally:
+            if _SIDE is not None:
+                _SIDE.join()
+            _SIDE = None
+
+    def _backward(self, d_eps, tape, d_feats, need_input_grad):
         W, lora, cfg = self.W, self.lora, self.cfg
         self._arena = ops.StatArena.for_pass(d_eps.device if d_eps is not None else self.W.conv_in[0].device, W, tape[-1][2]["B"], cfg.norm_num_groups)
         kind, _, sv = tape[-1]

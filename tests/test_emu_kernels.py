@@ -77,7 +77,7 @@ def test_wgrad_conv(stride, src_mode):
 
 # geometries the LDS-DMA + transpose-read kernels take (wgrad_tr.hip): 8x8 (8 image rows per 64-pixel stage), 16x16 (4 rows), 64-wide
 # (one row per stage, two channel tiles), 128-wide (two stages per image row); the plain cases above cover the plain kernel incl. ragged M
-@pytest.mark.parametrize("B,H,W,C", [(2, 8, 8, 64), (1, 16, 16, 128), (1, 2, 64, 64), (1, 1, 128, 64), (3, 4, 16, 64)])
+@pytest.mark.parametrize("B,H,W,C", [(64, 8, 8, 64), (16, 16, 16, 128), (32, 2, 64, 64), (32, 1, 128, 64), (64, 4, 16, 64)])
 def test_wgrad_conv_transpose_read_kernel(B, H, W, C):
     import ctypes
     from pcm_amd import capi
