@@ -114,7 +114,9 @@ class LatentSource:
         self.shards, self.uncond = None, None
         if args.latents_dir:
             from safetensors.torch import load_file
-            files = sorted(glob.glob(os.path.join(args.latents_dir, "*.safetensors")))[rank::world]
+            every = sorted(glob.glob(os.path.join(args.latents_dir, "*.safetensors")))
+            files = every[rank::world]
+            self.uncond = find_in_shards(every, "uncond_prompt_embeds", device)      # one global tensor: "in any shard", whichever rank reads it
             if not files:
                 raise FileNotFoundError(f"no shards for rank {rank} in {args.latents_dir}")
             data = [load_file(f) for f in files]
@@ -129,8 +131,13 @@ class LatentSource:
             self.shards = True
         elif not args.synthetic_data:
             raise SystemExit("pcm_amd: give --latents_dir or --synthetic_data (VAE/CLIP encoding is out of scope, see --help)")
-        if self.uncond is None:
-            self.uncond = torch.randn(77, 768, generator=self.g, device=device) if not self.shards else torch.zeros_like(self.pe[0])
+        if self.uncond is None and self.shards:
+            # the CFG teacher step needs the CLIP encoding of the empty caption (train_pcm_lora_sd15.py:1053-1059); zeros or noise in its
+            # place would distill against a meaningless guidance direction without any sign of it
+            raise SystemExit("pcm_amd: --latents_dir shards carry no 'uncond_prompt_embeds' [77,768] (the encoding of the empty prompt): "
+                             "add it to any one shard")
+        if self.uncond is None:       # --synthetic_data only
+            self.uncond = torch.randn(77, 768, generator=self.g, device=device)
         self.uncond = self.uncond.expand(self.bs, *self.uncond.shape[-2:]).contiguous()
 
     def __len__(self):
@@ -147,6 +154,27 @@ class LatentSource:
             drop = torch.rand(self.bs, generator=self.g, device=self.device) < self.p_empty
             pe = torch.where(drop[:, None, None], self.uncond, pe)
         return lat, pe
+
+
+def find_in_shards(files, key, device):
+    """A run-global tensor (the unconditional embedding) may sit in ANY shard, not necessarily in one this rank trains on."""
+    from safetensors import safe_open
+    for f in files:
+        with safe_open(f, "pt") as sf:
+            if key in sf.keys():
+                return sf.get_tensor(key).float().to(device)
+    return None
+
+
+def agreed_steps_per_epoch(n_local, world):
+    """Ranks read disjoint shard subsets ([rank::world]) that need not hold the same number of samples; every rank must run the SAME number
+    of steps or the gradient all-reduce of the longer ranks never completes: take the minimum over the ranks (one tiny all-reduce)."""
+    if world <= 1 or not torch.distributed.is_initialized():
+        return n_local
+    backend = torch.distributed.get_backend()
+    t = torch.tensor([n_local], dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
+    torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MIN)
+    return int(t.item())
 
 
 def pick_device(local_rank):
@@ -260,7 +288,7 @@ def main(args):
                      ema_rate=args.ema_rate)
     D = Distiller(W, lora, cfg, world_size=world)
     src = LatentSource(args, rank, world, device)
-    steps_per_epoch = len(src)
+    steps_per_epoch = agreed_steps_per_epoch(len(src), world)
     if args.max_train_steps is None:
         args.max_train_steps = args.num_train_epochs * steps_per_epoch
     global_step = 0

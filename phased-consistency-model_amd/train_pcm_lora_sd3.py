@@ -121,21 +121,26 @@ class SD3Source:
         un, unp = None, None
         if args.latents_dir:
             from safetensors.torch import load_file
-            files = sorted(glob.glob(os.path.join(args.latents_dir, "*.safetensors")))[rank::world]
+            every = sorted(glob.glob(os.path.join(args.latents_dir, "*.safetensors")))
+            files = every[rank::world]
+            un = base.find_in_shards(every, "uncond_prompt_embeds", device)          # run-global: may sit in a shard of another rank
+            unp = base.find_in_shards(every, "uncond_pooled_prompt_embeds", device)
             if not files:
                 raise FileNotFoundError(f"no shards for rank {rank} in {args.latents_dir}")
             data = [load_file(f) for f in files]
             self.lat = torch.cat([d["latents"] for d in data]).float().to(device)
             self.pe = torch.cat([d["prompt_embeds"] for d in data]).float().to(device)
             self.pp = torch.cat([d["pooled_prompt_embeds"] for d in data]).float().to(device)
-            for d in data:
-                un = d.get("uncond_prompt_embeds", un)
-                unp = d.get("uncond_pooled_prompt_embeds", unp)
             self.Lc = self.pe.shape[1]
             self.shards = True
         elif not args.synthetic_data:
             raise SystemExit("pcm_amd: give --latents_dir or --synthetic_data (VAE / text encoding is out of scope, see --help)")
-        if un is None:
+        if self.shards and (un is None or unp is None):
+            # the w = 3 CFG teacher step needs the text encoders' output for the empty caption (train_pcm_lora_sd3.py:1216-1226); a random
+            # stand-in would distill against a meaningless guidance direction without any sign of it
+            raise SystemExit("pcm_amd: --latents_dir shards carry no 'uncond_prompt_embeds' / 'uncond_pooled_prompt_embeds' (the encoding of "
+                             "the empty prompt): add them to any one shard")
+        if un is None:       # --synthetic_data only
             un = torch.randn(self.Lc, self.jd, generator=self.g, device=device)
         if unp is None:
             unp = torch.randn(self.pd, generator=self.g, device=device)
@@ -221,7 +226,7 @@ def main(args):
     D = SD3Distiller(W, lora, cfg, world_size=world)
     src = SD3Source(args, rank, world, device, mcfg)
     if args.max_train_steps is None:
-        args.max_train_steps = args.num_train_epochs * len(src)
+        args.max_train_steps = args.num_train_epochs * base.agreed_steps_per_epoch(len(src), world)
     global_step = 0
     if rank == 0:
         os.makedirs(os.path.join(args.output_dir, args.logging_dir), exist_ok=True)

@@ -94,7 +94,7 @@ def main(args):
     D = SD3AdvDistiller(W, lora, cfg, disc, adv_weight=args.adv_weight, adv_lr=args.adv_lr, loss_type=args.loss_type, world_size=world)
     src = sd3.SD3Source(args, rank, world, device, mcfg)
     if args.max_train_steps is None:
-        args.max_train_steps = args.num_train_epochs * len(src)
+        args.max_train_steps = args.num_train_epochs * base.agreed_steps_per_epoch(len(src), world)
     global_step, gen_steps = 0, 0
     if rank == 0:
         os.makedirs(os.path.join(args.output_dir, args.logging_dir), exist_ok=True)

@@ -133,7 +133,7 @@ def main(args):
         D = Distiller(W, lora, cfg, world_size=world)
     src = SdxlSource(args, rank, world, device)
     if args.max_train_steps is None:
-        args.max_train_steps = args.num_train_epochs * len(src)
+        args.max_train_steps = args.num_train_epochs * base.agreed_steps_per_epoch(len(src), world)
     if rank == 0:
         os.makedirs(os.path.join(args.output_dir, args.logging_dir), exist_ok=True)
     global_step = gen_steps = 0
