@@ -16,19 +16,21 @@
 #include "pcm_common.h"
 
 #define LOG2E 1.4426950408889634f
-// timing ablations of the forward kernel (tools/attn_ablate.py, -DPCM_ABLATE builds only; results are wrong by construction):
-// 1 = no exp (p = scaled score), 2 = no global loads / LDS restage inside the loop, 4 = no PV MFMAs, 8 = no QK^T MFMAs, 16 = no barriers
+// cycle stamps of the forward kernel (tools/attn_timeline.py, -DPCM_ABLATE builds only): lane 0 of every wave of ONE mid-grid workgroup
+// records s_memtime at 6 points of each of its first 32 key tiles
 #ifdef PCM_ABLATE
-static int g_attn_ablate = 0;
-extern "C" void pcm_debug_attn_ablate(int m) { g_attn_ablate = m; }
-#define ATTN_DBG_PARAM , int dbg
-#define ATTN_DBG_ARG , g_attn_ablate
-#define ATTN_ABL(bit) (dbg & (bit))
+__device__ unsigned long long g_attn_stamps[4][32][8];
+extern "C" int pcm_debug_attn_stamps(unsigned long long* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_attn_stamps), sizeof(g_attn_stamps)); }
+#define ATTN_STAMP(k)                                                                                                        \
+  do {                                                                                                                       \
+    if (stamp_on && (kv0 >> 6) < 32 && lane == 0) g_attn_stamps[wave][kv0 >> 6][k] = __builtin_readcyclecounter();          \
+  } while (0)
 #else
+#define ATTN_STAMP(k) do { } while (0)
+#endif
 #define ATTN_DBG_PARAM
 #define ATTN_DBG_ARG
 #define ATTN_ABL(bit) 0
-#endif
 
 template <int D>
 struct AttnCfg {
@@ -189,15 +191,22 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* q, const bf
   const TrFrag<D> trf(lane);
   RowStage<D, 64> kst, vst;
   if (AttnPrefetch<D>::value) { kst.load(kb, ldk, 0, Lk, tid); vst.load(vb, ldk, 0, Lk, tid); }
+#ifdef PCM_ABLATE
+  const bool stamp_on = blockIdx.x == gridDim.x / 2 && blockIdx.y == gridDim.y / 2 && blockIdx.z == gridDim.z / 2;
+#endif
   for (int kv0 = 0; kv0 < Lk; kv0 += 64) {
+    ATTN_STAMP(0);
     if (!ATTN_ABL(16)) __syncthreads();
+    ATTN_STAMP(1);
     if (AttnPrefetch<D>::value) {
       if (!ATTN_ABL(2) || kv0 == 0) { kst.store(Ks, Lk, tid); vst.store(Vs, Lk, tid); }
     } else {
       load_rowmajor<D, 64>(Ks, kb, ldk, kv0, Lk, tid);
       load_rowmajor<D, 64>(Vs, vb, ldk, kv0, Lk, tid);
     }
+    ATTN_STAMP(2);
     if (!ATTN_ABL(16)) __syncthreads();
+    ATTN_STAMP(3);
     if (AttnPrefetch<D>::value && kv0 + 64 < Lk && !ATTN_ABL(2)) { kst.load(kb, ldk, kv0 + 64, Lk, tid); vst.load(vb, ldk, kv0 + 64, Lk, tid); }
     f32x16 s_[2];
 #pragma unroll
@@ -226,12 +235,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* q, const bf
           if (kv >= Lk) s_[t][r] = -1e30f;
         }
     }
-    float mx = -1e30f;
+    // row maximum: four independent chains (a single chain of 16 dependent v_max3 sits on the critical path between the QK^T MFMAs and
+    // the exponentials), halves combined by a VALU lane swap
+    float mxa[4] = {-1e30f, -1e30f, -1e30f, -1e30f};
 #pragma unroll
     for (int t = 0; t < 2; t++)
 #pragma unroll
-      for (int r = 0; r < 16; r++) mx = fmaxf(mx, s_[t][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
+      for (int r = 0; r < 16; r++) mxa[r & 3] = fmaxf(mxa[r & 3], s_[t][r]);
+    float mx = pcm_xhalf_max(fmaxf(fmaxf(mxa[0], mxa[1]), fmaxf(mxa[2], mxa[3])));
     float m_new = fmaxf(m_run, mx * sc);
     float psum = 0.f;
 #pragma unroll
@@ -256,6 +267,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* q, const bf
     bf16x8 pf[4];
 #pragma unroll
     for (int ss = 0; ss < 4; ss++) pf[ss] = pack_frag(s_[ss >> 1], ss & 1);
+    ATTN_STAMP(4);
     if constexpr (V_EARLY) {
       vq[0].wait();
       pcm_static_for<1, C::DV>([&](auto it) { vq[decltype(it)::value].keep(); });
@@ -267,8 +279,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* q, const bf
 #pragma unroll
       for (int ss = 0; ss < 4; ss++) acc_o[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v4.frag(ss), pf[ss], acc_o[i], 0, 0, 0);
     });
+    ATTN_STAMP(5);
   }
-  float l_tot = l_run + __shfl_xor(l_run, 32);
+  float l_tot = pcm_xhalf_sum(l_run);
   if constexpr (ONES) {   // accumulator row D: tile D/32, local row D%32 -> lane half (loc>>2)&1 (= 0 for 40 / 80), register (loc&3) + 4*(loc>>3)
     constexpr int LOC = D % 32;
     static_assert(((LOC >> 2) & 1) == 0, "ones row must sit in the low lane half");

@@ -127,6 +127,21 @@ __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f +
 __device__ __forceinline__ float gelu_erf_grad_f(float x) {
   return 0.5f * (1.0f + pcm_erf_f(x * 0.70710678118654752f)) + x * 0.3989422804014327f * PCM_EXPF(-0.5f * x * x);
 }
+// combine a value with the one held by the lane 32 apart (the two halves of a 32x32 MFMA accumulator column).  v_permlane32_swap is a VALU
+// instruction: no LDS round trip and no lgkmcnt wait in the middle of a softmax (ds_bpermute is both).
+#ifdef PCM_HOST_EMU
+__device__ __forceinline__ float pcm_xhalf_max(float v) { return fmaxf(v, __shfl_xor(v, 32)); }
+__device__ __forceinline__ float pcm_xhalf_sum(float v) { return v + __shfl_xor(v, 32); }
+#else
+__device__ __forceinline__ float pcm_xhalf_max(float v) {
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float pcm_xhalf_sum(float v) {
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+#endif
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

@@ -23,7 +23,7 @@ ADAPTER_DIMS_SDXL = (320, 640, 1280, 1280)                            # discrimi
 
 
 class Head:
-    __slots__ = ("C", "p", "g", "wf", "wb")
+    __slots__ = ("C", "p", "g", "wf", "wb", "off0", "off1")
 
 
 class Discriminator:
@@ -60,6 +60,8 @@ class Discriminator:
         for k, h, C, offs in layout:
             hd = Head()
             hd.C = C
+            hd.off0 = min(o for o, _ in offs.values())                    # this head's range of the flat buffers
+            hd.off1 = max(o + (math.prod(shp) + 3) // 4 * 4 for o, shp in offs.values())
             hd.p = {n: self.params[o:o + math.prod(shp)].view(shp) for n, (o, shp) in offs.items()}
             hd.g = {n: self.grads[o:o + math.prod(shp)].view(shp) for n, (o, shp) in offs.items()}
             # torch default init of nn.Conv2d / nn.GroupNorm (DiscriminatorHead.__init__, :349-362)
@@ -134,11 +136,15 @@ class Discriminator:
                 tape.append(dict(f=f, H=H, W=W, B=B, a1=a1, st1=st1, n1=n1, a2=a2, st2=st2, h2=h2))
         return (logits, tape) if save else logits
 
-    def backward(self, d_logits, tape, param_grads=True, feature_grads=False):
+    def backward(self, d_logits, tape, param_grads=True, feature_grads=False, on_bucket=None):
         """d_logits: 36 fp32 [M] gradients.  Accumulates parameter gradients (discriminator step) and / or returns
-        the 9 feature gradients (generator step)."""
+        the 9 feature gradients (generator step).  ``on_bucket(off0, off1)``: called when the parameter gradients of ALL heads of one
+        feature are final (flat range of self.grads) -- the data-parallel trainer starts that bucket's all-reduce behind the rest."""
         d_feats = [None] * self.head_num
-        for (k, hd), dl, sv in zip(self.heads, d_logits, tape):
+        first_of = {}
+        for i, (k, hd) in enumerate(self.heads):
+            first_of.setdefault(k, hd.off0)
+        for i, ((k, hd), dl, sv) in enumerate(zip(self.heads, d_logits, tape)):
             B, H, W, C = sv["B"], sv["H"], sv["W"], hd.C
             M = B * H * W
             geo = dict(Hs=H, Ws=W) if self.ksize == 3 else None
@@ -170,6 +176,8 @@ class Discriminator:
                 ops.gemm([Seg(d_a1 if geo else d_a1.reshape(M, C), hd.wb["conv1.0"], conv=geo)], M, C, d_f, residual=None if d_feats[k] is None else d_feats[k].view(M, C),
                          Ho=H, Wo=W)                                                   # 4 heads share one feature: sum in the epilogue
                 d_feats[k] = d_f.view(B, H * W, C)
+            if on_bucket is not None and param_grads and (i + 1 == len(self.heads) or self.heads[i + 1][0] != k):
+                on_bucket(first_of[k], hd.off1)
         return d_feats
 
     def _conv_param_grads(self, hd, name, x, dy, M, wg):
@@ -188,7 +196,7 @@ class Discriminator:
         capi.lib().call("pcm_colsum_bf16", ops.ptr(dy), ops.ptr(hd.g[name + ".bias"]), 1, M, C, capi.Lib.stream())
 
     # ------------------------------------------------------------------ losses (discriminator_sd15.py:412-434)
-    def d_loss_backward(self, logits_fake_real, tape, B_half, weight=1.0):
+    def d_loss_backward(self, logits_fake_real, tape, B_half, weight=1.0, on_bucket=None):
         """logits of the batched [fake; real] pass.  Returns loss (fp64 [1]); accumulates head gradients."""
         loss = torch.zeros(1, dtype=torch.float64, device=self.device)
         n_heads = self.head_num * self.nh
@@ -197,7 +205,7 @@ class Discriminator:
             half = lg.numel() // 2
             df, dr = ops.hinge_loss(lg[:half], lg[half:], 0, weight / n_heads, loss)
             d_logits.append(torch.cat([df, dr]))
-        self.backward(d_logits, tape, param_grads=True, feature_grads=False)
+        self.backward(d_logits, tape, param_grads=True, feature_grads=False, on_bucket=on_bucket)
         return loss
 
     def g_loss_backward(self, logits_fake, tape, weight=1.0, grad_scale=1.0):

@@ -140,6 +140,10 @@ class LoraState:
             layout.append((path, shp, total, total + rank * ain))
             total += rank * ain + shp[0] * rank
         self.numel = total
+        # flat-buffer offset of the first module of the mid / up blocks: the backward finishes [late_offset:] (up blocks, then mid) before it
+        # enters the down blocks, so that part of the gradient buffer can be all-reduced while the down blocks still back-propagate
+        late = [oa for path, _, oa, _ in layout if path.startswith(("mid_block", "up_blocks"))]
+        self.late_offset = min(late) if late and min(late) > 0 else None
         self.params = torch.zeros(total, dtype=torch.float32, device=self.device)
         self.grads = torch.zeros_like(self.params)
         self.exp_avg = torch.zeros_like(self.params)
@@ -731,7 +735,7 @@ class UNet:
             return v
         return [(kind, p, half(sv)) for kind, p, sv in tape]
 
-    def backward(self, d_eps, tape, d_feats=None, need_input_grad=False):
+    def backward(self, d_eps, tape, d_feats=None, need_input_grad=False, on_late=None):
         """d_eps [B,4,H,W] fp32 -> LoRA grads accumulated in self.lora.grads (if any).
         Feature-tap tapes (``forward(features=True, save=True)``) take ``d_feats`` (list of 9 gradients, entries may
         be None) instead of d_eps.  ``need_input_grad`` also back-propagates through the first resnet and conv_in and
@@ -744,13 +748,13 @@ class UNet:
                 self._side = WgradSide()
             _SIDE = self._side
         try:
-            return self._backward(d_eps, tape, d_feats, need_input_grad)
+            return self._backward(d_eps, tape, d_feats, need_input_grad, on_late)
         finally:
             if _SIDE is not None:
                 _SIDE.join()
             _SIDE = None
 
-    def _backward(self, d_eps, tape, d_feats, need_input_grad):
+    def _backward(self, d_eps, tape, d_feats, need_input_grad, on_late=None):
         W, lora, cfg = self.W, self.lora, self.cfg
         self._arena = ops.StatArena.for_pass(d_eps.device if d_eps is not None else self.W.conv_in[0].device, W, tape[-1][2]["B"], cfg.norm_num_groups)
         kind, _, sv = tape[-1]
@@ -765,6 +769,13 @@ class UNet:
         idx = len(tape) - 2
         while idx >= 0:
             kind, p, sv = tape[idx]
+            if on_late is not None and p is not None and p.startswith("down_blocks"):
+                # every LoRA gradient of the up and mid blocks is final (lora.grads[lora.late_offset:]): the data-parallel trainer starts
+                # that bucket's all-reduce here, behind the rest of the backward
+                if _SIDE is not None:
+                    _SIDE.join()
+                on_late()
+                on_late = None
             if kind == "feat":
                 df = d_feats[sv["k"]]
                 if df is not None:

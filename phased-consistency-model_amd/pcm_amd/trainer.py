@@ -7,7 +7,9 @@ Behavioural notes kept from the reference: the "target network" 
 LoRA weights under no-grad (update_ema is defined but never called; ``ema_rate`` here defaults to
 None = reference behaviour); ``w`` only scales the teacher CFG step; index 0 is a boundary sample.
 """
+import gc
 import math
+import os
 
 import numpy as np
 import torch
@@ -71,6 +73,9 @@ class Distiller:
         self.step_dev = torch.zeros(1, dtype=torch.int64, device=self.device)
         self.lr_dev = torch.full((1,), float(cfg.learning_rate), dtype=torch.float32, device=self.device)
         self._graph = None
+        self._late_work = None
+        # two-bucket gradient exchange (world_size > 1): the mid/up-block bucket is reduced while the down blocks back-propagate
+        self.bucketed = os.environ.get("PCM_DDP_BUCKETS", "1") != "0"
         self.ema = None
         if cfg.ema_rate is not None:
             self.ema = lora.params.clone()
@@ -82,7 +87,7 @@ class Distiller:
         return start, t
 
     def forward_backward(self, latents, prompt_embeds, uncond_prompt_embeds, noise, index, w, backward=True, added_cond=None,
-                         uncond_added_cond=None, grad_scale=1.0, zero_grad=True):
+                         uncond_added_cond=None, grad_scale=1.0, zero_grad=True, on_late=None):
         """Everything of the step before the gradient exchange: returns a dict of device tensors.
         ``added_cond`` / ``uncond_added_cond``: SDXL ``added_cond_kwargs`` ({'text_embeds': [B,1280], 'time_ids': [B,6]},
         train_pcm_lora_sdxl_adv.py:1113-1131, :1409-1421) for UNets with text_time conditioning; None for SD1.5."""
@@ -126,7 +131,7 @@ class Distiller:
             return out
         if zero_grad:
             self.lora.zero_grad()
-        self.student.backward(d_eps, tape)                                                       # :1296
+        self.student.backward(d_eps, tape, on_late=on_late)                                      # :1296
         return out
 
     def step(self, latents, prompt_embeds, uncond_prompt_embeds, noise, index, w, lr=None, update=True, added_cond=None,
@@ -137,8 +142,10 @@ class Distiller:
         ``accum=(i, k)``: micro-batch i of k under ``--gradient_accumulation_steps k`` (``accelerator.accumulate``, :1120): the loss
         gradient is scaled by 1/k, gradients add up over the k calls, and exchange + clip + AdamW run with the last one only."""
         i, k = accum if accum is not None else (0, 1)
+        bucket = self.world_size > 1 and update and i == k - 1 and self.lora.late_offset is not None and self.bucketed
         out = self.forward_backward(latents, prompt_embeds, uncond_prompt_embeds, noise, index, w, backward=update, added_cond=added_cond,
-                                    uncond_added_cond=uncond_added_cond, grad_scale=1.0 / k, zero_grad=(i == 0))
+                                    uncond_added_cond=uncond_added_cond, grad_scale=1.0 / k, zero_grad=(i == 0),
+                                    on_late=self._all_reduce_late if bucket else None)
         if not update or i < k - 1:
             return out
         if lr is not None:
@@ -168,10 +175,28 @@ class Distiller:
             self._optimizer_apply()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        self._g_fb, self._g_opt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        self._g_fb, self._g_opt, self._g_fb2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), None
+        split = (self.world_size > 1 and self.bucketed and lo.late_offset is not None) or os.environ.get("PCM_SPLIT_GRAPH") == "1"
         # thread_local: the RCCL watchdog thread of a multi-rank job may query its events while this thread captures
-        with torch.cuda.graph(self._g_fb, capture_error_mode="thread_local"):
-            self._static_out = self.forward_backward(**self._static)
+        if not split:
+            with torch.cuda.graph(self._g_fb, capture_error_mode="thread_local"):
+                self._static_out = self.forward_backward(**self._static)
+        else:
+            # data parallel: the forward + backward is captured as TWO graphs cut where the backward leaves the mid block, so that the
+            # all-reduce of the up/mid-block gradient bucket (not captured) is enqueued between them and overlaps the second graph
+            self._g_fb2 = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize(); gc.collect(); torch.cuda.empty_cache()
+            cap = torch.cuda.Stream()
+            cap.wait_stream(torch.cuda.current_stream())
+
+            def cut():
+                self._g_fb.capture_end()
+                self._g_fb2.capture_begin(pool=self._g_fb.pool(), capture_error_mode="thread_local")
+            with torch.cuda.stream(cap):
+                self._g_fb.capture_begin(capture_error_mode="thread_local")
+                self._static_out = self.forward_backward(**self._static, on_late=cut)
+                self._g_fb2.capture_end()
+            torch.cuda.current_stream().wait_stream(cap)
         with torch.cuda.graph(self._g_opt, pool=self._g_fb.pool(), capture_error_mode="thread_local"):
             self._optimizer_apply()
         for dst, src in zip((lo.params, lo.exp_avg, lo.exp_avg_sq, self.step_dev, self.lr_dev), saved):
@@ -193,15 +218,32 @@ class Distiller:
         if lr is not None:
             self.lr_dev.fill_(float(lr))
         self._g_fb.replay()
+        if self._g_fb2 is not None:
+            if self.world_size > 1:
+                self._all_reduce_late()
+            self._g_fb2.replay()
         self.all_reduce_grads()
         self.step_count += 1
         self._g_opt.replay()
         return self._static_out
 
+    def _all_reduce_late(self):
+        """called by the backward when the up / mid-block gradients are final: their bucket goes out (async, on RCCL's own stream, ordered
+        behind the launches issued so far) while the down blocks still back-propagate"""
+        self._late_work = torch.distributed.all_reduce(self.lora.grads[self.lora.late_offset:], op=torch.distributed.ReduceOp.SUM,
+                                                       group=self.pg, async_op=True)
+
     def all_reduce_grads(self):
-        """DDP: one all-reduce (sum) of the flat 67 M-element LoRA gradient buffer over RCCL/xGMI;
-        the 1/world_size mean is folded into the AdamW kernel's grad_scale."""
-        if self.world_size > 1:
+        """DDP exchange: all-reduce (sum) of the flat 67 M-element fp32 LoRA gradient buffer over RCCL/xGMI, as ONE collective or --
+        when the backward already started the late bucket -- as the remaining early (down-block) bucket plus a wait; the 1/world_size mean is
+        folded into the AdamW kernel's grad_scale."""
+        if self.world_size <= 1:
+            return
+        if getattr(self, "_late_work", None) is not None:
+            torch.distributed.all_reduce(self.lora.grads[:self.lora.late_offset], op=torch.distributed.ReduceOp.SUM, group=self.pg)
+            self._late_work.wait()
+            self._late_work = None
+        else:
             torch.distributed.all_reduce(self.lora.grads, op=torch.distributed.ReduceOp.SUM, group=self.pg)
 
     def optimizer_step(self):
@@ -274,7 +316,8 @@ class AdvDistiller(Distiller):
                                          torch.cat([prompt_embeds, prompt_embeds]), features=taps, added_cond=cat2(ac, None))
             logits, dtape = disc.forward(feats, save=True)
             disc.grads.zero_()
-            out["d_loss"] = disc.d_loss_backward(logits, dtape, B)                              # :1383-1391
+            self._disc_works = []
+            out["d_loss"] = disc.d_loss_backward(logits, dtape, B, on_bucket=self._disc_bucket if self.world_size > 1 else None)   # :1383-1391
             out["real_adv"] = real_adv
             self._disc_optimizer_step()
             return out
@@ -293,11 +336,22 @@ class AdvDistiller(Distiller):
         out["grad_sumsq"] = self.lora.gradsq
         return out
 
+    def _disc_bucket(self, off0, off1):
+        """the heads of one tapped feature are done: their 0.07-0.47 GB of fp32 gradients go out (async) while the remaining heads still
+        back-propagate -- 9 collectives per discriminator step instead of one 2.66 GB all-reduce at its end (fp32 like the
+        reference's DDP, and only on discriminator steps: generator steps never call this)"""
+        self._disc_works.append(torch.distributed.all_reduce(self.disc.grads[off0:off1], op=torch.distributed.ReduceOp.SUM, group=self.pg, async_op=True))
+
     def _disc_optimizer_step(self):
         """optimizer_discriminator (:1026-1032): AdamW(lr=adv_lr, betas=(0, 0.999)), global-norm clip over the heads."""
         cfg, d = self.cfg, self.disc
         if self.world_size > 1:
-            torch.distributed.all_reduce(d.grads, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+            if getattr(self, "_disc_works", None):
+                for wk in self._disc_works:
+                    wk.wait()
+                self._disc_works = []
+            else:
+                torch.distributed.all_reduce(d.grads, op=torch.distributed.ReduceOp.SUM, group=self.pg)
         d.step_dev += 1
         ops.sumsq(d.grads, d.gradsq)
         ops.adamw_clip_step(d.params, d.grads, d.exp_avg, d.exp_avg_sq, d.gradsq, cfg.max_grad_norm, self.adv_lr, 0.0, 0.999,

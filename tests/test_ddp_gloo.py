@@ -23,6 +23,7 @@ def _worker(rank, world, port, outdir):
     lora = LoraState(cfg, 64, 8.0, "cpu", seed=5, b_std=0.01)
     D = Distiller.__new__(Distiller)       # exchange step only: no UNet weights needed
     D.lora, D.cfg, D.world_size, D.pg, D.step_count, D.ema = lora, StepConfig(learning_rate=1e-3), world, None, 0, None
+    D._late_work, D.bucketed = None, True
     D.step_dev = torch.zeros(1, dtype=torch.int64)
     D.lr_dev = torch.full((1,), 1e-3)
     g = torch.Generator().manual_seed(100 + rank)
@@ -89,7 +90,13 @@ def _step_worker(rank, world, port, outdir):
     inp = OS.draw_inputs(4, OS.StepConfig(multiphase=2), seed=11, latent_hw=8, ctx_len=7, ctx_dim=64)       # the GLOBAL batch of 4
     n = 4 // world
     sl = slice(rank * n, (rank + 1) * n)                                                                      # this rank's shard
+    fired = []
+    if world > 1:        # the two-bucket exchange: the mid/up-block bucket leaves from inside the backward, the down-block bucket after it
+        assert lora.late_offset is not None and 0 < lora.late_offset < lora.numel
+        orig = D._all_reduce_late
+        D._all_reduce_late = lambda: (fired.append(1), orig())[1]
     out = D.step(*(inp[k][sl].contiguous() for k in ("latents", "prompt_embeds", "uncond_prompt_embeds", "noise", "index", "w")))
+    assert (world == 1) or (fired == [1] and D._late_work is None)
     torch.save((lora.params.clone(), float(out["loss"])), os.path.join(outdir, f"w{world}r{rank}.pt"))
     if world > 1:
         torch.distributed.barrier()
@@ -180,3 +187,77 @@ def test_sd3_two_rank_step_matches_single_process_on_the_global_batch(tmp_path):
     cos = float((u2 * u1).sum() / (u2.norm() * u1.norm()))
     print("SD3 update cosine 2-rank vs single %.4f, norm ratio %.3f" % (cos, float(u2.norm() / u1.norm())))
     assert cos > 0.9 and 0.8 < float(u2.norm() / u1.norm()) < 1.25
+
+
+def _adv_worker(rank, world, port, outdir, global_step):
+    """One adversarial step (even: discriminator update, odd: generator update) of a tiny UNet + heads on this rank's shard."""
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "phased-consistency-model_amd"), os.path.join(ROOT, "tests")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    if world > 1:
+        torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    from emu_lib import emu_lib
+    from oracle import pcm_step as OS
+    from oracle import unet_sd15 as O
+    from pcm_amd import capi
+    from pcm_amd.discriminator import Discriminator
+    from pcm_amd.model import LoraState, UNetWeights
+    from pcm_amd.trainer import AdvDistiller, StepConfig
+    from pcm_amd.unet_spec import UNetConfig
+    capi.set_lib(emu_lib())
+    kw = dict(block_out_channels=(64, 128), layers_per_block=1, cross_attention_dim=64, heads=2, norm_num_groups=32)
+    sd = O.init_state_dict(O.UNetConfig(**kw), 0)
+    W = UNetWeights(UNetConfig(**kw), sd, "cpu")
+    lora = LoraState(UNetConfig(**kw), 64, 8.0, "cpu", seed=5, b_std=0.05)
+    disc = Discriminator((64, 128, 128, 128, 64), num_h_per_head=2, device="cpu", seed=2)
+    D = AdvDistiller(W, lora, StepConfig(multiphase=2, loss_type="huber", learning_rate=1e-3, w_min=4.0, w_max=5.0), disc, adv_weight=0.1, adv_lr=1e-3,
+                     world_size=world)
+    G = 4
+    inp = OS.draw_inputs(G, OS.StepConfig(multiphase=2), seed=11, latent_hw=8, ctx_len=7, ctx_dim=64)
+    g = torch.Generator().manual_seed(9)
+    extra = dict(noise_fake=torch.randn(G, 4, 8, 8, generator=g), noise_real=torch.randn(G, 4, 8, 8, generator=g), adv_u=torch.rand(G, generator=g))
+    n = G // world
+    sl = slice(rank * n, (rank + 1) * n)
+    buckets = []
+    if world > 1:
+        orig = D._disc_bucket
+        D._disc_bucket = lambda a, b: (buckets.append((a, b)), orig(a, b))[1]
+    p_l0, p_d0 = lora.params.clone(), disc.params.clone()
+    args = [inp[k][sl].contiguous() for k in ("latents", "prompt_embeds", "uncond_prompt_embeds", "noise", "index", "w")]
+    D.step_adv(global_step, *args, *(extra[k][sl].contiguous() for k in ("noise_fake", "noise_real", "adv_u")))
+    if world > 1 and global_step % 2 == 0:      # one bucket per tapped feature, covering the whole flat buffer exactly once, in order
+        assert len(buckets) == 5 and buckets[0][0] == 0 and buckets[-1][1] == disc.numel
+        assert all(a[1] == b[0] for a, b in zip(buckets, buckets[1:]))
+    torch.save((lora.params - p_l0, disc.params - p_d0, (disc.grads if global_step % 2 == 0 else lora.grads).clone() / world),
+               os.path.join(outdir, f"a{global_step}w{world}r{rank}.pt"))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+def test_adversarial_two_rank_step_matches_single_process_on_the_global_batch(tmp_path):
+    """sd15_adv.py:1375-1431 under data parallelism: on a discriminator step the head gradients are exchanged (one bucket per tapped
+    feature, launched from inside the head backward) and the student is untouched; on a generator step the LoRA buckets are exchanged and
+    the heads are untouched.  2 ranks x 2 samples must move the parameters like 1 process x 4 samples."""
+    ctx = mp.get_context("spawn")
+    for gs, port in ((0, 29761), (1, 29771)):
+        ps = [ctx.Process(target=_adv_worker, args=(r, 2, port, str(tmp_path), gs)) for r in range(2)]
+        ps.append(ctx.Process(target=_adv_worker, args=(0, 1, port + 1, str(tmp_path), gs)))
+        for p in ps:
+            p.start()
+        for p in ps:
+            p.join(900)
+            assert p.exitcode == 0
+        (l0, d0, g0), (l1, d1, g1) = (torch.load(os.path.join(str(tmp_path), f"a{gs}w2r{r}.pt")) for r in range(2))
+        ls, ds, gs1 = torch.load(os.path.join(str(tmp_path), f"a{gs}w1r0.pt"))
+        assert torch.equal(l0, l1) and torch.equal(d0, d1) and torch.equal(g0, g1), "ranks diverged"
+        moved, still, ref = (d0, l0, ds) if gs == 0 else (l0, d0, ls)
+        assert float(still.abs().max()) == 0.0 and float(moved.abs().max()) > 0
+
+        def cosine(a, b):
+            return float((a.double() * b.double()).sum() / (a.double().norm() * b.double().norm()))
+        # exchanged gradient (sum over ranks / world) vs the global-batch gradient; the first AdamW step is sign-like (g / (|g| + eps)), so the
+        # UPDATE cosine counts sign agreement and amplifies the bf16 noise of the near-cancelling adversarial gradient (tests/test_emu_adv.py)
+        print("adversarial step %d: gradient cosine 2-rank vs single %.4f (norm ratio %.3f), update cosine %.4f" % (
+            gs, cosine(g0, gs1), float(g0.norm() / gs1.norm()), cosine(moved, ref)))
+        assert cosine(g0, gs1) > 0.95 and 0.85 < float(g0.norm() / gs1.norm()) < 1.18
+        assert cosine(moved, ref) > 0.8 and 0.8 < float(moved.norm() / ref.norm()) < 1.25
