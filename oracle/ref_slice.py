@@ -13,6 +13,8 @@ Slices used (reference file:line):
   scheduling_ddpm_modified.py:500-554  DDPMScheduler.add_noise / .noise_travel (method bodies
                                   lifted and bound to a stub that carries ``alphas_cumprod``)
   discriminator_sd15.py:348-434   DiscriminatorHead, Discriminator.d_loss/g_loss
+  discriminator_sd15.py:16-345    modified_forward (the reference's copy of UNet2DConditionModel.forward with the 9 feature taps), executed on
+                                  a duck-typed block tree built from the oracle's block functions (modified_forward_on_oracle_blocks)
   text_to_image_sd3/train_pcm_lora_sd3.py:153-230  extract_into_tensor, EulerSolver (flow-matching PCM math)
   text_to_image_sd3/pcm_fm_{deterministic,stochastic}_scheduler.py:35-242  the two sampler classes (bases and the
                                   config decorator stripped; ``self.config`` supplied by a stub)
@@ -138,3 +140,74 @@ def sd3_sampler_class(kind="deterministic"):
             super().__init__(num_train_timesteps, shift, pcm_timesteps)
     Sampler.__name__ = cname
     return Sampler
+
+
+def modified_forward_on_oracle_blocks(ucfg, sd, sample, timesteps, encoder_hidden_states):
+    """Run the REFERENCE'S OWN ``modified_forward`` (discriminator_sd15.py:16-345) -- its statement of the UNet wiring: time embedding, conv_in,
+    the down loop with its residual tuple, the mid block, the up loop slicing ``len(upsample_block.resnets)`` residuals off that tuple, and
+    the 9 feature taps -- on a duck-typed module tree whose BLOCKS are the oracle's block functions (oracle/unet_sd15._Net: diffusers' block
+    internals are not vendored by the reference, so those stay a restatement).  Pins the block order, the skip bookkeeping and the tap
+    points of oracle.unet_sd15.unet_forward(..., return_features=True) to reference source: the two must agree bit for bit."""
+    import typing
+    from . import unet_sd15 as O
+    F = torch.nn.functional
+    ns = _slice(os.path.join(SD15_DIR, "discriminator_sd15.py"), ["modified_forward"],
+                extra_ns={"Union": typing.Union, "Optional": typing.Optional, "Dict": typing.Dict, "Any": typing.Any, "Tuple": typing.Tuple})
+    net = O._Net(ucfg, sd, None)
+    boc, n = ucfg.block_out_channels, len(ucfg.block_out_channels)
+
+    class Down:
+        def __init__(self, i):
+            self.i, self.has_cross_attention = i, bool(ucfg.down_attn[i])
+
+        def __call__(self, hidden_states, temb, encoder_hidden_states=None, attention_mask=None, cross_attention_kwargs=None,
+                     encoder_attention_mask=None, scale=1.0):
+            i, h, res = self.i, hidden_states, ()
+            for j in range(ucfg.layers_per_block):
+                h = net.resnet(f"down_blocks.{i}.resnets.{j}.", h, temb)
+                if self.has_cross_attention:
+                    h = net.transformer(f"down_blocks.{i}.attentions.{j}.", h, encoder_hidden_states, ucfg.transformer_depth[i], ucfg.heads_at(i))
+                res += (h,)
+            if i < n - 1:
+                h = net.conv(f"down_blocks.{i}.downsamplers.0.conv", h, stride=2)
+                res += (h,)
+            return h, res
+
+    class Mid:
+        has_cross_attention = True
+
+        def __call__(self, hidden_states, temb, encoder_hidden_states=None, attention_mask=None, cross_attention_kwargs=None,
+                     encoder_attention_mask=None):
+            h = net.resnet("mid_block.resnets.0.", hidden_states, temb)
+            h = net.transformer("mid_block.attentions.0.", h, encoder_hidden_states, ucfg.mid_depth, ucfg.heads_at(n - 1))
+            return net.resnet("mid_block.resnets.1.", h, temb)
+
+    class Up:
+        def __init__(self, i):
+            self.i, self.has_cross_attention = i, bool(ucfg.down_attn[n - 1 - i])
+            self.resnets = [None] * (ucfg.layers_per_block + 1)          # only len() is read by the reference
+
+        def __call__(self, hidden_states, temb, res_hidden_states_tuple, encoder_hidden_states=None, cross_attention_kwargs=None,
+                     upsample_size=None, attention_mask=None, encoder_attention_mask=None, scale=1.0):
+            i, h = self.i, hidden_states
+            for j in range(ucfg.layers_per_block + 1):
+                r = res_hidden_states_tuple[-1]
+                res_hidden_states_tuple = res_hidden_states_tuple[:-1]
+                h = net.resnet(f"up_blocks.{i}.resnets.{j}.", torch.cat([h, r], dim=1), temb)
+                if self.has_cross_attention:
+                    lv = n - 1 - i
+                    h = net.transformer(f"up_blocks.{i}.attentions.{j}.", h, encoder_hidden_states, ucfg.transformer_depth[lv], ucfg.heads_at(lv))
+            if i < n - 1:
+                h = net.conv(f"up_blocks.{i}.upsamplers.0.conv", F.interpolate(h, scale_factor=2.0, mode="nearest"))
+            return h
+
+    unet = types.SimpleNamespace(
+        num_upsamplers=n - 1,
+        config=types.SimpleNamespace(center_input_sample=False, addition_embed_type=None, class_embed_type=None,
+                                     class_embeddings_concat=False, encoder_hid_dim_type=None),
+        time_proj=lambda t: O.timestep_embedding(t, boc[0]),
+        time_embedding=lambda t_emb, cond=None: net.linear("time_embedding.linear_2", F.silu(net.linear("time_embedding.linear_1", t_emb))),
+        class_embedding=None, time_embed_act=None, encoder_hid_proj=None,
+        conv_in=lambda x: net.conv("conv_in", x),
+        down_blocks=[Down(i) for i in range(n)], mid_block=Mid(), up_blocks=[Up(i) for i in range(n)])
+    return ns["modified_forward"](unet, sample, timesteps, encoder_hidden_states)
