@@ -16,6 +16,8 @@
 // taps / K tails fetch a 16-byte zero page.  MFMA: v_mfma_f32_32x32x16_bf16 with the WEIGHT tile
 // as the A operand, so every lane owns 4 consecutive output channels per accumulator quad
 // (8-byte bf16 stores, channel-contiguous).
+#include <stdlib.h>
+
 #include "gemm_dev.h"
 
 __device__ __attribute__((aligned(16))) static const uint4 pcm_zero_page = {0u, 0u, 0u, 0u};
@@ -356,6 +358,9 @@ struct GemmPlan { int BM, BN, tiles_m, tiles_n, splitk, kt_per_split; size_t ws_
 static int g_force_bm = 0, g_force_bn = 0;
 static int g_big_mode = -1;   // -1: read PCM_GEMM_BIG once (0 = never use gemm8p, 1 = planner, 2 = wherever eligible); tuning only
 extern "C" void pcm_debug_gemm_big_mode(int mode) { g_big_mode = mode; }
+static int g_conv_co = -1, g_conv_md = -1;    // -1: PCM_GEMM_CONV_CO / PCM_GEMM_CONV_MD env; both default 0 (measured slower: gemm8p.hip)
+extern "C" void pcm_debug_gemm_conv_order(int chunk_outer) { g_conv_co = chunk_outer ? 1 : 0; }
+extern "C" void pcm_debug_gemm_conv_md(int mask_delta) { g_conv_md = mask_delta ? 1 : 0; }
 static int g_ablate = 0;      // see PCM_ABL in gemm_dev.h (no effect in the product build)
 extern "C" void pcm_debug_gemm_ablate(int mask) { g_ablate = mask; }
 static int g_last_plan = 0;   // tests only: 1000*big_fn + splitk of the most recent pcm_gemm_bf16 launch
@@ -494,6 +499,9 @@ extern "C" int pcm_gemm_bf16(const pcm_gemm_seg* segs, int nseg, const pcm_gemm_
   g.bias = e->bias; g.rowvec = (const bf16_t*)e->rowvec; g.rpb = e->rows_per_batch > 0 ? e->rows_per_batch : 1;
   g.res = (const bf16_t*)e->residual; g.ldr = e->ldr; g.out = e->out; g.ldo = e->ldo;
   g.out_f32 = e->out_dtype == PCM_F32; g.act = e->act; g.alpha = e->alpha; g.dbg = g_ablate;
+  if (g_conv_co < 0) { const char* ev = getenv("PCM_GEMM_CONV_CO"); g_conv_co = ev ? atoi(ev) : 0; }
+  if (g_conv_md < 0) { const char* ev = getenv("PCM_GEMM_CONV_MD"); g_conv_md = ev ? atoi(ev) : 0; }
+  g.conv_co = g_conv_co; g.conv_md = g_conv_md || g_conv_co;
   if (gemm_n64_ok(segs, nseg, e)) {
     g_last_plan = 64;
     int rc = pcm_gemm_n64_launch(g, stream);

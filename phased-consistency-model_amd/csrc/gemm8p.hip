@@ -20,10 +20,19 @@
 // scalar offset; out-of-range rows / padding taps use an offset beyond num_records, which the hardware zero-fills.
 #include "gemm_dev.h"
 
+// cycle stamps (tools/gemm8p_timeline.py, -DPCM_ABLATE builds only): lane 0 of every wave of ONE mid-grid tile records s_memtime at three
+// points of each phase (start | fragment reads retired + barrier passed | MFMAs issued + closing barrier passed) for its first 16 K-tiles
+#ifdef PCM_ABLATE
+__device__ unsigned long long g_g8_stamps[8][16][12];
+extern "C" int pcm_debug_gemm8p_stamps(unsigned long long* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_g8_stamps), sizeof(g_g8_stamps)); }
+#define G8_STAMP(k) do { if (stamp_on && t < 16 && lane == 0) g_g8_stamps[wave][t][k] = __builtin_readcyclecounter(); } while (0)
+#else
+#define G8_STAMP(k) do { } while (0)
+#endif
 #define PCM_RSRC_FLAGS 0x00020000
 #define PCM_OOB 0x80000000u
 
-template <int F0>
+template <int F0, bool MD, bool CO>
 __global__ __launch_bounds__(512) void pcm_gemm8p_kernel(GemmDev g) {
 #if defined(__HIP_DEVICE_COMPILE__) || defined(PCM_HOST_EMU)   // the host pass only needs the launch stub (buffer-resource builtins are device-only)
   constexpr int F1 = 2, FN = F0 + F1, WNC = 16 * FN, BN = 4 * WNC;
@@ -64,7 +73,22 @@ __global__ __launch_bounds__(512) void pcm_gemm8p_kernel(GemmDev g) {
   }
   const int T = total_kt;
   // the segment descriptors in use are held as local (SGPR) copies: no runtime-indexed kernarg access
-  int a_seg = 0, a_tap = 0, a_chunk = 0, a_nchunk, a_ntap;
+  // K order of a 3x3 segment.  tap-outer (tap, chunk): the row offsets change once per tap, but a pixel's 9 shifted reads are a whole pass
+  // over the channels apart -- with 32 tiles per XCD the hot set (32 x 256 pixels x C x 2 B) outgrows the 4 MB L2 and every tap
+  // re-fetches the activation tile through the fabric (measured 4.65x the algorithmic bytes on the 320-channel 64x64 convs).
+  // chunk-outer (chunk, tap), taken for the stride-1 direct view: the 9 taps of one 64-channel chunk are CONSECUTIVE K-tiles, so 8 of the
+  // 9 reads hit L2.  Its cost is a new tap every K-tile: rows keep the CENTRE-tap offset and a 9-bit validity mask (once per segment),
+  // the tap is one wave-uniform signed delta -- 3 VALU per row at issue time instead of the per-tap re-key.
+  // Kernel variants (the launcher picks; each compiles one address path -- merged into one kernel the scalar state spilled 46 SGPRs).
+  // SHIPPED: <F0, false, false> -- tap-outer order, per-tap re-key.  The two alternatives were built and MEASURED SLOWER on MI355X on all
+  // 12 conv shapes of the bs-16 step (tools/gemm_conv_order_ab.py, profiles/r02_e_gemm8p_conv_variants_ab.txt); they stay as A/B options:
+  //   MD  (PCM_GEMM_CONV_MD=1) "mask + delta" addressing for calls whose 3x3 segments are all stride 1 / direct: rows keep the centre-tap
+  //       offset and the 9-bit mask, the tap is a scalar delta applied at issue time (3 VALU per row per piece) instead of the per-tap
+  //       re-key: 0.88-1.02x (the issue-time VALU sits on the phase path; the re-key runs once per C/64 K-tiles);
+  //   CO  (PCM_GEMM_CONV_CO=1, implies MD) chunk-outer K order: 4x less fabric traffic, 0.82-0.95x the speed (1.12x only at 8x8).
+  auto seg_co = [&](const SegDev& s_) { return MD && s_.mode == PCM_SEG_CONV3X3; };
+  int a_seg = 0, a_tap = 0, a_chunk = 0, a_nchunk, a_ntap, a_delta = 0;
+  bool a_co;
   int b_seg[2], b_kt[2];
   SegDev ca = g.seg[0];
   {
@@ -73,12 +97,14 @@ __global__ __launch_bounds__(512) void pcm_gemm8p_kernel(GemmDev g) {
     b_seg[0] = b_seg[1] = a_seg; b_kt[0] = b_kt[1] = k;
     a_nchunk = (ca.mode == PCM_SEG_CONV3X3 ? ca.C : ca.K) >> 6;
     a_ntap = ca.mode == PCM_SEG_CONV3X3 ? 9 : 1;
-    a_tap = k / a_nchunk; a_chunk = k - a_tap * a_nchunk;
+    a_co = seg_co(ca);
+    if (CO && a_co) { a_chunk = k / 9; a_tap = k - 9 * a_chunk; } else { a_tap = k / a_nchunk; a_chunk = k - a_tap * a_nchunk; }
   }
   const bf16_t* b_w[2] = {ca.w, ca.w};
-  int b_K[2] = {ca.K, ca.K}, b_nkt[2] = {ca.ktiles, ca.ktiles};
-  int a_key[2][2];          // per A row: plain -> m, conv -> b<<20 | y<<10 | x ; -1 = row beyond M
-  unsigned a_voff[2][2];    // byte offset of the row's 16-B chunk for the current (segment, tap)
+  int b_K[2] = {ca.K, ca.K}, b_nkt[2] = {ca.ktiles, ca.ktiles}, b_nch[2] = {a_nchunk, a_nchunk};
+  bool b_co[2] = {CO && a_co, CO && a_co};
+  int a_key[2][2];          // per A row: plain -> m, conv -> b<<20 | y<<10 | x ; -1 = row beyond M.  chunk-outer: the 9-bit tap validity mask
+  unsigned a_voff[2][2];    // byte offset of the row's 16-B chunk for the current (segment, tap).  chunk-outer: for the CENTRE tap
   unsigned w_voff0[F0], w_voff1[F1];
   auto a_rekey = [&]() {
     const SegDev& cs = ca;
@@ -91,13 +117,20 @@ __global__ __launch_bounds__(512) void pcm_gemm8p_kernel(GemmDev g) {
         if (cs.mode == PCM_SEG_CONV3X3) {
           int bb = m / HoWo, rem = m - bb * HoWo, y = rem / g.Wo, x = rem - y * g.Wo;
           key = (bb << 20) | (y << 10) | x;
+          if (MD) {
+            const int ym = (y > 0 ? 1 : 0) | 2 | (y < cs.Hs - 1 ? 4 : 0), xm = (x > 0 ? 1 : 0) | 2 | (x < cs.Ws - 1 ? 4 : 0);
+            key = ((ym & 1) ? xm : 0) | (xm << 3) | ((ym & 4) ? xm << 6 : 0);
+            a_voff[h][j] = (unsigned)((bb * cs.Hs + y) * cs.Ws + x) * (unsigned)(cs.C * 2) + csw16;
+            if (m >= g.M) key = 0;
+          }
         }
-        a_key[h][j] = m < g.M ? key : -1;
+        a_key[h][j] = (m < g.M || a_co) ? key : -1;
       }
   };
   auto a_prepare_tap = [&]() {
     const SegDev& cs = ca;
     const int ty = a_tap / 3, tx = a_tap - ty * 3;
+    if (a_co) { a_delta = ((ty - 1) * cs.Ws + (tx - 1)) * (cs.C * 2); return; }
 #pragma unroll
     for (int h = 0; h < 2; h++)
 #pragma unroll
@@ -105,7 +138,7 @@ __global__ __launch_bounds__(512) void pcm_gemm8p_kernel(GemmDev g) {
         const int key = a_key[h][j];
         bool ok = key >= 0;
         unsigned off;
-        if (cs.mode == PCM_SEG_PLAIN) {
+        if (MD || cs.mode == PCM_SEG_PLAIN) {          // (MD variant: a segment that is not mask + delta addressed is a plain one)
           off = (unsigned)key * (unsigned)(cs.lda * 2);
         } else {
           int bb = key >> 20, y = (key >> 10) & 1023, x = key & 1023;
@@ -128,6 +161,24 @@ __global__ __launch_bounds__(512) void pcm_gemm8p_kernel(GemmDev g) {
     }
   };
   auto a_advance = [&]() {
+    if (CO && a_co) {
+      a_tap++;
+      if (a_tap == 9) {
+        a_tap = 0; a_chunk++;
+        if (a_chunk == a_nchunk) {
+          a_chunk = 0; a_seg++;
+          if (a_seg < g.nseg) {
+            ca = g.seg[1];
+            a_nchunk = (ca.mode == PCM_SEG_CONV3X3 ? ca.C : ca.K) >> 6;
+            a_ntap = ca.mode == PCM_SEG_CONV3X3 ? 9 : 1;
+            a_co = seg_co(ca);
+            a_rekey();
+          }
+        }
+      }
+      if (a_seg < g.nseg) a_prepare_tap();
+      return;
+    }
     a_chunk++;
     if (a_chunk == a_nchunk) {
       a_chunk = 0; a_tap++;
@@ -137,6 +188,7 @@ __global__ __launch_bounds__(512) void pcm_gemm8p_kernel(GemmDev g) {
           ca = g.seg[1];
           a_nchunk = (ca.mode == PCM_SEG_CONV3X3 ? ca.C : ca.K) >> 6;
           a_ntap = ca.mode == PCM_SEG_CONV3X3 ? 9 : 1;
+          a_co = seg_co(ca);
           a_rekey();
         }
       }
@@ -147,7 +199,10 @@ __global__ __launch_bounds__(512) void pcm_gemm8p_kernel(GemmDev g) {
     b_kt[p]++;
     if (b_kt[p] == b_nkt[p]) {
       b_kt[p] = 0; b_seg[p]++;
-      if (b_seg[p] < g.nseg) { b_w[p] = g.seg[1].w; b_K[p] = g.seg[1].K; b_nkt[p] = g.seg[1].ktiles; w_prepare(p); }
+      if (b_seg[p] < g.nseg) {
+        b_w[p] = g.seg[1].w; b_K[p] = g.seg[1].K; b_nkt[p] = g.seg[1].ktiles; b_co[p] = CO && seg_co(g.seg[1]); b_nch[p] = g.seg[1].C >> 6;
+        w_prepare(p);
+      }
     }
   };
   bool dma_on = true;
@@ -157,13 +212,19 @@ __global__ __launch_bounds__(512) void pcm_gemm8p_kernel(GemmDev g) {
     char* dst = smem + stage * STAGE + (h ? OFF_A1 : 0) + wave * 1024;
     const unsigned soff = (unsigned)(a_chunk * 128);   // the tap is in the row offsets; plain segments have one tap
 #pragma unroll
-    for (int j = 0; j < 2; j++) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, PCM_AS3(dst + j * 8192), 16, a_voff[h][j], soff, 0, 0);
+    for (int j = 0; j < 2; j++) {
+      unsigned v = a_voff[h][j];
+      if (a_co) v = ((a_key[h][j] >> a_tap) & 1) ? v + (unsigned)a_delta : PCM_OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, PCM_AS3(dst + j * 8192), 16, v, soff, 0, 0);
+    }
   };
   auto issue_b = [&](int p, int stage) {
     if (PCM_ABL(8) && !dma_on) return;
     __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)b_w[p], 0, PCM_OOB, PCM_RSRC_FLAGS);
     char* dst = smem + stage * STAGE + (p ? OFF_B1 : OFF_B0) + wave * 1024;
-    const unsigned soff = (unsigned)(b_kt[p] * 128);
+    int kk = b_kt[p];                                  // K-tile of the weight operand in ITS storage order (tap, chunk)
+    if (b_co[p]) { const int c = kk / 9; kk = (kk - 9 * c) * b_nch[p] + c; }
+    const unsigned soff = (unsigned)(kk * 128);
     if (p == 0) {
 #pragma unroll
       for (int j = 0; j < F0; j++) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, PCM_AS3(dst + j * 8192), 16, w_voff0[j], soff, 0, 0);
@@ -236,13 +297,18 @@ __global__ __launch_bounds__(512) void pcm_gemm8p_kernel(GemmDev g) {
   __builtin_amdgcn_sched_barrier(0)
 
   dma_on = false;
+#ifdef PCM_ABLATE
+  const bool stamp_on = blockIdx.x == gridDim.x / 2;
+#endif
   for (int t = 0; t < T; t++) {
     const char* cur = smem + (t & 1) * STAGE;
     const bool more1 = t + 1 < T, more2 = t + 2 < T;
     // ---- phase 1: C00 = A0 x B0; stage B0 of tile t+1 (its region in the other buffer was last read in phase 4 of t-1)
+    G8_STAMP(0);
     read_a(cur); read_b0(cur + OFF_B0);
     if (more1) { issue_b(0, (t + 1) & 1); if (t + 2 < T) b_advance(0); }
     PCM_PHASE_SYNC_IN();
+    G8_STAMP(1);
     if (!PCM_ABL(4))
 #pragma unroll
     for (int kh = 0; kh < 2; kh++)
@@ -251,10 +317,12 @@ __global__ __launch_bounds__(512) void pcm_gemm8p_kernel(GemmDev g) {
 #pragma unroll
         for (int f = 0; f < F0; f++) acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0f[f][kh], af[i][kh], acc[i][f], 0, 0, 0);
     PCM_PHASE_SYNC_OUT();
+    G8_STAMP(2);
     // ---- phase 2: C01 = A0 x B1; stage A0 of tile t+2 over the A0 just consumed
     read_b1(cur + OFF_B1);
     if (more2) issue_a(0, t & 1);
     PCM_PHASE_SYNC_IN();
+    G8_STAMP(3);
     if (!PCM_ABL(4))
 #pragma unroll
     for (int kh = 0; kh < 2; kh++)
@@ -263,10 +331,14 @@ __global__ __launch_bounds__(512) void pcm_gemm8p_kernel(GemmDev g) {
 #pragma unroll
         for (int f = 0; f < F1; f++) acc[i][F0 + f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1f[f][kh], af[i][kh], acc[i][F0 + f], 0, 0, 0);
     PCM_PHASE_SYNC_OUT();
+    G8_STAMP(4);
     // ---- phase 3: C11 = A1 x B1; stage B1 of tile t+2
     read_a(cur + OFF_A1);
+    G8_STAMP(10);
     if (more2) { issue_b(1, t & 1); if (t + 3 < T) b_advance(1); }
+    G8_STAMP(11);
     PCM_PHASE_SYNC_IN();
+    G8_STAMP(5);
     if (!PCM_ABL(4))
 #pragma unroll
     for (int kh = 0; kh < 2; kh++)
@@ -275,6 +347,7 @@ __global__ __launch_bounds__(512) void pcm_gemm8p_kernel(GemmDev g) {
 #pragma unroll
         for (int f = 0; f < F1; f++) acc[4 + i][F0 + f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1f[f][kh], af[i][kh], acc[4 + i][F0 + f], 0, 0, 0);
     PCM_PHASE_SYNC_OUT();
+    G8_STAMP(6);
     // ---- phase 4: C10 = A1 x B0 (B0 fragments re-read); stage A1 of tile t+2; retire everything tile t+1 needs
     read_b0(cur + OFF_B0);
     if (more2) {
@@ -284,7 +357,9 @@ __global__ __launch_bounds__(512) void pcm_gemm8p_kernel(GemmDev g) {
     } else {
       PCM_WAIT_VMCNT(0);
     }
+    G8_STAMP(7);
     PCM_PHASE_SYNC_IN();
+    G8_STAMP(8);
     if (!PCM_ABL(4))
 #pragma unroll
     for (int kh = 0; kh < 2; kh++)
@@ -293,6 +368,7 @@ __global__ __launch_bounds__(512) void pcm_gemm8p_kernel(GemmDev g) {
 #pragma unroll
         for (int f = 0; f < F0; f++) acc[4 + i][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0f[f][kh], af[i][kh], acc[4 + i][f], 0, 0, 0);
     PCM_PHASE_SYNC_OUT();
+    G8_STAMP(9);
   }
   if (wm == 0) __builtin_amdgcn_s_barrier();   // realign the two groups
 
@@ -367,17 +443,29 @@ __global__ __launch_bounds__(512) void pcm_gemm8p_kernel(GemmDev g) {
 
 size_t pcm_gemm8p_lds_bytes(int fn) { return 2 * (size_t)(256 + 64 * fn) * 128; }
 
-template <int F0>
+template <int F0, bool MD, bool CO>
 static int launch8p(const GemmDev& g, void* stream) {
   const size_t smem = pcm_gemm8p_lds_bytes(F0 + 2);
   dim3 grid(g.tiles_m * g.tiles_n, g.splitk);
   static bool lds_ok = false;
   if (!lds_ok) {
-    hipError_t er = hipFuncSetAttribute((const void*)pcm_gemm8p_kernel<F0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipError_t er = hipFuncSetAttribute((const void*)pcm_gemm8p_kernel<F0, MD, CO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     PCM_CHECK(er == hipSuccess, PCM_EHIP, "pcm_gemm_bf16: hipFuncSetAttribute(LDS %zu): %s", smem, hipGetErrorString(er));
     lds_ok = true;
   }
-  PCM_LAUNCH((pcm_gemm8p_kernel<F0>), grid, dim3(512), smem, stream, g);
+  PCM_LAUNCH((pcm_gemm8p_kernel<F0, MD, CO>), grid, dim3(512), smem, stream, g);
   return 0;
 }
-int pcm_gemm8p_launch(const GemmDev& g, int fn, void* stream) { return fn == 5 ? launch8p<3>(g, stream) : launch8p<2>(g, stream); }
+int pcm_gemm8p_launch(const GemmDev& g, int fn, void* stream) {
+  // mask + delta variant: the call has a 3x3 segment and every 3x3 segment is the stride-1 direct view (g.conv_md: A/B hook, default on)
+  bool md = false;
+  if (g.conv_md) {
+    for (int i = 0; i < g.nseg; i++)
+      if (g.seg[i].mode == PCM_SEG_CONV3X3) md = true;
+    for (int i = 0; i < g.nseg; i++)
+      if (g.seg[i].mode == PCM_SEG_CONV3X3 && (g.seg[i].stride != 1 || g.seg[i].src_mode != PCM_SRC_DIRECT)) md = false;
+  }
+  const bool co = md && g.conv_co;
+  if (fn == 5) return co ? launch8p<3, true, true>(g, stream) : (md ? launch8p<3, true, false>(g, stream) : launch8p<3, false, false>(g, stream));
+  return co ? launch8p<2, true, true>(g, stream) : (md ? launch8p<2, true, false>(g, stream) : launch8p<2, false, false>(g, stream));
+}

@@ -21,6 +21,7 @@ struct GemmDev {
   int tiles_m, tiles_n;
   int splitk, kt_per_split;   // split-K: blockIdx.y = K slice; raw fp32 partial tiles go to slab ws[slice][M][N]
   float* ws;
+  int conv_md, conv_co;       // gemm8p.hip address-path / K-order variants of the stride-1 direct 3x3 view (A/B hooks; defaults 1, 0)
   int dbg;                    // ablation mask: only read by -DPCM_ABLATE builds (tools/probes/build_ablate.py), 0 otherwise
 };
 // timing ablations for tools/gemm8p_ablate.py (results are wrong by construction): 1 = no global stores in the epilogue, 2 = no epilogue,

@@ -101,6 +101,25 @@ def test_big_tile_kernel(which, lazy_dma, monkeypatch):
     assert excess <= 0, (which, lazy_dma, err)
 
 
+@pytest.mark.parametrize("md,co", [(1, 0), (1, 1)])
+@pytest.mark.parametrize("which", ["conv", "conv_conv", "conv_splitk"])
+def test_big_tile_conv_address_variants(which, md, co):
+    """gemm8p variants of the stride-1 direct 3x3 view (gemm8p.hip): the shipped one is the per-tap re-key in tap-outer order (what the other
+    gemm8p tests run); the mask + delta addressing (md = 1) and the chunk-outer K order (co = 1) are A/B options that measured slower on the
+    GPU and must keep giving the same results"""
+    import kernel_cases as KC
+    from pcm_amd import capi
+    dll = capi.lib().dll
+    dll.pcm_debug_gemm_conv_md(md)
+    dll.pcm_debug_gemm_conv_order(co)
+    try:
+        excess, err = KC.case_gemm_big("cpu", which)
+    finally:
+        dll.pcm_debug_gemm_conv_md(0)
+        dll.pcm_debug_gemm_conv_order(0)
+    assert excess <= 0, (which, md, co, err)
+
+
 @pytest.mark.parametrize("M,K", [(200, 320), (64, 1280), (130, 768), (77, 192), (40, 640), (33, 2560), (20, 960)])
 def test_rank64_streaming_kernel(M, K):
     import kernel_cases as KC
