@@ -85,8 +85,11 @@ def test_full_step_vs_oracle(setup, b_std):
     os.makedirs("gpurun_out", exist_ok=True)
     with open("gpurun_out/step_parity_bstd%g.json" % b_std, "w") as f:
         json.dump(dict(report, loss=loss, oracle_loss=rloss, b_std=b_std), f)
-    assert report["noise_pred"] < 3e-2 and report["cond_teacher_output"] < 3e-2 and report["target_noise_pred"] < 3e-2
-    assert report["x_prev"] < 3e-2 and report["model_pred"] < 3e-2 and report["target"] < 3e-2
-    assert report["loss_rel"] < 2e-2
-    assert report["grad_rel"] < 0.15 and report["grad_norm_rel"] < 0.05
-    assert report["param_rel"] < 5e-4 and report["update_cos"] > 0.9
+    # Bounds = ~1.5-2x what MI355X measures (profiles/step_parity_bstd*.json, r02_error_budget_sd15_bs2.json); every one of them is
+    # BELOW the deviation of the reference's own bf16-autocast numerics from the same fp32 oracle (eps 1.2e-2, model_pred 2.6e-3,
+    # target 2.9e-3, x_prev 1.6e-3, loss 9.4e-3), so a regression to "merely as good as the reference's mixed precision" fails here.
+    assert report["noise_pred"] < 1.2e-2 and report["cond_teacher_output"] < 1.2e-2 and report["target_noise_pred"] < 1.2e-2
+    assert report["x_prev"] < 1.6e-3 and report["model_pred"] < 2.6e-3 and report["target"] < 2.9e-3
+    assert report["loss_rel"] < 9e-3
+    assert report["grad_rel"] < 6e-2 and report["grad_norm_rel"] < 0.02
+    assert report["param_rel"] < 2e-4 and report["update_cos"] > 0.94
