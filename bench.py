@@ -216,7 +216,7 @@ def main():
         flops = sum(p[0] for p in prof)
         tms = sum(times)
         fam = flops / (tms * 1e-3) / 1e12
-        # the dominant kernel of the step (rocprofv3: ~35 % of the step time) is the 256x320 phased tile pcm_gemm8p_kernel<3>
+        # the dominant kernel of the step (rocprofv3: ~41 % of the kernel time) is the 256x320 phased tile pcm_gemm8p_kernel<3,false,false>
         # (plan code 5xxx of pcm_debug_last_gemm_plan); the family aggregate is reported next to it
         dom = [(p[0], t) for p, t in zip(prof, times) if p[4] // 1000 == 5]
         d_fl, d_ms = sum(x[0] for x in dom), sum(x[1] for x in dom)
@@ -232,20 +232,25 @@ def main():
                 for k, (n, t, fl) in rows:
                     f.write("%-44s calls %4d  total %8.3f ms  avg %7.1f us  %7.1f TF/s\n" % (k, n, t, 1e3 * t / n, fl / t / 1e9))
         # HBM-side bytes of the dominant kernel from the committed PMC passes (separate rocprofv3 --pmc runs, gfx950 FETCH_SIZE x2
-        # correction calibrated on a known copy): profiles/r01_e_pmc_gemm8p_traffic.json.  It is for ONE launch of the largest
+        # correction calibrated on a known copy): profiles/r02_pmc_gemm8p_traffic.json (round 1: r01_e_...).  It is for ONE launch of the largest
         # 64x64-resolution conv (M=131072, 320->320 + LoRA; algorithmic 186 MB): the 9 taps re-read the activation tile through
         # the fabric (served by the 256 MB Infinity Cache, not by HBM); see DESIGN.md section 6.
         traffic, traffic_note = None, None
         try:
-            pj = json.load(open(os.path.join(ROOT, "profiles", "r01_e_pmc_gemm8p_traffic.json")))
-            traffic = round(pj["tap_outer_K_order (shipped)"]["traffic_MB_corrected"] * 1e6)
+            p2 = os.path.join(ROOT, "profiles", "r02_pmc_gemm8p_traffic.json")
+            if os.path.exists(p2):
+                pj = json.load(open(p2))
+                traffic = round(pj["kernel"]["traffic_MB_corrected"] * 1e6)
+            else:
+                pj = json.load(open(os.path.join(ROOT, "profiles", "r01_e_pmc_gemm8p_traffic.json")))
+                traffic = round(pj["tap_outer_K_order (shipped)"]["traffic_MB_corrected"] * 1e6)
             traffic_note = "bytes per launch of the M=131072 320->320 conv3x3 (+LoRA) launch of this kernel; algorithmic %.0f MB" % (
                 pj["algorithmic_MB"]["read"] + pj["algorithmic_MB"]["write"])
         except Exception:
             pass
         roofline = {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_note": traffic_note,
-                    "kernel": "pcm_gemm8p_kernel<3> (256x320 phased tile; all its launches of one step)",
+                    "kernel": "pcm_gemm8p_kernel<3,false,false> (256x320 phased tile; all its launches of one step)",
                     "launches": len(dom), "avg_launch_us": round(1e3 * d_ms / max(1, len(dom)), 1),
                     "algorithmic_tflop": round(d_fl / 1e12, 2), "kernel_ms_per_step": round(d_ms, 2),
                     "gemm_family": {"kernels": "pcm_gemm8p<3>/<2>, pcm_gemm_kernel tiles, pcm_gemm_n64 (every pcm_gemm_bf16 launch)",

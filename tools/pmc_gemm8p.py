@@ -1,5 +1,5 @@
 """Workload for the PMC passes (FETCH_SIZE / WRITE_SIZE) on the dominant kernel: the 64x64-resolution 3x3 conv of the step
-(M = 131072 pixels, 320 -> 320 channels, LoRA segment) through pcm_gemm8p_kernel<3>, 3 launches."""
+(M = 131072 pixels, 320 -> 320 channels, LoRA segment) through pcm_gemm8p_kernel<3,false,false> (the shipped instantiation), 3 launches."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "phased-consistency-model_amd"))
