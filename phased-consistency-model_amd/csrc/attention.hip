@@ -107,14 +107,47 @@ struct TrQuad {
 // the LDS write happens after the next barrier, so L2/HBM latency hides under the MFMA phase) ----
 // Loads are UNCONDITIONAL from clamped addresses (a predicated load + zero select makes hipcc wait
 // vmcnt(0) right after issue: WAW on the destination); out-of-range rows are zeroed at store time.
+// Per-thread geometry of a ROWS x D tile copy, computed ONCE per kernel: byte offset of each of the thread's 16-B pieces from the tile's
+// first row in global memory and in the LDS image.  With it a full tile costs no VALU address math at all (round 2 measured ~40 VALU
+// instructions per tile here -- two v_mad_i64, clamps, 16 validity selects -- and on gfx950 VALU work does NOT overlap the MFMAs of the
+// same SIMD: tools/probes/mfmavalu.hip): the tile base is wave-uniform (scalar registers), the loads are base + 32-bit offset.
+template <int D, int ROWS>
+struct RowGeom {
+  using C = AttnCfg<D>;
+  static constexpr int N = (ROWS * C::DG + 255) / 256;
+  unsigned goff[N], loff[N];
+  __device__ __forceinline__ RowGeom(int ld, int tid) {
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      int u = tid + 256 * i;
+      if (u >= ROWS * C::DG) u = ROWS * C::DG - 1;     // threads beyond the last piece re-load it (their store is predicated off)
+      const int rr = u / C::DG, c = u - rr * C::DG;
+      goff[i] = (unsigned)(rr * ld + 8 * c) * 2u;
+      loff[i] = (unsigned)((rr * C::RKU + c) * 16);
+    }
+  }
+};
 template <int D, int ROWS>
 struct RowStage {
   using C = AttnCfg<D>;
-  static constexpr int N = (ROWS * C::DG + 255) / 256;
+  static constexpr int N = RowGeom<D, ROWS>::N;
   uint4 r[N];
   int row0_;
-  __device__ __forceinline__ void load(const bf16_t* src, int ld, int row0, int nrows_valid, int tid) {
+  // full tiles (wave-uniform test, a real branch): unconditional loads from uniform base + per-thread offset.  Only the last tile of a
+  // ragged sequence takes the clamped path (loads stay unconditional there too: a predicated load + zero select makes hipcc wait
+  // vmcnt(0) right after issue; out-of-range rows are zeroed at store time).
+  __device__ __forceinline__ void load(const RowGeom<D, ROWS>& gm, const bf16_t* src, int ld, int row0, int nrows_valid, int tid) {
     row0_ = row0;
+    if (row0 + ROWS <= nrows_valid) {
+      asm volatile("" ::: "memory");
+      // raw buffer load: resource (scalar) on the operand's base, the tile's first row in the scalar offset, the per-thread piece in
+      // a 32-bit VGPR offset -- no 64-bit per-thread pointers to keep or to advance (operand spans stay far below 2 GB per (batch, head))
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, 0x80000000u, 0x00020000);
+      const int soff = row0 * ld * 2;
+#pragma unroll
+      for (int i = 0; i < N; i++) r[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, gm.goff[i], soff, 0));
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < N; i++) {
       int u = tid + 256 * i;
@@ -125,18 +158,22 @@ struct RowStage {
       r[i] = *(const uint4*)(src + (size_t)row * ld + 8 * c);
     }
   }
-  // full (wave-uniform): every row of the tile is valid -> no per-piece validity selects (the common case: only the last
-  // tile of a ragged sequence is partial)
-  __device__ __forceinline__ void store(char* dst, int nrows_valid, int tid) const {
-    const bool full = row0_ + ROWS <= nrows_valid;
+  __device__ __forceinline__ void store(const RowGeom<D, ROWS>& gm, char* dst, int nrows_valid, int tid) const {
+    if (row0_ + ROWS <= nrows_valid) {
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < N; i++)
+        if (tid + 256 * i < ROWS * C::DG) *(uint4*)(dst + gm.loff[i]) = r[i];
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < N; i++) {
       int u = tid + 256 * i;
-      int rr = u / C::DG, c = u - rr * C::DG;
+      int rr = u / C::DG;
       if (u < ROWS * C::DG) {
         uint4 v = r[i];
-        if (!full && row0_ + rr >= nrows_valid) v = make_uint4(0u, 0u, 0u, 0u);
-        *(uint4*)(dst + (rr * C::RKU + c) * 16) = v;
+        if (row0_ + rr >= nrows_valid) v = make_uint4(0u, 0u, 0u, 0u);
+        *(uint4*)(dst + gm.loff[i]) = v;
       }
     }
   }
@@ -162,8 +199,10 @@ __device__ __forceinline__ bf16x8 pack_frag(const f32x16& p, int half) {
 }
 
 // ============================================================================ forward
+// second launch-bound = minimum waves per SIMD (HIP): head dims up to 64 fit three workgroups per CU (<= 168 VGPRs), which hides the
+// barrier / LDS latencies of a tile measurably better than two (tools/attn_occupancy.py)
 template <int D>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t* o,
+__global__ __launch_bounds__(256, (D <= 64 ? 3 : 1)) void attn_fwd_kernel(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t* o,
                                                        float* lse, int H, int Lq, int Lk, int ldq, int ldk, int ldo, float scale ATTN_DBG_PARAM) {
   using C = AttnCfg<D>;
   __shared__ __attribute__((aligned(16))) char Ks[TileBytes<D>::value];
@@ -189,8 +228,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* q, const bf
   fill_pad_chunks<D, 64>(Ks, tid, false);
   fill_pad_chunks<D, 64>(Vs, tid, ONES);
   const TrFrag<D> trf(lane);
+  const RowGeom<D, 64> geo(ldk, tid);
   RowStage<D, 64> kst, vst;
-  if (AttnPrefetch<D>::value) { kst.load(kb, ldk, 0, Lk, tid); vst.load(vb, ldk, 0, Lk, tid); }
+  if (AttnPrefetch<D>::value) { kst.load(geo, kb, ldk, 0, Lk, tid); vst.load(geo, vb, ldk, 0, Lk, tid); }
 #ifdef PCM_ABLATE
   const bool stamp_on = blockIdx.x == gridDim.x / 2 && blockIdx.y == gridDim.y / 2 && blockIdx.z == gridDim.z / 2;
 #endif
@@ -199,7 +239,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* q, const bf
     if (!ATTN_ABL(16)) __syncthreads();
     ATTN_STAMP(1);
     if (AttnPrefetch<D>::value) {
-      if (!ATTN_ABL(2) || kv0 == 0) { kst.store(Ks, Lk, tid); vst.store(Vs, Lk, tid); }
+      if (!ATTN_ABL(2) || kv0 == 0) { kst.store(geo, Ks, Lk, tid); vst.store(geo, Vs, Lk, tid); }
     } else {
       load_rowmajor<D, 64>(Ks, kb, ldk, kv0, Lk, tid);
       load_rowmajor<D, 64>(Vs, vb, ldk, kv0, Lk, tid);
@@ -207,7 +247,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* q, const bf
     ATTN_STAMP(2);
     if (!ATTN_ABL(16)) __syncthreads();
     ATTN_STAMP(3);
-    if (AttnPrefetch<D>::value && kv0 + 64 < Lk && !ATTN_ABL(2)) { kst.load(kb, ldk, kv0 + 64, Lk, tid); vst.load(vb, ldk, kv0 + 64, Lk, tid); }
+    if (AttnPrefetch<D>::value && kv0 + 64 < Lk && !ATTN_ABL(2)) { kst.load(geo, kb, ldk, kv0 + 64, Lk, tid); vst.load(geo, vb, ldk, kv0 + 64, Lk, tid); }
     f32x16 s_[2];
 #pragma unroll
     for (int t = 0; t < 2; t++) {
@@ -243,27 +283,34 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* q, const bf
 #pragma unroll
       for (int r = 0; r < 16; r++) mxa[r & 3] = fmaxf(mxa[r & 3], s_[t][r]);
     float mx = pcm_xhalf_max(fmaxf(fmaxf(mxa[0], mxa[1]), fmaxf(mxa[2], mxa[3])));
-    float m_new = fmaxf(m_run, mx * sc);
-    float psum = 0.f;
-#pragma unroll
-    for (int t = 0; t < 2; t++)
-#pragma unroll
-      for (int r = 0; r < 16; r++) {
-        float p = ATTN_ABL(1) ? fmaf(s_[t][r], sc, -m_new) : PCM_EXP2F(fmaf(s_[t][r], sc, -m_new));
-        s_[t][r] = p;
-        if (!ONES) psum += p;
-      }
-    if (__all(m_new == m_run)) {      // running max unchanged for the whole wave: no rescale pass
-      l_run += psum;
-    } else {
-      float alpha = PCM_EXP2F(m_run - m_new);
-      l_run = l_run * alpha + psum;
+    const float m_new = fmaxf(m_run, mx * sc);
+    // Lazy reference update: the running reference m_run only has to keep exp2(s*sc - m_run) inside the fp32 / bf16 range, it need not be
+    // the exact row maximum (softmax is shift invariant; the final 1/l and the LSE use the same reference).  While no row of the wave
+    // has grown by more than 2^8 the old reference stays (p <= 256, same relative precision in bf16) and the rescale of the O
+    // accumulators -- 16 v_pk_mul_f32 + an exp per tile, needed on most tiles when the test was "m_new == m_run" -- is skipped.
+    if (!__all(m_new <= m_run + 8.0f)) {
+      const float alpha = PCM_EXP2F(m_run - m_new);
+      l_run *= alpha;
       m_run = m_new;
 #pragma unroll
       for (int i = 0; i < C::DV; i++)
 #pragma unroll
         for (int r = 0; r < 16; r++) acc_o[i][r] *= alpha;
     }
+    float psum = 0.f;
+    {
+      const f32x2 sc2 = {sc, sc}, nm2 = {-m_run, -m_run};
+#pragma unroll
+      for (int t = 0; t < 2; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {       // two scores per v_pk_fma_f32
+          const f32x2 x = pcm_pk_fma(f32x2{s_[t][r], s_[t][r + 1]}, sc2, nm2);
+          const float p0 = ATTN_ABL(1) ? x[0] : PCM_EXP2F(x[0]), p1 = ATTN_ABL(1) ? x[1] : PCM_EXP2F(x[1]);
+          s_[t][r] = p0; s_[t][r + 1] = p1;
+          if (!ONES) psum += p0 + p1;
+        }
+    }
+    l_run += psum;
     bf16x8 pf[4];
 #pragma unroll
     for (int ss = 0; ss < 4; ss++) pf[ss] = pack_frag(s_[ss >> 1], ss & 1);
@@ -330,7 +377,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* o, const 
 
 // ============================================================================ backward: dQ
 template <int D>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* q, const bf16_t* k, const bf16_t* v, const bf16_t* dO,
+__global__ __launch_bounds__(256, (D <= 40 ? 3 : 1)) void attn_bwd_dq_kernel(const bf16_t* q, const bf16_t* k, const bf16_t* v, const bf16_t* dO,
                                                           const float* lse, const float* delta, bf16_t* dq, int H, int Lq,
                                                           int Lk, int ldq, int ldk, int ldo, float scale) {
   using C = AttnCfg<D>;
@@ -360,19 +407,21 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* q, const
   fill_pad_chunks<D, 64>(Ks, tid, false);
   fill_pad_chunks<D, 64>(Vs, tid, false);
   const TrFrag<D> trf(lane);
+  const RowGeom<D, 64> geo(ldk, tid);
   RowStage<D, 64> kst, vst;
-  if (AttnPrefetch<D>::value) { kst.load(kb, ldk, 0, Lk, tid); vst.load(vb, ldk, 0, Lk, tid); }
+  if (AttnPrefetch<D>::value) { kst.load(geo, kb, ldk, 0, Lk, tid); vst.load(geo, vb, ldk, 0, Lk, tid); }
+  const f32x2 sc2 = {sc, sc}, nl2 = {-L2, -L2}, scl2 = {scale, scale}, ndl2 = {-dl * scale, -dl * scale};
   for (int kv0 = 0; kv0 < Lk; kv0 += 64) {
     __syncthreads();
     if (AttnPrefetch<D>::value) {
-      kst.store(Ks, Lk, tid); vst.store(Vs, Lk, tid);
+      kst.store(geo, Ks, Lk, tid); vst.store(geo, Vs, Lk, tid);
     } else {
       load_rowmajor<D, 64>(Ks, kb, ldk, kv0, Lk, tid);
       load_rowmajor<D, 64>(Vs, vb, ldk, kv0, Lk, tid);
     }
     __syncthreads();
     if (AttnPrefetch<D>::value && kv0 + 64 < Lk) {
-      kst.load(kb, ldk, kv0 + 64, Lk, tid); vst.load(vb, ldk, kv0 + 64, Lk, tid);
+      kst.load(geo, kb, ldk, kv0 + 64, Lk, tid); vst.load(geo, vb, ldk, kv0 + 64, Lk, tid);
     }
     f32x16 s_[2], dp[2];
 #pragma unroll
@@ -387,12 +436,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* q, const
         dp[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[s], dp[t], 0, 0, 0);
       }
     }
+    // dS^T = p * (dP - delta) * scale, two scores per packed instruction: v_pk_fma (exponent), 2 x v_exp, v_pk_fma ((dP - delta) * scale),
+    // v_pk_mul -- 2.5 VALU per score instead of 5 (VALU time is not hidden behind the MFMAs on this chip)
 #pragma unroll
     for (int t = 0; t < 2; t++)
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        float p = PCM_EXP2F(fmaf(s_[t][r], sc, -L2));
-        s_[t][r] = p * (dp[t][r] - dl) * scale;  // dS^T
+      for (int r = 0; r < 16; r += 2) {
+        const f32x2 x = pcm_pk_fma(f32x2{s_[t][r], s_[t][r + 1]}, sc2, nl2);
+        const f32x2 p = {PCM_EXP2F(x[0]), PCM_EXP2F(x[1])};
+        const f32x2 y = pcm_pk_fma(f32x2{dp[t][r], dp[t][r + 1]}, scl2, ndl2) * p;
+        s_[t][r] = y[0]; s_[t][r + 1] = y[1];
       }
     if (kv0 + 64 > Lk) {
       asm volatile("" ::: "memory");   // keep this a real (wave-uniform) branch: if-converted it costs 3 VALU ops per score in every tile
@@ -440,7 +493,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16_t* q, con
   using C = AttnCfg<D>;
   __shared__ __attribute__((aligned(16))) char Qs[TileBytes<D>::value];
   __shared__ __attribute__((aligned(16))) char Os[TileBytes<D>::value];
-  __shared__ float L2s[64], dls[64];
+  __shared__ __attribute__((aligned(16))) float L2s[64], dls[64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y, kv0 = blockIdx.x * 128 + wave * 32;
   const bf16_t* qb = q + (size_t)b * Lq * ldq + h * D;
@@ -464,30 +517,37 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16_t* q, con
   fill_pad_chunks<D, 64>(Qs, tid, false);
   fill_pad_chunks<D, 64>(Os, tid, false);
   const TrFrag<D> trf(lane);
+  const RowGeom<D, 64> geq(ldq, tid), geo(ldo, tid);
   RowStage<D, 64> qst, ost;
   float l2r = 0.f, dlr = 0.f;
+  const float* lse_bh = lse + ((size_t)b * H + h) * Lq;
+  const float* dl_bh = delta + ((size_t)b * H + h) * Lq;
   auto stage_load = [&](int q0_) {
-    qst.load(qb, ldq, q0_, Lq, tid); ost.load(dob, ldo, q0_, Lq, tid);
-    {
+    qst.load(geq, qb, ldq, q0_, Lq, tid); ost.load(geo, dob, ldo, q0_, Lq, tid);
+    if (q0_ + 64 <= Lq) {          // uniform base + lane offset; only the ragged last tile clamps
+      asm volatile("" ::: "memory");
+      l2r = lse_bh[q0_ + (tid & 63)];
+      dlr = dl_bh[q0_ + (tid & 63)];
+    } else {
       int qr = q0_ + (tid & 63);
       if (qr >= Lq) qr = Lq - 1;
-      l2r = lse[((size_t)b * H + h) * Lq + qr];
-      dlr = delta[((size_t)b * H + h) * Lq + qr];
+      l2r = lse_bh[qr];
+      dlr = dl_bh[qr];
     }
   };
   if (AttnPrefetch<D>::value) stage_load(0);
   for (int qq0 = 0; qq0 < Lq; qq0 += 64) {
     __syncthreads();
     if (AttnPrefetch<D>::value) {
-      qst.store(Qs, Lq, tid); ost.store(Os, Lq, tid);
-      if (tid < 64) { L2s[tid] = l2r; dls[tid] = dlr; }
+      qst.store(geq, Qs, Lq, tid); ost.store(geo, Os, Lq, tid);
+      if (tid < 64) { L2s[tid] = -l2r; dls[tid] = -dlr * scale; }
     } else {
       load_rowmajor<D, 64>(Qs, qb, ldq, qq0, Lq, tid);
       load_rowmajor<D, 64>(Os, dob, ldo, qq0, Lq, tid);
       if (tid < 64) {
         int qr = qq0 + tid;
-        L2s[tid] = qr < Lq ? lse[((size_t)b * H + h) * Lq + qr] : 0.f;
-        dls[tid] = qr < Lq ? delta[((size_t)b * H + h) * Lq + qr] : 0.f;
+        L2s[tid] = qr < Lq ? -lse_bh[qr] : 0.f;
+        dls[tid] = qr < Lq ? -dl_bh[qr] * scale : 0.f;
       }
     }
     __syncthreads();
@@ -505,15 +565,22 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16_t* q, con
         dp[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ofr, vf[s], dp[t], 0, 0, 0);   // dP[q][kv]
       }
     }
+    // L2s / dls hold -lse and -delta*scale of the tile's 64 queries: the addends of the two packed fmas (see the dQ kernel)
+    {
+      const f32x2 sc2 = {sc, sc}, scl2 = {scale, scale};
 #pragma unroll
-    for (int t = 0; t < 2; t++)
+      for (int t = 0; t < 2; t++)
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        int ql = 32 * t + 4 * hi + (r & 3) + 8 * (r >> 2);
-        float p = PCM_EXP2F(fmaf(s_[t][r], sc, -L2s[ql]));
-        dp[t][r] = p * (dp[t][r] - dls[ql]) * scale;  // dS[q][kv]
-        s_[t][r] = p;
-      }
+        for (int r = 0; r < 16; r += 2) {
+          const int ql = 32 * t + 4 * hi + (r & 3) + 8 * (r >> 2);     // r even -> ql even: the pair (ql, ql + 1) is one 8-byte LDS read
+          const f32x2 nl = *(const f32x2*)&L2s[ql], nd = *(const f32x2*)&dls[ql];
+          const f32x2 x = pcm_pk_fma(f32x2{s_[t][r], s_[t][r + 1]}, sc2, nl);
+          const f32x2 p = {PCM_EXP2F(x[0]), PCM_EXP2F(x[1])};
+          const f32x2 y = pcm_pk_fma(f32x2{dp[t][r], dp[t][r + 1]}, scl2, nd) * p;   // dS[q][kv]
+          dp[t][r] = y[0]; dp[t][r + 1] = y[1];
+          s_[t][r] = p[0]; s_[t][r + 1] = p[1];
+        }
+    }
     if (!blk_full || qq0 + 64 > Lq) {
       asm volatile("" ::: "memory");   // real branch, see the forward kernel
 #pragma unroll

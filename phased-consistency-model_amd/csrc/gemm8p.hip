@@ -427,6 +427,37 @@ __global__ __launch_bounds__(512) void pcm_gemm8p_kernel(GemmDev g) {
       }
       continue;
     }
+    if (g.res || g.rowvec) {
+      // pieces with a residual / row-vector operand: two pieces per trip, their global loads issued before the first is consumed (one
+      // after the other every piece pays the full load latency: 0.93x on the residual-carrying projections, tools/gemm_ab_libs.py).
+      // Deeper unrolling spills (the accumulators of the later passes are still live), and pieces without such operands lose 5-10 %
+      // to the longer code, so they keep the plain loop below.
+      constexpr int IT = 64 * C8 / 512;
+      static_assert(IT * 512 == 64 * C8, "store loop covers the pass exactly");
+      for (int it0 = 0; it0 < IT; it0 += 2) {
+        EpiAux aux[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+          const int idx = tid + 512 * (it0 + u);
+          const int lr = idx / C8, c8 = idx - lr * C8;
+          const int m = m0 + 128 * (lr >> 5) + 32 * q + (lr & 31), n = n0 + 8 * c8;
+          if (it0 + u < IT && m < g.M && n < g.N) aux[u] = pcm_epi_load8(g, m, n);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+          const int idx = tid + 512 * (it0 + u);
+          const int lr = idx / C8, c8 = idx - lr * C8;
+          const int m = m0 + 128 * (lr >> 5) + 32 * q + (lr & 31), n = n0 + 8 * c8;
+          if (it0 + u >= IT || m >= g.M || n >= g.N) continue;
+          const float4 lo = *(const float4*)(smem + ((size_t)lr * CH + ((2 * c8) ^ (lr & 15))) * 16);
+          const float4 hi4 = *(const float4*)(smem + ((size_t)lr * CH + ((2 * c8 + 1) ^ (lr & 15))) * 16);
+          float v[8] = {lo.x, lo.y, lo.z, lo.w, hi4.x, hi4.y, hi4.z, hi4.w};
+          if (PCM_ABL(1)) { if (v[0] != 123456.f) continue; }
+          pcm_epi_finish8(g, m, n, v, aux[u]);
+        }
+      }
+      continue;
+    }
     for (int idx = tid; idx < 64 * C8; idx += 512) {
       const int lr = idx / C8, c8 = idx - lr * C8;
       const int m = m0 + 128 * (lr >> 5) + 32 * q + (lr & 31), n = n0 + 8 * c8;

@@ -60,6 +60,38 @@ __device__ __forceinline__ void pcm_epi_store8(const GemmDev& g, int m, int n, f
   *(uint4*)((bf16_t*)g.out + (size_t)m * g.ldo + n) = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
 }
 
+// The same epilogue split into a LOAD half and a FINISH half so that a kernel can put the global loads (row vector, residual) of several
+// 8-channel pieces in flight before it consumes the first one (gemm8p.hip: 4-5 pieces per thread per pass; issued one after the other
+// each piece pays the full load latency).
+struct EpiAux { uint4 rowvec, res; };
+__device__ __forceinline__ EpiAux pcm_epi_load8(const GemmDev& g, int m, int n) {
+  EpiAux x;
+  x.rowvec = g.rowvec ? *(const uint4*)(g.rowvec + (size_t)(m / g.rpb) * g.N + n) : make_uint4(0u, 0u, 0u, 0u);
+  x.res = g.res ? *(const uint4*)(g.res + (size_t)m * g.ldr + n) : make_uint4(0u, 0u, 0u, 0u);
+  return x;
+}
+__device__ __forceinline__ void pcm_epi_finish8(const GemmDev& g, int m, int n, float v[8], const EpiAux& x) {
+  if (g.bias) {
+    const float4 b0 = *(const float4*)(g.bias + n), b1 = *(const float4*)(g.bias + n + 4);
+    v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+  }
+  if (g.rowvec) {
+    const unsigned tw[4] = {x.rowvec.x, x.rowvec.y, x.rowvec.z, x.rowvec.w};
+#pragma unroll
+    for (int e = 0; e < 4; e++) { v[2 * e] += bf2f((bf16_t)(tw[e] & 0xffff)); v[2 * e + 1] += bf2f((bf16_t)(tw[e] >> 16)); }
+  }
+  if (g.act == PCM_ACT_SILU) {
+#pragma unroll
+    for (int e = 0; e < 8; e++) v[e] = silu_f(v[e]);
+  }
+  if (g.res) {
+    const unsigned tw[4] = {x.res.x, x.res.y, x.res.z, x.res.w};
+#pragma unroll
+    for (int e = 0; e < 4; e++) { v[2 * e] += bf2f((bf16_t)(tw[e] & 0xffff)); v[2 * e + 1] += bf2f((bf16_t)(tw[e] >> 16)); }
+  }
+  *(uint4*)((bf16_t*)g.out + (size_t)m * g.ldo + n) = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+}
+
 // 256 x (64*FN) phased kernel (gemm8p.hip).  fn = 5 -> 256x320, fn = 4 -> 256x256.  grid = (tiles_m*tiles_n, splitk)
 int pcm_gemm8p_launch(const GemmDev& g, int fn, void* stream);
 size_t pcm_gemm8p_lds_bytes(int fn);

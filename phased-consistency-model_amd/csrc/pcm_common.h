@@ -67,6 +67,10 @@ typedef short bf16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ bf16x8 pcm_join4(bf16x4 a, bf16x4 b) { return bf16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]}; }
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+// two fp32 values per VALU instruction (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: 4.5 SIMD cycles for two results against 3.2 for one
+// v_fma_f32, tools/probes/valubench.hip) -- element-wise operators on this type select the packed instructions
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pcm_pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 typedef unsigned short bf16_t;
 
 // thread-local last-error string (C-ABI: never throw across the boundary)

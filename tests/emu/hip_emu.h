@@ -213,6 +213,15 @@ inline void buffer_load_lds(BufferRsrc rs, void* lds, int size, uint32_t voff, u
   dma_issue((char*)w.lp[bsel][0] + (size_t)l * size, oob ? nullptr : rs.base + voff + soff, size);
 }
 
+// plain buffer load of 16 bytes per lane (register destination): same address rule as buffer_load_lds, synchronous
+typedef int emu_v4i __attribute__((ext_vector_type(4)));
+inline emu_v4i buffer_load_b128(BufferRsrc rs, uint32_t voff, uint32_t soff, int) {
+  emu_v4i r = {0, 0, 0, 0};
+  bool oob = soff > rs.num_records || voff >= rs.num_records - soff;
+  if (!oob) memcpy(&r, rs.base + voff + soff, 16);
+  return r;
+}
+
 }  // namespace pcm_emu
 
 #define threadIdx (pcm_emu::g_threadIdx)
@@ -233,6 +242,7 @@ inline void buffer_load_lds(BufferRsrc rs, void* lds, int size, uint32_t voff, u
 typedef pcm_emu::BufferRsrc __amdgpu_buffer_rsrc_t;
 #define __builtin_amdgcn_make_buffer_rsrc(p, stride, n, flags) pcm_emu::make_buffer_rsrc((const void*)(p), stride, n, flags)
 #define __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, l, size, voff, soff, imm, aux) pcm_emu::buffer_load_lds(rs, (void*)(l), size, voff, soff, imm, aux)
+#define __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, aux) pcm_emu::buffer_load_b128(rs, voff, soff, aux)
 #define PCM_WAIT_VMCNT(n) pcm_emu::wait_vmcnt(n)
 #define PCM_WAIT_LGKMCNT0() ((void)0)
 
