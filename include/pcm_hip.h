@@ -108,6 +108,9 @@ typedef struct {
   float alpha;
 } pcm_wgrad_args;
 int pcm_lora_wgrad_bf16(const pcm_wgrad_args* a, void* stream);
+/* n (1..64) independent jobs of the call above in as few launches as possible: the weight gradients of one autograd node (lora_A and
+ * lora_B of a module; the six of a fused q/k/v projection) are 3-20 us kernels each, so they share launches.  Same result as n calls. */
+int pcm_lora_wgrad_multi_bf16(const pcm_wgrad_args* list, int n, void* stream);
 
 /* ---- GroupNorm(32)(+SiLU), channels-last  (diffusers ResnetBlock2D.norm1/2, conv_norm_out,
  * Transformer2DModel.norm) --------------------------------------------------------------- */

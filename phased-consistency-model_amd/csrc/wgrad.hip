@@ -129,11 +129,11 @@ extern "C" void pcm_debug_wgrad_grid(int target_blocks, int min_chunks) {   // t
   g_wg_minchunks = min_chunks > 0 ? min_chunks : 4;
 }
 
-extern "C" int pcm_lora_wgrad_bf16(const pcm_wgrad_args* p, void* stream) {
+static int wg_convert(const pcm_wgrad_args* p, WgDev& a) {
   PCM_CHECK(p && p->big && p->small_ && p->out && p->M > 0 && p->G > 0, PCM_EINVAL, "pcm_lora_wgrad_bf16: null/empty");
   PCM_CHECK(PCM_ALIGNED16(p->big) && PCM_ALIGNED16(p->small_) && (p->lds_ % 8) == 0 && p->lds_ >= 64, PCM_EALIGN,
             "pcm_lora_wgrad_bf16: operand alignment / small ld");
-  WgDev a; memset(&a, 0, sizeof(a));
+  memset(&a, 0, sizeof(a));
   a.big = (const bf16_t*)p->big; a.ldb = p->ldb; a.G = p->G; a.mode = p->mode; a.Hs = p->Hs; a.Ws = p->Ws; a.C = p->C;
   a.stride = p->stride; a.src_mode = p->src_mode; a.Ho = p->Ho > 0 ? p->Ho : 1; a.Wo = p->Wo > 0 ? p->Wo : 1;
   a.small_ = (const bf16_t*)p->small_; a.lds_ = p->lds_; a.M = p->M; a.out = p->out; a.g_stride = p->g_stride;
@@ -146,6 +146,26 @@ extern "C" int pcm_lora_wgrad_bf16(const pcm_wgrad_args* p, void* stream) {
     PCM_CHECK(p->mode == PCM_SEG_PLAIN && (p->G % 8) == 0 && (p->ldb % 8) == 0 && p->ldb >= p->G && !p->out_conv, PCM_EINVAL,
               "pcm_lora_wgrad_bf16: plain view needs G%%8==0, ldb%%8==0");
   }
+  return PCM_OK;
+}
+
+// n independent weight gradients (pcm_hip.h): the plain-view jobs share launches (wgrad_tr.hip), the others run as single calls
+extern "C" int pcm_lora_wgrad_multi_bf16(const pcm_wgrad_args* list, int n, void* stream) {
+  PCM_CHECK(list && n > 0 && n <= 64, PCM_EINVAL, "pcm_lora_wgrad_multi_bf16: 1..64 jobs");
+  WgDev jobs[64];
+  unsigned char taken[64];
+  for (int i = 0; i < n; i++)
+    if (int rc = wg_convert(list + i, jobs[i])) return rc;
+  if (int rc = pcm_wgrad_tr_launch_multi(jobs, n, taken, stream)) return rc;
+  for (int i = 0; i < n; i++)
+    if (!taken[i])
+      if (int rc = pcm_lora_wgrad_bf16(list + i, stream)) return rc;
+  return pcm_post_launch("pcm_lora_wgrad_multi_bf16");
+}
+
+extern "C" int pcm_lora_wgrad_bf16(const pcm_wgrad_args* p, void* stream) {
+  WgDev a;
+  if (int rc = wg_convert(p, a)) return rc;
   {   // LDS-DMA + transpose-read kernels (wgrad_tr.hip) for the plain and the stride-1 3x3 views; everything else stays here
     const int rc = pcm_wgrad_tr_launch(a, stream);
     if (rc == 0) return pcm_post_launch("pcm_lora_wgrad_bf16");

@@ -10,5 +10,8 @@ struct WgDev {
 };
 
 
+#define PCM_WGRAD_MULTI_MAX 8
+// several plain-view jobs in one launch (wgrad_tr.hip); taken[i] = 1 for the jobs it launched, the caller runs the others one by one
+int pcm_wgrad_tr_launch_multi(const WgDev* jobs, int n, unsigned char* taken, void* stream);
 // returns 0 when a transpose-read kernel took the call, 1 when the geometry is not one of theirs (caller falls back), < 0 on error
 int pcm_wgrad_tr_launch(const WgDev& a, void* stream);

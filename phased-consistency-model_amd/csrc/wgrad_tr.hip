@@ -15,6 +15,7 @@
 // LDS images carry an XOR swizzle on the 16-B chunk index so that the 4 rows x 32 B quads of a transpose read fall on distinct banks;
 // the DMA writes LDS linearly, so the swizzle is applied to the SOURCE chunk a lane fetches (guide rule 21).
 #include <stdlib.h>
+#include <string.h>
 
 #include "wgrad_dev.h"
 
@@ -22,15 +23,13 @@
 #define WT_OOB 0x80000000u
 
 // ------------------------------------------------------------------------------------------------ plain view
-template <bool SWAP>
-__global__ __launch_bounds__(256) void pcm_wgrad_tr_kernel(WgDev a) {
-#if defined(__HIP_DEVICE_COMPILE__) || defined(PCM_HOST_EMU)
+template <bool SWAP, typename WG>
+__device__ __forceinline__ void pcm_wgrad_tr_body(const WG& a, const int bx, const int by, char* smem) {
   constexpr int BIGB = 64 * 256, SMB = 64 * 128, STAGE = BIGB + SMB;   // Big tile [64][128] bf16, Small tile [64][64] bf16
-  PCM_DYN_SMEM(smem);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int g0 = blockIdx.x * 128;
-  const int m_begin = blockIdx.y * a.m_per_block;
+  const int g0 = bx * 128;
+  const int m_begin = by * a.m_per_block;
   int m_end = m_begin + a.m_per_block; if (m_end > a.M) m_end = a.M;
   const int nst = (m_end - m_begin + 63) >> 6;
   // ---- DMA geometry.  Big: one instruction = 4 rows x 16 chunks (lane -> row lane>>4, LDS chunk lane&15); Small: 8 rows x 8 chunks.
@@ -114,6 +113,36 @@ __global__ __launch_bounds__(256) void pcm_wgrad_tr_kernel(WgDev a) {
       const int g = g0 + 32 * wave + (SWAP ? l31 : ii), r = 32 * rt + (SWAP ? ii : l31);
       if (g < a.G) atomicAdd(a.out + (size_t)g * a.g_stride + (size_t)r * a.r_stride, acc[rt][e] * a.alpha);
     }
+}
+template <bool SWAP>
+__global__ __launch_bounds__(256) void pcm_wgrad_tr_kernel(WgDev a) {
+#if defined(__HIP_DEVICE_COMPILE__) || defined(PCM_HOST_EMU)
+  PCM_DYN_SMEM(smem);
+  pcm_wgrad_tr_body<SWAP>(a, blockIdx.x, blockIdx.y, smem);
+#endif
+}
+// Several independent weight gradients in ONE launch (the dA / dB pair of a LoRA module, the six of a fused q/k/v projection): the
+// single launches are 3-20 us of work behind ~4 us of launch + ramp each (556 per bs-16 step).  1-D grid; a block finds its job by the
+// prefix table and reads that job's argument block from the kernarg segment by index (scalar loads; no per-job copies in registers).
+struct WgMulti { WgDev d[PCM_WGRAD_MULTI_MAX]; int blk_start[PCM_WGRAD_MULTI_MAX + 1]; int tiles_g[PCM_WGRAD_MULTI_MAX]; int n; };
+__global__ __launch_bounds__(256) void pcm_wgrad_tr_multi_kernel(WgMulti mm) {
+#if defined(__HIP_DEVICE_COMPILE__) || defined(PCM_HOST_EMU)
+  PCM_DYN_SMEM(smem);
+  const int bid = blockIdx.x;
+  int i = 0;
+#pragma unroll
+  for (int k = 1; k < PCM_WGRAD_MULTI_MAX; k++)
+    if (k < mm.n && bid >= mm.blk_start[k]) i = k;
+  const int lid = bid - mm.blk_start[i], tg = mm.tiles_g[i];
+  const int by = lid / tg, bx = lid - by * tg;
+#ifdef PCM_HOST_EMU
+  const WgDev& a = mm.d[i];
+#else
+  typedef const __attribute__((address_space(4))) WgDev* kptr;
+  const __attribute__((address_space(4))) WgDev& a = ((kptr)__builtin_amdgcn_kernarg_segment_ptr())[i];   // d[] is the first member
+#endif
+  if (a.swap) pcm_wgrad_tr_body<true>(a, bx, by, smem);
+  else pcm_wgrad_tr_body<false>(a, bx, by, smem);
 #endif
 }
 
@@ -243,6 +272,56 @@ static long g_wgtr_count[2] = {0, 0};   // tests: launches taken by the plain / 
 extern "C" long pcm_debug_wgrad_tr_count(int conv) { return g_wgtr_count[conv ? 1 : 0]; }
 static int g_wgtr_blocks = 512, g_wgtr_auto = 1;      // tuning hook: n > 0 forces ~n blocks, 0 restores the shipped rule
 extern "C" void pcm_debug_wgrad_tr_blocks(int n) { g_wgtr_auto = n <= 0; g_wgtr_blocks = n > 0 ? n : 512; }
+
+// plain view: is it one of this file's, and how is it split?  (fills a.m_per_block; returns false -> caller falls back)
+static bool wgtr_plan_plain(WgDev& a, int* tiles_g_out, int* msplit_out) {
+  if (g_wgtr_mode < 0) { const char* e = getenv("PCM_WGRAD_TR"); g_wgtr_mode = e ? atoi(e) : 1; }
+  if (!g_wgtr_mode || a.out_conv || a.mode == PCM_SEG_CONV3X3) return false;
+  if ((size_t)a.M * a.lds_ * 2 >= 0x7ff00000u || (size_t)a.M * a.ldb * 2 >= 0x7ff00000u) return false;
+  auto cdiv = [](long x, long y) { return (int)((x + y - 1) / y); };
+  const int tiles_g = cdiv(a.G, 128), stages = cdiv(a.M, 64);
+  int msplit = a.M / 1024;
+  if (msplit * tiles_g < 128) msplit = cdiv(128, tiles_g);
+  if (!g_wgtr_auto) msplit = cdiv(PCM_GRID_CAP(g_wgtr_blocks), tiles_g);
+  if (msplit * tiles_g > PCM_GRID_CAP(2048)) msplit = cdiv(PCM_GRID_CAP(2048), tiles_g);
+  if (msplit > cdiv(stages, 2)) msplit = cdiv(stages, 2);
+  if (msplit < 1) msplit = 1;
+  a.m_per_block = cdiv(stages, msplit) * 64;
+  *tiles_g_out = tiles_g; *msplit_out = cdiv(a.M, a.m_per_block);
+  return true;
+}
+static long g_wgtr_multi = 0;   // tests: multi-job launches
+extern "C" long pcm_debug_wgrad_tr_multi_count(void) { return g_wgtr_multi; }
+// jobs[0..n): plain-view jobs that wgtr_plan_plain accepted are packed into launches of up to PCM_WGRAD_MULTI_MAX; taken[i] = 1 for those
+int pcm_wgrad_tr_launch_multi(const WgDev* jobs, int n, unsigned char* taken, void* stream) {
+  WgMulti mm; memset(&mm, 0, sizeof(mm));
+  const size_t smem = 2 * (64 * 256 + 64 * 128);
+  auto flush = [&]() {
+    if (mm.n == 0) return;
+    if (mm.n == 1) {
+      const WgDev& a = mm.d[0];
+      const int msplit = mm.blk_start[1] / mm.tiles_g[0];
+      if (a.swap) PCM_LAUNCH((pcm_wgrad_tr_kernel<true>), dim3(mm.tiles_g[0], msplit), dim3(256), smem, stream, a);
+      else PCM_LAUNCH((pcm_wgrad_tr_kernel<false>), dim3(mm.tiles_g[0], msplit), dim3(256), smem, stream, a);
+    } else {
+      PCM_LAUNCH(pcm_wgrad_tr_multi_kernel, dim3(mm.blk_start[mm.n]), dim3(256), smem, stream, mm);
+      g_wgtr_multi++;
+    }
+    g_wgtr_count[0] += mm.n;
+    mm.n = 0;
+  };
+  for (int i = 0; i < n; i++) {
+    WgDev a = jobs[i];
+    int tg = 0, ms = 0;
+    taken[i] = 0;
+    if (!wgtr_plan_plain(a, &tg, &ms)) continue;
+    taken[i] = 1;
+    mm.d[mm.n] = a; mm.tiles_g[mm.n] = tg; mm.blk_start[mm.n + 1] = mm.blk_start[mm.n] + tg * ms; mm.n++;
+    if (mm.n == PCM_WGRAD_MULTI_MAX) flush();
+  }
+  flush();
+  return 0;
+}
 
 int pcm_wgrad_tr_launch(const WgDev& a0, void* stream) {
   if (g_wgtr_mode < 0) { const char* e = getenv("PCM_WGRAD_TR"); g_wgtr_mode = e ? atoi(e) : 1; }

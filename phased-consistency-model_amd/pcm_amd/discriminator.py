@@ -186,13 +186,15 @@ class Discriminator:
         C = hd.C
         if self.ksize == 1:      # dW[co][ci] = sum_m dy[m][co] * x[m][ci]: plain rank-64 wgrad per 64 output channels
             gW = hd.g[name + ".weight"].view(C, C)
-            for co in range(0, C, 64):
-                ops.lora_wgrad(x.reshape(M, C), dy[:, co:co + 64], gW[co:co + 64], 1.0, M, G=C, g_stride=1, r_stride=C, lds=C)
+            with ops.wgrad_batch():       # the Cout/64 chunks share launches
+                for co in range(0, C, 64):
+                    ops.lora_wgrad(x.reshape(M, C), dy[:, co:co + 64], gW[co:co + 64], 1.0, M, G=C, g_stride=1, r_stride=C, lds=C)
             capi.lib().call("pcm_colsum_bf16", ops.ptr(dy), ops.ptr(hd.g[name + ".bias"]), 1, M, C, capi.Lib.stream())
             return
         gW = hd.g[name + ".weight"].view(C, 9 * C)
-        for co in range(0, C, 64):
-            ops.lora_wgrad(x, dy[:, co:co + 64], gW[co:co + 64], 1.0, M, conv=wg, g_stride=1, r_stride=9 * C, lds=C)
+        with ops.wgrad_batch():           # (3x3 view: the jobs the multi-launch kernel does not take run one by one inside the call)
+            for co in range(0, C, 64):
+                ops.lora_wgrad(x, dy[:, co:co + 64], gW[co:co + 64], 1.0, M, conv=wg, g_stride=1, r_stride=9 * C, lds=C)
         capi.lib().call("pcm_colsum_bf16", ops.ptr(dy), ops.ptr(hd.g[name + ".bias"]), 1, M, C, capi.Lib.stream())
 
     # ------------------------------------------------------------------ losses (discriminator_sd15.py:412-434)

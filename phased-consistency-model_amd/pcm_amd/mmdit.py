@@ -325,10 +325,11 @@ class MMDiT:
                     rk, t3, xn_ = lora.rank, r["t3"], r["xn"]
                     u3 = torch.empty(Mx, fq.r3, dtype=BF16, device=d_o.device)
                     ops.gemm([Seg(d3x, fq.Bs_cat_bwd, k_algo=D)], Mx, fq.r3, u3)
-                    for jj, lm in enumerate((fq.q, fq.k, fq.v)):
-                        ops.lora_wgrad(d3x[:, jj * D:(jj + 1) * D], t3[:, jj * rk:(jj + 1) * rk], lm.gB, lora.scaling, Mx, G=D, g_stride=rk, r_stride=1,
-                                       ldb=3 * D, lds=fq.r3)
-                        ops.lora_wgrad(xn_, u3[:, jj * rk:(jj + 1) * rk], lm.gA, 1.0, Mx, G=fq.K, g_stride=1, r_stride=fq.K, lds=fq.r3)
+                    with ops.wgrad_batch():
+                        for jj, lm in enumerate((fq.q, fq.k, fq.v)):
+                            ops.lora_wgrad(d3x[:, jj * D:(jj + 1) * D], t3[:, jj * rk:(jj + 1) * rk], lm.gB, lora.scaling, Mx, G=D, g_stride=rk, r_stride=1,
+                                           ldb=3 * D, lds=fq.r3)
+                            ops.lora_wgrad(xn_, u3[:, jj * rk:(jj + 1) * rk], lm.gA, 1.0, Mx, G=fq.K, g_stride=1, r_stride=fq.K, lds=fq.r3)
                     segs.append(Seg(u3, fq.A_cat_bwd))
                 d_xn = torch.empty(Mx, D, dtype=BF16, device=d_o.device)
                 ops.gemm(segs, Mx, D, d_xn)

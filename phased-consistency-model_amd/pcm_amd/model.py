@@ -375,12 +375,13 @@ def layer_bwd(W: UNetWeights, lora, path, dy, saved, need_dx=True, residual=None
         ops.gemm([Seg(dy, lm.Bs_bwd)], M, lm.r, u)                      # u = dy (sB)   [M, r]
 
         def wg():
-            ops.lora_wgrad(dy, t, lm.gB, lora.scaling, M, G=L.N, g_stride=lm.r, r_stride=1)   # dB = s dy^T t
-            if L.kind == "conv3":
-                ops.lora_wgrad(x, u, lm.gA, 1.0, M, conv=dict(Hs=geo.Hs, Ws=geo.Ws, Ho=geo.Ho, Wo=geo.Wo, stride=geo.stride,
-                                                              src_mode=geo.src_mode), g_stride=1, r_stride=L.K)
-            else:
-                ops.lora_wgrad(x, u, lm.gA, 1.0, M, G=L.K, g_stride=1, r_stride=L.K)          # dA = u^T x
+            with ops.wgrad_batch():       # dB and dA share one launch where the kernels allow it
+                ops.lora_wgrad(dy, t, lm.gB, lora.scaling, M, G=L.N, g_stride=lm.r, r_stride=1)   # dB = s dy^T t
+                if L.kind == "conv3":
+                    ops.lora_wgrad(x, u, lm.gA, 1.0, M, conv=dict(Hs=geo.Hs, Ws=geo.Ws, Ho=geo.Ho, Wo=geo.Wo, stride=geo.stride,
+                                                                  src_mode=geo.src_mode), g_stride=1, r_stride=L.K)
+                else:
+                    ops.lora_wgrad(x, u, lm.gA, 1.0, M, G=L.K, g_stride=1, r_stride=L.K)          # dA = u^T x
         _wgrad(wg, dy, t, x, u)
     if not need_dx:
         return None
@@ -536,9 +537,10 @@ class UNet:
             u3 = torch.empty(M, fq.r3, dtype=BF16, device=d_o.device)
             ops.gemm([Seg(d3, fq.Bs_cat_bwd, k_algo=C)], M, fq.r3, u3)                  # u_j = d_j (s B_j): block-diagonal operand
             def wg():
-                for j, (lm, dj) in enumerate(((fq.q, dq), (fq.k, dk), (fq.v, dv))):
-                    ops.lora_wgrad(dj, t3[:, j * r:(j + 1) * r], lm.gB, lora.scaling, M, G=C, g_stride=r, r_stride=1, ldb=3 * C, lds=fq.r3)
-                    ops.lora_wgrad(x, u3[:, j * r:(j + 1) * r], lm.gA, 1.0, M, G=fq.K, g_stride=1, r_stride=fq.K, lds=fq.r3)
+                with ops.wgrad_batch():       # six weight gradients, one launch
+                    for j, (lm, dj) in enumerate(((fq.q, dq), (fq.k, dk), (fq.v, dv))):
+                        ops.lora_wgrad(dj, t3[:, j * r:(j + 1) * r], lm.gB, lora.scaling, M, G=C, g_stride=r, r_stride=1, ldb=3 * C, lds=fq.r3)
+                        ops.lora_wgrad(x, u3[:, j * r:(j + 1) * r], lm.gA, 1.0, M, G=fq.K, g_stride=1, r_stride=fq.K, lds=fq.r3)
             _wgrad(wg, d3, t3, x, u3)
             d_xn = torch.empty(M, fq.K, dtype=BF16, device=d_o.device)
             ops.gemm([Seg(d3, W.qkv_bwd[p]), Seg(u3, fq.A_cat_bwd)], M, fq.K, d_xn)

@@ -439,7 +439,36 @@ def lora_wgrad(big, small, out, alpha, M, G=None, conv=None, g_stride=None, r_st
     a.g_stride = g_stride if g_stride is not None else 0
     a.r_stride = r_stride if r_stride is not None else 0
     a.out_conv = 1 if out_conv else 0
+    if _WG_BATCH is not None:
+        _WG_BATCH.append((a, big, small))      # the tensors stay referenced until the batch is launched
+        return
     capi.lib().call("pcm_lora_wgrad_bf16", C.byref(a), _stream())
+
+
+_WG_BATCH = None
+
+
+class wgrad_batch:
+    """``with ops.wgrad_batch(): ...`` -- the lora_wgrad calls inside are collected and issued by ONE pcm_lora_wgrad_multi_bf16 call at
+    exit (the weight gradients of one module: lora_A + lora_B, or the six of a fused q/k/v projection, share kernel launches).
+    Nothing else may be launched between a collected call and the exit that overwrites its operands."""
+
+    def __enter__(self):
+        global _WG_BATCH
+        assert _WG_BATCH is None, "wgrad_batch does not nest"
+        _WG_BATCH = []
+        return self
+
+    def __exit__(self, et, ev, tb):
+        global _WG_BATCH
+        jobs, _WG_BATCH = _WG_BATCH, None
+        if et is not None or not jobs:
+            return False
+        for i in range(0, len(jobs), 64):
+            chunk = jobs[i:i + 64]
+            arr = (WgradArgs * len(chunk))(*[j[0] for j in chunk])
+            capi.lib().call("pcm_lora_wgrad_multi_bf16", arr, len(chunk), _stream())
+        return False
 
 
 def attn_fwd(q, k, v, H, d, scale=None):

@@ -224,6 +224,32 @@ def case_wgrad_plain(dev, M, N, K):
     close(dA, 0.125 * u.float().cpu().T @ x.float().cpu(), 2e-3, 2e-3 * M ** 0.5, "dA")
 
 
+def case_wgrad_multi(dev):
+    """Ten independent weight gradients through ONE ops.wgrad_batch (pcm_lora_wgrad_multi_bf16): both output orientations, ragged M,
+    column slices of wider rows, different sizes in one launch, more jobs than one launch holds (8), and a 3x3-view job that the
+    multi-launch kernel does not take (it must run on its own inside the same call)."""
+    jobs, refs = [], []
+    with ops.wgrad_batch():
+        for i, (M, G) in enumerate([(300, 192), (64, 64), (1000, 72), (130, 320), (77, 136), (512, 640), (200, 200), (333, 64), (90, 128)]):
+            big = rnd(M, G + 16, seed=10 + i, dev=dev)[:, 8:8 + G]            # a column slice: ldb != G
+            small = rnd(M, 64, seed=30 + i, dev=dev)
+            swap = i % 2 == 0
+            out = torch.zeros((64, G) if swap else (G, 64), dtype=torch.float32, device=dev)
+            ops.lora_wgrad(big, small, out, 0.5, M, G=G, g_stride=1 if swap else 64, r_stride=G if swap else 1, ldb=G + 16)
+            ref = 0.5 * small.float().cpu().T @ big.float().cpu()
+            jobs.append(out); refs.append((ref if swap else ref.T, M))
+        B, Hs, C = 2, 8, 64
+        x = rnd(B, Hs, Hs, C, seed=50, dev=dev); u = rnd(B * Hs * Hs, 64, seed=51, dev=dev)
+        A = torch.zeros(64, C, 3, 3, requires_grad=True)
+        F.conv2d(x.float().cpu().permute(0, 3, 1, 2), A, None, padding=1).backward(u.float().cpu().view(B, Hs, Hs, 64).permute(0, 3, 1, 2))
+        dA = torch.zeros(64, 3, 3, C, dtype=torch.float32, device=dev)
+        ops.lora_wgrad(x, u, dA, 1.0, B * Hs * Hs, conv=dict(Hs=Hs, Ws=Hs, Ho=Hs, Wo=Hs), g_stride=1, r_stride=9 * C)
+        assert float(dA.abs().max()) == 0.0 and all(float(o.abs().max()) == 0.0 for o in jobs)   # nothing runs before the batch closes
+    for k, (o, (ref, M)) in enumerate(zip(jobs, refs)):
+        close(o, ref, 2e-3, 2e-3 * M ** 0.5, "multi job %d" % k)
+    close(dA, A.grad.permute(0, 2, 3, 1), 2e-3, 2e-3 * (B * Hs * Hs) ** 0.5, "conv job inside the batch")
+
+
 def case_wgrad_conv(dev, B, Hs, Ws, C, stride, src_mode=0):
     x = rnd(B, Hs, Ws, C, seed=1, dev=dev)
     xn = x.float().cpu().permute(0, 3, 1, 2)

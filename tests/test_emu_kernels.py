@@ -88,6 +88,16 @@ def test_wgrad_conv_transpose_read_kernel(B, H, W, C):
     assert cnt(1) == n0 + 1      # the khwc-layout call took the transpose-read kernel (the peft-layout call stays on wgrad.hip)
 
 
+def test_wgrad_multi_job_launch():
+    import ctypes
+    from pcm_amd import capi
+    cnt = capi.lib().dll.pcm_debug_wgrad_tr_multi_count
+    cnt.restype = ctypes.c_long
+    n0 = cnt()
+    K.case_wgrad_multi("cpu")
+    assert cnt() == n0 + 1       # 9 plain jobs = ONE multi-job launch of 8 + a single-job launch; the 10th (3x3 view) runs on its own kernel
+
+
 def test_wgrad_transpose_read_matches_register_transposing_kernel():
     """A/B of the two implementations of the same contract on one ragged plain shape (both must agree with the reference)."""
     from pcm_amd import capi

@@ -69,6 +69,10 @@ def test_wgrad_plain(M, N, K_):
     K.case_wgrad_plain("cuda", M, N, K_)
 
 
+def test_wgrad_multi_job_launch():
+    K.case_wgrad_multi("cuda")
+
+
 @pytest.mark.parametrize("stride,src_mode,C", [(1, 0, 320), (2, 0, 64), (1, 1, 128)])
 def test_wgrad_conv(stride, src_mode, C):
     K.case_wgrad_conv("cuda", 2, 16, 16, C, stride, src_mode)
