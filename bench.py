@@ -187,12 +187,12 @@ def main():
             x2 = torch.cat([b["latents"], b["noise"]]); t2 = torch.cat([D.tables.ddim_timesteps[b["index"]]] * 2)
             c2 = torch.cat([b["prompt_embeds"], b["prompt_embeds"]])
         reps = 3
-        D.student.forward(x2, t2, c2, save=True)
+        D.student.forward(x2, t2, c2, save=True, save_half=True)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(reps):
-            D.student.forward(x2, t2, c2, save=True)
+            D.student.forward(x2, t2, c2, save=True, save_half=True)
         e1.record()
         torch.cuda.synchronize()
         f_ms = e0.elapsed_time(e1) / reps

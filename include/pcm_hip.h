@@ -42,7 +42,7 @@ extern "C" {
 #define PCM_ACT_LEAKY 2 /* LeakyReLU(0.01): DiscriminatorHead, discriminator_sd15.py:354 */
 /* GEGLU fused into the projection (diffusers GEGLU.forward: hidden, gate = proj(x).chunk(2); hidden * gelu(gate)).
  * The weight rows (and bias) must be packed INTERLEAVED in groups of 8: [v0..v7, g0..g7, v8..v15, g8..g15, ...] (N = 2*inner
- * rows); the output has N/2 columns (ldo >= N/2).  No residual / row vector; bf16 output only. */
+ * rows); the output has N/2 columns (ldo >= N/2).  No residual / row vector; bf16 output only.  Optional second output: pre_out. */
 #define PCM_ACT_GEGLU 3
 
 const char* pcm_last_error(void);
@@ -87,6 +87,11 @@ typedef struct {
   float alpha;            /* scales the accumulated sum before bias (1.0 normally) */
   void* workspace;        /* optional fp32 scratch for split-K (under-filled grids with long K); NULL = never split */
   size_t workspace_bytes; /* >= pcm_gemm_workspace_bytes(...) */
+  /* PCM_ACT_GEGLU only (abi >= 2): besides the activated output the call can keep the PRE-activation (sum + bias, bf16, interleaved
+   * column order of the packed weight, N columns) of rows m < pre_rows in pre_out[m][ldp] -- what autograd saves for GEGLU.backward
+   * (the grad-requiring half of a batch); pcm_geglu_bwd_interleaved reads it.  NULL / 0: nothing kept. */
+  void* pre_out;
+  int pre_rows, ldp;
 } pcm_gemm_epi;
 
 /* bytes of `workspace` the call would use (0: no split-K for this shape) */
@@ -154,6 +159,9 @@ int pcm_layernorm_bwd(const void* x, const void* dy, const float* gamma, const f
 /* ---- GEGLU (diffusers GEGLU: h, g = proj(x).chunk(2,-1); h * gelu_erf(g)) ---------------- */
 int pcm_geglu_fwd(const void* hg, void* out, int M, int C4, void* stream);           /* hg [M][2*C4] */
 int pcm_geglu_bwd(const void* hg, const void* dout, void* dhg, int M, int C4, void* stream);
+/* the same gradient from the INTERLEAVED pre-activation kept by a fused PCM_ACT_GEGLU projection (pcm_gemm_epi.pre_out, row stride ldp);
+ * dhg comes out in the standard [values | gates] column order */
+int pcm_geglu_bwd_interleaved(const void* pre, int ldp, const void* dout, void* dhg, int M, int C4, void* stream);
 
 /* ---- scaled-dot-product attention (Attention.processor: torch SDPA / xformers
  * memory_efficient_attention, train_pcm_lora_sd15.py:947-957) ------------------------------

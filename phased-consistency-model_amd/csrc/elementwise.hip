@@ -201,14 +201,20 @@ __global__ __launch_bounds__(256) void geglu_fwd_kernel(const uint4* hg, uint4* 
     }
   }
 }
-__global__ __launch_bounds__(256) void geglu_bwd_kernel(const uint4* hg, const uint4* dout, uint4* dhg, int M, int CV4) {
+// IL: the saved pre-activation is in the INTERLEAVED column order of the fused projection (8 values, their 8 gates, ...: pcm_hip.h
+// PCM_ACT_GEGLU with pre_out); the gradient is written in the standard [values | gates] order the dgrad / wgrad GEMMs expect
+template <bool IL>
+__global__ __launch_bounds__(256) void geglu_bwd_kernel(const uint4* hg, const uint4* dout, uint4* dhg, int M, int CV4, int ldp4) {
   EwWalk w(M, CV4);
   while (w.v < w.nvec) {
     uint4 hr[EW_U], gr[EW_U], dr[EW_U]; unsigned rr[EW_U], cc[EW_U]; bool ok[EW_U];
 #pragma unroll
     for (int u = 0; u < EW_U; u++) {
       rr[u] = w.r; cc[u] = w.c; ok[u] = w.v < w.nvec;
-      if (ok[u]) { const uint4* p = hg + (size_t)w.r * 2 * CV4 + w.c; hr[u] = p[0]; gr[u] = p[CV4]; dr[u] = dout[w.v]; }
+      if (ok[u]) {
+        const uint4* p = IL ? hg + (size_t)w.r * ldp4 + 2 * w.c : hg + (size_t)w.r * 2 * CV4 + w.c;
+        hr[u] = p[0]; gr[u] = p[IL ? 1 : CV4]; dr[u] = dout[w.v];
+      }
       w.step();
     }
 #pragma unroll
@@ -231,8 +237,14 @@ extern "C" int pcm_geglu_fwd(const void* hg, void* out, int M, int C4, void* str
 }
 extern "C" int pcm_geglu_bwd(const void* hg, const void* dout, void* dhg, int M, int C4, void* stream) {
   PCM_CHECK(hg && dout && dhg && (C4 % 8) == 0 && ew_fits32(M, C4 / 8), PCM_EINVAL, "pcm_geglu_bwd: C4%%8, M*C4/8 < 2^31");
-  PCM_LAUNCH(geglu_bwd_kernel, dim3(ew_blocks_u((long)M * (C4 / 8))), dim3(256), 0, stream, (const uint4*)hg, (const uint4*)dout, (uint4*)dhg, M, C4 / 8);
+  PCM_LAUNCH(geglu_bwd_kernel<false>, dim3(ew_blocks_u((long)M * (C4 / 8))), dim3(256), 0, stream, (const uint4*)hg, (const uint4*)dout, (uint4*)dhg, M, C4 / 8, 0);
   return pcm_post_launch("pcm_geglu_bwd");
+}
+extern "C" int pcm_geglu_bwd_interleaved(const void* pre, int ldp, const void* dout, void* dhg, int M, int C4, void* stream) {
+  PCM_CHECK(pre && dout && dhg && (C4 % 8) == 0 && (ldp % 8) == 0 && ldp >= 2 * C4 && ew_fits32(M, C4 / 8) && PCM_ALIGNED16(pre), PCM_EINVAL,
+            "pcm_geglu_bwd_interleaved: C4%%8, ldp%%8, ldp >= 2*C4, M*C4/8 < 2^31");
+  PCM_LAUNCH(geglu_bwd_kernel<true>, dim3(ew_blocks_u((long)M * (C4 / 8))), dim3(256), 0, stream, (const uint4*)pre, (const uint4*)dout, (uint4*)dhg, M, C4 / 8, ldp / 8);
+  return pcm_post_launch("pcm_geglu_bwd_interleaved");
 }
 
 // ---- pixel sum: out[b][c] = sum_hw x[b][hw][c]  (fp32, zeroed here) ----

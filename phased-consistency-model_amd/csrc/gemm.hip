@@ -493,12 +493,16 @@ extern "C" int pcm_gemm_bf16(const pcm_gemm_seg* segs, int nseg, const pcm_gemm_
   if (geglu)
     PCM_CHECK((e->N % 16) == 0 && (e->ldo % 8) == 0 && e->out_dtype != PCM_F32 && !e->residual && !e->rowvec && gemm_big_ok(segs, nseg, e), PCM_EUNSUPPORTED,
               "pcm_gemm_bf16: PCM_ACT_GEGLU needs N%%16==0, K%%64==0 per segment, bf16 output, no residual / row vector");
+  if (e->pre_out)
+    PCM_CHECK(geglu && PCM_ALIGNED16(e->pre_out) && (e->ldp % 8) == 0 && e->ldp >= e->N && e->pre_rows >= 0, PCM_EINVAL,
+              "pcm_gemm_bf16: pre_out needs PCM_ACT_GEGLU, 16-byte alignment, ldp%%8==0, ldp >= N");
   if (e->residual) PCM_CHECK((((uintptr_t)e->residual) & 7) == 0 && (e->ldr % 4) == 0, PCM_EALIGN, "pcm_gemm_bf16: residual alignment");
   if (e->rowvec) PCM_CHECK(e->rows_per_batch > 0, PCM_EINVAL, "pcm_gemm_bf16: rows_per_batch");
   g.nseg = nseg; g.M = e->M; g.N = e->N; g.Ho = e->Ho > 0 ? e->Ho : 1; g.Wo = e->Wo > 0 ? e->Wo : 1;
   g.bias = e->bias; g.rowvec = (const bf16_t*)e->rowvec; g.rpb = e->rows_per_batch > 0 ? e->rows_per_batch : 1;
   g.res = (const bf16_t*)e->residual; g.ldr = e->ldr; g.out = e->out; g.ldo = e->ldo;
   g.out_f32 = e->out_dtype == PCM_F32; g.act = e->act; g.alpha = e->alpha; g.dbg = g_ablate;
+  g.pre_out = (bf16_t*)e->pre_out; g.pre_rows = e->pre_out ? e->pre_rows : 0; g.ldp = e->ldp;
   if (g_conv_co < 0) { const char* ev = getenv("PCM_GEMM_CONV_CO"); g_conv_co = ev ? atoi(ev) : 0; }
   if (g_conv_md < 0) { const char* ev = getenv("PCM_GEMM_CONV_MD"); g_conv_md = ev ? atoi(ev) : 0; }
   g.conv_co = g_conv_co; g.conv_md = g_conv_md || g_conv_co;

@@ -420,6 +420,11 @@ __global__ __launch_bounds__(512) void pcm_gemm8p_kernel(GemmDev g) {
 #pragma unroll
           for (int e = 0; e < 16; e++) vv[e] += g.bias[n + e];
         }
+        if (g.pre_out && m < g.pre_rows) {   // what the backward of GEGLU needs: the pre-activation, in this (interleaved) column order
+          uint4* pp = (uint4*)(g.pre_out + (size_t)m * g.ldp + n);
+          pp[0] = make_uint4(pack_bf2(vv[0], vv[1]), pack_bf2(vv[2], vv[3]), pack_bf2(vv[4], vv[5]), pack_bf2(vv[6], vv[7]));
+          pp[1] = make_uint4(pack_bf2(vv[8], vv[9]), pack_bf2(vv[10], vv[11]), pack_bf2(vv[12], vv[13]), pack_bf2(vv[14], vv[15]));
+        }
         float o[8];
 #pragma unroll
         for (int e = 0; e < 8; e++) o[e] = vv[e] * gelu_erf_f(vv[8 + e]);

@@ -22,6 +22,8 @@ struct GemmDev {
   int splitk, kt_per_split;   // split-K: blockIdx.y = K slice; raw fp32 partial tiles go to slab ws[slice][M][N]
   float* ws;
   int conv_md, conv_co;       // gemm8p.hip address-path / K-order variants of the stride-1 direct 3x3 view (A/B hooks; defaults 1, 0)
+  bf16_t* pre_out;            // PCM_ACT_GEGLU: optional second output, the interleaved pre-activation of rows < pre_rows (row stride ldp)
+  int pre_rows, ldp;
   int dbg;                    // ablation mask: only read by -DPCM_ABLATE builds (tools/probes/build_ablate.py), 0 otherwise
 };
 // timing ablations for tools/gemm8p_ablate.py (results are wrong by construction): 1 = no global stores in the epilogue, 2 = no epilogue,

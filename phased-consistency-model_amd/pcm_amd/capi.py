@@ -30,7 +30,8 @@ class GemmEpi(C.Structure):
     _fields_ = [("M", C.c_int), ("N", C.c_int), ("Ho", C.c_int), ("Wo", C.c_int), ("bias", vp),
                 ("rowvec", vp), ("rows_per_batch", C.c_int), ("residual", vp), ("ldr", C.c_int),
                 ("out", vp), ("ldo", C.c_int), ("out_dtype", C.c_int), ("act", C.c_int),
-                ("alpha", C.c_float), ("workspace", vp), ("workspace_bytes", C.c_size_t)]
+                ("alpha", C.c_float), ("workspace", vp), ("workspace_bytes", C.c_size_t),
+                ("pre_out", vp), ("pre_rows", C.c_int), ("ldp", C.c_int)]
 
 
 class WgradArgs(C.Structure):
@@ -69,6 +70,7 @@ _PROTOS = {
     "pcm_layernorm_bwd": [vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
     "pcm_geglu_fwd": [vp, vp, i32, i32, vp],
     "pcm_geglu_bwd": [vp, vp, vp, i32, i32, vp],
+    "pcm_geglu_bwd_interleaved": [vp, i32, vp, vp, i32, i32, vp],
     "pcm_attn_fwd": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp],
     "pcm_attn_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp],
     "pcm_attn_fwd_ws": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp, C.c_size_t, vp],

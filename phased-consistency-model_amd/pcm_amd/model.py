@@ -103,9 +103,20 @@ class UNetWeights:
 # LoRA state
 # ----------------------------------------------------------------------------------------------
 class LoraModule:
-    __slots__ = ("path", "kind", "N", "K", "C", "r", "A", "B", "gA", "gB", "A_fwd", "A_bwd", "Bs_fwd", "Bs_bwd")
+    __slots__ = ("path", "kind", "N", "K", "C", "r", "A", "B", "gA", "gB", "A_fwd", "A_bwd", "Bs_fwd", "Bs_bwd", "Bs_geglu")
 
 
+class HalfSaved:
+    """A tensor saved for the backward that already holds ONLY the first (grad-requiring) half of the batch rows
+    (``UNet.forward(save=True, save_half=True)``): ``tape_first_half`` takes it as is instead of slicing it."""
+    __slots__ = ("t",)
+
+    def __init__(self, t):
+        self.t = t
+
+
+# debug hook: PCM_FUSE_GEGLU=0 keeps the feed-forward's GEGLU as a separate pass in the grad-requiring forward (A/B measurement)
+FUSE_GEGLU_GRAD = os.environ.get("PCM_FUSE_GEGLU", "1") != "0"
 # debug hook: PCM_LORA_QKV=0 runs the self-attention q/k/v LoRA projections as three separate layers (A/B measurement)
 FUSE_LORA_QKV = os.environ.get("PCM_LORA_QKV", "1") != "0"
 
@@ -194,7 +205,7 @@ class LoraState:
             off = ototal
             ototal += (n + 7) // 8 * 8      # keep every operand 16-byte aligned
             return off
-        layout2 = []
+        layout2, geglu_ops = [], []
         for path, shp, oa, ob in layout:
             m = self.modules[path]
             o_af, o_ab, o_bf, o_bb = alloc(r * m.K), alloc(m.K * r), alloc(m.N * r), alloc(r * m.N)
@@ -207,6 +218,13 @@ class LoraState:
             else:
                 descs.append((oa, o_af, o_ab, r, m.K, m.K, m.K, r, 1.0))               # A [r][K] -> copy + A^T [K][r]
             descs.append((ob, o_bf, o_bb, m.N, r, r, r, m.N, self.scaling))             # s*B [N][r] -> copy + transpose [r][N]
+            if path.endswith("ff.net.0.proj") and m.kind == "lin" and m.N % 16 == 0:
+                # fused-GEGLU forward operand: rows of s*B interleaved [8 values, 8 gates, ...] like Layer.w_geglu -- two strided copies
+                # of (8 rows x r) blocks: values block j -> rows 16j.., gates block j -> rows 16j+8..
+                o_bg, inner = alloc(m.N * r), m.N // 2
+                geglu_ops.append((m, o_bg))
+                descs.append((ob, o_bg, -1, inner // 8, 8 * r, 8 * r, 16 * r, 0, self.scaling))
+                descs.append((ob + inner * r, o_bg + 8 * r, -1, inner // 8, 8 * r, 8 * r, 16 * r, 0, self.scaling))
         # self-attention q/k/v triples additionally get CONCATENATED operands, so the three rank-64 down-projections
         # are one [M,C]x[C,192] GEMM and the three up-projections ride the fused QKV GEMM as one block-diagonal K=192
         # segment (the off-diagonal blocks stay at the zeros this buffer is created with):
@@ -244,6 +262,8 @@ class LoraState:
             else:
                 m.A_fwd, m.A_bwd = self.operands[o_af:o_af + r * m.K].view(r, m.K), self.operands[o_ab:o_ab + m.K * r].view(m.K, r)
             m.Bs_fwd, m.Bs_bwd = self.operands[o_bf:o_bf + m.N * r].view(m.N, r), self.operands[o_bb:o_bb + r * m.N].view(r, m.N)
+        for m, o_bg in geglu_ops:
+            m.Bs_geglu = self.operands[o_bg:o_bg + m.N * r].view(m.N, r)
         arr = (capi.PackDesc * len(descs))()
         starts = np.zeros(len(descs) + 1, dtype=np.int32)
         for i, d in enumerate(descs):
@@ -424,6 +444,7 @@ class UNet:
         self.W, self.lora, self.cfg = weights, lora, weights.cfg
         self._arena = None      # per-pass arena of pre-zeroed GroupNorm statistics (ops.StatArena)
         self._side = None       # WgradSide of this runner's backward passes
+        self._save_half = False
 
     # ---- norm helpers ----
     def _gn(self, path, x, act, eps, save):
@@ -579,18 +600,34 @@ class UNet:
             g3, b3 = W.norms[b + "norm3"]
             n3, mu3, rs3 = ops.layernorm_fwd(h2, g3, b3)
             Lff = W.layers[b + "ff.net.0.proj"]
-            if lora is None and not rec and Lff.w_geglu is not None and M >= 128:
-                # frozen no-grad pass: GEGLU applied in the projection's epilogue (the 2*inner-wide pre-activation never reaches HBM)
+            lmff = lora.modules.get(b + "ff.net.0.proj") if lora is not None else None
+            pre = None
+            if Lff.w_geglu is not None and M >= 128 and (lmff is None or getattr(lmff, "Bs_geglu", None) is not None) and \
+                    (FUSE_GEGLU_GRAD or (lora is None and not rec)):
+                # GEGLU applied in the projection's epilogue: the 2*inner-wide pre-activation does not make the round trip through HBM
+                # for a separate activation pass.  Frozen no-grad pass: it never reaches HBM at all.  Recording pass: the epilogue
+                # also stores it (bf16, interleaved column order) for the rows whose backward will run -- with save_half only the
+                # online half of the fused online + target batch -- and geglu_bwd_interleaved reads it.
                 hg = None
+                segs, t_ff = [Seg(n3, Lff.w_geglu)], None
+                if lmff is not None:
+                    t_ff = torch.empty(M, lmff.r, dtype=BF16, device=n3.device)
+                    ops.gemm([Seg(n3, lmff.A_fwd)], M, lmff.r, t_ff)
+                    segs.append(Seg(t_ff, lmff.Bs_geglu))
+                if rec:
+                    pre = torch.empty(M // 2 if self._save_half else M, Lff.N, dtype=BF16, device=n3.device)
+                    sf0["x"], sf0["t"], sf0["M"], sf0["geo"] = n3, t_ff, M, None
                 gg = torch.empty(M, Lff.N // 2, dtype=BF16, device=n3.device)
-                ops.gemm([Seg(n3, Lff.w_geglu)], M, Lff.N, gg, bias=Lff.bias_geglu, act=capi.ACT_GEGLU, ldo=Lff.N // 2)
+                ops.gemm(segs, M, Lff.N, gg, bias=Lff.bias_geglu, act=capi.ACT_GEGLU, ldo=Lff.N // 2, pre_out=pre)
+                if pre is not None and self._save_half:
+                    pre = HalfSaved(pre)
             else:
                 hg = layer_fwd(W, lora, b + "ff.net.0.proj", n3, M, save=sf0)
                 gg = ops.geglu_fwd(hg)
             h3 = layer_fwd(W, lora, b + "ff.net.2", gg, M, save=sf2, residual=h2)
             if rec:
                 blocks.append(dict(sa1=sa1, sa2=sa2, sf0=sf0, sf2=sf2, h=h, mu1=mu1, rs1=rs1, h1=h1, mu2=mu2, rs2=rs2, h2=h2, mu3=mu3,
-                                   rs3=rs3, hg=hg))
+                                   rs3=rs3, hg=hg, pre=pre))
             h = h3
         out = layer_fwd(W, lora, p + "proj_out", h, M, save=spo, residual=x.view(M, C))
         if rec:
@@ -609,7 +646,7 @@ class UNet:
             b, bs = p + f"transformer_blocks.{k}.", sv[f"blk{k}"]
             # ff: h3 = h2 + ff2(geglu(ff0(LN3(h2))))
             d_gg = layer_bwd(W, lora, b + "ff.net.2", d_h, bs["sf2"])
-            d_hg = ops.geglu_bwd(bs["hg"], d_gg)
+            d_hg = ops.geglu_bwd_interleaved(bs["pre"], d_gg) if bs.get("pre") is not None else ops.geglu_bwd(bs["hg"], d_gg)
             d_n3 = layer_bwd(W, lora, b + "ff.net.0.proj", d_hg, bs["sf0"])
             d_h2 = ops.layernorm_bwd(bs["h2"], d_n3, W.norms[b + "norm3"][0], bs["mu3"], bs["rs3"], dres=d_h)
             # attn2: h2 = h1 + attn2(LN2(h1), text)
@@ -623,10 +660,13 @@ class UNet:
         return ops.add(d_x.view(M, C), d_out).view(B, H * Wd, C)
 
     # ---- whole network ----
-    def forward(self, sample, timesteps, encoder_hidden_states, save=False, features=False, added_cond=None):
+    def forward(self, sample, timesteps, encoder_hidden_states, save=False, features=False, added_cond=None, save_half=False):
         """``features=True`` is the reference's ``modified_forward`` (discriminator_sd15.py:16-345): returns the 9
-        hidden states after every down block, the mid block and every up block (no conv_norm_out / conv_out)."""
+        hidden states after every down block, the mid block and every up block (no conv_norm_out / conv_out).
+        ``save_half``: the caller will back-propagate through ``tape_first_half`` only (fused online + target batch), so tensors
+        that exist only for the backward may be kept for the first half of the batch alone."""
         cfg, W, lora = self.cfg, self.W, self.lora
+        self._save_half = bool(save and save_half)
         B, _, H, Wd = sample.shape
         boc, n = cfg.block_out_channels, len(cfg.block_out_channels)
         tape = [] if save else None
@@ -726,6 +766,8 @@ class UNet:
         the recorded ``B`` / ``M`` halved.  Used to run the online (grad) and the target (no-grad) forward of the
         distillation step as ONE 2B-sample launch schedule and back-propagate through the online half only."""
         def half(v, key=None):
+            if isinstance(v, HalfSaved):
+                return v.t
             if isinstance(v, torch.Tensor):
                 assert v.shape[0] % 2 == 0, (key, tuple(v.shape))
                 return v[: v.shape[0] // 2]

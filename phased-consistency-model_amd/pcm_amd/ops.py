@@ -48,7 +48,7 @@ class Seg:
 
 
 def gemm(segs, M, N, out, bias=None, rowvec=None, rows_per_batch=0, residual=None, act=capi.ACT_NONE,
-         alpha=1.0, Ho=0, Wo=0, ldo=None, ldr=None):
+         alpha=1.0, Ho=0, Wo=0, ldo=None, ldr=None, pre_out=None):
     arr = (GemmSeg * len(segs))()
     for i, s in enumerate(segs):
         s.fill(arr[i])
@@ -62,6 +62,8 @@ def gemm(segs, M, N, out, bias=None, rowvec=None, rows_per_batch=0, residual=Non
     e.out_dtype = capi.PCM_F32 if out.dtype == torch.float32 else capi.PCM_BF16
     e.act, e.alpha = act, alpha
     e.workspace, e.workspace_bytes = None, 0
+    # fused GEGLU: optional second output = the interleaved pre-activation of the first pre_out.shape[0] rows (kept for the backward)
+    e.pre_out, e.pre_rows, e.ldp = (ptr(pre_out), pre_out.shape[0], pre_out.shape[-1]) if pre_out is not None else (None, 0, 0)
     wsb = capi.lib().dll.pcm_gemm_workspace_bytes(arr, len(segs), C.byref(e))
     if wsb:   # split-K slabs (caller-owned scratch)
         ws = torch.empty(wsb // 4, dtype=torch.float32, device=out.device)
@@ -177,6 +179,15 @@ def geglu_bwd(hg, dout):
     M, C8 = hg.numel() // hg.shape[-1], hg.shape[-1]
     dhg = torch.empty_like(hg)
     capi.lib().call("pcm_geglu_bwd", ptr(hg), ptr(dout), ptr(dhg), M, C8 // 2, _stream())
+    return dhg
+
+
+def geglu_bwd_interleaved(pre, dout):
+    """GEGLU gradient from the interleaved pre-activation a fused projection kept (gemm(..., act=ACT_GEGLU, pre_out=pre));
+    the result is in the standard [values | gates] column order."""
+    M, C2 = pre.shape[0], pre.shape[-1]
+    dhg = torch.empty(M, C2, dtype=BF16, device=pre.device)
+    capi.lib().call("pcm_geglu_bwd_interleaved", ptr(pre), C2, ptr(dout), ptr(dhg), M, C2 // 2, _stream())
     return dhg
 
 

@@ -112,7 +112,8 @@ class Distiller:
             # LoRA, no grad, :1261-1268) as ONE 2B-sample schedule: samples are independent, so each half is exactly the
             # separate forward; the backward runs on the online half of the tape only
             eps_st, tape2 = self.student.forward(torch.cat([noisy, x_prev32]), torch.cat([start_t, t_n]),
-                                                 torch.cat([prompt_embeds, prompt_embeds]), save=True, added_cond=cat2(added_cond, None))
+                                                 torch.cat([prompt_embeds, prompt_embeds]), save=True, save_half=True,
+                                                 added_cond=cat2(added_cond, None))
             eps_s, eps_t = eps_st[:B], eps_st[B:]
             tape = self.student.tape_first_half(tape2)
         else:

@@ -577,7 +577,28 @@ def case_gemm_geglu(dev, M=300, K=128, inner=160):
     h = x.float() @ w.float().T + bias
     ref = h[:, :inner] * F.gelu(h[:, inner:])
     err = (out.float() - ref).abs()
-    return float((err - (2e-2 + 1e-2 * ref.abs())).max())
+    excess = float((err - (2e-2 + 1e-2 * ref.abs())).max())
+    # second output: the interleaved pre-activation of the first `rows` rows (what the backward of GEGLU needs) -- plus a LoRA segment
+    # with interleaved s*B rows; rows beyond `rows` must stay untouched; geglu_bwd_interleaved == geglu_bwd on the de-interleaved tensor
+    rows = (M // 2 + 7) // 8 * 8
+    t = torch.randn(M, 64, generator=g).bfloat16().to(dev)
+    bl = (torch.randn(2 * inner, 64, generator=g) * 0.05).bfloat16().to(dev)
+    pre = torch.full((rows + 8, 2 * inner), 7.0, dtype=torch.bfloat16, device=dev)
+    out2 = torch.empty(M, inner, dtype=torch.bfloat16, device=dev)
+    ops.gemm([ops.Seg(x, w[perm].contiguous()), ops.Seg(t, bl[perm].contiguous())], M, 2 * inner, out2, bias=bias[perm].contiguous(),
+             act=capi.ACT_GEGLU, ldo=inner, pre_out=pre[:rows])
+    h2 = h + t.float() @ bl.float().T
+    ref2 = h2[:, :inner] * F.gelu(h2[:, inner:])
+    excess = max(excess, float(((out2.float() - ref2).abs() - (2e-2 + 1e-2 * ref2.abs())).max()))
+    assert bool((pre[rows:] == 7.0).all()), "rows >= pre_rows were written"
+    pre_std = torch.empty(rows, 2 * inner, dtype=torch.bfloat16, device=dev)
+    pre_std[:, perm] = pre[:rows]
+    excess = max(excess, float(((pre_std.float() - h2[:rows]).abs() - (2e-2 + 1e-2 * h2[:rows].abs())).max()))
+    dout = torch.randn(rows, inner, generator=g).bfloat16().to(dev)
+    d_il = ops.geglu_bwd_interleaved(pre[:rows], dout)
+    d_std = ops.geglu_bwd(pre_std, dout)
+    assert torch.equal(d_il, d_std), "geglu_bwd_interleaved differs from geglu_bwd on the same values"
+    return excess
 
 
 def case_pcm_fm_math(dev, g):

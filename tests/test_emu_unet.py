@@ -58,6 +58,9 @@ def test_unet_forward_backward_vs_oracle():
     out_s, tape = student.forward(x, t, ctx, save=True)
     # the self-attention q/k/v LoRA projections ran as the fused (concatenated / block-diagonal operand) schedule
     assert lora.qkv and all(sv["blk0"]["sa1"].get("fused") for kind, _, sv in tape if kind == "transformer")
+    # ... and the feed-forward of the widest level (M = 128 rows here) took the fused-GEGLU projection that keeps the pre-activation
+    from pcm_amd import model as Mdl
+    assert not Mdl.FUSE_GEGLU_GRAD or any(sv["blk0"]["pre"] is not None and sv["blk0"]["hg"] is None for kind, _, sv in tape if kind == "transformer")
     scale = ref_t.abs().max().item()
     err_t = (out_t - ref_t).abs().max().item()
     err_s = (out_s - ref_s.detach()).abs().max().item()
@@ -79,6 +82,53 @@ def test_unet_forward_backward_vs_oracle():
             assert rel < 0.15, (p, rel)
     print("grad rel err: global %.3e worst module %.3e" % ((num / den) ** 0.5, worst))
     assert (num / den) ** 0.5 < 0.05
+
+
+def test_fused_online_target_pass_keeps_half_of_the_geglu_pre_activation():
+    """forward(save=True, save_half=True) on [online; target] + tape_first_half == forward(save=True) on the online half alone:
+    same eps for both halves, same LoRA gradients (the fused-GEGLU projection stores its pre-activation for the first half only)."""
+    from oracle import unet_sd15 as O
+    from pcm_amd import model as Mdl
+    from pcm_amd.model import LoraState, UNet, UNetWeights
+    oc, pc = tiny_cfgs()
+    sd = O.init_state_dict(oc, 0)
+    B, Hh = 2, 8
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2 * B, 4, Hh, Hh, generator=g)
+    t = torch.tensor([19, 759, 300, 40])
+    ctx = torch.randn(2 * B, 7, 64, generator=g)
+    d_eps = torch.randn(B, 4, Hh, Hh, generator=g)
+    W = UNetWeights(pc, sd, "cpu")
+    lora = LoraState(pc, 64, 8.0, "cpu", seed=1, b_std=0.05)
+    student = UNet(W, lora)
+    out2, tape2 = student.forward(x, t, ctx, save=True, save_half=True)
+    pres = [sv["blk0"]["pre"] for kind, _, sv in tape2 if kind == "transformer" and sv["blk0"]["pre"] is not None]
+    assert pres and all(isinstance(p_, Mdl.HalfSaved) and p_.t.shape[0] * 2 == 2 * B * Hh * Hh for p_ in pres)
+    lora.zero_grad()
+    student.backward(d_eps, student.tape_first_half(tape2))
+    g_half = lora.grads.clone()
+    # (a) the online half run on its own: identical eps; gradients agree to the bf16 noise of the different GEMM plans (M halves)
+    out1, tape1 = student.forward(x[:B], t[:B], ctx[:B], save=True)
+    assert torch.equal(out1, out2[:B])
+    lora.zero_grad()
+    student.backward(d_eps, tape1)
+    rel = float((g_half - lora.grads).norm() / lora.grads.norm())
+    assert rel < 2e-2, rel
+    # (b) the same fused batch with GEGLU as a separate pass (the pre-activation saved for all rows): same plans elsewhere
+    Mdl.FUSE_GEGLU_GRAD = False
+    try:
+        out3, tape3 = student.forward(x, t, ctx, save=True, save_half=True)
+        assert all(sv["blk0"]["pre"] is None and sv["blk0"]["hg"] is not None for kind, _, sv in tape3 if kind == "transformer")
+        lora.zero_grad()
+        student.backward(d_eps, student.tape_first_half(tape3))
+    finally:
+        Mdl.FUSE_GEGLU_GRAD = True
+    scale = float(out3.abs().max())
+    assert float((out3 - out2).abs().max()) < 0.02 * scale
+    # two bf16 evaluations of the same gradient (each ~2.2 % from the fp32 oracle on this narrow config, see the test above)
+    rel = float((g_half - lora.grads).norm() / lora.grads.norm())
+    cos = float((g_half * lora.grads).sum() / (g_half.norm() * lora.grads.norm()))
+    assert rel < 4e-2 and cos > 0.999, (rel, cos)
 
 
 def test_sdxl_topology_forward_backward_vs_oracle():

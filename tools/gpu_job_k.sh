@@ -1,4 +1,4 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT; O=gpurun_out/k; mkdir -p $O
-timeout 120 tools/probes/mfmavalu > $O/mfmavalu.txt 2>&1; echo "mfmavalu rc=$?" >> $O/rc.log
-cat $O/mfmavalu.txt
+timeout 120 tools/probes/dmabench > $O/dmabench.txt 2>&1; echo "dmabench rc=$?" >> $O/rc.log
+cat $O/dmabench.txt
