@@ -138,11 +138,11 @@ struct RowStage {
   // vmcnt(0) right after issue; out-of-range rows are zeroed at store time).
   __device__ __forceinline__ void load(const RowGeom<D, ROWS>& gm, const bf16_t* src, int ld, int row0, int nrows_valid, int tid) {
     row0_ = row0;
+    // raw buffer loads: resource (scalar) on the operand's base, the tile's first row in the scalar offset, the per-thread piece in a
+    // 32-bit VGPR offset -- no 64-bit per-thread pointers to keep or to advance (operand spans stay far below 2 GB per (batch, head))
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, 0x80000000u, 0x00020000);
     if (row0 + ROWS <= nrows_valid) {
       asm volatile("" ::: "memory");
-      // raw buffer load: resource (scalar) on the operand's base, the tile's first row in the scalar offset, the per-thread piece in
-      // a 32-bit VGPR offset -- no 64-bit per-thread pointers to keep or to advance (operand spans stay far below 2 GB per (batch, head))
-      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, 0x80000000u, 0x00020000);
       const int soff = row0 * ld * 2;
 #pragma unroll
       for (int i = 0; i < N; i++) r[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, gm.goff[i], soff, 0));
@@ -155,7 +155,7 @@ struct RowStage {
       int rr = u / C::DG, c = u - rr * C::DG;
       int row = row0 + rr;
       if (row >= nrows_valid) row = nrows_valid - 1;
-      r[i] = *(const uint4*)(src + (size_t)row * ld + 8 * c);
+      r[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)(row * ld + 8 * c) * 2u, 0, 0));
     }
   }
   __device__ __forceinline__ void store(const RowGeom<D, ROWS>& gm, char* dst, int nrows_valid, int tid) const {
@@ -199,10 +199,10 @@ __device__ __forceinline__ bf16x8 pack_frag(const f32x16& p, int half) {
 }
 
 // ============================================================================ forward
-// second launch-bound = minimum waves per SIMD (HIP): head dims up to 64 fit three workgroups per CU (<= 168 VGPRs), which hides the
-// barrier / LDS latencies of a tile measurably better than two (tools/attn_occupancy.py)
+// second launch-bound = minimum waves per SIMD (HIP): three workgroups per CU (<= 168 VGPRs) hide the barrier / LDS latencies of a tile
+// measurably better than two (tools/attn_occupancy.py).  Head dims 32 / 40 are held there; 64 lands at 166 VGPRs on its own.
 template <int D>
-__global__ __launch_bounds__(256, (D <= 64 ? 3 : 1)) void attn_fwd_kernel(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t* o,
+__global__ __launch_bounds__(256, (D <= 40 ? 3 : 1)) void attn_fwd_kernel(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t* o,
                                                        float* lse, int H, int Lq, int Lk, int ldq, int ldk, int ldo, float scale ATTN_DBG_PARAM) {
   using C = AttnCfg<D>;
   __shared__ __attribute__((aligned(16))) char Ks[TileBytes<D>::value];

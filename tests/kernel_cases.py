@@ -432,7 +432,10 @@ def case_teacher_input_grad(dev):
     assert len(feats) == 9
     d_feats, loss = [], 0.0
     for k, ((f, H, Wd), fr) in enumerate(zip(feats, feats_ref)):
-        close(f.float().view(B, H, Wd, -1).permute(0, 3, 1, 2), fr.detach(), 3e-2, 3e-2 * float(fr.detach().abs().max()), f"feature {k}")
+        # the 1x1-resolution mid block normalises 4 values per GroupNorm group: bf16 rounding noise is amplified there (2.0-3.6 % of the
+        # feature's range over seeds and GEMM plans, against 0.6-2.4 % for the other eight taps)
+        ft = 5e-2 if H * Wd == 1 else 3e-2
+        close(f.float().view(B, H, Wd, -1).permute(0, 3, 1, 2), fr.detach(), ft, ft * float(fr.detach().abs().max()), f"feature {k}")
         d = torch.randn(fr.shape, generator=torch.Generator().manual_seed(50 + k))
         loss = loss + (fr * d).sum()
         d_feats.append(d.permute(0, 2, 3, 1).reshape(B, H * Wd, -1).bfloat16().contiguous().to(dev))
