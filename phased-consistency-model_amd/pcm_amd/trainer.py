@@ -156,14 +156,19 @@ class Distiller:
         return out
 
     # ---- hipGraph replay of the step: ~5400 launches become two graph launches --------------------
-    def capture(self, B, H=64, W=64, ctx_len=77, ctx_dim=768):
+    def capture(self, B, H=64, W=64, ctx_len=77, ctx_dim=768, added_cond=None, uncond_added_cond=None):
         """Capture forward+backward and the optimizer as two hipGraphs around the (eager) gradient
-        all-reduce.  The eager warm-up pass runs on scratch state: LoRA / Adam state is restored."""
+        all-reduce.  The eager warm-up pass runs on scratch state: LoRA / Adam state is restored.
+        ``added_cond`` / ``uncond_added_cond`` (SDXL text_time conditioning): example dicts; their tensors become static graph inputs
+        that step_graphed refreshes."""
         dev = self.device
         f32 = dict(dtype=torch.float32, device=dev)
         self._static = dict(latents=torch.zeros(B, 4, H, W, **f32), prompt_embeds=torch.zeros(B, ctx_len, ctx_dim, **f32),
                             uncond_prompt_embeds=torch.zeros(B, ctx_len, ctx_dim, **f32), noise=torch.zeros(B, 4, H, W, **f32),
                             index=torch.zeros(B, dtype=torch.int64, device=dev), w=torch.ones(B, **f32))
+        if added_cond is not None:
+            self._static["added_cond"] = {k: v.clone() for k, v in added_cond.items()}
+            self._static["uncond_added_cond"] = {k: v.clone() for k, v in (uncond_added_cond or added_cond).items()}
         lo = self.lora
         saved = [t.clone() for t in (lo.params, lo.exp_avg, lo.exp_avg_sq, self.step_dev, self.lr_dev)]
         if self.ema is not None:
@@ -209,13 +214,17 @@ class Distiller:
         self._static_out["grad_sumsq"] = lo.gradsq
         self._graph = True
 
-    def step_graphed(self, latents, prompt_embeds, uncond_prompt_embeds, noise, index, w, lr=None):
+    def step_graphed(self, latents, prompt_embeds, uncond_prompt_embeds, noise, index, w, lr=None, added_cond=None, uncond_added_cond=None):
         """Same as step() through the captured graphs.  Returned tensors are the graph's static outputs
         (overwritten by the next call)."""
         st = self._static
         st["latents"].copy_(latents); st["prompt_embeds"].copy_(prompt_embeds)
         st["uncond_prompt_embeds"].copy_(uncond_prompt_embeds); st["noise"].copy_(noise)
         st["index"].copy_(index); st["w"].copy_(w)
+        for name, val in (("added_cond", added_cond), ("uncond_added_cond", uncond_added_cond)):
+            if val is not None:
+                for k, v in val.items():
+                    st[name][k].copy_(v)
         if lr is not None:
             self.lr_dev.fill_(float(lr))
         self._g_fb.replay()

@@ -58,6 +58,23 @@ def test_sdxl_topology_step_vs_oracle():
     ratio = float(mine.norm() / refg.norm())
     print("sdxl-topology step: loss %.5f / %.5f, LoRA grad cos %.4f norm ratio %.3f" % (float(out["loss"]), float(ref["loss"]), cos, ratio))
     assert cos > 0.93 and 0.85 < ratio < 1.15
+    # the same step through hipGraph replay (text_time conditioning as static graph inputs): three replays on three different input sets
+    # must reproduce the eager step() on a twin trainer with the same state
+    lora_g = LoraState(pc, 64, 8.0, "cuda", seed=1, b_std=0.05)
+    lora_e = LoraState(pc, 64, 8.0, "cuda", seed=1, b_std=0.05)
+    Dg, De = Distiller(W, lora_g, cfg), Distiller(W, lora_e, cfg)
+    ac, uac = cu(inp["added_cond"]), cu(inp["uncond_added_cond"])
+    Dg.capture(B, H=32, W=32, ctx_len=77, ctx_dim=64, added_cond=ac, uncond_added_cond=uac)
+    for rep in range(3):
+        inp2 = OS.draw_inputs(B, ocfg, seed=20 + rep, latent_hw=32, ctx_len=77, ctx_dim=64)
+        a6 = [cu(inp2[k]) for k in ("latents", "prompt_embeds", "uncond_prompt_embeds", "noise", "index", "w")]
+        ac2 = dict(text_embeds=ac["text_embeds"] * (1.0 + 0.1 * rep), time_ids=ac["time_ids"])
+        og = Dg.step_graphed(*a6, added_cond=ac2, uncond_added_cond=uac)
+        lg = float(og["loss"])
+        oe = De.step(*a6, added_cond=ac2, uncond_added_cond=uac)
+        assert abs(lg - float(oe["loss"])) <= 1e-6 * abs(float(oe["loss"])), (rep, lg, float(oe["loss"]))
+    rel = float((lora_g.params - lora_e.params).norm() / lora_e.params.norm())
+    assert rel < 1e-6, rel
 
 
 @pytest.mark.parametrize("global_step", [0, 1])

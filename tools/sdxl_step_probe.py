@@ -34,3 +34,15 @@ for it in range(3):
     print("step %d: %.1f ms, loss %.5f, grad sumsq %.3e, peak %.1f GB" % (it, 1e3 * (time.time() - t1), float(out["loss"]), float(out["grad_sumsq"]), torch.cuda.max_memory_allocated() / 1e9), flush=True)
     assert torch.isfinite(out["loss"]).all()
 print("images/sec (eager launches, bs %d): %.2f" % (B, B / (time.time() - t1)))
+if len(sys.argv) > 2 and sys.argv[2] == "graph":      # the same step through hipGraph replay (Distiller.capture with the text_time inputs static)
+    D.capture(B, H=128, W=128, ctx_len=77, ctx_dim=2048, added_cond=ac, uncond_added_cond=uac)
+    for it in range(3):
+        lat, pe, un, nz = rn(B, 4, 128, 128), rn(B, 77, 2048), torch.zeros(B, 77, 2048, device=dev), rn(B, 4, 128, 128)
+        idx = torch.randint(0, 40, (B,), generator=g, device=dev)
+        w = 6.0 + torch.rand(B, generator=g, device=dev)
+        torch.cuda.synchronize(); t1 = time.time()
+        out = D.step_graphed(lat, pe, un, nz, idx, w, added_cond=ac, uncond_added_cond=uac)
+        torch.cuda.synchronize()
+        print("graphed step %d: %.1f ms, loss %.5f" % (it, 1e3 * (time.time() - t1), float(out["loss"])), flush=True)
+        assert torch.isfinite(out["loss"]).all()
+    print("images/sec (hipGraph replay, bs %d): %.2f" % (B, B / (time.time() - t1)))
