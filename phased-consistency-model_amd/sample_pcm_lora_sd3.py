@@ -26,6 +26,10 @@ def parse_args(argv=None):
     p.add_argument("--lora_dir", default=None, help="trainer output directory (reads its pytorch_lora_weights.safetensors)")
     p.add_argument("--lora_file", default=None, help="a LoRA safetensors file (diffusers 'transformer.*' or peft keys); module set and rank are read from it")
     p.add_argument("--lora_scale", type=float, default=1.0, help="sd3_test.py's alpha: LoRA tensors are multiplied by sqrt(alpha)")
+    p.add_argument("--lora_alpha", type=float, default=8.0,
+                   help="LoRA alpha the file was trained with (scaling = alpha / rank).  8 = this repo's and the reference trainers' raw output "
+                        "(lora_alpha=8 at train_pcm_lora_sd3.py:973-978).  Files processed by the reference's convert.py (A/2, B/2, meant to be "
+                        "loaded by diffusers with alpha = rank) need --lora_alpha <rank>, e.g. 32")
     p.add_argument("--lora_rank", type=int, default=32)
     p.add_argument("--prompt_embeds", default=None)
     p.add_argument("--synthetic_prompts", type=int, default=0)
@@ -56,7 +60,7 @@ def main(args):
     del sd
     lora_file = args.lora_file or (os.path.join(args.lora_dir, "pytorch_lora_weights.safetensors") if args.lora_dir else None)
     if lora_file:
-        lora = ck.sd3_lora_from_file(cfg, lora_file, dev, scale=args.lora_scale)
+        lora = ck.sd3_lora_from_file(cfg, lora_file, dev, lora_alpha=args.lora_alpha, scale=args.lora_scale)
     else:
         lora = sd3_lora_state(cfg, args.lora_rank, 8.0, dev, seed=args.seed)          # B = 0: the teacher
     g = torch.Generator(device=dev).manual_seed(args.seed)

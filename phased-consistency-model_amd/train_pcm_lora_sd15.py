@@ -209,12 +209,22 @@ def sched_step(step, world):
     return step * world
 
 
+def reseed_for_resume(src, args, rank, global_step):
+    """A resumed run must not replay the noise / timestep / data draws of step 0: the stream generators are re-seeded with an offset
+    derived from the restored step count (the reference resumes accelerate's saved RNG state; here the state is a function of the step).
+    Returns the CPU generator for the guidance-scale draws."""
+    off = 7919 * int(global_step)
+    if off:
+        src.g.manual_seed((args.seed or 0) + rank + off)
+    return torch.Generator().manual_seed((args.seed or 0) + rank + off)
+
+
 def lr_at(args, step):
     """get_scheduler(args.lr_scheduler, ...) (:1026-1031): 'constant' ignores warmup (App. A.6)."""
     if args.lr_scheduler == "constant":
         return args.learning_rate
     if args.lr_scheduler == "constant_with_warmup":
-        return args.learning_rate * min(1.0, (step + 1) / max(1, args.lr_warmup_steps))
+        return args.learning_rate * min(1.0, step / max(1, args.lr_warmup_steps))     # diffusers get_constant_schedule_with_warmup: lr 0 on the first step
     if args.lr_scheduler == "linear":
         w = args.lr_warmup_steps
         if step < w:
@@ -304,7 +314,7 @@ def main(args):
             global_step = ck.load_state(D, os.path.join(args.output_dir, path))
     logf = open(os.path.join(args.output_dir, args.logging_dir, f"{args.tracker_project_name}.jsonl"), "a") if rank == 0 else None
     logger.info("***** Running training *****  world=%d  per-GPU batch=%d  total steps=%d", world, args.train_batch_size, args.max_train_steps)
-    cpu_gen = torch.Generator().manual_seed((args.seed or 0) + rank)
+    cpu_gen = reseed_for_resume(src, args, rank, global_step)
     t_last = time.time()
     while global_step < args.max_train_steps:
         lr = lr_at(args, sched_step(global_step, world))

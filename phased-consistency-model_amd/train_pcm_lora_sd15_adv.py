@@ -84,7 +84,7 @@ def main(args):
             global_step = ck.load_state(D, os.path.join(args.output_dir, path))     # the heads restart from scratch, as in the reference
             gen_steps = global_step // 2
     logf = open(os.path.join(args.output_dir, args.logging_dir, f"{args.tracker_project_name}.jsonl"), "a") if rank == 0 else None
-    cpu_gen = torch.Generator().manual_seed((args.seed or 0) + rank)
+    cpu_gen = base.reseed_for_resume(src, args, rank, global_step)
     while global_step < args.max_train_steps:
         latents, pe = src.batch()
         B = latents.shape[0]

@@ -237,6 +237,7 @@ def main(args):
         else:
             logger.info("Resuming from checkpoint %s", path)
             global_step = ck.load_state(D, os.path.join(args.output_dir, path))
+    base.reseed_for_resume(src, args, rank, global_step)
     logf = open(os.path.join(args.output_dir, args.logging_dir, f"{args.tracker_project_name}.jsonl"), "a") if rank == 0 else None
     logger.info("***** Running training *****  world=%d  per-GPU batch=%d  total steps=%d", world, args.train_batch_size, args.max_train_steps)
     t_last = time.time()

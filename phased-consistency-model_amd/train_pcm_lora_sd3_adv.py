@@ -103,6 +103,7 @@ def main(args):
         if path is not None:
             global_step = ck.load_state(D, os.path.join(args.output_dir, path))     # the heads restart from scratch, as in the reference
             gen_steps = global_step // 2
+    base.reseed_for_resume(src, args, rank, global_step)
     logf = open(os.path.join(args.output_dir, args.logging_dir, f"{args.tracker_project_name}.jsonl"), "a") if rank == 0 else None
     logger.info("***** Running training *****  world=%d  per-GPU batch=%d  total steps=%d  LoRA modules=%d", world, args.train_batch_size,
                 args.max_train_steps, len(lora.modules))

@@ -141,8 +141,9 @@ def main(args):
         path = os.path.basename(args.resume_from_checkpoint) if args.resume_from_checkpoint != "latest" else ck.latest_checkpoint(args.output_dir)
         if path is not None:
             global_step = ck.load_state(D, os.path.join(args.output_dir, path))
+            gen_steps = global_step // 2 if adv else global_step       # the lr schedule counts generator steps (every second step)
     logf = open(os.path.join(args.output_dir, args.logging_dir, f"{args.tracker_project_name}.jsonl"), "a") if rank == 0 else None
-    cpu_gen = torch.Generator().manual_seed((args.seed or 0) + rank)
+    cpu_gen = base.reseed_for_resume(src, args, rank, global_step)
     uac = dict(text_embeds=src.uncond_pooled, time_ids=src.time_ids)
     while global_step < args.max_train_steps:
         latents, pe, pooled = src.batch()

@@ -516,7 +516,9 @@ def test_scheduler_position_follows_accelerate_per_script():
     cli = load_cli()
     assert cli.sched_step(10, 1) == 10 and cli.sched_step(10, 8) == 80
     a = types.SimpleNamespace(learning_rate=1e-4, lr_warmup_steps=80, max_train_steps=1000, lr_scheduler="constant_with_warmup")
-    assert abs(cli.lr_at(a, cli.sched_step(9, 8)) - 1e-4 * 73 / 80) < 1e-12          # 8 GPUs: warm-up over after 10 optimizer steps
+    # diffusers get_constant_schedule_with_warmup: lr_lambda(step) = step / max(1, warmup) (lr 0 at step 0, like the linear / cosine ramps)
+    assert abs(cli.lr_at(a, cli.sched_step(9, 8)) - 1e-4 * 72 / 80) < 1e-12          # 8 GPUs: warm-up over after 10 optimizer steps
+    assert cli.lr_at(a, 0) == 0.0
     assert cli.lr_at(a, cli.sched_step(10, 8)) == 1e-4
     assert "sched_step" in inspect.getsource(cli.main) and "sched_step" in inspect.getsource(_load("train_pcm_lora_sd15_adv").main)
     assert "sched_step" in inspect.getsource(_load("train_pcm_lora_sdxl_adv").main)
