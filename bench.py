@@ -225,12 +225,12 @@ def main():
         if os.environ.get("PCM_GEMM_TABLE"):
             agg = {}
             for fl, e0, e1, key, _plan in prof:
-                a = agg.setdefault(str(key), [0, 0.0, 0.0])
+                a = agg.setdefault(str(key) + " plan %d" % _plan, [0, 0.0, 0.0])
                 a[0] += 1; a[1] += e0.elapsed_time(e1); a[2] += fl
             rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
             with open(os.environ["PCM_GEMM_TABLE"], "w") as f:
                 for k, (n, t, fl) in rows:
-                    f.write("%-44s calls %4d  total %8.3f ms  avg %7.1f us  %7.1f TF/s\n" % (k, n, t, 1e3 * t / n, fl / t / 1e9))
+                    f.write("%-56s calls %4d  total %8.3f ms  avg %7.1f us  %7.1f TF/s\n" % (k, n, t, 1e3 * t / n, fl / t / 1e9))
         # HBM-side bytes of the dominant kernel from the committed PMC passes (separate rocprofv3 --pmc runs, gfx950 FETCH_SIZE x2
         # correction calibrated on a known copy): profiles/r02_pmc_gemm8p_traffic.json (round 1: r01_e_...).  It is for ONE launch of the largest
         # 64x64-resolution conv (M=131072, 320->320 + LoRA; algorithmic 186 MB): the 9 taps re-read the activation tile through

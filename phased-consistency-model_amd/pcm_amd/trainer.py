@@ -346,6 +346,63 @@ class AdvDistiller(Distiller):
         out["grad_sumsq"] = self.lora.gradsq
         return out
 
+    def capture_adv(self, B, H=64, W=64, ctx_len=77, ctx_dim=768, added_cond=None, uncond_added_cond=None):
+        """Capture the discriminator step and the generator step as two hipGraphs (single GPU: the steps contain no host decision and
+        no collective; ~3200 / ~4500 launches each, whose enqueue time otherwise bounds the adversarial step).  Warm-up runs on scratch
+        state: LoRA, heads and both optimizers are restored afterwards."""
+        if self.world_size != 1:
+            raise RuntimeError("capture_adv: single-process only (the multi-GPU adversarial step interleaves bucketed all-reduces)")
+        dev, d, lo = self.device, self.disc, self.lora
+        f32 = dict(dtype=torch.float32, device=dev)
+        st = dict(latents=torch.zeros(B, 4, H, W, **f32), prompt_embeds=torch.zeros(B, ctx_len, ctx_dim, **f32),
+                  uncond_prompt_embeds=torch.zeros(B, ctx_len, ctx_dim, **f32), noise=torch.zeros(B, 4, H, W, **f32),
+                  index=torch.zeros(B, dtype=torch.int64, device=dev), w=torch.ones(B, **f32),
+                  noise_fake=torch.zeros(B, 4, H, W, **f32), noise_real=torch.zeros(B, 4, H, W, **f32), adv_u=torch.zeros(B, **f32))
+        if added_cond is not None:
+            st["added_cond"] = {k: v.clone() for k, v in added_cond.items()}
+            st["uncond_added_cond"] = {k: v.clone() for k, v in (uncond_added_cond or added_cond).items()}
+        self._adv_static = st
+        keep = (lo.params, lo.exp_avg, lo.exp_avg_sq, self.step_dev, self.lr_dev, d.params, d.exp_avg, d.exp_avg_sq, d.step_dev)
+        saved = [t.clone() for t in keep]
+        count = self.step_count
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            self.step_adv(0, **st)
+            self.step_adv(1, **st)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self._g_d, self._g_g = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._g_d):
+            self._out_d = self.step_adv(0, **st)
+        with torch.cuda.graph(self._g_g, pool=self._g_d.pool()):
+            self._out_g = self.step_adv(1, **st)
+        for dst, src in zip(keep, saved):
+            dst.copy_(src)
+        self.step_count = count
+        lo.repack()
+        d.repack()
+
+    def step_adv_graphed(self, global_step, latents, prompt_embeds, uncond_prompt_embeds, noise, index, w, noise_fake, noise_real, adv_u,
+                         lr=None, added_cond=None, uncond_added_cond=None):
+        """step_adv through the captured graphs; the returned tensors are the graph's static outputs."""
+        st = self._adv_static
+        for k, v in (("latents", latents), ("prompt_embeds", prompt_embeds), ("uncond_prompt_embeds", uncond_prompt_embeds), ("noise", noise),
+                     ("index", index), ("w", w), ("noise_fake", noise_fake), ("noise_real", noise_real), ("adv_u", adv_u)):
+            st[k].copy_(v)
+        for name, val in (("added_cond", added_cond), ("uncond_added_cond", uncond_added_cond)):
+            if val is not None:
+                for k, v in val.items():
+                    st[name][k].copy_(v)
+        if global_step % 2 == 0:
+            self._g_d.replay()
+            return self._out_d
+        if lr is not None:
+            self.lr_dev.fill_(float(lr))
+        self._g_g.replay()
+        self.step_count += 1
+        return self._out_g
+
     def _disc_bucket(self, off0, off1):
         """the heads of one tapped feature are done: their 0.07-0.47 GB of fp32 gradients go out (async) while the remaining heads still
         back-propagate -- 9 collectives per discriminator step instead of one 2.66 GB all-reduce at its end (fp32 like the

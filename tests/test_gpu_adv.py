@@ -61,3 +61,47 @@ def test_adv_step_full_size(global_step):
         assert abs(out["loss_cm"].item() - float(ref["loss_cm"])) < 2e-2 * abs(float(ref["loss_cm"]))
         assert abs(out["g_loss"].item() - float(ref["g_loss"])) < 2e-2 * abs(float(ref["g_loss"]))
         assert cos > 0.95
+
+
+def test_adv_steps_graph_replay_equals_eager():
+    """AdvDistiller.capture_adv: D, G, D, G through the two captured hipGraphs == the same four eager steps on a twin trainer
+    (narrow 2-level UNet, 5 tapped features x 2 heads; real learning rates so every step changes the state the next one reads)."""
+    from oracle import pcm_step as OS
+    from oracle import unet_sd15 as O
+    from pcm_amd import capi
+    from pcm_amd.discriminator import Discriminator
+    from pcm_amd.model import LoraState, UNetWeights
+    from pcm_amd.trainer import AdvDistiller, StepConfig
+    from pcm_amd.unet_spec import UNetConfig
+    capi.set_lib(None)
+    capi.lib()
+    kw = dict(block_out_channels=(64, 128), layers_per_block=1, cross_attention_dim=64, heads=2, norm_num_groups=32)
+    oc, pc = O.UNetConfig(**kw), UNetConfig(**kw)
+    sd = O.init_state_dict(oc, 0)
+    W = UNetWeights(pc, sd, "cuda")
+    dims = (64, 128, 128, 128, 64)
+    cfg = StepConfig(multiphase=2, loss_type="huber", w_min=4.0, w_max=5.0, learning_rate=1e-4)
+    ocfg = OS.StepConfig(multiphase=2, loss_type="huber", w_min=4.0, w_max=5.0)
+    trainers = []
+    for _ in range(2):
+        lora = LoraState(pc, 64, 8.0, "cuda", seed=1, b_std=0.05)
+        disc = Discriminator(dims, num_h_per_head=2, device="cuda", seed=2)
+        trainers.append(AdvDistiller(W, lora, cfg, disc, adv_weight=0.1, adv_lr=1e-4))
+    Dg, De = trainers
+    B, Hh = 2, 16
+    Dg.capture_adv(B, H=Hh, W=Hh, ctx_len=77, ctx_dim=64)
+    for step in range(4):
+        inp = OS.draw_inputs(B, ocfg, seed=40 + step, latent_hw=Hh, ctx_len=77, ctx_dim=64)
+        g = torch.Generator().manual_seed(90 + step)
+        inp["noise_fake"], inp["noise_real"] = torch.randn(B, 4, Hh, Hh, generator=g), torch.randn(B, 4, Hh, Hh, generator=g)
+        inp["adv_u"] = torch.rand(B, generator=g)
+        a = [inp[k].cuda() for k in ("latents", "prompt_embeds", "uncond_prompt_embeds", "noise", "index", "w", "noise_fake", "noise_real", "adv_u")]
+        og = Dg.step_adv_graphed(step, *a)
+        key = "d_loss" if step % 2 == 0 else "loss_cm"
+        lg = float(og[key])
+        oe = De.step_adv(step, *a)
+        le = float(oe[key])
+        assert abs(lg - le) <= 1e-5 * abs(le) + 1e-9, (step, key, lg, le)
+    rel = lambda x, y: float((x - y).norm() / (y.norm() + 1e-30))
+    assert rel(Dg.lora.params, De.lora.params) < 1e-5 and rel(Dg.disc.params, De.disc.params) < 1e-5
+    assert Dg.step_count == De.step_count == 2

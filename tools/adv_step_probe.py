@@ -44,3 +44,21 @@ for gs in (0, 1, 2, 3, 4, 5):
           torch.cuda.max_memory_allocated() / 1e9), flush=True)
 d, gg = min(res["D"][1:]), min(res["G"][1:])
 print("bs %d: D step %.1f ms, G step %.1f ms -> %.2f images/sec per GPU over a D+G pair (one student update per pair; eager launches)" % (B, d, gg, 2 * B / ((d + gg) * 1e-3)))
+if len(sys.argv) > 2 and sys.argv[2] == "graph":     # the same D / G steps through hipGraph replay (AdvDistiller.capture_adv)
+    capi.Lib.call = orig
+    D.capture_adv(B)
+    print("captured, %.1f GB allocated, peak %.1f GB" % (torch.cuda.memory_allocated() / 1e9, torch.cuda.max_memory_allocated() / 1e9), flush=True)
+    res = {}
+    for gs in (0, 1, 2, 3, 4, 5):
+        lat, pe, un, nz = rn(B, 4, 64, 64), rn(B, 77, 768), rn(B, 77, 768), rn(B, 4, 64, 64)
+        idx = torch.randint(0, 50, (B,), generator=g, device=dev); w = 4.0 + torch.rand(B, generator=g, device=dev)
+        nf, nr, au = rn(B, 4, 64, 64), rn(B, 4, 64, 64), torch.rand(B, generator=g, device=dev)
+        torch.cuda.synchronize(); t0 = time.time()
+        out = D.step_adv_graphed(gs, lat, pe, un, nz, idx, w, nf, nr, au)
+        torch.cuda.synchronize(); dt = 1e3 * (time.time() - t0)
+        kind = "D" if gs % 2 == 0 else "G"
+        res.setdefault(kind, []).append(dt)
+        print("graphed global_step %d (%s step): %.1f ms, %s" % (gs, kind, dt, ("d_loss %.4f" % float(out["d_loss"])) if kind == "D" else
+              ("loss_cm %.5f g_loss %.4f" % (float(out["loss_cm"]), float(out["g_loss"])))), flush=True)
+    d, gg = min(res["D"][1:]), min(res["G"][1:])
+    print("bs %d, hipGraph replay: D step %.1f ms, G step %.1f ms -> %.2f images/sec per GPU over a D+G pair" % (B, d, gg, 2 * B / ((d + gg) * 1e-3)))
