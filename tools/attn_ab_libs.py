@@ -17,14 +17,20 @@ for (B, L, Lk, d, H) in [(32, 4096, 4096, 40, 8), (16, 4096, 4096, 40, 8), (32, 
     q = torch.randn(B, L, H * d, device="cuda").bfloat16(); k = torch.randn(B, Lk, H * d, device="cuda").bfloat16()
     v = torch.randn(B, Lk, H * d, device="cuda").bfloat16(); do = torch.randn(B, L, H * d, device="cuda").bfloat16()
     fl = 4.0 * B * H * L * Lk * d
-    res, outs = [], []
+    # A and B are timed INTERLEAVED (A, B, A, B, ...; min of the rounds): timed one after the other the library measured second
+    # came out 3-13 % faster on the long forward shapes whichever library it was (clock ramp after the operand setup)
+    res, outs = [[1e9, 1e9], [1e9, 1e9]], []
     for l in libs:
         capi.set_lib(l)
         o, lse = ops.attn_fwd(q, k, v, H, d)
-        tf = min(bench(lambda: ops.attn_fwd(q, k, v, H, d)) for _ in range(2))
-        tb = min(bench(lambda: ops.attn_bwd(q, k, v, o, do, lse, H, d)) for _ in range(2))
         g = ops.attn_bwd(q, k, v, o, do, lse, H, d)
-        res.append((tf, tb)); outs.append((o.float(), [x.float() for x in g]))
+        outs.append((o.float(), [x.float() for x in g], o, lse))
+    for rnd_ in range(4):
+        for i, l in enumerate(libs):
+            capi.set_lib(l)
+            o, lse = outs[i][2], outs[i][3]
+            res[i][0] = min(res[i][0], bench(lambda: ops.attn_fwd(q, k, v, H, d)))
+            res[i][1] = min(res[i][1], bench(lambda: ops.attn_bwd(q, k, v, o, do, lse, H, d)))
     def rel(a, b): return float((a - b).norm() / (b.norm() + 1e-30))
     print("B=%2d H=%2d L=%4d Lk=%4d d=%3d | fwd A %7.3f ms %6.0f TF/s  B %7.3f ms %6.0f TF/s (x%.3f) | bwd A %7.3f ms %6.0f  B %7.3f ms %6.0f (x%.3f) | rel diff o %.1e dq %.1e dk %.1e dv %.1e" % (
         B, H, L, Lk, d, res[0][0], fl / res[0][0] / 1e9, res[1][0], fl / res[1][0] / 1e9, res[1][0] / res[0][0],
