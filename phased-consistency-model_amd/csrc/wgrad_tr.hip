@@ -334,7 +334,7 @@ int pcm_wgrad_tr_launch(const WgDev& a0, void* stream) {
     if ((size_t)a.M * a.ldb * 2 >= 0x7ff00000u) return 1;
     const int tiles_g = cdiv(a.G, 128), stages = cdiv(a.M, 64);
     // split over M.  A block ends with 8192 fp32 atomics (32 KB) against 24 KB of operand reads per stage, and the L2 atomic units, not
-    // HBM, bound the launch once the atomics pass ~10 % of the reads: measured (MI355X, tools/gpu_job_f.sh) M = 65536 x G = 320 best at
+    // HBM, bound the launch once the atomics pass ~10 % of the reads: measured (MI355X, tools/jobs/r02_wgrad_blocks.sh) M = 65536 x G = 320 best at
     // 128..256 blocks (17 us; 512: 23.5), G = 2560 at ~1024 (71 us), so: msplit = M / 1024 rows, but at least ~128 blocks in all.
     int msplit = a.M / 1024;
     if (msplit * tiles_g < 128) msplit = cdiv(128, tiles_g);
