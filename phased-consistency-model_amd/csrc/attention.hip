@@ -378,7 +378,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* o, const 
 // ============================================================================ backward: dQ
 template <int D>
 __global__ __launch_bounds__(256, (D <= 40 ? 3 : 1)) void attn_bwd_dq_kernel(const bf16_t* q, const bf16_t* k, const bf16_t* v, const bf16_t* dO,
-                                                          const float* lse, const float* delta, bf16_t* dq, int H, int Lq,
+                                                          const float* lse, float* delta, const bf16_t* o, bf16_t* dq, int H, int Lq,
                                                           int Lk, int ldq, int ldk, int ldo, float scale) {
   using C = AttnCfg<D>;
   __shared__ __attribute__((aligned(16))) char Ks[TileBytes<D>::value];
@@ -397,7 +397,24 @@ __global__ __launch_bounds__(256, (D <= 40 ? 3 : 1)) void attn_bwd_dq_kernel(con
   }
   const int qrow = q0 + l31;
   const float L2 = qrow < Lq ? lse[((size_t)b * H + h) * Lq + qrow] : 0.f;
-  const float dl = qrow < Lq ? delta[((size_t)b * H + h) * Lq + qrow] : 0.f;
+  // delta[q] = sum_d dO[q][d] * O[q][d]: with ``o`` given it is computed HERE from the dO fragments the lane already holds plus the matching O
+  // fragments (two half-row partial sums, one lane swap) and published for the dK/dV kernel, which runs after this one -- the separate
+  // attn_delta pass (one launch and one more read of O and dO per attention) is then skipped
+  float dl;
+  if (o) {
+    const bf16_t* ob = o + (size_t)b * Lq * ldo + h * D;
+    float part = 0.f;
+#pragma unroll
+    for (int s = 0; s < C::DK16; s++) {
+      const bf16x8 of = gfrag<D>(ob, ldo, qrow, Lq, s, hi);
+#pragma unroll
+      for (int e = 0; e < 8; e++) part += bf2f((bf16_t)of[e]) * bf2f((bf16_t)dof[s][e]);
+    }
+    dl = pcm_xhalf_sum(part);
+    if (hi == 0 && qrow < Lq) delta[((size_t)b * H + h) * Lq + qrow] = dl;
+  } else {
+    dl = qrow < Lq ? delta[((size_t)b * H + h) * Lq + qrow] : 0.f;
+  }
   f32x16 acc[C::DV];
 #pragma unroll
   for (int i = 0; i < C::DV; i++)
@@ -676,12 +693,13 @@ extern "C" int pcm_attn_bwd_ws(const void* q, const void* k, const void* v, cons
   if (int rc = attn_check("pcm_attn_bwd", q, k, v, B, H, Lq, Lk, d, ldq, ldk, ldo)) return rc;
   PCM_CHECK(o && dO && lse && delta && PCM_ALIGNED16(o) && PCM_ALIGNED16(dO), PCM_EALIGN, "pcm_attn_bwd: o/dO/lse/delta");
   PCM_CHECK(B <= 65535 && H <= 65535, PCM_EUNSUPPORTED, "pcm_attn_bwd: batch / head count beyond the grid limit");
-  PCM_LAUNCH(attn_delta_kernel, dim3((Lq * H + 255) / 256, B), dim3(256), 0, stream, (const bf16_t*)o, (const bf16_t*)dO, delta, H, Lq, d, ldo);
+  // delta: by the dQ kernel when there is one (it holds the dO rows anyway), by its own pass otherwise
+  if (!dq) PCM_LAUNCH(attn_delta_kernel, dim3((Lq * H + 255) / 256, B), dim3(256), 0, stream, (const bf16_t*)o, (const bf16_t*)dO, delta, H, Lq, d, ldo);
   if (dq) {
     dim3 grid((Lq + 127) / 128, H, B), block(256);
 #define DQ_CALL(DD)                                                                                                          \
   PCM_LAUNCH((attn_bwd_dq_kernel<DD>), grid, block, 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)dO, \
-             lse, delta, (bf16_t*)dq, H, Lq, Lk, ldq, ldk, ldo, scale)
+             lse, delta, (const bf16_t*)o, (bf16_t*)dq, H, Lq, Lk, ldq, ldk, ldo, scale)
     ATTN_DISPATCH(d, DQ_CALL)
   }
   if (dk && dv) {
