@@ -506,6 +506,11 @@ extern "C" int pcm_gemm_bf16(const pcm_gemm_seg* segs, int nseg, const pcm_gemm_
   if (g_conv_co < 0) { const char* ev = getenv("PCM_GEMM_CONV_CO"); g_conv_co = ev ? atoi(ev) : 0; }
   if (g_conv_md < 0) { const char* ev = getenv("PCM_GEMM_CONV_MD"); g_conv_md = ev ? atoi(ev) : 0; }
   g.conv_co = g_conv_co; g.conv_md = g_conv_md || g_conv_co;
+  if (e->N == 64 && nseg == 1 && segs[0].mode == PCM_SEG_CONV3X3) {   // conv LoRA down-projection: halo-window kernel where the geometry allows
+    const int rc = pcm_conv_r64_launch(g, stream);
+    if (rc < 0) return rc;
+    if (rc == 0) { g_last_plan = 65; return pcm_post_launch("pcm_gemm_bf16"); }
+  }
   if (gemm_n64_ok(segs, nseg, e)) {
     g_last_plan = 64;
     int rc = pcm_gemm_n64_launch(g, stream);

@@ -564,6 +564,37 @@ def case_gemm_n64(dev, M, K):
     return float((err - (2e-2 + 1e-2 * ref.abs())).max())
 
 
+def case_conv_r64(dev, B, H, W, C, expect_kernel=True):
+    """conv LoRA down-projection t = conv3x3(x, A), A: C -> 64 (N = 64 implicit GEMM): the halo-window kernel (conv_r64.hip) where the
+    geometry allows it, the generic tile otherwise -- both against torch conv2d on the same bf16 operands."""
+    import ctypes
+    from pcm_amd import capi, ops
+    cnt = capi.lib().dll.pcm_debug_conv_r64_count
+    cnt.restype = ctypes.c_long
+    x = rnd(B, H, W, C, seed=1, dev=dev)
+    A = rnd(64, C, 3, 3, seed=2, dev=dev, scale=0.05)
+    wk = A.permute(0, 2, 3, 1).reshape(64, 9 * C).contiguous()          # [r][(kh, kw, ci)]
+    M = B * H * W
+    ref = F.conv2d(x.float().cpu().permute(0, 3, 1, 2), A.float().cpu(), None, padding=1).permute(0, 2, 3, 1).reshape(M, 64)
+    n0 = cnt()
+    out = torch.full((M, 64), 7.0, dtype=torch.bfloat16, device=dev)
+    capi.lib().dll.pcm_debug_conv_r64(2)         # 2: take every shape the kernel can run (the product skips launches with < 256 patches)
+    try:
+        ops.gemm([ops.Seg(x, wk, conv=dict(Hs=H, Ws=W))], M, 64, out, Ho=H, Wo=W)
+    finally:
+        capi.lib().dll.pcm_debug_conv_r64(1)
+    assert (cnt() == n0 + 1) == expect_kernel, (cnt() - n0, expect_kernel)
+    close(out, ref, 1e-2, 1e-2 * float(ref.abs().max()), "conv r64 %dx%dx%dx%d" % (B, H, W, C))
+    if expect_kernel:    # same numbers from the generic path
+        capi.lib().dll.pcm_debug_conv_r64(0)
+        try:
+            out2 = torch.empty(M, 64, dtype=torch.bfloat16, device=dev)
+            ops.gemm([ops.Seg(x, wk, conv=dict(Hs=H, Ws=W))], M, 64, out2, Ho=H, Wo=W)
+        finally:
+            capi.lib().dll.pcm_debug_conv_r64(1)
+        close(out, out2.float().cpu(), 1e-2, 1e-2 * float(ref.abs().max()), "conv r64 vs generic")
+
+
 def case_gemm_geglu(dev, M=300, K=128, inner=160):
     """Projection with the GEGLU epilogue (interleaved value/gate rows) vs torch; returns max abs excess over tolerance."""
     import torch.nn.functional as F

@@ -126,6 +126,21 @@ def test_rank64_streaming_kernel(M, K):
     assert KC.case_gemm_n64("cpu", M, K) <= 0
 
 
+# patch geometries of conv_r64.hip: 8-wide (16 rows per patch), 16-wide (8 rows), 32-wide (4 rows), 64-wide (2 rows), 128-wide (two 64-column
+# patches per row pair), two images, two channel chunks; and shapes it must leave to the generic tile (8x8 image: no 128-pixel patch)
+@pytest.mark.parametrize("lazy_dma", ["0", "1"])
+@pytest.mark.parametrize("B,H,W,C", [(1, 16, 8, 64), (2, 8, 16, 128), (1, 4, 32, 64), (2, 2, 64, 64), (1, 2, 128, 64), (1, 16, 16, 192)])
+def test_conv_lora_down_projection_halo_kernel(B, H, W, C, lazy_dma, monkeypatch):
+    import kernel_cases as KC
+    monkeypatch.setenv("PCM_EMU_LAZY_DMA", lazy_dma)
+    KC.case_conv_r64("cpu", B, H, W, C)
+
+
+def test_conv_lora_down_projection_fallback_shapes():
+    import kernel_cases as KC
+    KC.case_conv_r64("cpu", 2, 8, 8, 64, expect_kernel=False)
+
+
 def test_fused_geglu_epilogue():
     import kernel_cases as KC
     assert KC.case_gemm_geglu("cpu") <= 0

@@ -107,6 +107,12 @@ def test_rank64_streaming_kernel(M, K):
     assert KC.case_gemm_n64("cuda", M, K) <= 0
 
 
+@pytest.mark.parametrize("B,H,W,C", [(4, 64, 64, 320), (4, 32, 32, 640), (8, 16, 16, 1280), (2, 128, 128, 320), (3, 16, 8, 64), (2, 8, 8, 1280)])
+def test_conv_lora_down_projection_halo_kernel(B, H, W, C):
+    import kernel_cases as KC
+    KC.case_conv_r64("cuda", B, H, W, C, expect_kernel=not (H == 8 and W == 8))
+
+
 def test_fused_geglu_epilogue():
     import kernel_cases as KC
     assert KC.case_gemm_geglu("cuda") <= 0
