@@ -561,9 +561,22 @@ __global__ __launch_bounds__(256) void rowdot_bwd_kernel(const bf16_t* x, const 
     if (dx) *(uint4*)(dx + m * C + cvl * 8) = ew_pack8(o);
     if (cvl == 0) sb += d;
   }
+  // block-level reduction of the k row-lanes in LDS, then one atomic per (block, channel) -- see gn_param_grad_kernel
+  __shared__ float red[256 * 8 + 32];
 #pragma unroll
-  for (int e = 0; e < 8; e++) atomicAdd(&dw[cvl * 8 + e], s[e]);
-  if (cvl == 0 && db) atomicAdd(db, sb);
+  for (int e = 0; e < 8; e++) red[(pl * CV + cvl) * 8 + e] = s[e];
+  if (cvl == 0) red[256 * 8 + pl] = sb;
+  __syncthreads();
+  for (int i = threadIdx.x; i < CV * 8; i += blockDim.x) {
+    float t = 0.f;
+    for (int j = 0; j < k; j++) t += red[j * CV * 8 + i];
+    atomicAdd(&dw[i], t);
+  }
+  if (threadIdx.x == 0 && db) {
+    float t = 0.f;
+    for (int j = 0; j < k; j++) t += red[256 * 8 + j];
+    atomicAdd(db, t);
+  }
 }
 extern "C" int pcm_rowdot_fwd(const void* x, const float* w, const float* bias, float* out, long M, int C, void* stream) {
   PCM_CHECK(x && w && out && M > 0 && (C % 8) == 0 && PCM_ALIGNED16(x), PCM_EINVAL, "pcm_rowdot_fwd: C%%8, alignment");

@@ -596,8 +596,19 @@ __global__ __launch_bounds__(256) void gn_param_grad_kernel(GNArgs a, float* dga
       s1[e] += dz * xh; s2[e] += dz;
     }
   }
+  // the k pixel-lanes of the block are reduced in LDS first: ONE atomic per (block, channel, parameter).  Per-thread atomics put
+  // k x blocks same-address operations on every channel (measured on the 36-head discriminator step: 320 us per call, 23 ms per step).
+  __shared__ float red[256 * 16];
 #pragma unroll
-  for (int e = 0; e < 8; e++) { atomicAdd(&dgamma[c0 + e], s1[e]); atomicAdd(&dbeta[c0 + e], s2[e]); }
+  for (int e = 0; e < 8; e++) { red[(pl * a.CVL + cvl) * 16 + e] = s1[e]; red[(pl * a.CVL + cvl) * 16 + 8 + e] = s2[e]; }
+  __syncthreads();
+  for (int i = threadIdx.x; i < a.CVL * 16; i += blockDim.x) {
+    float t = 0.f;
+    for (int j = 0; j < k; j++) t += red[j * a.CVL * 16 + i];
+    const int cv = i >> 4, e = i & 15;
+    float* dst = (e < 8 ? dgamma : dbeta) + (zc * a.CVL + cv) * 8 + (e & 7);
+    atomicAdd(dst, t);
+  }
 }
 extern "C" int pcm_groupnorm_param_grad(const void* x, const void* dy, const double* stats, const float* gamma, const float* beta,
                                         float* dgamma, float* dbeta, int B, int HW, int C, int G, float eps, int act, void* stream) {

@@ -209,6 +209,12 @@ def case_pack(dev):
     assert torch.equal(d.cpu(), rb.flip(2, 3).permute(1, 2, 3, 0).reshape(24, -1))
     f2, d2 = ops.pack_conv3x3(wc.permute(0, 2, 3, 1).contiguous(), khwc=True)
     assert torch.equal(f2.cpu(), f.cpu()) and torch.equal(d2.cpu(), d.cpu())
+    # the [N][tap][C] source goes through a 32 x 32 tile transpose: ragged tiles in both directions, with a scale
+    wr = rnd(70, 3, 3, 40, seed=3, dev=dev, dtype=torch.float32)
+    f3, d3 = ops.pack_conv3x3(wr, khwc=True, scale=0.5)
+    rb = (wr.cpu() * 0.5).bfloat16().permute(0, 3, 1, 2)          # [N][C][3][3]
+    assert torch.equal(f3.cpu(), rb.permute(0, 2, 3, 1).reshape(70, -1))
+    assert torch.equal(d3.cpu(), rb.flip(2, 3).permute(1, 2, 3, 0).reshape(40, -1))
 
 
 def case_wgrad_plain(dev, M, N, K):
@@ -367,6 +373,29 @@ def case_adv_kernels(dev, golden):
     close(dxx, d.cpu()[:, None] * w.cpu()[None, :], 1e-2, 1e-2, "rowdot dx")
     close(dw, (d.cpu()[:, None] * xx.float().cpu()).sum(0), 1e-4, 1e-4, "rowdot dw")
     close(dbb, d.cpu().sum().reshape(1), 1e-5, 1e-5, "rowdot db")
+    # the discriminator's real widths: 40 column vectors x 6 row lanes per block (block-level LDS reduction before the atomics), many blocks
+    B, HW, C, G = 2, 300, 320, 32
+    x = rnd(B, HW, C, seed=11, dev=dev, shift=0.2)
+    gamma = rnd(C, seed=12, dev=dev, dtype=torch.float32, shift=1.0, scale=0.2)
+    beta = rnd(C, seed=13, dev=dev, dtype=torch.float32, scale=0.2)
+    dy = rnd(B, HW, C, seed=14, dev=dev)
+    y, stats = ops.groupnorm_fwd(x, gamma, beta, G, 1e-5, capi.ACT_LEAKY)
+    xr = x.float().cpu().permute(0, 2, 1)
+    gr, br = gamma.cpu().clone().requires_grad_(True), beta.cpu().clone().requires_grad_(True)
+    F.leaky_relu(F.group_norm(xr, G, gr, br, 1e-5), 0.01).backward(dy.float().cpu().permute(0, 2, 1))
+    dg, db = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+    ops.groupnorm_param_grad(x, dy, stats, gamma, beta, dg, db, G, 1e-5, capi.ACT_LEAKY)
+    close(dg, gr.grad, 5e-3, 5e-2, "dgamma (C=320)")
+    close(db, br.grad, 5e-3, 5e-2, "dbeta (C=320)")
+    M = 1000
+    xx = rnd(M, C, seed=15, dev=dev)
+    w = rnd(C, seed=16, dev=dev, dtype=torch.float32, scale=0.2)
+    d = rnd(M, seed=18, dev=dev, dtype=torch.float32)
+    dw, dbb = torch.zeros(C, device=dev), torch.zeros(1, device=dev)
+    dxx = ops.rowdot_bwd(xx, w, d, dw, dbb)
+    close(dxx, d.cpu()[:, None] * w.cpu()[None, :], 1e-2, 1e-2, "rowdot dx (C=320)")
+    close(dw, (d.cpu()[:, None] * xx.float().cpu()).sum(0), 1e-3, 1e-3, "rowdot dw (C=320)")
+    close(dbb, d.cpu().sum().reshape(1), 1e-4, 1e-4, "rowdot db (C=320)")
 
 
 def case_discriminator_heads(dev, dims=(64, 128), hw=(6, 3), B=2, nh=2):
