@@ -8,7 +8,9 @@ AdamW + operand repack.  Workload = BASELINE.json configs[1]: SD1.5 UNet (random
 offline), 4 phases, 512 px (64x64x4 latents), per-GPU batch 16, bf16 MFMA compute / fp32 accumulate.
 
 Launch:  python bench.py --gpus 1            (single process)
+         python bench.py --gpus N            (spawns its own N ranks, one per GPU, rendezvous on 127.0.0.1)
          python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N
+A WORLD_SIZE that disagrees with --gpus is an error, never a silent 1-rank run.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -30,7 +32,7 @@ TF_STEP = 2 * TF_STUDENT_FWD + 2 * TF_TEACHER_FWD + TF_BWD     # 4.52
 PEAK_BF16_TFLOPS = 2500.0                                        # dense MFMA bf16, MI355X_MICROARCH.md
 
 
-def cpu_baseline(seed, max_seconds=150.0):
+def cpu_baseline(seed, max_seconds=400.0):
     """The oracle (CPU fp32 restatement of the reference step; kind "port": diffusers/peft are not installable here, see
     BASELINE.md section 3) timed on this host in BASELINE.json configs[0] exactly as SURVEY section 8(d) prescribes: SD1.5 UNet,
     bs 2, 2 phases, CFG solver on, fp32, torch AdamW, 1 warm-up step + up to 3 timed steps.  Bounded: timed steps stop early once
@@ -69,6 +71,28 @@ def cpu_baseline(seed, max_seconds=150.0):
                       % (bs, warm, len(times), max_seconds, loss)}
 
 
+def self_spawn(n):
+    """Launcher for ``python bench.py --gpus N`` without torchrun: N children, one rank per GPU, same argv."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = p.wait() or rc
+        if rc:                      # one rank died: do not leave the others waiting in a collective
+            for q in procs:
+                if q.poll() is None:
+                    q.terminate()
+    return rc
+
+
 def log(msg):
     if int(os.environ.get("RANK", "0")) == 0 or os.environ.get("PCM_BENCH_DEBUG"):
         print("[bench %7.1fs] %s" % (time.time() - T0, msg), file=sys.stderr, flush=True)
@@ -89,7 +113,14 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain ``python bench.py --gpus N`` (no torchrun): become the launcher -- one child process per GPU with the torchrun
+        # environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*), rendezvous on 127.0.0.1; rank 0's JSON line is the only stdout
+        sys.exit(self_spawn(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: launch with `python bench.py --gpus N` (self-spawning) or "
+                         "`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`" % (args.gpus, world))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if "PCM_FORCE_DEVICE" in os.environ:          # single-GPU rehearsal of the N>1 path (with PCM_DIST_BACKEND=gloo)
@@ -100,6 +131,16 @@ def main():
         torch.distributed.init_process_group(os.environ.get("PCM_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+    rccl_ranks, devices = 1, [torch.cuda.get_device_name(dev)]
+    if world > 1:
+        # what the collective library itself saw: an all-reduce of ones counts the ranks, an all-gather collects each rank's device
+        ones = torch.ones(1, device=dev)
+        torch.distributed.all_reduce(ones)
+        rccl_ranks = int(ones.item())
+        names = [None] * world
+        torch.distributed.all_gather_object(names, "%s (cuda:%d, rank %d)" % (torch.cuda.get_device_name(dev), local_rank, rank))
+        devices = names
+        assert rccl_ranks == world == torch.distributed.get_world_size(), (rccl_ranks, world)
 
     from pcm_amd import capi, ops
     from pcm_amd.model import LoraState, UNetWeights
@@ -162,6 +203,8 @@ def main():
         torch.cuda.synchronize()
         log("rank %d: warmup step %d done" % (rank, i))
     sync()
+    if world > 1 and use_graph:
+        D.comm_events = []
     t0 = time.perf_counter()
     last = None
     for b in batches[args.warmup:]:
@@ -176,6 +219,14 @@ def main():
     ms = dt * 1e3 / args.steps
     log("timed %d steps: %.1f ms/step (host enqueue %.1f ms/step)" % (args.steps, ms, t_enq * 1e3 / args.steps))
     value = world * B / (dt / args.steps)
+    comm = None
+    if world > 1:
+        ev, D.comm_events = D.comm_events, None
+        comm = {"backend": torch.distributed.get_backend(), "rccl_ranks": rccl_ranks, "devices": devices,
+                "buckets": 2 if (D.bucketed and lora.late_offset is not None) else 1, "grad_bytes": int(lora.grads.numel() * 4),
+                "exposed_allreduce_ms_per_step": round(sum(a.elapsed_time(b) for a, b in ev) / max(1, len(ev)), 3) if ev else None,
+                "note": "exposed = stream time between the end of the backward graph and the optimizer graph on rank 0 (early bucket + wait for the "
+                        "late bucket that was launched between the two backward graphs)"}
     loss = float(last["loss"].item())
 
     # north_star quantity: MFMA fraction of the TWO-TIMESTEP STUDENT FORWARD (online at t_{n+k} + target at t_n: rows a6 + a12 of
@@ -269,7 +320,7 @@ def main():
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                 "config": {"workload": "SD1.5 PCM-LoRA distillation step, %d phases, 64x64x4 latents, per-GPU batch %d, "
                                        "LoRA r=64 (67.25M trainable), huber, AdamW, random-init UNet (859.5M)" % (args.multiphase, B),
-                           "global_batch": world * B, "parallelism": "dp%d" % world, "launch": "hipGraph replay" if use_graph else "eager", "loss_last": round(loss, 6)},
+                           "global_batch": world * B, "parallelism": "dp%d" % world, "comm": comm, "launch": "hipGraph replay" if use_graph else "eager", "loss_last": round(loss, 6)},
                 "roofline": roofline, "cpu_baseline": cpu}
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -562,7 +562,7 @@ __global__ __launch_bounds__(256) void rowdot_bwd_kernel(const bf16_t* x, const 
     if (cvl == 0) sb += d;
   }
   // block-level reduction of the k row-lanes in LDS, then one atomic per (block, channel) -- see gn_param_grad_kernel
-  __shared__ float red[256 * 8 + 32];
+  __shared__ float red[256 * 8 + 256];   // bias partials: one per row-lane, k = blockDim/CV <= 256 (C = 8)
 #pragma unroll
   for (int e = 0; e < 8; e++) red[(pl * CV + cvl) * 8 + e] = s[e];
   if (cvl == 0) red[256 * 8 + pl] = sb;

@@ -74,6 +74,7 @@ class Distiller:
         self.lr_dev = torch.full((1,), float(cfg.learning_rate), dtype=torch.float32, device=self.device)
         self._graph = None
         self._late_work = None
+        self.comm_events = None           # a list: step_graphed appends (start, end) events around the gradient exchange
         # two-bucket gradient exchange (world_size > 1): the mid/up-block bucket is reduced while the down blocks back-propagate
         self.bucketed = os.environ.get("PCM_DDP_BUCKETS", "1") != "0"
         self.ema = None
@@ -232,7 +233,15 @@ class Distiller:
             if self.world_size > 1:
                 self._all_reduce_late()
             self._g_fb2.replay()
-        self.all_reduce_grads()
+        ev = self.comm_events
+        if ev is not None and self.world_size > 1:   # bench.py: exposed time of the exchange = what sits between backward and optimizer
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self.all_reduce_grads()
+            e1.record()
+            ev.append((e0, e1))
+        else:
+            self.all_reduce_grads()
         self.step_count += 1
         self._g_opt.replay()
         return self._static_out

@@ -122,9 +122,6 @@ class LatentSource:
             data = [load_file(f) for f in files]
             self.lat = torch.cat([d["latents"] for d in data]).float().to(device)
             self.pe = torch.cat([d["prompt_embeds"] for d in data]).float().to(device)   # resident in HBM (288 GB)
-            for d in data:
-                if "uncond_prompt_embeds" in d:
-                    self.uncond = d["uncond_prompt_embeds"].float().to(device)
             if getattr(args, "max_train_samples", None):            # debugging knob of the reference's parser: truncate the training set
                 n = max(1, args.max_train_samples // world)
                 self.lat, self.pe = self.lat[:n], self.pe[:n]
@@ -224,7 +221,8 @@ def lr_at(args, step):
     if args.lr_scheduler == "constant":
         return args.learning_rate
     if args.lr_scheduler == "constant_with_warmup":
-        return args.learning_rate * min(1.0, step / max(1, args.lr_warmup_steps))     # diffusers get_constant_schedule_with_warmup: lr 0 on the first step
+        # diffusers get_constant_schedule_with_warmup's lambda: step / max(1, warmup) while step < warmup, else 1 (so warmup 0 -> 1.0 at step 0)
+        return args.learning_rate * (1.0 if step >= args.lr_warmup_steps else step / max(1.0, args.lr_warmup_steps))
     if args.lr_scheduler == "linear":
         w = args.lr_warmup_steps
         if step < w:
@@ -266,7 +264,10 @@ def main(args):
     logging.basicConfig(format="%(asctime)s - %(levelname)s - %(name)s - %(message)s", datefmt="%m/%d/%Y %H:%M:%S",
                         level=logging.INFO if rank == 0 else logging.WARNING)
     if args.mixed_precision == "fp16":
-        logger.info("--mixed_precision=fp16 requested: this build computes in bf16 MFMA / fp32 accumulate (no GradScaler needed)")
+        logger.warning("--mixed_precision=fp16 requested: this build computes in bf16 MFMA / fp32 accumulate (no GradScaler needed). "
+                       "Precision consequence: the reference's frozen teacher (train_pcm_lora_sd15.py:1218, fp16 autocast) has ~1e-3 rel-L2 "
+                       "error on eps vs fp32, this bf16 path ~9e-3 (DESIGN.md section 2, row a10); the loss deviation stays within the bf16 "
+                       "budget of DESIGN.md section 5")
     if args.gradient_accumulation_steps < 1:
         raise SystemExit("pcm_amd: --gradient_accumulation_steps must be >= 1")
     ignored = [k for k in IGNORED if getattr(args, k) not in (None, False, 0, 8, 200)]

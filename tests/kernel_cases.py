@@ -21,6 +21,13 @@ def close(a, b, rtol, atol, what=""):
     assert bool((err <= tol).all()), f"{what}: max err {err.max().item():.3e} (max ref {b.abs().max().item():.3e})"
 
 
+def rel_l2(a, b, tol, what=""):
+    a, b = a.float().cpu(), b.float().cpu()
+    r = float((a - b).norm() / b.norm().clamp_min(1e-30))
+    assert r <= tol, f"{what}: rel-L2 {r:.3e} > {tol:.1e} (ref rms {float(b.pow(2).mean().sqrt()):.3e})"
+    return r
+
+
 def case_groupnorm(dev, B, HW, C, G, act, eps=1e-5):
     x = rnd(B, HW, C, seed=1, dev=dev, shift=0.3)
     gamma = rnd(C, seed=2, dev=dev, dtype=torch.float32, shift=1.0, scale=0.2)
@@ -291,15 +298,17 @@ def case_attention(dev, B, H, Lq, Lk, d, spike=False):
     s = heads(qr, Lq) @ heads(kr, Lk).transpose(-1, -2) * d ** -0.5
     ref = (torch.softmax(s, -1) @ heads(vr, Lk)).transpose(1, 2).reshape(B, Lq, H * d)
     o, lse = ops.attn_fwd(q, k, v, H, d)
-    close(o, ref.detach(), 2e-2, 2e-2, "attn fwd")
+    # Relative bounds: at L=4096 the output rms is ~0.026, so an absolute 2e-2 would accept zeros.  bf16 output rounding alone is
+    # 2^-9 = 2e-3 per element; P is rounded to bf16 before the PV MFMA (another ~2e-3, averaged down over the keys).
+    rel_l2(o, ref.detach(), 5e-3, "attn fwd")
+    close(o, ref.detach(), 1e-2, 1e-2 * float(ref.detach().abs().max()), "attn fwd (max-abs, scaled by |ref|max)")
     ref_lse = torch.logsumexp(s.detach(), -1) * 1.4426950408889634
     close(lse, ref_lse, 1e-3, 2e-2, "lse")
     ref.backward(dO.float().cpu())
     dq, dk, dv = ops.attn_bwd(q, k, v, o, dO, lse, H, d)
-    sc = max(1.0, float(qr.grad.abs().max()))
-    close(dq, qr.grad, 3e-2, 3e-2 * sc, "dq")
-    close(dk, kr.grad, 3e-2, 3e-2 * max(1.0, float(kr.grad.abs().max())), "dk")
-    close(dv, vr.grad, 3e-2, 3e-2 * max(1.0, float(vr.grad.abs().max())), "dv")
+    for name, got, want in (("dq", dq, qr.grad), ("dk", dk, kr.grad), ("dv", dv, vr.grad)):
+        rel_l2(got, want, 1.5e-2, name)
+        close(got, want, 3e-2, 3e-2 * float(want.abs().max()), name + " (max-abs, scaled by |ref|max)")
 
 
 def case_lora_repack(dev):
@@ -396,6 +405,16 @@ def case_adv_kernels(dev, golden):
     close(dxx, d.cpu()[:, None] * w.cpu()[None, :], 1e-2, 1e-2, "rowdot dx (C=320)")
     close(dw, (d.cpu()[:, None] * xx.float().cpu()).sum(0), 1e-3, 1e-3, "rowdot dw (C=320)")
     close(dbb, d.cpu().sum().reshape(1), 1e-4, 1e-4, "rowdot db (C=320)")
+    # narrow rows: C = 32 -> 64 row lanes per block (more than the 32 bias slots the first LDS layout reserved: out-of-bounds write, ASan-visible)
+    M, C = 500, 32
+    xx = rnd(M, C, seed=25, dev=dev)
+    w = rnd(C, seed=26, dev=dev, dtype=torch.float32, scale=0.2)
+    d = rnd(M, seed=28, dev=dev, dtype=torch.float32)
+    dw, dbb = torch.zeros(C, device=dev), torch.zeros(1, device=dev)
+    dxx = ops.rowdot_bwd(xx, w, d, dw, dbb)
+    close(dxx, d.cpu()[:, None] * w.cpu()[None, :], 1e-2, 1e-2, "rowdot dx (C=32)")
+    close(dw, (d.cpu()[:, None] * xx.float().cpu()).sum(0), 1e-3, 1e-3, "rowdot dw (C=32)")
+    close(dbb, d.cpu().sum().reshape(1), 1e-4, 1e-4, "rowdot db (C=32)")
 
 
 def case_discriminator_heads(dev, dims=(64, 128), hw=(6, 3), B=2, nh=2):
