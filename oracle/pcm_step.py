@@ -7,6 +7,7 @@ whole step is fp32: this is BASELINE.json configs[0] ("CPU diffusers reference")
 Random draws are INPUTS here (noise, index, w) so that the HIP path can be fed the same
 values; ``draw_inputs`` reproduces the reference's draw order for a seeded run.
 """
+import functools
 import math
 from collections import OrderedDict
 
@@ -15,6 +16,7 @@ import torch
 
 from . import pcm_math as M
 from .unet_sd15 import unet_forward
+from .unet_sd15 import unet_forward as _unet_forward
 
 
 class StepConfig:
@@ -49,9 +51,12 @@ def draw_inputs(bsz, cfg: StepConfig, seed, latent_hw=64, ctx_len=77, ctx_dim=76
                 uncond_prompt_embeds=uncond_prompt_embeds, noise=noise, index=index, w=w)
 
 
-def distill_step_forward(ucfg, sd, lora, inp, cfg: StepConfig):
+def distill_step_forward(ucfg, sd, lora, inp, cfg: StepConfig, storage=None, compute=torch.float32):
     """Forward half of the step; returns every intermediate the parity tests compare.
-    ``lora`` tensors must have requires_grad set by the caller if gradients are wanted."""
+    ``lora`` tensors must have requires_grad set by the caller if gradients are wanted.
+    ``storage="bf16"``: the three UNet evaluations use the rounding-point-matched oracle (unet_sd15._Net); the reference-owned
+    solver / loss math stays fp32 / fp64 exactly as the HIP kernels compute it."""
+    unet_forward = functools.partial(_unet_forward, storage=storage, compute=compute)    # same name on purpose: the call sites below read like the reference
     acp, alpha_s, sigma_s, solver = make_solver(cfg)
     latents, noise, index = inp["latents"], inp["noise"], inp["index"]
     pe, upe = inp["prompt_embeds"], inp["uncond_prompt_embeds"]
@@ -122,7 +127,7 @@ def adamw_step(params, grads, state, step, cfg: StepConfig):
         p.addcdiv_(m, denom, value=-cfg.lr / bc1)
 
 
-def distill_step(ucfg, sd, lora, inp, cfg: StepConfig, opt_state, step):
+def distill_step(ucfg, sd, lora, inp, cfg: StepConfig, opt_state, step, storage=None):
     """Whole step: forward, backward (LoRA only), clip, AdamW.  Mutates ``lora`` in place.
     Returns the forward dict plus 'grads' (post-clip, pre-step, flattened per LoRA tensor in
     dict order A,B) and 'grad_norm'."""
@@ -133,7 +138,7 @@ def distill_step(ucfg, sd, lora, inp, cfg: StepConfig, opt_state, step):
         b = b.detach().requires_grad_(True)
         lora_rg[k] = (a, b)
         leaves += [a, b]
-    out = distill_step_forward(ucfg, sd, lora_rg, inp, cfg)
+    out = distill_step_forward(ucfg, sd, lora_rg, inp, cfg, storage=storage)
     grads = torch.autograd.grad(out["loss"], leaves, allow_unused=True)
     grads = [torch.zeros_like(l) if g is None else g for g, l in zip(grads, leaves)]
     gn = clip_grad_norm_(grads, cfg.max_grad_norm)

@@ -240,40 +240,106 @@ def timestep_embedding(t, dim):
     return torch.cat([torch.cos(arg), torch.sin(arg)], dim=-1)
 
 
+class _RoundBF16(torch.autograd.Function):
+    """x -> bf16 -> fp32 (a STORE in bf16).  Backward: the cotangent passes straight through and is itself rounded -- the HIP path
+    keeps the gradient of a bf16-stored activation in bf16 as well."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(g.dtype)
+
+
+_WCACHE = {}
+
+
+def _derived(w, rounded, dtype):
+    """(bf16-rounded and/or dtype-converted) copy of a frozen parameter, cached by tensor identity (the HIP path packs weights once)."""
+    if not rounded and w.dtype == dtype:
+        return w
+    key = (id(w), w._version, tuple(w.shape), rounded, dtype)
+    hit = _WCACHE.get(key)
+    if hit is None or hit[0] is not w:
+        if len(_WCACHE) > 8192:
+            _WCACHE.clear()
+        v = w.detach()
+        if rounded:
+            v = v.to(torch.bfloat16)
+        hit = (w, v.to(dtype))
+        _WCACHE[key] = hit
+    return hit[1]
+
+
 class _Net:
-    def __init__(self, cfg, sd, lora, lora_alpha=8.0):
+    """``storage="bf16"``: the ROUNDING-POINT-MATCHED oracle.  fp32 compute everywhere, but every tensor DESIGN.md section 3 says the HIP
+    path STORES in bf16 is rounded to bf16 at the same point: frozen weights and the LoRA operands (A and s*B) as MFMA operands, the output
+    of every GEMM / conv epilogue (after bias, time-embedding row vector, residual add, activation -- those run on the fp32 accumulator),
+    GroupNorm / LayerNorm outputs, the rank-64 projection t = x A^T, q/k/v, the softmax probabilities fed to the PV product, the
+    attention output, the GEGLU product.  What remains between this oracle and the HIP path is accumulation order (and the
+    probabilities' rounding happening on unnormalised values in the kernel), so the comparison can be asserted at the north-star 1e-3.
+    ``storage=None`` is the plain fp32 restatement.
+    ``compute``: arithmetic dtype between the rounding points (default fp32).  ``storage="bf16", compute=torch.float64`` is the same
+    network with the same rounding points and a different accumulation precision -- its distance from the fp32-compute run measures how
+    far two correct evaluations of the SAME bf16-storage network drift apart (the yardstick of tests/test_*_rounding_matched.py)."""
+
+    def __init__(self, cfg, sd, lora, lora_alpha=8.0, storage=None, compute=torch.float32):
+        assert storage in (None, "bf16")
         self.cfg, self.sd, self.lora = cfg, sd, lora or {}
         self.alpha = lora_alpha
+        self.bf16 = storage == "bf16"
+        self.dt = compute
 
-    def linear(self, path, x):
-        y = F.linear(x, self.sd[path + ".weight"], self.sd.get(path + ".bias"))
+    def q(self, x):
+        return _RoundBF16.apply(x) if self.bf16 else x
+
+    def w(self, path):
+        return _derived(self.sd[path + ".weight"], self.bf16, self.dt)
+
+    def par(self, key):
+        """a parameter the HIP path keeps in fp32 (biases, norm affine, conv_in / conv_out weights)"""
+        t = self.sd.get(key)
+        return None if t is None else _derived(t, False, self.dt)
+
+    def _lora_ops(self, path):
+        A, B = self.lora[path]
+        s = self.alpha / A.shape[0]
+        if self.bf16:        # operands the kernels read: bf16(A) and bf16(s * B), both rounded from the fp32 master values
+            return self.q(A).to(self.dt), self.q(B * s).to(self.dt), 1.0
+        return A.to(self.dt), B.to(self.dt), s
+
+    def linear(self, path, x, keep_f32=False, weight_f32=False):
+        y = F.linear(x, self.par(path + ".weight") if weight_f32 else self.w(path), self.par(path + ".bias"))
         if path in self.lora:
-            A, B = self.lora[path]
-            y = y + F.linear(F.linear(x, A), B) * (self.alpha / A.shape[0])
-        return y
+            A, B, s = self._lora_ops(path)
+            y = y + F.linear(self.q(F.linear(x, A)), B) * s
+        return y if keep_f32 else self.q(y)
 
-    def conv(self, path, x, stride=1):
-        w = self.sd[path + ".weight"]
+    def conv(self, path, x, stride=1, keep_f32=False, weight_f32=False):
+        w = self.par(path + ".weight") if weight_f32 else self.w(path)
         pad = w.shape[-1] // 2
-        y = F.conv2d(x, w, self.sd.get(path + ".bias"), stride=stride, padding=pad)
+        y = F.conv2d(x, w, self.par(path + ".bias"), stride=stride, padding=pad)
         if path in self.lora:
-            A, B = self.lora[path]
-            y = y + F.conv2d(F.conv2d(x, A, None, stride=stride, padding=pad), B) * (self.alpha / A.shape[0])
-        return y
+            A, B, s = self._lora_ops(path)
+            y = y + F.conv2d(self.q(F.conv2d(x, A, None, stride=stride, padding=pad)), B) * s
+        return y if keep_f32 else self.q(y)
 
     def gn(self, path, x, eps):
-        return F.group_norm(x, self.cfg.norm_num_groups, self.sd[path + ".weight"], self.sd[path + ".bias"], eps)
+        return F.group_norm(x, self.cfg.norm_num_groups, self.par(path + ".weight"), self.par(path + ".bias"), eps)
 
     def ln(self, path, x):
-        return F.layer_norm(x, (x.shape[-1],), self.sd[path + ".weight"], self.sd[path + ".bias"], 1e-5)
+        return F.layer_norm(x, (x.shape[-1],), self.par(path + ".weight"), self.par(path + ".bias"), 1e-5)
 
     def resnet(self, p, x, emb):
-        h = self.conv(p + "conv1", F.silu(self.gn(p + "norm1", x, self.cfg.norm_eps)))
-        h = h + self.linear(p + "time_emb_proj", F.silu(emb))[:, :, None, None]
-        h = self.conv(p + "conv2", F.silu(self.gn(p + "norm2", h, self.cfg.norm_eps)))
+        # epilogue order of the HIP path: fp32 accumulator + bias + time-embedding row (itself a bf16-stored projection) -> ONE rounding
+        h = self.conv(p + "conv1", self.q(F.silu(self.gn(p + "norm1", x, self.cfg.norm_eps))), keep_f32=True)
+        h = self.q(h + self.linear(p + "time_emb_proj", self.q(F.silu(emb)))[:, :, None, None])
+        h = self.conv(p + "conv2", self.q(F.silu(self.gn(p + "norm2", h, self.cfg.norm_eps))), keep_f32=True)
         if (p + "conv_shortcut.weight") in self.sd:
             x = self.conv(p + "conv_shortcut", x)
-        return x + h
+        return self.q(x + h)             # residual added on the fp32 accumulator, then stored
 
     def attention(self, p, x, ctx, H):
         B, L, C = x.shape
@@ -285,50 +351,69 @@ class _Net:
         k = k.view(B, -1, H, d).transpose(1, 2)
         v = v.view(B, -1, H, d).transpose(1, 2)
         s = torch.softmax(q @ k.transpose(-1, -2) * (d ** -0.5), dim=-1)
-        o = (s @ v).transpose(1, 2).reshape(B, L, C)
-        return self.linear(p + "to_out.0", o)
+        if self.bf16:
+            # the kernel feeds bf16 probabilities to the PV MFMA and takes the row sum of the SAME rounded values as the denominator
+            s = self.q(s)
+            o = self.q((s @ v) / s.sum(-1, keepdim=True)).transpose(1, 2).reshape(B, L, C)
+        else:
+            o = (s @ v).transpose(1, 2).reshape(B, L, C)
+        return self.linear(p + "to_out.0", o, keep_f32=True)      # the caller adds the residual before the store
 
     def transformer(self, p, x, ctx, depth=1, heads=None):
         heads = heads if heads is not None else self.cfg.heads_at(0)
         B, C, Hh, Ww = x.shape
         r = x
-        h = self.gn(p + "norm", x, 1e-6)
+        h = self.q(self.gn(p + "norm", x, 1e-6))
         if self.cfg.use_linear_projection:       # Transformer2DModel: reshape first, then a Linear proj_in
             h = self.linear(p + "proj_in", h.permute(0, 2, 3, 1).reshape(B, Hh * Ww, C))
         else:
             h = self.conv(p + "proj_in", h).permute(0, 2, 3, 1).reshape(B, Hh * Ww, C)
         for k in range(depth):
             b = p + f"transformer_blocks.{k}."
-            n = self.ln(b + "norm1", h)
-            h = h + self.attention(b + "attn1.", n, n, heads)
-            h = h + self.attention(b + "attn2.", self.ln(b + "norm2", h), ctx, heads)
-            n = self.ln(b + "norm3", h)
-            a, g = self.linear(b + "ff.net.0.proj", n).chunk(2, dim=-1)
-            h = h + self.linear(b + "ff.net.2", a * F.gelu(g))
+            n = self.q(self.ln(b + "norm1", h))
+            h = self.q(h + self.attention(b + "attn1.", n, n, heads))
+            h = self.q(h + self.attention(b + "attn2.", self.q(self.ln(b + "norm2", h)), ctx, heads))
+            n = self.q(self.ln(b + "norm3", h))
+            # GEGLU runs in the projection's epilogue on the fp32 accumulator (fused path); only the product is stored
+            a, g = self.linear(b + "ff.net.0.proj", n, keep_f32=self.geglu_fused(B * Hh * Ww)).chunk(2, dim=-1)
+            h = self.q(h + self.linear(b + "ff.net.2", self.q(a * F.gelu(g)), keep_f32=True))
         if self.cfg.use_linear_projection:
-            h = self.linear(p + "proj_out", h).reshape(B, Hh, Ww, C).permute(0, 3, 1, 2)
-            return h + r
+            h = self.linear(p + "proj_out", h, keep_f32=True).reshape(B, Hh, Ww, C).permute(0, 3, 1, 2)
+            return self.q(h + r)
         h = h.reshape(B, Hh, Ww, C).permute(0, 3, 1, 2)
-        return self.conv(p + "proj_out", h) + r
+        return self.q(self.conv(p + "proj_out", h, keep_f32=True) + r)
+
+    @staticmethod
+    def geglu_fused(M):
+        """the HIP schedule fuses GEGLU into the projection from 128 rows up (pcm_amd/model.py transformer_fwd); below that the
+        pre-activation makes a bf16 round trip"""
+        return M >= 128
 
 
 def unet_forward(cfg, sd, sample, timesteps, encoder_hidden_states, lora=None, lora_alpha=8.0,
-                 return_features=False, added_cond=None):
+                 return_features=False, added_cond=None, storage=None, compute=torch.float32):
     """UNet2DConditionModel.forward(sample, timestep, encoder_hidden_states).sample in fp32.
     ``return_features`` mimics discriminator_sd15.py modified_forward (features after every down
-    block, mid, every up block; no conv_norm_out/conv_out)."""
-    net = _Net(cfg, sd, lora, lora_alpha)
+    block, mid, every up block; no conv_norm_out/conv_out).
+    ``storage="bf16"``: the rounding-point-matched variant (see _Net)."""
+    net = _Net(cfg, sd, lora, lora_alpha, storage, compute)
+    q = net.q
     boc = cfg.block_out_channels
     n = len(boc)
-    t_emb = timestep_embedding(timesteps, boc[0]).to(sample.dtype)
-    emb = net.linear("time_embedding.linear_2", F.silu(net.linear("time_embedding.linear_1", t_emb)))
+    out_dtype = sample.dtype
+    sample = sample.to(compute)
+    encoder_hidden_states = q(encoder_hidden_states.to(compute))
+    t_emb = q(timestep_embedding(timesteps, boc[0]).to(sample.dtype))
+    # SiLU of both embedding projections runs in the GEMM epilogue (fp32) before the store
+    emb = net.linear("time_embedding.linear_2", q(F.silu(net.linear("time_embedding.linear_1", t_emb, keep_f32=True))), keep_f32=True)
     if cfg.addition_time_embed_dim:
         # addition_embed_type="text_time" (get_aug_embed): emb += add_embedding(cat(text_embeds, add_time_proj(time_ids.flatten())))
         B = sample.shape[0]
-        tid = timestep_embedding(added_cond["time_ids"].flatten(), cfg.addition_time_embed_dim).reshape(B, -1).to(sample.dtype)
-        add_in = torch.cat([added_cond["text_embeds"].to(sample.dtype), tid], dim=-1)
-        emb = emb + net.linear("add_embedding.linear_2", F.silu(net.linear("add_embedding.linear_1", add_in)))
-    h = net.conv("conv_in", sample)
+        tid = q(timestep_embedding(added_cond["time_ids"].flatten(), cfg.addition_time_embed_dim).reshape(B, -1).to(sample.dtype))
+        add_in = torch.cat([q(added_cond["text_embeds"].to(sample.dtype)), tid], dim=-1)
+        a1 = q(F.silu(net.linear("add_embedding.linear_1", add_in, keep_f32=True)))
+        emb = q(q(emb) + net.linear("add_embedding.linear_2", a1, keep_f32=True))      # emb_t stored, then the residual add in the epilogue
+    h = net.conv("conv_in", sample, weight_f32=True)                                # conv_in / conv_out keep fp32 weights
     skips = [h]
     feats = []
     for i in range(n):
@@ -360,8 +445,8 @@ def unet_forward(cfg, sd, sample, timesteps, encoder_hidden_states, lora=None, l
         feats.append(h)
     if return_features:
         return feats
-    h = F.silu(net.gn("conv_norm_out", h, cfg.norm_eps))
-    return net.conv("conv_out", h)
+    h = q(F.silu(net.gn("conv_norm_out", h, cfg.norm_eps)))
+    return net.conv("conv_out", h, keep_f32=True, weight_f32=True).to(out_dtype)
 
 
 def peft_state_dict(lora):

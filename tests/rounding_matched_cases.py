@@ -1,0 +1,164 @@
+"""Parity against the ROUNDING-POINT-MATCHED oracle (oracle/unet_sd15.py ``storage="bf16"``), shared by the emulator and the GPU test files.
+
+Why two kinds of case.  The HIP path stores activations in bf16.  An oracle that rounds at the same points agrees with it to a few
+1e-5 per op (only the fp32 accumulation order differs), but a deep network AMPLIFIES that: a relative difference d in front of a bf16
+store flips about d/ulp of the stored elements by one ulp (2^-8 relative), i.e. it comes out as sqrt(d * ulp) -- 1e-7 -> 2e-5 -> 3e-4
+-> 1e-3 -> ... -> the bf16 noise floor within four or five stores.  Two CORRECT evaluations of the same bf16-storage network therefore
+decorrelate down to the bf16 noise level after a few layers, whatever the oracle.  So:
+
+* block level (one resnet / one transformer block on a SHARED input, where the amplification has not yet happened) the comparison is
+  asserted at the north-star 1e-3 -- this is where a wrong rounding point, a missing bias or a wrong epilogue order shows;
+* end to end the yardstick is measured, not assumed: the matched oracle evaluated with fp64 arithmetic between the SAME rounding points
+  is as far from its own fp32-arithmetic run as any correct implementation can be expected to be ("floor"); the HIP path must sit within
+  a small factor of that floor from the matched oracle, on eps and on the loss.
+"""
+import torch
+import torch.nn.functional as F
+
+from pcm_amd import capi, ops
+from pcm_amd.model import LoraState, UNet, UNetWeights, layer_fwd
+from pcm_amd.ops import Seg
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def _setup(dev, kw, b_std=0.02):
+    from oracle import unet_sd15 as O
+    from pcm_amd.unet_spec import UNetConfig
+    oc, pc = O.UNetConfig(**kw), UNetConfig(**kw)
+    sd = O.init_state_dict(oc, 0)
+    W = UNetWeights(pc, sd, dev)
+    lora = LoraState(pc, 64, 8.0, dev, seed=1, b_std=b_std)
+    olora = {p: (lora.A_peft(m).detach().cpu().clone(), m.B.detach().cpu().clone()) for p, m in lora.modules.items()}
+    return O, oc, pc, sd, W, lora, olora
+
+
+def case_blocks(dev, kw, B, H, ctx_len, level=0, report=None):
+    """One resnet and one transformer block of ``level`` (LoRA on), HIP vs the matched oracle on the SAME bf16 input; plus every op of
+    the transformer block fed with the HIP path's own intermediate, so each rounding point is checked on its own."""
+    O, oc, pc, sd, W, lora, olora = _setup(dev, kw)
+    C = pc.block_out_channels[level]
+    heads = pc.heads_at(level)
+    L, M = H * H, B * H * H
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, L, C, generator=g).bfloat16()
+    ctx = torch.randn(B, ctx_len, pc.cross_attention_dim, generator=g).bfloat16()
+    tt = torch.tensor([259, 759, 13, 990][:B])
+    st = UNet(W, lora)
+    st._arena = None
+    net = O._Net(oc, sd, olora, 8.0, "bf16")
+    net32 = O._Net(oc, sd, olora, 8.0, None)
+    rep = {}
+
+    def nchw(h, c=C):
+        return h.float().cpu().view(B, H, H, c).permute(0, 3, 1, 2)
+
+    def tok(h):
+        return h.permute(0, 2, 3, 1).reshape(B, L, -1)
+    xd, ctxd = x.to(dev), ctx.to(dev)
+    with torch.no_grad():
+        # time embedding chain: sinusoid -> linear_1+SiLU -> linear_2 (+SiLU for the resnets)
+        t_emb = ops.timestep_embedding(tt.to(dev), pc.block_out_channels[0])
+        te_o = net.q(O.timestep_embedding(tt, oc.block_out_channels[0]))
+        rep["t_emb"] = rel(t_emb, te_o)
+        e1 = layer_fwd(W, None, "time_embedding.linear_1", t_emb, B, act=capi.ACT_SILU)
+        emb_act = layer_fwd(W, None, "time_embedding.linear_2", e1, B, act=capi.ACT_SILU)
+        e1_o = net.q(F.silu(net.linear("time_embedding.linear_1", t_emb.float().cpu(), keep_f32=True)))
+        emb_o = net.linear("time_embedding.linear_2", e1.float().cpu(), keep_f32=True)
+        rep["emb_linear_1"] = rel(e1, e1_o)
+        rep["emb_act"] = rel(emb_act, net.q(F.silu(emb_o)))
+        # resnet of this level (input channels = C: the second resnet of a down block)
+        p = "down_blocks.%d.resnets.1." % level
+        r = st.resnet_fwd(p, xd, emb_act, B, H, H, None)
+        rep["resnet"] = rel(nchw(r), net.resnet(p, nchw(x), emb_o))
+        rep["resnet_vs_fp32"] = rel(nchw(r), net32.resnet(p, nchw(x), emb_o))
+        rep["gn_silu"] = rel(nchw(st._gn(p + "norm1", xd, capi.ACT_SILU, 1e-5, None)), net.q(F.silu(net.gn(p + "norm1", nchw(x), 1e-5))))
+        # transformer block, whole
+        p = "down_blocks.%d.attentions.0." % level
+        b = p + "transformer_blocks.0."
+        tr = st.transformer_fwd(p, xd, ctxd, B, H, H, None, 1, heads)
+        rep["transformer"] = rel(nchw(tr), net.transformer(p, nchw(x), ctx.float(), 1, heads))
+        rep["transformer_vs_fp32"] = rel(nchw(tr), net32.transformer(p, nchw(x), ctx.float(), 1, heads))
+        # ... and op by op, each fed with the HIP path's own previous tensor
+        n = st._gn(p + "norm", xd, capi.ACT_NONE, 1e-6, None)
+        rep["t.gn"] = rel(nchw(n), net.q(net.gn(p + "norm", nchw(x), 1e-6)))
+        h = layer_fwd(W, lora, p + "proj_in", n.view(M, C), M)
+        rep["t.proj_in"] = rel(h.view(B, L, C), tok(net.conv(p + "proj_in", nchw(n))))
+        hf = h.float().cpu().view(B, L, C)
+        n1, _, _ = ops.layernorm_fwd(h.view(B, L, C), *W.norms[b + "norm1"])
+        rep["t.ln1"] = rel(n1, net.q(net.ln(b + "norm1", hf)))
+        n1f = n1.float().cpu()
+        fq = lora.qkv[b + "attn1."]
+        t3 = torch.empty(M, fq.r3, dtype=torch.bfloat16, device=dev)
+        ops.gemm([Seg(n1.view(M, C), fq.A_cat_fwd)], M, fq.r3, t3)
+        qkv = torch.empty(M, 3 * C, dtype=torch.bfloat16, device=dev)
+        ops.gemm([Seg(n1.view(M, C), W.qkv[b + "attn1."]), Seg(t3, fq.Bs_cat_fwd, k_algo=lora.rank)], M, 3 * C, qkv)
+        for j, nm in enumerate(("to_q", "to_k", "to_v")):
+            rep["t.attn1." + nm] = rel(qkv[:, j * C:(j + 1) * C].reshape(B, L, C), net.linear(b + "attn1." + nm, n1f))
+        q3 = qkv.view(B, L, 3 * C)
+        d = C // heads
+        o, _ = ops.attn_fwd(q3[:, :, :C], q3[:, :, C:2 * C], q3[:, :, 2 * C:], heads, d)
+        qf, kf, vf = [q3[:, :, i * C:(i + 1) * C].float().cpu().view(B, L, heads, d).transpose(1, 2) for i in range(3)]
+        s = torch.softmax(qf @ kf.transpose(-1, -2) * d ** -0.5, -1)
+        # the probabilities' bf16 rounding is a different realisation in the kernel (unnormalised values against a lazily moved
+        # reference); its size is the same: compare with the exact attention rounded once
+        rep["t.attn1.core_vs_exact"] = rel(o, net.q((s @ vf).transpose(1, 2).reshape(B, L, C)))
+        h1 = layer_fwd(W, lora, b + "attn1.to_out.0", o.view(M, C), M, residual=h)
+        rep["t.attn1.to_out+res"] = rel(h1.view(B, L, C), net.q(hf + net.linear(b + "attn1.to_out.0", o.float().cpu(), keep_f32=True)))
+        n3, _, _ = ops.layernorm_fwd(h1.view(B, L, C), *W.norms[b + "norm3"])
+        n3f = n3.float().cpu()
+        Lff, lmff = W.layers[b + "ff.net.0.proj"], lora.modules[b + "ff.net.0.proj"]
+        t_ff = torch.empty(M, 64, dtype=torch.bfloat16, device=dev)
+        ops.gemm([Seg(n3.view(M, C), lmff.A_fwd)], M, 64, t_ff)
+        gg = torch.empty(M, Lff.N // 2, dtype=torch.bfloat16, device=dev)
+        ops.gemm([Seg(n3.view(M, C), Lff.w_geglu), Seg(t_ff, lmff.Bs_geglu)], M, Lff.N, gg, bias=Lff.bias_geglu, act=capi.ACT_GEGLU, ldo=Lff.N // 2)
+        a, g_ = net.linear(b + "ff.net.0.proj", n3f, keep_f32=True).chunk(2, -1)
+        rep["t.geglu"] = rel(gg.view(B, L, -1), net.q(a * F.gelu(g_)))
+        h3 = layer_fwd(W, lora, b + "ff.net.2", gg, M, residual=h1)
+        rep["t.ff2+res"] = rel(h3.view(B, L, C), net.q(h1.float().cpu().view(B, L, C) + net.linear(b + "ff.net.2", gg.float().cpu().view(B, L, -1), keep_f32=True)))
+    if report is not None:
+        report.update(rep)
+    print({k: "%.2e" % v for k, v in rep.items()})
+    # every op on its own: a handful of one-ulp flips (exp / erf approximations, accumulation order)
+    for k in ("t_emb", "emb_linear_1", "emb_act", "gn_silu", "t.gn", "t.proj_in", "t.ln1", "t.attn1.to_q", "t.attn1.to_k", "t.attn1.to_v",
+              "t.attn1.to_out+res", "t.geglu", "t.ff2+res"):
+        assert rep[k] < 2e-4, (k, rep[k])
+    assert rep["t.attn1.core_vs_exact"] < 2.5e-3, rep["t.attn1.core_vs_exact"]      # bf16 probabilities: one rounding realisation apart
+    # whole blocks on a shared input: the north-star 1e-3 (resnet: 2 GroupNorms + 3 contractions + the embedding projection deep);
+    # the transformer block carries the attention probabilities' rounding (above) through two attentions
+    assert rep["resnet"] < 1e-3, rep["resnet"]
+    assert rep["transformer"] < 2.5e-3, rep["transformer"]
+    return rep
+
+
+def case_step_floor(dev, kw, B, hw, ctx_dim, index=None, report=None, seed=453645634):
+    """Forward of one distillation step: HIP vs the matched oracle, with the yardstick measured on the oracle itself."""
+    from oracle import pcm_step as OS
+    from pcm_amd.trainer import Distiller, StepConfig
+    O, oc, pc, sd, W, lora, olora = _setup(dev, kw)
+    ocfg = OS.StepConfig(multiphase=2, loss_type="huber", lr=5e-6, adam_weight_decay=1e-3, w_min=4.0, w_max=5.0)
+    cfg = StepConfig(multiphase=2, loss_type="huber", learning_rate=5e-6, adam_weight_decay=1e-3, w_min=4.0, w_max=5.0)
+    inp = OS.draw_inputs(B, ocfg, seed=seed, latent_hw=hw, ctx_len=77, ctx_dim=ctx_dim)
+    if index is not None:
+        inp["index"] = torch.tensor(index)
+    with torch.no_grad():
+        m32 = OS.distill_step_forward(oc, sd, olora, inp, ocfg, storage="bf16")
+        m64 = OS.distill_step_forward(oc, sd, olora, inp, ocfg, storage="bf16", compute=torch.float64)
+        f32 = OS.distill_step_forward(oc, sd, olora, inp, ocfg)
+    D = Distiller(W, lora, cfg)
+    d = {k: v.to(dev) for k, v in inp.items()}
+    out = D.forward_backward(d["latents"], d["prompt_embeds"], d["uncond_prompt_embeds"], d["noise"], d["index"], d["w"], backward=False)
+    keys = ("noise_pred", "cond_teacher_output", "target_noise_pred", "x_prev", "model_pred", "target")
+    rep = {"hip_vs_matched": {k: rel(out[k], m32[k]) for k in keys}, "floor_matched_fp64_vs_fp32": {k: rel(m64[k], m32[k]) for k in keys},
+           "hip_vs_fp32": {k: rel(out[k], f32[k]) for k in keys}, "matched_vs_fp32": {k: rel(m32[k], f32[k]) for k in keys}}
+    lh, l32, l64, lf = float(out["loss"]), float(m32["loss"]), float(m64["loss"]), float(f32["loss"])
+    rep["loss"] = dict(hip=lh, matched=l32, matched_fp64=l64, fp32=lf, hip_vs_matched=abs(lh - l32) / l32, floor=abs(l64 - l32) / l32,
+                       hip_vs_fp32=abs(lh - lf) / lf, matched_vs_fp32=abs(l32 - lf) / lf)
+    if report is not None:
+        report.update(rep)
+    for k, v in rep.items():
+        print(k, {a: ("%.2e" % b if isinstance(b, float) else b) for a, b in v.items()})
+    return rep

@@ -1,0 +1,36 @@
+"""Emulator (CPU) run of the rounding-point-matched parity cases (tests/rounding_matched_cases.py): the same csrc kernels, tiny UNet with the
+SD1.5 topology."""
+import pytest
+import torch
+
+from emu_lib import emu_lib
+from pcm_amd import capi
+
+import rounding_matched_cases as R
+
+KW = dict(block_out_channels=(64, 128, 128), cross_attention_dim=64, heads=2, norm_num_groups=32)
+KEYS = ("noise_pred", "cond_teacher_output", "target_noise_pred", "x_prev", "model_pred", "target")
+
+
+@pytest.fixture(autouse=True)
+def _use_emu():
+    capi.set_lib(emu_lib())
+    yield
+    capi.set_lib(None)
+
+
+def test_blocks_vs_rounding_matched_oracle():
+    R.case_blocks("cpu", KW, 2, 16, 77)
+
+
+@pytest.mark.slow
+def test_step_within_the_bf16_storage_floor():
+    """end to end: the HIP path is no further from the matched oracle than the matched oracle is from ITSELF when only its accumulation
+    precision changes (fp64 instead of fp32 between the same rounding points)."""
+    reps = [R.case_step_floor("cpu", KW, 2, 16, 64, seed=s) for s in (1001, 1002)]
+    for rep in reps:
+        for k in KEYS:
+            assert rep["hip_vs_matched"][k] <= 1.3 * rep["floor_matched_fp64_vs_fp32"][k] + 2e-4, (k, rep["hip_vs_matched"][k], rep["floor_matched_fp64_vs_fp32"][k])
+    hip = sum(r["loss"]["hip_vs_matched"] for r in reps) / len(reps)
+    floor = sum(r["loss"]["floor"] for r in reps) / len(reps)
+    assert hip <= 2.0 * floor + 1e-3, (hip, floor)
