@@ -116,3 +116,20 @@ def _run_adv(global_step, sdxl):
         cos = float((mine.double() * refg.double()).sum() / (mine.double().norm() * refg.double().norm()))
         assert cos > 0.95 and rel(mine, refg) < 0.35, (cos, rel(mine, refg))
         assert torch.equal(disc.params, p_disc)            # the heads are untouched on generator steps
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("global_step", [0, 1])
+def test_adv_step_four_heads_per_tap_real_learning_rates(global_step):
+    """the BASELINE configs[2] SHAPE on the emulator: four heads per tapped feature, batch 2, non-zero lr / adv_lr; compares the head / LoRA
+    updates with the oracle's clip + AdamW (tests/adv_cases.py; the full-size run is tests/test_gpu_adv.py)."""
+    import adv_cases as A
+    kw = dict(block_out_channels=(64, 128), layers_per_block=1, cross_attention_dim=64, heads=2, norm_num_groups=32)
+    rep = A.case_adv_c3("cpu", kw, (64, 128, 128, 128, 64), 2, 16, 7, 64, global_step)
+    assert rep["heads"] == 20 and rep["fake_adv"] < 5e-3
+    if global_step % 2 == 0:
+        assert rep["d_loss_rel"] < 5e-3 and rep["lora_untouched"] and rep["head_grad_cos"] > 0.99 and min(rep["head_grad_cos_per_tap"]) > 0.985
+        assert rep["head_update_cos"] > 0.9 and abs(rep["head_update_norm_ratio"] - 1) < 1e-2
+    else:
+        assert rep["loss_cm_rel"] < 2e-2 and rep["g_loss_rel"] < 5e-3 and rep["heads_untouched"]
+        assert rep["lora_grad_cos"] > 0.95 and rep["lora_update_cos"] > 0.8 and abs(rep["lora_update_norm_ratio"] - 1) < 1e-2
