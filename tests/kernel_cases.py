@@ -284,12 +284,14 @@ def case_wgrad_conv(dev, B, Hs, Ws, C, stride, src_mode=0):
     close(dA2.permute(0, 3, 1, 2), A.grad, 2e-3, 2e-3 * M ** 0.5, "dA conv (khwc layout)")
 
 
-def case_attention(dev, B, H, Lq, Lk, d, spike=False):
+def case_attention(dev, B, H, Lq, Lk, d, spike=False, spike_at=None):
     q = rnd(B, Lq, H * d, seed=1, dev=dev)
     k = rnd(B, Lk, H * d, seed=2, dev=dev)
     v = rnd(B, Lk, H * d, seed=3, dev=dev)
     if spike:  # force a large running-max jump late in the key stream (online-softmax rescale path)
         k[:, Lk - 3, :] = k[:, Lk - 3, :] * 6
+    for pos in (spike_at or ()):   # ... and in the middle of the stream: the pipelined forward rescales O one tile after the move
+        k[:, pos, :] = k[:, pos, :] * 5
     dO = rnd(B, Lq, H * d, seed=4, dev=dev)
     qr, kr, vr = [t.float().cpu().requires_grad_(True) for t in (q, k, v)]
 
@@ -307,7 +309,9 @@ def case_attention(dev, B, H, Lq, Lk, d, spike=False):
     ref.backward(dO.float().cpu())
     dq, dk, dv = ops.attn_bwd(q, k, v, o, dO, lse, H, d)
     for name, got, want in (("dq", dq, qr.grad), ("dk", dk, kr.grad), ("dv", dv, vr.grad)):
-        rel_l2(got, want, 1.5e-2, name)
+        # (several x5 / x6 key spikes make the softmax nearly one-hot: dS = P (dP - delta) is then a difference of nearly equal bf16-rounded
+        # terms -- those stress cases get 2.5e-2)
+        rel_l2(got, want, 2.5e-2 if spike_at else 1.5e-2, name)
         close(got, want, 3e-2, 3e-2 * float(want.abs().max()), name + " (max-abs, scaled by |ref|max)")
 
 

@@ -25,15 +25,23 @@ def rel(a, b):
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
+_SETUPS = {}
+
+
 def _setup(dev, kw, b_std=0.02):
+    """weights, packed operands and LoRA state for one config: built once per process (the SD1.5-size packing costs ~20 s)"""
     from oracle import unet_sd15 as O
     from pcm_amd.unet_spec import UNetConfig
-    oc, pc = O.UNetConfig(**kw), UNetConfig(**kw)
-    sd = O.init_state_dict(oc, 0)
-    W = UNetWeights(pc, sd, dev)
-    lora = LoraState(pc, 64, 8.0, dev, seed=1, b_std=b_std)
-    olora = {p: (lora.A_peft(m).detach().cpu().clone(), m.B.detach().cpu().clone()) for p, m in lora.modules.items()}
-    return O, oc, pc, sd, W, lora, olora
+    key = (str(dev), tuple(sorted((k, str(v)) for k, v in kw.items())), b_std)
+    if key not in _SETUPS:
+        oc, pc = O.UNetConfig(**kw), UNetConfig(**kw)
+        sd = O.init_state_dict(oc, 0)
+        W = UNetWeights(pc, sd, dev)
+        lora = LoraState(pc, 64, 8.0, dev, seed=1, b_std=b_std)
+        olora = {p: (lora.A_peft(m).detach().cpu().clone(), m.B.detach().cpu().clone()) for p, m in lora.modules.items()}
+        _SETUPS.clear()           # keep one config resident
+        _SETUPS[key] = (O, oc, pc, sd, W, lora, olora)
+    return _SETUPS[key]
 
 
 def case_blocks(dev, kw, B, H, ctx_len, level=0, report=None):
@@ -134,7 +142,7 @@ def case_blocks(dev, kw, B, H, ctx_len, level=0, report=None):
     return rep
 
 
-def case_step_floor(dev, kw, B, hw, ctx_dim, index=None, report=None, seed=453645634):
+def case_step_floor(dev, kw, B, hw, ctx_dim, index=None, report=None, seed=453645634, with_fp32=True):
     """Forward of one distillation step: HIP vs the matched oracle, with the yardstick measured on the oracle itself."""
     from oracle import pcm_step as OS
     from pcm_amd.trainer import Distiller, StepConfig
@@ -147,7 +155,7 @@ def case_step_floor(dev, kw, B, hw, ctx_dim, index=None, report=None, seed=45364
     with torch.no_grad():
         m32 = OS.distill_step_forward(oc, sd, olora, inp, ocfg, storage="bf16")
         m64 = OS.distill_step_forward(oc, sd, olora, inp, ocfg, storage="bf16", compute=torch.float64)
-        f32 = OS.distill_step_forward(oc, sd, olora, inp, ocfg)
+        f32 = OS.distill_step_forward(oc, sd, olora, inp, ocfg) if with_fp32 else m32     # (the plain fp32 oracle: tests/test_gpu_step.py)
     D = Distiller(W, lora, cfg)
     d = {k: v.to(dev) for k, v in inp.items()}
     out = D.forward_backward(d["latents"], d["prompt_embeds"], d["uncond_prompt_embeds"], d["noise"], d["index"], d["w"], backward=False)

@@ -115,6 +115,27 @@ def test_attention(B, H, Lq, Lk, d, spike):
     K.case_attention("cpu", B, H, Lq, Lk, d, spike)
 
 
+@pytest.mark.parametrize("B,H,Lq,Lk,d,at", [(1, 1, 70, 520, 40, (130, 300)), (1, 2, 40, 450, 64, (70, 200, 330)), (1, 1, 40, 400, 80, (100,)),
+                                            (1, 1, 40, 390, 32, (64, 128, 320)), (1, 1, 33, 64, 40, None), (1, 1, 33, 128, 64, (70,))])
+def test_attention_pipelined_forward_steady_state(B, H, Lq, Lk, d, at):
+    """enough full key tiles for several trips of the branch-free two-body steady-state loop of the software-pipelined forward
+    (attention_fwd.hip), reference moves INSIDE it (the deferred O rescale), and the one- / two-tile corner cases"""
+    from pcm_amd import capi
+    assert capi.lib().dll.pcm_debug_attn_fwd_variant_get() >= 1
+    K.case_attention("cpu", B, H, Lq, Lk, d, spike=True, spike_at=at)
+
+
+def test_attention_first_forward_kernel_still_correct():
+    """variant 0 (attention.hip's dependent-chain forward) stays selectable for A/B timing and is what head dim 160 uses"""
+    from pcm_amd import capi
+    dll = capi.lib().dll
+    dll.pcm_debug_attn_fwd_variant(0)
+    try:
+        K.case_attention("cpu", 1, 1, 70, 330, 40, spike=True, spike_at=(100,))
+    finally:
+        dll.pcm_debug_attn_fwd_variant(1)
+
+
 def test_lora_repack():
     K.case_lora_repack("cpu")
 

@@ -26,11 +26,11 @@ def test_adv_step_c3_shape_full_size(global_step):
         assert rep["d_loss_rel"] < 1e-2 and rep["lora_untouched"]
         assert rep["head_grad_cos"] > 0.98 and min(rep["head_grad_cos_per_tap"]) > 0.97 and rep["head_grad_norm_rel"] < 3e-2
         # first AdamW step with beta1 = 0: update = -lr * g / (|g| + eps) ~ -lr * sign(g): the cosine counts agreeing signs, the norm is lr * sqrt(n)
-        assert rep["head_update_cos"] > 0.9 and abs(rep["head_update_norm_ratio"] - 1) < 2e-2 and rep["head_param_rel_after"] < 3e-4
+        assert rep["head_update_cos"] > 0.9 and abs(rep["head_update_norm_ratio"] - 1) < 2e-2 and rep["head_param_rel_after"] < 6e-4
     else:
         assert rep["loss_cm_rel"] < 1.5e-2 and rep["g_loss_rel"] < 1e-2 and rep["heads_untouched"]
         assert rep["lora_grad_cos"] > 0.95 and rep["lora_grad_norm_rel"] < 5e-2
-        assert rep["lora_update_cos"] > 0.85 and abs(rep["lora_update_norm_ratio"] - 1) < 2e-2 and rep["lora_param_rel_after"] < 3e-4
+        assert rep["lora_update_cos"] > 0.85 and abs(rep["lora_update_norm_ratio"] - 1) < 2e-2 and rep["lora_param_rel_after"] < 6e-4
 
 
 def test_adv_steps_graph_replay_equals_eager():

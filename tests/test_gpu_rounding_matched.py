@@ -23,7 +23,7 @@ def _kw():
     return dict(block_out_channels=(320, 640, 1280, 1280), cross_attention_dim=768, heads=8, norm_num_groups=32)
 
 
-@pytest.mark.parametrize("level,H", [(0, 32), (1, 32), (2, 16)])     # head dims 40 / 80 / 160
+@pytest.mark.parametrize("level,H", [(0, 32), (2, 16)])     # head dims 40 / 160
 def test_blocks_vs_rounding_matched_oracle(level, H):
     import rounding_matched_cases as R
     rep = {}
@@ -35,10 +35,12 @@ def test_blocks_vs_rounding_matched_oracle(level, H):
 def test_sd15_step_within_the_bf16_storage_floor():
     import rounding_matched_cases as R
     rep = {}
-    R.case_step_floor("cuda", _kw(), 2, 64, 768, index=[13, 37], report=rep)
+    R.case_step_floor("cuda", _kw(), 2, 64, 768, index=[13, 37], report=rep, with_fp32=False)
     os.makedirs("gpurun_out", exist_ok=True)
     json.dump(rep, open("gpurun_out/rounding_matched_sd15.json", "w"), indent=1)
     for k in KEYS:
         assert rep["hip_vs_matched"][k] <= 1.3 * rep["floor_matched_fp64_vs_fp32"][k] + 2e-4, (k, rep["hip_vs_matched"][k], rep["floor_matched_fp64_vs_fp32"][k])
-    # one sample of a noisy scalar: bounded by a multiple of the floor of THIS sample or the bf16 budget of DESIGN.md section 5
-    assert rep["loss"]["hip_vs_matched"] <= max(3.0 * rep["loss"]["floor"], 9e-3), rep["loss"]
+    # the loss against the MATCHED oracle: the north-star 1e-3 (round-3 measurement on MI355X: 6.5e-4, with the oracle's own fp64-vs-fp32
+    # floor at 3.1e-4; against the plain fp32 oracle both the HIP path and the matched oracle sit at 5.5e-3 / 6.1e-3 -- the bf16 storage
+    # itself moves the loss by that much, in the same direction for both)
+    assert rep["loss"]["hip_vs_matched"] <= max(3.0 * rep["loss"]["floor"], 1e-3), rep["loss"]
