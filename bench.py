@@ -93,6 +93,138 @@ def self_spawn(n):
     return rc
 
 
+def bench_other_config(args, world, rank, local_rank, dev, sync):
+    """BASELINE.json configs[2..4] on this launch's GPUs with the same timing contract as the default (configs[1]) run: synthetic inputs
+    resident in HBM, W warm-up steps, K timed steps between barriers, one JSON line.  ``roofline`` here is the whole step against the
+    bf16 MFMA peak with the algorithmic TFLOP of pcm_amd/flops.py (config walk, 2 FLOP/MAC) -- no per-kernel split, no cpu_baseline
+    (BASELINE.json's CPU-runnable case is configs[0], reported by the default run)."""
+    from pcm_amd import capi, flops
+    capi.lib()
+    cfgname = args.config
+    g = torch.Generator(device=dev).manual_seed(453645634 + rank)
+    rn = lambda *s_, **k: torch.randn(*s_, generator=g, device=dev, **k)   # noqa: E731
+    note = None
+    if cfgname == "c3":
+        from pcm_amd.discriminator import ADAPTER_DIMS, Discriminator
+        from pcm_amd.model import LoraState, UNetWeights
+        from pcm_amd.trainer import AdvDistiller, StepConfig
+        from pcm_amd.unet_spec import UNetConfig, random_state_dict
+        B = args.batch or 8
+        ucfg = UNetConfig.sd15()
+        W = UNetWeights(ucfg, random_state_dict(ucfg, 0, dev), dev)
+        lora = LoraState(ucfg, 64, 8.0, dev, seed=1)
+        disc = Discriminator(ADAPTER_DIMS, num_h_per_head=4, device=dev, seed=2)
+        D = AdvDistiller(W, lora, StepConfig(multiphase=2, loss_type="huber", learning_rate=5e-6, adam_weight_decay=1e-3, w_min=4.0, w_max=5.0),
+                         disc, adv_weight=0.1, adv_lr=1e-5, world_size=world)
+        m = flops.unet_macs(ucfg)
+        t = flops.step_tflop(m)
+        hf = 2e-12 * flops.heads_macs(ADAPTER_DIMS, (32, 16, 8, 8, 8, 16, 32, 64, 64))
+        fw4 = 2 * t["student_fwd"] + 2 * t["teacher_fwd"]
+        tf_d = fw4 + 2 * t["teacher_fwd"] + 2 * hf + 2 * (2 * hf)                 # [fake; real] feature pass + heads fwd + heads dgrad/wgrad
+        tf_g = fw4 + t["teacher_fwd"] + hf + 2 * hf + (t["teacher_fwd"] + 2e-12 * m["attn_core"]) + t["backward"]
+        tf_sample = 0.5 * (tf_d + tf_g)                                          # steps alternate D, G; every step consumes one batch
+        use_graph = world == 1 and not args.no_graph
+        if use_graph:
+            D.capture_adv(B)
+
+        def draw():
+            return [rn(B, 4, 64, 64), rn(B, 77, 768), rn(B, 77, 768), rn(B, 4, 64, 64), torch.randint(0, 50, (B,), generator=g, device=dev),
+                    4.0 + torch.rand(B, generator=g, device=dev), rn(B, 4, 64, 64), rn(B, 4, 64, 64), torch.rand(B, generator=g, device=dev)]
+        state = {"gs": 0}
+
+        def step(b):
+            f = D.step_adv_graphed if use_graph else D.step_adv
+            out = f(state["gs"], *b)
+            state["gs"] += 1
+            return out
+        workload = ("SD1.5 PCM-LoRA + latent discriminator (9 taps x 4 heads = 36 heads, 663.8M head params), 2 phases, 64x64x4 latents, per-GPU "
+                    "batch %d, alternating D / G steps (each consumes one batch)" % B)
+        metric = "distillation images/sec SD1.5 adversarial (36 heads) 512px"
+        note = "algorithmic TFLOP/sample: D step %.2f, G step %.2f" % (tf_d, tf_g)
+        if args.steps % 2:
+            args.steps += 1      # whole D + G pairs
+    elif cfgname == "c4":
+        from pcm_amd.model import LoraState, UNetWeights
+        from pcm_amd.trainer import Distiller, StepConfig
+        from pcm_amd.unet_spec import UNetConfig, random_state_dict
+        B = args.batch or 4
+        ucfg = UNetConfig.sdxl()
+        sd = random_state_dict(ucfg, 0, dev)
+        W = UNetWeights(ucfg, sd, dev)
+        del sd
+        lora = LoraState(ucfg, 64, 8.0, dev, seed=1)
+        D = Distiller(W, lora, StepConfig(multiphase=4, num_ddim_timesteps=40, w_min=6.0, w_max=7.0, learning_rate=2e-6, adam_weight_decay=0.0,
+                                          loss_type="huber"), world_size=world)
+        tf_sample = flops.step_tflop(flops.unet_macs(ucfg, 128, 128, 77, 64))["step"]
+        tids = torch.tensor([[1024, 1024, 0, 0, 1024, 1024]] * B, device=dev)
+        ac = dict(text_embeds=rn(B, 1280), time_ids=tids)
+        uac = dict(text_embeds=torch.zeros(B, 1280, device=dev), time_ids=tids)
+        un = torch.zeros(B, 77, 2048, device=dev)
+        use_graph = not args.no_graph
+        if use_graph:
+            D.capture(B, H=128, W=128, ctx_len=77, ctx_dim=2048, added_cond=ac, uncond_added_cond=uac)
+
+        def draw():
+            return [rn(B, 4, 128, 128), rn(B, 77, 2048), un, rn(B, 4, 128, 128), torch.randint(0, 40, (B,), generator=g, device=dev),
+                    6.0 + torch.rand(B, generator=g, device=dev)]
+
+        def step(b):
+            return (D.step_graphed if use_graph else D.step)(*b, added_cond=ac, uncond_added_cond=uac)
+        workload = "SDXL PCM-LoRA distillation step (2.57B UNet, text_time conditioning), 4 phases, 128x128x4 latents (1024 px), per-GPU batch %d, LoRA r=64" % B
+        metric = "distillation images/sec SDXL 1024px"
+    else:
+        from pcm_amd.mmdit import MMDiTWeights, sd3_lora_state
+        from pcm_amd.mmdit_spec import MMDiTConfig, random_state_dict
+        from pcm_amd.trainer_sd3 import SD3Distiller, SD3StepConfig
+        B = args.batch or 2
+        mcfg = MMDiTConfig.sd3_medium()
+        sd = random_state_dict(mcfg, 0, dev)
+        W = MMDiTWeights(mcfg, sd, dev)
+        del sd
+        lora = sd3_lora_state(mcfg, 32, 8.0, dev, seed=1)
+        D = SD3Distiller(W, lora, SD3StepConfig(multiphase=2, num_euler_timesteps=100, learning_rate=5e-6, adam_weight_decay=1e-3), world_size=world)
+        tf_sample = flops.step_tflop(flops.mmdit_macs(mcfg))["step"]
+        use_graph = not args.no_graph
+        if use_graph:
+            D.capture(B)
+
+        def draw():
+            return [rn(B, 16, 128, 128), rn(B, 154, 4096), rn(B, 2048), rn(B, 154, 4096), rn(B, 2048), rn(B, 16, 128, 128),
+                    torch.randint(0, 100, (B,), generator=g, device=dev)]
+
+        def step(b):
+            return (D.step_graphed if use_graph else D.step)(*b)
+        workload = "SD3-medium (MMDiT 2.03B, 4096 image + 154 text tokens) PCM-LoRA distillation step, 2 phases, 128x128x16 latents, per-GPU batch %d, LoRA r=32" % B
+        metric = "distillation images/sec SD3-medium 1024px"
+    torch.cuda.synchronize()
+    log("%s: model ready (%.1f GB allocated), %s" % (cfgname, torch.cuda.memory_allocated() / 2**30, "hipGraph replay" if use_graph else "eager"))
+    batches = [draw() for _ in range(args.warmup + args.steps)]
+    for b in batches[:args.warmup]:
+        step(b)
+    sync()
+    t0 = time.perf_counter()
+    for b in batches[args.warmup:]:
+        step(b)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt.item())
+    ms = dt * 1e3 / args.steps
+    ach = tf_sample * B / (ms * 1e-3)
+    if rank == 0:
+        line = {"metric": metric, "value": round(world * B / (dt / args.steps), 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+                "data": "synthetic", "config": {"workload": workload, "baseline_config": cfgname, "global_batch": world * B, "parallelism": "dp%d" % world,
+                                                "launch": "hipGraph replay" if use_graph else "eager", "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 1e9, 1)},
+                "roofline": {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
+                             "traffic": None, "what": "whole step, algorithmic TFLOP from the config walk of pcm_amd/flops.py",
+                             "algorithmic_tflop_per_sample_step": round(tf_sample, 3), "note": note},
+                "cpu_baseline": None}
+        print(json.dumps(line), flush=True)
+
+
 def log(msg):
     if int(os.environ.get("RANK", "0")) == 0 or os.environ.get("PCM_BENCH_DEBUG"):
         print("[bench %7.1fs] %s" % (time.time() - T0, msg), file=sys.stderr, flush=True)
@@ -106,7 +238,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=16, help="per-GPU batch (BASELINE config: 16)")
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the BASELINE config's -- c2 16, c3 8, c4 4, c5 2)")
+    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4", "c5"],
+                    help="BASELINE.json configs[1..4]; c2 (SD1.5 bs 16, the headline metric) is what the driver runs")
     ap.add_argument("--multiphase", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -142,6 +276,16 @@ def main():
         devices = names
         assert rccl_ranks == world == torch.distributed.get_world_size(), (rccl_ranks, world)
 
+    if args.config != "c2":
+        def sync0():
+            if world > 1:
+                torch.distributed.barrier(device_ids=[local_rank]) if torch.distributed.get_backend() == "nccl" else torch.distributed.barrier()
+            torch.cuda.synchronize()
+        bench_other_config(args, world, rank, local_rank, dev, sync0)
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
+    args.batch = args.batch or 16
     from pcm_amd import capi, ops
     from pcm_amd.model import LoraState, UNetWeights
     from pcm_amd.trainer import Distiller, StepConfig
