@@ -2,30 +2,19 @@
 // train_pcm_lora_sd15.py:947-957, for every forward of the step).
 //
 // Why a second forward kernel.  The first one (attention.hip) runs each 64-key tile as a dependent chain inside a wave:
-//   QK^T MFMAs -> softmax VALU -> PV MFMAs.  Nothing of a wave's own VALU work is independent of its MFMAs, so overlap only happens by
-// chance between co-resident waves; measured 1190 cycles per tile against 448 cycles of MFMA issue + ~550 cycles of VALU issue (the sum).
-// A CDNA4 SIMD does issue a wave's VALU instructions under that wave's own running MFMA (MI355X_MICROARCH.md: up to ~5 single-issue
-// instructions per 32-cycle 32x32x16 MFMA gap; the round-2 probe `profiles/r02_g_mfma_valu_overlap.txt` row "4 v_fma per MFMA, AGPR
-// accumulators": 87 % of the VALU time hidden) -- provided the instruction stream offers INDEPENDENT work.  This kernel supplies it:
+//   QK^T MFMAs -> softmax VALU -> PV MFMAs, and relies on three co-resident waves per SIMD to overlap one wave's VALU with another's MFMAs.
+// This one makes the overlap available INSIDE every wave's instruction stream:
 //
 //   body j (one basic block in the steady state):   S_{j+1} = K_{j+1} Q^T          6 MFMAs  \   independent of each other:
-//                                                    O     += V_{j-1}^T P_{j-1}^T    8 MFMAs   >  the scheduler interleaves them
-//                                                    P_j    = softmax-numerators(S_j)  ~100 VALU /
+//                                                    O     += V_{j-1}^T P_{j-1}^T    8 MFMAs   >  sched_group_barrier interleaves them
+//                                                    P_j    = softmax-numerators(S_j)  ~100 VALU /   (one MFMA, 3 exp, 4 VALU, ...)
 //
 // i.e. the score MFMAs run one tile AHEAD and the PV MFMAs one tile BEHIND the softmax.  K and V tiles are double-buffered in LDS (K_{j+1}
 // and V_{j-1} are read while K_{j+2} and V_j are stored), one barrier per tile instead of two; global loads run two tiles ahead in
 // registers.  The lazy softmax reference (attention.hip) is kept; a reference move rescales O AFTER the body's PV MFMAs (P_{j-1} is still
 // in the old scale), which only costs anything on the rare tiles that move it.
-// Accumulators: with AG the kernel asks for AccVGPR accumulators (the VALU of the softmax then does not compete with the MFMAs for the
-// VGPR ports); S is read through v_accvgpr_read in that form.  Both forms are built; the launcher picks (pcm_debug_attn_fwd_variant).
+// What it bought is measured, not assumed: see the table at the launcher below (3-5 % at head dims 64 / 80, nothing at 40).
 #include "attn_dev.h"
-
-template <int D>
-struct FwdState {
-  using C = AttnCfg<D>;
-  f32x16 acc_o[C::DV];
-  float m_run, l_run;
-};
 
 // softmax numerators of one 64-key tile held as S^T fragments (lane = query row l31, 16 + 16 scores): raw-domain exp2 against the lazily
 // moved reference.  Returns the packed bf16 P fragments; ``alpha`` (per lane) and ``moved`` (wave-uniform) describe a reference move.
@@ -270,16 +259,31 @@ __global__ __launch_bounds__(256, WPS) void attn_fwd_pipe_kernel(const bf16_t* q
   }
 }
 
-// variant of the forward the launcher of attention.hip uses: 0 = the first kernel (attention.hip), 1 = pipelined / VGPR accumulators,
-// 2 = pipelined / AccVGPR accumulators, 3 = pipelined / AccVGPR / one wave per SIMD.  Default set below; tools and tests may switch it.
-static int g_attn_fwd_variant = 1;
+// Which forward runs (pcm_debug_attn_fwd_variant): -1 = by shape (default, the round-3 measurement below), 0 = always the first kernel
+// (attention.hip), 1 = pipelined / VGPR accumulators, 2 = pipelined / AccVGPR accumulators, 3 = pipelined / AccVGPR / one wave per SIMD.
+//
+// MEASURED on MI355X (profiles/r03_b_attention_fwd_variants.txt, TFLOP/s, interleaved timing of the four variants of one build):
+//   shape (B, H, L, Lk, d)        first kernel   pipelined VGPR   pipelined AGPR (2 / SIMD)   AGPR (1 / SIMD)
+//   32, 8, 4096, 4096, 40              614            594 (x0.97)        552 (x0.90)              503 (x0.82)
+//   32, 8, 1024, 1024, 80              620            648 (x1.05)        489                      468
+//    4, 10, 4096, 4096, 64             776            800 (x1.03)        690                      495
+//    2, 24, 4250, 4250, 64             720            756 (x1.05)        646                      455
+//   32, 8, 4096, 77, 40                206            137 (x0.66: the pipeline's prologue is most of a two-tile stream)
+// i.e. giving every wave independent VALU work next to its MFMAs buys 3-5 % at head dims 64 / 80 and nothing at 40.  With VGPR
+// accumulators the MFMA and the VALU of one SIMD contend for the VGPR ports whichever wave they come from (same throughput from three
+// dependent-chain waves per SIMD as from two pipelined ones: the per-tile time stays the SUM of ~450 MFMA-issue and ~550 VALU-issue
+// cycles), and the AccVGPR forms hipcc generates pay for the separation with 64-94 v_accvgpr copies per tile.  The d = 40 forward is
+// VALU-bound on this chip: 32 v_exp_f32 (quarter rate) + ~65 other VALU per 14 MFMAs, against the ~4 VALU a 32x32x16 MFMA can hide.
+// Default: the pipelined VGPR form where it measured faster (head dim 64 / 80, key streams of >= 8 tiles), the first kernel elsewhere.
+static int g_attn_fwd_variant = -1;
 extern "C" void pcm_debug_attn_fwd_variant(int v) { g_attn_fwd_variant = v; }
 extern "C" int pcm_debug_attn_fwd_variant_get() { return g_attn_fwd_variant; }
 
-// returns false when the variant / head dim has no pipelined instantiation (the caller falls back to the first kernel)
+// returns false when the first kernel (attention.hip) is to run: by choice of the variant, or no pipelined instantiation for the head dim
 bool pcm_attn_fwd_pipe_launch(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int Lq, int Lk, int d, int ldq,
                               int ldk, int ldo, float scale, void* stream) {
-  const int var = g_attn_fwd_variant;
+  int var = g_attn_fwd_variant;
+  if (var < 0) var = ((d == 64 || d == 80) && Lk >= 512) ? 1 : 0;
   if (var < 1 || var > 3 || d > 80) return false;
   dim3 grid((Lq + 127) / 128, H, B), block(256);
 #define PIPE_CALL(DD, AGF, WPS)                                                                                                     \

@@ -121,8 +121,12 @@ def test_attention_pipelined_forward_steady_state(B, H, Lq, Lk, d, at):
     """enough full key tiles for several trips of the branch-free two-body steady-state loop of the software-pipelined forward
     (attention_fwd.hip), reference moves INSIDE it (the deferred O rescale), and the one- / two-tile corner cases"""
     from pcm_amd import capi
-    assert capi.lib().dll.pcm_debug_attn_fwd_variant_get() >= 1
-    K.case_attention("cpu", B, H, Lq, Lk, d, spike=True, spike_at=at)
+    dll = capi.lib().dll
+    dll.pcm_debug_attn_fwd_variant(1)          # (the default picks a kernel by shape: force the pipelined one)
+    try:
+        K.case_attention("cpu", B, H, Lq, Lk, d, spike=True, spike_at=at)
+    finally:
+        dll.pcm_debug_attn_fwd_variant(-1)
 
 
 def test_attention_first_forward_kernel_still_correct():
@@ -133,7 +137,7 @@ def test_attention_first_forward_kernel_still_correct():
     try:
         K.case_attention("cpu", 1, 1, 70, 330, 40, spike=True, spike_at=(100,))
     finally:
-        dll.pcm_debug_attn_fwd_variant(1)
+        dll.pcm_debug_attn_fwd_variant(-1)
 
 
 def test_lora_repack():

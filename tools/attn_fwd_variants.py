@@ -36,4 +36,4 @@ for (B, L, Lk, d, H) in [(32, 4096, 4096, 40, 8), (16, 4096, 4096, 40, 8), (32, 
     print("B=%2d H=%2d L=%4d Lk=%4d d=%3d | " % (B, H, L, Lk, d) + " | ".join(
         "v%d %7.3f ms %5.0f TF/s (x%.2f) do %.0e dlse %.0e" % (var, best[var], fl / best[var] / 1e9, best[variants[0]] / best[var], rel(outs[var][0], ref[0]),
                                                              float((outs[var][1] - ref[1]).abs().max())) for var in variants), flush=True)
-dll.pcm_debug_attn_fwd_variant(1)
+dll.pcm_debug_attn_fwd_variant(-1)
