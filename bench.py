@@ -30,6 +30,7 @@ import torch  # noqa: E402
 TF_STUDENT_FWD, TF_TEACHER_FWD, TF_BWD = 0.8976, 0.8033, 1.12
 TF_STEP = 2 * TF_STUDENT_FWD + 2 * TF_TEACHER_FWD + TF_BWD     # 4.52
 PEAK_BF16_TFLOPS = 2500.0                                        # dense MFMA bf16, MI355X_MICROARCH.md
+PEAK_HBM_BYTES = 8.0e12                                          # HBM3E peak (6.29 TB/s measured copy), MI355X_MICROARCH.md
 
 
 def cpu_baseline(seed, max_seconds=400.0):
@@ -123,7 +124,7 @@ def bench_other_config(args, world, rank, local_rank, dev, sync):
         tf_d = fw4 + 2 * t["teacher_fwd"] + 2 * hf + 2 * (2 * hf)                 # [fake; real] feature pass + heads fwd + heads dgrad/wgrad
         tf_g = fw4 + t["teacher_fwd"] + hf + 2 * hf + (t["teacher_fwd"] + 2e-12 * m["attn_core"]) + t["backward"]
         tf_sample = 0.5 * (tf_d + tf_g)                                          # steps alternate D, G; every step consumes one batch
-        use_graph = world == 1 and not args.no_graph
+        use_graph = not args.no_graph       # world > 1: segmented capture, cut at the head-gradient buckets / the LoRA exchange
         if use_graph:
             D.capture_adv(B)
 
@@ -135,6 +136,7 @@ def bench_other_config(args, world, rank, local_rank, dev, sync):
         def step(b):
             f = D.step_adv_graphed if use_graph else D.step_adv
             out = f(state["gs"], *b)
+            state["d" if state["gs"] % 2 == 0 else "g"] = out
             state["gs"] += 1
             return out
         workload = ("SD1.5 PCM-LoRA + latent discriminator (9 taps x 4 heads = 36 heads, 663.8M head params), 2 phases, 64x64x4 latents, per-GPU "
@@ -213,11 +215,15 @@ def bench_other_config(args, world, rank, local_rank, dev, sync):
         dt = float(tt.item())
     ms = dt * 1e3 / args.steps
     ach = tf_sample * B / (ms * 1e-3)
+    losses = None
+    if cfgname == "c3" and "d" in state and "g" in state:      # last D / G step of this rank (graph replay and eager launches must agree on them)
+        losses = {"d_loss_last": round(float(state["d"]["d_loss"]), 6), "loss_cm_last": round(float(state["g"]["loss_cm"]), 6),
+                  "g_loss_last": round(float(state["g"]["g_loss"]), 6)}
     if rank == 0:
         line = {"metric": metric, "value": round(world * B / (dt / args.steps), 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
                 "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
                 "data": "synthetic", "config": {"workload": workload, "baseline_config": cfgname, "global_batch": world * B, "parallelism": "dp%d" % world,
-                                                "launch": "hipGraph replay" if use_graph else "eager", "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 1e9, 1)},
+                                                "launch": "hipGraph replay" if use_graph else "eager", "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 1e9, 1), "losses": losses},
                 "roofline": {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
                              "traffic": None, "what": "whole step, algorithmic TFLOP from the config walk of pcm_amd/flops.py",
                              "algorithmic_tflop_per_sample_step": round(tf_sample, 3), "note": note},
@@ -413,13 +419,29 @@ def main():
         fam = flops / (tms * 1e-3) / 1e12
         # the dominant kernel of the step (rocprofv3: ~41 % of the kernel time) is the 256x320 phased tile pcm_gemm8p_kernel<3,false,false>
         # (plan code 5xxx of pcm_debug_last_gemm_plan); the family aggregate is reported next to it
-        dom = [(p[0], t) for p, t in zip(prof, times) if p[4] // 1000 == 5]
+        dom = [(p[0], t, p[5]) for p, t in zip(prof, times) if p[4] // 1000 == 5]
         d_fl, d_ms = sum(x[0] for x in dom), sum(x[1] for x in dom)
         ach = d_fl / (d_ms * 1e-3) / 1e12 if dom else fam
+        # The kernel's launches fall into two classes with different roofs.  A launch is "hbm" when moving its ALGORITHMIC bytes at the
+        # 8 TB/s peak takes longer than its flops at the 2.5 PFLOP/s peak (arithmetic intensity below 312 flop/byte: the 1x1 / linear
+        # projections with K <= 1344), "mfma" otherwise (the 3x3 convolutions and long-K projections).  Each class against its own roof:
+        cls = {"mfma": [0, 0.0, 0.0, 0.0], "hbm": [0, 0.0, 0.0, 0.0]}
+        for fl, t_ms, nb in dom:
+            c = cls["hbm" if nb / PEAK_HBM_BYTES > fl / (PEAK_BF16_TFLOPS * 1e12) else "mfma"]
+            c[0] += 1; c[1] += t_ms; c[2] += fl; c[3] += nb
+        classes = {}
+        for name, (n_, t_ms, fl, nb) in cls.items():
+            if not n_:
+                continue
+            tf_s, gb_s = fl / (t_ms * 1e-3) / 1e12, nb / (t_ms * 1e-3) / 1e9
+            classes[name + "_bound_launches"] = {
+                "launches": n_, "kernel_ms_per_step": round(t_ms, 2), "algorithmic_tflop": round(fl / 1e12, 2), "algorithmic_gb": round(nb / 1e9, 2),
+                "achieved_tflops": round(tf_s, 1), "achieved_gb_s": round(gb_s, 1),
+                "frac_of_own_roof": round(tf_s / PEAK_BF16_TFLOPS if name == "mfma" else gb_s * 1e9 / PEAK_HBM_BYTES, 4)}
         log("roofline leg done")
         if os.environ.get("PCM_GEMM_TABLE"):
             agg = {}
-            for fl, e0, e1, key, _plan in prof:
+            for fl, e0, e1, key, _plan, _nb in prof:
                 a = agg.setdefault(str(key) + " plan %d" % _plan, [0, 0.0, 0.0])
                 a[0] += 1; a[1] += e0.elapsed_time(e1); a[2] += fl
             rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
@@ -447,7 +469,7 @@ def main():
                     "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_note": traffic_note,
                     "kernel": "pcm_gemm8p_kernel<3,false,false> (256x320 phased tile; all its launches of one step)",
                     "launches": len(dom), "avg_launch_us": round(1e3 * d_ms / max(1, len(dom)), 1),
-                    "algorithmic_tflop": round(d_fl / 1e12, 2), "kernel_ms_per_step": round(d_ms, 2),
+                    "algorithmic_tflop": round(d_fl / 1e12, 2), "kernel_ms_per_step": round(d_ms, 2), "classes": classes,
                     "gemm_family": {"kernels": "pcm_gemm8p<3>/<2>, pcm_gemm_kernel tiles, pcm_gemm_n64 (every pcm_gemm_bf16 launch)",
                                     "launches": len(prof), "algorithmic_tflop_per_step": round(flops / 1e12, 2),
                                     "kernel_ms_per_step": round(tms, 2), "achieved": round(fam, 1), "frac": round(fam / PEAK_BF16_TFLOPS, 4)},

@@ -73,9 +73,16 @@ def gemm(segs, M, N, out, bias=None, rowvec=None, rows_per_batch=0, residual=Non
         ev0.record()
         capi.lib().call("pcm_gemm_bf16", arr, len(segs), C.byref(e), capi.Lib.stream())
         ev1.record()
+        # algorithmic HBM bytes of the launch: every operand read once (a conv source once, not once per tap), the output written once
+        nbytes = 0
+        for s in segs:
+            nbytes += s.a.numel() * s.a.element_size() if s.conv is not None else M * s.w.shape[-1] * 2
+            nbytes += s.w.numel() * 2
+        out_cols = N // 2 if act == capi.ACT_GEGLU else N
+        nbytes += M * out_cols * out.element_size() + (M * N * 2 if residual is not None else 0) + (pre_out.numel() * 2 if pre_out is not None else 0)
         GEMM_PROFILE.append((2.0 * M * N * sum(s.k_algo for s in segs), ev0, ev1,
                              (M, N, tuple(s.w.shape[-1] for s in segs), "conv" if segs[0].conv else "lin"),
-                             capi.lib().dll.pcm_debug_last_gemm_plan()))
+                             capi.lib().dll.pcm_debug_last_gemm_plan(), nbytes))
         return out
     capi.lib().call("pcm_gemm_bf16", arr, len(segs), C.byref(e), capi.Lib.stream())
     return out

@@ -56,8 +56,47 @@ class DDIMTables:
         self.edges = torch.from_numpy(edges).long().to(device)
 
 
+class SegmentedGraph:
+    """A launch sequence captured as SEVERAL hipGraphs cut at the points where a collective has to be issued from the host (RCCL calls are
+    not captured): replay = graph, host action, graph, host action, ..., graph.  All segments share one memory pool."""
+
+    def __init__(self, pool=None):
+        self.items, self.cur, self.pool = [], None, pool
+
+    def begin(self):
+        self.cur = torch.cuda.CUDAGraph()
+        if self.pool is None:
+            self.cur.capture_begin(capture_error_mode="thread_local")
+        else:
+            self.cur.capture_begin(pool=self.pool, capture_error_mode="thread_local")
+
+    def cut(self, host_fn):
+        """called from inside the code being captured, where the eager path would issue a collective"""
+        self.cur.capture_end()
+        if self.pool is None:
+            self.pool = self.cur.pool()
+        self.items += [self.cur, host_fn]
+        self.begin()
+
+    def end(self):
+        self.cur.capture_end()
+        if self.pool is None:
+            self.pool = self.cur.pool()
+        self.items.append(self.cur)
+        self.cur = None
+
+    def replay(self):
+        for it in self.items:
+            if isinstance(it, torch.cuda.CUDAGraph):
+                it.replay()
+            else:
+                it()
+
+
 class Distiller:
     """Owns the frozen UNet weights, the LoRA state and the optimizer state of one rank."""
+    _seg = None            # SegmentedGraph being captured (AdvDistiller.capture_adv at world_size > 1); None: collectives are issued directly
+    comm_events = None     # a list: step_graphed appends (start, end) events around the gradient exchange
 
     def __init__(self, weights: UNetWeights, lora: LoraState, cfg: StepConfig, world_size=1, process_group=None):
         self.W, self.lora, self.cfg = weights, lora, cfg
@@ -75,6 +114,7 @@ class Distiller:
         self._graph = None
         self._late_work = None
         self.comm_events = None           # a list: step_graphed appends (start, end) events around the gradient exchange
+        self._seg = None                  # SegmentedGraph being captured (AdvDistiller.capture_adv at world_size > 1)
         # two-bucket gradient exchange (world_size > 1): the mid/up-block bucket is reduced while the down blocks back-propagate
         self.bucketed = os.environ.get("PCM_DDP_BUCKETS", "1") != "0"
         self.ema = None
@@ -265,9 +305,18 @@ class Distiller:
         else:
             torch.distributed.all_reduce(self.lora.grads, op=torch.distributed.ReduceOp.SUM, group=self.pg)
 
+    def _collective(self, fn):
+        """issue a collective -- or, while a SegmentedGraph is being captured, cut the graph there and make ``fn`` the host action between
+        the two segments (the captured pass itself never communicates)"""
+        if self._seg is not None:
+            self._seg.cut(fn)
+        else:
+            fn()
+
     def optimizer_step(self):
-        self.all_reduce_grads()
-        self.step_count += 1
+        self._collective(self.all_reduce_grads)
+        if self._seg is None:
+            self.step_count += 1
         self._optimizer_apply()
 
     def _optimizer_apply(self):
@@ -336,7 +385,8 @@ class AdvDistiller(Distiller):
             logits, dtape = disc.forward(feats, save=True)
             disc.grads.zero_()
             self._disc_works = []
-            out["d_loss"] = disc.d_loss_backward(logits, dtape, B, on_bucket=self._disc_bucket if self.world_size > 1 else None)   # :1383-1391
+            bucket = (lambda a, b_: self._collective(lambda: self._disc_bucket(a, b_))) if self.world_size > 1 else None
+            out["d_loss"] = disc.d_loss_backward(logits, dtape, B, on_bucket=bucket)                                                # :1383-1391
             out["real_adv"] = real_adv
             self._disc_optimizer_step()
             return out
@@ -359,8 +409,6 @@ class AdvDistiller(Distiller):
         """Capture the discriminator step and the generator step as two hipGraphs (single GPU: the steps contain no host decision and
         no collective; ~3200 / ~4500 launches each, whose enqueue time otherwise bounds the adversarial step).  Warm-up runs on scratch
         state: LoRA, heads and both optimizers are restored afterwards."""
-        if self.world_size != 1:
-            raise RuntimeError("capture_adv: single-process only (the multi-GPU adversarial step interleaves bucketed all-reduces)")
         dev, d, lo = self.device, self.disc, self.lora
         f32 = dict(dtype=torch.float32, device=dev)
         st = dict(latents=torch.zeros(B, 4, H, W, **f32), prompt_embeds=torch.zeros(B, ctx_len, ctx_dim, **f32),
@@ -381,11 +429,30 @@ class AdvDistiller(Distiller):
             self.step_adv(1, **st)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        self._g_d, self._g_g = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._g_d):
-            self._out_d = self.step_adv(0, **st)
-        with torch.cuda.graph(self._g_g, pool=self._g_d.pool()):
-            self._out_g = self.step_adv(1, **st)
+        if self.world_size == 1:
+            self._g_d, self._g_g = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._g_d):
+                self._out_d = self.step_adv(0, **st)
+            with torch.cuda.graph(self._g_g, pool=self._g_d.pool()):
+                self._out_g = self.step_adv(1, **st)
+        else:
+            # data parallel: the D step is cut at its nine head-gradient buckets (each all-reduce goes out between two segments and
+            # overlaps the heads that are still back-propagating) and in front of the head optimizer; the G step in front of the LoRA
+            # gradient exchange.  10 + 1 and 1 + 1 graph launches per step instead of ~3200 / ~4500 eager launches.
+            torch.cuda.synchronize(); gc.collect(); torch.cuda.empty_cache()
+            cap = torch.cuda.Stream()
+            cap.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(cap):
+                self._g_d = self._seg = SegmentedGraph()
+                self._seg.begin()
+                self._out_d = self.step_adv(0, **st)
+                self._seg.end()
+                self._g_g = self._seg = SegmentedGraph(pool=self._g_d.pool)
+                self._seg.begin()
+                self._out_g = self.step_adv(1, **st)
+                self._seg.end()
+                self._seg = None
+            torch.cuda.current_stream().wait_stream(cap)
         for dst, src in zip(keep, saved):
             dst.copy_(src)
         self.step_count = count
@@ -418,16 +485,21 @@ class AdvDistiller(Distiller):
         reference's DDP, and only on discriminator steps: generator steps never call this)"""
         self._disc_works.append(torch.distributed.all_reduce(self.disc.grads[off0:off1], op=torch.distributed.ReduceOp.SUM, group=self.pg, async_op=True))
 
+    def _disc_finish_exchange(self):
+        """wait for the per-tap buckets launched from inside the head backward (or, if none were, reduce the whole buffer)"""
+        d = self.disc
+        if getattr(self, "_disc_works", None):
+            for wk in self._disc_works:
+                wk.wait()
+            self._disc_works = []
+        else:
+            torch.distributed.all_reduce(d.grads, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+
     def _disc_optimizer_step(self):
         """optimizer_discriminator (:1026-1032): AdamW(lr=adv_lr, betas=(0, 0.999)), global-norm clip over the heads."""
         cfg, d = self.cfg, self.disc
         if self.world_size > 1:
-            if getattr(self, "_disc_works", None):
-                for wk in self._disc_works:
-                    wk.wait()
-                self._disc_works = []
-            else:
-                torch.distributed.all_reduce(d.grads, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+            self._collective(self._disc_finish_exchange)
         d.step_dev += 1
         ops.sumsq(d.grads, d.gradsq)
         ops.adamw_clip_step(d.params, d.grads, d.exp_avg, d.exp_avg_sq, d.gradsq, cfg.max_grad_norm, self.adv_lr, 0.0, 0.999,
