@@ -289,10 +289,16 @@ bool pcm_attn_fwd_pipe_launch(const void* q, const void* k, const void* v, void*
 #define PIPE_CALL(DD, AGF, WPS)                                                                                                     \
   PCM_LAUNCH((attn_fwd_pipe_kernel<DD, AGF, WPS>), grid, block, 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse, \
              H, Lq, Lk, ldq, ldk, ldo, scale)
+  // the two AccVGPR forms (measured 10-37 % slower, table above; the d = 80 one spills) are only built for A/B probes (-DPCM_ATTN_AGPR_VARIANTS)
+#ifdef PCM_ATTN_AGPR_VARIANTS
 #define PIPE_VAR(DD)                                        \
   if (var == 1) { PIPE_CALL(DD, false, 2); }                \
   else if (var == 2) { PIPE_CALL(DD, true, 2); }            \
   else { PIPE_CALL(DD, true, 1); }
+#else
+  if (var != 1) return false;
+#define PIPE_VAR(DD) PIPE_CALL(DD, false, 2);
+#endif
   switch (d) {
     case 32: PIPE_VAR(32) break;
     case 40: PIPE_VAR(40) break;

@@ -178,6 +178,9 @@ def test_loss_curve_20_steps_vs_oracle():
         inp = OS.draw_inputs(4, ocfg, seed=1000 + step, latent_hw=16, ctx_len=77, ctx_dim=64)
         with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
             l16 = float(OS.distill_step_forward(oc, sd, olora, inp, ocfg)["loss"])
+        with torch.no_grad():     # the rounding-point-matched oracle (bf16 storage, fp32 / fp64 arithmetic) on the same parameters
+            lm = float(OS.distill_step_forward(oc, sd, olora, inp, ocfg, storage="bf16")["loss"])
+            lm64 = float(OS.distill_step_forward(oc, sd, olora, inp, ocfg, storage="bf16", compute=torch.float64)["loss"])
         ref = OS.distill_step(oc, sd, olora, inp, ocfg, state, step)          # fp32; updates olora in place
         dev = {k: v.cuda() for k, v in inp.items()}
         out = D.step(dev["latents"], dev["prompt_embeds"], dev["uncond_prompt_embeds"], dev["noise"], dev["index"], dev["w"])
@@ -186,7 +189,8 @@ def test_loss_curve_20_steps_vs_oracle():
         # sqrt coefficients (host sqrt is not correctly rounded on every box), i.e. ~2.4e-7 of the LARGER term
         assert torch.allclose(out["noisy_model_input"].cpu(), ref["noisy_model_input"], rtol=1e-6, atol=2e-6)
         lf, lh = float(ref["loss"]), float(out["loss"].item())
-        rows.append(dict(step=step, oracle_fp32=lf, ref_bf16_autocast=l16, hip=lh, hip_rel=(lh - lf) / lf, ref_bf16_rel=(l16 - lf) / lf))
+        rows.append(dict(step=step, oracle_fp32=lf, ref_bf16_autocast=l16, hip=lh, hip_rel=(lh - lf) / lf, ref_bf16_rel=(l16 - lf) / lf,
+                         matched=lm, hip_vs_matched=(lh - lm) / lm, matched_floor=(lm64 - lm) / lm))
     mh = sum(abs(r["hip_rel"]) for r in rows) / len(rows)
     m16 = sum(abs(r["ref_bf16_rel"]) for r in rows) / len(rows)
     first = sum(abs(r["hip_rel"]) for r in rows[:5]) / 5
@@ -194,7 +198,11 @@ def test_loss_curve_20_steps_vs_oracle():
     # parameters after 20 updates: both sides applied AdamW to their own gradients
     flat_h = torch.cat([torch.cat([lora.A_peft(m).detach().cpu().reshape(-1), m.B.detach().cpu().reshape(-1)]) for m in lora.modules.values()])
     flat_o = torch.cat([torch.cat([a.reshape(-1), b.reshape(-1)]) for a, b in olora.values()])
+    mm = sum(abs(r["hip_vs_matched"]) for r in rows) / len(rows)
+    mfl = sum(abs(r["matched_floor"]) for r in rows) / len(rows)
     rep = dict(mean_abs_rel_hip=mh, mean_abs_rel_ref_bf16_autocast=m16, first5=first, last5=last, max_abs_rel_hip=max(abs(r["hip_rel"]) for r in rows),
+               mean_abs_rel_hip_vs_matched_oracle=mm, mean_abs_rel_matched_oracle_fp64_vs_fp32=mfl,
+               mean_signed_rel_hip_vs_matched_oracle=sum(r["hip_vs_matched"] for r in rows) / len(rows),
                param_rel_after_20=rel(flat_h, flat_o), rows=rows)
     print(json.dumps({k: v for k, v in rep.items() if k != "rows"}, indent=1))
     for r in rows:
@@ -203,5 +211,8 @@ def test_loss_curve_20_steps_vs_oracle():
     json.dump(rep, open("gpurun_out/loss_curve_20.json", "w"), indent=1)
     assert all(math.isfinite(r["hip"]) for r in rows)
     assert mh <= 1.5 * m16 + 1e-3, rep
+    # against the matched oracle the curve sits at the oracle's own accumulation-precision floor (tiny config: 2048 loss elements per step,
+    # the floor itself is several 1e-3; at the SD1.5 size it is 3e-4 and the HIP loss agrees to 6.5e-4, tests/test_gpu_rounding_matched.py)
+    assert mm <= 1.5 * mfl + 1e-3, rep
     assert last <= first + 2.0 * m16 + 1e-3, rep
     assert rep["param_rel_after_20"] < 1e-3, rep
