@@ -56,6 +56,10 @@ class DDIMTables:
         self.edges = torch.from_numpy(edges).long().to(device)
 
 
+SEG_TIMING = os.environ.get("PCM_SEG_TIMING") == "1"
+SEG_FORCE = os.environ.get("PCM_SEG_FORCE") == "1"      # debugging aid: segmented capture of the adversarial step at world_size 1 too
+
+
 class SegmentedGraph:
     """A launch sequence captured as SEVERAL hipGraphs cut at the points where a collective has to be issued from the host (RCCL calls are
     not captured): replay = graph, host action, graph, host action, ..., graph.  All segments share one memory pool."""
@@ -86,11 +90,31 @@ class SegmentedGraph:
         self.cur = None
 
     def replay(self):
+        if SEG_TIMING:
+            return self._replay_timed()
         for it in self.items:
             if isinstance(it, torch.cuda.CUDAGraph):
                 it.replay()
             else:
                 it()
+
+    def _replay_timed(self):
+        """PCM_SEG_TIMING=1: host time of every item (graph launch / host action) and the final drain, printed per replay (debugging aid)"""
+        import sys
+        import time
+        t, parts = time.perf_counter(), []
+        for it in self.items:
+            if isinstance(it, torch.cuda.CUDAGraph):
+                it.replay()
+                kind = "g"
+            else:
+                it()
+                kind = "h"
+            t2 = time.perf_counter()
+            parts.append("%s%.1f" % (kind, 1e3 * (t2 - t)))
+            t = t2
+        torch.cuda.synchronize()
+        print("[seg replay, ms] " + " ".join(parts) + " | drain %.1f" % (1e3 * (time.perf_counter() - t)), file=sys.stderr, flush=True)
 
 
 class Distiller:
@@ -385,7 +409,7 @@ class AdvDistiller(Distiller):
             logits, dtape = disc.forward(feats, save=True)
             disc.grads.zero_()
             self._disc_works = []
-            bucket = (lambda a, b_: self._collective(lambda: self._disc_bucket(a, b_))) if self.world_size > 1 else None
+            bucket = (lambda a, b_: self._collective(lambda: self._disc_bucket(a, b_))) if (self.world_size > 1 or SEG_FORCE) else None
             out["d_loss"] = disc.d_loss_backward(logits, dtape, B, on_bucket=bucket)                                                # :1383-1391
             out["real_adv"] = real_adv
             self._disc_optimizer_step()
@@ -429,7 +453,7 @@ class AdvDistiller(Distiller):
             self.step_adv(1, **st)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        if self.world_size == 1:
+        if self.world_size == 1 and not SEG_FORCE:
             self._g_d, self._g_g = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._g_d):
                 self._out_d = self.step_adv(0, **st)
@@ -483,11 +507,14 @@ class AdvDistiller(Distiller):
         """the heads of one tapped feature are done: their 0.07-0.47 GB of fp32 gradients go out (async) while the remaining heads still
         back-propagate -- 9 collectives per discriminator step instead of one 2.66 GB all-reduce at its end (fp32 like the
         reference's DDP, and only on discriminator steps: generator steps never call this)"""
-        self._disc_works.append(torch.distributed.all_reduce(self.disc.grads[off0:off1], op=torch.distributed.ReduceOp.SUM, group=self.pg, async_op=True))
+        if self.world_size > 1:
+            self._disc_works.append(torch.distributed.all_reduce(self.disc.grads[off0:off1], op=torch.distributed.ReduceOp.SUM, group=self.pg, async_op=True))
 
     def _disc_finish_exchange(self):
         """wait for the per-tap buckets launched from inside the head backward (or, if none were, reduce the whole buffer)"""
         d = self.disc
+        if self.world_size <= 1:
+            return
         if getattr(self, "_disc_works", None):
             for wk in self._disc_works:
                 wk.wait()
@@ -498,7 +525,7 @@ class AdvDistiller(Distiller):
     def _disc_optimizer_step(self):
         """optimizer_discriminator (:1026-1032): AdamW(lr=adv_lr, betas=(0, 0.999)), global-norm clip over the heads."""
         cfg, d = self.cfg, self.disc
-        if self.world_size > 1:
+        if self.world_size > 1 or SEG_FORCE:
             self._collective(self._disc_finish_exchange)
         d.step_dev += 1
         ops.sumsq(d.grads, d.gradsq)
