@@ -124,7 +124,10 @@ def bench_other_config(args, world, rank, local_rank, dev, sync):
         tf_d = fw4 + 2 * t["teacher_fwd"] + 2 * hf + 2 * (2 * hf)                 # [fake; real] feature pass + heads fwd + heads dgrad/wgrad
         tf_g = fw4 + t["teacher_fwd"] + hf + 2 * hf + (t["teacher_fwd"] + 2e-12 * m["attn_core"]) + t["backward"]
         tf_sample = 0.5 * (tf_d + tf_g)                                          # steps alternate D, G; every step consumes one batch
-        use_graph = not args.no_graph       # world > 1: segmented capture, cut at the head-gradient buckets / the LoRA exchange
+        # world > 1: segmented capture, cut at the head-gradient buckets / the LoRA exchange.  Over gloo (the one-device rehearsal) the
+        # replayed D step waits ~137 s for the nine async bucket all-reduces (profiles/r03_d_segmented_replay_timing.txt; the same
+        # segmented graphs with no-op host actions replay at full speed): graphs only with RCCL there unless PCM_ADV_GRAPH=1
+        use_graph = not args.no_graph and (world == 1 or torch.distributed.get_backend() == "nccl" or os.environ.get("PCM_ADV_GRAPH") == "1")
         if use_graph:
             D.capture_adv(B)
 
@@ -367,7 +370,14 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     ms = dt * 1e3 / args.steps
-    log("timed %d steps: %.1f ms/step (host enqueue %.1f ms/step)" % (args.steps, ms, t_enq * 1e3 / args.steps))
+    # host cost of ONE step's launches with an empty queue (outside the timed region).  The "host enqueue" figure of the timed loop is
+    # mostly back-pressure: with several steps queued hipGraphLaunch blocks until the GPU frees queue space, so it tracks the GPU time.
+    t1 = time.perf_counter()
+    run(batches[-1])
+    host_idle_ms = (time.perf_counter() - t1) * 1e3
+    sync()
+    log("timed %d steps: %.1f ms/step (host enqueue %.1f ms/step with %d steps queued; %.2f ms for one step's launches on an idle queue)"
+        % (args.steps, ms, t_enq * 1e3 / args.steps, args.steps, host_idle_ms))
     value = world * B / (dt / args.steps)
     comm = None
     if world > 1:
@@ -486,7 +496,8 @@ def main():
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                 "config": {"workload": "SD1.5 PCM-LoRA distillation step, %d phases, 64x64x4 latents, per-GPU batch %d, "
                                        "LoRA r=64 (67.25M trainable), huber, AdamW, random-init UNet (859.5M)" % (args.multiphase, B),
-                           "global_batch": world * B, "parallelism": "dp%d" % world, "comm": comm, "launch": "hipGraph replay" if use_graph else "eager", "loss_last": round(loss, 6)},
+                           "global_batch": world * B, "parallelism": "dp%d" % world, "comm": comm, "launch": "hipGraph replay" if use_graph else "eager", "loss_last": round(loss, 6),
+                           "host_ms_per_step_idle_queue": round(host_idle_ms, 2)},
                 "roofline": roofline, "cpu_baseline": cpu}
         print(json.dumps(line), flush=True)
     if world > 1:

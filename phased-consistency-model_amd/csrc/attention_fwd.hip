@@ -46,14 +46,20 @@ __device__ __forceinline__ void softmax_tile(f32x16 (&s_)[2], float sc, float& m
   l_run *= alpha;
   m_run = m_use;
   float psum = 0.f;
+  {
+    // two scores per v_pk_fma_f32: with VGPR-form accumulators VALU issue slots are what the tile time is made of (PMC, round 3: 8.3
+    // VALU per MFMA with scalar fmas against 7.1 in the first kernel)
+    const f32x2 sc2 = {sc, sc}, nm2 = {-m_run, -m_run};
 #pragma unroll
-  for (int t = 0; t < 2; t++)
+    for (int t = 0; t < 2; t++)
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-      const float p = PCM_EXP2F(__builtin_fmaf(s_[t][r], sc, -m_run));
-      s_[t][r] = p;
-      if (!ONES) psum += p;
-    }
+      for (int r = 0; r < 16; r += 2) {
+        const f32x2 x = pcm_pk_fma(f32x2{s_[t][r], s_[t][r + 1]}, sc2, nm2);
+        const float p0 = PCM_EXP2F(x[0]), p1 = PCM_EXP2F(x[1]);
+        s_[t][r] = p0; s_[t][r + 1] = p1;
+        if (!ONES) psum += p0 + p1;
+      }
+  }
   l_run += psum;
 #pragma unroll
   for (int ss = 0; ss < 4; ss++) pf[ss] = pack_frag(s_[ss >> 1], ss & 1);
@@ -94,6 +100,26 @@ __device__ __forceinline__ void fwd_sched_pipeline() {
   constexpr int NR = 2 * C::DK16 + 8 * C::DV;           // LDS fragment reads per body
   __builtin_amdgcn_sched_group_barrier(0x200, 2 * RowGeom<D, 64>::N, 0);
   __builtin_amdgcn_sched_group_barrier(0x020, 2 * RowGeom<D, 64>::N, 0);
+  if constexpr (C::DV >= 3) {
+    // wide heads (d = 80: 22 MFMAs, 34 fragment reads): all reads up front do not fit the register budget -- the K fragments first, the
+    // V^T fragments two per MFMA group as the stream goes
+    constexpr int NK = 2 * C::DK16, NV = 8 * C::DV;
+    __builtin_amdgcn_sched_group_barrier(0x100, NK, 0);
+    __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);
+    pcm_static_for<0, 3>([&](auto) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+    });
+    pcm_static_for<3, NM>([&](auto it) {
+      constexpr int g = decltype(it)::value;
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+      if constexpr (2 * g < NV) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+    });
+    return;
+  }
   __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);
   // row maximum (no exponential can start before it): ~26 VALU spread under the first three score MFMAs
   __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);
@@ -104,7 +130,7 @@ __device__ __forceinline__ void fwd_sched_pipeline() {
   pcm_static_for<3, NM>([&](auto) {
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
     __builtin_amdgcn_sched_group_barrier(0x400, 3, 0);
-    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
   });
 #endif
 }
