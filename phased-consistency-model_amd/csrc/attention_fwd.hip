@@ -300,7 +300,9 @@ __global__ __launch_bounds__(256, WPS) void attn_fwd_pipe_kernel(const bf16_t* q
 // dependent-chain waves per SIMD as from two pipelined ones: the per-tile time stays the SUM of ~450 MFMA-issue and ~550 VALU-issue
 // cycles), and the AccVGPR forms hipcc generates pay for the separation with 64-94 v_accvgpr copies per tile.  The d = 40 forward is
 // VALU-bound on this chip: 32 v_exp_f32 (quarter rate) + ~65 other VALU per 14 MFMAs, against the ~4 VALU a 32x32x16 MFMA can hide.
-// Default: the pipelined VGPR form where it measured faster (head dim 64 / 80, key streams of >= 8 tiles), the first kernel elsewhere.
+// After the second pass (packed fma in the softmax: 81 instead of 95 VALU per d = 40 body; V^T reads streamed with the MFMA groups at
+// d = 80; profiles/r03_e_attention_fwd_variants.txt): d = 40 x0.99-1.00, d = 80 x1.11, d = 64 x1.01 (L 4096) / x1.05 (L 4250) / x0.98 (L 1024).
+// Default: the pipelined VGPR form where it measured faster (d = 80 from 8 key tiles, d = 64 from 32 key tiles), the first kernel elsewhere.
 static int g_attn_fwd_variant = -1;
 extern "C" void pcm_debug_attn_fwd_variant(int v) { g_attn_fwd_variant = v; }
 extern "C" int pcm_debug_attn_fwd_variant_get() { return g_attn_fwd_variant; }
@@ -309,7 +311,7 @@ extern "C" int pcm_debug_attn_fwd_variant_get() { return g_attn_fwd_variant; }
 bool pcm_attn_fwd_pipe_launch(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int Lq, int Lk, int d, int ldq,
                               int ldk, int ldo, float scale, void* stream) {
   int var = g_attn_fwd_variant;
-  if (var < 0) var = ((d == 64 || d == 80) && Lk >= 512) ? 1 : 0;
+  if (var < 0) var = ((d == 80 && Lk >= 512) || (d == 64 && Lk >= 2048)) ? 1 : 0;
   if (var < 1 || var > 3 || d > 80) return false;
   dim3 grid((Lq + 127) / 128, H, B), block(256);
 #define PIPE_CALL(DD, AGF, WPS)                                                                                                     \
