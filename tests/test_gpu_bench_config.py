@@ -40,6 +40,28 @@ def sd15():
     return cfg, W
 
 
+def assert_grads_match_per_module(lora, grads_a, grads_b, tol_all=1e-5, tol_mod=2e-4):
+    """graph replay vs eager launches run the same kernels in the same order: the LoRA gradient buffers may differ only by the order of
+    fp32 atomics.  Checked on the whole flat buffer AND per LoRA module (a corrupted module -- the round-2 hipMemset-node bug hit
+    time_emb_proj only -- hides under a whole-buffer norm), relative to the module's own gradient norm."""
+    assert rel(grads_a, grads_b) < tol_all, rel(grads_a, grads_b)
+    base = lora.grads.data_ptr()
+    worst = (0.0, None)
+    for path, m in lora.modules.items():
+        for t in (m.gA, m.gB):
+            o0 = (t.data_ptr() - base) // 4
+            a, b = grads_a[o0:o0 + t.numel()].double(), grads_b[o0:o0 + t.numel()].double()
+            nb = float(b.norm())
+            if nb == 0.0:
+                assert float(a.norm()) == 0.0, path
+                continue
+            r = float((a - b).norm()) / nb
+            if r > worst[0]:
+                worst = (r, path)
+    assert worst[0] < tol_mod, worst
+    return worst
+
+
 def test_graph_replay_equals_eager_bs16_and_batch_split(sd15):
     from pcm_amd.model import LoraState
     from pcm_amd.trainer import Distiller, StepConfig
@@ -67,7 +89,8 @@ def test_graph_replay_equals_eager_bs16_and_batch_split(sd15):
     rep = {"loss_eager": loss_e, "loss_graph": loss_g, "loss_rel": abs(loss_g - loss_e) / abs(loss_e),
            "grad_rel_graph_vs_eager": rel(grads_g, grads_e), "eps_rel_graph_vs_eager": rel(D._static_out["noise_pred"], eps_e)}
     # same kernels, same launch order; the only freedom is the order of fp32 / fp64 atomics (LoRA wgrad, GroupNorm statistics)
-    assert rep["loss_rel"] < 1e-5 and rep["eps_rel_graph_vs_eager"] < 1e-3 and rep["grad_rel_graph_vs_eager"] < 2e-3, rep
+    assert rep["loss_rel"] < 1e-6 and rep["eps_rel_graph_vs_eager"] < 1e-6 and rep["grad_rel_graph_vs_eager"] < 1e-5, rep   # measured: 0, 0, 1.1e-7
+    rep["worst_module_grad_rel"] = assert_grads_match_per_module(lora, grads_g, grads_e)
     # one whole optimizer step through both paths from the same state
     p0 = [t.clone() for t in (lora.params, lora.exp_avg, lora.exp_avg_sq, D.step_dev)]
     D.step(**inp)
@@ -144,7 +167,7 @@ def test_split_graph_capture_equals_eager(monkeypatch):
         restore()
         D.step_graphed(**inp)
         torch.cuda.synchronize()
-        assert rel(lora.grads, ge) < 1e-4, (rep_i, rel(lora.grads, ge))
+        assert_grads_match_per_module(lora, lora.grads, ge)
         ue, ug = (pe - p0[0]).double(), (lora.params - p0[0]).double()
         assert float((ue * ug).sum() / (ue.norm() * ug.norm())) > 0.9999, rep_i
 

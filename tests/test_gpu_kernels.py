@@ -88,6 +88,20 @@ def test_attention(B, H, Lq, Lk, d, spike):
     K.case_attention("cuda", B, H, Lq, Lk, d, spike)
 
 
+@pytest.mark.parametrize("B,H,Lq,Lk,d,at", [(2, 8, 1024, 1024, 80, (300, 700)), (1, 8, 4096, 4096, 40, (1000, 3000)), (1, 10, 2176, 2176, 64, (64, 2100)),
+                                            (1, 2, 200, 77, 40, None), (1, 4, 333, 1000, 32, (500,))])
+def test_attention_pipelined_forward(B, H, Lq, Lk, d, at):
+    """the software-pipelined forward (attention_fwd.hip) FORCED on every head dim it is built for, incl. shapes the by-shape default would
+    give to the first kernel: long streams with reference moves inside the steady-state loop, a two-tile stream, ragged tails"""
+    from pcm_amd import capi
+    dll = capi.lib().dll
+    dll.pcm_debug_attn_fwd_variant(1)
+    try:
+        K.case_attention("cuda", B, H, Lq, Lk, d, spike=True, spike_at=at)
+    finally:
+        dll.pcm_debug_attn_fwd_variant(-1)
+
+
 def test_lora_repack():
     K.case_lora_repack("cuda")
 
