@@ -201,9 +201,11 @@ def test_loss_curve_20_steps_vs_oracle():
         inp = OS.draw_inputs(4, ocfg, seed=1000 + step, latent_hw=16, ctx_len=77, ctx_dim=64)
         with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
             l16 = float(OS.distill_step_forward(oc, sd, olora, inp, ocfg)["loss"])
-        with torch.no_grad():     # the rounding-point-matched oracle (bf16 storage, fp32 / fp64 arithmetic) on the same parameters
-            lm = float(OS.distill_step_forward(oc, sd, olora, inp, ocfg, storage="bf16")["loss"])
-            lm64 = float(OS.distill_step_forward(oc, sd, olora, inp, ocfg, storage="bf16", compute=torch.float64)["loss"])
+        with torch.no_grad():     # the rounding-point-matched oracle (bf16 storage, fp32 arithmetic) on the same parameters; its own
+            lm = float(OS.distill_step_forward(oc, sd, olora, inp, ocfg, storage="bf16")["loss"])      # fp64-arithmetic floor on 3 of the
+            lm64 = lm                                                                                   # 20 steps (fp64 convs are slow on CPU)
+            if step in (1, 10, 20):
+                lm64 = float(OS.distill_step_forward(oc, sd, olora, inp, ocfg, storage="bf16", compute=torch.float64)["loss"])
         ref = OS.distill_step(oc, sd, olora, inp, ocfg, state, step)          # fp32; updates olora in place
         dev = {k: v.cuda() for k, v in inp.items()}
         out = D.step(dev["latents"], dev["prompt_embeds"], dev["uncond_prompt_embeds"], dev["noise"], dev["index"], dev["w"])
@@ -222,7 +224,7 @@ def test_loss_curve_20_steps_vs_oracle():
     flat_h = torch.cat([torch.cat([lora.A_peft(m).detach().cpu().reshape(-1), m.B.detach().cpu().reshape(-1)]) for m in lora.modules.values()])
     flat_o = torch.cat([torch.cat([a.reshape(-1), b.reshape(-1)]) for a, b in olora.values()])
     mm = sum(abs(r["hip_vs_matched"]) for r in rows) / len(rows)
-    mfl = sum(abs(r["matched_floor"]) for r in rows) / len(rows)
+    mfl = sum(abs(r["matched_floor"]) for r in rows if r["step"] in (1, 10, 20)) / 3
     rep = dict(mean_abs_rel_hip=mh, mean_abs_rel_ref_bf16_autocast=m16, first5=first, last5=last, max_abs_rel_hip=max(abs(r["hip_rel"]) for r in rows),
                mean_abs_rel_hip_vs_matched_oracle=mm, mean_abs_rel_matched_oracle_fp64_vs_fp32=mfl,
                mean_signed_rel_hip_vs_matched_oracle=sum(r["hip_vs_matched"] for r in rows) / len(rows),
