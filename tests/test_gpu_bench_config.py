@@ -201,11 +201,19 @@ def test_loss_curve_20_steps_vs_oracle():
         inp = OS.draw_inputs(4, ocfg, seed=1000 + step, latent_hw=16, ctx_len=77, ctx_dim=64)
         with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
             l16 = float(OS.distill_step_forward(oc, sd, olora, inp, ocfg)["loss"])
-        with torch.no_grad():     # the rounding-point-matched oracle (bf16 storage, fp32 arithmetic) on the same parameters; its own
-            lm = float(OS.distill_step_forward(oc, sd, olora, inp, ocfg, storage="bf16")["loss"])      # fp64-arithmetic floor on 3 of the
-            lm64 = lm                                                                                   # 20 steps (fp64 convs are slow on CPU)
-            if step in (1, 10, 20):
-                lm64 = float(OS.distill_step_forward(oc, sd, olora, inp, ocfg, storage="bf16", compute=torch.float64)["loss"])
+        # the rounding-point-matched oracle (bf16 storage, fp32 arithmetic) on the same parameters; its own fp64-arithmetic floor on 3 of the
+        # 20 steps.  This narrow model is thousands of tiny CPU ops per forward (one bf16 round trip per stored tensor): with the GPU box's
+        # 128 torch threads each of them pays a thread-pool hand-shake (measured 14 s per forward there against 0.5 s on 8 threads)
+        nthr = torch.get_num_threads()
+        torch.set_num_threads(min(nthr, 8))
+        try:
+            with torch.no_grad():
+                lm = float(OS.distill_step_forward(oc, sd, olora, inp, ocfg, storage="bf16")["loss"])
+                lm64 = lm
+                if step in (1, 10, 20):
+                    lm64 = float(OS.distill_step_forward(oc, sd, olora, inp, ocfg, storage="bf16", compute=torch.float64)["loss"])
+        finally:
+            torch.set_num_threads(nthr)
         ref = OS.distill_step(oc, sd, olora, inp, ocfg, state, step)          # fp32; updates olora in place
         dev = {k: v.cuda() for k, v in inp.items()}
         out = D.step(dev["latents"], dev["prompt_embeds"], dev["uncond_prompt_embeds"], dev["noise"], dev["index"], dev["w"])
