@@ -172,7 +172,7 @@ def test_split_graph_capture_equals_eager(monkeypatch):
         assert float((ue * ug).sum() / (ue.norm() * ug.norm())) > 0.9999, rep_i
 
 
-def test_loss_curve_20_steps_vs_oracle():
+def test_loss_curve_20_steps_vs_oracle(request):
     """north_star: 'loss curves matching reference to 1e-3 rel'.  The reference trains under bf16/fp16 autocast; the yardstick is
     therefore measured, not assumed: the same 20 steps are evaluated by the fp32 oracle, by the oracle under bfloat16 autocast (the
     reference's arithmetic) and by the HIP path.  Asserted: (1) the HIP curve is as close to fp32 as the reference's own bf16 curve
@@ -197,23 +197,19 @@ def test_loss_curve_20_steps_vs_oracle():
     D = Distiller(W, lora, cfg)
     state = {}
     rows = []
+    # this narrow model is thousands of tiny CPU ops per oracle forward: with the GPU box's 128 torch threads every one of them pays a
+    # thread-pool hand-shake (measured 14 s per matched-oracle forward there against 0.5 s on 8 threads)
+    request.addfinalizer(lambda n=torch.get_num_threads(): torch.set_num_threads(n))
+    torch.set_num_threads(min(torch.get_num_threads(), 8))
     for step in range(1, 21):
         inp = OS.draw_inputs(4, ocfg, seed=1000 + step, latent_hw=16, ctx_len=77, ctx_dim=64)
         with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
             l16 = float(OS.distill_step_forward(oc, sd, olora, inp, ocfg)["loss"])
-        # the rounding-point-matched oracle (bf16 storage, fp32 arithmetic) on the same parameters; its own fp64-arithmetic floor on 3 of the
-        # 20 steps.  This narrow model is thousands of tiny CPU ops per forward (one bf16 round trip per stored tensor): with the GPU box's
-        # 128 torch threads each of them pays a thread-pool hand-shake (measured 14 s per forward there against 0.5 s on 8 threads)
-        nthr = torch.get_num_threads()
-        torch.set_num_threads(min(nthr, 8))
-        try:
-            with torch.no_grad():
-                lm = float(OS.distill_step_forward(oc, sd, olora, inp, ocfg, storage="bf16")["loss"])
-                lm64 = lm
-                if step in (1, 10, 20):
-                    lm64 = float(OS.distill_step_forward(oc, sd, olora, inp, ocfg, storage="bf16", compute=torch.float64)["loss"])
-        finally:
-            torch.set_num_threads(nthr)
+        with torch.no_grad():     # the rounding-point-matched oracle (bf16 storage, fp32 arithmetic) on the same parameters; its own
+            lm = float(OS.distill_step_forward(oc, sd, olora, inp, ocfg, storage="bf16")["loss"])      # fp64-arithmetic floor on 3 of the
+            lm64 = lm                                                                                   # 20 steps
+            if step in (1, 10, 20):
+                lm64 = float(OS.distill_step_forward(oc, sd, olora, inp, ocfg, storage="bf16", compute=torch.float64)["loss"])
         ref = OS.distill_step(oc, sd, olora, inp, ocfg, state, step)          # fp32; updates olora in place
         dev = {k: v.cuda() for k, v in inp.items()}
         out = D.step(dev["latents"], dev["prompt_embeds"], dev["uncond_prompt_embeds"], dev["noise"], dev["index"], dev["w"])
