@@ -142,8 +142,10 @@ def case_blocks(dev, kw, B, H, ctx_len, level=0, report=None):
     return rep
 
 
-def case_step_floor(dev, kw, B, hw, ctx_dim, index=None, report=None, seed=453645634, with_fp32=True):
-    """Forward of one distillation step: HIP vs the matched oracle, with the yardstick measured on the oracle itself."""
+def case_step_floor(dev, kw, B, hw, ctx_dim, index=None, report=None, seed=453645634, with_fp32=True, with_grads=False):
+    """Forward of one distillation step: HIP vs the matched oracle, with the yardstick measured on the oracle itself.
+    ``with_grads``: also the LoRA gradients (the matched oracle rounds the cotangent of every bf16-stored tensor to bf16 as well) -- the
+    same three-way comparison on the flat gradient vector (narrow configs only: two more oracle backward passes)."""
     from oracle import pcm_step as OS
     from pcm_amd.trainer import Distiller, StepConfig
     O, oc, pc, sd, W, lora, olora = _setup(dev, kw)
@@ -160,11 +162,24 @@ def case_step_floor(dev, kw, B, hw, ctx_dim, index=None, report=None, seed=45364
     d = {k: v.to(dev) for k, v in inp.items()}
     out = D.forward_backward(d["latents"], d["prompt_embeds"], d["uncond_prompt_embeds"], d["noise"], d["index"], d["w"], backward=False)
     keys = ("noise_pred", "cond_teacher_output", "target_noise_pred", "x_prev", "model_pred", "target")
-    rep = {"hip_vs_matched": {k: rel(out[k], m32[k]) for k in keys}, "floor_matched_fp64_vs_fp32": {k: rel(m64[k], m32[k]) for k in keys},
-           "hip_vs_fp32": {k: rel(out[k], f32[k]) for k in keys}, "matched_vs_fp32": {k: rel(m32[k], f32[k]) for k in keys}}
-    lh, l32, l64, lf = float(out["loss"]), float(m32["loss"]), float(m64["loss"]), float(f32["loss"])
-    rep["loss"] = dict(hip=lh, matched=l32, matched_fp64=l64, fp32=lf, hip_vs_matched=abs(lh - l32) / l32, floor=abs(l64 - l32) / l32,
-                       hip_vs_fp32=abs(lh - lf) / lf, matched_vs_fp32=abs(l32 - lf) / lf)
+    rep = {"hip_vs_matched": {k: rel(out[k], m32[k]) for k in keys}, "floor_matched_fp64_vs_fp32": {k: rel(m64[k], m32[k]) for k in keys}}
+    lh, l32, l64 = float(out["loss"]), float(m32["loss"]), float(m64["loss"])
+    rep["loss"] = dict(hip=lh, matched=l32, matched_fp64=l64, hip_vs_matched=abs(lh - l32) / l32, floor=abs(l64 - l32) / l32)
+    if with_fp32:
+        lf = float(f32["loss"])
+        rep["hip_vs_fp32"] = {k: rel(out[k], f32[k]) for k in keys}
+        rep["matched_vs_fp32"] = {k: rel(m32[k], f32[k]) for k in keys}
+        rep["loss"].update(fp32=lf, hip_vs_fp32=abs(lh - lf) / lf, matched_vs_fp32=abs(l32 - lf) / lf)
+    if with_grads:
+        def oracle_grads(**kw_):
+            ol = {p_: (a.clone().requires_grad_(True), b.clone().requires_grad_(True)) for p_, (a, b) in olora.items()}
+            OS.distill_step_forward(oc, sd, ol, inp, ocfg, **kw_)["loss"].backward()
+            return torch.cat([t.grad.reshape(-1) for p_ in lora.modules for t in ol[p_]])
+        gm, gm64, g32 = oracle_grads(storage="bf16"), oracle_grads(storage="bf16", compute=torch.float64), oracle_grads()
+        lora.zero_grad()
+        D.forward_backward(d["latents"], d["prompt_embeds"], d["uncond_prompt_embeds"], d["noise"], d["index"], d["w"])
+        mine = torch.cat([t.reshape(-1).cpu() for m in lora.modules.values() for t in (lora.gA_peft(m), m.gB)])
+        rep["lora_grad"] = dict(hip_vs_matched=rel(mine, gm), floor=rel(gm64, gm), hip_vs_fp32=rel(mine, g32), matched_vs_fp32=rel(gm, g32))
     if report is not None:
         report.update(rep)
     for k, v in rep.items():
