@@ -358,9 +358,9 @@ struct GemmPlan { int BM, BN, tiles_m, tiles_n, splitk, kt_per_split; size_t ws_
 static int g_force_bm = 0, g_force_bn = 0;
 static int g_big_mode = -1;   // -1: read PCM_GEMM_BIG once (0 = never use gemm8p, 1 = planner, 2 = wherever eligible); tuning only
 extern "C" void pcm_debug_gemm_big_mode(int mode) { g_big_mode = mode; }
-static int g_conv_co = -1, g_conv_md = -1;    // -1: PCM_GEMM_CONV_CO / PCM_GEMM_CONV_MD env; both default 0 (measured slower: gemm8p.hip)
-extern "C" void pcm_debug_gemm_conv_order(int chunk_outer) { g_conv_co = chunk_outer ? 1 : 0; }
-extern "C" void pcm_debug_gemm_conv_md(int mask_delta) { g_conv_md = mask_delta ? 1 : 0; }
+static int g_conv_co = -1, g_conv_md = -1;    // -1: PCM_GEMM_CONV_CO / PCM_GEMM_CONV_MD env if set, else the by-shape choice of the gemm8p launcher
+extern "C" void pcm_debug_gemm_conv_order(int chunk_outer) { g_conv_co = chunk_outer < 0 ? -1 : (chunk_outer ? 1 : 0); }   // -1: back to by-shape
+extern "C" void pcm_debug_gemm_conv_md(int mask_delta) { g_conv_md = mask_delta < 0 ? -1 : (mask_delta ? 1 : 0); }
 static int g_ablate = 0;      // see PCM_ABL in gemm_dev.h (no effect in the product build)
 extern "C" void pcm_debug_gemm_ablate(int mask) { g_ablate = mask; }
 static int g_last_plan = 0;   // tests only: 1000*big_fn + splitk of the most recent pcm_gemm_bf16 launch
@@ -503,9 +503,12 @@ extern "C" int pcm_gemm_bf16(const pcm_gemm_seg* segs, int nseg, const pcm_gemm_
   g.res = (const bf16_t*)e->residual; g.ldr = e->ldr; g.out = e->out; g.ldo = e->ldo;
   g.out_f32 = e->out_dtype == PCM_F32; g.act = e->act; g.alpha = e->alpha; g.dbg = g_ablate;
   g.pre_out = (bf16_t*)e->pre_out; g.pre_rows = e->pre_out ? e->pre_rows : 0; g.ldp = e->ldp;
-  if (g_conv_co < 0) { const char* ev = getenv("PCM_GEMM_CONV_CO"); g_conv_co = ev ? atoi(ev) : 0; }
-  if (g_conv_md < 0) { const char* ev = getenv("PCM_GEMM_CONV_MD"); g_conv_md = ev ? atoi(ev) : 0; }
-  g.conv_co = g_conv_co; g.conv_md = g_conv_md || g_conv_co;
+  // conv addressing / K order: explicit choice through the env / debug hooks, otherwise by shape (gemm8p.hip launcher)
+  int cco = g_conv_co, cmd = g_conv_md;
+  if (cco < 0 && getenv("PCM_GEMM_CONV_CO")) cco = atoi(getenv("PCM_GEMM_CONV_CO")) ? 1 : 0;
+  if (cmd < 0 && getenv("PCM_GEMM_CONV_MD")) cmd = atoi(getenv("PCM_GEMM_CONV_MD")) ? 1 : 0;
+  g.conv_auto = cco < 0 && cmd < 0;
+  g.conv_co = cco > 0; g.conv_md = cmd > 0 || cco > 0;
   if (e->N == 64 && nseg == 1 && segs[0].mode == PCM_SEG_CONV3X3) {   // conv LoRA down-projection: halo-window kernel where the geometry allows
     const int rc = pcm_conv_r64_launch(g, stream);
     if (rc < 0) return rc;

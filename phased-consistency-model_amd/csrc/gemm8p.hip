@@ -479,8 +479,12 @@ __global__ __launch_bounds__(512) void pcm_gemm8p_kernel(GemmDev g) {
 
 size_t pcm_gemm8p_lds_bytes(int fn) { return 2 * (size_t)(256 + 64 * fn) * 128; }
 
+static int g_last_8p_variant = -1;      // of the last launch: bit 0 = mask + delta addressing, bit 1 = chunk-outer K order (tests read it)
+extern "C" int pcm_debug_last_gemm8p_variant() { return g_last_8p_variant; }
+
 template <int F0, bool MD, bool CO>
 static int launch8p(const GemmDev& g, void* stream) {
+  g_last_8p_variant = (MD ? 1 : 0) | (CO ? 2 : 0);
   const size_t smem = pcm_gemm8p_lds_bytes(F0 + 2);
   dim3 grid(g.tiles_m * g.tiles_n, g.splitk);
   static bool lds_ok = false;
@@ -500,6 +504,17 @@ int pcm_gemm8p_launch(const GemmDev& g, int fn, void* stream) {
       if (g.seg[i].mode == PCM_SEG_CONV3X3) md = true;
     for (int i = 0; i < g.nseg; i++)
       if (g.seg[i].mode == PCM_SEG_CONV3X3 && (g.seg[i].stride != 1 || g.seg[i].src_mode != PCM_SRC_DIRECT)) md = false;
+  }
+  // by shape (conv_co / conv_md unset = -1 -> 0 here): the chunk-outer order only pays on 8x8 feature maps, where a tile spans four images
+  // and the tap-outer re-key runs every K-tile anyway (profiles/r02_e_gemm8p_conv_variants_ab.txt: x1.12 at 8x8, x0.82-0.95 elsewhere)
+  if (!g.conv_md && g.conv_auto) {
+    bool small = false, all_direct = true;
+    for (int i = 0; i < g.nseg; i++)
+      if (g.seg[i].mode == PCM_SEG_CONV3X3) {
+        if (g.seg[i].stride != 1 || g.seg[i].src_mode != PCM_SRC_DIRECT) all_direct = false;
+        else if (g.seg[i].Hs * g.seg[i].Ws <= 64) small = true;
+      }
+    if (small && all_direct) return fn == 5 ? launch8p<3, true, true>(g, stream) : launch8p<2, true, true>(g, stream);
   }
   const bool co = md && g.conv_co;
   if (fn == 5) return co ? launch8p<3, true, true>(g, stream) : (md ? launch8p<3, true, false>(g, stream) : launch8p<3, false, false>(g, stream));

@@ -555,9 +555,11 @@ def case_gemm_big(dev, which):
             stride, src_mode, lora = {"conv": (1, capi.SRC_DIRECT, "plain"), "conv_s2": (2, capi.SRC_DIRECT, None),
                                       "conv_up": (1, capi.SRC_UPSAMPLE2, "plain"), "conv_zi": (1, capi.SRC_ZEROINS2, None),
                                       "conv_conv": (1, capi.SRC_DIRECT, "conv"), "conv_splitk": (1, capi.SRC_DIRECT, "plain"),
-                                      "conv_persist": (1, capi.SRC_DIRECT, "plain")}[which]
-            Hs = {"conv": 16, "conv_s2": 32, "conv_up": 8, "conv_zi": 8, "conv_conv": 16, "conv_splitk": 16, "conv_persist": 16}[which]
+                                      "conv_persist": (1, capi.SRC_DIRECT, "plain"), "conv_small_map": (1, capi.SRC_DIRECT, "conv")}[which]
+            Hs = {"conv": 16, "conv_s2": 32, "conv_up": 8, "conv_zi": 8, "conv_conv": 16, "conv_splitk": 16, "conv_persist": 16, "conv_small_map": 8}[which]
             B, Ci, Co = (1, 256, 320) if which == "conv_splitk" else (2, 128 if which == "conv" else 64, 320)
+            if which == "conv_small_map":      # 8x8 feature maps, five images per 256-row tile and a ragged last tile: the by-shape chunk-outer order
+                B, Ci, Co = 5, 128, 320
             if which == "conv_persist":
                 B, Ci, Co = (9, 64, 640) if dev == "cpu" else (300, 64, 640)
             x = rnd(B, Hs, Hs, Ci, seed=7)
@@ -599,7 +601,7 @@ def case_gemm_big(dev, which):
     return float((err - tol).max()), float(err.max())
 
 
-GEMM_BIG_CASES = ["plain_lora", "ragged", "two_tiles_k", "splitk", "conv", "conv_s2", "conv_up", "conv_zi", "conv_conv", "conv_splitk", "persist", "persist_splitk", "conv_persist"]
+GEMM_BIG_CASES = ["plain_lora", "ragged", "two_tiles_k", "splitk", "conv", "conv_s2", "conv_up", "conv_zi", "conv_conv", "conv_splitk", "persist", "persist_splitk", "conv_persist", "conv_small_map"]
 
 
 def case_gemm_n64(dev, M, K):

@@ -31,7 +31,7 @@ for (M, N, Ci, Hs, lora) in shapes:
         dll.pcm_debug_gemm_conv_md(md); dll.pcm_debug_gemm_conv_order(co)
         f = lambda: ops.gemm(segs, M, N, o, Ho=Hs, Wo=Hs)
         res.append((bench(f, cold=True), bench(f, cold=False)))
-    dll.pcm_debug_gemm_conv_md(0); dll.pcm_debug_gemm_conv_order(0)
+    dll.pcm_debug_gemm_conv_md(-1); dll.pcm_debug_gemm_conv_order(-1)
     print("M=%6d N=%4d Ci=%4d %dx%d | re-key tap-outer %7.1f us %6.0f TF/s (warm %7.1f) | mask+delta tap-outer %7.1f us %6.0f TF/s (warm %7.1f) x%.3f | chunk-outer %7.1f us %6.0f TF/s x%.3f" % (
         M, N, Ci, Hs, Hs, res[0][0] * 1e3, fl / res[0][0] / 1e9, res[0][1] * 1e3, res[1][0] * 1e3, fl / res[1][0] / 1e9, res[1][1] * 1e3, res[0][0] / res[1][0],
         res[2][0] * 1e3, fl / res[2][0] / 1e9, res[0][0] / res[2][0]), flush=True)
