@@ -358,8 +358,8 @@ struct GemmPlan { int BM, BN, tiles_m, tiles_n, splitk, kt_per_split; size_t ws_
 static int g_force_bm = 0, g_force_bn = 0;
 static int g_big_mode = -1;   // -1: read PCM_GEMM_BIG once (0 = never use gemm8p, 1 = planner, 2 = wherever eligible); tuning only
 extern "C" void pcm_debug_gemm_big_mode(int mode) { g_big_mode = mode; }
-static int g_conv_co = -1, g_conv_md = -1;    // -1: PCM_GEMM_CONV_CO / PCM_GEMM_CONV_MD env if set, else the by-shape choice of the gemm8p launcher
-extern "C" void pcm_debug_gemm_conv_order(int chunk_outer) { g_conv_co = chunk_outer < 0 ? -1 : (chunk_outer ? 1 : 0); }   // -1: back to by-shape
+static int g_conv_co = -1, g_conv_md = -1;    // -1: PCM_GEMM_CONV_CO / PCM_GEMM_CONV_MD env if set, else 0 (the shipped tap-outer / re-key path)
+extern "C" void pcm_debug_gemm_conv_order(int chunk_outer) { g_conv_co = chunk_outer < 0 ? -1 : (chunk_outer > 1 ? 2 : (chunk_outer ? 1 : 0)); }   // -1: default; 2: by shape
 extern "C" void pcm_debug_gemm_conv_md(int mask_delta) { g_conv_md = mask_delta < 0 ? -1 : (mask_delta ? 1 : 0); }
 static int g_ablate = 0;      // see PCM_ABL in gemm_dev.h (no effect in the product build)
 extern "C" void pcm_debug_gemm_ablate(int mask) { g_ablate = mask; }
@@ -504,11 +504,14 @@ extern "C" int pcm_gemm_bf16(const pcm_gemm_seg* segs, int nseg, const pcm_gemm_
   g.out_f32 = e->out_dtype == PCM_F32; g.act = e->act; g.alpha = e->alpha; g.dbg = g_ablate;
   g.pre_out = (bf16_t*)e->pre_out; g.pre_rows = e->pre_out ? e->pre_rows : 0; g.ldp = e->ldp;
   // conv addressing / K order: explicit choice through the env / debug hooks, otherwise by shape (gemm8p.hip launcher)
+  // default: the tap-outer order with the per-tap re-key everywhere.  PCM_GEMM_CONV_CO=2 / pcm_debug_gemm_conv_order(2) = chunk-outer BY SHAPE
+  // (8x8 maps only): x1.12 on that launch alone with cold operands (round 2), but 117.5-117.7 vs 117.2-117.3 ms per bs-16 step in the
+  // interleaved A/B of round 3 (profiles/r03_k_conv_order_by_shape_ab.txt) -- not taken.
   int cco = g_conv_co, cmd = g_conv_md;
-  if (cco < 0 && getenv("PCM_GEMM_CONV_CO")) cco = atoi(getenv("PCM_GEMM_CONV_CO")) ? 1 : 0;
+  if (cco < 0 && getenv("PCM_GEMM_CONV_CO")) cco = atoi(getenv("PCM_GEMM_CONV_CO"));
   if (cmd < 0 && getenv("PCM_GEMM_CONV_MD")) cmd = atoi(getenv("PCM_GEMM_CONV_MD")) ? 1 : 0;
-  g.conv_auto = cco < 0 && cmd < 0;
-  g.conv_co = cco > 0; g.conv_md = cmd > 0 || cco > 0;
+  g.conv_auto = cco == 2;
+  g.conv_co = cco == 1; g.conv_md = cmd > 0 || cco == 1;
   if (e->N == 64 && nseg == 1 && segs[0].mode == PCM_SEG_CONV3X3) {   // conv LoRA down-projection: halo-window kernel where the geometry allows
     const int rc = pcm_conv_r64_launch(g, stream);
     if (rc < 0) return rc;

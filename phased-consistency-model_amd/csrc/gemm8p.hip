@@ -505,8 +505,8 @@ int pcm_gemm8p_launch(const GemmDev& g, int fn, void* stream) {
     for (int i = 0; i < g.nseg; i++)
       if (g.seg[i].mode == PCM_SEG_CONV3X3 && (g.seg[i].stride != 1 || g.seg[i].src_mode != PCM_SRC_DIRECT)) md = false;
   }
-  // by shape (conv_co / conv_md unset = -1 -> 0 here): the chunk-outer order only pays on 8x8 feature maps, where a tile spans four images
-  // and the tap-outer re-key runs every K-tile anyway (profiles/r02_e_gemm8p_conv_variants_ab.txt: x1.12 at 8x8, x0.82-0.95 elsewhere)
+  // by shape (opt-in, conv order hook / env = 2): chunk-outer only on 8x8 feature maps, where a tile spans four images and the tap-outer
+  // re-key runs every K-tile anyway (x1.12 on that launch in isolation, profiles/r02_e_*; no gain on the whole step, profiles/r03_k_*)
   if (!g.conv_md && g.conv_auto) {
     bool small = false, all_direct = true;
     for (int i = 0; i < g.nseg; i++)

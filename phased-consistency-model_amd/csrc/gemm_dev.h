@@ -22,7 +22,7 @@ struct GemmDev {
   int splitk, kt_per_split;   // split-K: blockIdx.y = K slice; raw fp32 partial tiles go to slab ws[slice][M][N]
   float* ws;
   int conv_md, conv_co;       // gemm8p.hip address-path / K-order variants of the stride-1 direct 3x3 view (A/B hooks; defaults 0, 0)
-  int conv_auto;              // no explicit choice was made: the gemm8p launcher picks by shape (chunk-outer on 8x8 feature maps)
+  int conv_auto;              // opt-in: the gemm8p launcher picks the K order by shape (chunk-outer on 8x8 feature maps)
   bf16_t* pre_out;            // PCM_ACT_GEGLU: optional second output, the interleaved pre-activation of rows < pre_rows (row stride ldp)
   int pre_rows, ldp;
   int dbg;                    // ablation mask: only read by -DPCM_ABLATE builds (tools/probes/build_ablate.py), 0 otherwise

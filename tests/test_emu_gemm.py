@@ -121,17 +121,21 @@ def test_big_tile_conv_address_variants(which, md, co):
 
 
 def test_big_tile_conv_order_by_shape():
-    """with no explicit choice the gemm8p launcher takes the chunk-outer K order on feature maps of at most 8x8 (measured x1.12 there, slower
-    elsewhere) and the tap-outer order otherwise: same results either way, and the plan it took is visible"""
+    """conv order 2 = by shape: the gemm8p launcher takes the chunk-outer K order on feature maps of at most 8x8 and the tap-outer order
+    otherwise (an opt-in: the whole-step A/B of round 3 showed no gain); the default (-1) is tap-outer everywhere.  Same results either way."""
     import kernel_cases as KC
     from pcm_amd import capi
     dll = capi.lib().dll
     dll.pcm_debug_gemm_conv_md(-1)
-    dll.pcm_debug_gemm_conv_order(-1)
-    for which, variant in (("conv", 0), ("conv_small_map", 3)):
-        excess, err = KC.case_gemm_big("cpu", which)
-        assert excess <= 0, (which, err)
-        assert dll.pcm_debug_last_gemm8p_variant() == variant, (which, dll.pcm_debug_last_gemm8p_variant())
+    try:
+        for order, expect in ((2, {"conv": 0, "conv_small_map": 3}), (-1, {"conv": 0, "conv_small_map": 0})):
+            dll.pcm_debug_gemm_conv_order(order)
+            for which, variant in expect.items():
+                excess, err = KC.case_gemm_big("cpu", which)
+                assert excess <= 0, (which, err)
+                assert dll.pcm_debug_last_gemm8p_variant() == variant, (order, which, dll.pcm_debug_last_gemm8p_variant())
+    finally:
+        dll.pcm_debug_gemm_conv_order(-1)
 
 
 @pytest.mark.parametrize("M,K", [(200, 320), (64, 1280), (130, 768), (77, 192), (40, 640), (33, 2560), (20, 960)])
