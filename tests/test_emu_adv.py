@@ -133,3 +133,72 @@ def test_adv_step_four_heads_per_tap_real_learning_rates(global_step):
     else:
         assert rep["loss_cm_rel"] < 2e-2 and rep["g_loss_rel"] < 5e-3 and rep["heads_untouched"]
         assert rep["lora_grad_cos"] > 0.95 and rep["lora_update_cos"] > 0.8 and abs(rep["lora_update_norm_ratio"] - 1) < 1e-2
+
+
+@pytest.mark.slow
+def test_segmented_capture_cuts_at_every_collective(monkeypatch):
+    """AdvDistiller.capture_adv at world_size > 1 cuts the captured step where the eager path issues a collective (trainer.SegmentedGraph /
+    Distiller._collective).  With a recording stand-in for torch.cuda.CUDAGraph the cut placement is checked on the CPU: the D step of a
+    5-tap discriminator becomes graph, [bucket all-reduce, graph] x 5, [wait for the buckets], graph; the G step graph, [LoRA exchange],
+    graph -- and nothing communicates while capturing."""
+    from oracle import pcm_step as OS
+    from oracle import unet_sd15 as O
+    from pcm_amd import trainer as T
+    from pcm_amd.discriminator import Discriminator
+    from pcm_amd.model import LoraState, UNetWeights
+    from pcm_amd.unet_spec import UNetConfig
+
+    class FakeGraph:
+        def __init__(self):
+            self.log = []
+
+        def capture_begin(self, **kw):
+            self.log.append(("begin", kw.get("pool")))
+
+        def capture_end(self):
+            self.log.append(("end", None))
+
+        def pool(self):
+            return "pool"
+
+        def replay(self):
+            self.log.append(("replay", None))
+    monkeypatch.setattr(torch.cuda, "CUDAGraph", FakeGraph)
+    monkeypatch.setattr(T, "SEG_FORCE", True)          # world_size 1: every collective is a no-op host action, the cuts are the same
+    kw = dict(block_out_channels=(64, 128), layers_per_block=1, cross_attention_dim=64, heads=2, norm_num_groups=32)
+    oc, pc = O.UNetConfig(**kw), UNetConfig(**kw)
+    W = UNetWeights(pc, O.init_state_dict(oc, 0), "cpu")
+    lora = LoraState(pc, 64, 8.0, "cpu", seed=1, b_std=0.05)
+    disc = Discriminator((64, 128, 128, 128, 64), num_h_per_head=2, device="cpu", seed=2)
+    D = T.AdvDistiller(W, lora, T.StepConfig(multiphase=2, loss_type="huber", w_min=4.0, w_max=5.0, learning_rate=1e-4), disc, adv_weight=0.1, adv_lr=1e-4)
+    ocfg = OS.StepConfig(multiphase=2, loss_type="huber", w_min=4.0, w_max=5.0)
+    inp = OS.draw_inputs(2, ocfg, seed=5, latent_hw=8, ctx_len=7, ctx_dim=64)
+    g = torch.Generator().manual_seed(9)
+    extra = [torch.randn(2, 4, 8, 8, generator=g), torch.randn(2, 4, 8, 8, generator=g), torch.rand(2, generator=g)]
+    args = [inp[k] for k in ("latents", "prompt_embeds", "uncond_prompt_embeds", "noise", "index", "w")] + extra
+    calls = []
+    monkeypatch.setattr(D, "_disc_bucket", lambda a, b: calls.append(("bucket", a, b)))
+    monkeypatch.setattr(D, "_disc_finish_exchange", lambda: calls.append(("finish",)))
+    monkeypatch.setattr(D, "all_reduce_grads", lambda: calls.append(("lora",)))
+    shapes = {}
+    for gs in (0, 1):
+        D._seg = seg = T.SegmentedGraph()
+        seg.begin()
+        D.step_adv(gs, *args)
+        seg.end()
+        D._seg = None
+        assert calls == [], "a collective ran during capture"
+        kinds = ["g" if isinstance(it, FakeGraph) else "h" for it in seg.items]
+        shapes[gs] = "".join(kinds)
+        assert all(it.log[0][0] == "begin" and it.log[-1][0] == "end" for it in seg.items if isinstance(it, FakeGraph))
+        assert [it.log[0][1] for it in seg.items if isinstance(it, FakeGraph)][1:] == ["pool"] * (kinds.count("g") - 1)   # one shared pool
+        seg.replay()
+        if gs == 0:
+            assert [c[0] for c in calls] == ["bucket"] * 5 + ["finish"], calls
+            offs = [(c[1], c[2]) for c in calls[:5]]
+            assert all(b > a for a, b in offs) and sorted(offs) == offs and offs[0][0] == 0 and offs[-1][1] <= disc.numel   # tap order, disjoint ranges
+        else:
+            assert calls == [("lora",)], calls
+        calls.clear()
+    assert shapes == {0: "g" + "hg" * 6, 1: "ghg"}, shapes
+    assert D.step_count == 0      # the captured pass does not advance the host-side step counter (step_adv_graphed does)
