@@ -125,14 +125,16 @@ def test_adv_step_four_heads_per_tap_real_learning_rates(global_step):
     updates with the oracle's clip + AdamW (tests/adv_cases.py; the full-size run is tests/test_gpu_adv.py)."""
     import adv_cases as A
     kw = dict(block_out_channels=(64, 128), layers_per_block=1, cross_attention_dim=64, heads=2, norm_num_groups=32)
-    rep = A.case_adv_c3("cpu", kw, (64, 128, 128, 128, 64), 2, 16, 7, 64, global_step)
+    rep = A.case_adv_c3("cpu", kw, (64, 128, 128, 128, 64), 2, 8, 7, 64, global_step)      # 8x8 latents: 17 s per step on the emulator
     assert rep["heads"] == 20 and rep["fake_adv"] < 5e-3
     if global_step % 2 == 0:
         assert rep["d_loss_rel"] < 5e-3 and rep["lora_untouched"] and rep["head_grad_cos"] > 0.99 and min(rep["head_grad_cos_per_tap"]) > 0.985
         assert rep["head_update_cos"] > 0.9 and abs(rep["head_update_norm_ratio"] - 1) < 1e-2
     else:
         assert rep["loss_cm_rel"] < 2e-2 and rep["g_loss_rel"] < 5e-3 and rep["heads_untouched"]
-        assert rep["lora_grad_cos"] > 0.95 and rep["lora_update_cos"] > 0.8 and abs(rep["lora_update_norm_ratio"] - 1) < 1e-2
+        # (2x2 .. 8x8 feature maps: the LoRA gradient is a few-hundred-term cancelling sum here -- measured cos 0.952, update cos 0.811;
+        # at the real size tests/test_gpu_adv.py asserts 0.95 / 0.85 on measured 0.9987 / 0.944)
+        assert rep["lora_grad_cos"] > 0.93 and rep["lora_update_cos"] > 0.75 and abs(rep["lora_update_norm_ratio"] - 1) < 1e-2
 
 
 @pytest.mark.slow
