@@ -23,14 +23,16 @@ def test_adv_step_c3_shape_full_size(global_step):
     json.dump(rep, open("gpurun_out/adv_c3_parity_step%d.json" % global_step, "w"), indent=1)
     assert rep["heads"] == 36 and rep["fake_adv"] < 3e-3
     if global_step % 2 == 0:
-        assert rep["d_loss_rel"] < 1e-2 and rep["lora_untouched"]
-        assert rep["head_grad_cos"] > 0.98 and min(rep["head_grad_cos_per_tap"]) > 0.97 and rep["head_grad_norm_rel"] < 3e-2
+        # bounds = measured on MI355X (profiles/r03_a_adv_c3_36heads_bs2_dstep.json: 1.1e-4, 0.9963, per tap >= 0.9904, 0.26 %, 0.937) with margin
+        assert rep["d_loss_rel"] < 1e-3 and rep["lora_untouched"]
+        assert rep["head_grad_cos"] > 0.99 and min(rep["head_grad_cos_per_tap"]) > 0.98 and rep["head_grad_norm_rel"] < 1e-2
         # first AdamW step with beta1 = 0: update = -lr * g / (|g| + eps) ~ -lr * sign(g): the cosine counts agreeing signs, the norm is lr * sqrt(n)
-        assert rep["head_update_cos"] > 0.9 and abs(rep["head_update_norm_ratio"] - 1) < 2e-2 and rep["head_param_rel_after"] < 6e-4
+        assert rep["head_update_cos"] > 0.92 and abs(rep["head_update_norm_ratio"] - 1) < 2e-2 and rep["head_param_rel_after"] < 6e-4
     else:
-        assert rep["loss_cm_rel"] < 1.5e-2 and rep["g_loss_rel"] < 1e-2 and rep["heads_untouched"]
-        assert rep["lora_grad_cos"] > 0.95 and rep["lora_grad_norm_rel"] < 5e-2
-        assert rep["lora_update_cos"] > 0.85 and abs(rep["lora_update_norm_ratio"] - 1) < 2e-2 and rep["lora_param_rel_after"] < 6e-4
+        # measured (profiles/r03_b_adv_c3_36heads_bs2_gstep.json): loss_cm 7.9e-3, g_loss 5e-5, cos 0.9987, norm 0.54 %, update cos 0.944
+        assert rep["loss_cm_rel"] < 1.2e-2 and rep["g_loss_rel"] < 1e-3 and rep["heads_untouched"]
+        assert rep["lora_grad_cos"] > 0.995 and rep["lora_grad_norm_rel"] < 2e-2
+        assert rep["lora_update_cos"] > 0.92 and abs(rep["lora_update_norm_ratio"] - 1) < 2e-2 and rep["lora_param_rel_after"] < 6e-4
 
 
 def test_adv_steps_graph_replay_equals_eager():
