@@ -179,7 +179,11 @@ def distill_step_adv(ucfg, sd, lora, disc_sd, inp, cfg: StepConfig, global_step,
         a, b = a.detach().requires_grad_(True), b.detach().requires_grad_(True)
         lora_rg[k] = (a, b)
         leaves += [a, b]
-    out = distill_step_forward(ucfg, sd, lora_rg, inp, cfg)
+    if global_step % 2 == 0:      # discriminator step: nothing is back-propagated through the student (:1375-1397) -> no autograd graph
+        with torch.no_grad():
+            out = distill_step_forward(ucfg, sd, lora_rg, inp, cfg)
+    else:
+        out = distill_step_forward(ucfg, sd, lora_rg, inp, cfg)
     model_pred, target, end_t = out["model_pred"], out["target"], out["end_timesteps"]
     span = cfg.num_train_timesteps // cfg.multiphase
     adv_t = end_t + torch.clamp((inp["adv_u"] * span).long(), max=span - 1)                     # :1288-1298
