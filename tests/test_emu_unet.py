@@ -235,3 +235,26 @@ def test_unet_non_square_ragged_resolution_vs_oracle():
         out = UNet(W, lora).forward(x, t, ctx)
         err = (out - ref).abs().max().item()
         assert out.shape == ref.shape and err < 0.03 * ref.abs().max().item(), (B, H, Wd, err)
+
+
+def test_unet_forward_same_through_both_attention_forward_kernels():
+    """the whole student forward (self-attention at head dims 32 / 64, text cross-attention with a two-tile ragged key stream) through the
+    software-pipelined attention forward equals the forward through the first kernel: the two kernels differ in schedule only"""
+    from oracle import unet_sd15 as O
+    from pcm_amd.model import LoraState, UNet, UNetWeights
+    oc, pc = tiny_cfgs()
+    sd = O.init_state_dict(oc, 0)
+    g = torch.Generator().manual_seed(11)
+    x, t, ctx = torch.randn(2, 4, 16, 16, generator=g), torch.tensor([19, 759]), torch.randn(2, 77, 64, generator=g)
+    W = UNetWeights(pc, sd, "cpu")
+    lora = LoraState(pc, 64, 8.0, "cpu", seed=1, b_std=0.05)
+    dll = capi.lib().dll
+    outs = []
+    try:
+        for var in (0, 1):
+            dll.pcm_debug_attn_fwd_variant(var)
+            outs.append(UNet(W, lora).forward(x, t, ctx))
+    finally:
+        dll.pcm_debug_attn_fwd_variant(-1)
+    rel = float((outs[1] - outs[0]).norm() / outs[0].norm())
+    assert rel < 1e-4, rel
