@@ -26,7 +26,20 @@ __global__ __launch_bounds__(256, (D <= 40 ? 3 : 1)) void attn_fwd_kernel(const 
   __shared__ __attribute__((aligned(16))) char Ks[TileBytes<D>::value];
   __shared__ __attribute__((aligned(16))) char Vs[TileBytes<D>::value];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
-  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 128 + wave * 32;
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (xcd_remap) {
+    // XCD-aware block -> (query block, head, image) map (opt-in A/B, pcm_debug_attn_xcd_remap): workgroup n runs on XCD n % 8, so with x
+    // fastest the query blocks of ONE (image, head) spread over all eight L2s and each of them fetches that head's K / V.  Here every run
+    // of 8 * gridDim.x workgroups serves eight (image, head) pairs, pair i entirely on XCD i; a ragged last group keeps the plain map.
+    const int nx = gridDim.x, nbh = gridDim.y * gridDim.z;
+    const int n = bx + nx * (by + (int)gridDim.y * bz);
+    const int grp = n / (8 * nx), r = n - grp * 8 * nx;
+    if (grp * 8 + 8 <= nbh) {
+      const int pair = grp * 8 + (r & 7);
+      bx = r >> 3; by = pair % (int)gridDim.y; bz = pair / (int)gridDim.y;
+    }
+  }
+  const int b = bz, h = by, q0 = bx * 128 + wave * 32;
   const bf16_t* qb = q + (size_t)b * Lq * ldq + h * D;
   const bf16_t* kb = k + (size_t)b * Lk * ldk + h * D;
   const bf16_t* vb = v + (size_t)b * Lk * ldk + h * D;
@@ -463,6 +476,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16_t* q, con
   }
 }
 
+static int g_attn_xcd_remap = 0;
+extern "C" void pcm_debug_attn_xcd_remap(int on) { g_attn_xcd_remap = on ? 1 : 0; }
 // attention_fwd.hip: the software-pipelined forward (false: no instantiation for this variant / head dim -> the kernel above runs)
 bool pcm_attn_fwd_pipe_launch(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int Lq, int Lk, int d, int ldq,
                               int ldk, int ldo, float scale, void* stream);

@@ -17,8 +17,8 @@ extern "C" int pcm_debug_attn_stamps(unsigned long long* dst) { return (int)hipM
 #else
 #define ATTN_STAMP(k) do { } while (0)
 #endif
-#define ATTN_DBG_PARAM
-#define ATTN_DBG_ARG
+#define ATTN_DBG_PARAM , int xcd_remap
+#define ATTN_DBG_ARG , g_attn_xcd_remap
 #define ATTN_ABL(bit) 0
 
 template <int D>

@@ -140,6 +140,21 @@ def test_attention_first_forward_kernel_still_correct():
         dll.pcm_debug_attn_fwd_variant(-1)
 
 
+@pytest.mark.parametrize("B,H,Lq,Lk,d", [(2, 5, 300, 200, 40), (1, 8, 260, 130, 64), (3, 3, 130, 77, 80)])
+def test_attention_forward_xcd_aware_block_map(B, H, Lq, Lk, d):
+    """the opt-in XCD-aware block -> (query block, head, image) map of the first forward kernel is a bijection: full groups of eight
+    (image, head) pairs are permuted, a ragged last group (B * H not a multiple of 8) keeps the plain map -- same results as the plain map"""
+    from pcm_amd import capi
+    dll = capi.lib().dll
+    dll.pcm_debug_attn_fwd_variant(0)
+    dll.pcm_debug_attn_xcd_remap(1)
+    try:
+        K.case_attention("cpu", B, H, Lq, Lk, d, spike=True)
+    finally:
+        dll.pcm_debug_attn_xcd_remap(0)
+        dll.pcm_debug_attn_fwd_variant(-1)
+
+
 def test_lora_repack():
     K.case_lora_repack("cpu")
 
