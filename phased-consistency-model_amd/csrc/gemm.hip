@@ -354,16 +354,18 @@ __global__ __launch_bounds__(256) void pcm_gemm_finalize_kernel(GemmDev g) {
 }
 
 // tile / split-K plan shared by pcm_gemm_bf16 and pcm_gemm_workspace_bytes
-struct GemmPlan { int BM, BN, tiles_m, tiles_n, splitk, kt_per_split; size_t ws_bytes; int big_fn; };
+struct GemmPlan { int BM, BN, tiles_m, tiles_n, splitk, kt_per_split; size_t ws_bytes; int big_fn; int w4_fn; };
 static int g_force_bm = 0, g_force_bn = 0;
-static int g_big_mode = -1;   // -1: read PCM_GEMM_BIG once (0 = never use gemm8p, 1 = planner, 2 = wherever eligible); tuning only
+// -1: read PCM_GEMM_BIG once.  0 = 4-wave tiles of this file only, 1 = planner (default), 2 = gemm8p wherever eligible (no gemm4w),
+// 3 = gemm4w wherever eligible (else as 2), 4 = planner without gemm4w; tuning / A-B only
+static int g_big_mode = -1;
 extern "C" void pcm_debug_gemm_big_mode(int mode) { g_big_mode = mode; }
 static int g_conv_co = -1, g_conv_md = -1;    // -1: PCM_GEMM_CONV_CO / PCM_GEMM_CONV_MD env if set, else 0 (the shipped tap-outer / re-key path)
 extern "C" void pcm_debug_gemm_conv_order(int chunk_outer) { g_conv_co = chunk_outer < 0 ? -1 : (chunk_outer > 1 ? 2 : (chunk_outer ? 1 : 0)); }   // -1: default; 2: by shape
 extern "C" void pcm_debug_gemm_conv_md(int mask_delta) { g_conv_md = mask_delta < 0 ? -1 : (mask_delta ? 1 : 0); }
 static int g_ablate = 0;      // see PCM_ABL in gemm_dev.h (no effect in the product build)
 extern "C" void pcm_debug_gemm_ablate(int mask) { g_ablate = mask; }
-static int g_last_plan = 0;   // tests only: 1000*big_fn + splitk of the most recent pcm_gemm_bf16 launch
+static int g_last_plan = 0;   // tests only: 1000*big_fn + splitk of the most recent pcm_gemm_bf16 launch (gemm4w: 10000 + 1000*fn + 1)
 extern "C" int pcm_debug_last_gemm_plan(void) { return g_last_plan; }
 static int big_mode() {
   if (g_big_mode < 0) { const char* e = getenv("PCM_GEMM_BIG"); g_big_mode = e ? atoi(e) : 1; }
@@ -373,10 +375,33 @@ static int big_mode() {
 extern "C" void pcm_debug_force_gemm_tile(int bm, int bn) { g_force_bm = bm; g_force_bn = bn; }
 
 // big_ok: the call satisfies gemm8p's preconditions (K%64==0 per segment, bf16 output with 16-B rows, < 2 GiB operands)
-static GemmPlan gemm_plan(int M, int N, int total_kt, bool allow_split, bool big_ok, bool must_big = false) {
+// gemm4w.hip (two workgroups per CU) takes the short-K launches: plain segments only, K-loop of at most PCM_GEMM_4W_MAXKT 64-wide K-tiles
+// (default 21: K + r <= 1344, the launches whose algorithmic bytes at 8 TB/s outlast their flops at 2.5 PFLOP/s, plus the K = 1280 + 64 projections)
+static int w4_max_kt() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("PCM_GEMM_4W_MAXKT"); v = e ? atoi(e) : 21; }
+  return v;
+}
+static GemmPlan gemm_plan(int M, int N, int total_kt, bool allow_split, bool big_ok, bool must_big = false, bool w4_ok = false) {
   GemmPlan p;
-  p.big_fn = 0;
-  if (must_big) allow_split = false;   // fused-GEGLU epilogue lives in gemm8p only, on complete sums
+  p.big_fn = 0; p.w4_fn = 0;
+  if (must_big) allow_split = false;   // fused-GEGLU epilogue lives in gemm8p / gemm4w only, on complete sums
+  if (w4_ok && big_ok && !g_force_bm && (big_mode() == 1 || big_mode() == 3) && M >= 128) {
+    int best_fn = 0; double best = 0.0;
+    for (int fn = 5; fn >= 4; fn--) {
+      const int bn = 64 * fn;
+      const long tm = (M + 127) / 128, tn = (N + bn - 1) / bn;
+      const double useful = ((double)M * N) / ((double)tm * 128 * tn * bn);
+      if (useful > best + 1e-9) { best = useful; best_fn = fn; }
+    }
+    const bool take = big_mode() == 3 ? true : (total_kt <= w4_max_kt() && best >= 0.8 && (long)((M + 127) / 128) * ((N + 64 * best_fn - 1) / (64 * best_fn)) >= 256);
+    if (best_fn && take) {
+      p.w4_fn = best_fn; p.BM = 128; p.BN = 64 * best_fn;
+      p.tiles_m = (M + 127) / 128; p.tiles_n = (N + p.BN - 1) / p.BN;
+      p.splitk = 1; p.kt_per_split = total_kt; p.ws_bytes = 0;
+      return p;
+    }
+  }
   if (big_ok && ((!g_force_bm && big_mode() > 0 && M >= 256) || must_big)) {
     // candidates 256x320 / 256x256 (+ split-K); pick by useful work per block-round of the 256 CUs
     int best_fn = 0, best_s = 1; double best = 0.0;
@@ -392,7 +417,7 @@ static GemmPlan gemm_plan(int M, int N, int total_kt, bool allow_split, bool big
         if (eff > best + 1e-9) { best = eff; best_fn = fn; best_s = s; }
       }
     }
-    const double need = (big_mode() >= 2 || must_big) ? 0.0 : 0.62;
+    const double need = (big_mode() == 2 || big_mode() == 3 || must_big) ? 0.0 : 0.62;
     if (best_fn && best >= need) {
       p.big_fn = best_fn; p.BM = 256; p.BN = 64 * best_fn;
       p.tiles_m = (M + 255) / 256; p.tiles_n = (N + p.BN - 1) / p.BN;
@@ -450,6 +475,12 @@ static bool gemm_big_ok(const pcm_gemm_seg* segs, int nseg, const pcm_gemm_epi* 
   if (e->rowvec && (((uintptr_t)e->rowvec) & 15)) return false;
   return true;
 }
+// gemm4w.hip: plain segments only (K % 64 == 0 is part of big_ok)
+static bool gemm_w4_ok(const pcm_gemm_seg* segs, int nseg) {
+  for (int i = 0; i < nseg; i++)
+    if (segs[i].mode != PCM_SEG_PLAIN) return false;
+  return true;
+}
 // rank-64 projection that the streaming kernel (gemm_n64.hip) takes
 static bool gemm_n64_ok(const pcm_gemm_seg* segs, int nseg, const pcm_gemm_epi* e) {
   return big_mode() > 0 && !g_force_bm && nseg == 1 && segs[0].mode == PCM_SEG_PLAIN && e->N == 64 && (segs[0].K % 64) == 0 &&
@@ -459,7 +490,7 @@ extern "C" size_t pcm_gemm_workspace_bytes(const pcm_gemm_seg* segs, int nseg, c
   if (!segs || !e || nseg < 1 || nseg > 2 || e->M <= 0 || e->N <= 0) return 0;
   if (gemm_n64_ok(segs, nseg, e)) return 0;
   // the workspace is sized for the plan that would be used WITH a workspace; pcm_gemm_bf16 re-plans identically
-  return gemm_plan(e->M, e->N, gemm_total_kt(segs, nseg), true, gemm_big_ok(segs, nseg, e), e->act == PCM_ACT_GEGLU).ws_bytes;
+  return gemm_plan(e->M, e->N, gemm_total_kt(segs, nseg), true, gemm_big_ok(segs, nseg, e), e->act == PCM_ACT_GEGLU, gemm_w4_ok(segs, nseg)).ws_bytes;
 }
 
 extern "C" int pcm_gemm_bf16(const pcm_gemm_seg* segs, int nseg, const pcm_gemm_epi* e, void* stream) {
@@ -523,14 +554,19 @@ extern "C" int pcm_gemm_bf16(const pcm_gemm_seg* segs, int nseg, const pcm_gemm_
     if (rc) return rc;
     return pcm_post_launch("pcm_gemm_bf16");
   }
-  GemmPlan pl = gemm_plan(e->M, e->N, gemm_total_kt(segs, nseg), e->workspace != nullptr, gemm_big_ok(segs, nseg, e), geglu);
+  GemmPlan pl = gemm_plan(e->M, e->N, gemm_total_kt(segs, nseg), e->workspace != nullptr, gemm_big_ok(segs, nseg, e), geglu, gemm_w4_ok(segs, nseg));
   if (pl.splitk > 1) {
     PCM_CHECK(e->workspace_bytes >= pl.ws_bytes && PCM_ALIGNED16(e->workspace), PCM_EINVAL,
               "pcm_gemm_bf16: workspace too small (%zu < %zu) or unaligned", (size_t)e->workspace_bytes, pl.ws_bytes);
     g.ws = (float*)e->workspace;
   }
   g.tiles_m = pl.tiles_m; g.tiles_n = pl.tiles_n; g.splitk = pl.splitk; g.kt_per_split = pl.kt_per_split;
-  g_last_plan = 1000 * pl.big_fn + pl.splitk;
+  g_last_plan = pl.w4_fn ? 10000 + 1000 * pl.w4_fn + 1 : 1000 * pl.big_fn + pl.splitk;
+  if (pl.w4_fn) {
+    int rc = pcm_gemm4w_launch(g, pl.w4_fn, stream);
+    if (rc) return rc;
+    return pcm_post_launch("pcm_gemm_bf16");
+  }
   if (pl.big_fn) {
     int rc = pcm_gemm8p_launch(g, pl.big_fn, stream);
     if (rc) return rc;

@@ -98,6 +98,8 @@ __device__ __forceinline__ void pcm_epi_finish8(const GemmDev& g, int m, int n, 
 // 256 x (64*FN) phased kernel (gemm8p.hip).  fn = 5 -> 256x320, fn = 4 -> 256x256.  grid = (tiles_m*tiles_n, splitk)
 int pcm_gemm8p_launch(const GemmDev& g, int fn, void* stream);
 size_t pcm_gemm8p_lds_bytes(int fn);
+// 128 x (64*FN) short-K kernel at two workgroups per CU (gemm4w.hip).  grid = tiles_m*tiles_n (tiles_m counts 128-row tiles); no split-K
+int pcm_gemm4w_launch(const GemmDev& g, int fn, void* stream);
 // rank-64 down-projection of a conv LoRA factor from a halo window (conv_r64.hip): 0 = launched, 1 = not one of its shapes, < 0 error
 int pcm_conv_r64_launch(const GemmDev& g, void* stream);
 // streaming kernel for the rank-64 projections (gemm_n64.hip)

@@ -604,6 +604,73 @@ def case_gemm_big(dev, which):
 GEMM_BIG_CASES = ["plain_lora", "ragged", "two_tiles_k", "splitk", "conv", "conv_s2", "conv_up", "conv_zi", "conv_conv", "conv_splitk", "persist", "persist_splitk", "conv_persist", "conv_small_map"]
 
 
+def case_gemm_4w(dev, which):
+    """The short-K kernel (gemm4w.hip: 128 x 320 / 128 x 256 tiles, two workgroups per CU) forced through pcm_debug_gemm_big_mode(3) on the
+    plain-segment flavours it serves; returns (max abs excess over tolerance, max abs err) against torch fp32 on the same bf16 operands."""
+    import torch.nn.functional as F
+    from pcm_amd import capi, ops
+
+    def rnd(*shape, seed=0, scale=1.0):
+        g = torch.Generator().manual_seed(seed)
+        return (torch.randn(*shape, generator=g) * scale).bfloat16().to(dev)
+
+    dll = capi.lib().dll
+    dll.pcm_debug_gemm_big_mode(3)
+    try:
+        if which == "plain_lora":      # 4 M tiles of 128x320, 10 + 2 K-steps over two segments, bias + residual
+            M, N, K = 512, 320, 320
+            x, w, t, bl = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.1), rnd(M, 64, seed=3), rnd(N, 64, seed=4, scale=0.1)
+            bias = torch.randn(N, generator=torch.Generator().manual_seed(5)).to(dev)
+            res = rnd(M, N, seed=6)
+            out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+            ops.gemm([ops.Seg(x, w), ops.Seg(t, bl)], M, N, out, bias=bias, residual=res)
+            ref = x.float() @ w.float().T + t.float() @ bl.float().T + bias + res.float()
+            fn = 5
+        elif which == "ragged":         # M tail, 128x256 tile with an N tail, SiLU + alpha, exactly two K-steps (prologue-only pipeline)
+            M, N, K = 300, 448, 64
+            x, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.2)
+            out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+            ops.gemm([ops.Seg(x, w)], M, N, out, act=capi.ACT_SILU, alpha=0.5)
+            ref = F.silu(0.5 * (x.float() @ w.float().T))
+            fn = 4
+        elif which == "qkv":            # fused q/k/v: N = 3 x 320, LoRA segment of K = 192, three K-steps ahead of a segment switch
+            M, N, K = 256, 960, 128
+            x, w, t, bl = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.1), rnd(M, 192, seed=3), rnd(N, 192, seed=4, scale=0.1)
+            out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+            ops.gemm([ops.Seg(x, w), ops.Seg(t, bl)], M, N, out)
+            ref = x.float() @ w.float().T + t.float() @ bl.float().T
+            fn = 5
+        elif which == "rowvec":         # per-image row vector (time embedding) + SiLU, strided activation rows (lda > K), strided output
+            M, N, K = 384, 640, 192
+            xa, w = rnd(M, K + 64, seed=1), rnd(N, K, seed=2, scale=0.1)
+            temb = rnd(3, N, seed=9)
+            outa = torch.full((M, N + 64), 3.0, dtype=torch.bfloat16, device=dev)
+            ops.gemm([ops.Seg(xa, w, lda=K + 64)], M, N, outa, rowvec=temb, rows_per_batch=128, act=capi.ACT_SILU, ldo=N + 64)
+            ref = F.silu(xa[:, :K].float() @ w.float().T + temb.float().repeat_interleave(128, 0))
+            assert bool((outa[:, N:].float() == 3.0).all())
+            out = outa[:, :N]
+            fn = 5
+        else:                            # "many": more tiles than the emulator keeps resident; odd K-step count
+            M, N, K = (1300, 640, 160 + 32 * 0) if dev == "cpu" else (70000, 640, 320)
+            K = 192 if dev == "cpu" else K
+            x, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.1)
+            res = rnd(M, N, seed=6)
+            out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+            ops.gemm([ops.Seg(x, w)], M, N, out, residual=res)
+            ref = x.float() @ w.float().T + res.float()
+            fn = 5
+        plan = dll.pcm_debug_last_gemm_plan()
+        assert plan == 10000 + 1000 * fn + 1, ("gemm4w not taken", which, plan)
+    finally:
+        dll.pcm_debug_gemm_big_mode(1)
+    err = (out.float() - ref).abs()
+    tol = 2e-2 + 1e-2 * ref.abs()
+    return float((err - tol).max()), float(err.max())
+
+
+GEMM_4W_CASES = ["plain_lora", "ragged", "qkv", "rowvec", "many"]
+
+
 def case_gemm_n64(dev, M, K):
     """Streaming rank-64 projection kernel (gemm_n64.hip) vs torch fp32; returns max abs excess over tolerance."""
     from pcm_amd import capi, ops
@@ -649,8 +716,18 @@ def case_conv_r64(dev, B, H, W, C, expect_kernel=True):
         close(out, out2.float().cpu(), 1e-2, 1e-2 * float(ref.abs().max()), "conv r64 vs generic")
 
 
-def case_gemm_geglu(dev, M=300, K=128, inner=160):
+def case_gemm_geglu(dev, M=300, K=128, inner=160, big_mode=1):
     """Projection with the GEGLU epilogue (interleaved value/gate rows) vs torch; returns max abs excess over tolerance."""
+    import torch.nn.functional as F
+    from pcm_amd import capi, ops
+    capi.lib().dll.pcm_debug_gemm_big_mode(big_mode)      # 3: the gemm4w.hip epilogue instead of gemm8p's
+    try:
+        return _case_gemm_geglu(dev, M, K, inner, big_mode)
+    finally:
+        capi.lib().dll.pcm_debug_gemm_big_mode(1)
+
+
+def _case_gemm_geglu(dev, M, K, inner, big_mode):
     import torch.nn.functional as F
     from pcm_amd import capi, ops
     g = torch.Generator().manual_seed(7)
@@ -661,7 +738,8 @@ def case_gemm_geglu(dev, M=300, K=128, inner=160):
     perm = torch.stack([(8 * j)[:, None] + e, inner + (8 * j)[:, None] + e], 1).reshape(-1)
     out = torch.empty(M, inner, dtype=torch.bfloat16, device=dev)
     ops.gemm([ops.Seg(x, w[perm].contiguous())], M, 2 * inner, out, bias=bias[perm].contiguous(), act=capi.ACT_GEGLU, ldo=inner)
-    assert capi.lib().dll.pcm_debug_last_gemm_plan() >= 4000
+    plan = capi.lib().dll.pcm_debug_last_gemm_plan()
+    assert (plan >= 14000) if big_mode == 3 else (4000 <= plan < 10000), plan
     h = x.float() @ w.float().T + bias
     ref = h[:, :inner] * F.gelu(h[:, inner:])
     err = (out.float() - ref).abs()

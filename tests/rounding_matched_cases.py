@@ -142,8 +142,10 @@ def case_blocks(dev, kw, B, H, ctx_len, level=0, report=None):
     return rep
 
 
-def case_step_floor(dev, kw, B, hw, ctx_dim, index=None, report=None, seed=453645634, with_fp32=True, with_grads=False):
+def case_step_floor(dev, kw, B, hw, ctx_dim, index=None, report=None, seed=453645634, with_fp32=True, with_grads=False, golden_name=None):
     """Forward of one distillation step: HIP vs the matched oracle, with the yardstick measured on the oracle itself.
+    ``golden_name``: the two matched-oracle evaluations come from the committed fixture (tests/step_golden_cases.py::ref_sd15_matched: the
+    SD1.5 size, bs 2, indices 13 / 37) instead of being evaluated here.
     ``with_grads``: also the LoRA gradients (the matched oracle rounds the cotangent of every bf16-stored tensor to bf16 as well) -- the
     same three-way comparison on the flat gradient vector (narrow configs only: two more oracle backward passes)."""
     from oracle import pcm_step as OS
@@ -154,10 +156,18 @@ def case_step_floor(dev, kw, B, hw, ctx_dim, index=None, report=None, seed=45364
     inp = OS.draw_inputs(B, ocfg, seed=seed, latent_hw=hw, ctx_len=77, ctx_dim=ctx_dim)
     if index is not None:
         inp["index"] = torch.tensor(index)
-    with torch.no_grad():
-        m32 = OS.distill_step_forward(oc, sd, olora, inp, ocfg, storage="bf16")
-        m64 = OS.distill_step_forward(oc, sd, olora, inp, ocfg, storage="bf16", compute=torch.float64)
-        f32 = OS.distill_step_forward(oc, sd, olora, inp, ocfg) if with_fp32 else m32     # (the plain fp32 oracle: tests/test_gpu_step.py)
+    if golden_name is not None:
+        import step_golden_cases as S
+        from golden_fixture import golden
+        assert not with_fp32 and not with_grads and (B, hw, tuple(index), seed) == (2, 64, (13, 37), 453645634)
+        gd = golden(golden_name, S.ref_sd15_matched)
+        m32, m64 = ({k[4:]: v for k, v in gd.items() if k.startswith(t + ".")} for t in ("m32", "m64"))
+        f32 = m32
+    else:
+        with torch.no_grad():
+            m32 = OS.distill_step_forward(oc, sd, olora, inp, ocfg, storage="bf16")
+            m64 = OS.distill_step_forward(oc, sd, olora, inp, ocfg, storage="bf16", compute=torch.float64)
+            f32 = OS.distill_step_forward(oc, sd, olora, inp, ocfg) if with_fp32 else m32     # (the plain fp32 oracle: tests/test_gpu_step.py)
     D = Distiller(W, lora, cfg)
     d = {k: v.to(dev) for k, v in inp.items()}
     out = D.forward_backward(d["latents"], d["prompt_embeds"], d["uncond_prompt_embeds"], d["noise"], d["index"], d["w"], backward=False)

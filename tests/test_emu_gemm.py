@@ -159,6 +159,23 @@ def test_conv_lora_down_projection_fallback_shapes():
     KC.case_conv_r64("cpu", 2, 8, 8, 64, expect_kernel=False)
 
 
+@pytest.mark.parametrize("lazy_dma", [False, True])
+@pytest.mark.parametrize("which", __import__("kernel_cases").GEMM_4W_CASES)
+def test_short_k_kernel(which, lazy_dma, monkeypatch):
+    """gemm4w.hip under both extremes of the LDS-DMA landing time (at issue / only at the counted wait that retires it)"""
+    if lazy_dma:
+        monkeypatch.setenv("PCM_EMU_LAZY_DMA", "1")
+    import kernel_cases as KC
+    excess, err = KC.case_gemm_4w("cpu", which)
+    assert excess <= 0, (which, excess, err)
+
+
+def test_fused_geglu_epilogue_short_k_kernel():
+    import kernel_cases as KC
+    assert KC.case_gemm_geglu("cpu", big_mode=3) <= 0
+    assert KC.case_gemm_geglu("cpu", M=256, K=64, inner=160, big_mode=3) <= 0
+
+
 def test_fused_geglu_epilogue():
     import kernel_cases as KC
     assert KC.case_gemm_geglu("cpu") <= 0

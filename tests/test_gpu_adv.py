@@ -18,7 +18,8 @@ def test_adv_step_c3_shape_full_size(global_step):
     capi.set_lib(None)
     capi.lib()
     kw = dict(block_out_channels=(320, 640, 1280, 1280), cross_attention_dim=768, heads=8, norm_num_groups=32)
-    rep = A.case_adv_c3("cuda", kw, ADAPTER_DIMS, 2, 64, 77, 768, global_step, nh=4, index=[30, 12])
+    rep = A.case_adv_c3("cuda", kw, ADAPTER_DIMS, 2, 64, 77, 768, global_step, nh=4, index=[30, 12],
+                        golden_name="sd15_adv_c3_bs2_step%d" % global_step)     # oracle side: committed fixture (tests/golden/make_golden_step.py)
     os.makedirs("gpurun_out", exist_ok=True)
     json.dump(rep, open("gpurun_out/adv_c3_parity_step%d.json" % global_step, "w"), indent=1)
     assert rep["heads"] == 36 and rep["fake_adv"] < 3e-3

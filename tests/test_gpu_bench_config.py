@@ -172,76 +172,104 @@ def test_split_graph_capture_equals_eager(monkeypatch):
         assert float((ue * ug).sum() / (ue.norm() * ug.norm())) > 0.9999, rep_i
 
 
-def test_loss_curve_20_steps_vs_oracle(request):
-    """north_star: 'loss curves matching reference to 1e-3 rel'.  The reference trains under bf16/fp16 autocast; the yardstick is
-    therefore measured, not assumed: the same 20 steps are evaluated by the fp32 oracle, by the oracle under bfloat16 autocast (the
-    reference's arithmetic) and by the HIP path.  Asserted: (1) the HIP curve is as close to fp32 as the reference's own bf16 curve
-    is (mean |rel| within 1.5x + 1e-3), (2) no drift: the error of the last 5 steps is not larger than that of the first 5 by more
-    than the noise, (3) the parts the reference owns in fp32 (timesteps, noisy input) are exact."""
-    from oracle import pcm_step as OS
+def test_c2_as_benchmarked_vs_oracle():
+    """BASELINE configs[1] EXACTLY as bench.py runs it -- SD1.5, multiphase = 4, bs 16, the fused 2B passes, the bs-16 tile / split-K plans
+    (train_pcm_lora_sd15.sh:12-17; sd15.py:1157-1174) -- against the fp32 oracle and the rounding-point-matched oracle on the same seeded
+    weights, LoRA factors (B ~ N(0, 0.02): every LoRA path live) and inputs.  Oracle side: tests/golden/step_sd15_c2_m4_bs16.safetensors
+    (tests/step_golden_cases.py::ref_c2).  Writes gpurun_out/c2_as_benchmarked_parity.json."""
+    import step_golden_cases as S
+    from golden_fixture import golden, sk_cos, sk_rel, sketch
     from oracle import unet_sd15 as O
     from pcm_amd import capi
     from pcm_amd.model import LoraState, UNetWeights
-    from pcm_amd.trainer import Distiller, StepConfig
+    from pcm_amd.trainer import Distiller
     from pcm_amd.unet_spec import UNetConfig
     capi.set_lib(None)
     capi.lib()
-    kw = dict(block_out_channels=(64, 128, 128, 128), cross_attention_dim=64, heads=2, norm_num_groups=32)
-    oc, pc = O.UNetConfig(**kw), UNetConfig(**kw)
-    sd = O.init_state_dict(oc, 0)
-    W = UNetWeights(pc, sd, "cuda")
-    lora = LoraState(pc, 64, 8.0, "cuda", seed=1, b_std=0.02)
-    olora = {p: (lora.A_peft(m).detach().cpu().clone(), m.B.detach().cpu().clone()) for p, m in lora.modules.items()}
-    ocfg = OS.StepConfig(multiphase=2, loss_type="huber", lr=5e-6, adam_weight_decay=1e-3, w_min=4.0, w_max=5.0)
-    cfg = StepConfig(multiphase=2, loss_type="huber", learning_rate=5e-6, adam_weight_decay=1e-3, w_min=4.0, w_max=5.0)
-    D = Distiller(W, lora, cfg)
-    state = {}
+    ref = golden("sd15_c2_m4_bs16", S.ref_c2)
+    cfg = UNetConfig.sd15()
+    W = UNetWeights(cfg, O.init_state_dict(O.UNetConfig.sd15(), 0), "cuda")
+    lora = LoraState(cfg, 64, 8.0, "cuda", seed=1, b_std=0.02)
+    assert sk_rel(sketch(S.lora_flat(lora, "p")), ref["sk_param_before"]) < 1e-6
+    _, scfg = S.step_cfgs(S.C2_PHASES)
+    D = Distiller(W, lora, scfg)
+    inp = {k: v.cuda() for k, v in S.c2_inputs().items()}
+    out = D.forward_backward(**inp)
+    torch.cuda.synchronize()
+    for k in S.TS:
+        assert torch.equal(out[k].cpu(), ref[k]), k
+    assert torch.allclose(out["noisy_model_input"][:4].cpu(), ref["noisy_model_input"], rtol=3e-7, atol=1e-7)
+    rep = {"vs_fp32": {k: rel(out[k].cpu(), ref[k]) for k in S.KEYS7}, "vs_matched": {k: rel(out[k].cpu(), ref["m32." + k]) for k in S.KEYS6}}
+    lh = float(out["loss"].item())
+    rep["loss"] = dict(hip=lh, fp32=ref["loss"], matched=ref["m32.loss"], hip_vs_fp32=abs(lh - ref["loss"]) / ref["loss"],
+                       hip_vs_matched=abs(lh - ref["m32.loss"]) / ref["m32.loss"], matched_vs_fp32=abs(ref["m32.loss"] - ref["loss"]) / ref["loss"])
+    mg = sketch(S.lora_flat(lora, "g"))
+    gn = math.sqrt(float(out["grad_sumsq"].item())) if "grad_sumsq" in out else float(lora.grads.double().norm())
+    rep["lora_grad"] = dict(rel=sk_rel(mg, ref["sk_grad"]), cos=sk_cos(mg, ref["sk_grad"]), norm_rel=abs(gn - ref["grad_norm"]) / ref["grad_norm"])
+    print(json.dumps(rep, indent=1))
+    os.makedirs("gpurun_out", exist_ok=True)
+    json.dump(rep, open("gpurun_out/c2_as_benchmarked_parity.json", "w"), indent=1)
+    # the bs-2 / 2-phase bounds of tests/test_gpu_step.py hold unchanged on the benchmarked configuration
+    f, m = rep["vs_fp32"], rep["vs_matched"]
+    assert f["noise_pred"] < 1.2e-2 and f["cond_teacher_output"] < 1.2e-2 and f["target_noise_pred"] < 1.2e-2, f
+    assert f["x_prev"] < 1.6e-3 and f["model_pred"] < 2.6e-3 and f["target"] < 2.9e-3, f
+    assert rep["loss"]["hip_vs_fp32"] < 9e-3 and rep["loss"]["hip_vs_matched"] < 1.5e-3, rep["loss"]
+    assert m["noise_pred"] < 1.2e-2 and m["model_pred"] < 2.6e-3 and m["target"] < 3.3e-3, m
+    assert rep["lora_grad"]["rel"] < 6e-2 and rep["lora_grad"]["cos"] > 0.998 and rep["lora_grad"]["norm_rel"] < 0.02, rep["lora_grad"]
+
+
+def test_loss_curve_20_steps_real_size_vs_oracle():
+    """north_star: 'loss curves matching reference to 1e-3 rel' (sd15.py:1283-1301) -- 20 consecutive optimizer steps at the REAL SD1.5 size:
+    bs 2, 2 phases, the recipe's lr 5e-6 / weight decay, LoRA B = 0 as the reference starts, fresh seeded inputs every step.  The oracle side
+    (tests/golden/step_sd15_curve20_bs2.safetensors, tests/step_golden_cases.py::ref_curve20) holds per step the fp32 oracle's loss along
+    ITS OWN AdamW trajectory, and on the same parameters the rounding-point-matched oracle's loss and the reference-style bf16-autocast loss;
+    the matched oracle's fp64-arithmetic floor on steps 1 / 10 / 20.  Asserted: mean |HIP - matched| <= 1e-3 (north star), no growth over
+    the 20 steps, the HIP curve not further from fp32 than the reference's own mixed precision, parameters after 20 updates."""
+    import step_golden_cases as S
+    from golden_fixture import golden, sk_cos, sk_rel, sketch
+    from oracle import unet_sd15 as O
+    from pcm_amd import capi
+    from pcm_amd.model import LoraState, UNetWeights
+    from pcm_amd.trainer import Distiller
+    from pcm_amd.unet_spec import UNetConfig
+    capi.set_lib(None)
+    capi.lib()
+    ref = golden("sd15_curve20_bs2", S.ref_curve20)
+    cfg = UNetConfig.sd15()
+    W = UNetWeights(cfg, O.init_state_dict(O.UNetConfig.sd15(), 0), "cuda")
+    lora = LoraState(cfg, 64, 8.0, "cuda", seed=1, b_std=0.0)
+    p0 = S.lora_flat(lora, "p")
+    _, scfg = S.step_cfgs(2)
+    D = Distiller(W, lora, scfg)
     rows = []
-    # this narrow model is thousands of tiny CPU ops per oracle forward: with the GPU box's 128 torch threads every one of them pays a
-    # thread-pool hand-shake (measured 14 s per matched-oracle forward there against 0.5 s on 8 threads)
-    request.addfinalizer(lambda n=torch.get_num_threads(): torch.set_num_threads(n))
-    torch.set_num_threads(min(torch.get_num_threads(), 8))
-    for step in range(1, 21):
-        inp = OS.draw_inputs(4, ocfg, seed=1000 + step, latent_hw=16, ctx_len=77, ctx_dim=64)
-        with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
-            l16 = float(OS.distill_step_forward(oc, sd, olora, inp, ocfg)["loss"])
-        with torch.no_grad():     # the rounding-point-matched oracle (bf16 storage, fp32 arithmetic) on the same parameters; its own
-            lm = float(OS.distill_step_forward(oc, sd, olora, inp, ocfg, storage="bf16")["loss"])      # fp64-arithmetic floor on 3 of the
-            lm64 = lm                                                                                   # 20 steps
-            if step in (1, 10, 20):
-                lm64 = float(OS.distill_step_forward(oc, sd, olora, inp, ocfg, storage="bf16", compute=torch.float64)["loss"])
-        ref = OS.distill_step(oc, sd, olora, inp, ocfg, state, step)          # fp32; updates olora in place
-        dev = {k: v.cuda() for k, v in inp.items()}
-        out = D.step(dev["latents"], dev["prompt_embeds"], dev["uncond_prompt_embeds"], dev["noise"], dev["index"], dev["w"])
-        assert torch.equal(out["timesteps"].cpu(), ref["timesteps"]) and torch.equal(out["end_timesteps"].cpu(), ref["end_timesteps"])
-        # fp32 add_noise: bit-exact against the committed golden (test_gpu_kernels.py); a live CPU oracle may differ by 1 ulp of the two
-        # sqrt coefficients (host sqrt is not correctly rounded on every box), i.e. ~2.4e-7 of the LARGER term
-        assert torch.allclose(out["noisy_model_input"].cpu(), ref["noisy_model_input"], rtol=1e-6, atol=2e-6)
-        lf, lh = float(ref["loss"]), float(out["loss"].item())
-        rows.append(dict(step=step, oracle_fp32=lf, ref_bf16_autocast=l16, hip=lh, hip_rel=(lh - lf) / lf, ref_bf16_rel=(l16 - lf) / lf,
-                         matched=lm, hip_vs_matched=(lh - lm) / lm, matched_floor=(lm64 - lm) / lm))
-    mh = sum(abs(r["hip_rel"]) for r in rows) / len(rows)
-    m16 = sum(abs(r["ref_bf16_rel"]) for r in rows) / len(rows)
-    first = sum(abs(r["hip_rel"]) for r in rows[:5]) / 5
-    last = sum(abs(r["hip_rel"]) for r in rows[-5:]) / 5
-    # parameters after 20 updates: both sides applied AdamW to their own gradients
-    flat_h = torch.cat([torch.cat([lora.A_peft(m).detach().cpu().reshape(-1), m.B.detach().cpu().reshape(-1)]) for m in lora.modules.values()])
-    flat_o = torch.cat([torch.cat([a.reshape(-1), b.reshape(-1)]) for a, b in olora.values()])
-    mm = sum(abs(r["hip_vs_matched"]) for r in rows) / len(rows)
-    mfl = sum(abs(r["matched_floor"]) for r in rows if r["step"] in (1, 10, 20)) / 3
-    rep = dict(mean_abs_rel_hip=mh, mean_abs_rel_ref_bf16_autocast=m16, first5=first, last5=last, max_abs_rel_hip=max(abs(r["hip_rel"]) for r in rows),
-               mean_abs_rel_hip_vs_matched_oracle=mm, mean_abs_rel_matched_oracle_fp64_vs_fp32=mfl,
-               mean_signed_rel_hip_vs_matched_oracle=sum(r["hip_vs_matched"] for r in rows) / len(rows),
-               param_rel_after_20=rel(flat_h, flat_o), rows=rows)
+    for step in range(1, S.CURVE_STEPS + 1):
+        inp = {k: v.cuda() for k, v in S.curve_inputs(step).items()}
+        out = D.step(inp["latents"], inp["prompt_embeds"], inp["uncond_prompt_embeds"], inp["noise"], inp["index"], inp["w"])
+        assert out["timesteps"].tolist() == ref["timesteps"][step - 1] and out["end_timesteps"].tolist() == ref["end_timesteps"][step - 1]
+        lh, lf, lm, l16 = float(out["loss"].item()), ref["fp32"][step - 1], ref["matched"][step - 1], ref["bf16_autocast"][step - 1]
+        rows.append(dict(step=step, hip=lh, oracle_fp32=lf, matched=lm, ref_bf16_autocast=l16, hip_vs_matched=(lh - lm) / lm,
+                         hip_vs_fp32=(lh - lf) / lf, ref_bf16_vs_fp32=(l16 - lf) / lf, matched_floor=ref["floor"][step - 1]))
+    n = len(rows)
+    mean = lambda key, rr=rows: sum(abs(r[key]) for r in rr) / len(rr)      # noqa: E731
+    p1 = S.lora_flat(lora, "p")
+    rep = dict(mean_abs_hip_vs_matched=mean("hip_vs_matched"), mean_signed_hip_vs_matched=sum(r["hip_vs_matched"] for r in rows) / n,
+               max_abs_hip_vs_matched=max(abs(r["hip_vs_matched"]) for r in rows),
+               matched_floor_mean_of_3=sum(rows[s - 1]["matched_floor"] for s in S.CURVE_FLOOR_STEPS) / len(S.CURVE_FLOOR_STEPS),
+               mean_abs_hip_vs_fp32=mean("hip_vs_fp32"), mean_abs_ref_bf16_autocast_vs_fp32=mean("ref_bf16_vs_fp32"),
+               first5_hip_vs_matched=mean("hip_vs_matched", rows[:5]), last5_hip_vs_matched=mean("hip_vs_matched", rows[-5:]),
+               first5_hip_vs_fp32=mean("hip_vs_fp32", rows[:5]), last5_hip_vs_fp32=mean("hip_vs_fp32", rows[-5:]),
+               param_rel_after_20=sk_rel(sketch(p1), ref["sk_param_after"]), update_cos_after_20=sk_cos(sketch(p1 - p0), ref["sk_update"]), rows=rows)
     print(json.dumps({k: v for k, v in rep.items() if k != "rows"}, indent=1))
     for r in rows:
-        print("step %2d  fp32 %.6f  ref-bf16 %+.2e  hip %+.2e" % (r["step"], r["oracle_fp32"], r["ref_bf16_rel"], r["hip_rel"]))
+        print("step %2d  fp32 %.6f  matched %+.2e  ref-bf16 %+.2e  hip-vs-fp32 %+.2e  hip-vs-matched %+.2e" %
+              (r["step"], r["oracle_fp32"], (r["matched"] - r["oracle_fp32"]) / r["oracle_fp32"], r["ref_bf16_vs_fp32"], r["hip_vs_fp32"], r["hip_vs_matched"]))
     os.makedirs("gpurun_out", exist_ok=True)
-    json.dump(rep, open("gpurun_out/loss_curve_20.json", "w"), indent=1)
+    json.dump(rep, open("gpurun_out/loss_curve_20_real_size.json", "w"), indent=1)
     assert all(math.isfinite(r["hip"]) for r in rows)
-    assert mh <= 1.5 * m16 + 1e-3, rep
-    # against the matched oracle the curve sits at the oracle's own accumulation-precision floor (tiny config: 2048 loss elements per step,
-    # the floor itself is several 1e-3; at the SD1.5 size it is 3e-4 and the HIP loss agrees to 6.5e-4, tests/test_gpu_rounding_matched.py)
-    assert mm <= 1.5 * mfl + 1e-3, rep
-    assert last <= first + 2.0 * m16 + 1e-3, rep
-    assert rep["param_rel_after_20"] < 1e-3, rep
+    assert rep["mean_abs_hip_vs_matched"] <= 1e-3, rep                                   # the north-star number, against the oracle that rounds where the HIP path does
+    assert rep["last5_hip_vs_matched"] <= rep["first5_hip_vs_matched"] + 1e-3, rep      # does not compound over optimizer updates
+    assert rep["mean_abs_hip_vs_fp32"] <= rep["mean_abs_ref_bf16_autocast_vs_fp32"] + 1e-3, rep
+    assert rep["last5_hip_vs_fp32"] <= rep["first5_hip_vs_fp32"] + 3e-3, rep
+    # 20 AdamW steps of lr 5e-6 from B = 0: |update| = 20 * lr * sqrt(n) against |A| -- both trajectories move every parameter by the same
+    # sign-like steps; the parameters agree to a fraction of the total update
+    assert rep["param_rel_after_20"] < 2e-4 and rep["update_cos_after_20"] > 0.85, rep

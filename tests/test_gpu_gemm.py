@@ -113,6 +113,47 @@ def test_conv_lora_down_projection_halo_kernel(B, H, W, C):
     KC.case_conv_r64("cuda", B, H, W, C, expect_kernel=not (H == 8 and W == 8))
 
 
+@pytest.mark.parametrize("which", __import__("kernel_cases").GEMM_4W_CASES)
+def test_short_k_kernel(which):
+    import kernel_cases as KC
+    for _ in range(3):   # repeated: a landing-time race would show as run-to-run differences
+        excess, err = KC.case_gemm_4w("cuda", which)
+        assert excess <= 0, (which, excess, err)
+
+
+def test_short_k_kernel_matches_big_tile_on_step_shapes():
+    """the planner's short-K choice (gemm4w.hip) against the 256-row tile on launches of the bs-16 step: same operands, same epilogue"""
+    from pcm_amd import capi, ops
+    dll = capi.lib().dll
+    g = torch.Generator().manual_seed(3)
+    for (M, N, K, r) in ((32768, 320, 320, 64), (16384, 2560, 320, 64), (8192, 1280, 1280, 0), (4096, 960, 320, 192)):
+        x, w = torch.randn(M, K, generator=g).bfloat16().cuda(), (torch.randn(N, K, generator=g) * 0.05).bfloat16().cuda()
+        segs = [ops.Seg(x, w)]
+        if r:
+            segs.append(ops.Seg(torch.randn(M, r, generator=g).bfloat16().cuda(), (torch.randn(N, r, generator=g) * 0.05).bfloat16().cuda()))
+        res = torch.randn(M, N, generator=g).bfloat16().cuda()
+        outs = []
+        for mode in (2, 3):
+            dll.pcm_debug_gemm_big_mode(mode)
+            try:
+                o = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+                ops.gemm(segs, M, N, o, residual=res)
+                plan = dll.pcm_debug_last_gemm_plan()
+                assert (plan > 10000) == (mode == 3), (mode, plan)
+                outs.append(o.float())
+            finally:
+                dll.pcm_debug_gemm_big_mode(1)
+        # same K order and fp32 accumulation: equal up to one bf16 ulp of a few outputs
+        assert float((outs[0] - outs[1]).abs().max()) <= 2.0 ** -7 * float(outs[0].abs().max()), (M, N, K)
+        assert float(((outs[0] - outs[1]).norm() / outs[0].norm())) < 1e-3
+
+
+def test_fused_geglu_epilogue_short_k_kernel():
+    import kernel_cases as KC
+    assert KC.case_gemm_geglu("cuda", big_mode=3) <= 0
+    assert KC.case_gemm_geglu("cuda", M=32768, K=320, inner=1280, big_mode=3) <= 0
+
+
 def test_fused_geglu_epilogue():
     import kernel_cases as KC
     assert KC.case_gemm_geglu("cuda") <= 0

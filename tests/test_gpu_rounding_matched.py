@@ -35,7 +35,7 @@ def test_blocks_vs_rounding_matched_oracle(level, H):
 def test_sd15_step_within_the_bf16_storage_floor():
     import rounding_matched_cases as R
     rep = {}
-    R.case_step_floor("cuda", _kw(), 2, 64, 768, index=[13, 37], report=rep, with_fp32=False)
+    R.case_step_floor("cuda", _kw(), 2, 64, 768, index=[13, 37], report=rep, with_fp32=False, golden_name="sd15_matched_m2_bs2")
     os.makedirs("gpurun_out", exist_ok=True)
     json.dump(rep, open("gpurun_out/rounding_matched_sd15.json", "w"), indent=1)
     for k in KEYS:

@@ -15,13 +15,11 @@ def test_sdxl_full_size_properties():
     capi.lib()
     dev = torch.device("cuda", 0)
     cfg = UNetConfig.sdxl()
-    sd = random_state_dict(cfg, 0, dev)
+    sd = random_state_dict(cfg, 0, "cpu")                  # seeded CPU draw: the committed oracle fixture was evaluated on the SAME weights
     W = UNetWeights(cfg, sd, dev)
-    sd_cpu = {k: v.cpu() for k, v in sd.items()}          # the oracle evaluates the SAME weights (drawn on the device, copied once)
     del sd
     torch.cuda.empty_cache()
-    _oracle_parity_one_sample(cfg, sd_cpu, W, dev)
-    del sd_cpu
+    _oracle_parity_one_sample(cfg, W, dev)
     lora = LoraState(cfg, 64, 8.0, dev, seed=1)                                  # B = 0 (peft init)
     g = torch.Generator(device=dev).manual_seed(0)
     r = lambda *s: torch.randn(*s, generator=g, device=dev)   # noqa: E731
@@ -48,35 +46,27 @@ def test_sdxl_full_size_properties():
     print("SDXL full-size step: loss %.5f, peak %.1f GB" % (float(res["loss"]), torch.cuda.max_memory_allocated() / 1e9))
 
 
-def _oracle_parity_one_sample(cfg, sd_cpu, W, dev):
+def _oracle_parity_one_sample(cfg, W, dev):
     """ONE sample at the real size against the fp32 oracle (oracle/unet_sd15.py with the SDXL config: 128x128 latents, 4096 / 1024 tokens,
     transformer depth 2 / 10, head_dim 64, text_time conditioning): the frozen teacher forward and a LoRA student forward (B ~ N(0, 0.02)).
+    The oracle's two outputs come from tests/golden/step_sdxl_fullsize_one_sample.safetensors (tests/step_golden_cases.py::ref_sdxl_one_sample).
     Bound: eps rel-L2 <= 1.5e-2 (the SD1.5-size measurement is 8.8e-3 for a 16-block network; SDXL is ~3x deeper in transformer blocks)."""
     import json
     import os
-    import time
-    from oracle import unet_sd15 as O
+    import step_golden_cases as S
+    from golden_fixture import golden
     from pcm_amd.model import LoraState, UNet
-    oc = O.UNetConfig.sdxl()
-    g = torch.Generator().manual_seed(7)
-    x, t, ctx = torch.randn(1, 4, 128, 128, generator=g), torch.tensor([759]), torch.randn(1, 77, 2048, generator=g)
-    ac = dict(text_embeds=torch.randn(1, 1280, generator=g), time_ids=torch.tensor([[1024, 1024, 0, 0, 1024, 1024]]))
+    ref = golden("sdxl_fullsize_one_sample", S.ref_sdxl_one_sample)
+    ref_t, ref_s = ref["teacher"], ref["student"]
+    x, t, ctx, ac = S.sdxl_one_sample_inputs()
     lora = LoraState(cfg, 64, 8.0, dev, seed=3, b_std=0.02)
-    olora = {p: (lora.A_peft(m).detach().cpu().clone(), m.B.detach().cpu().clone()) for p, m in lora.modules.items()}
-    t0 = time.time()
-    with torch.no_grad():
-        ref_t = O.unet_forward(oc, sd_cpu, x, t, ctx, added_cond=ac)
-        ref_s = O.unet_forward(oc, sd_cpu, x, t, ctx, olora, 8.0, added_cond=ac)
-    cpu_s = time.time() - t0
     acd = {k: v.to(dev) for k, v in ac.items()}
     out_t = UNet(W, None).forward(x.to(dev), t.to(dev), ctx.to(dev), added_cond=acd).cpu()
     out_s = UNet(W, lora).forward(x.to(dev), t.to(dev), ctx.to(dev), added_cond=acd).cpu()
     rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())   # noqa: E731
-    rep = dict(teacher_eps_rel_l2=rel(out_t, ref_t), student_eps_rel_l2=rel(out_s, ref_s), lora_effect_rel=rel(ref_s, ref_t), oracle_seconds=cpu_s)
+    rep = dict(teacher_eps_rel_l2=rel(out_t, ref_t), student_eps_rel_l2=rel(out_s, ref_s), lora_effect_rel=rel(ref_s, ref_t), oracle_seconds=ref["oracle_seconds"])
     print("SDXL full-size oracle parity (1 sample):", rep)
     os.makedirs("gpurun_out", exist_ok=True)
     json.dump(rep, open("gpurun_out/sdxl_fullsize_oracle_parity.json", "w"), indent=1)
     assert rep["teacher_eps_rel_l2"] < 1.5e-2 and rep["student_eps_rel_l2"] < 1.5e-2, rep
     assert rep["lora_effect_rel"] > 3 * rep["student_eps_rel_l2"], rep           # the LoRA branch is visible above the error
-    del lora
-    torch.cuda.empty_cache()

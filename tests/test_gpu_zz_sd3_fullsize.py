@@ -17,43 +17,34 @@ def test_sd3_medium_full_size_properties():
     capi.lib()
     dev = torch.device("cuda", 0)
     cfg = MMDiTConfig.sd3_medium()
-    sd = random_state_dict(cfg, 0, dev)
+    sd = random_state_dict(cfg, 0, "cpu")                  # seeded CPU draw: the committed oracle fixture was evaluated on the SAME weights
     W = MMDiTWeights(cfg, sd, dev)
-    sd_cpu = {k: v.cpu() for k, v in sd.items()}          # the oracle evaluates the SAME weights
     del sd
     torch.cuda.empty_cache()
-    _oracle_parity_one_sample(cfg, sd_cpu, W, dev)
-    del sd_cpu
+    _oracle_parity_one_sample(cfg, W, dev)
     lora = sd3_lora_state(cfg, 32, 8.0, dev, seed=1)                     # B = 0 (reference init)
     loss, gnorm = run_property_case(dev, cfg, W, lora, 128, 154)
     torch.cuda.synchronize()
     print("SD3 full-size step: loss %.5f, grad norm %.4e, peak %.1f GB" % (loss, gnorm, torch.cuda.max_memory_allocated() / 1e9))
 
 
-def _oracle_parity_one_sample(cfg, sd_cpu, W, dev):
+def _oracle_parity_one_sample(cfg, W, dev):
     """ONE sample at SD3-medium's real size (24 blocks x 1536, 4096 image + 154 text tokens) against the fp32 oracle
-    (oracle/mmdit_sd3.py): transformer forward without and with LoRA (rank 32, B ~ N(0, 0.05)).  Bound: rel-L2 <= 1.5e-2."""
+    (oracle/mmdit_sd3.py): transformer forward without and with LoRA (rank 32, B ~ N(0, 0.05)); the oracle's outputs come from
+    tests/golden/step_sd3_fullsize_one_sample.safetensors (tests/step_golden_cases.py::ref_sd3_one_sample).  Bound: rel-L2 <= 1.5e-2."""
     import json
     import os
-    import time
-    from oracle import mmdit_sd3 as O
+    import step_golden_cases as S
+    from golden_fixture import golden
     from pcm_amd.mmdit import MMDiT, sd3_lora_state
-    oc = O.MMDiTConfig.sd3_medium()
-    g = torch.Generator().manual_seed(7)
-    x, t = torch.randn(1, 16, 128, 128, generator=g), torch.tensor([640.5])
-    ctx, pooled = torch.randn(1, 154, 4096, generator=g), torch.randn(1, 2048, generator=g)
+    ref = golden("sd3_fullsize_one_sample", S.ref_sd3_one_sample)
+    ref_t, ref_s = ref["teacher"], ref["student"]
     lora = sd3_lora_state(cfg, 32, 8.0, dev, seed=3, b_std=0.05)
-    olora = {p: (m.A[:32].detach().cpu().clone(), m.B[:, :32].detach().cpu().clone()) for p, m in lora.modules.items()}
-    t0 = time.time()
-    with torch.no_grad():
-        ref_t = O.mmdit_forward(oc, sd_cpu, x, t, ctx, pooled)
-        ref_s = O.mmdit_forward(oc, sd_cpu, x, t, ctx, pooled, olora, 8.0)
-    cpu_s = time.time() - t0
-    a = [v.to(dev) for v in (x, t, ctx, pooled)]
+    a = [v.to(dev) for v in S.sd3_one_sample_inputs()]
     out_t = MMDiT(W, None).forward(*a).cpu()
     out_s = MMDiT(W, lora).forward(*a).cpu()
     rel = lambda u, v: float((u.double() - v.double()).norm() / v.double().norm())   # noqa: E731
-    rep = dict(teacher_rel_l2=rel(out_t, ref_t), student_rel_l2=rel(out_s, ref_s), lora_effect_rel=rel(ref_s, ref_t), oracle_seconds=cpu_s)
+    rep = dict(teacher_rel_l2=rel(out_t, ref_t), student_rel_l2=rel(out_s, ref_s), lora_effect_rel=rel(ref_s, ref_t), oracle_seconds=ref["oracle_seconds"])
     print("SD3 full-size oracle parity (1 sample):", rep)
     os.makedirs("gpurun_out", exist_ok=True)
     json.dump(rep, open("gpurun_out/sd3_fullsize_oracle_parity.json", "w"), indent=1)
