@@ -9,8 +9,11 @@
  *
  * Contract
  *  - plain pointers + sizes; the CALLER owns every buffer; the library never allocates or frees
- *    device memory and keeps no mutable global state (one immutable 16-byte zero page lives in
- *    the code object for out-of-bounds LDS-DMA lanes).
+ *    device memory.  Global state: one immutable 16-byte zero page in the code object (out-of-bounds
+ *    LDS-DMA lanes), once-only hipFuncSetAttribute flags, environment switches read once
+ *    (PCM_GEMM_BIG, PCM_GEMM_4W_MAXKT, PCM_GEMM_CONV_CO / _MD), and the pcm_debug_* tuning / test hooks
+ *    (tile forcing, kernel-family mode, last-plan read-back, ...) -- process-wide, not thread-safe,
+ *    used by tools/ and tests/ only; a product caller never touches them.
  *  - every call enqueues on `stream` (a hipStream_t passed as void*; torch's current stream)
  *    and returns without synchronising; safe under hipGraph stream capture.
  *  - return 0 on success, a negative PCM_E* code otherwise; never throws.  pcm_last_error()
@@ -41,8 +44,10 @@ extern "C" {
 #define PCM_ACT_SILU 1
 #define PCM_ACT_LEAKY 2 /* LeakyReLU(0.01): DiscriminatorHead, discriminator_sd15.py:354 */
 /* GEGLU fused into the projection (diffusers GEGLU.forward: hidden, gate = proj(x).chunk(2); hidden * gelu(gate)).
- * The weight rows (and bias) must be packed INTERLEAVED in groups of 8: [v0..v7, g0..g7, v8..v15, g8..g15, ...] (N = 2*inner
- * rows); the output has N/2 columns (ldo >= N/2).  No residual / row vector; bf16 output only.  Optional second output: pre_out. */
+ * The weight rows (and bias) must be packed INTERLEAVED in groups of 2: [v0, v1, g0, g1, v2, v3, g2, g3, ...] (N = 2*inner rows;
+ * abi >= 3 -- abi 2 interleaved in groups of 8): the four consecutive output channels one MFMA lane accumulates are then the two
+ * values and the two gates of one output pair, and value * gelu(gate) is formed in registers.  The output has N/2 columns
+ * (ldo >= N/2).  No residual / row vector; bf16 output only.  Optional second output: pre_out. */
 #define PCM_ACT_GEGLU 3
 
 const char* pcm_last_error(void);

@@ -1,3 +1,5 @@
+// pcm-build-flags: -mllvm -amdgpu-mfma-vgpr-form
+// (read by pcm_amd/build.py: MFMA results stay in VGPRs -- the softmax reads every accumulator; the AGPR form costs a v_accvgpr copy per value per tile)
 // Scaled-dot-product attention over latent tokens for the SD1.5 UNet (8 heads, head_dim 40/80/160,
 // Lq in {4096,1024,256,64}, Lk = Lq (self) or 77 (text)), flash-style: scores never leave the CU.
 //

@@ -1,3 +1,5 @@
+// (no pcm-build-flags line on purpose: this file is built with hipcc's default accumulator form; its VGPR / ACCVGPR variants are selected per
+// kernel inside the source, profiles/r03_b_attention_fwd_variants.txt)
 // Software-pipelined attention forward (SDPA over latent tokens; replaces F.scaled_dot_product_attention / xformers,
 // train_pcm_lora_sd15.py:947-957, for every forward of the step).
 //

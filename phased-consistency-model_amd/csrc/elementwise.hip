@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void geglu_fwd_kernel(const uint4* hg, uint4* 
     }
   }
 }
-// IL: the saved pre-activation is in the INTERLEAVED column order of the fused projection (8 values, their 8 gates, ...: pcm_hip.h
+// IL: the saved pre-activation is in the INTERLEAVED column order of the fused projection (2 values, their 2 gates, ...: pcm_hip.h
 // PCM_ACT_GEGLU with pre_out); the gradient is written in the standard [values | gates] order the dgrad / wgrad GEMMs expect
 template <bool IL>
 __global__ __launch_bounds__(256) void geglu_bwd_kernel(const uint4* hg, const uint4* dout, uint4* dhg, int M, int CV4, int ldp4) {
@@ -222,6 +222,11 @@ __global__ __launch_bounds__(256) void geglu_bwd_kernel(const uint4* hg, const u
       if (!ok[u]) continue;
       float h[8], g[8], d[8], dh[8], dg[8];
       ew_unpack8(hr[u], h); ew_unpack8(gr[u], g); ew_unpack8(dr[u], d);
+      if (IL) {   // 16 interleaved columns [v0 v1 g0 g1 | v2 v3 g2 g3 | v4 v5 g4 g5 | v6 v7 g6 g7] -> values h[0..7], gates g[0..7]
+        const float a[8] = {h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]}, b[8] = {g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7]};
+        h[0] = a[0]; h[1] = a[1]; h[2] = a[4]; h[3] = a[5]; h[4] = b[0]; h[5] = b[1]; h[6] = b[4]; h[7] = b[5];
+        g[0] = a[2]; g[1] = a[3]; g[2] = a[6]; g[3] = a[7]; g[4] = b[2]; g[5] = b[3]; g[6] = b[6]; g[7] = b[7];
+      }
 #pragma unroll
       for (int e = 0; e < 8; e++) { dh[e] = d[e] * gelu_erf_f(g[e]); dg[e] = d[e] * h[e] * gelu_erf_grad_f(g[e]); }
       uint4* q = dhg + (size_t)rr[u] * 2 * CV4 + cc[u];

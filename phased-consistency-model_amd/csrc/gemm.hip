@@ -363,7 +363,7 @@ extern "C" void pcm_debug_gemm_big_mode(int mode) { g_big_mode = mode; }
 static int g_conv_co = -1, g_conv_md = -1;    // -1: PCM_GEMM_CONV_CO / PCM_GEMM_CONV_MD env if set, else 0 (the shipped tap-outer / re-key path)
 extern "C" void pcm_debug_gemm_conv_order(int chunk_outer) { g_conv_co = chunk_outer < 0 ? -1 : (chunk_outer > 1 ? 2 : (chunk_outer ? 1 : 0)); }   // -1: default; 2: by shape
 extern "C" void pcm_debug_gemm_conv_md(int mask_delta) { g_conv_md = mask_delta < 0 ? -1 : (mask_delta ? 1 : 0); }
-static int g_ablate = 0;      // see PCM_ABL in gemm_dev.h (no effect in the product build)
+static int g_ablate = 0;      // see PCM_ABL in gemm_dev.h (no effect in the product build); bits 8.. = gemm4w start stagger override + 1
 extern "C" void pcm_debug_gemm_ablate(int mask) { g_ablate = mask; }
 static int g_last_plan = 0;   // tests only: 1000*big_fn + splitk of the most recent pcm_gemm_bf16 launch (gemm4w: 10000 + 1000*fn + 1)
 extern "C" int pcm_debug_last_gemm_plan(void) { return g_last_plan; }
@@ -375,11 +375,19 @@ static int big_mode() {
 extern "C" void pcm_debug_force_gemm_tile(int bm, int bn) { g_force_bm = bm; g_force_bn = bn; }
 
 // big_ok: the call satisfies gemm8p's preconditions (K%64==0 per segment, bf16 output with 16-B rows, < 2 GiB operands)
-// gemm4w.hip (two workgroups per CU) takes the short-K launches: plain segments only, K-loop of at most PCM_GEMM_4W_MAXKT 64-wide K-tiles
-// (default 21: K + r <= 1344, the launches whose algorithmic bytes at 8 TB/s outlast their flops at 2.5 PFLOP/s, plus the K = 1280 + 64 projections)
+// gemm4w.hip (two workgroups per CU, 128-row tiles).  Measured against gemm8p on every plain-segment launch of the bs-16 step
+// (profiles/r04_d_gemm_ab_libs_*.txt): with the shared epilogue it wins only on the fused-GEGLU feed-forward projections with K <= 384
+// (x0.91-0.93: their tile is epilogue-heavy and N = 8 x 320 gives 8192 small tiles to interleave); it loses 2-30 % elsewhere (twice the
+// weight traffic per flop, and the HBM-bound projections are bound by bytes, not by the missing overlap).  The planner follows that;
+// PCM_GEMM_4W_MAXKT (64-wide K-tiles incl. the LoRA segment, default 6) moves the boundary, PCM_GEMM_BIG=3 / 4 force it on / off.
 static int w4_max_kt() {
   static int v = -1;
-  if (v < 0) { const char* e = getenv("PCM_GEMM_4W_MAXKT"); v = e ? atoi(e) : 21; }
+  if (v < 0) { const char* e = getenv("PCM_GEMM_4W_MAXKT"); v = e ? atoi(e) : 6; }
+  return v;
+}
+static int w4_stagger_default() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("PCM_GEMM_4W_STAGGER"); v = e ? atoi(e) : 0; }
   return v;
 }
 static GemmPlan gemm_plan(int M, int N, int total_kt, bool allow_split, bool big_ok, bool must_big = false, bool w4_ok = false) {
@@ -394,7 +402,7 @@ static GemmPlan gemm_plan(int M, int N, int total_kt, bool allow_split, bool big
       const double useful = ((double)M * N) / ((double)tm * 128 * tn * bn);
       if (useful > best + 1e-9) { best = useful; best_fn = fn; }
     }
-    const bool take = big_mode() == 3 ? true : (total_kt <= w4_max_kt() && best >= 0.8 && (long)((M + 127) / 128) * ((N + 64 * best_fn - 1) / (64 * best_fn)) >= 256);
+    const bool take = big_mode() == 3 ? true : (must_big && total_kt <= w4_max_kt() && best >= 0.8 && (long)((M + 127) / 128) * ((N + 64 * best_fn - 1) / (64 * best_fn)) >= 1024);
     if (best_fn && take) {
       p.w4_fn = best_fn; p.BM = 128; p.BN = 64 * best_fn;
       p.tiles_m = (M + 127) / 128; p.tiles_n = (N + p.BN - 1) / p.BN;
@@ -532,15 +540,18 @@ extern "C" int pcm_gemm_bf16(const pcm_gemm_seg* segs, int nseg, const pcm_gemm_
   g.nseg = nseg; g.M = e->M; g.N = e->N; g.Ho = e->Ho > 0 ? e->Ho : 1; g.Wo = e->Wo > 0 ? e->Wo : 1;
   g.bias = e->bias; g.rowvec = (const bf16_t*)e->rowvec; g.rpb = e->rows_per_batch > 0 ? e->rows_per_batch : 1;
   g.res = (const bf16_t*)e->residual; g.ldr = e->ldr; g.out = e->out; g.ldo = e->ldo;
-  g.out_f32 = e->out_dtype == PCM_F32; g.act = e->act; g.alpha = e->alpha; g.dbg = g_ablate;
+  g.out_f32 = e->out_dtype == PCM_F32; g.act = e->act; g.alpha = e->alpha; g.dbg = g_ablate & 0xff;
+  g.w4_stagger = (g_ablate >> 8) ? (g_ablate >> 8) - 1 : w4_stagger_default();
   g.pre_out = (bf16_t*)e->pre_out; g.pre_rows = e->pre_out ? e->pre_rows : 0; g.ldp = e->ldp;
   // conv addressing / K order: explicit choice through the env / debug hooks, otherwise by shape (gemm8p.hip launcher)
   // default: the tap-outer order with the per-tap re-key everywhere.  PCM_GEMM_CONV_CO=2 / pcm_debug_gemm_conv_order(2) = chunk-outer BY SHAPE
   // (8x8 maps only): x1.12 on that launch alone with cold operands (round 2), but 117.5-117.7 vs 117.2-117.3 ms per bs-16 step in the
   // interleaved A/B of round 3 (profiles/r03_k_conv_order_by_shape_ab.txt) -- not taken.
-  int cco = g_conv_co, cmd = g_conv_md;
-  if (cco < 0 && getenv("PCM_GEMM_CONV_CO")) cco = atoi(getenv("PCM_GEMM_CONV_CO"));
-  if (cmd < 0 && getenv("PCM_GEMM_CONV_MD")) cmd = atoi(getenv("PCM_GEMM_CONV_MD")) ? 1 : 0;
+  // the environment is read ONCE (not per launch: ~5400 launches per eager step); -1 in g_conv_* = "the cached environment value", so the
+  // debug hooks can still override and reset
+  static const int env_co = getenv("PCM_GEMM_CONV_CO") ? atoi(getenv("PCM_GEMM_CONV_CO")) : 0;
+  static const int env_md = getenv("PCM_GEMM_CONV_MD") ? (atoi(getenv("PCM_GEMM_CONV_MD")) ? 1 : 0) : 0;
+  const int cco = g_conv_co < 0 ? env_co : g_conv_co, cmd = g_conv_md < 0 ? env_md : g_conv_md;
   g.conv_auto = cco == 2;
   g.conv_co = cco == 1; g.conv_md = cmd > 0 || cco == 1;
   if (e->N == 64 && nseg == 1 && segs[0].mode == PCM_SEG_CONV3X3) {   // conv LoRA down-projection: halo-window kernel where the geometry allows

@@ -19,9 +19,20 @@
 //   * epilogue: the fp32 tile goes through LDS in four 32-row passes for 16-B coalesced bf16 stores (bias, row vector, SiLU, residual,
 //     fused GEGLU with the optional pre-activation output) -- same per-piece code as gemm8p.
 #include "gemm_dev.h"
+#include "gemm_epilogue.h"
 
 #define PCM_RSRC_FLAGS 0x00020000
 #define PCM_OOB 0x80000000u
+
+// cycle stamps (tools/gemm4w_ablate.py, -DPCM_ABLATE builds only): lane 0 of every wave of ONE mid-grid tile records s_memtime at
+// {entry, first K-step landed, K loop done, after each epilogue pass}; slot 7 = HW_ID of the wave
+#ifdef PCM_ABLATE
+__device__ unsigned long long g_g4_stamps[4][8];
+extern "C" int pcm_debug_gemm4w_stamps(unsigned long long* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_g4_stamps), sizeof(g_g4_stamps)); }
+#define G4_STAMP(k) do { if (stamp_on && lane == 0) g_g4_stamps[wn][k] = __builtin_readcyclecounter(); } while (0)
+#else
+#define G4_STAMP(k) do { } while (0)
+#endif
 
 template <int FN>
 __global__ __launch_bounds__(256, 2) void pcm_gemm4w_kernel(GemmDev g) {
@@ -39,6 +50,22 @@ __global__ __launch_bounds__(256, 2) void pcm_gemm4w_kernel(GemmDev g) {
   }
   const int tile_n = bid % g.tiles_n, tile_m = bid / g.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
+#ifdef PCM_ABLATE
+  const bool stamp_on = blockIdx.x == gridDim.x / 2;
+#endif
+#ifndef PCM_HOST_EMU
+  if (g.w4_stagger > 0) {
+    // HW_REG_HW_ID (id 4): bits 19:16 = TG_ID, the slot of this workgroup on its CU.  The two co-resident workgroups of a CU hold slots of
+    // opposite parity; the odd one starts late, which turns "both in their MFMA phases, then both in their epilogues" into alternation.
+    const unsigned hwid = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+#ifdef PCM_ABLATE
+    if (stamp_on && lane == 0) g_g4_stamps[wn][7] = hwid;
+#endif
+    if ((hwid >> 16) & 1)
+      for (int i = 0; i < g.w4_stagger; i++) __builtin_amdgcn_s_sleep(32);
+  }
+#endif
+  G4_STAMP(0);
 
   // ---- loader: lane -> row lane>>2 of a 16-row group, 16-B slot lane&3; this wave owns groups wn + 4j of both operands
   const int lrow = lane >> 2;
@@ -60,7 +87,9 @@ __global__ __launch_bounds__(256, 2) void pcm_gemm4w_kernel(GemmDev g) {
       w_voff[j] = n < g.N ? (unsigned)n * (unsigned)(cs.K * 2) + csw16 : PCM_OOB;
     }
   };
+  bool dma_on = true;
   auto issue = [&](int stage) {
+    if (PCM_ABL(8) && !dma_on) { it_k++; return; }
     __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)cs.a, 0, PCM_OOB, PCM_RSRC_FLAGS);
     __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)cs.w, 0, PCM_OOB, PCM_RSRC_FLAGS);
     char* dst = smem + stage * STAGE + wn * 1024;
@@ -91,6 +120,8 @@ __global__ __launch_bounds__(256, 2) void pcm_gemm4w_kernel(GemmDev g) {
     PCM_WAIT_VMCNT(0);
   }
   __builtin_amdgcn_s_barrier();
+  G4_STAMP(1);
+  dma_on = false;
 
   // fragment reads: lane (frow = lane&15, fk = lane>>4) reads row base+frow, logical 16-B chunk fk (k = 8*fk .. 8*fk+7); every base is a
   // multiple of 16, so the swizzle key depends on frow only
@@ -109,6 +140,7 @@ __global__ __launch_bounds__(256, 2) void pcm_gemm4w_kernel(GemmDev g) {
     __builtin_amdgcn_sched_barrier(0);
     if (t + 2 < T) issue(t & 1);
     __builtin_amdgcn_s_setprio(1);
+    if (!PCM_ABL(4))
 #pragma unroll
     for (int i = 0; i < 8; i++)
 #pragma unroll
@@ -124,92 +156,21 @@ __global__ __launch_bounds__(256, 2) void pcm_gemm4w_kernel(GemmDev g) {
     __builtin_amdgcn_sched_barrier(0);
   }
 
+  G4_STAMP(2);
+  if (PCM_ABL(2)) { if (g.alpha != 123456.f) return; }
   // ---- epilogue.  lane owns pixel row (lane&15) of a fragment and 4 consecutive channels 4*(lane>>4)+r.
-  // 32 rows x BN fp32 per pass through LDS (the K-loop stages are dead) so that the global side is whole 16-B pieces of rows
-  constexpr int CH = BN / 4, C8 = BN / 8;
-#pragma unroll
-  for (int q = 0; q < 4; q++) {
-    if (q) __syncthreads();
-#pragma unroll
-    for (int ii = 0; ii < 2; ii++) {
-      const int lr = 16 * ii + frow;
-#pragma unroll
-      for (int f = 0; f < FN; f++) {
-        const int ch = (WNC / 4) * wn + 4 * f + fk;
-        const f32x4 a = acc[2 * q + ii][f];
-        *(float4*)(smem + ((size_t)lr * CH + (ch ^ (lr & 15))) * 16) = make_float4(a[0] * g.alpha, a[1] * g.alpha, a[2] * g.alpha, a[3] * g.alpha);
-      }
-    }
-    __syncthreads();
-    if (g.act == PCM_ACT_GEGLU) {   // 16 packed columns = 8 values + their 8 gates -> 8 outputs
-      constexpr int C16 = BN / 16;
-      for (int idx = tid; idx < 32 * C16; idx += 256) {
-        const int lr = idx / C16, c16 = idx - lr * C16;
-        const int m = m0 + 32 * q + lr, n = n0 + 16 * c16;
-        if (m >= g.M || n >= g.N) continue;
-        float vv[16];
-#pragma unroll
-        for (int c = 0; c < 4; c++) {
-          const float4 t4 = *(const float4*)(smem + ((size_t)lr * CH + ((4 * c16 + c) ^ (lr & 15))) * 16);
-          vv[4 * c] = t4.x; vv[4 * c + 1] = t4.y; vv[4 * c + 2] = t4.z; vv[4 * c + 3] = t4.w;
-        }
-        if (g.bias) {
-#pragma unroll
-          for (int e = 0; e < 16; e++) vv[e] += g.bias[n + e];
-        }
-        if (g.pre_out && m < g.pre_rows) {   // what the backward of GEGLU needs: the pre-activation, in this (interleaved) column order
-          uint4* pp = (uint4*)(g.pre_out + (size_t)m * g.ldp + n);
-          pp[0] = make_uint4(pack_bf2(vv[0], vv[1]), pack_bf2(vv[2], vv[3]), pack_bf2(vv[4], vv[5]), pack_bf2(vv[6], vv[7]));
-          pp[1] = make_uint4(pack_bf2(vv[8], vv[9]), pack_bf2(vv[10], vv[11]), pack_bf2(vv[12], vv[13]), pack_bf2(vv[14], vv[15]));
-        }
-        float o[8];
-#pragma unroll
-        for (int e = 0; e < 8; e++) o[e] = vv[e] * gelu_erf_f(vv[8 + e]);
-        *(uint4*)((bf16_t*)g.out + (size_t)m * g.ldo + (n >> 1)) = make_uint4(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]), pack_bf2(o[4], o[5]), pack_bf2(o[6], o[7]));
-      }
-      continue;
-    }
-    constexpr int IT = 32 * C8 / 256;
-    static_assert(IT * 256 == 32 * C8, "store loop covers the pass exactly");
-    if (g.res || g.rowvec) {
-      // residual / row-vector pieces: the global loads of two pieces in flight before the first is consumed (gemm8p.hip, same trade)
-      for (int it0 = 0; it0 < IT; it0 += 2) {
-        EpiAux aux[2];
-#pragma unroll
-        for (int u = 0; u < 2; u++) {
-          const int idx = tid + 256 * (it0 + u);
-          const int lr = idx / C8, c8 = idx - lr * C8;
-          const int m = m0 + 32 * q + lr, n = n0 + 8 * c8;
-          if (it0 + u < IT && m < g.M && n < g.N) aux[u] = pcm_epi_load8(g, m, n);
-        }
-#pragma unroll
-        for (int u = 0; u < 2; u++) {
-          const int idx = tid + 256 * (it0 + u);
-          const int lr = idx / C8, c8 = idx - lr * C8;
-          const int m = m0 + 32 * q + lr, n = n0 + 8 * c8;
-          if (it0 + u >= IT || m >= g.M || n >= g.N) continue;
-          const float4 lo = *(const float4*)(smem + ((size_t)lr * CH + ((2 * c8) ^ (lr & 15))) * 16);
-          const float4 hi4 = *(const float4*)(smem + ((size_t)lr * CH + ((2 * c8 + 1) ^ (lr & 15))) * 16);
-          float v[8] = {lo.x, lo.y, lo.z, lo.w, hi4.x, hi4.y, hi4.z, hi4.w};
-          pcm_epi_finish8(g, m, n, v, aux[u]);
-        }
-      }
-      continue;
-    }
-    for (int idx = tid; idx < 32 * C8; idx += 256) {
-      const int lr = idx / C8, c8 = idx - lr * C8;
-      const int m = m0 + 32 * q + lr, n = n0 + 8 * c8;
-      if (m >= g.M || n >= g.N) continue;
-      const float4 lo = *(const float4*)(smem + ((size_t)lr * CH + ((2 * c8) ^ (lr & 15))) * 16);
-      const float4 hi4 = *(const float4*)(smem + ((size_t)lr * CH + ((2 * c8 + 1) ^ (lr & 15))) * 16);
-      float v[8] = {lo.x, lo.y, lo.z, lo.w, hi4.x, hi4.y, hi4.z, hi4.w};
-      pcm_epi_store8(g, m, n, v);
-    }
-  }
+  // four passes of 32 rows x BN fp32 through LDS (the K-loop stages are dead; the loop's last barrier already separates them from the
+  // fragment reads), shared with gemm8p.hip: gemm_epilogue.h
+  PcmEpi<FN, 1>::run(g, smem, acc, tid, 0, wn, m0, n0, false);
+  G4_STAMP(6);
 #endif
 }
 
-size_t pcm_gemm4w_lds_bytes(int fn) { return 2 * (size_t)(128 + 64 * fn) * 64; }
+// two K stages, or the bf16 staging of the fused-GEGLU epilogue (64 rows of outputs + pre-activations), whichever is larger
+size_t pcm_gemm4w_lds_bytes(int fn) {
+  const size_t kloop = 2 * (size_t)(128 + 64 * fn) * 64, geglu = fn == 5 ? PcmEpi<5, 1>::geglu_lds_bytes() : PcmEpi<4, 1>::geglu_lds_bytes();
+  return kloop > geglu ? kloop : geglu;
+}
 
 template <int FN>
 static int launch4w(const GemmDev& g, void* stream) {

@@ -19,6 +19,7 @@
 // Sources are addressed through raw buffer resources: per-row 32-bit byte offsets in VGPRs, the K advance in the
 // scalar offset; out-of-range rows / padding taps use an offset beyond num_records, which the hardware zero-fills.
 #include "gemm_dev.h"
+#include "gemm_epilogue.h"
 
 // cycle stamps (tools/gemm8p_timeline.py, -DPCM_ABLATE builds only): lane 0 of every wave of ONE mid-grid tile records s_memtime at three
 // points of each phase (start | fragment reads retired + barrier passed | MFMAs issued + closing barrier passed) for its first 16 K-tiles
@@ -388,92 +389,8 @@ __global__ __launch_bounds__(512) void pcm_gemm8p_kernel(GemmDev g) {
     }
     return;
   }
-  // stage 64 rows x BN fp32 per pass through LDS (K-loop buffers are dead) so the global side is whole 16-B pieces of rows
-  constexpr int CH = BN / 4, C8 = BN / 8;
-#pragma unroll
-  for (int q = 0; q < 4; q++) {
-    __syncthreads();
-#pragma unroll
-    for (int ii = 0; ii < 2; ii++) {
-      const int lr = 32 * wm + 16 * ii + frow;
-#pragma unroll
-      for (int f = 0; f < FN; f++) {
-        const int ch = (WNC / 4) * wn + 4 * f + fk;
-        const f32x4 a = acc[2 * q + ii][f];
-        *(float4*)(smem + ((size_t)lr * CH + (ch ^ (lr & 15))) * 16) = make_float4(a[0] * g.alpha, a[1] * g.alpha, a[2] * g.alpha, a[3] * g.alpha);
-      }
-    }
-    __syncthreads();
-    if (g.act == PCM_ACT_GEGLU) {   // 16 packed columns = 8 values + their 8 gates -> 8 outputs
-      constexpr int C16 = BN / 16;
-      for (int idx = tid; idx < 64 * C16; idx += 512) {
-        const int lr = idx / C16, c16 = idx - lr * C16;
-        const int m = m0 + 128 * (lr >> 5) + 32 * q + (lr & 31), n = n0 + 16 * c16;
-        if (m >= g.M || n >= g.N) continue;
-        float vv[16];
-#pragma unroll
-        for (int c = 0; c < 4; c++) {
-          const float4 t4 = *(const float4*)(smem + ((size_t)lr * CH + ((4 * c16 + c) ^ (lr & 15))) * 16);
-          vv[4 * c] = t4.x; vv[4 * c + 1] = t4.y; vv[4 * c + 2] = t4.z; vv[4 * c + 3] = t4.w;
-        }
-        if (g.bias) {
-#pragma unroll
-          for (int e = 0; e < 16; e++) vv[e] += g.bias[n + e];
-        }
-        if (g.pre_out && m < g.pre_rows) {   // what the backward of GEGLU needs: the pre-activation, in this (interleaved) column order
-          uint4* pp = (uint4*)(g.pre_out + (size_t)m * g.ldp + n);
-          pp[0] = make_uint4(pack_bf2(vv[0], vv[1]), pack_bf2(vv[2], vv[3]), pack_bf2(vv[4], vv[5]), pack_bf2(vv[6], vv[7]));
-          pp[1] = make_uint4(pack_bf2(vv[8], vv[9]), pack_bf2(vv[10], vv[11]), pack_bf2(vv[12], vv[13]), pack_bf2(vv[14], vv[15]));
-        }
-        float o[8];
-#pragma unroll
-        for (int e = 0; e < 8; e++) o[e] = vv[e] * gelu_erf_f(vv[8 + e]);
-        *(uint4*)((bf16_t*)g.out + (size_t)m * g.ldo + (n >> 1)) = make_uint4(pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]), pack_bf2(o[4], o[5]), pack_bf2(o[6], o[7]));
-      }
-      continue;
-    }
-    if (g.res || g.rowvec) {
-      // pieces with a residual / row-vector operand: two pieces per trip, their global loads issued before the first is consumed (one
-      // after the other every piece pays the full load latency: 0.93x on the residual-carrying projections, tools/gemm_ab_libs.py).
-      // Deeper unrolling spills (the accumulators of the later passes are still live), and pieces without such operands lose 5-10 %
-      // to the longer code, so they keep the plain loop below.
-      constexpr int IT = 64 * C8 / 512;
-      static_assert(IT * 512 == 64 * C8, "store loop covers the pass exactly");
-      for (int it0 = 0; it0 < IT; it0 += 2) {
-        EpiAux aux[2];
-#pragma unroll
-        for (int u = 0; u < 2; u++) {
-          const int idx = tid + 512 * (it0 + u);
-          const int lr = idx / C8, c8 = idx - lr * C8;
-          const int m = m0 + 128 * (lr >> 5) + 32 * q + (lr & 31), n = n0 + 8 * c8;
-          if (it0 + u < IT && m < g.M && n < g.N) aux[u] = pcm_epi_load8(g, m, n);
-        }
-#pragma unroll
-        for (int u = 0; u < 2; u++) {
-          const int idx = tid + 512 * (it0 + u);
-          const int lr = idx / C8, c8 = idx - lr * C8;
-          const int m = m0 + 128 * (lr >> 5) + 32 * q + (lr & 31), n = n0 + 8 * c8;
-          if (it0 + u >= IT || m >= g.M || n >= g.N) continue;
-          const float4 lo = *(const float4*)(smem + ((size_t)lr * CH + ((2 * c8) ^ (lr & 15))) * 16);
-          const float4 hi4 = *(const float4*)(smem + ((size_t)lr * CH + ((2 * c8 + 1) ^ (lr & 15))) * 16);
-          float v[8] = {lo.x, lo.y, lo.z, lo.w, hi4.x, hi4.y, hi4.z, hi4.w};
-          if (PCM_ABL(1)) { if (v[0] != 123456.f) continue; }
-          pcm_epi_finish8(g, m, n, v, aux[u]);
-        }
-      }
-      continue;
-    }
-    for (int idx = tid; idx < 64 * C8; idx += 512) {
-      const int lr = idx / C8, c8 = idx - lr * C8;
-      const int m = m0 + 128 * (lr >> 5) + 32 * q + (lr & 31), n = n0 + 8 * c8;
-      if (m >= g.M || n >= g.N) continue;
-      const float4 lo = *(const float4*)(smem + ((size_t)lr * CH + ((2 * c8) ^ (lr & 15))) * 16);
-      const float4 hi4 = *(const float4*)(smem + ((size_t)lr * CH + ((2 * c8 + 1) ^ (lr & 15))) * 16);
-      float v[8] = {lo.x, lo.y, lo.z, lo.w, hi4.x, hi4.y, hi4.z, hi4.w};
-      if (PCM_ABL(1)) { if (v[0] != 123456.f) continue; }
-      pcm_epi_store8(g, m, n, v);
-    }
-  }
+  // four passes of 64 rows x BN fp32 through LDS (the K-loop buffers are dead), shared with gemm4w.hip: gemm_epilogue.h
+  PcmEpi<FN, 2>::run(g, smem, acc, tid, wm, wn, m0, n0, true);
 #endif
 }
 

@@ -26,6 +26,8 @@ struct GemmDev {
   bf16_t* pre_out;            // PCM_ACT_GEGLU: optional second output, the interleaved pre-activation of rows < pre_rows (row stride ldp)
   int pre_rows, ldp;
   int dbg;                    // ablation mask: only read by -DPCM_ABLATE builds (tools/probes/build_ablate.py), 0 otherwise
+  int w4_stagger;             // gemm4w.hip: start delay (units of ~0.85 us) of the odd-numbered workgroup slot of a CU, so that the two
+                              // co-resident workgroups do not run their MFMA and their epilogue phases in lockstep; 0 = none
 };
 // timing ablations for tools/gemm8p_ablate.py (results are wrong by construction): 1 = no global stores in the epilogue, 2 = no epilogue,
 // 4 = no MFMAs, 8 = no LDS-DMA after the prologue.  Compiled out of the product library.

@@ -1,0 +1,182 @@
+// Fused epilogue of the 128-row-per-wave tiles (gemm8p.hip: 256 x (64*FN), 8 waves as 2 x 4; gemm4w.hip: 128 x (64*FN), 4 waves as 1 x 4).
+// A lane holds, per 16x16 accumulator (i, f), pixel row 16*i + (lane & 15) of its wave's 128 rows and channels 16*f + 4*(lane >> 4) .. +3.
+// The fp32 tile goes through LDS in four passes of 32*WM rows (the K-loop stages are dead) so that the global side is whole 16-B pieces of
+// rows: bias, per-image row vector (time embedding), SiLU, residual, fused GEGLU (+ optional pre-activation output), bf16 stores.
+//
+// Round 4 (measured with the stamps / ablations of tools/gemm4w_ablate.py, profiles/r04_b_*): the 4 passes of a short-K tile took 2-3x its
+// K loop, and the stores were NOT the cost ("no global stores" changed nothing on the GEGLU projections).  What was:
+//   * bias was re-loaded from global memory for every 8 / 16-column piece (16 scalar loads per GEGLU piece: 160 gather instructions per
+//     thread and tile through the texture path).  Now BN/4 threads load the tile's bias row ONCE into LDS (behind the staging area) and the
+//     pieces read it from there (alpha * acc, then + bias: the same fp32 operations in the same order as before).
+//   * residual pieces were loaded two at a time inside the piece loop: ~3 exposed HBM round trips per pass, 12 per tile.  Now piece `it` of
+//     pass q+1 is requested as soon as piece `it` of pass q has been consumed (ONE register set of 5 pieces per thread: a second set
+//     spilled the 256 x 320 tile): the load flies under the rest of the pass and the next staging.  x0.90-0.97 on the residual-carrying
+//     projections; epilogues without a residual keep the plain piece loop (the unrolled form cost them 3-15 %: profiles/r04_c_*).
+#pragma once
+#include "gemm_dev.h"
+
+// one residual OR row-vector operand piece (the epilogues that carry both keep the in-loop loads for the second one)
+template <int FN, int WM>
+struct PcmEpi {
+  static constexpr int WNC = 16 * FN, BN = 4 * WNC, ROWS = 32 * WM, NT = 256 * WM;
+  static constexpr int CH = BN / 4, C8 = BN / 8, C16 = BN / 16;
+  static constexpr int IT = ROWS * C8 / NT;            // 16-B output pieces per thread and pass
+  static_assert(IT * NT == ROWS * C8, "store loop covers the pass exactly");
+
+  // row / column of piece `it` of this thread in pass q
+  static __device__ __forceinline__ void piece(int tid, int it, int q, int m0, int n0, int& lr, int& c8, int& m, int& n) {
+    const int idx = tid + NT * it;
+    lr = idx / C8; c8 = idx - lr * C8;
+    m = m0 + 128 * (lr >> 5) + 32 * q + (lr & 31); n = n0 + 8 * c8;
+  }
+
+  static __device__ __forceinline__ uint4 fetch(const GemmDev& g, const bf16_t* src, bool is_res, int tid, int it, int q, int m0, int n0) {
+    int lr, c8, m, n;
+    piece(tid, it, q, m0, n0, lr, c8, m, n);
+    if (m >= g.M || n >= g.N) return make_uint4(0u, 0u, 0u, 0u);
+    return is_res ? *(const uint4*)(src + (size_t)m * g.ldr + n) : *(const uint4*)(src + (size_t)(m / g.rpb) * g.N + n);
+  }
+
+  // ---- fused GEGLU, in registers.  The packed weight rows are interleaved in groups of 2 (pcm_hip.h PCM_ACT_GEGLU): columns 4p .. 4p+3 of
+  // the GEMM are [value 2p, value 2p+1, gate 2p, gate 2p+1], i.e. ONE lane's four accumulator elements hold both values and both gates of
+  // output pair p -- no LDS round trip to bring them together.  out = v * gelu_erf(g) is packed to bf16 at once; the bf16 tile (half the
+  // columns, half the bytes per element: 1/4 of the fp32 staging traffic) goes through LDS in two 64-row passes for 16-B coalesced
+  // stores, together with the bf16 pre-activation tile when the caller keeps it for the backward.
+  // (round 4: the previous form staged fp32, then ran value * gelu(gate) per 16-column piece in a serial per-thread loop: 2/3 of the
+  //  tile time of the K = 320 feed-forward projection, tools/gemm4w_ablate.py.)
+  static constexpr int OUT_STRIDE = BN + 16, PRE_STRIDE = 2 * BN + 16;      // bytes per staged row (+16: bank spread of the 4-B / 8-B writes)
+  static constexpr int GROWS = 64 * WM;                                     // rows per GEGLU pass
+  static constexpr size_t geglu_lds_bytes() { return (size_t)GROWS * (OUT_STRIDE + PRE_STRIDE); }
+  template <typename Acc>
+  static __device__ __forceinline__ void run_geglu(const GemmDev& g, char* smem, const Acc& acc, int tid, int wm, int wn, int m0, int n0, bool sync_first) {
+    const int lane = tid & 63, frow = lane & 15, fk = lane >> 4;
+    char* pre_lds = smem + (size_t)GROWS * OUT_STRIDE;
+    f32x4 bq[FN];
+#pragma unroll
+    for (int f = 0; f < FN; f++) {
+      const int n = n0 + WNC * wn + 16 * f + 4 * fk;
+      const float4 b4 = (g.bias && n < g.N) ? *(const float4*)(g.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+      bq[f] = f32x4{b4.x, b4.y, b4.z, b4.w};
+    }
+    const bool keep_pre = g.pre_out != nullptr;
+    constexpr int OC = BN / 16, PC = BN / 8;          // 16-B pieces per staged row: outputs / pre-activations
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      if (q || sync_first) __syncthreads();
+#pragma unroll
+      for (int ii = 0; ii < 4; ii++) {
+        const int lr = 64 * wm + 16 * ii + frow;
+#pragma unroll
+        for (int f = 0; f < FN; f++) {
+          const f32x4 a = acc[4 * q + ii][f] * g.alpha + bq[f];
+          const unsigned o = pack_bf2(a[0] * gelu_erf_f(a[2]), a[1] * gelu_erf_f(a[3]));
+          *(unsigned*)(smem + (size_t)lr * OUT_STRIDE + 2 * (WNC / 2) * wn + 16 * f + 4 * fk) = o;
+          if (keep_pre) *(uint2*)(pre_lds + (size_t)lr * PRE_STRIDE + 2 * WNC * wn + 32 * f + 8 * fk) = make_uint2(pack_bf2(a[0], a[1]), pack_bf2(a[2], a[3]));
+        }
+      }
+      __syncthreads();
+      for (int idx = tid; idx < GROWS * OC; idx += NT) {
+        const int lr = idx / OC, c = idx - lr * OC;
+        const int m = m0 + 128 * (lr >> 6) + 64 * q + (lr & 63), n = n0 + 16 * c;
+        if (m >= g.M || n >= g.N) continue;
+        if (PCM_ABL(1)) { if (g.alpha == 123456.f) continue; }
+        *(uint4*)((bf16_t*)g.out + (size_t)m * g.ldo + (n >> 1)) = *(const uint4*)(smem + (size_t)lr * OUT_STRIDE + 16 * c);
+      }
+      if (keep_pre)      // what the backward of GEGLU needs: the pre-activation of rows < pre_rows, in the interleaved column order
+        for (int idx = tid; idx < GROWS * PC; idx += NT) {
+          const int lr = idx / PC, c = idx - lr * PC;
+          const int m = m0 + 128 * (lr >> 6) + 64 * q + (lr & 63), n = n0 + 8 * c;
+          if (m >= g.M || m >= g.pre_rows || n >= g.N) continue;
+          *(uint4*)(g.pre_out + (size_t)m * g.ldp + n) = *(const uint4*)(pre_lds + (size_t)lr * PRE_STRIDE + 16 * c);
+        }
+    }
+  }
+
+  template <typename Acc>
+  static __device__ __forceinline__ void run(const GemmDev& g, char* smem, const Acc& acc, int tid, int wm, int wn, int m0, int n0, bool sync_first) {
+#ifndef PCM_HOST_EMU
+    // the piece geometry below is a function of tid only: opaque copies keep hipcc from computing it (or anything shared with it) ahead of
+    // the K loop and carrying it through the loop -- the 256 x 320 tile has no register to spare there (measured: 60+ spills, reloads inside
+    // the K loop, without this)
+    asm volatile("" : "+v"(tid));
+    asm volatile("" : "+s"(m0), "+s"(n0));
+#endif
+    if (g.act == PCM_ACT_GEGLU) { run_geglu(g, smem, acc, tid, wm, wn, m0, n0, sync_first); return; }
+    const int lane = tid & 63, frow = lane & 15, fk = lane >> 4;
+    // residual pieces are requested a pass ahead of their use (one register set of IT pieces; a row vector rides in the loop: L2-resident)
+    const bool pf_on = g.res != nullptr;
+    uint4 pf[IT];
+#pragma unroll
+    for (int it = 0; it < IT; it++) pf[it] = pf_on ? fetch(g, g.res, true, tid, it, 0, m0, n0) : make_uint4(0u, 0u, 0u, 0u);
+    // the tile's BN bias values: ONE global load by BN/4 threads, kept in LDS behind the staging area for all four passes
+    float4* bias_lds = (float4*)(smem + (size_t)ROWS * CH * 16);
+    float4 b_mine = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < BN / 4 && g.bias && n0 + 4 * tid < g.N) b_mine = *(const float4*)(g.bias + n0 + 4 * tid);
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      if (q || sync_first) __syncthreads();
+#pragma unroll
+      for (int ii = 0; ii < 2; ii++) {
+        const int lr = 32 * wm + 16 * ii + frow;
+#pragma unroll
+        for (int f = 0; f < FN; f++) {
+          const int ch = (WNC / 4) * wn + 4 * f + fk;
+          const f32x4 a = acc[2 * q + ii][f] * g.alpha;
+          *(float4*)(smem + ((size_t)lr * CH + (ch ^ (lr & 15))) * 16) = make_float4(a[0], a[1], a[2], a[3]);
+        }
+      }
+      if (q == 0 && tid < BN / 4) bias_lds[tid] = b_mine;
+      __syncthreads();
+      if (pf_on) {
+#pragma unroll
+        for (int it = 0; it < IT; it++) {
+          int lr, c8, m, n;
+          piece(tid, it, q, m0, n0, lr, c8, m, n);
+          const uint4 px = pf[it];
+          if (q < 3) pf[it] = fetch(g, g.res, true, tid, it, q + 1, m0, n0);    // the same piece of the next pass, a pass ahead
+          if (m >= g.M || n >= g.N) continue;
+          const float4 lo = *(const float4*)(smem + ((size_t)lr * CH + ((2 * c8) ^ (lr & 15))) * 16);
+          const float4 hi4 = *(const float4*)(smem + ((size_t)lr * CH + ((2 * c8 + 1) ^ (lr & 15))) * 16);
+          float v[8] = {lo.x, lo.y, lo.z, lo.w, hi4.x, hi4.y, hi4.z, hi4.w};
+          if (PCM_ABL(1)) { if (v[0] != 123456.f) continue; }
+          finish(g, bias_lds, m, n, c8, v, px);
+        }
+        continue;
+      }
+      for (int idx = tid; idx < ROWS * C8; idx += NT) {
+        const int lr = idx / C8, c8 = idx - lr * C8;
+        const int m = m0 + 128 * (lr >> 5) + 32 * q + (lr & 31), n = n0 + 8 * c8;
+        if (m >= g.M || n >= g.N) continue;
+        const float4 lo = *(const float4*)(smem + ((size_t)lr * CH + ((2 * c8) ^ (lr & 15))) * 16);
+        const float4 hi4 = *(const float4*)(smem + ((size_t)lr * CH + ((2 * c8 + 1) ^ (lr & 15))) * 16);
+        float v[8] = {lo.x, lo.y, lo.z, lo.w, hi4.x, hi4.y, hi4.z, hi4.w};
+        if (PCM_ABL(1)) { if (v[0] != 123456.f) continue; }
+        finish(g, bias_lds, m, n, c8, v, make_uint4(0u, 0u, 0u, 0u));
+      }
+    }
+  }
+
+  // bias (LDS copy of the tile's bias row), row vector, SiLU, residual (already loaded: ``res``), one 16-B bf16 store
+  static __device__ __forceinline__ void finish(const GemmDev& g, const float4* bias_lds, int m, int n, int c8, float (&v)[8], const uint4 res) {
+    if (g.bias) {
+      const float4 b0 = bias_lds[2 * c8], b1 = bias_lds[2 * c8 + 1];
+      v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+    }
+    if (g.rowvec) {
+      const uint4 t = *(const uint4*)(g.rowvec + (size_t)(m / g.rpb) * g.N + n);
+      const unsigned tw[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+      for (int e = 0; e < 4; e++) { v[2 * e] += bf2f((bf16_t)(tw[e] & 0xffff)); v[2 * e + 1] += bf2f((bf16_t)(tw[e] >> 16)); }
+    }
+    if (g.act == PCM_ACT_SILU) {
+#pragma unroll
+      for (int e = 0; e < 8; e++) v[e] = silu_f(v[e]);
+    }
+    if (g.res) {
+      const unsigned tw[4] = {res.x, res.y, res.z, res.w};
+#pragma unroll
+      for (int e = 0; e < 4; e++) { v[2 * e] += bf2f((bf16_t)(tw[e] & 0xffff)); v[2 * e + 1] += bf2f((bf16_t)(tw[e] >> 16)); }
+    }
+    *(uint4*)((bf16_t*)g.out + (size_t)m * g.ldo + n) = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+  }
+};

@@ -36,4 +36,4 @@ void pcm_zero_async(void* p, size_t bytes, void* stream) {
 }
 
 extern "C" const char* pcm_last_error(void) { return g_err; }
-extern "C" int pcm_abi_version(void) { return 2; }   // 2: pcm_gemm_epi gained pre_out / pre_rows / ldp (PCM_ACT_GEGLU second output)
+extern "C" int pcm_abi_version(void) { return 3; }   // 2: pcm_gemm_epi gained pre_out / pre_rows / ldp (PCM_ACT_GEGLU second output); 3: PCM_ACT_GEGLU rows interleaved in groups of 2 (was 8)

@@ -12,9 +12,20 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libpcm_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
-# per-file extras.  attention: keep MFMA results in VGPRs (gfx950 register file is unified) -- the softmax reads
-# every accumulator, and the AGPR form costs a v_accvgpr_read/write per value per tile
-EXTRA = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+# per-file extras are declared IN the source: a line `// pcm-build-flags: <flags>` in the first 40 lines (attention*.hip: keep MFMA
+# results in VGPRs -- the softmax reads every accumulator, and the AGPR form costs a v_accvgpr_read/write per value per tile)
+MARKER = "// pcm-build-flags:"
+
+
+def extra_flags(src):
+    out = []
+    with open(src) as f:
+        for i, line in enumerate(f):
+            if i >= 40:
+                break
+            if line.startswith(MARKER):
+                out += line[len(MARKER):].split()
+    return out
 
 
 def _stale(out, deps):
@@ -33,7 +44,7 @@ def build(force=False, verbose=False):
         o = os.path.join(objdir, os.path.basename(s)[:-4] + ".o")
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            jobs.append([HIPCC] + FLAGS + EXTRA.get(os.path.basename(s), []) + ["-c", s, "-o", o])
+            jobs.append([HIPCC] + FLAGS + extra_flags(s) + ["-c", s, "-o", o])
 
     def run(cmd):
         if verbose:

@@ -27,6 +27,16 @@ BF16 = torch.bfloat16
 # ----------------------------------------------------------------------------------------------
 # frozen base weights, packed
 # ----------------------------------------------------------------------------------------------
+GEGLU_GROUP = 2     # interleave granularity of the fused-GEGLU operands (include/pcm_hip.h, PCM_ACT_GEGLU)
+
+
+def geglu_perm(inner, device="cpu"):
+    """row order of the interleaved [values | gates] projection: G values, their G gates, the next G values, ..."""
+    j = torch.arange(inner // GEGLU_GROUP, device=device)
+    e = torch.arange(GEGLU_GROUP, device=device)
+    return torch.stack([(GEGLU_GROUP * j)[:, None] + e, inner + (GEGLU_GROUP * j)[:, None] + e], 1).reshape(-1)
+
+
 class PackedLayer:
     """One Linear / conv1x1 / conv3x3 of the base model in MFMA operand layouts."""
     __slots__ = ("kind", "N", "K", "C", "w_fwd", "w_bwd", "bias", "w_geglu", "bias_geglu")
@@ -46,12 +56,10 @@ class PackedLayer:
         self.w_geglu = self.bias_geglu = None
 
     def pack_geglu(self):
-        """Extra forward operand for the fused GEGLU epilogue (PCM_ACT_GEGLU): rows interleaved [8 values, 8 gates, ...].
-        Built from the packed bf16 rows (a row permutation), used by the no-grad LoRA-free (teacher) pass."""
+        """Extra forward operand for the fused GEGLU epilogue (PCM_ACT_GEGLU): rows interleaved [2 values, their 2 gates, ...] so that the
+        four consecutive channels one MFMA lane accumulates are one output pair's values and gates.  A row permutation of the packed bf16 rows."""
         inner = self.N // 2
-        j = torch.arange(inner // 8, device=self.w_fwd.device)
-        e = torch.arange(8, device=self.w_fwd.device)
-        perm = torch.stack([(8 * j)[:, None] + e, inner + (8 * j)[:, None] + e], 1).reshape(-1)
+        perm = geglu_perm(inner, self.w_fwd.device)
         self.w_geglu = self.w_fwd.view(self.N, self.K)[perm].contiguous()
         self.bias_geglu = None if self.bias is None else self.bias[perm].contiguous()
 
@@ -219,12 +227,12 @@ class LoraState:
                 descs.append((oa, o_af, o_ab, r, m.K, m.K, m.K, r, 1.0))               # A [r][K] -> copy + A^T [K][r]
             descs.append((ob, o_bf, o_bb, m.N, r, r, r, m.N, self.scaling))             # s*B [N][r] -> copy + transpose [r][N]
             if path.endswith("ff.net.0.proj") and m.kind == "lin" and m.N % 16 == 0:
-                # fused-GEGLU forward operand: rows of s*B interleaved [8 values, 8 gates, ...] like Layer.w_geglu -- two strided copies
-                # of (8 rows x r) blocks: values block j -> rows 16j.., gates block j -> rows 16j+8..
-                o_bg, inner = alloc(m.N * r), m.N // 2
+                # fused-GEGLU forward operand: rows of s*B interleaved [G values, G gates, ...] like Layer.w_geglu -- two strided copies
+                # of (G rows x r) blocks: values block j -> rows 2Gj.., gates block j -> rows 2Gj+G..
+                o_bg, inner, G = alloc(m.N * r), m.N // 2, GEGLU_GROUP
                 geglu_ops.append((m, o_bg))
-                descs.append((ob, o_bg, -1, inner // 8, 8 * r, 8 * r, 16 * r, 0, self.scaling))
-                descs.append((ob + inner * r, o_bg + 8 * r, -1, inner // 8, 8 * r, 8 * r, 16 * r, 0, self.scaling))
+                descs.append((ob, o_bg, -1, inner // G, G * r, G * r, 2 * G * r, 0, self.scaling))
+                descs.append((ob + inner * r, o_bg + G * r, -1, inner // G, G * r, G * r, 2 * G * r, 0, self.scaling))
         # self-attention q/k/v triples additionally get CONCATENATED operands, so the three rank-64 down-projections
         # are one [M,C]x[C,192] GEMM and the three up-projections ride the fused QKV GEMM as one block-diagonal K=192
         # segment (the off-diagonal blocks stay at the zeros this buffer is created with):
@@ -577,11 +585,14 @@ class UNet:
             layer_bwd(W, lora, p + "to_v", dv.view(B * Lk, C), sv["sv"], need_dx=False)
         return d_xn
 
-    def transformer_fwd(self, p, x, text, B, H, Wd, tape, depth=1, heads=None):
-        """Transformer2DModel: GroupNorm -> proj_in -> ``depth`` BasicTransformerBlocks -> proj_out + input residual."""
+    def transformer_fwd(self, p, x, text, B, H, Wd, tape, depth=1, heads=None, dup_after_attn1=False):
+        """Transformer2DModel: GroupNorm -> proj_in -> ``depth`` BasicTransformerBlocks -> proj_out + input residual.
+        ``dup_after_attn1``: ``x`` holds B samples that stand for a batch [x; x] of 2B whose halves differ only in ``text`` (2B rows):
+        everything up to and including the first self-attention is computed once and duplicated there; returns 2B samples."""
         W, lora = self.W, self.lora
         heads = heads if heads is not None else self.cfg.heads_at(0)
         C, L, M = x.shape[-1], H * Wd, B * H * Wd
+        assert not dup_after_attn1 or (tape is None and text.shape[0] == 2 * B)
         Lt = text.shape[1]
         rec = tape is not None
         sgn, spi, spo = ({} if rec else None for _ in range(3))
@@ -594,6 +605,10 @@ class UNet:
             g1, b1 = W.norms[b + "norm1"]
             n1, mu1, rs1 = ops.layernorm_fwd(h, g1, b1)
             h1 = self._attn_fwd(b + "attn1.", n1, n1, B, L, L, C, h, sa1, heads)
+            if dup_after_attn1 and k == 0:      # the first cross-attention is where the two halves start to differ
+                h1 = torch.cat([h1.view(M, C), h1.view(M, C)])
+                x = torch.cat([x.view(M, C), x.view(M, C)]).view(2 * B, L, C)
+                B, M = 2 * B, 2 * M
             g2, b2 = W.norms[b + "norm2"]
             n2, mu2, rs2 = ops.layernorm_fwd(h1, g2, b2)
             h2 = self._attn_fwd(b + "attn2.", n2, text.view(B * Lt, -1), B, L, Lt, C, h1, sa2, heads)
@@ -660,12 +675,17 @@ class UNet:
         return ops.add(d_x.view(M, C), d_out).view(B, H * Wd, C)
 
     # ---- whole network ----
-    def forward(self, sample, timesteps, encoder_hidden_states, save=False, features=False, added_cond=None, save_half=False):
+    def forward(self, sample, timesteps, encoder_hidden_states, save=False, features=False, added_cond=None, save_half=False, dup_halves=False):
         """``features=True`` is the reference's ``modified_forward`` (discriminator_sd15.py:16-345): returns the 9
         hidden states after every down block, the mid block and every up block (no conv_norm_out / conv_out).
         ``save_half``: the caller will back-propagate through ``tape_first_half`` only (fused online + target batch), so tensors
-        that exist only for the backward may be kept for the first half of the batch alone."""
+        that exist only for the backward may be kept for the first half of the batch alone.
+        ``dup_halves``: the caller guarantees that the two halves of the batch have IDENTICAL sample, timestep and added_cond rows and
+        differ only in encoder_hidden_states (the teacher's cond / uncond pass, train_pcm_lora_sd15.py:1217-1252): conv_in, the first
+        resnet and the first transformer block's self-attention are computed on one half and duplicated (result-identical)."""
         cfg, W, lora = self.cfg, self.W, self.lora
+        dup_halves = bool(dup_halves and not save and not features and sample.shape[0] % 2 == 0 and cfg.down_attn[0]
+                          and not cfg.addition_time_embed_dim)
         self._save_half = bool(save and save_half)
         B, _, H, Wd = sample.shape
         boc, n = cfg.block_out_channels, len(cfg.block_out_channels)
@@ -689,11 +709,22 @@ class UNet:
             emb_act = ops.silu(emb)
         else:
             emb_act = layer_fwd(W, None, "time_embedding.linear_2", e1, B, act=capi.ACT_SILU)  # silu(emb): only use of emb
-        h = ops.conv_in_fwd(sample.contiguous(), W.conv_in[0], W.conv_in[1], boc[0])
-        skips = [(h, H, Wd)]
+        if dup_halves:
+            Bh = B // 2
+            h = ops.conv_in_fwd(sample[:Bh].contiguous(), W.conv_in[0], W.conv_in[1], boc[0])
+            skips = [(torch.cat([h, h]), H, Wd)]
+        else:
+            h = ops.conv_in_fwd(sample.contiguous(), W.conv_in[0], W.conv_in[1], boc[0])
+            skips = [(h, H, Wd)]
         feats = []
         for i in range(n):
             for j in range(cfg.layers_per_block):
+                if dup_halves and i == 0 and j == 0:
+                    h = self.resnet_fwd("down_blocks.0.resnets.0.", h, emb_act[:Bh].contiguous(), Bh, H, Wd, tape)
+                    h = self.transformer_fwd("down_blocks.0.attentions.0.", h, text, Bh, H, Wd, tape, cfg.transformer_depth[0], cfg.heads_at(0),
+                                             dup_after_attn1=True)
+                    skips.append((h, H, Wd))
+                    continue
                 h = self.resnet_fwd(f"down_blocks.{i}.resnets.{j}.", h, emb_act, B, H, Wd, tape)
                 if cfg.down_attn[i]:
                     h = self.transformer_fwd(f"down_blocks.{i}.attentions.{j}.", h, text, B, H, Wd, tape, cfg.transformer_depth[i], cfg.heads_at(i))

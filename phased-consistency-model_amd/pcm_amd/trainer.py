@@ -57,6 +57,8 @@ class DDIMTables:
 
 
 SEG_TIMING = os.environ.get("PCM_SEG_TIMING") == "1"
+# the teacher's cond / uncond halves share sample and timestep: compute the common prefix once (0 restores the plain 2B pass, for A/B)
+DEDUP_TEACHER_PREFIX = os.environ.get("PCM_DEDUP_TEACHER", "1") != "0"
 SEG_FORCE = os.environ.get("PCM_SEG_FORCE") == "1"      # debugging aid: segmented capture of the adversarial step at world_size 1 too
 
 
@@ -88,6 +90,16 @@ class SegmentedGraph:
             self.pool = self.cur.pool()
         self.items.append(self.cur)
         self.cur = None
+
+    def abort(self):
+        """the code being captured raised: close the open capture so that the stream is usable again (the segments are discarded)"""
+        if self.cur is not None:
+            try:
+                self.cur.capture_end()
+            except RuntimeError:
+                pass
+            self.cur = None
+        self.items = []
 
     def replay(self):
         if SEG_TIMING:
@@ -168,8 +180,10 @@ class Distiller:
             eps_c = self.teacher.forward(noisy, start_t, prompt_embeds, added_cond=added_cond)
             eps_u = eps_c
         else:
+            # (the halves share sample and timestep: the prefix up to the first cross-attention is computed once, UNet.forward dup_halves)
             both = self.teacher.forward(torch.cat([noisy, noisy]), torch.cat([start_t, start_t]),
-                                        torch.cat([prompt_embeds, uncond_prompt_embeds]), added_cond=cat2(added_cond, uncond_added_cond))
+                                        torch.cat([prompt_embeds, uncond_prompt_embeds]), added_cond=cat2(added_cond, uncond_added_cond),
+                                        dup_halves=DEDUP_TEACHER_PREFIX)
             eps_c, eps_u = both[:B], both[B:]
         x_prev64, x_prev32 = ops.cfg_ddim_step(eps_c, eps_u, noisy, start_t, index, w, T.acp, T.acp_prev)   # :1254-1258
         if self.fuse_online_target:
@@ -467,15 +481,25 @@ class AdvDistiller(Distiller):
             cap = torch.cuda.Stream()
             cap.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(cap):
-                self._g_d = self._seg = SegmentedGraph()
-                self._seg.begin()
-                self._out_d = self.step_adv(0, **st)
-                self._seg.end()
-                self._g_g = self._seg = SegmentedGraph(pool=self._g_d.pool)
-                self._seg.begin()
-                self._out_g = self.step_adv(1, **st)
-                self._seg.end()
-                self._seg = None
+                try:
+                    self._g_d = self._seg = SegmentedGraph()
+                    self._seg.begin()
+                    self._out_d = self.step_adv(0, **st)
+                    self._seg.end()
+                    self._g_g = self._seg = SegmentedGraph(pool=self._g_d.pool)
+                    self._seg.begin()
+                    self._out_g = self.step_adv(1, **st)
+                    self._seg.end()
+                except BaseException:
+                    # a failure inside a segment (OOM, a collective issued outside _collective): no capture may stay open and _seg must not
+                    # keep routing later collectives into cut() of a dead graph; the caller falls back to eager steps
+                    if self._seg is not None:
+                        self._seg.abort()
+                    self._g_d = self._g_g = None
+                    raise
+                finally:
+                    self._seg = None
+                    self._disc_works = []
             torch.cuda.current_stream().wait_stream(cap)
         for dst, src in zip(keep, saved):
             dst.copy_(src)

@@ -734,12 +734,12 @@ def _case_gemm_geglu(dev, M, K, inner, big_mode):
     x = torch.randn(M, K, generator=g).bfloat16().to(dev)
     w = (torch.randn(2 * inner, K, generator=g) * 0.1).bfloat16().to(dev)
     bias = torch.randn(2 * inner, generator=g).to(dev)
-    j, e = torch.arange(inner // 8, device=dev), torch.arange(8, device=dev)
-    perm = torch.stack([(8 * j)[:, None] + e, inner + (8 * j)[:, None] + e], 1).reshape(-1)
+    from pcm_amd.model import geglu_perm
+    perm = geglu_perm(inner, dev)
     out = torch.empty(M, inner, dtype=torch.bfloat16, device=dev)
     ops.gemm([ops.Seg(x, w[perm].contiguous())], M, 2 * inner, out, bias=bias[perm].contiguous(), act=capi.ACT_GEGLU, ldo=inner)
     plan = capi.lib().dll.pcm_debug_last_gemm_plan()
-    assert (plan >= 14000) if big_mode == 3 else (4000 <= plan < 10000), plan
+    assert (plan >= 14000) if big_mode == 3 else ((4000 <= plan < 10000) if big_mode in (2, 4) else plan >= 4000), plan
     h = x.float() @ w.float().T + bias
     ref = h[:, :inner] * F.gelu(h[:, inner:])
     err = (out.float() - ref).abs()

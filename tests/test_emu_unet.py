@@ -258,3 +258,29 @@ def test_unet_forward_same_through_both_attention_forward_kernels():
         dll.pcm_debug_attn_fwd_variant(-1)
     rel = float((outs[1] - outs[0]).norm() / outs[0].norm())
     assert rel < 1e-4, rel
+
+
+def test_teacher_shared_prefix_equals_plain_2b_pass():
+    """UNet.forward(dup_halves=True): the teacher's [cond; uncond] batch shares sample and timestep between its halves
+    (train_pcm_lora_sd15.py:1217-1252); conv_in, the first resnet and the first self-attention are computed once and duplicated where the
+    first cross-attention makes the halves differ -- per sample the same operations as the plain 2B pass.  Bitwise equal when the prefix's
+    half-size GEMMs take the same tile / split-K plan (measured at B = 16); otherwise the two passes are two bf16 evaluations of one function and
+    sit as far from each other as each sits from the fp32 oracle."""
+    from oracle import unet_sd15 as O
+    from pcm_amd.model import UNet, UNetWeights
+    oc, pc = tiny_cfgs()
+    sd = O.init_state_dict(oc, 0)
+    W = UNetWeights(pc, sd, "cpu")
+    g = torch.Generator().manual_seed(5)
+    rel = lambda a, b: float((a - b).norm() / b.norm())   # noqa: E731
+    for B in (2, 8):         # GroupNorm statistics: partials form / atomics arena (2B >= 16)
+        x, t = torch.randn(B, 4, 16, 16, generator=g), torch.randint(0, 1000, (B,), generator=g)
+        c, u = torch.randn(B, 9, 64, generator=g), torch.randn(B, 9, 64, generator=g)
+        T = UNet(W, None)
+        args = (torch.cat([x, x]), torch.cat([t, t]), torch.cat([c, u]))
+        a, b = T.forward(*args), T.forward(*args, dup_halves=True)
+        with torch.no_grad():
+            ref = O.unet_forward(oc, sd, *args)
+        ea, eb = rel(a, ref), rel(b, ref)
+        assert eb <= 1.2 * ea + 1e-3 and rel(a, b) <= 1.5 * max(ea, eb), (B, ea, eb, rel(a, b))
+        assert rel(a[:B], a[B:]) > 0.1, B        # the text conditioning is live

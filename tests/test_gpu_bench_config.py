@@ -132,6 +132,23 @@ def test_graph_replay_equals_eager_bs16_and_batch_split(sd15):
     assert rep["loss_rel_16_vs_8x2"] < 3e-3 and rep["grad_rel_16_vs_8x2"] < 5e-2, rep
 
 
+def test_teacher_shared_prefix_equals_plain_2b_pass(sd15):
+    """the benchmarked teacher pass (bs 16: [cond; uncond] = 32 samples, prefix computed on 16, UNet.forward dup_halves) against the plain
+    2B pass at the real size: same kernels per sample; only the GroupNorm fp64 atomics may associate differently"""
+    from pcm_amd.model import UNet
+    cfg, W = sd15
+    g = torch.Generator(device="cuda").manual_seed(5)
+    B = 16
+    x, t = torch.randn(B, 4, 64, 64, generator=g, device="cuda"), torch.randint(0, 1000, (B,), generator=g, device="cuda")
+    c, u = torch.randn(B, 77, 768, generator=g, device="cuda"), torch.randn(B, 77, 768, generator=g, device="cuda")
+    T = UNet(W, None)
+    args = (torch.cat([x, x]), torch.cat([t, t]), torch.cat([c, u]))
+    a, b = T.forward(*args), T.forward(*args, dup_halves=True)
+    torch.cuda.synchronize()
+    assert rel(b, a) < 1e-3, rel(b, a)          # (bitwise equal on the host emulator; fp64 atomics order on the device)
+    assert rel(a[:B], a[B:]) > 1e-2             # the halves do differ (the text conditioning is live)
+
+
 def test_split_graph_capture_equals_eager(monkeypatch):
     """The data-parallel capture (two forward+backward graphs cut where the backward leaves the mid block, so that the late gradient
     bucket's all-reduce sits between them) replays to the same update as the eager schedule -- exercised here on one GPU."""

@@ -18,7 +18,9 @@ def bench(fn, n=10):
     for _ in range(n): fn()
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / n * 1e3
-shapes = [(131072, 2560, (320, 64), "lin", 0, "b"), (131072, 2560, (320,), "lin", 0, "b"), (131072, 320, (320, 64), "lin", 0, ""), (131072, 320, (320, 64), "lin", 0, "br"),
+shapes = [(131072, 2560, (320, 64), "lin", 0, "bg"), (131072, 2560, (320,), "lin", 0, "bg"), (32768, 5120, (640,), "lin", 0, "bg"), (8192, 10240, (1280,), "lin", 0, "bg"),
+          (131072, 320, (320,), "lin", 0, "br"), (131072, 320, (320,), "lin", 0, "b"), (131072, 960, (320,), "lin", 0, ""), (8192, 1280, (1280,), "lin", 0, "br"),
+          (131072, 2560, (320, 64), "lin", 0, "b"), (131072, 2560, (320,), "lin", 0, "b"), (131072, 320, (320, 64), "lin", 0, ""), (131072, 320, (320, 64), "lin", 0, "br"),
           (131072, 320, (1280, 64), "lin", 0, "br"), (131072, 960, (320, 192), "lin", 0, ""), (32768, 5120, (640, 64), "lin", 0, "b"), (32768, 640, (640, 64), "lin", 0, "br"),
           (32768, 640, (640,), "lin", 0, ""), (8192, 1280, (1280, 64), "lin", 0, "br"), (65536, 320, (320, 64), "lin", 0, "br"), (16384, 640, (640, 64), "lin", 0, ""),
           (131072, 320, (2880, 64), "conv", 64, "bv"), (131072, 320, (2880, 64), "conv", 64, "br"), (32768, 1280, (11520, 64), "conv", 32, "br"), (8192, 1280, (11520, 64), "conv", 16, "bv")]
@@ -41,12 +43,15 @@ for (M, N, Ks, kind, Hs, opt) in shapes:
     if "r" in opt: kw["residual"] = torch.randn(M, N, device="cuda").bfloat16()
     if "v" in opt: kw["rowvec"] = torch.randn(B, N, device="cuda").bfloat16(); kw["rows_per_batch"] = M // B
     if kind == "conv": kw.update(Ho=Hs, Wo=Hs)
+    No = N
+    if "g" in opt:          # fused GEGLU epilogue (interleaved value / gate columns): N/2 outputs
+        kw.update(act=capi.ACT_GEGLU, ldo=N // 2); No = N // 2
     outs, ts = [], [[] for _ in cfgs]
     for rep in range(3):
         for i, (l, persist) in enumerate(cfgs):
             capi.set_lib(l)
             if persist is not None: l.dll.pcm_debug_gemm8p_persist(persist)
-            out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+            out = torch.empty(M, No, device="cuda", dtype=torch.bfloat16)
             ts[i].append(bench(lambda: ops.gemm(segs, M, N, out, **kw)))
             if rep == 0: outs.append(out.float())
     mins = [min(t) for t in ts]
