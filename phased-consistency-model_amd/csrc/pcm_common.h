@@ -108,8 +108,7 @@ __device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {
 __device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack_bf2(f, 0.f) & 0xffffu); }
 #endif
 // Activations are evaluated per element inside HBM-bound kernels (GroupNorm+SiLU touches every activation of the UNet), so their
-// VALU cost matters: v_rcp_f32 (1 ulp) instead of the IEEE division sequence (~10 instructions), and erf by Abramowitz-Stegun
-// 7.1.26 (|error| < 1.5e-7, one exp + one rcp + 5 fma) instead of the branchy libm erff.  Results are rounded to bf16.
+// VALU cost matters: v_rcp_f32 (1 ulp) instead of the IEEE division sequence (~10 instructions).  Results are rounded to bf16.
 #ifdef PCM_HOST_EMU
 #define PCM_RCPF(x) (1.0f / (x))
 #else
@@ -120,16 +119,20 @@ __device__ __forceinline__ float silu_grad_f(float x) {
   float s = PCM_RCPF(1.0f + PCM_EXPF(-x));
   return s * (1.0f + x * (1.0f - s));
 }
-__device__ __forceinline__ float pcm_erf_f(float z) {
-  const float az = fabsf(z);
-  const float t = PCM_RCPF(1.0f + 0.3275911f * az);
-  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-  const float e = 1.0f - poly * PCM_EXPF(-az * az);
-  return z < 0.f ? -e : e;
+// GELU (erf form, F.gelu default) = x * Phi(x).  Phi - 1/2 is evaluated as an odd degree-17 polynomial on |x| <= 4 (clamped beyond:
+// Phi(-4) = 3.2e-5): max |Phi error| 2.9e-5, i.e. |gelu error| <= 1.2e-4 absolute on [-4, 4] and 3.2e-5 * |x| beyond -- 40x below one bf16
+// rounding of the result -- in 11 full-rate VALU operations and NO transcendental.  The Abramowitz-Stegun erf used before (exp + rcp, both quarter rate) made
+// value * gelu(gate) of the fused feed-forward epilogue cost as many SIMD cycles as the K = 320 projection's MFMAs (round 4).
+__device__ __forceinline__ float pcm_phi_f(float x) {
+  const float t = fminf(fmaxf(x, -4.0f), 4.0f), z = t * t;
+  float p = 7.804711256e-11f;
+  p = p * z - 6.827683748e-09f; p = p * z + 2.666981721e-07f; p = p * z - 6.222018266e-06f; p = p * z + 9.829133151e-05f;
+  p = p * z - 1.130966313e-03f; p = p * z + 9.869967510e-03f; p = p * z - 6.640203406e-02f; p = p * z + 3.989198652e-01f;
+  return p * t + 0.5f;
 }
-__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + pcm_erf_f(x * 0.70710678118654752f)); }
-__device__ __forceinline__ float gelu_erf_grad_f(float x) {
-  return 0.5f * (1.0f + pcm_erf_f(x * 0.70710678118654752f)) + x * 0.3989422804014327f * PCM_EXPF(-0.5f * x * x);
+__device__ __forceinline__ float gelu_erf_f(float x) { return x * pcm_phi_f(x); }
+__device__ __forceinline__ float gelu_erf_grad_f(float x) {      // Phi(x) + x * phi(x)
+  return pcm_phi_f(x) + x * 0.3989422804014327f * PCM_EXPF(-0.5f * x * x);
 }
 // combine a value with the one held by the lane 32 apart (the two halves of a 32x32 MFMA accumulator column).  v_permlane32_swap is a VALU
 // instruction: no LDS round trip and no lgkmcnt wait in the middle of a softmax (ds_bpermute is both).

@@ -134,7 +134,9 @@ def test_graph_replay_equals_eager_bs16_and_batch_split(sd15):
 
 def test_teacher_shared_prefix_equals_plain_2b_pass(sd15):
     """the benchmarked teacher pass (bs 16: [cond; uncond] = 32 samples, prefix computed on 16, UNet.forward dup_halves) against the plain
-    2B pass at the real size: same kernels per sample; only the GroupNorm fp64 atomics may associate differently"""
+    2B pass at the real size.  Per sample the same operations; the prefix runs at half the rows, so its GEMMs / GroupNorm statistics take
+    other plans (another fp32 summation order in front of the bf16 stores): two bf16 evaluations of one function, as far apart as a bs-16
+    batch and the same samples in 8 batches of 2 (eps 8.6e-3, test above) -- MI355X: 7.6e-3."""
     from pcm_amd.model import UNet
     cfg, W = sd15
     g = torch.Generator(device="cuda").manual_seed(5)
@@ -145,8 +147,8 @@ def test_teacher_shared_prefix_equals_plain_2b_pass(sd15):
     args = (torch.cat([x, x]), torch.cat([t, t]), torch.cat([c, u]))
     a, b = T.forward(*args), T.forward(*args, dup_halves=True)
     torch.cuda.synchronize()
-    assert rel(b, a) < 1e-3, rel(b, a)          # (bitwise equal on the host emulator; fp64 atomics order on the device)
-    assert rel(a[:B], a[B:]) > 1e-2             # the halves do differ (the text conditioning is live)
+    assert rel(b, a) < 1.5e-2, rel(b, a)
+    assert rel(a[:B], a[B:]) > 10 * rel(b, a)   # the halves do differ (the text conditioning is live)
 
 
 def test_split_graph_capture_equals_eager(monkeypatch):
