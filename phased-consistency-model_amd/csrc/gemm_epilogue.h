@@ -104,7 +104,11 @@ struct PcmEpi {
     if (g.act == PCM_ACT_GEGLU) { run_geglu(g, smem, acc, tid, wm, wn, m0, n0, sync_first); return; }
     const int lane = tid & 63, frow = lane & 15, fk = lane >> 4;
     // residual pieces are requested a pass ahead of their use (one register set of IT pieces; a row vector rides in the loop: L2-resident)
+#ifdef PCM_EPI_NO_RES_PATH      // (A/B build only: tools/jobs/r04_g_*.sh)
+    const bool pf_on = false;
+#else
     const bool pf_on = g.res != nullptr;
+#endif
     uint4 pf[IT];
 #pragma unroll
     for (int it = 0; it < IT; it++) pf[it] = pf_on ? fetch(g, g.res, true, tid, it, 0, m0, n0) : make_uint4(0u, 0u, 0u, 0u);
@@ -139,9 +143,14 @@ struct PcmEpi {
           const float4 hi4 = *(const float4*)(smem + ((size_t)lr * CH + ((2 * c8 + 1) ^ (lr & 15))) * 16);
           float v[8] = {lo.x, lo.y, lo.z, lo.w, hi4.x, hi4.y, hi4.z, hi4.w};
           if (PCM_ABL(1)) { if (v[0] != 123456.f) continue; }
-          finish(g, bias_lds, m, n, c8, v, px);
+          finish_any(g, bias_lds, m, n, c8, v, px);
         }
         continue;
+      }
+      // no residual: bias-free (q / k / v, LoRA-down style projections), bias only, bias + time-embedding row (resnet conv1), generic
+      if (g.act != PCM_ACT_SILU) {
+        if (!g.rowvec) { if (g.bias) plain_pass<true, false>(g, smem, bias_lds, tid, q, m0, n0); else plain_pass<false, false>(g, smem, bias_lds, tid, q, m0, n0); continue; }
+        if (g.bias) { plain_pass<true, true>(g, smem, bias_lds, tid, q, m0, n0); continue; }
       }
       for (int idx = tid; idx < ROWS * C8; idx += NT) {
         const int lr = idx / C8, c8 = idx - lr * C8;
@@ -151,13 +160,39 @@ struct PcmEpi {
         const float4 hi4 = *(const float4*)(smem + ((size_t)lr * CH + ((2 * c8 + 1) ^ (lr & 15))) * 16);
         float v[8] = {lo.x, lo.y, lo.z, lo.w, hi4.x, hi4.y, hi4.z, hi4.w};
         if (PCM_ABL(1)) { if (v[0] != 123456.f) continue; }
-        finish(g, bias_lds, m, n, c8, v, make_uint4(0u, 0u, 0u, 0u));
+        finish_any(g, bias_lds, m, n, c8, v, make_uint4(0u, 0u, 0u, 0u));
       }
     }
   }
 
-  // bias (LDS copy of the tile's bias row), row vector, SiLU, residual (already loaded: ``res``), one 16-B bf16 store
+  // bias (LDS copy of the tile's bias row), row vector, SiLU, residual (already loaded: ``res``), one 16-B bf16 store.  The flags are
+  // COMPILE-TIME: the piece loops are instantiated per flag set and selected once per tile (hipcc unswitched the old single loop by itself;
+  // it does not do so for this one: measured as 96 instead of 56 instructions per piece and +3-6 % on the bias-free projections)
+  template <bool BIAS, bool RV, bool SILU, bool RES>
   static __device__ __forceinline__ void finish(const GemmDev& g, const float4* bias_lds, int m, int n, int c8, float (&v)[8], const uint4 res) {
+    if (BIAS) {
+      const float4 b0 = bias_lds[2 * c8], b1 = bias_lds[2 * c8 + 1];
+      v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+    }
+    if (RV) {
+      const uint4 t = *(const uint4*)(g.rowvec + (size_t)(m / g.rpb) * g.N + n);
+      const unsigned tw[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+      for (int e = 0; e < 4; e++) { v[2 * e] += bf2f((bf16_t)(tw[e] & 0xffff)); v[2 * e + 1] += bf2f((bf16_t)(tw[e] >> 16)); }
+    }
+    if (SILU) {
+#pragma unroll
+      for (int e = 0; e < 8; e++) v[e] = silu_f(v[e]);
+    }
+    if (RES) {
+      const unsigned tw[4] = {res.x, res.y, res.z, res.w};
+#pragma unroll
+      for (int e = 0; e < 4; e++) { v[2 * e] += bf2f((bf16_t)(tw[e] & 0xffff)); v[2 * e + 1] += bf2f((bf16_t)(tw[e] >> 16)); }
+    }
+    *(uint4*)((bf16_t*)g.out + (size_t)m * g.ldo + n) = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+  }
+  // the generic form (flags read at run time): the residual path and the rare flag sets
+  static __device__ __forceinline__ void finish_any(const GemmDev& g, const float4* bias_lds, int m, int n, int c8, float (&v)[8], const uint4 res) {
     if (g.bias) {
       const float4 b0 = bias_lds[2 * c8], b1 = bias_lds[2 * c8 + 1];
       v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
@@ -178,5 +213,19 @@ struct PcmEpi {
       for (int e = 0; e < 4; e++) { v[2 * e] += bf2f((bf16_t)(tw[e] & 0xffff)); v[2 * e + 1] += bf2f((bf16_t)(tw[e] >> 16)); }
     }
     *(uint4*)((bf16_t*)g.out + (size_t)m * g.ldo + n) = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+  }
+  // one pass of the plain piece loop with compile-time flags
+  template <bool BIAS, bool RV>
+  static __device__ __forceinline__ void plain_pass(const GemmDev& g, const char* smem, const float4* bias_lds, int tid, int q, int m0, int n0) {
+    for (int idx = tid; idx < ROWS * C8; idx += NT) {
+      const int lr = idx / C8, c8 = idx - lr * C8;
+      const int m = m0 + 128 * (lr >> 5) + 32 * q + (lr & 31), n = n0 + 8 * c8;
+      if (m >= g.M || n >= g.N) continue;
+      const float4 lo = *(const float4*)(smem + ((size_t)lr * CH + ((2 * c8) ^ (lr & 15))) * 16);
+      const float4 hi4 = *(const float4*)(smem + ((size_t)lr * CH + ((2 * c8 + 1) ^ (lr & 15))) * 16);
+      float v[8] = {lo.x, lo.y, lo.z, lo.w, hi4.x, hi4.y, hi4.z, hi4.w};
+      if (PCM_ABL(1)) { if (v[0] != 123456.f) continue; }
+      finish<BIAS, RV, false, false>(g, bias_lds, m, n, c8, v, make_uint4(0u, 0u, 0u, 0u));
+    }
   }
 };

@@ -119,16 +119,17 @@ __device__ __forceinline__ float silu_grad_f(float x) {
   float s = PCM_RCPF(1.0f + PCM_EXPF(-x));
   return s * (1.0f + x * (1.0f - s));
 }
-// GELU (erf form, F.gelu default) = x * Phi(x).  Phi - 1/2 is evaluated as an odd degree-17 polynomial on |x| <= 4 (clamped beyond:
-// Phi(-4) = 3.2e-5): max |Phi error| 2.9e-5, i.e. |gelu error| <= 1.2e-4 absolute on [-4, 4] and 3.2e-5 * |x| beyond -- 40x below one bf16
-// rounding of the result -- in 11 full-rate VALU operations and NO transcendental.  The Abramowitz-Stegun erf used before (exp + rcp, both quarter rate) made
+// GELU (erf form, F.gelu default) = x * Phi(x).  Phi - 1/2 is evaluated as an odd degree-17 polynomial on |x| <= 4 (0 / 1 beyond:
+// Phi(-4) = 3.2e-5): max |Phi error| 3.2e-5, i.e. |gelu error| <= 1.3e-4 absolute everywhere -- 40x below one bf16 rounding of a result of
+// that size -- in 15 full-rate VALU operations and NO transcendental.  The Abramowitz-Stegun erf used before (exp + rcp, both quarter rate) made
 // value * gelu(gate) of the fused feed-forward epilogue cost as many SIMD cycles as the K = 320 projection's MFMAs (round 4).
 __device__ __forceinline__ float pcm_phi_f(float x) {
   const float t = fminf(fmaxf(x, -4.0f), 4.0f), z = t * t;
   float p = 7.804711256e-11f;
   p = p * z - 6.827683748e-09f; p = p * z + 2.666981721e-07f; p = p * z - 6.222018266e-06f; p = p * z + 9.829133151e-05f;
   p = p * z - 1.130966313e-03f; p = p * z + 9.869967510e-03f; p = p * z - 6.640203406e-02f; p = p * z + 3.989198652e-01f;
-  return p * t + 0.5f;
+  const float phi = p * t + 0.5f;
+  return x < -4.0f ? 0.0f : (x > 4.0f ? 1.0f : phi);      // tails exact to 3.2e-5: gelu(x) -> 0 / x, no |x| * 3.2e-5 drift for large gates
 }
 __device__ __forceinline__ float gelu_erf_f(float x) { return x * pcm_phi_f(x); }
 __device__ __forceinline__ float gelu_erf_grad_f(float x) {      // Phi(x) + x * phi(x)

@@ -18,8 +18,9 @@ def cos(a, b):
     return float((a * b).sum() / (a.norm() * b.norm() + 1e-300))
 
 
-def head_flat(disc, which):
-    """this build's head tensors (parameters ``p`` or gradients ``g``) in the reference's names / layouts, as {name: tensor}"""
+def head_flat(disc, which, cpu=True):
+    """this build's head tensors (parameters ``p`` or gradients ``g``) in the reference's names / layouts, as {name: tensor}
+    (``cpu=False``: clones on the heads' own device -- the full-size comparison sketches 664 M elements there)"""
     out, cnt = {}, {}
     for k, hd in disc.heads:
         h = cnt.get(k, 0)
@@ -30,7 +31,7 @@ def head_flat(disc, which):
                 v = v.permute(0, 3, 1, 2) if disc.ksize == 3 else v.view(hd.C, hd.C, 1, 1)
             elif n == "conv_out.weight":
                 v = v.view(1, hd.C, 1, 1)
-            out[f"heads.{k}.{h}.{n}"] = v.cpu().clone()
+            out[f"heads.{k}.{h}.{n}"] = v.cpu().clone() if cpu else v.contiguous().clone()
     return out
 
 
@@ -111,7 +112,7 @@ def case_adv_c3(dev, kw, dims, B, hw, ctx_len, ctx_dim, global_step, nh=4, lr=5e
     oc, pc, lora, disc, ocfg, cfg, inp = _setup(dev, kw, dims, B, hw, ctx_len, ctx_dim, nh, lr, index, seed)
     W = UNetWeights(pc, O.init_state_dict(oc, 0), dev)
     D = AdvDistiller(W, lora, cfg, disc, adv_weight=adv_weight, adv_lr=adv_lr)
-    lora_p0, head_p0 = lora.params.clone(), head_flat(disc, "p")
+    lora_p0, head_p0 = lora.params.clone(), head_flat(disc, "p", cpu=False)
     p0 = torch.cat([torch.cat([lora.A_peft(m).detach().cpu().reshape(-1), m.B.detach().cpu().reshape(-1)]) for m in lora.modules.values()])
     names = list(head_p0)
     dvc = {k: v.to(dev) for k, v in inp.items()}
@@ -122,14 +123,14 @@ def case_adv_c3(dev, kw, dims, B, hw, ctx_len, ctx_dim, global_step, nh=4, lr=5e
     if global_step % 2 == 0:
         rep["d_loss"], rep["d_loss_oracle"] = float(out["d_loss"]), float(ref["d_loss"])
         rep["d_loss_rel"] = abs(rep["d_loss"] - rep["d_loss_oracle"]) / abs(rep["d_loss_oracle"])
-        mine_g = head_flat(disc, "g")
+        mine_g = head_flat(disc, "g", cpu=False)
         mg = sketch_cat([mine_g[n] for n in names])
         rep["head_grad_rel"], rep["head_grad_cos"] = sk_rel(mg, ref["sk_head_grad"]), sk_cos(mg, ref["sk_head_grad"])
         # per tapped feature (the 4 heads of one feature share its bucket)
         rep["head_grad_cos_per_tap"] = [sk_cos(sketch_cat([mine_g[n] for n in names if n.startswith("heads.%d." % k)]), ref["sk_head_grad_tap%d" % k])
                                         for k in range(len(dims))]
         del mine_g
-        mine_p = head_flat(disc, "p")
+        mine_p = head_flat(disc, "p", cpu=False)
         up_m = sketch_cat([mine_p[n] - head_p0[n] for n in names])
         gn = float(ref["head_grad_norm"])
         rep["head_grad_norm_rel"] = abs(math.sqrt(float(disc.gradsq.item())) - gn) / gn
@@ -150,6 +151,6 @@ def case_adv_c3(dev, kw, dims, B, hw, ctx_len, ctx_dim, global_step, nh=4, lr=5e
         rep["lora_update_cos"] = sk_cos(up_m, ref["sk_lora_update"])
         rep["lora_update_norm_ratio"] = float(up_m.norm() / ref["sk_lora_update"].double().norm())
         rep["lora_param_rel_after"] = sk_rel(sketch(mine1), ref["sk_lora_param_after"])
-        rep["heads_untouched"] = all(torch.equal(v, head_p0[n]) for n, v in head_flat(disc, "p").items())
+        rep["heads_untouched"] = all(torch.equal(v, head_p0[n]) for n, v in head_flat(disc, "p", cpu=False).items())
     print({k: (("%.4g" % v) if isinstance(v, float) else v) for k, v in rep.items()})
     return rep

@@ -21,25 +21,31 @@ _P = (1 << 31) - 1                     # Mersenne prime; indices stay below 2^30
 _A1, _B1, _A2, _B2 = 1103515245, 12345, 1664525, 1013904223
 
 
-def sketch(t, m=M_SKETCH):
-    """count-sketch of the flattened tensor (float64 [m]); element order = the tensor's own (row-major) order"""
-    flat = t.detach().reshape(-1).to("cpu")
+def sketch(t, m=M_SKETCH, offset=0, out=None):
+    """count-sketch of the flattened tensor (float64 [m], on the CPU); element order = the tensor's own (row-major) order, element i of
+    ``t`` counted as global index ``offset + i``.  Evaluated on the tensor's device (fp64 sums: the result does not depend on it)."""
+    flat = t.detach().reshape(-1)
     n = flat.numel()
-    assert n < (1 << 30)
-    out = torch.zeros(m, dtype=torch.float64)
+    assert offset + n < (1 << 30)
+    acc = torch.zeros(m, dtype=torch.float64, device=flat.device)
     CH = 1 << 24
     for s in range(0, n, CH):
         e = min(n, s + CH)
-        i = torch.arange(s, e, dtype=torch.int64)
+        i = torch.arange(offset + s, offset + e, dtype=torch.int64, device=flat.device)
         h = ((i * _A1 + _B1) % _P) % m
         sg = (((i * _A2 + _B2) % _P) & 1).to(torch.float64) * 2 - 1
-        out.index_add_(0, h, flat[s:e].to(torch.float64) * sg)
-    return out
+        acc.index_add_(0, h, flat[s:e].to(torch.float64) * sg)
+    acc = acc.cpu()
+    return acc if out is None else out.add_(acc)
 
 
 def sketch_cat(tensors, m=M_SKETCH):
-    """sketch of torch.cat([t.reshape(-1) for t in tensors]) without materialising the concatenation twice"""
-    return sketch(torch.cat([t.detach().reshape(-1).to("cpu") for t in tensors]), m)
+    """sketch of torch.cat([t.reshape(-1) for t in tensors]), tensor by tensor (no concatenation, each on its own device)"""
+    out, off = torch.zeros(m, dtype=torch.float64), 0
+    for t in tensors:
+        sketch(t, m, offset=off, out=out)
+        off += t.numel()
+    return out
 
 
 def sk_rel(a, b):

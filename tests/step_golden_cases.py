@@ -152,7 +152,7 @@ def ref_c2():
     olora = olora_of(lora)
     out = {k: [] for k in TS + ("noisy_model_input",) + KEYS7}
     mout = {k: [] for k in KEYS6}
-    losses, mlosses, gacc = [], [], None
+    losses, mlosses, gacc, gacc_m = [], [], None, None
     for i in range(0, C2_B, 2):
         sub = {k: v[i:i + 2] for k, v in inp.items()}
         t0 = time.time()
@@ -168,10 +168,17 @@ def ref_c2():
         for k in out:
             out[k].append(r[k].detach())
         losses.append(float(r["loss"]))
-        with torch.no_grad():
-            m = OS.distill_step_forward(oc, sd, olora, sub, ocfg, storage="bf16")
+        leaves_m, lrg_m = [], {}
+        for k, (a, b) in olora.items():
+            a, b = a.detach().clone().requires_grad_(True), b.detach().clone().requires_grad_(True)
+            lrg_m[k] = (a, b)
+            leaves_m += [a, b]
+        m = OS.distill_step_forward(oc, sd, lrg_m, sub, ocfg, storage="bf16")       # the matched oracle rounds cotangents of bf16-stored tensors too
+        gm = torch.autograd.grad(m["loss"], leaves_m, allow_unused=True)
+        flat_m = torch.cat([(torch.zeros_like(l) if g is None else g).reshape(-1) for g, l in zip(gm, leaves_m)])
+        gacc_m = flat_m if gacc_m is None else gacc_m + flat_m
         for k in KEYS6:
-            mout[k].append(m[k].float())
+            mout[k].append(m[k].detach().float())
         mlosses.append(float(m["loss"]))
         print("c2 micro-batch %d: %.1f s" % (i // 2, time.time() - t0), flush=True)
     res = {k: torch.cat(v) for k, v in out.items()}
@@ -182,6 +189,9 @@ def ref_c2():
     res["loss"], res["m32.loss"] = sum(losses) / n, sum(mlosses) / n
     res["grad_norm"] = float(g.double().norm())
     res["sk_grad"] = sketch(g)
+    gm_ = gacc_m / n
+    res["sk_grad_m32"] = sketch(gm_)
+    res["grad_m32_vs_fp32"] = float((gm_.double() - g.double()).norm() / g.double().norm())
     res["sk_param_before"] = sketch(lora_flat(lora, "p"))
     return res
 

@@ -6,9 +6,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "phased-consistency-model_amd"))
 import torch
 from pcm_amd import ops, capi
-libs = [capi.Lib(os.path.abspath(p)) for p in sys.argv[1:3]]
+libs = [capi.Lib(os.path.abspath(p)) for p in sys.argv[1:] if p.endswith(".so")]
 # third column: library B with its persistent tile loop switched off (when it has the hook) -- isolates the epilogue changes
-cfgs = [(libs[0], None), (libs[1], None)]
+cfgs = [(l, None) for l in libs]
 if False and hasattr(libs[1].dll, "pcm_debug_gemm8p_persist"):
     cfgs.append((libs[1], 0))
 def bench(fn, n=10):
@@ -18,7 +18,8 @@ def bench(fn, n=10):
     for _ in range(n): fn()
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / n * 1e3
-shapes = [(131072, 2560, (320, 64), "lin", 0, "bg"), (131072, 2560, (320,), "lin", 0, "bg"), (32768, 5120, (640,), "lin", 0, "bg"), (8192, 10240, (1280,), "lin", 0, "bg"),
+shapes = [(8500, 1536, (1536, 64), "lin", 0, "b"), (8500, 6144, (1536, 64), "lin", 0, "b"), (8500, 1536, (6144, 64), "lin", 0, "b"), (65536, 640, (640, 64), "lin", 0, "br"), (16384, 5120, (1280, 64), "lin", 0, "bg"),
+          (131072, 2560, (320, 64), "lin", 0, "bg"), (131072, 2560, (320,), "lin", 0, "bg"), (32768, 5120, (640,), "lin", 0, "bg"), (8192, 10240, (1280,), "lin", 0, "bg"),
           (131072, 320, (320,), "lin", 0, "br"), (131072, 320, (320,), "lin", 0, "b"), (131072, 960, (320,), "lin", 0, ""), (8192, 1280, (1280,), "lin", 0, "br"),
           (131072, 2560, (320, 64), "lin", 0, "b"), (131072, 2560, (320,), "lin", 0, "b"), (131072, 320, (320, 64), "lin", 0, ""), (131072, 320, (320, 64), "lin", 0, "br"),
           (131072, 320, (1280, 64), "lin", 0, "br"), (131072, 960, (320, 192), "lin", 0, ""), (32768, 5120, (640, 64), "lin", 0, "b"), (32768, 640, (640, 64), "lin", 0, "br"),
@@ -58,5 +59,5 @@ for (M, N, Ks, kind, Hs, opt) in shapes:
     same = float((outs[0] - outs[1]).abs().max())
     for i, v in enumerate(mins): tot[i] += v
     print("%-34s %-3s  A %7.1f us | B %7.1f us (x%.3f)%s  max|A-B| %.3g" % (str((M, N, Ks, kind)), opt, mins[0], mins[1], mins[1] / mins[0],
-          " | B no-persist %7.1f us (x%.3f)" % (mins[2], mins[2] / mins[0]) if len(mins) > 2 else "", same), flush=True)
+          "".join(" | %s %7.1f us (x%.3f)" % ("CDEF"[i - 2], mins[i], mins[i] / mins[0]) for i in range(2, len(mins))), same), flush=True)
 print("sum: " + "  ".join("%.1f us (x%.3f)" % (t, t / tot[0]) for t in tot))
