@@ -462,6 +462,14 @@ def main():
                 "launches": n_, "kernel_ms_per_step": round(t_ms, 2), "algorithmic_tflop": round(fl / 1e12, 2), "algorithmic_gb": round(nb / 1e9, 2),
                 "achieved_tflops": round(tf_s, 1), "achieved_gb_s": round(gb_s, 1),
                 "frac_of_own_roof": round(tf_s / PEAK_BF16_TFLOPS if name == "mfma" else gb_s * 1e9 / PEAK_HBM_BYTES, 4)}
+        # the two-workgroups-per-CU kernel (plan code 1xxxx: the K <= 384 fused-GEGLU feed-forward projections), against both roofs
+        w4l = [(p[0], t, p[5]) for p, t in zip(prof, times) if p[4] >= 10000]
+        w4 = None
+        if w4l:
+            w_fl, w_ms, w_nb = sum(x[0] for x in w4l), sum(x[1] for x in w4l), sum(x[2] for x in w4l)
+            w4 = {"kernel": "pcm_gemm4w_kernel<5> (128x320 tile, two workgroups per CU)", "launches": len(w4l), "kernel_ms_per_step": round(w_ms, 2),
+                  "achieved_tflops": round(w_fl / (w_ms * 1e-3) / 1e12, 1), "frac_mfma": round(w_fl / (w_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+                  "achieved_gb_s": round(w_nb / (w_ms * 1e-3) / 1e9, 1), "frac_hbm": round(w_nb / (w_ms * 1e-3) / PEAK_HBM_BYTES, 4)}
         log("roofline leg done")
         if os.environ.get("PCM_GEMM_TABLE"):
             agg = {}
@@ -496,7 +504,8 @@ def main():
                     "kernel": "pcm_gemm8p_kernel<3,false,false> (256x320 phased tile; all its launches of one step)",
                     "launches": len(dom), "avg_launch_us": round(1e3 * d_ms / max(1, len(dom)), 1),
                     "algorithmic_tflop": round(d_fl / 1e12, 2), "kernel_ms_per_step": round(d_ms, 2), "classes": classes,
-                    "gemm_family": {"kernels": "pcm_gemm8p<3>/<2>, pcm_gemm_kernel tiles, pcm_gemm_n64 (every pcm_gemm_bf16 launch)",
+                    "short_k_kernel": w4,
+                    "gemm_family": {"kernels": "pcm_gemm8p<3>/<2>, pcm_gemm4w<5>, pcm_gemm_kernel tiles, pcm_gemm_n64 (every pcm_gemm_bf16 launch)",
                                     "launches": len(prof), "algorithmic_tflop_per_step": round(flops / 1e12, 2),
                                     "kernel_ms_per_step": round(tms, 2), "achieved": round(fam, 1), "frac": round(fam / PEAK_BF16_TFLOPS, 4)},
                     "step_tflops_algorithmic": round(TF_STEP * B / (ms * 1e-3), 1), "step_frac": round(TF_STEP * B / (ms * 1e-3) / PEAK_BF16_TFLOPS, 4),
