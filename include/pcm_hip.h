@@ -122,6 +122,14 @@ int pcm_lora_wgrad_bf16(const pcm_wgrad_args* a, void* stream);
  * lora_B of a module; the six of a fused q/k/v projection) are 3-20 us kernels each, so they share launches.  Same result as n calls. */
 int pcm_lora_wgrad_multi_bf16(const pcm_wgrad_args* list, int n, void* stream);
 
+/* ---- Dense conv3x3 weight gradient, channels-last  (autograd of the trainable nn.Conv2d(C, C, 3, 1, 1) layers of DiscriminatorHead,
+ * discriminator_sd15.py:349-362, in the discriminator step train_pcm_lora_sd15_adv.py:1383-1391) --------------------------------
+ *   dW[co][kh][kw][ci] += alpha * sum_{b,y,x} dy[b][y][x][co] * x[b][y+kh-1][x+kw-1][ci]        (stride 1, zero padding 1)
+ * x [B,H,W,Cin] bf16, dy [B,H,W,Cout] bf16 (both dense), dW fp32 in the library's [co][kh][kw][ci] layout (accumulated into: the caller
+ * zeroes it once per optimizer step).  Needs H%8 == 0, W%8 == 0, Cin%8 == 0, Cout%64 == 0 and each operand below 2 GB; PCM_EINVAL
+ * otherwise (the Cout/64 rank-64 calls of pcm_lora_wgrad_bf16 compute the same sum for any geometry). */
+int pcm_conv3x3_wgrad_bf16(const void* x, const void* dy, float* dW, int B, int H, int W, int Cin, int Cout, float alpha, void* stream);
+
 /* ---- GroupNorm(32)(+SiLU), channels-last  (diffusers ResnetBlock2D.norm1/2, conv_norm_out,
  * Transformer2DModel.norm) --------------------------------------------------------------- */
 /* stats[b][g] = {sum, sumsq} in fp64, zeroed by the call itself */

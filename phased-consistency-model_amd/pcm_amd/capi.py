@@ -52,6 +52,7 @@ _PROTOS = {
     "pcm_gemm_bf16": [C.POINTER(GemmSeg), i32, C.POINTER(GemmEpi), vp],
     "pcm_lora_wgrad_bf16": [C.POINTER(WgradArgs), vp],
     "pcm_lora_wgrad_multi_bf16": [C.POINTER(WgradArgs), C.c_int, vp],
+    "pcm_conv3x3_wgrad_bf16": [vp, vp, vp, i32, i32, i32, i32, i32, f32, vp],
     "pcm_groupnorm_stats": [vp, vp, i32, i32, i32, i32, vp],
     "pcm_groupnorm_stats_acc": [vp, vp, i32, i32, i32, i32, vp],
     "pcm_groupnorm_stats_ws": [vp, vp, i32, i32, i32, i32, vp, C.c_size_t, vp],

@@ -181,8 +181,8 @@ class Discriminator:
         return d_feats
 
     def _conv_param_grads(self, hd, name, x, dy, M, wg):
-        """full conv3x3 weight gradient dW[co][tap][ci] = sum_m dy[m][co] * im2col(x)[m][(tap,ci)] as Cout/64 launches of
-        the rank-64 wgrad kernel (64 output channels each), bias gradient = pixel sum of dy."""
+        """full conv3x3 weight gradient dW[co][tap][ci] = sum_m dy[m][co] * im2col(x)[m][(tap,ci)]: the dense kernel
+        (csrc/wgrad_dense.hip) where the geometry allows, else Cout/64 launches of the rank-64 wgrad kernel; bias gradient = pixel sum of dy."""
         C = hd.C
         if self.ksize == 1:      # dW[co][ci] = sum_m dy[m][co] * x[m][ci]: plain rank-64 wgrad per 64 output channels
             gW = hd.g[name + ".weight"].view(C, C)
@@ -192,9 +192,12 @@ class Discriminator:
             capi.lib().call("pcm_colsum_bf16", ops.ptr(dy), ops.ptr(hd.g[name + ".bias"]), 1, M, C, capi.Lib.stream())
             return
         gW = hd.g[name + ".weight"].view(C, 9 * C)
-        with ops.wgrad_batch():           # (3x3 view: the jobs the multi-launch kernel does not take run one by one inside the call)
-            for co in range(0, C, 64):
-                ops.lora_wgrad(x, dy[:, co:co + 64], gW[co:co + 64], 1.0, M, conv=wg, g_stride=1, r_stride=9 * C, lds=C)
+        if ops.conv3x3_wgrad_ok(wg["Hs"], wg["Ws"], C, C):          # dense kernel: one launch, x staged once per 128 input channels
+            ops.conv3x3_wgrad(x.reshape(-1, wg["Hs"], wg["Ws"], C), dy, gW, M // (wg["Hs"] * wg["Ws"]), wg["Hs"], wg["Ws"])
+        else:
+            with ops.wgrad_batch():       # (3x3 view: the jobs the multi-launch kernel does not take run one by one inside the call)
+                for co in range(0, C, 64):
+                    ops.lora_wgrad(x, dy[:, co:co + 64], gW[co:co + 64], 1.0, M, conv=wg, g_stride=1, r_stride=9 * C, lds=C)
         capi.lib().call("pcm_colsum_bf16", ops.ptr(dy), ops.ptr(hd.g[name + ".bias"]), 1, M, C, capi.Lib.stream())
 
     # ------------------------------------------------------------------ losses (discriminator_sd15.py:412-434)

@@ -463,6 +463,19 @@ def lora_wgrad(big, small, out, alpha, M, G=None, conv=None, g_stride=None, r_st
     capi.lib().call("pcm_lora_wgrad_bf16", C.byref(a), _stream())
 
 
+def conv3x3_wgrad(x, dy, dW, B, H, W, alpha=1.0):
+    """dW[co][kh][kw][ci] += alpha * sum_p dy[p][co] * x[p + (kh-1, kw-1)][ci]: dense 3x3 / stride 1 / pad 1 weight gradient
+    (x [B,H,W,Cin] bf16, dy [B*H*W, Cout] bf16, dW fp32 [Cout, 3, 3, Cin] or [Cout, 9*Cin]); csrc/wgrad_dense.hip."""
+    Cin, Cout = x.shape[-1], dy.shape[-1]
+    assert x.is_contiguous() and dy.is_contiguous() and dW.is_contiguous() and dW.numel() == 9 * Cin * Cout
+    capi.lib().call("pcm_conv3x3_wgrad_bf16", ptr(x), ptr(dy), ptr(dW), B, H, W, Cin, Cout, alpha, _stream())
+
+
+def conv3x3_wgrad_ok(H, W, Cin, Cout):
+    """geometries csrc/wgrad_dense.hip takes (pcm_hip.h)"""
+    return H % 8 == 0 and W % 8 == 0 and Cin % 8 == 0 and Cout % 64 == 0
+
+
 _WG_BATCH = None
 
 

@@ -284,6 +284,22 @@ def case_wgrad_conv(dev, B, Hs, Ws, C, stride, src_mode=0):
     close(dA2.permute(0, 3, 1, 2), A.grad, 2e-3, 2e-3 * M ** 0.5, "dA conv (khwc layout)")
 
 
+def case_wgrad_dense(dev, B, H, W, Cin, Cout, alpha=1.0, prefill=True):
+    """pcm_conv3x3_wgrad_bf16 (csrc/wgrad_dense.hip) against autograd of F.conv2d: accumulates into a pre-filled dW in the library's
+    [co][kh][kw][ci] layout."""
+    x = rnd(B, H, W, Cin, seed=1, dev=dev)
+    dy = rnd(B * H * W, Cout, seed=2, dev=dev)
+    Wt = torch.zeros(Cout, Cin, 3, 3, requires_grad=True)
+    F.conv2d(x.float().cpu().permute(0, 3, 1, 2), Wt, None, padding=1).backward(dy.float().cpu().view(B, H, W, Cout).permute(0, 3, 1, 2))
+    ref = Wt.grad.permute(0, 2, 3, 1) * alpha
+    pre = (torch.arange(Cout * 9 * Cin, dtype=torch.float32).view(Cout, 3, 3, Cin) % 7 - 3) * 0.25 if prefill else torch.zeros(Cout, 3, 3, Cin)
+    dW = pre.clone().to(dev)
+    assert ops.conv3x3_wgrad_ok(H, W, Cin, Cout)
+    ops.conv3x3_wgrad(x, dy, dW, B, H, W, alpha)
+    M = B * H * W
+    close(dW.cpu() - pre, ref, 2e-3, 2e-3 * M ** 0.5 * alpha, "dense conv3x3 wgrad %s" % ((B, H, W, Cin, Cout),))
+
+
 def case_attention(dev, B, H, Lq, Lk, d, spike=False, spike_at=None):
     q = rnd(B, Lq, H * d, seed=1, dev=dev)
     k = rnd(B, Lk, H * d, seed=2, dev=dev)

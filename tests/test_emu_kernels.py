@@ -88,6 +88,22 @@ def test_wgrad_conv_transpose_read_kernel(B, H, W, C):
     assert cnt(1) == n0 + 1      # the khwc-layout call took the transpose-read kernel (the peft-layout call stays on wgrad.hip)
 
 
+# dense 3x3 weight gradient (wgrad_dense.hip): one 8x8 patch; borders on all four sides + several patches per image + two images; a
+# ragged input-channel tile (72 of 128) and two output tiles; enough stages for the M split (atomic epilogue) under the emulator's grid cap
+@pytest.mark.parametrize("B,H,W,Cin,Cout,alpha", [(1, 8, 8, 64, 64, 1.0), (2, 16, 24, 72, 128, 0.5), (8, 16, 16, 128, 64, 1.0), (1, 8, 16, 192, 64, 1.0)])
+def test_wgrad_dense_conv3x3(B, H, W, Cin, Cout, alpha):
+    K.case_wgrad_dense("cpu", B, H, W, Cin, Cout, alpha)
+
+
+def test_wgrad_dense_conv3x3_rejects_unsupported_geometry():
+    import torch
+    from pcm_amd import capi, ops
+    x = torch.zeros(1, 6, 8, 64, dtype=torch.bfloat16); dy = torch.zeros(48, 64, dtype=torch.bfloat16); dW = torch.zeros(64, 9 * 64)
+    with pytest.raises(capi.PcmError, match="pcm_conv3x3_wgrad_bf16"):
+        ops.conv3x3_wgrad(x, dy, dW, 1, 6, 8)
+    assert not ops.conv3x3_wgrad_ok(6, 8, 64, 64) and not ops.conv3x3_wgrad_ok(8, 8, 64, 96)
+
+
 def test_wgrad_multi_job_launch():
     import ctypes
     from pcm_amd import capi

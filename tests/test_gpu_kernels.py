@@ -78,6 +78,14 @@ def test_wgrad_conv(stride, src_mode, C):
     K.case_wgrad_conv("cuda", 2, 16, 16, C, stride, src_mode)
 
 
+# dense 3x3 weight gradient (wgrad_dense.hip) on the discriminator-head geometries: the 8x8 tap at 1280 channels (one owner per tile:
+# read-add-write epilogue), 16x16 at 640 and 32x32 at 320 (M split + atomics, ragged 128-channel tile), a 64x64 tap, rectangular images
+@pytest.mark.parametrize("B,H,W,Cin,Cout,alpha", [(4, 8, 8, 1280, 1280, 1.0), (4, 16, 16, 640, 640, 1.0), (2, 32, 32, 320, 320, 0.5),
+                                                  (1, 64, 64, 320, 320, 1.0), (3, 16, 40, 192, 128, 1.0)])
+def test_wgrad_dense_conv3x3(B, H, W, Cin, Cout, alpha):
+    K.case_wgrad_dense("cuda", B, H, W, Cin, Cout, alpha)
+
+
 @pytest.mark.parametrize("B,H,Lq,Lk,d,spike", [(1, 8, 1024, 1024, 40, False), (2, 8, 256, 77, 80, False),
                                                (2, 8, 256, 256, 160, True), (1, 8, 64, 64, 160, False),
                                                (1, 2, 4096, 4096, 40, True), (1, 8, 4096, 77, 40, False),
