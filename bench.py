@@ -228,6 +228,25 @@ def bench_other_config(args, world, rank, local_rank, dev, sync):
         dt = float(tt.item())
     ms = dt * 1e3 / args.steps
     ach = tf_sample * B / (ms * 1e-3)
+    if os.environ.get("PCM_GEMM_TABLE") and rank == 0 and world == 1:
+        # diagnostic only (after the timed region): one more eager step (c3: a D + G pair) with HIP events around every pcm_gemm_bf16 launch
+        from pcm_amd import ops
+        ops.GEMM_PROFILE = []
+        eager_steps = [draw() for _ in range(2 if cfgname == "c3" else 1)]
+        ug, use_graph = use_graph, False
+        for b in eager_steps:
+            step(b)
+        use_graph = ug
+        torch.cuda.synchronize()
+        prof, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
+        agg = {}
+        for fl, e0, e1, key, _plan, _nb in prof:
+            a = agg.setdefault(str(key) + " plan %d" % _plan, [0, 0.0, 0.0])
+            a[0] += 1; a[1] += e0.elapsed_time(e1); a[2] += fl
+        with open(os.environ["PCM_GEMM_TABLE"], "w") as f:
+            f.write("# %s: every pcm_gemm_bf16 launch of %d eager step(s), by shape (M, N, (K per segment), kind) and plan\n" % (cfgname, len(eager_steps)))
+            for k, (n, t, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+                f.write("%-56s calls %4d  total %8.3f ms  avg %7.1f us  %7.1f TF/s\n" % (k, n, t, 1e3 * t / n, fl / t / 1e9))
     losses = None
     if cfgname == "c3" and "d" in state and "g" in state:      # last D / G step of this rank (graph replay and eager launches must agree on them)
         losses = {"d_loss_last": round(float(state["d"]["d_loss"]), 6), "loss_cm_last": round(float(state["g"]["loss_cm"]), 6),
