@@ -371,7 +371,7 @@ static int big_mode() {
   if (g_big_mode < 0) { const char* e = getenv("PCM_GEMM_BIG"); g_big_mode = e ? atoi(e) : 1; }
   return g_big_mode;
 }
-// tuning hook (tools/ only): force the block tile of subsequent pcm_gemm_bf16 calls; (0,0) restores the planner
+// tuning hook (tools/ only): force the block tile (bm | ksplit << 16, bn) of subsequent pcm_gemm_bf16 calls; (0,0) restores the planner
 extern "C" void pcm_debug_force_gemm_tile(int bm, int bn) { g_force_bm = bm; g_force_bn = bn; }
 
 // big_ok: the call satisfies gemm8p's preconditions (K%64==0 per segment, bf16 output with 16-B rows, < 2 GiB operands)
@@ -436,8 +436,14 @@ static GemmPlan gemm_plan(int M, int N, int total_kt, bool allow_split, bool big
     }
   }
   if (g_force_bm) {
-    p.splitk = 1; p.kt_per_split = total_kt; p.ws_bytes = 0; p.BM = g_force_bm; p.BN = g_force_bn;
+    p.splitk = 1; p.kt_per_split = total_kt; p.ws_bytes = 0; p.BM = g_force_bm & 0xffff; p.BN = g_force_bn;
     p.tiles_m = (M + p.BM - 1) / p.BM; p.tiles_n = (N + p.BN - 1) / p.BN;
+    const int fs = g_force_bm >> 16;          // tuning: bits 16.. of the forced BM = K split
+    if (fs > 1 && allow_split && total_kt >= 2 * fs) {
+      p.kt_per_split = (total_kt + fs - 1) / fs;
+      p.splitk = (total_kt + p.kt_per_split - 1) / p.kt_per_split;
+      p.ws_bytes = (size_t)p.splitk * M * N * sizeof(float);
+    }
     return p;
   }
   p.splitk = 1; p.kt_per_split = total_kt; p.ws_bytes = 0;

@@ -1,0 +1,5 @@
+#!/bin/bash
+# round 4, call N: plan sweep on the small-M GEMM shapes of the deep UNet levels (tools/gemm_small_m.py)
+cd $GRAFT_REPO_ROOT; O=gpurun_out/r04n; mkdir -p $O; export TMPDIR=/tmp
+timeout 900 python tools/gemm_small_m.py > $O/small_m_sweep.txt 2> $O/small_m_sweep.err; echo "sweep rc=$?" >> $O/rc.log
+cat $O/rc.log; cat $O/small_m_sweep.txt; tail -3 $O/small_m_sweep.err
