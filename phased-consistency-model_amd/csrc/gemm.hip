@@ -435,6 +435,15 @@ static GemmPlan gemm_plan(int M, int N, int total_kt, bool allow_split, bool big
       return p;
     }
   }
+  if (g_force_bm && (g_force_bm & 0xffff) == 256 && big_ok && (g_force_bn == 256 || g_force_bn == 320)) {   // tuning: the phased tile, forced
+    const int fs = (g_force_bm >> 16) > 1 && allow_split && !must_big ? (g_force_bm >> 16) : 1;
+    p.big_fn = g_force_bn / 64; p.BM = 256; p.BN = g_force_bn;
+    p.tiles_m = (M + 255) / 256; p.tiles_n = (N + p.BN - 1) / p.BN;
+    p.kt_per_split = (total_kt + fs - 1) / fs;
+    p.splitk = (total_kt + p.kt_per_split - 1) / p.kt_per_split;
+    p.ws_bytes = p.splitk > 1 ? (size_t)p.splitk * M * N * sizeof(float) : 0;
+    return p;
+  }
   if (g_force_bm) {
     p.splitk = 1; p.kt_per_split = total_kt; p.ws_bytes = 0; p.BM = g_force_bm & 0xffff; p.BN = g_force_bn;
     p.tiles_m = (M + p.BM - 1) / p.BM; p.tiles_n = (N + p.BN - 1) / p.BN;
@@ -452,7 +461,11 @@ static GemmPlan gemm_plan(int M, int N, int total_kt, bool allow_split, bool big
   auto ntiles = [&](int bm, int bn) { return (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
   long tiles = ntiles(p.BM, p.BN);
   if (tiles < 256 && p.BM == 256) { p.BM = 128; tiles = ntiles(128, 64); }
-  if (tiles < 256 && allow_split && total_kt >= 16) {
+  // short K (<= 1536 incl. the LoRA segment): a smaller tile and no K split beats the slab round trip + finalize launch, and the grid
+  // should hold ~2 tiles per CU (tools/gemm_small_m.py, profiles/r04_n_small_m_plan_sweep.txt: (2048, 1280, K 1280) 128x128 / 3 slabs
+  // 25.9 us, 64x64 16.3; (1024, 1280, 1280) 20.5 -> 14.4; (8192, 640, 640) 128x128 20.5, 128x64 16.9; (4096, 1280, 1280) 29.7 -> 27.1)
+  const bool short_k = total_kt <= 24 && ntiles(64, 64) >= 256;      // (grids that even 64x64 tiles do not fill keep the K split)
+  if (!short_k && tiles < 256 && allow_split && total_kt >= 16) {
     // under-filled grid with a long K loop: slice K across blockIdx.y (slab reduction, no atomics)
     int s = (int)((384 + tiles - 1) / tiles);
     if (s > total_kt / 4) s = total_kt / 4;
@@ -464,8 +477,9 @@ static GemmPlan gemm_plan(int M, int N, int total_kt, bool allow_split, bool big
     }
   }
   if (p.splitk == 1) {  // otherwise shrink the tile until the grid fills the chip
-    if (tiles < 256 && p.BN == 128) { p.BN = 64; tiles = ntiles(128, 64); }
-    if (tiles < 256) { p.BM = 64; p.BN = 64; }
+    const long want = short_k ? 512 : 256;
+    if (tiles < want && p.BN == 128) { p.BN = 64; tiles = ntiles(128, 64); }
+    if (tiles < want && p.BM <= 128) { p.BM = 64; p.BN = 64; }
   }
   p.tiles_m = (M + p.BM - 1) / p.BM;
   p.tiles_n = (N + p.BN - 1) / p.BN;
