@@ -427,6 +427,22 @@ static GemmPlan gemm_plan(int M, int N, int total_kt, bool allow_split, bool big
     }
     const double need = (big_mode() == 2 || big_mode() == 3 || must_big) ? 0.0 : 0.62;
     if (best_fn && best >= need) {
+      // WHICH phased-tile plan: a time model fitted to the plan sweep of round 4 (tools/gemm_small_m.py, profiles/r04_n_*): a block-round
+      // costs 10 us + 1.4 us (256x256) / 1.75 us (256x320) per 64-wide K step; a K split adds the slab round trip (s fp32 slabs written
+      // and read back at ~3.5 TB/s) and the finalize launch.  The occupancy score above valued a split at a flat 15 %: on
+      // (16384, 1536, K 1536) it took 2 slabs (143 us) where no split runs 94 us, on (8192, 1536, K 6144) 4 slabs (182 us) against 134.
+      double best_t = 1e30;
+      for (int fn = 5; fn >= 4; fn--) {
+        const int bn = 64 * fn;
+        const long tiles = (long)((M + 255) / 256) * ((N + bn - 1) / bn);
+        for (int sp = 1; sp <= 8; sp++) {
+          if (sp > 1 && (!allow_split || total_kt / sp < 12)) break;
+          const long rounds = (tiles * sp + 255) / 256;
+          double t = (double)rounds * (((total_kt + sp - 1) / sp) * (fn == 5 ? 1.75 : 1.4) + 10.0);
+          if (sp > 1) t += ((double)sp * M * N * 4.0 + (double)M * N * 2.0) / 3.5e6 + 3.0;
+          if (t < best_t - 1e-9) { best_t = t; best_fn = fn; best_s = sp; }
+        }
+      }
       p.big_fn = best_fn; p.BM = 256; p.BN = 64 * best_fn;
       p.tiles_m = (M + 255) / 256; p.tiles_n = (N + p.BN - 1) / p.BN;
       p.kt_per_split = (total_kt + best_s - 1) / best_s;
