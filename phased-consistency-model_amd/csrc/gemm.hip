@@ -367,6 +367,13 @@ static int g_ablate = 0;      // see PCM_ABL in gemm_dev.h (no effect in the pro
 extern "C" void pcm_debug_gemm_ablate(int mask) { g_ablate = mask; }
 static int g_last_plan = 0;   // tests only: 1000*big_fn + splitk of the most recent pcm_gemm_bf16 launch (gemm4w: 10000 + 1000*fn + 1)
 extern "C" int pcm_debug_last_gemm_plan(void) { return g_last_plan; }
+// A/B only: PCM_GEMM_PLAN_LEGACY=1 = the planner as it was before the round-4 re-fit (flat 15 % price of a K split, K split for every
+// under-filled small-tile grid)
+static bool plan_legacy() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("PCM_GEMM_PLAN_LEGACY"); v = e ? atoi(e) : 0; }
+  return v != 0;
+}
 static int big_mode() {
   if (g_big_mode < 0) { const char* e = getenv("PCM_GEMM_BIG"); g_big_mode = e ? atoi(e) : 1; }
   return g_big_mode;
@@ -432,7 +439,7 @@ static GemmPlan gemm_plan(int M, int N, int total_kt, bool allow_split, bool big
       // and read back at ~3.5 TB/s) and the finalize launch.  The occupancy score above valued a split at a flat 15 %: on
       // (16384, 1536, K 1536) it took 2 slabs (143 us) where no split runs 94 us, on (8192, 1536, K 6144) 4 slabs (182 us) against 134.
       double best_t = 1e30;
-      for (int fn = 5; fn >= 4; fn--) {
+      for (int fn = 5; fn >= 4 && !plan_legacy(); fn--) {
         const int bn = 64 * fn;
         const long tiles = (long)((M + 255) / 256) * ((N + bn - 1) / bn);
         for (int sp = 1; sp <= 8; sp++) {
@@ -480,7 +487,7 @@ static GemmPlan gemm_plan(int M, int N, int total_kt, bool allow_split, bool big
   // short K (<= 1536 incl. the LoRA segment): a smaller tile and no K split beats the slab round trip + finalize launch, and the grid
   // should hold ~2 tiles per CU (tools/gemm_small_m.py, profiles/r04_n_small_m_plan_sweep.txt: (2048, 1280, K 1280) 128x128 / 3 slabs
   // 25.9 us, 64x64 16.3; (1024, 1280, 1280) 20.5 -> 14.4; (8192, 640, 640) 128x128 20.5, 128x64 16.9; (4096, 1280, 1280) 29.7 -> 27.1)
-  const bool short_k = total_kt <= 24 && ntiles(64, 64) >= 256;      // (grids that even 64x64 tiles do not fill keep the K split)
+  const bool short_k = total_kt <= 24 && ntiles(64, 64) >= 256 && !plan_legacy();      // (grids that even 64x64 tiles do not fill keep the K split)
   if (!short_k && tiles < 256 && allow_split && total_kt >= 16) {
     // under-filled grid with a long K loop: slice K across blockIdx.y (slab reduction, no atomics)
     int s = (int)((384 + tiles - 1) / tiles);
