@@ -70,43 +70,57 @@ __global__ __launch_bounds__(256) void pcm_gemm_n64_kernel(GemmDev g) {
   }
 }
 
-// Small-M variant (M <= 16384: the 16x16 / 8x8 / 32x32 feature maps).  There the pass is latency bound, not bandwidth bound: a
-// block owns 16 rows and splits K over its waves (160 columns per wave and sub-chunk), every wave reads its activation AND
-// weight fragments straight from global / L2 (no LDS staging, no chunk loop for K <= 1280), the partial 16x64 tiles are
-// summed through LDS.  One memory round trip instead of one per K-chunk.
-template <int NW>
+// Small-M variant (M <= 16384: the 16x16 / 8x8 / 32x32 feature maps, the 4096-token SDXL / SD3 levels).  There the pass is latency bound,
+// not bandwidth bound: a block owns 16 RF rows and splits K over its waves (32 NS columns per wave and sub-chunk, NS = 5 or 4), every wave
+// reads its activation AND weight fragments straight from global / L2 (no LDS staging, no chunk loop for K <= 1280), the partial tiles are
+// summed through LDS.  One memory round trip instead of one per K-chunk.  RF = 2 (32 rows per block) where that still gives >= 256 blocks:
+// every block reads the whole 64 x K weight matrix from L2, which at 16 rows per block is 4x the activation bytes ((8192, K 5120): 335 MB
+// of weight reads for 84 MB of activations).
+template <int NW, int RF, int NS>
 __global__ __launch_bounds__(64 * NW) void pcm_gemm_n64_ksplit_kernel(GemmDev g, int sub) {
-  __shared__ __attribute__((aligned(16))) float red[NW][16][64];
+  __shared__ __attribute__((aligned(16))) float red[NW][16 * RF][64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int frow = lane & 15, fk = lane >> 4;
   const SegDev& sg = g.seg[0];
-  int m = blockIdx.x * 16 + frow; if (m > g.M - 1) m = g.M - 1;
-  const bf16_t* xr = sg.a + (size_t)m * sg.lda + 8 * fk;
+  const bf16_t* xr[RF];
+#pragma unroll
+  for (int j = 0; j < RF; j++) {
+    int m = blockIdx.x * (16 * RF) + 16 * j + frow; if (m > g.M - 1) m = g.M - 1;
+    xr[j] = sg.a + (size_t)m * sg.lda + 8 * fk;
+  }
   const bf16_t* wr = sg.w + (size_t)frow * sg.K + 8 * fk;
-  f32x4 acc[4];
+  f32x4 acc[RF][4];
 #pragma unroll
-  for (int f = 0; f < 4; f++) acc[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int j = 0; j < RF; j++)
+#pragma unroll
+    for (int f = 0; f < 4; f++) acc[j][f] = f32x4{0.f, 0.f, 0.f, 0.f};
   for (int sc = 0; sc < sub; sc++) {
-    const int k0 = (wave * sub + sc) * 160;
-    bf16x8 xf[5], wf[4][5];
+    const int k0 = (wave * sub + sc) * (32 * NS);
+    bf16x8 xf[RF][NS], wf[4][NS];
 #pragma unroll
-    for (int s = 0; s < 5; s++) xf[s] = *(const bf16x8*)(xr + k0 + 32 * s);
+    for (int j = 0; j < RF; j++)
+#pragma unroll
+      for (int s = 0; s < NS; s++) xf[j][s] = *(const bf16x8*)(xr[j] + k0 + 32 * s);
 #pragma unroll
     for (int f = 0; f < 4; f++)
 #pragma unroll
-      for (int s = 0; s < 5; s++) wf[f][s] = *(const bf16x8*)(wr + (size_t)(16 * f) * sg.K + k0 + 32 * s);
-    __builtin_amdgcn_sched_barrier(0);   // all 25 loads in flight before the first MFMA (hipcc otherwise sinks them one by one)
+      for (int s = 0; s < NS; s++) wf[f][s] = *(const bf16x8*)(wr + (size_t)(16 * f) * sg.K + k0 + 32 * s);
+    __builtin_amdgcn_sched_barrier(0);   // all loads in flight before the first MFMA (hipcc otherwise sinks them one by one)
 #pragma unroll
-    for (int s = 0; s < 5; s++)
+    for (int s = 0; s < NS; s++)
 #pragma unroll
-      for (int f = 0; f < 4; f++) acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[f][s], xf[s], acc[f], 0, 0, 0);
+      for (int f = 0; f < 4; f++)
+#pragma unroll
+        for (int j = 0; j < RF; j++) acc[j][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[f][s], xf[j][s], acc[j][f], 0, 0, 0);
   }
 #pragma unroll
-  for (int f = 0; f < 4; f++) *(float4*)&red[wave][frow][16 * f + 4 * fk] = make_float4(acc[f][0], acc[f][1], acc[f][2], acc[f][3]);
+  for (int j = 0; j < RF; j++)
+#pragma unroll
+    for (int f = 0; f < 4; f++) *(float4*)&red[wave][16 * j + frow][16 * f + 4 * fk] = make_float4(acc[j][f][0], acc[j][f][1], acc[j][f][2], acc[j][f][3]);
   __syncthreads();
-  for (int idx = tid; idx < 256; idx += 64 * NW) {
+  for (int idx = tid; idx < 256 * RF; idx += 64 * NW) {
     const int row = idx >> 4, c4 = idx & 15;
-    const int mm = blockIdx.x * 16 + row;
+    const int mm = blockIdx.x * (16 * RF) + row;
     if (mm >= g.M) continue;
     float4 t = *(const float4*)&red[0][row][4 * c4];
 #pragma unroll
@@ -116,6 +130,14 @@ __global__ __launch_bounds__(64 * NW) void pcm_gemm_n64_ksplit_kernel(GemmDev g,
     }
     *(uint2*)((bf16_t*)g.out + (size_t)mm * g.ldo + 4 * c4) = make_uint2(pack_bf2(t.x * g.alpha, t.y * g.alpha), pack_bf2(t.z * g.alpha, t.w * g.alpha));
   }
+}
+template <int RF, int NS>
+static void launch_ksplit(const GemmDev& g, int parts, void* stream) {
+  const dim3 grid((g.M + 16 * RF - 1) / (16 * RF));
+  if (parts % 8 == 0) PCM_LAUNCH((pcm_gemm_n64_ksplit_kernel<8, RF, NS>), grid, dim3(512), 0, stream, g, parts / 8);
+  else if (parts % 4 == 0) PCM_LAUNCH((pcm_gemm_n64_ksplit_kernel<4, RF, NS>), grid, dim3(256), 0, stream, g, parts / 4);
+  else if (parts % 2 == 0) PCM_LAUNCH((pcm_gemm_n64_ksplit_kernel<2, RF, NS>), grid, dim3(128), 0, stream, g, parts / 2);
+  else PCM_LAUNCH((pcm_gemm_n64_ksplit_kernel<1, RF, NS>), grid, dim3(64), 0, stream, g, parts);
 }
 
 template <int NS, int RF>
@@ -128,13 +150,10 @@ static void launch_n64(const GemmDev& g, void* stream) {
 // residual / activation
 int pcm_gemm_n64_launch(const GemmDev& g, void* stream) {
   const int K = g.seg[0].K;
-  if (g.M <= 16384 && K % 160 == 0) {
-    const int parts = K / 160;                       // 160-column pieces; NW waves take parts/NW each
-    const dim3 grid((g.M + 15) / 16);
-    if (parts % 8 == 0) PCM_LAUNCH((pcm_gemm_n64_ksplit_kernel<8>), grid, dim3(512), 0, stream, g, parts / 8);
-    else if (parts % 4 == 0) PCM_LAUNCH((pcm_gemm_n64_ksplit_kernel<4>), grid, dim3(256), 0, stream, g, parts / 4);
-    else if (parts % 2 == 0) PCM_LAUNCH((pcm_gemm_n64_ksplit_kernel<2>), grid, dim3(128), 0, stream, g, parts / 2);
-    else PCM_LAUNCH((pcm_gemm_n64_ksplit_kernel<1>), grid, dim3(64), 0, stream, g, parts);
+  if (g.M <= 16384 && (K % 160 == 0 || K % 128 == 0)) {
+    const bool two = g.M >= 32 * PCM_GRID_CAP(256);  // 32 rows per block where that still fills the chip
+    if (K % 160 == 0) { if (two) launch_ksplit<2, 5>(g, K / 160, stream); else launch_ksplit<1, 5>(g, K / 160, stream); }
+    else { if (two) launch_ksplit<2, 4>(g, K / 128, stream); else launch_ksplit<1, 4>(g, K / 128, stream); }
     return 0;
   }
   const bool wide = (g.M + 127) / 128 >= 512;       // enough 128-row blocks for two per CU: 32 rows per wave, else 16
