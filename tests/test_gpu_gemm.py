@@ -102,7 +102,7 @@ def test_big_tile_kernel_large_shapes_match_small_tile():
 
 
 @pytest.mark.parametrize("M,K", [(65536, 320), (4096, 1280), (1232, 768), (16384, 640), (200, 192), (131072, 320), (65536, 2560), (8192, 1280), (2048, 2560), (1024, 960), (32768, 640),
-                                 (8192, 6144), (8192, 5120), (4096, 10240), (8192, 1536), (616, 2048), (9000, 1280)])
+                                 (8192, 6144), (8192, 5120), (4096, 10240), (8192, 1536), (616, 2048), (9000, 1280), (4096, 5120), (16384, 1536)])
 def test_rank64_streaming_kernel(M, K):
     import kernel_cases as KC
     assert KC.case_gemm_n64("cuda", M, K) <= 0

@@ -30,7 +30,7 @@ def timed(fn):
 
 
 def sweep(name, fl, call):
-    arms = [("planner", 1, (0, 0)), ("8p", 2, (0, 0))]
+    arms = [("planner", 1, (0, 0)), ("8p", 2, (0, 0)), ("4w", 3, (0, 0))]
     for (bm, bn) in ((128, 128), (128, 64), (64, 64), (256, 256), (256, 320)):
         for sp in (1, 2, 3, 4, 6, 8):
             arms.append(("%dx%d/%d" % (bm, bn, sp), 0, (bm | (sp << 16), bn)))
