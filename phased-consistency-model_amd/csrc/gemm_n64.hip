@@ -6,6 +6,8 @@
 // straight into registers in MFMA fragment layout before touching any of them, several blocks per CU, so the CU keeps
 // hundreds of KB in flight.  The 64 x KC weight chunk is staged once per block in LDS (padded rows, conflict-free b128 reads).
 // v_mfma_f32_16x16x32_bf16 with the weights as the A operand: lane owns 4 consecutive channels of one row (8-byte stores).
+#include <stdlib.h>
+
 #include "gemm_dev.h"
 
 template <int NS, int RF>   // NS = 32-column steps per K-chunk (KC = 32*NS); RF = 16-row fragments per wave
@@ -134,10 +136,6 @@ __global__ __launch_bounds__(64 * NW) void pcm_gemm_n64_ksplit_kernel(GemmDev g,
 template <int RF, int NS>
 static void launch_ksplit(const GemmDev& g, int parts, void* stream) {
   const dim3 grid((g.M + 16 * RF - 1) / (16 * RF));
-  if (RF == 1 && NS == 5 && parts % 16 == 0 && parts >= 32) {   // long K at 16 rows per block: 16 waves halve the serial round trips per wave
-    PCM_LAUNCH((pcm_gemm_n64_ksplit_kernel<16, 1, 5>), grid, dim3(1024), 0, stream, g, parts / 16);
-    return;
-  }
   if (parts % 8 == 0) PCM_LAUNCH((pcm_gemm_n64_ksplit_kernel<8, RF, NS>), grid, dim3(512), 0, stream, g, parts / 8);
   else if (parts % 4 == 0) PCM_LAUNCH((pcm_gemm_n64_ksplit_kernel<4, RF, NS>), grid, dim3(256), 0, stream, g, parts / 4);
   else if (parts % 2 == 0) PCM_LAUNCH((pcm_gemm_n64_ksplit_kernel<2, RF, NS>), grid, dim3(128), 0, stream, g, parts / 2);
@@ -156,9 +154,12 @@ int pcm_gemm_n64_launch(const GemmDev& g, void* stream) {
   const int K = g.seg[0].K;
   // (128-column pieces only up to M = 8192: at (16384, K 1536) the chunked streaming kernel below runs 17.4 us, this one 21.7)
   if (g.M <= 16384 && (K % 160 == 0 || (K % 128 == 0 && g.M <= 8192))) {
-    const bool two = g.M >= 32 * PCM_GRID_CAP(256);  // 32 rows per block where that still fills the chip
-    if (K % 160 == 0) { if (two) launch_ksplit<2, 5>(g, K / 160, stream); else launch_ksplit<1, 5>(g, K / 160, stream); }
-    else { if (two) launch_ksplit<2, 4>(g, K / 128, stream); else launch_ksplit<1, 4>(g, K / 128, stream); }
+    // rows per block: 16 RF.  Every block re-reads the whole weight matrix from L2, so RF as large as the grid allows (>= 128 blocks);
+    // RF = 4 (224 VGPRs) only for long K, where the weight bytes dominate.  PCM_N64_RF overrides (tuning).
+    static const int env_rf = getenv("PCM_N64_RF") ? atoi(getenv("PCM_N64_RF")) : 0;
+    int rf = env_rf ? env_rf : (g.M >= 64 * PCM_GRID_CAP(128) && K >= 2560 ? 4 : (g.M >= 32 * PCM_GRID_CAP(128) ? 2 : 1));
+    if (K % 160 == 0) { if (rf == 4) launch_ksplit<4, 5>(g, K / 160, stream); else if (rf == 2) launch_ksplit<2, 5>(g, K / 160, stream); else launch_ksplit<1, 5>(g, K / 160, stream); }
+    else { if (rf == 4) launch_ksplit<4, 4>(g, K / 128, stream); else if (rf == 2) launch_ksplit<2, 4>(g, K / 128, stream); else launch_ksplit<1, 4>(g, K / 128, stream); }
     return 0;
   }
   const bool wide = (g.M + 127) / 128 >= 512;       // enough 128-row blocks for two per CU: 32 rows per wave, else 16

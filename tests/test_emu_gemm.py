@@ -140,7 +140,7 @@ def test_big_tile_conv_order_by_shape():
 
 # (K % 160 == 0 or K % 128 == 0: the K-split kernel -- 160- / 128-column pieces, one or two 16-row fragments per block (emulator: two from M = 128),
 # 1 / 2 / 4 / 8 waves; otherwise the chunked streaming kernel)
-@pytest.mark.parametrize("M,K", [(200, 320), (64, 1280), (130, 768), (77, 192), (40, 640), (33, 2560), (20, 960), (150, 1536), (129, 6144), (50, 2048), (140, 640), (33, 5120)])
+@pytest.mark.parametrize("M,K", [(200, 320), (64, 1280), (130, 768), (77, 192), (40, 640), (33, 2560), (20, 960), (150, 1536), (129, 6144), (50, 2048), (140, 640), (33, 5120), (260, 2560), (300, 6144)])
 def test_rank64_streaming_kernel(M, K):
     import kernel_cases as KC
     assert KC.case_gemm_n64("cpu", M, K) <= 0
