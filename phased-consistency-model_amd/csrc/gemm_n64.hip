@@ -154,10 +154,12 @@ int pcm_gemm_n64_launch(const GemmDev& g, void* stream) {
   const int K = g.seg[0].K;
   // (128-column pieces only up to M = 8192: at (16384, K 1536) the chunked streaming kernel below runs 17.4 us, this one 21.7)
   if (g.M <= 16384 && (K % 160 == 0 || (K % 128 == 0 && g.M <= 8192))) {
-    // rows per block: 16 RF.  Every block re-reads the whole weight matrix from L2, so RF as large as the grid allows (>= 128 blocks);
-    // RF = 4 (224 VGPRs) only for long K, where the weight bytes dominate.  PCM_N64_RF overrides (tuning).
+    // rows per block: 16 RF.  Every block re-reads the whole weight matrix from L2, so more rows per block cut the L2 traffic -- as long as
+    // the grid still covers the chip: measured per shape with RF forced (profiles/r04_t_n64_ksplit_rows_per_block.txt), the fastest form
+    // is RF = 4 (224 VGPRs) from 256 blocks of 64 rows, RF = 2 from 256 blocks of 32 rows, RF = 1 below (at M = 4096 RF = 2 is 15 % slower
+    // at every K).  PCM_N64_RF overrides (tuning).
     static const int env_rf = getenv("PCM_N64_RF") ? atoi(getenv("PCM_N64_RF")) : 0;
-    int rf = env_rf ? env_rf : (g.M >= 64 * PCM_GRID_CAP(128) && K >= 2560 ? 4 : (g.M >= 32 * PCM_GRID_CAP(128) ? 2 : 1));
+    int rf = env_rf ? env_rf : (g.M >= 64 * PCM_GRID_CAP(256) ? 4 : (g.M >= 32 * PCM_GRID_CAP(256) ? 2 : 1));
     if (K % 160 == 0) { if (rf == 4) launch_ksplit<4, 5>(g, K / 160, stream); else if (rf == 2) launch_ksplit<2, 5>(g, K / 160, stream); else launch_ksplit<1, 5>(g, K / 160, stream); }
     else { if (rf == 4) launch_ksplit<4, 4>(g, K / 128, stream); else if (rf == 2) launch_ksplit<2, 4>(g, K / 128, stream); else launch_ksplit<1, 4>(g, K / 128, stream); }
     return 0;
