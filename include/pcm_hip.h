@@ -52,6 +52,14 @@ extern "C" {
 
 const char* pcm_last_error(void);
 int pcm_abi_version(void);
+/* The 16-bit storage / MFMA operand format of THIS build of the library: PCM_FMT_BF16 (libpcm_hip.so, the default and what bench.py
+ * measures) or PCM_FMT_F16 (libpcm_hip_f16.so: the same sources compiled with -DPCM_ACT_F16 -- IEEE half, for the reference's
+ * --mixed_precision=fp16 recipes, train_pcm_lora_sd15.sh:9, and for the 1e-3 loss validation against the fp32 oracle).  Wherever this
+ * header says "bf16" for a buffer it means "the library's 16-bit format"; entry-point names do not change.  fp32 / fp64 arguments
+ * (master weights, accumulators, statistics, losses) are the same in both. */
+#define PCM_FMT_BF16 0
+#define PCM_FMT_F16 1
+int pcm_act_dtype(void);
 
 /* ---- contraction: Linear / conv1x1 / conv3x3 (implicit GEMM) + LoRA injection --------------
  * replaces F.linear / F.conv2d inside diffusers ResnetBlock2D.conv1/conv2, Attention.to_q/k/v/
@@ -337,6 +345,18 @@ int pcm_adamw_clip_step(float* p, const float* g, float* m, float* v, const doub
                         int step, float grad_scale, long n,
                         const int64_t* step_dev /*NULL: use `step`*/, const float* lr_dev /*NULL: use `lr`*/,
                         void* stream);
+/* Loss scaling for the half build (accelerate's GradScaler around train_pcm_lora_sd15.py:1296-1299 when --mixed_precision=fp16):
+ * pcm_scale_f32_dev multiplies the loss gradient by the scale S held in DEVICE memory before the backward; the *_scaled optimizer step
+ * divides it out again (g' = g * grad_scale / S, clip on the unscaled norm) and does NOTHING when *gradsq is not finite;
+ * pcm_loss_scale_update then applies GradScaler.update(): S *= growth after `interval` consecutive finite steps, S *= backoff (and
+ * *step_dev -= 1: a skipped update is not an optimizer step) after a non-finite one.  Everything stays capturable in a hipGraph. */
+int pcm_scale_f32_dev(float* x, const float* scale_dev, long n, void* stream);
+int pcm_adamw_clip_step_scaled(float* p, const float* g, float* m, float* v, const double* gradsq,
+                               float max_norm, float lr, float beta1, float beta2, float eps, float wd,
+                               float grad_scale, long n, const int64_t* step_dev, const float* lr_dev /*NULL: use `lr`*/,
+                               const float* loss_scale_dev, void* stream);
+int pcm_loss_scale_update(float* scale, int* good_steps, int64_t* step_dev /*may be NULL*/, const double* gradsq,
+                          float growth, float backoff, int interval, void* stream);
 /* update_ema (train_pcm_lora_sd15.py:344-355; defined by the reference, never called) */
 int pcm_ema_update(float* target, const float* source, float rate, long n, void* stream);
 

@@ -54,7 +54,7 @@ __device__ __forceinline__ void fill_pad_chunks(char* dst, int tid, bool ones) {
   constexpr int NP = C::RKU - C::DG;
   for (int u = tid; u < ROWS * NP; u += 256) {
     int r = u / NP, c = C::DG + (u - r * NP);
-    *(uint4*)(dst + (r * C::RKU + c) * 16) = make_uint4((ones && c == C::DG) ? 0x00003f80u : 0u, 0u, 0u, 0u);
+    *(uint4*)(dst + (r * C::RKU + c) * 16) = make_uint4((ones && c == C::DG) ? (unsigned)PCM_ONE_BITS : 0u, 0u, 0u, 0u);
   }
 }
 // fragment with the contraction index along the tile ROWS: A[i = column 32*it + (lane&31)][k], k-slot (hi, e) of step ss = tile row

@@ -28,8 +28,17 @@ extern "C" int pcm_sumsq_f32(const float* g, double* out, long n, void* stream) 
 // stays valid while the step count and the learning-rate schedule advance.
 __global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, float* m, float* v, const double* gradsq,
                                                     float max_norm, float lr, float b1, float b2, float eps, float wd,
-                                                    int step, float gscale, long n, const int64_t* step_dev, const float* lr_dev) {
+                                                    int step, float gscale, long n, const int64_t* step_dev, const float* lr_dev,
+                                                    const float* loss_scale_dev) {
   __shared__ float hyp[3];
+  // loss-scaled gradients (half build, pcm_adamw_clip_step_scaled): g holds S * grad with S in device memory.  A non-finite global norm
+  // means some backward value overflowed: the whole update is SKIPPED, as torch.cuda.amp.GradScaler.step does; pcm_loss_scale_update
+  // (next launch) then lowers S and takes the step count back.
+  if (loss_scale_dev) {
+    const double gs = *gradsq;
+    if (!(gs == gs) || gs > 1.7e308) return;
+    gscale /= *loss_scale_dev;
+  }
   if (threadIdx.x == 0) {
     float st = step_dev ? (float)(*step_dev) : (float)step;
     hyp[0] = 1.0f - powf(b1, st);
@@ -60,8 +69,45 @@ extern "C" int pcm_adamw_clip_step(float* p, const float* g, float* m, float* v,
                                    float beta1, float beta2, float eps, float wd, int step, float grad_scale, long n,
                                    const int64_t* step_dev, const float* lr_dev, void* stream) {
   PCM_CHECK(p && g && m && v && n > 0 && (step >= 1 || step_dev), PCM_EINVAL, "pcm_adamw_clip_step: null/empty or step<1");
-  PCM_LAUNCH(adamw_kernel, dim3(op_blocks(n)), dim3(256), 0, stream, p, g, m, v, gradsq, max_norm, lr, beta1, beta2, eps, wd, step, grad_scale, n, step_dev, lr_dev);
+  PCM_LAUNCH(adamw_kernel, dim3(op_blocks(n)), dim3(256), 0, stream, p, g, m, v, gradsq, max_norm, lr, beta1, beta2, eps, wd, step, grad_scale, n, step_dev, lr_dev,
+             (const float*)nullptr);
   return pcm_post_launch("pcm_adamw_clip_step");
+}
+
+// ---- dynamic loss scaling (the reference's fp16 runs go through accelerate's torch.cuda.amp.GradScaler: train_pcm_lora_sd15.py:1034 with
+// --mixed_precision=fp16, :1296-1299 backward / clip / step).  All state lives in device memory so a captured hipGraph of the step stays valid:
+//   scale[0] = S (the loss gradient is multiplied by it before the backward: pcm_scale_f32_dev), good[0] = finite steps since the last change.
+extern "C" int pcm_adamw_clip_step_scaled(float* p, const float* g, float* m, float* v, const double* gradsq, float max_norm, float lr,
+                                          float beta1, float beta2, float eps, float wd, float grad_scale, long n,
+                                          const int64_t* step_dev, const float* lr_dev, const float* loss_scale_dev, void* stream) {
+  PCM_CHECK(p && g && m && v && gradsq && n > 0 && step_dev && loss_scale_dev, PCM_EINVAL, "pcm_adamw_clip_step_scaled: null/empty");
+  PCM_LAUNCH(adamw_kernel, dim3(op_blocks(n)), dim3(256), 0, stream, p, g, m, v, gradsq, max_norm, lr, beta1, beta2, eps, wd, 1, grad_scale, n, step_dev, lr_dev,
+             loss_scale_dev);
+  return pcm_post_launch("pcm_adamw_clip_step_scaled");
+}
+__global__ void loss_scale_update_kernel(float* scale, int* good, int64_t* step_dev, const double* gradsq, float growth, float backoff, int interval) {
+  const double gs = *gradsq;
+  if ((gs == gs) && gs <= 1.7e308) {
+    if (++good[0] >= interval) { good[0] = 0; scale[0] *= growth; }
+  } else {
+    good[0] = 0; scale[0] *= backoff;
+    if (step_dev) step_dev[0] -= 1;          // the skipped update does not count as an optimizer step
+  }
+}
+extern "C" int pcm_loss_scale_update(float* scale, int* good_steps, int64_t* step_dev, const double* gradsq, float growth, float backoff,
+                                     int interval, void* stream) {
+  PCM_CHECK(scale && good_steps && gradsq && growth >= 1.f && backoff > 0.f && backoff <= 1.f && interval > 0, PCM_EINVAL, "pcm_loss_scale_update: bad arguments");
+  PCM_LAUNCH(loss_scale_update_kernel, dim3(1), dim3(1), 0, stream, scale, good_steps, step_dev, gradsq, growth, backoff, interval);
+  return pcm_post_launch("pcm_loss_scale_update");
+}
+__global__ __launch_bounds__(256) void scale_dev_kernel(float* x, const float* s, long n) {
+  const float f = *s;
+  OP_LOOP(i, n) x[i] *= f;
+}
+extern "C" int pcm_scale_f32_dev(float* x, const float* scale_dev, long n, void* stream) {
+  PCM_CHECK(x && scale_dev && n > 0, PCM_EINVAL, "pcm_scale_f32_dev: null/empty");
+  PCM_LAUNCH(scale_dev_kernel, dim3(op_blocks(n)), dim3(256), 0, stream, x, scale_dev, n);
+  return pcm_post_launch("pcm_scale_f32_dev");
 }
 
 __global__ __launch_bounds__(256) void ema_kernel(float* t, const float* s, float rate, long n) {

@@ -86,6 +86,39 @@ void pcm_set_error(const char* fmt, ...);
 int pcm_post_launch(const char* what);
 void pcm_zero_async(void* p, size_t bytes, void* stream);   // zero fill as a kernel launch (runtime.hip: why not hipMemsetAsync)
 
+// ---- the 16-bit activation / weight format.  Default build: bfloat16 (libpcm_hip.so).  -DPCM_ACT_F16 (pcm_amd/build.py variant "f16",
+// libpcm_hip_f16.so) compiles the SAME sources with IEEE half as the storage and MFMA operand type: the reference's
+// --mixed_precision=fp16 recipes (train_pcm_lora_sd15.sh:9) and the validation mode behind DESIGN section 5's 1e-3 loss comparison (half keeps 11
+// significand bits against 8).  Everything that touches the format is in this block: bf2f / f2bf / pack_bf2 and the two MFMA builtins (the kernels
+// carry operands as raw 16-bit lanes, ``bf16_t`` / ``bf16x8`` are format-agnostic containers; entry points keep their *_bf16 names).
+// pcm_act_dtype() (runtime.hip) reports which one a library was built with.
+#ifdef PCM_ACT_F16
+#define PCM_ONE_BITS 0x3c00u      // 1.0 in the 16-bit format (attention: the "ones" column that makes the PV MFMA produce the softmax denominator)
+#ifdef PCM_HOST_EMU
+__device__ __forceinline__ float bf2f(bf16_t h) { return pcm_emu::half_to_float(h); }
+__device__ __forceinline__ bf16_t f2bf(float f) { return pcm_emu::float_to_half(f); }
+__device__ __forceinline__ unsigned pack_bf2(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
+#else
+typedef _Float16 pcm_h2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 pcm_h8_t __attribute__((ext_vector_type(8)));
+typedef float pcm_f2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float bf2f(bf16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
+__device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {        // round-to-nearest-even (v_cvt_pk_f16_f32), overflow -> inf
+  pcm_f2_t v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, pcm_h2_t));
+}
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (_Float16)f); }
+__device__ __forceinline__ f32x16 pcm_mfma_32x32x16_h(bf16x8 a, bf16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(pcm_h8_t, a), __builtin_bit_cast(pcm_h8_t, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 pcm_mfma_16x16x32_h(bf16x8 a, bf16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(pcm_h8_t, a), __builtin_bit_cast(pcm_h8_t, b), c, 0, 0, 0);
+}
+#define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) pcm_mfma_32x32x16_h((a), (b), (c))
+#define __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z) pcm_mfma_16x16x32_h((a), (b), (c))
+#endif
+#else   // bfloat16
+#define PCM_ONE_BITS 0x3f80u
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((unsigned)h) << 16); }
 #ifdef PCM_HOST_EMU
 __device__ __forceinline__ bf16_t f2bf(float f) {  // round-to-nearest-even, NaN kept quiet
@@ -106,6 +139,7 @@ __device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {
   return __builtin_bit_cast(unsigned, __builtin_convertvector(v, pcm_bf2_t));
 }
 __device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack_bf2(f, 0.f) & 0xffffu); }
+#endif
 #endif
 // Activations are evaluated per element inside HBM-bound kernels (GroupNorm+SiLU touches every activation of the UNet), so their
 // VALU cost matters: v_rcp_f32 (1 ulp) instead of the IEEE division sequence (~10 instructions).  Results are rounded to bf16.

@@ -32,9 +32,20 @@ def _stale(out, deps):
     return (not os.path.exists(out)) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps)
 
 
-def build(force=False, verbose=False):
+# variants: the same sources, another 16-bit activation / weight format (csrc/pcm_common.h).  "bf16" is the product default and what
+# bench.py measures; "f16" (-DPCM_ACT_F16 -> lib/libpcm_hip_f16.so) serves --mixed_precision=fp16 and the fp32-oracle loss validation.
+VARIANTS = {"bf16": ("libpcm_hip.so", "obj", []), "f16": ("libpcm_hip_f16.so", "obj_f16", ["-DPCM_ACT_F16"])}
+
+
+def lib_path(variant="bf16"):
+    return os.path.join(LIBDIR, VARIANTS[variant][0])
+
+
+def build(force=False, verbose=False, variant="bf16"):
+    libname, objname, vflags = VARIANTS[variant]
+    lib = os.path.join(LIBDIR, libname)
     os.makedirs(LIBDIR, exist_ok=True)
-    objdir = os.path.join(LIBDIR, "obj")
+    objdir = os.path.join(LIBDIR, objname)
     os.makedirs(objdir, exist_ok=True)
     hdrs = glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(os.path.dirname(os.path.dirname(HERE)), "include", "pcm_hip.h")]
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
@@ -44,7 +55,7 @@ def build(force=False, verbose=False):
         o = os.path.join(objdir, os.path.basename(s)[:-4] + ".o")
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            jobs.append([HIPCC] + FLAGS + extra_flags(s) + ["-c", s, "-o", o])
+            jobs.append([HIPCC] + FLAGS + vflags + extra_flags(s) + ["-c", s, "-o", o])
 
     def run(cmd):
         if verbose:
@@ -56,10 +67,16 @@ def build(force=False, verbose=False):
 
     with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
         list(ex.map(run, jobs))
-    if force or jobs or _stale(LIB, objs):
-        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
-    return LIB
+    if force or jobs or _stale(lib, objs):
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
+    return lib
+
+
+def build_all(force=False, verbose=False):
+    return [build(force, verbose, v) for v in VARIANTS]
 
 
 if __name__ == "__main__":
-    print(build(force="-f" in sys.argv, verbose=True))
+    for v in VARIANTS:
+        if v == "bf16" or "--all" in sys.argv or ("--" + v) in sys.argv:
+            print(build(force="-f" in sys.argv, verbose=True, variant=v))

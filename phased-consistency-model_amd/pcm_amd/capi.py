@@ -11,6 +11,7 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(HERE, "lib", "libpcm_hip.so")
+F16_LIB = os.path.join(HERE, "lib", "libpcm_hip_f16.so")      # the same sources compiled with -DPCM_ACT_F16 (pcm_amd/precision.py)
 
 PCM_BF16, PCM_F32 = 0, 1
 ACT_NONE, ACT_SILU, ACT_LEAKY, ACT_GEGLU = 0, 1, 2, 3
@@ -109,6 +110,9 @@ _PROTOS = {
     "pcm_consistency_loss": [vp, vp, vp, i32, f32, vp, vp, f32, i32, i32, vp],
     "pcm_sumsq_f32": [vp, vp, i64, vp],
     "pcm_adamw_clip_step": [vp, vp, vp, vp, vp, f32, f32, f32, f32, f32, f32, i32, f32, i64, vp, vp, vp],
+    "pcm_adamw_clip_step_scaled": [vp, vp, vp, vp, vp, f32, f32, f32, f32, f32, f32, f32, i64, vp, vp, vp, vp],
+    "pcm_loss_scale_update": [vp, vp, vp, vp, f32, f32, i32, vp],
+    "pcm_scale_f32_dev": [vp, vp, i64, vp],
     "pcm_ema_update": [vp, vp, f32, i64, vp],
     "pcm_pack_linear": [vp, vp, vp, i32, i32, f32, vp],
     "pcm_pack_conv3x3": [vp, vp, vp, i32, i32, f32, i32, vp],
@@ -141,6 +145,8 @@ class Lib:
         self.dll = C.CDLL(path)
         self.dll.pcm_last_error.restype = C.c_char_p
         self.dll.pcm_abi_version.restype = C.c_int
+        self.dll.pcm_act_dtype.restype = C.c_int
+        self.act_dtype = int(self.dll.pcm_act_dtype())       # 0: bfloat16 build, 1: IEEE-half build (include/pcm_hip.h PCM_FMT_*)
         self.dll.pcm_gemm_workspace_bytes.restype = C.c_size_t
         self.dll.pcm_gemm_workspace_bytes.argtypes = [C.POINTER(GemmSeg), C.c_int, C.POINTER(GemmEpi)]
         self.dll.pcm_attn_workspace_bytes.restype = C.c_size_t

@@ -17,7 +17,9 @@ import torch
 from . import capi, ops
 from .ops import Seg
 
-BF16 = torch.bfloat16
+from .precision import act_dtype as _act_dtype  # noqa: E402
+
+BF16 = _act_dtype()      # the library's 16-bit dtype: bfloat16, or float16 after precision.set_precision("fp16") (which rebinds this name)
 ADAPTER_DIMS = (320, 640, 1280, 1280, 1280, 1280, 1280, 640, 320)   # discriminator_sd15.py:377
 ADAPTER_DIMS_SDXL = (320, 640, 1280, 1280)                            # discriminator_sdxl.py:377-386 (down blocks + mid only)
 

@@ -21,7 +21,9 @@ from . import capi, ops
 from .ops import Seg
 from .unet_spec import UNetConfig, lora_target_modules, param_spec
 
-BF16 = torch.bfloat16
+from .precision import act_dtype as _act_dtype  # noqa: E402
+
+BF16 = _act_dtype()      # the library's 16-bit dtype: bfloat16, or float16 after precision.set_precision("fp16") (which rebinds this name)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -337,10 +339,11 @@ class Geo:
 
 
 def layer_fwd(W: UNetWeights, lora, path, x, M, geo=None, save=None, rowvec=None, rows_per_batch=0, residual=None,
-              act=capi.ACT_NONE, out_dtype=BF16):
+              act=capi.ACT_NONE, out_dtype=None):
     """y = base(x) + s*B(A(x)) [+ bias + rowvec + residual].  x: [M, K] (lin) or NHWC source (conv3).
     ``save`` (dict) receives what the backward needs."""
     L = W.layers[path]
+    out_dtype = BF16 if out_dtype is None else out_dtype
     lm = lora.modules.get(path) if lora is not None else None
     conv = geo.conv() if L.kind == "conv3" else None
     Ho, Wo = (geo.Ho, geo.Wo) if conv else (0, 0)

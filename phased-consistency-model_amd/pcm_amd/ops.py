@@ -8,7 +8,9 @@ import torch
 from . import capi
 from .capi import GemmEpi, GemmSeg, WgradArgs, ptr
 
-BF16 = torch.bfloat16
+from .precision import act_dtype as _act_dtype  # noqa: E402
+
+BF16 = _act_dtype()      # the library's 16-bit dtype: bfloat16, or float16 after precision.set_precision("fp16") (which rebinds this name)
 GEMM_PROFILE = None  # set to a list by bench.py to time every pcm_gemm_bf16 launch
 
 
@@ -428,6 +430,23 @@ def sumsq(g, out=None):
 def adamw_clip_step(p, g, m, v, gradsq, max_norm, lr, b1, b2, eps, wd, step, grad_scale=1.0, step_dev=None, lr_dev=None):
     capi.lib().call("pcm_adamw_clip_step", ptr(p), ptr(g), ptr(m), ptr(v), ptr(gradsq), max_norm, lr, b1, b2, eps, wd,
                     step, grad_scale, p.numel(), ptr(step_dev), ptr(lr_dev), _stream())
+
+
+def adamw_clip_step_scaled(p, g, m, v, gradsq, max_norm, lr, b1, b2, eps, wd, grad_scale, step_dev, lr_dev, loss_scale_dev):
+    """AdamW on loss-scaled gradients (fp16 build): g' = g * grad_scale / S, no update when gradsq is not finite."""
+    capi.lib().call("pcm_adamw_clip_step_scaled", ptr(p), ptr(g), ptr(m), ptr(v), ptr(gradsq), max_norm, lr, b1, b2, eps, wd,
+                    grad_scale, p.numel(), ptr(step_dev), ptr(lr_dev), ptr(loss_scale_dev), _stream())
+
+
+def loss_scale_update(scale_dev, good_dev, step_dev, gradsq, growth=2.0, backoff=0.5, interval=2000):
+    """torch.cuda.amp.GradScaler.update() on device state (defaults = GradScaler's)."""
+    capi.lib().call("pcm_loss_scale_update", ptr(scale_dev), ptr(good_dev), ptr(step_dev), ptr(gradsq), growth, backoff, interval, _stream())
+
+
+def scale_by_dev(x, scale_dev):
+    """x (fp32, in place) *= scale_dev[0]"""
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    capi.lib().call("pcm_scale_f32_dev", ptr(x), ptr(scale_dev), x.numel(), _stream())
 
 
 def ema_update(target, source, rate):

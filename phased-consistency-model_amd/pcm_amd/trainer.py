@@ -14,7 +14,7 @@ import os
 import numpy as np
 import torch
 
-from . import capi, ops
+from . import capi, ops, precision
 from .model import LoraState, UNet, UNetWeights
 
 
@@ -149,6 +149,13 @@ class Distiller:
         self.lr_dev = torch.full((1,), float(cfg.learning_rate), dtype=torch.float32, device=self.device)
         self._graph = None
         self._late_work = None
+        # fp16 build (precision.set_precision("fp16"), the reference's --mixed_precision=fp16): the backward runs on S * d(loss) with the
+        # GradScaler state in device memory (S = 65536 at start, x2 after 2000 finite steps, x0.5 and no update after a non-finite
+        # gradient norm: torch.cuda.amp.GradScaler defaults, which accelerate uses at train_pcm_lora_sd15.py:1034) -- capturable.
+        self.loss_scale_dev = self.loss_good_dev = None
+        if precision.precision() == "fp16":
+            self.loss_scale_dev = torch.full((1,), float(os.environ.get("PCM_LOSS_SCALE", "65536")), dtype=torch.float32, device=self.device)
+            self.loss_good_dev = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.comm_events = None           # a list: step_graphed appends (start, end) events around the gradient exchange
         self._seg = None                  # SegmentedGraph being captured (AdvDistiller.capture_adv at world_size > 1)
         # two-bucket gradient exchange (world_size > 1): the mid/up-block bucket is reduced while the down blocks back-propagate
@@ -203,6 +210,8 @@ class Distiller:
         target, _, _ = ops.phase_jump(eps_t, x_prev64, t_n, index, T.acp, T.acp_prev, T.ddim_timesteps_prev, T.edges,
                                       target_mode=True)                                          # :1269-1280
         loss, d_eps = ops.consistency_loss(model_pred, target, coef, cfg.loss_type == "huber", cfg.huber_c, grad_scale=grad_scale)   # :1283-1293
+        if self.loss_scale_dev is not None:
+            ops.scale_by_dev(d_eps, self.loss_scale_dev)          # GradScaler.scale(loss).backward(): the whole backward carries S
         out = dict(loss=loss, noisy_model_input=noisy, noise_pred=eps_s, model_pred=model_pred, cond_teacher_output=eps_c,
                    uncond_teacher_output=eps_u, x_prev=x_prev64, target_noise_pred=eps_t, target=target,
                    start_timesteps=start_t, timesteps=t_n, end_timesteps=end_t)
@@ -364,16 +373,23 @@ class Distiller:
         gscale = 1.0 / self.world_size
         self.step_dev += 1
         ops.sumsq(lo.grads, lo.gradsq)                                                           # :1298 clip_grad_norm_
-        ops.adamw_clip_step(lo.params, lo.grads, lo.exp_avg, lo.exp_avg_sq, lo.gradsq, cfg.max_grad_norm,
-                            cfg.learning_rate, cfg.adam_beta1, cfg.adam_beta2, cfg.adam_epsilon,
-                            cfg.adam_weight_decay, 1, gscale, step_dev=self.step_dev, lr_dev=self.lr_dev)   # :1299
+        if self.loss_scale_dev is not None:      # unscale + clip + step (skipped when the norm is not finite), then GradScaler.update()
+            ops.adamw_clip_step_scaled(lo.params, lo.grads, lo.exp_avg, lo.exp_avg_sq, lo.gradsq, cfg.max_grad_norm, cfg.learning_rate,
+                                       cfg.adam_beta1, cfg.adam_beta2, cfg.adam_epsilon, cfg.adam_weight_decay, gscale,
+                                       self.step_dev, self.lr_dev, self.loss_scale_dev)
+            ops.loss_scale_update(self.loss_scale_dev, self.loss_good_dev, self.step_dev, lo.gradsq)
+        else:
+            ops.adamw_clip_step(lo.params, lo.grads, lo.exp_avg, lo.exp_avg_sq, lo.gradsq, cfg.max_grad_norm,
+                                cfg.learning_rate, cfg.adam_beta1, cfg.adam_beta2, cfg.adam_epsilon,
+                                cfg.adam_weight_decay, 1, gscale, step_dev=self.step_dev, lr_dev=self.lr_dev)   # :1299
         if self.ema is not None:
             ops.ema_update(self.ema, lo.params, cfg.ema_rate)
         lo.repack()
 
     def grad_norm(self):
         """Host read of the last global grad norm (forces a sync; for logging only)."""
-        return math.sqrt(float(self.lora.gradsq.item())) / self.world_size
+        s = float(self.loss_scale_dev.item()) if self.loss_scale_dev is not None else 1.0
+        return math.sqrt(float(self.lora.gradsq.item())) / self.world_size / s
 
 
 class AdvDistiller(Distiller):
@@ -382,6 +398,9 @@ class AdvDistiller(Distiller):
 
     def __init__(self, weights, lora, cfg, discriminator, adv_weight=0.1, adv_lr=1e-5, world_size=1, process_group=None):
         super().__init__(weights, lora, cfg, world_size, process_group)
+        if self.loss_scale_dev is not None:
+            raise RuntimeError("the adversarial step is built for the bf16 library only (its discriminator / generator backward seeds carry no loss scale); "
+                               "run it with --mixed_precision=bf16")
         self.disc, self.adv_weight, self.adv_lr = discriminator, adv_weight, adv_lr
         self.adv_lr_dev = torch.full((1,), float(adv_lr), dtype=torch.float32, device=self.device)
 

@@ -115,12 +115,43 @@ typedef short bf16x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
+// IEEE half <-> float (the -DPCM_ACT_F16 build of the kernels: csrc/pcm_common.h); round-to-nearest-even, overflow -> inf, subnormals kept
+inline float half_to_float(uint16_t h) {
+  uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 31u, m = h & 1023u, u;
+  if (e == 0) {
+    if (m == 0) u = sign;
+    else { int sh = 0; while (!(m & 1024u)) { m <<= 1; sh++; } u = sign | ((uint32_t)(113 - sh) << 23) | ((m & 1023u) << 13); }
+  } else if (e == 31) u = sign | 0x7f800000u | (m << 13);
+  else u = sign | ((e + 112u) << 23) | (m << 13);
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+inline uint16_t float_to_half(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  const uint32_t sign = (u >> 16) & 0x8000u, a = u & 0x7fffffffu;
+  if (a > 0x7f800000u) return (uint16_t)(sign | 0x7e00u);                  // NaN
+  if (a >= 0x47800000u) return (uint16_t)(sign | 0x7c00u);                 // >= 65536 -> inf (65520 .. 65536 rounds to inf below)
+  if (a < 0x33000001u) return (uint16_t)sign;                              // <= 2^-25 -> 0 (ties to even)
+  int e = (int)(a >> 23) - 127;
+  uint32_t m = (a & 0x7fffffu) | 0x800000u;
+  int shift = e < -14 ? 13 + (-14 - e) : 13;                               // subnormal results shift further
+  uint32_t q = m >> shift, rem = m & ((1u << shift) - 1u), half = 1u << (shift - 1);
+  if (rem > half || (rem == half && (q & 1u))) q++;
+  uint32_t h = e < -14 ? q : (((uint32_t)(e + 15) << 10) + (q - 1024u));   // q carries the implicit bit; a mantissa carry bumps the exponent
+  return (uint16_t)(sign | h);
+}
+#ifdef PCM_ACT_F16
+inline float bf2f(short s) { return half_to_float((uint16_t)s); }
+#else
 inline float bf2f(short s) {
   uint32_t u = ((uint32_t)(uint16_t)s) << 16;
   float f;
   memcpy(&f, &u, 4);
   return f;
 }
+#endif
 
 // D[i][j] += sum_k A[i][k] B[k][j];  A: lane l holds A[l&31][8*(l>>5)+e]; B: B[8*(l>>5)+e][l&31];
 // D: lane l reg r -> j = l&31, i = (r&3) + 8*(r>>2) + 4*(l>>5)
