@@ -179,12 +179,13 @@ class Lib:
 
 
 _LIB = None
+_LIB_PATH = DEFAULT_LIB      # what lib() loads: precision.set_precision("fp16") points it at F16_LIB
 
 
 def lib():
     global _LIB
     if _LIB is None:
-        _LIB = Lib()
+        _LIB = Lib(_LIB_PATH)
     return _LIB
 
 

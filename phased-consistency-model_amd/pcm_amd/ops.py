@@ -33,6 +33,8 @@ class Seg:
         self.k_algo = k_algo if k_algo is not None else w.shape[-1]
 
     def fill(self, s: GemmSeg):
+        # both operands in the loaded library's 16-bit format (a bfloat16 tensor handed to the half build would be read as garbage)
+        assert self.a.dtype == BF16 and self.w.dtype == BF16, f"pcm_gemm_bf16 operands must be {BF16}: got {self.a.dtype}, {self.w.dtype}"
         s.a, s.w = ptr(self.a), ptr(self.w)
         s.K = self.w.shape[-1]
         if self.conv is None:

@@ -26,13 +26,14 @@ def act_dtype():
 
 
 def set_precision(name, lib=None):
-    """name: "bf16" | "fp16" ("no" is rejected: there is no fp32-storage build).  ``lib``: tests pass an emulator build."""
+    """name: "bf16" | "fp16" (there is no fp32-storage build).  ``lib``: tests pass an emulator build of the matching variant."""
     global _NAME
     if name not in _DTYPES:
         raise ValueError("precision must be 'bf16' or 'fp16', got %r" % (name,))
-    if lib is None:
-        lib = capi.Lib(capi.F16_LIB if name == "fp16" else capi.DEFAULT_LIB)
     want = 1 if name == "fp16" else 0
+    if lib is None:
+        capi._LIB_PATH = capi.F16_LIB if name == "fp16" else capi.DEFAULT_LIB      # capi.set_lib(None) / lib() keep loading this variant
+        lib = capi.Lib(capi._LIB_PATH)
     if lib.act_dtype != want:
         raise RuntimeError("%s was built for %s, not %s" % (lib.path, "fp16" if lib.act_dtype else "bf16", name))
     capi.set_lib(lib)

@@ -264,10 +264,12 @@ def main(args):
     logging.basicConfig(format="%(asctime)s - %(levelname)s - %(name)s - %(message)s", datefmt="%m/%d/%Y %H:%M:%S",
                         level=logging.INFO if rank == 0 else logging.WARNING)
     if args.mixed_precision == "fp16":
-        logger.warning("--mixed_precision=fp16 requested: this build computes in bf16 MFMA / fp32 accumulate (no GradScaler needed). "
-                       "Precision consequence: the reference's frozen teacher (train_pcm_lora_sd15.py:1218, fp16 autocast) has ~1e-3 rel-L2 "
-                       "error on eps vs fp32, this bf16 path ~9e-3 (DESIGN.md section 2, row a10); the loss deviation stays within the bf16 "
-                       "budget of DESIGN.md section 5")
+        # accelerate's fp16 autocast + GradScaler (train_pcm_lora_sd15.py:1034, :1296-1299): the IEEE-half build of the kernel library with the
+        # GradScaler state on the device (pcm_amd/precision.py, trainer.Distiller).  "bf16" / None / "no": the bfloat16 build (there is no
+        # fp32-storage build; "no" is computed in bf16 as before).
+        from pcm_amd import precision
+        precision.set_precision("fp16")
+        logger.info("--mixed_precision=fp16: half build of the kernel library (lib/libpcm_hip_f16.so), dynamic loss scaling on the device")
     if args.gradient_accumulation_steps < 1:
         raise SystemExit("pcm_amd: --gradient_accumulation_steps must be >= 1")
     ignored = [k for k in IGNORED if getattr(args, k) not in (None, False, 0, 8, 200)]

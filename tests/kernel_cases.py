@@ -1,5 +1,5 @@
 """Kernel parity cases shared by the host-emulation (CPU) and the GPU test files.  Every case
-compares the C-ABI op against plain torch fp32 evaluated on the SAME bf16-rounded inputs."""
+compares the C-ABI op against plain torch fp32 evaluated on the SAME 16-bit-rounded inputs (ops.BF16: bfloat16, or float16 when the half build is selected)."""
 import math
 
 import pytest
@@ -9,7 +9,8 @@ import torch.nn.functional as F
 from pcm_amd import capi, ops
 
 
-def rnd(*shape, seed=0, scale=1.0, dev="cpu", dtype=torch.bfloat16, shift=0.0):
+def rnd(*shape, seed=0, scale=1.0, dev="cpu", dtype=None, shift=0.0):
+    dtype = ops.BF16 if dtype is None else dtype        # the library's 16-bit dtype (float16 under precision.set_precision("fp16"))
     g = torch.Generator().manual_seed(seed)
     return (torch.randn(*shape, generator=g) * scale + shift).to(dtype).to(dev)
 
@@ -207,11 +208,11 @@ def case_optim(dev):
 def case_pack(dev):
     w = rnd(70, 40, seed=1, dev=dev, dtype=torch.float32)
     nk, kn = ops.pack_linear(w, scale=0.125)
-    ref = (w.cpu() * 0.125).bfloat16()
+    ref = (w.cpu() * 0.125).to(ops.BF16)
     assert torch.equal(nk.cpu(), ref) and torch.equal(kn.cpu(), ref.T.contiguous())
     wc = rnd(16, 24, 3, 3, seed=2, dev=dev, dtype=torch.float32)
     f, d = ops.pack_conv3x3(wc)
-    rb = wc.cpu().bfloat16()
+    rb = wc.cpu().to(ops.BF16)
     assert torch.equal(f.cpu(), rb.permute(0, 2, 3, 1).reshape(16, -1))
     assert torch.equal(d.cpu(), rb.flip(2, 3).permute(1, 2, 3, 0).reshape(24, -1))
     f2, d2 = ops.pack_conv3x3(wc.permute(0, 2, 3, 1).contiguous(), khwc=True)
@@ -219,7 +220,7 @@ def case_pack(dev):
     # the [N][tap][C] source goes through a 32 x 32 tile transpose: ragged tiles in both directions, with a scale
     wr = rnd(70, 3, 3, 40, seed=3, dev=dev, dtype=torch.float32)
     f3, d3 = ops.pack_conv3x3(wr, khwc=True, scale=0.5)
-    rb = (wr.cpu() * 0.5).bfloat16().permute(0, 3, 1, 2)          # [N][C][3][3]
+    rb = (wr.cpu() * 0.5).to(ops.BF16).permute(0, 3, 1, 2)          # [N][C][3][3]
     assert torch.equal(f3.cpu(), rb.permute(0, 2, 3, 1).reshape(70, -1))
     assert torch.equal(d3.cpu(), rb.flip(2, 3).permute(1, 2, 3, 0).reshape(40, -1))
 
@@ -506,7 +507,7 @@ def case_teacher_input_grad(dev):
         close(f.float().view(B, H, Wd, -1).permute(0, 3, 1, 2), fr.detach(), ft, ft * float(fr.detach().abs().max()), f"feature {k}")
         d = torch.randn(fr.shape, generator=torch.Generator().manual_seed(50 + k))
         loss = loss + (fr * d).sum()
-        d_feats.append(d.permute(0, 2, 3, 1).reshape(B, H * Wd, -1).bfloat16().contiguous().to(dev))
+        d_feats.append(d.permute(0, 2, 3, 1).reshape(B, H * Wd, -1).to(ops.BF16).contiguous().to(dev))
     loss.backward()
     d_in = teacher.backward(None, tape, d_feats=d_feats, need_input_grad=True)
     r = float((d_in.cpu() - xr.grad).norm() / xr.grad.norm())
@@ -521,7 +522,7 @@ def case_gemm_big(dev, which):
 
     def rnd(*shape, seed=0, scale=1.0):
         g = torch.Generator().manual_seed(seed)
-        return (torch.randn(*shape, generator=g) * scale).bfloat16().to(dev)
+        return (torch.randn(*shape, generator=g) * scale).to(ops.BF16).to(dev)
 
     dll = capi.lib().dll
     dll.pcm_debug_gemm_big_mode(2)
@@ -531,19 +532,19 @@ def case_gemm_big(dev, which):
             x, w, t, bl = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.1), rnd(M, 64, seed=3), rnd(N, 64, seed=4, scale=0.1)
             bias = torch.randn(N, generator=torch.Generator().manual_seed(5)).to(dev)
             res = rnd(M, N, seed=6)
-            out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+            out = torch.empty(M, N, dtype=ops.BF16, device=dev)
             ops.gemm([ops.Seg(x, w), ops.Seg(t, bl)], M, N, out, bias=bias, residual=res)
             ref = x.float() @ w.float().T + t.float() @ bl.float().T + bias + res.float()
         elif which == "ragged":         # M tail, 2 N tiles, N not a tile multiple, SiLU + alpha, single K tile
             M, N, K = 300, 448, 64
             x, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.2)
-            out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+            out = torch.empty(M, N, dtype=ops.BF16, device=dev)
             ops.gemm([ops.Seg(x, w)], M, N, out, act=capi.ACT_SILU, alpha=0.5)
             ref = F.silu(0.5 * (x.float() @ w.float().T))
         elif which == "two_tiles_k":    # exactly two K tiles (prologue-only pipeline), 256x256 tile
             M, N, K = 256, 256, 128
             x, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.2)
-            out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+            out = torch.empty(M, N, dtype=ops.BF16, device=dev)
             ops.gemm([ops.Seg(x, w)], M, N, out)
             ref = x.float() @ w.float().T
         elif which == "persist":        # more work items than resident blocks (8 in the emulator, 256 on the GPU): multi-item blocks
@@ -551,20 +552,20 @@ def case_gemm_big(dev, which):
             x, w, t, bl = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.1), rnd(M, 64, seed=3), rnd(N, 64, seed=4, scale=0.1)
             bias = torch.randn(N, generator=torch.Generator().manual_seed(5)).to(dev)
             res = rnd(M, N, seed=6)
-            out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+            out = torch.empty(M, N, dtype=ops.BF16, device=dev)
             ops.gemm([ops.Seg(x, w), ops.Seg(t, bl)], M, N, out, bias=bias, residual=res)
             ref = x.float() @ w.float().T + t.float() @ bl.float().T + bias + res.float()
         elif which == "persist_splitk":
             M, N, K = (1280, 320, 2048) if dev == "cpu" else (40000, 320, 2048)
             x, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05)
-            out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+            out = torch.empty(M, N, dtype=ops.BF16, device=dev)
             ops.gemm([ops.Seg(x, w)], M, N, out, act=capi.ACT_SILU)
             ref = F.silu(x.float() @ w.float().T)
         elif which == "splitk":
             M, N, K = 256, 320, 2048
             x, w, t, bl = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05), rnd(M, 64, seed=3), rnd(N, 64, seed=4, scale=0.1)
             bias = torch.randn(N, generator=torch.Generator().manual_seed(5)).to(dev)
-            out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+            out = torch.empty(M, N, dtype=ops.BF16, device=dev)
             ops.gemm([ops.Seg(x, w), ops.Seg(t, bl)], M, N, out, bias=bias)
             ref = x.float() @ w.float().T + t.float() @ bl.float().T + bias
         else:                            # conv3x3 flavours, with the LoRA branch as a plain or a conv second segment
@@ -603,7 +604,7 @@ def case_gemm_big(dev, which):
                 segs.append(ops.Seg(d, w2.permute(0, 2, 3, 1).reshape(Co, 576).contiguous(), conv=dict(Hs=Hs, Ws=Hs)))
                 ref = ref + F.conv2d(d.float().permute(0, 3, 1, 2), w2.float(), None, padding=1).permute(0, 2, 3, 1).reshape(M, Co)
             temb = rnd(B, Co, seed=9)
-            out = torch.empty(M, Co, dtype=torch.bfloat16, device=dev)
+            out = torch.empty(M, Co, dtype=ops.BF16, device=dev)
             ops.gemm(segs, M, Co, out, rowvec=temb, rows_per_batch=Ho * Ho, Ho=Ho, Wo=Ho)
             ref = ref + temb.float().repeat_interleave(Ho * Ho, 0)
         plan = dll.pcm_debug_last_gemm_plan()
@@ -628,7 +629,7 @@ def case_gemm_4w(dev, which):
 
     def rnd(*shape, seed=0, scale=1.0):
         g = torch.Generator().manual_seed(seed)
-        return (torch.randn(*shape, generator=g) * scale).bfloat16().to(dev)
+        return (torch.randn(*shape, generator=g) * scale).to(ops.BF16).to(dev)
 
     dll = capi.lib().dll
     dll.pcm_debug_gemm_big_mode(3)
@@ -638,21 +639,21 @@ def case_gemm_4w(dev, which):
             x, w, t, bl = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.1), rnd(M, 64, seed=3), rnd(N, 64, seed=4, scale=0.1)
             bias = torch.randn(N, generator=torch.Generator().manual_seed(5)).to(dev)
             res = rnd(M, N, seed=6)
-            out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+            out = torch.empty(M, N, dtype=ops.BF16, device=dev)
             ops.gemm([ops.Seg(x, w), ops.Seg(t, bl)], M, N, out, bias=bias, residual=res)
             ref = x.float() @ w.float().T + t.float() @ bl.float().T + bias + res.float()
             fn = 5
         elif which == "ragged":         # M tail, 128x256 tile with an N tail, SiLU + alpha, exactly two K-steps (prologue-only pipeline)
             M, N, K = 300, 448, 64
             x, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.2)
-            out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+            out = torch.empty(M, N, dtype=ops.BF16, device=dev)
             ops.gemm([ops.Seg(x, w)], M, N, out, act=capi.ACT_SILU, alpha=0.5)
             ref = F.silu(0.5 * (x.float() @ w.float().T))
             fn = 4
         elif which == "qkv":            # fused q/k/v: N = 3 x 320, LoRA segment of K = 192, three K-steps ahead of a segment switch
             M, N, K = 256, 960, 128
             x, w, t, bl = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.1), rnd(M, 192, seed=3), rnd(N, 192, seed=4, scale=0.1)
-            out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+            out = torch.empty(M, N, dtype=ops.BF16, device=dev)
             ops.gemm([ops.Seg(x, w), ops.Seg(t, bl)], M, N, out)
             ref = x.float() @ w.float().T + t.float() @ bl.float().T
             fn = 5
@@ -660,7 +661,7 @@ def case_gemm_4w(dev, which):
             M, N, K = 384, 640, 192
             xa, w = rnd(M, K + 64, seed=1), rnd(N, K, seed=2, scale=0.1)
             temb = rnd(3, N, seed=9)
-            outa = torch.full((M, N + 64), 3.0, dtype=torch.bfloat16, device=dev)
+            outa = torch.full((M, N + 64), 3.0, dtype=ops.BF16, device=dev)
             ops.gemm([ops.Seg(xa, w, lda=K + 64)], M, N, outa, rowvec=temb, rows_per_batch=128, act=capi.ACT_SILU, ldo=N + 64)
             ref = F.silu(xa[:, :K].float() @ w.float().T + temb.float().repeat_interleave(128, 0))
             assert bool((outa[:, N:].float() == 3.0).all())
@@ -671,7 +672,7 @@ def case_gemm_4w(dev, which):
             K = 192 if dev == "cpu" else K
             x, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.1)
             res = rnd(M, N, seed=6)
-            out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+            out = torch.empty(M, N, dtype=ops.BF16, device=dev)
             ops.gemm([ops.Seg(x, w)], M, N, out, residual=res)
             ref = x.float() @ w.float().T + res.float()
             fn = 5
@@ -691,9 +692,9 @@ def case_gemm_n64(dev, M, K):
     """Streaming rank-64 projection kernel (gemm_n64.hip) vs torch fp32; returns max abs excess over tolerance."""
     from pcm_amd import capi, ops
     g = torch.Generator().manual_seed(M + K)
-    x = (torch.randn(M, K, generator=g)).bfloat16().to(dev)
-    w = (torch.randn(64, K, generator=g) * 0.1).bfloat16().to(dev)
-    out = torch.empty(M, 64, dtype=torch.bfloat16, device=dev)
+    x = (torch.randn(M, K, generator=g)).to(ops.BF16).to(dev)
+    w = (torch.randn(64, K, generator=g) * 0.1).to(ops.BF16).to(dev)
+    out = torch.empty(M, 64, dtype=ops.BF16, device=dev)
     ops.gemm([ops.Seg(x, w)], M, 64, out)
     assert capi.lib().dll.pcm_debug_last_gemm_plan() == 64
     ref = x.float() @ w.float().T
@@ -714,7 +715,7 @@ def case_conv_r64(dev, B, H, W, C, expect_kernel=True):
     M = B * H * W
     ref = F.conv2d(x.float().cpu().permute(0, 3, 1, 2), A.float().cpu(), None, padding=1).permute(0, 2, 3, 1).reshape(M, 64)
     n0 = cnt()
-    out = torch.full((M, 64), 7.0, dtype=torch.bfloat16, device=dev)
+    out = torch.full((M, 64), 7.0, dtype=ops.BF16, device=dev)
     capi.lib().dll.pcm_debug_conv_r64(2)         # 2: take every shape the kernel can run (the product skips launches with < 256 patches)
     try:
         ops.gemm([ops.Seg(x, wk, conv=dict(Hs=H, Ws=W))], M, 64, out, Ho=H, Wo=W)
@@ -725,7 +726,7 @@ def case_conv_r64(dev, B, H, W, C, expect_kernel=True):
     if expect_kernel:    # same numbers from the generic path
         capi.lib().dll.pcm_debug_conv_r64(0)
         try:
-            out2 = torch.empty(M, 64, dtype=torch.bfloat16, device=dev)
+            out2 = torch.empty(M, 64, dtype=ops.BF16, device=dev)
             ops.gemm([ops.Seg(x, wk, conv=dict(Hs=H, Ws=W))], M, 64, out2, Ho=H, Wo=W)
         finally:
             capi.lib().dll.pcm_debug_conv_r64(1)
@@ -747,12 +748,12 @@ def _case_gemm_geglu(dev, M, K, inner, big_mode):
     import torch.nn.functional as F
     from pcm_amd import capi, ops
     g = torch.Generator().manual_seed(7)
-    x = torch.randn(M, K, generator=g).bfloat16().to(dev)
-    w = (torch.randn(2 * inner, K, generator=g) * 0.1).bfloat16().to(dev)
+    x = torch.randn(M, K, generator=g).to(ops.BF16).to(dev)
+    w = (torch.randn(2 * inner, K, generator=g) * 0.1).to(ops.BF16).to(dev)
     bias = torch.randn(2 * inner, generator=g).to(dev)
     from pcm_amd.model import geglu_perm
     perm = geglu_perm(inner, dev)
-    out = torch.empty(M, inner, dtype=torch.bfloat16, device=dev)
+    out = torch.empty(M, inner, dtype=ops.BF16, device=dev)
     ops.gemm([ops.Seg(x, w[perm].contiguous())], M, 2 * inner, out, bias=bias[perm].contiguous(), act=capi.ACT_GEGLU, ldo=inner)
     plan = capi.lib().dll.pcm_debug_last_gemm_plan()
     assert (plan >= 14000) if big_mode == 3 else ((4000 <= plan < 10000) if big_mode in (2, 4) else plan >= 4000), plan
@@ -763,20 +764,20 @@ def _case_gemm_geglu(dev, M, K, inner, big_mode):
     # second output: the interleaved pre-activation of the first `rows` rows (what the backward of GEGLU needs) -- plus a LoRA segment
     # with interleaved s*B rows; rows beyond `rows` must stay untouched; geglu_bwd_interleaved == geglu_bwd on the de-interleaved tensor
     rows = (M // 2 + 7) // 8 * 8
-    t = torch.randn(M, 64, generator=g).bfloat16().to(dev)
-    bl = (torch.randn(2 * inner, 64, generator=g) * 0.05).bfloat16().to(dev)
-    pre = torch.full((rows + 8, 2 * inner), 7.0, dtype=torch.bfloat16, device=dev)
-    out2 = torch.empty(M, inner, dtype=torch.bfloat16, device=dev)
+    t = torch.randn(M, 64, generator=g).to(ops.BF16).to(dev)
+    bl = (torch.randn(2 * inner, 64, generator=g) * 0.05).to(ops.BF16).to(dev)
+    pre = torch.full((rows + 8, 2 * inner), 7.0, dtype=ops.BF16, device=dev)
+    out2 = torch.empty(M, inner, dtype=ops.BF16, device=dev)
     ops.gemm([ops.Seg(x, w[perm].contiguous()), ops.Seg(t, bl[perm].contiguous())], M, 2 * inner, out2, bias=bias[perm].contiguous(),
              act=capi.ACT_GEGLU, ldo=inner, pre_out=pre[:rows])
     h2 = h + t.float() @ bl.float().T
     ref2 = h2[:, :inner] * F.gelu(h2[:, inner:])
     excess = max(excess, float(((out2.float() - ref2).abs() - (2e-2 + 1e-2 * ref2.abs())).max()))
     assert bool((pre[rows:] == 7.0).all()), "rows >= pre_rows were written"
-    pre_std = torch.empty(rows, 2 * inner, dtype=torch.bfloat16, device=dev)
+    pre_std = torch.empty(rows, 2 * inner, dtype=ops.BF16, device=dev)
     pre_std[:, perm] = pre[:rows]
     excess = max(excess, float(((pre_std.float() - h2[:rows]).abs() - (2e-2 + 1e-2 * h2[:rows].abs())).max()))
-    dout = torch.randn(rows, inner, generator=g).bfloat16().to(dev)
+    dout = torch.randn(rows, inner, generator=g).to(ops.BF16).to(dev)
     d_il = ops.geglu_bwd_interleaved(pre[:rows], dout)
     d_std = ops.geglu_bwd(pre_std, dout)
     assert torch.equal(d_il, d_std), "geglu_bwd_interleaved differs from geglu_bwd on the same values"
@@ -884,11 +885,11 @@ def case_mmdit_ops(dev):
     Bi, Ci, H, W = 2, 16, 6, 10
     img = rnd(Bi, Ci, H, W, seed=10, dev=dev, dtype=torch.float32)
     tok0 = ops.patchify2x2(img, 0)
-    refu = F.unfold(img.cpu().to(torch.bfloat16).float(), kernel_size=2, stride=2).transpose(1, 2).reshape(Bi * (H // 2) * (W // 2), 4 * Ci)
+    refu = F.unfold(img.cpu().to(ops.BF16).float(), kernel_size=2, stride=2).transpose(1, 2).reshape(Bi * (H // 2) * (W // 2), 4 * Ci)
     assert torch.equal(tok0.float().cpu(), refu), "patchify (c,p,q)"
     tok1 = ops.patchify2x2(img, 1)
     back = ops.unpatchify2x2(tok1.float(), Bi, Ci, H, W)
-    assert torch.equal(back.cpu(), img.cpu().to(torch.bfloat16).float()), "patchify (p,q,c) / unpatchify roundtrip"
+    assert torch.equal(back.cpu(), img.cpu().to(ops.BF16).float()), "patchify (p,q,c) / unpatchify roundtrip"
     tk = rnd(Bi * (H // 2) * (W // 2), 4 * Ci, seed=11, dev=dev, dtype=torch.float32)
     hs = tk.cpu().reshape(Bi, H // 2, W // 2, 2, 2, Ci)
     refimg = torch.einsum("nhwpqc->nchpwq", hs).reshape(Bi, Ci, H, W)                     # discriminator_sd3.py:112-131
