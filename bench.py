@@ -253,7 +253,7 @@ def bench_other_config(args, world, rank, local_rank, dev, sync):
                   "g_loss_last": round(float(state["g"]["g_loss"]), 6)}
     if rank == 0:
         line = {"metric": metric, "value": round(world * B / (dt / args.steps), 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
-                "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+                "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision,
                 "data": "synthetic", "config": {"workload": workload, "baseline_config": cfgname, "global_batch": world * B, "parallelism": "dp%d" % world,
                                                 "launch": "hipGraph replay" if use_graph else "eager", "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 1e9, 1), "losses": losses},
                 "roofline": {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
@@ -283,7 +283,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16"],
+                    help="16-bit format of activations / weights / MFMA operands.  bf16 = BASELINE.json's configs (the default and the headline number); "
+                         "fp16 = the IEEE-half build of the library (the reference's --mixed_precision=fp16 recipes), same MFMA rate, loss-scaled backward")
     args = ap.parse_args()
+    if args.precision == "fp16":
+        from pcm_amd import precision
+        precision.set_precision("fp16")
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # plain ``python bench.py --gpus N`` (no torchrun): become the launcher -- one child process per GPU with the torchrun
@@ -537,7 +543,7 @@ def main():
     if rank == 0:
         line = {"metric": "distillation images/sec (two UNet fwd + bwd) SD1.5 512px bs=16", "value": round(value, 3),
                 "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
-                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
                 "config": {"workload": "SD1.5 PCM-LoRA distillation step, %d phases, 64x64x4 latents, per-GPU batch %d, "
                                        "LoRA r=64 (67.25M trainable), huber, AdamW, random-init UNet (859.5M)" % (args.multiphase, B),
                            "global_batch": world * B, "parallelism": "dp%d" % world, "comm": comm, "launch": "hipGraph replay" if use_graph else "eager", "loss_last": round(loss, 6),

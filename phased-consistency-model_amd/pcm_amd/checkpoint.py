@@ -157,8 +157,13 @@ def save_state(distiller, output_dir, global_step):
     lo = distiller.lora
     save_file({"exp_avg": lo.exp_avg.detach().cpu(), "exp_avg_sq": lo.exp_avg_sq.detach().cpu()},
               os.path.join(output_dir, "optimizer.safetensors"))
+    state = {"global_step": global_step, "optimizer_step": distiller.step_count}
+    if getattr(distiller, "loss_scale_dev", None) is not None:      # fp16 build: the GradScaler state (accelerate saves scaler.pt, :1338)
+        state["optimizer_step"] = int(distiller.step_dev.item())    # updates skipped on a non-finite norm are not optimizer steps
+        state["loss_scale"] = float(distiller.loss_scale_dev.item())
+        state["loss_scale_good_steps"] = int(distiller.loss_good_dev.item())
     with open(os.path.join(output_dir, "trainer_state.json"), "w") as f:
-        json.dump({"global_step": global_step, "optimizer_step": distiller.step_count}, f)
+        json.dump(state, f)
 
 
 def load_state(distiller, input_dir):
@@ -172,6 +177,9 @@ def load_state(distiller, input_dir):
         st = json.load(f)
     distiller.step_count = st["optimizer_step"]
     distiller.step_dev.fill_(st["optimizer_step"])      # the AdamW kernel reads its bias-correction step from device memory
+    if getattr(distiller, "loss_scale_dev", None) is not None and "loss_scale" in st:
+        distiller.loss_scale_dev.fill_(st["loss_scale"])
+        distiller.loss_good_dev.fill_(st["loss_scale_good_steps"])
     return st["global_step"]
 
 

@@ -133,6 +133,7 @@ class Distiller:
     """Owns the frozen UNet weights, the LoRA state and the optimizer state of one rank."""
     _seg = None            # SegmentedGraph being captured (AdvDistiller.capture_adv at world_size > 1); None: collectives are issued directly
     comm_events = None     # a list: step_graphed appends (start, end) events around the gradient exchange
+    loss_scale_dev = loss_good_dev = None      # device-side GradScaler state, set by __init__ under precision "fp16"
 
     def __init__(self, weights: UNetWeights, lora: LoraState, cfg: StepConfig, world_size=1, process_group=None):
         self.W, self.lora, self.cfg = weights, lora, cfg
@@ -258,7 +259,10 @@ class Distiller:
             self._static["added_cond"] = {k: v.clone() for k, v in added_cond.items()}
             self._static["uncond_added_cond"] = {k: v.clone() for k, v in (uncond_added_cond or added_cond).items()}
         lo = self.lora
-        saved = [t.clone() for t in (lo.params, lo.exp_avg, lo.exp_avg_sq, self.step_dev, self.lr_dev)]
+        state = [lo.params, lo.exp_avg, lo.exp_avg_sq, self.step_dev, self.lr_dev]
+        if self.loss_scale_dev is not None:
+            state += [self.loss_scale_dev, self.loss_good_dev]
+        saved = [t.clone() for t in state]
         if self.ema is not None:
             saved.append(self.ema.clone())
         count = self.step_count
@@ -293,7 +297,7 @@ class Distiller:
             torch.cuda.current_stream().wait_stream(cap)
         with torch.cuda.graph(self._g_opt, pool=self._g_fb.pool(), capture_error_mode="thread_local"):
             self._optimizer_apply()
-        for dst, src in zip((lo.params, lo.exp_avg, lo.exp_avg_sq, self.step_dev, self.lr_dev), saved):
+        for dst, src in zip(state, saved):
             dst.copy_(src)
         if self.ema is not None:
             self.ema.copy_(saved[-1])

@@ -21,7 +21,10 @@ UBSAN = os.environ.get("PCM_EMU_UBSAN") == "1"
 OUT = os.path.join(HERE, "libpcm_emu_asan.so" if ASAN else ("libpcm_emu_ubsan.so" if UBSAN else "libpcm_emu.so"))
 
 
-def build(force=False):
+def build(force=False, variant="bf16"):
+    """variant "f16": the IEEE-half build of the same sources (-DPCM_ACT_F16, csrc/pcm_common.h) -> libpcm_emu_f16.so"""
+    f16 = variant == "f16"
+    OUT = globals()["OUT"].replace(".so", "_f16.so") if f16 else globals()["OUT"]
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip"))) + [os.path.join(HERE, "hip_emu.cpp")]
     deps = srcs + glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(HERE, "hip_emu.h"),
                                                            os.path.join(ROOT, "include", "pcm_hip.h")]
@@ -31,10 +34,12 @@ def build(force=False):
     procs = []
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
     for s in srcs:
-        o = os.path.join(HERE, "build", os.path.basename(s) + (".asan.o" if ASAN else (".ubsan.o" if UBSAN else ".o")))
+        o = os.path.join(HERE, "build", os.path.basename(s) + (".f16" if f16 else "") + (".asan.o" if ASAN else (".ubsan.o" if UBSAN else ".o")))
         objs.append(o)
         cmd = [CLANG, "-x", "c++", "-DPCM_HOST_EMU", "-I", HERE, "-O1" if ASAN else "-O2", "-std=c++17", "-fPIC",
                "-Wno-unused-value", "-Wno-deprecated-declarations", "-Wno-psabi", "-c", s, "-o", o]
+        if f16:
+            cmd[3:3] = ["-DPCM_ACT_F16"]
         if ASAN:
             cmd[1:1] = ["-fsanitize=address", "-fno-omit-frame-pointer", "-g", "-shared-libasan"]
         elif UBSAN:

@@ -4,13 +4,13 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, "emu"))
-_cached = None
+_cached = {}
 
 
-def emu_lib():
-    global _cached
-    if _cached is None:
+def emu_lib(variant="bf16"):
+    """variant "f16": the IEEE-half build (-DPCM_ACT_F16) of the same sources"""
+    if variant not in _cached:
         import build_emu
         from pcm_amd import capi
-        _cached = capi.Lib(build_emu.build())
-    return _cached
+        _cached[variant] = capi.Lib(build_emu.build(variant=variant))
+    return _cached[variant]

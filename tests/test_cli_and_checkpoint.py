@@ -97,13 +97,13 @@ def test_sdxl_cli_flag_surface_matches_reference():
 def test_capi_exports_every_declared_symbol():
     from pcm_amd import build as B
     from pcm_amd import capi
-    lib = B.build()
     header = open(os.path.join(ROOT, "include", "pcm_hip.h")).read()
     declared = set(re.findall(r"^\s*(?:int|const char\*)\s+(pcm_\w+)\s*\(", header, flags=re.M))
-    L = capi.Lib(lib)
-    for name in declared:
-        assert hasattr(L.dll, name), f"{name} declared in include/pcm_hip.h but not exported"
-    assert declared - {"pcm_last_error", "pcm_abi_version"} == set(capi._PROTOS), (declared ^ set(capi._PROTOS))
+    for variant in B.VARIANTS:              # the bfloat16 build and the IEEE-half build export the same C ABI
+        L = capi.Lib(B.build(variant=variant))
+        for name in declared:
+            assert hasattr(L.dll, name), f"{name} declared in include/pcm_hip.h but not exported by the {variant} build"
+    assert declared - {"pcm_last_error", "pcm_abi_version", "pcm_act_dtype"} == set(capi._PROTOS), (declared ^ set(capi._PROTOS))
 
 
 def test_missing_library_fails_loudly(tmp_path):

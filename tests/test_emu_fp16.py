@@ -1,0 +1,150 @@
+"""Host-emulation (CPU) checks of the IEEE-half build of the kernels (-DPCM_ACT_F16, csrc/pcm_common.h): the same parity cases through
+tests/emu/libpcm_emu_f16.so, the device-side loss scaler, and the precision switch itself (pcm_amd/precision.py)."""
+import math
+
+import pytest
+import torch
+
+import kernel_cases as K
+from emu_lib import emu_lib
+from pcm_amd import capi, ops, precision
+
+
+@pytest.fixture(autouse=True)
+def _half_emu():
+    precision.set_precision("fp16", lib=emu_lib("f16"))
+    assert ops.BF16 == torch.float16 and capi.lib().act_dtype == 1
+    yield
+    precision.set_precision("bf16", lib=emu_lib("bf16"))
+    capi.set_lib(None)
+    assert ops.BF16 == torch.bfloat16
+
+
+def rel(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def test_kernel_cases_half_build():
+    K.case_groupnorm("cpu", 2, 40, 320, 32, 1)
+    K.case_layernorm("cpu", 9, 320)
+    K.case_elementwise("cpu")
+    K.case_timestep_embedding("cpu")
+    K.case_pack("cpu")
+    K.case_wgrad_plain("cpu", 70, 64, 128)
+    K.case_wgrad_conv("cpu", 1, 6, 5, 64, 1, 0)
+    K.case_gemm_n64("cpu", 200, 192)
+    K.case_conv_r64("cpu", 1, 8, 8, 64, expect_kernel=False)
+    K.case_lora_repack("cpu")
+
+
+@pytest.mark.parametrize("Lq,Lk,d", [(70, 70, 40), (33, 77, 80), (64, 64, 160)])
+def test_attention_half_build(Lq, Lk, d):
+    K.case_attention("cpu", 1, 2, Lq, Lk, d)
+
+
+def test_gemm_tiles_half_build():
+    K.case_gemm_big("cpu", "plain_lora")
+    K.case_gemm_big("cpu", "conv")
+    K.case_gemm_4w("cpu", "plain_lora")
+    K.case_gemm_geglu("cpu")
+
+
+def test_half_conversions_and_mfma_are_ieee_half():
+    """a plain GEMM on values that bfloat16 cannot hold (11-bit significands) is exact to the output rounding: the half MFMA + converts are in"""
+    g = torch.Generator().manual_seed(0)
+    M, N, Kd = 64, 64, 64
+    x = (torch.randint(1024, 2048, (M, Kd), generator=g).float() / 1024).half()       # 1.0 .. 2.0 in steps of 2^-10: exact in half only
+    w = (torch.randint(-8, 9, (N, Kd), generator=g).float() / 8).half()
+    assert not torch.equal(x.float().bfloat16().float(), x.float())
+    out = torch.empty(M, N, dtype=torch.float32)
+    ops.gemm([ops.Seg(x, w)], M, N, out)
+    assert torch.equal(out, x.float() @ w.float().t())            # every partial sum is exactly representable in fp32
+    out16 = torch.empty(M, N, dtype=torch.float16)
+    ops.gemm([ops.Seg(x, w)], M, N, out16)
+    assert torch.equal(out16, (x.float() @ w.float().t()).half())  # round-to-nearest-even into half
+    big = torch.full((M, Kd), 300.0).half()
+    ops.gemm([ops.Seg(big, big[:N])], M, N, out16)                # 64 * 9e4 = 5.76e6 > 65504: half output saturates to inf (no wrap, no NaN)
+    assert bool(torch.isinf(out16).all())
+
+
+def test_device_side_grad_scaler_semantics():
+    """pcm_scale_f32_dev / pcm_adamw_clip_step_scaled / pcm_loss_scale_update == torch.cuda.amp.GradScaler(65536, 2, 0.5, interval) around
+    clip_grad_norm_ + AdamW (train_pcm_lora_sd15.py:1296-1299 under --mixed_precision=fp16)."""
+    n, S0 = 1000, 65536.0
+    g = torch.Generator().manual_seed(1)
+    p = torch.randn(n, generator=g)
+    grad = torch.randn(n, generator=g) * 1e-3
+    m, v = torch.zeros(n), torch.zeros(n)
+    scale, good, step = torch.tensor([S0]), torch.zeros(1, dtype=torch.int32), torch.zeros(1, dtype=torch.int64)
+    lr = torch.tensor([1e-3])
+    sq = torch.zeros(1, dtype=torch.float64)
+    # reference: torch AdamW on the unscaled gradient with the same clip
+    pr = p.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([pr], lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2)
+
+    def hip_step(gs):
+        step.add_(1)
+        ops.sumsq(gs, sq)
+        ops.adamw_clip_step_scaled(p, gs, m, v, sq, 0.01, 1e-3, 0.9, 0.999, 1e-8, 1e-2, 1.0, step, lr, scale)
+        ops.loss_scale_update(scale, good, step, sq, growth=2.0, backoff=0.5, interval=2)
+
+    d = grad.clone()
+    ops.scale_by_dev(d, scale)
+    assert torch.equal(d, grad * S0)
+    hip_step(d)                                                   # finite: applied
+    pr.grad = grad.clone()
+    torch.nn.utils.clip_grad_norm_([pr], 0.01)
+    opt.step()
+    assert torch.allclose(p, pr.detach(), rtol=2e-6, atol=1e-7) and int(step) == 1 and int(good) == 1 and float(scale) == S0
+    bad = d.clone(); bad[3] = float("nan")
+    p0, m0, v0 = p.clone(), m.clone(), v.clone()
+    hip_step(bad)                                                 # non-finite: skipped, scale halves, the step is not counted
+    assert torch.equal(p, p0) and torch.equal(m, m0) and torch.equal(v, v0) and int(step) == 1 and int(good) == 0 and float(scale) == S0 / 2
+    for k in range(2):                                            # two finite steps at the new scale: applied, then the scale grows back
+        d = grad.clone(); ops.scale_by_dev(d, scale)
+        hip_step(d)
+        pr.grad = grad.clone()
+        torch.nn.utils.clip_grad_norm_([pr], 0.01)
+        opt.step()
+    assert torch.allclose(p, pr.detach(), rtol=5e-6, atol=1e-7) and int(step) == 3 and int(good) == 0 and float(scale) == S0
+
+
+def test_tiny_unet_forward_half_build_closer_to_fp32_than_bf16():
+    """teacher forward of a 3-level SD1.5-topology UNet through the half emulator build against the fp32 oracle: the error sits at the
+    half rounding level (the bf16 build: ~8x that, tests/test_emu_unet.py)."""
+    from oracle import unet_sd15 as O
+    from pcm_amd.model import UNet, UNetWeights
+    from pcm_amd.unet_spec import UNetConfig as PC
+    kw = dict(block_out_channels=(64, 128, 128), cross_attention_dim=64, heads=2, norm_num_groups=32)
+    oc, pc = O.UNetConfig(**kw), PC(**kw)
+    sd = O.init_state_dict(oc, 0)
+    g = torch.Generator().manual_seed(11)
+    x, t, ctx = torch.randn(1, 4, 8, 8, generator=g), torch.tensor([419]), torch.randn(1, 7, 64, generator=g)
+    ref = O.unet_forward(oc, sd, x, t, ctx)
+    W = UNetWeights(pc, sd, "cpu")
+    assert W.layers[next(iter(W.layers))].w_fwd.dtype == torch.float16
+    out = UNet(W, None).forward(x, t, ctx)
+    r = rel(out.float(), ref)
+    print("tiny UNet, half build vs fp32 oracle: rel-L2 %.3e" % r)
+    assert math.isfinite(r) and r < 2.5e-3, r
+
+
+def test_precision_switch_loads_the_matching_library():
+    """the product libraries (dlopen works without a GPU): each reports its format, set_precision refuses a mismatch and rebinds the dtype"""
+    from pcm_amd import build as B
+    bf, h = capi.Lib(B.build(variant="bf16")), capi.Lib(B.build(variant="f16"))
+    assert (bf.act_dtype, h.act_dtype) == (0, 1)
+    assert not [n for n in capi._PROTOS if n not in h.fn], "libpcm_hip_f16.so must export the whole C ABI"
+    with pytest.raises(RuntimeError, match="built for"):
+        precision.set_precision("fp16", lib=bf)
+    with pytest.raises(ValueError):
+        precision.set_precision("fp32")
+    precision.set_precision("bf16")
+    assert capi.lib().path == capi.DEFAULT_LIB and ops.BF16 == torch.bfloat16 and precision.act_dtype() == torch.bfloat16
+    precision.set_precision("fp16")
+    assert capi.lib().path == capi.F16_LIB and ops.BF16 == torch.float16
+    capi.set_lib(None)
+    assert capi.lib().path == capi.F16_LIB            # set_lib(None) re-loads the CURRENT precision's library
+    precision.set_precision("bf16")
+    assert capi.lib().path == capi.DEFAULT_LIB
