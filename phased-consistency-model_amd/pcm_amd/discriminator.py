@@ -203,8 +203,9 @@ class Discriminator:
         capi.lib().call("pcm_colsum_bf16", ops.ptr(dy), ops.ptr(hd.g[name + ".bias"]), 1, M, C, capi.Lib.stream())
 
     # ------------------------------------------------------------------ losses (discriminator_sd15.py:412-434)
-    def d_loss_backward(self, logits_fake_real, tape, B_half, weight=1.0, on_bucket=None):
-        """logits of the batched [fake; real] pass.  Returns loss (fp64 [1]); accumulates head gradients."""
+    def d_loss_backward(self, logits_fake_real, tape, B_half, weight=1.0, on_bucket=None, loss_scale_dev=None):
+        """logits of the batched [fake; real] pass.  Returns loss (fp64 [1]); accumulates head gradients.
+        ``loss_scale_dev`` (half build): the fp32 logit gradients are multiplied by the device-side loss scale before the 16-bit backward."""
         loss = torch.zeros(1, dtype=torch.float64, device=self.device)
         n_heads = self.head_num * self.nh
         d_logits = []
@@ -212,16 +213,20 @@ class Discriminator:
             half = lg.numel() // 2
             df, dr = ops.hinge_loss(lg[:half], lg[half:], 0, weight / n_heads, loss)
             d_logits.append(torch.cat([df, dr]))
+            if loss_scale_dev is not None:
+                ops.scale_by_dev(d_logits[-1], loss_scale_dev)
         self.backward(d_logits, tape, param_grads=True, feature_grads=False, on_bucket=on_bucket)
         return loss
 
-    def g_loss_backward(self, logits_fake, tape, weight=1.0, grad_scale=1.0):
-        """Returns (loss fp64 [1], d_feats): gradient of grad_scale * g_loss wrt the 9 teacher features."""
+    def g_loss_backward(self, logits_fake, tape, weight=1.0, grad_scale=1.0, loss_scale_dev=None):
+        """Returns (loss fp64 [1], d_feats): gradient of grad_scale * g_loss (times the device-side loss scale, half build) wrt the 9 teacher features."""
         loss = torch.zeros(1, dtype=torch.float64, device=self.device)
         n_heads = self.head_num * self.nh
         d_logits = []
         for lg in logits_fake:
             df, _ = ops.hinge_loss(lg, None, 1, weight / n_heads, loss, grad_scale=grad_scale)
+            if loss_scale_dev is not None:
+                ops.scale_by_dev(df, loss_scale_dev)
             d_logits.append(df)
         d_feats = self.backward(d_logits, tape, param_grads=False, feature_grads=True)
         return loss, d_feats

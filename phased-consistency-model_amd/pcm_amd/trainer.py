@@ -402,9 +402,6 @@ class AdvDistiller(Distiller):
 
     def __init__(self, weights, lora, cfg, discriminator, adv_weight=0.1, adv_lr=1e-5, world_size=1, process_group=None):
         super().__init__(weights, lora, cfg, world_size, process_group)
-        if self.loss_scale_dev is not None:
-            raise RuntimeError("the adversarial step is built for the bf16 library only (its discriminator / generator backward seeds carry no loss scale); "
-                               "run it with --mixed_precision=bf16")
         self.disc, self.adv_weight, self.adv_lr = discriminator, adv_weight, adv_lr
         self.adv_lr_dev = torch.full((1,), float(adv_lr), dtype=torch.float32, device=self.device)
 
@@ -447,15 +444,17 @@ class AdvDistiller(Distiller):
             disc.grads.zero_()
             self._disc_works = []
             bucket = (lambda a, b_: self._collective(lambda: self._disc_bucket(a, b_))) if (self.world_size > 1 or SEG_FORCE) else None
-            out["d_loss"] = disc.d_loss_backward(logits, dtape, B, on_bucket=bucket)                                                # :1383-1391
+            out["d_loss"] = disc.d_loss_backward(logits, dtape, B, on_bucket=bucket, loss_scale_dev=self.loss_scale_dev)           # :1383-1391
             out["real_adv"] = real_adv
             self._disc_optimizer_step()
             return out
         feats, utape = self.teacher.forward(fake_adv, adv_t, prompt_embeds, features=taps, save=True, added_cond=ac)
         logits, dtape = disc.forward(feats, save=True)
-        g_loss, d_feats = disc.g_loss_backward(logits, dtape, grad_scale=self.adv_weight)       # :1414-1421
+        g_loss, d_feats = disc.g_loss_backward(logits, dtape, grad_scale=self.adv_weight, loss_scale_dev=self.loss_scale_dev)       # :1414-1421
         d_fake = self.teacher.backward(None, utape, d_feats=d_feats, need_input_grad=True)
         loss_cm, d_eps = ops.consistency_loss(model_pred, target, coef, cfg.loss_type == "huber", cfg.huber_c)
+        if self.loss_scale_dev is not None:      # half build: both terms of loss_cm + adv_weight * g_loss carry the loss scale (d_fake already does)
+            ops.scale_by_dev(d_eps, self.loss_scale_dev)
         ops.scale_add_rows(d_eps, d_fake, sr, coef)          # d fake_adv/d model_pred = sqrt(r); d model_pred/d eps = coef
         out.update(loss_cm=loss_cm, g_loss=g_loss, d_fake_adv=d_fake, d_eps=d_eps)
         self.lora.zero_grad()
@@ -481,6 +480,8 @@ class AdvDistiller(Distiller):
             st["uncond_added_cond"] = {k: v.clone() for k, v in (uncond_added_cond or added_cond).items()}
         self._adv_static = st
         keep = (lo.params, lo.exp_avg, lo.exp_avg_sq, self.step_dev, self.lr_dev, d.params, d.exp_avg, d.exp_avg_sq, d.step_dev)
+        if self.loss_scale_dev is not None:
+            keep += (self.loss_scale_dev, self.loss_good_dev)
         saved = [t.clone() for t in keep]
         count = self.step_count
         side = torch.cuda.Stream()
@@ -576,6 +577,11 @@ class AdvDistiller(Distiller):
             self._collective(self._disc_finish_exchange)
         d.step_dev += 1
         ops.sumsq(d.grads, d.gradsq)
-        ops.adamw_clip_step(d.params, d.grads, d.exp_avg, d.exp_avg_sq, d.gradsq, cfg.max_grad_norm, self.adv_lr, 0.0, 0.999,
-                            cfg.adam_epsilon, cfg.adam_weight_decay, 1, 1.0 / self.world_size, step_dev=d.step_dev, lr_dev=self.adv_lr_dev)
+        if self.loss_scale_dev is not None:      # one GradScaler for both optimizers, updated once per global step (accelerate)
+            ops.adamw_clip_step_scaled(d.params, d.grads, d.exp_avg, d.exp_avg_sq, d.gradsq, cfg.max_grad_norm, self.adv_lr, 0.0, 0.999,
+                                       cfg.adam_epsilon, cfg.adam_weight_decay, 1.0 / self.world_size, d.step_dev, self.adv_lr_dev, self.loss_scale_dev)
+            ops.loss_scale_update(self.loss_scale_dev, self.loss_good_dev, d.step_dev, d.gradsq)
+        else:
+            ops.adamw_clip_step(d.params, d.grads, d.exp_avg, d.exp_avg_sq, d.gradsq, cfg.max_grad_norm, self.adv_lr, 0.0, 0.999,
+                                cfg.adam_epsilon, cfg.adam_weight_decay, 1, 1.0 / self.world_size, step_dev=d.step_dev, lr_dev=self.adv_lr_dev)
         d.repack()

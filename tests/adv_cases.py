@@ -112,6 +112,7 @@ def case_adv_c3(dev, kw, dims, B, hw, ctx_len, ctx_dim, global_step, nh=4, lr=5e
     oc, pc, lora, disc, ocfg, cfg, inp = _setup(dev, kw, dims, B, hw, ctx_len, ctx_dim, nh, lr, index, seed)
     W = UNetWeights(pc, O.init_state_dict(oc, 0), dev)
     D = AdvDistiller(W, lora, cfg, disc, adv_weight=adv_weight, adv_lr=adv_lr)
+    gsc = float(D.loss_scale_dev.item()) if D.loss_scale_dev is not None else 1.0      # half build: the gradient buffers hold S * grad
     lora_p0, head_p0 = lora.params.clone(), head_flat(disc, "p", cpu=False)
     p0 = torch.cat([torch.cat([lora.A_peft(m).detach().cpu().reshape(-1), m.B.detach().cpu().reshape(-1)]) for m in lora.modules.values()])
     names = list(head_p0)
@@ -124,7 +125,7 @@ def case_adv_c3(dev, kw, dims, B, hw, ctx_len, ctx_dim, global_step, nh=4, lr=5e
         rep["d_loss"], rep["d_loss_oracle"] = float(out["d_loss"]), float(ref["d_loss"])
         rep["d_loss_rel"] = abs(rep["d_loss"] - rep["d_loss_oracle"]) / abs(rep["d_loss_oracle"])
         mine_g = head_flat(disc, "g", cpu=False)
-        mg = sketch_cat([mine_g[n] for n in names])
+        mg = sketch_cat([mine_g[n] for n in names]) / gsc
         rep["head_grad_rel"], rep["head_grad_cos"] = sk_rel(mg, ref["sk_head_grad"]), sk_cos(mg, ref["sk_head_grad"])
         # per tapped feature (the 4 heads of one feature share its bucket)
         rep["head_grad_cos_per_tap"] = [sk_cos(sketch_cat([mine_g[n] for n in names if n.startswith("heads.%d." % k)]), ref["sk_head_grad_tap%d" % k])
@@ -133,7 +134,7 @@ def case_adv_c3(dev, kw, dims, B, hw, ctx_len, ctx_dim, global_step, nh=4, lr=5e
         mine_p = head_flat(disc, "p", cpu=False)
         up_m = sketch_cat([mine_p[n] - head_p0[n] for n in names])
         gn = float(ref["head_grad_norm"])
-        rep["head_grad_norm_rel"] = abs(math.sqrt(float(disc.gradsq.item())) - gn) / gn
+        rep["head_grad_norm_rel"] = abs(math.sqrt(float(disc.gradsq.item())) / gsc - gn) / gn
         rep["head_update_cos"] = sk_cos(up_m, ref["sk_head_update"])
         rep["head_update_norm_ratio"] = float(up_m.norm() / ref["sk_head_update"].double().norm())
         rep["head_param_rel_after"] = sk_rel(sketch_cat([mine_p[n] for n in names]), ref["sk_head_param_after"])
@@ -142,11 +143,11 @@ def case_adv_c3(dev, kw, dims, B, hw, ctx_len, ctx_dim, global_step, nh=4, lr=5e
         for k in ("loss_cm", "g_loss"):
             rep[k], rep[k + "_oracle"] = float(out[k]), float(ref[k])
             rep[k + "_rel"] = abs(rep[k] - rep[k + "_oracle"]) / abs(rep[k + "_oracle"])
-        mg = sketch_cat([t for m in lora.modules.values() for t in (lora.gA_peft(m), m.gB)])
+        mg = sketch_cat([t for m in lora.modules.values() for t in (lora.gA_peft(m), m.gB)]) / gsc
         rep["lora_grad_rel"], rep["lora_grad_cos"] = sk_rel(mg, ref["sk_lora_grad"]), sk_cos(mg, ref["sk_lora_grad"])
         mine1 = torch.cat([torch.cat([lora.A_peft(m).detach().cpu().reshape(-1), m.B.detach().cpu().reshape(-1)]) for m in lora.modules.values()])
         gn = float(ref["lora_grad_norm"])
-        rep["lora_grad_norm_rel"] = abs(math.sqrt(float(lora.gradsq.item())) - gn) / gn
+        rep["lora_grad_norm_rel"] = abs(math.sqrt(float(lora.gradsq.item())) / gsc - gn) / gn
         up_m = sketch(mine1 - p0)
         rep["lora_update_cos"] = sk_cos(up_m, ref["sk_lora_update"])
         rep["lora_update_norm_ratio"] = float(up_m.norm() / ref["sk_lora_update"].double().norm())

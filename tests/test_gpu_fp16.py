@@ -199,3 +199,35 @@ def test_fp16_graph_replay_equals_eager_and_overflow_is_skipped():
     out = D.step(*args)                      # the next step runs at the lower scale and is applied
     torch.cuda.synchronize()
     assert int(D.step_dev.item()) == 4 and not torch.equal(lora.params, p) and math.isfinite(float(out["loss"].item()))
+
+
+@pytest.mark.parametrize("global_step", [0, 1])
+def test_fp16_adv_step_c3_shape_full_size(global_step):
+    """BASELINE configs[2]'s step (SD1.5 UNet, 36 heads, bs 2, lr 5e-6 / adv_lr 1e-5) through the half build: discriminator step (even) and
+    generator step (odd) against the fp32-oracle fixture (tests/adv_cases.py); both backward seeds carry the device-side loss scale, the two
+    optimizers share one GradScaler state (train_pcm_lora_sd15_adv.py:1383-1431 under --mixed_precision=fp16)."""
+    import adv_cases as A
+    from pcm_amd.discriminator import ADAPTER_DIMS
+    kw = dict(block_out_channels=(320, 640, 1280, 1280), cross_attention_dim=768, heads=8, norm_num_groups=32)
+    rep = A.case_adv_c3("cuda", kw, ADAPTER_DIMS, 2, 64, 77, 768, global_step, nh=4, index=[30, 12],
+                        golden_name="sd15_adv_c3_bs2_step%d" % global_step)
+    os.makedirs("gpurun_out", exist_ok=True)
+    json.dump(rep, open("gpurun_out/fp16_adv_c3_parity_step%d.json" % global_step, "w"), indent=1)
+    assert rep["heads"] == 36 and rep["fake_adv"] < 6e-4
+    if global_step % 2 == 0:
+        assert rep["d_loss_rel"] < 1e-3 and rep["lora_untouched"]
+        assert rep["head_grad_cos"] > 0.995 and min(rep["head_grad_cos_per_tap"]) > 0.99 and rep["head_grad_norm_rel"] < 5e-3
+        assert rep["head_update_cos"] > 0.95 and abs(rep["head_update_norm_ratio"] - 1) < 2e-2 and rep["head_param_rel_after"] < 6e-4
+    else:
+        assert rep["loss_cm_rel"] < 2e-3 and rep["g_loss_rel"] < 1e-3 and rep["heads_untouched"]
+        assert rep["lora_grad_cos"] > 0.999 and rep["lora_grad_norm_rel"] < 5e-3
+        assert rep["lora_update_cos"] > 0.97 and abs(rep["lora_update_norm_ratio"] - 1) < 2e-2 and rep["lora_param_rel_after"] < 3e-4
+
+
+def test_fp16_adv_steps_graph_replay_equals_eager():
+    """D, G, D, G through the two captured hipGraphs == eager, with the loss scale and the shared GradScaler state inside the graphs
+    (the bf16 suite's case, tests/test_gpu_adv.py, run under the half build: its capi.set_lib(None) re-loads the current precision's library)"""
+    from pcm_amd import capi
+    from test_gpu_adv import test_adv_steps_graph_replay_equals_eager as case
+    case()
+    assert capi.lib().act_dtype == 1
