@@ -253,6 +253,17 @@ def lr_at(args, step):
     raise ValueError(f"unsupported --lr_scheduler {args.lr_scheduler}")
 
 
+def apply_mixed_precision(args):
+    """--mixed_precision (handed to accelerate at train_pcm_lora_sd15.py:1034).  fp16: accelerate's fp16 autocast + GradScaler (:1296-1299)
+    = the IEEE-half build of the kernel library with the GradScaler state on the device (pcm_amd/precision.py, trainer.Distiller /
+    AdvDistiller).  "bf16" / None / "no": the bfloat16 build (there is no fp32-storage build; "no" is computed in bf16).  Call before any
+    weights are packed.  Shared by the SD1.5, SD1.5-adversarial and SDXL-adversarial scripts."""
+    if getattr(args, "mixed_precision", None) == "fp16":
+        from pcm_amd import precision
+        precision.set_precision("fp16")
+        logger.info("--mixed_precision=fp16: half build of the kernel library (lib/libpcm_hip_f16.so), dynamic loss scaling on the device")
+
+
 def main(args):
     from pcm_amd import capi, checkpoint as ck
     from pcm_amd.model import LoraState, UNetWeights
@@ -263,13 +274,7 @@ def main(args):
     local_rank = max(args.local_rank, 0)
     logging.basicConfig(format="%(asctime)s - %(levelname)s - %(name)s - %(message)s", datefmt="%m/%d/%Y %H:%M:%S",
                         level=logging.INFO if rank == 0 else logging.WARNING)
-    if args.mixed_precision == "fp16":
-        # accelerate's fp16 autocast + GradScaler (train_pcm_lora_sd15.py:1034, :1296-1299): the IEEE-half build of the kernel library with the
-        # GradScaler state on the device (pcm_amd/precision.py, trainer.Distiller).  "bf16" / None / "no": the bfloat16 build (there is no
-        # fp32-storage build; "no" is computed in bf16 as before).
-        from pcm_amd import precision
-        precision.set_precision("fp16")
-        logger.info("--mixed_precision=fp16: half build of the kernel library (lib/libpcm_hip_f16.so), dynamic loss scaling on the device")
+    apply_mixed_precision(args)
     if args.gradient_accumulation_steps < 1:
         raise SystemExit("pcm_amd: --gradient_accumulation_steps must be >= 1")
     ignored = [k for k in IGNORED if getattr(args, k) not in (None, False, 0, 8, 200)]

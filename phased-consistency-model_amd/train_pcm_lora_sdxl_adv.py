@@ -109,6 +109,7 @@ def main(args):
         torch.cuda.set_device(local_rank)
         torch.distributed.init_process_group("nccl", rank=rank, world_size=world)
     device = base.pick_device(local_rank)
+    base.apply_mixed_precision(args)
     capi.lib()
     ucfg = base.unet_config(args, "sdxl")
     sd = random_state_dict(ucfg, 0, device) if args.pretrained_teacher_model == "random" else ck.load_unet_state_dict(args.pretrained_teacher_model)

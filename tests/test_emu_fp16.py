@@ -148,3 +148,43 @@ def test_precision_switch_loads_the_matching_library():
     assert capi.lib().path == capi.F16_LIB            # set_lib(None) re-loads the CURRENT precision's library
     precision.set_precision("bf16")
     assert capi.lib().path == capi.DEFAULT_LIB
+
+
+def test_cli_mixed_precision_fp16_end_to_end(tmp_path, monkeypatch):
+    """train_pcm_lora_sd15.py --mixed_precision=fp16 as a program (narrow UNet, host emulator of the half build): the flag selects the half
+    library, steps are loss-scaled and applied, the checkpoint carries the GradScaler state and a resumed run restores it."""
+    import importlib.util
+    import json
+    import os
+    from safetensors.torch import save_file
+    pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "phased-consistency-model_amd")
+    spec = importlib.util.spec_from_file_location("pcm_cli_fp16", os.path.join(pkg, "train_pcm_lora_sd15.py"))
+    cli = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cli)
+    g = torch.Generator().manual_seed(0)
+    shards = tmp_path / "s"
+    shards.mkdir()
+    save_file({"latents": torch.randn(6, 4, 8, 8, generator=g), "prompt_embeds": torch.randn(6, 7, 64, generator=g),
+               "uncond_prompt_embeds": torch.randn(7, 64, generator=g)}, str(shards / "a.safetensors"))
+    monkeypatch.setenv("PCM_CLI_DEVICE", "cpu")
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    real, asked = precision.set_precision, []
+    precision.set_precision("bf16", lib=emu_lib("bf16"))          # the program starts in the default format ...
+
+    def via_emulator(name, lib=None):                              # ... and its set_precision("fp16") gets the emulator's half build
+        asked.append(name)
+        real(name, lib=emu_lib("f16" if name == "fp16" else "bf16"))
+    monkeypatch.setattr(precision, "set_precision", via_emulator)
+    out = tmp_path / "o"
+    common = ["--pretrained_teacher_model", "random", "--tiny_model", "--latents_dir", str(shards), "--train_batch_size", "1", "--learning_rate", "1e-3",
+              "--multiphase", "2", "--seed", "1", "--output_dir", str(out), "--mixed_precision", "fp16", "--loss_type", "huber", "--checkpointing_steps", "2"]
+    cli.main(cli.parse_args(common + ["--max_train_steps", "2"]))
+    assert asked == ["fp16"] and ops.BF16 == torch.float16 and capi.lib().act_dtype == 1
+    st = json.load(open(out / "checkpoint-2" / "trainer_state.json"))
+    assert st["loss_scale"] == 65536.0 and st["loss_scale_good_steps"] == 2 and st["optimizer_step"] == 2
+    log = [json.loads(l) for l in open(out / "logs" / "text2image-fine-tune.jsonl")]
+    assert [r["step"] for r in log] == [1, 2] and all(math.isfinite(r["loss"]) and 0 < r["grad_norm"] < 1e3 for r in log)   # the UNSCALED norm is logged
+    cli.main(cli.parse_args(common + ["--max_train_steps", "3", "--resume_from_checkpoint", "latest"]))
+    st = json.load(open(out / "checkpoint-2" / "trainer_state.json"))
+    log = [json.loads(l) for l in open(out / "logs" / "text2image-fine-tune.jsonl")]
+    assert log[-1]["step"] == 3 and math.isfinite(log[-1]["loss"])
