@@ -33,7 +33,7 @@ def test_kernel_cases_half_build():
     K.case_pack("cpu")
     K.case_wgrad_plain("cpu", 70, 64, 128)
     K.case_wgrad_conv("cpu", 1, 6, 5, 64, 1, 0)
-    K.case_gemm_n64("cpu", 200, 192)
+    assert K.case_gemm_n64("cpu", 200, 192) <= 0
     K.case_conv_r64("cpu", 1, 8, 8, 64, expect_kernel=False)
     K.case_lora_repack("cpu")
 
@@ -44,10 +44,9 @@ def test_attention_half_build(Lq, Lk, d):
 
 
 def test_gemm_tiles_half_build():
-    K.case_gemm_big("cpu", "plain_lora")
-    K.case_gemm_big("cpu", "conv")
-    K.case_gemm_4w("cpu", "plain_lora")
-    K.case_gemm_geglu("cpu")
+    for excess, err in (K.case_gemm_big("cpu", "plain_lora"), K.case_gemm_big("cpu", "conv"), K.case_gemm_4w("cpu", "plain_lora")):
+        assert excess <= 0, err
+    assert K.case_gemm_geglu("cpu") <= 0
 
 
 def test_half_conversions_and_mfma_are_ieee_half():

@@ -15,6 +15,9 @@ lin = [(2048, 1280, 1280), (4096, 1280, 1280), (1024, 1280, 1280), (8192, 640, 6
        (8192, 640, 2560), (4096, 1280, 5120), (2048, 10240, 1280), (8192, 1280, 1280), (8192, 3840, 1280), (616, 1280, 2048), (308, 1536, 1536), (2, 9216, 1536), (616, 1536, 1536),
        (16384, 1536, 1536), (8192, 1536, 1536), (8192, 1536, 6144), (2464, 1280, 768)]
 conv = [(8, 8, 8, 1280), (16, 8, 8, 1280), (32, 8, 8, 1280), (16, 16, 16, 1280), (16, 16, 16, 640)]      # (B, H, W, C): C -> C 3x3
+if os.environ.get("AB_SHAPES"):          # "M,N,K;M,N,K;..." replaces the linear list (and drops the convs)
+    lin = [tuple(int(v) for v in t.split(",")) for t in os.environ["AB_SHAPES"].split(";")]
+    conv = []
 only = os.environ.get("AB_ONLY")
 ROUNDS, REP = 5, 6
 
@@ -31,7 +34,7 @@ def timed(fn):
 
 def sweep(name, fl, call):
     arms = [("planner", 1, (0, 0)), ("8p", 2, (0, 0)), ("4w", 3, (0, 0))]
-    for (bm, bn) in ((128, 128), (128, 64), (64, 64), (256, 256), (256, 320)):
+    for (bm, bn) in ((128, 128), (128, 64), (64, 64), (256, 256), (256, 320)):      # (+ (256, 192) with tools/probes/patches/r04_gemm8p_256x192_tile.patch applied)
         for sp in (1, 2, 3, 4, 6, 8):
             arms.append(("%dx%d/%d" % (bm, bn, sp), 0, (bm | (sp << 16), bn)))
     res = {a[0]: [] for a in arms}
