@@ -231,3 +231,14 @@ def test_fp16_adv_steps_graph_replay_equals_eager():
     from test_gpu_adv import test_adv_steps_graph_replay_equals_eager as case
     case()
     assert capi.lib().act_dtype == 1
+
+
+def test_fp16_sdxl_topology_step_vs_oracle():
+    """the SDXL wiring (added conditioning, linear projections, 1 / 2 / 3-deep transformers; narrow config, live fp32 oracle) through the
+    half build: same case as tests/test_gpu_sdxl.py, bounds ~10x tighter than the bf16 build's"""
+    from test_gpu_sdxl import sdxl_topology_step_case
+    rep, _ = sdxl_topology_step_case()
+    for k in ("noise_pred", "uncond_teacher_output", "x_prev", "target"):
+        assert rep[k] < 3e-3, (k, rep)
+    # MI355X: eps 1.2e-3, x_prev 2.8e-4, loss 2.1e-4, gradient cosine 0.9991 (bf16 build: 9.7e-3, 2.3e-3, 9.2e-3, 0.975)
+    assert rep["loss_rel"] < 2e-3 and rep["grad_cos"] > 0.995 and 0.98 < rep["grad_norm_ratio"] < 1.02, rep
