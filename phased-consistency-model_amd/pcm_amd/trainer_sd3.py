@@ -28,6 +28,10 @@ class SD3Distiller(Distiller):
 
     def __init__(self, weights: MMDiTWeights, lora: LoraState, cfg: SD3StepConfig, world_size=1, process_group=None):
         # (Distiller.__init__ builds the UNet runners and DDIM tables; this variant has its own, the optimizer half is inherited)
+        from . import precision
+        if precision.precision() == "fp16":
+            # the flow-matching step seeds its backward without the loss scale: in half its gradients would silently underflow
+            raise RuntimeError("the SD3 / MMDiT trainer runs on the bf16 build of the library only (precision.set_precision('bf16'))")
         self.W, self.lora, self.cfg = weights, lora, cfg
         self.device = lora.device
         self.solver = fm.EulerSolver(fm.flow_sigmas(cfg.num_train_timesteps, cfg.shift), cfg.num_train_timesteps, cfg.num_euler_timesteps, self.device)

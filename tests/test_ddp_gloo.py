@@ -67,8 +67,9 @@ def test_two_rank_allreduce_and_step(tmp_path):
     assert torch.allclose(p0, ref_p, rtol=1e-5, atol=1e-7)
 
 
-def _step_worker(rank, world, port, outdir):
-    """Full distillation step (fused online+target forward, LoRA backward, all-reduce, clip + AdamW) of a tiny UNet on this rank's shard."""
+def _step_worker(rank, world, port, outdir, prec="bf16"):
+    """Full distillation step (fused online+target forward, LoRA backward, all-reduce, clip + AdamW) of a tiny UNet on this rank's shard.
+    ``prec`` "fp16": through the half build of the emulator library, loss-scaled (the all-reduce then sums S * grad)."""
     sys.path[:0] = [ROOT, os.path.join(ROOT, "phased-consistency-model_amd"), os.path.join(ROOT, "tests")]
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     if world > 1:
@@ -81,12 +82,16 @@ def _step_worker(rank, world, port, outdir):
     from pcm_amd.trainer import Distiller, StepConfig
     from pcm_amd.unet_spec import UNetConfig
     capi.set_lib(emu_lib())
+    if prec == "fp16":
+        from pcm_amd import precision
+        precision.set_precision("fp16", lib=emu_lib("f16"))
     kw = dict(block_out_channels=(64, 64), layers_per_block=1, cross_attention_dim=64, heads=2)
     sd = O.init_state_dict(O.UNetConfig(**kw), 0)
     W = UNetWeights(UNetConfig(**kw), sd, "cpu")
     lora = LoraState(UNetConfig(**kw), 64, 8.0, "cpu", seed=5, b_std=0.02)
     cfg = StepConfig(multiphase=2, learning_rate=1e-3, w_min=4.0, w_max=5.0)
     D = Distiller(W, lora, cfg, world_size=world)
+    assert (D.loss_scale_dev is not None) == (prec == "fp16")
     inp = OS.draw_inputs(4, OS.StepConfig(multiphase=2), seed=11, latent_hw=8, ctx_len=7, ctx_dim=64)       # the GLOBAL batch of 4
     n = 4 // world
     sl = slice(rank * n, (rank + 1) * n)                                                                      # this rank's shard
@@ -97,10 +102,31 @@ def _step_worker(rank, world, port, outdir):
         D._all_reduce_late = lambda: (fired.append(1), orig())[1]
     out = D.step(*(inp[k][sl].contiguous() for k in ("latents", "prompt_embeds", "uncond_prompt_embeds", "noise", "index", "w")))
     assert (world == 1) or (fired == [1] and D._late_work is None)
+    if prec == "fp16":      # a finite step: applied, counted, the scale unchanged -- on every rank alike
+        assert float(D.loss_scale_dev) == 65536.0 and int(D.loss_good_dev) == 1 and int(D.step_dev) == 1
     torch.save((lora.params.clone(), float(out["loss"])), os.path.join(outdir, f"w{world}r{rank}.pt"))
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+
+
+def test_two_rank_full_step_half_build(tmp_path):
+    """the same data-parallel step through the IEEE-half build (loss-scaled backward: the all-reduce sums S * grad, AdamW divides S and the
+    world size out): ranks stay identical and land on the single-process update"""
+    ctx = mp.get_context("spawn")
+    ps = [ctx.Process(target=_step_worker, args=(r, 2, 29761, str(tmp_path), "fp16")) for r in range(2)]
+    ps.append(ctx.Process(target=_step_worker, args=(0, 1, 29762, str(tmp_path), "fp16")))
+    for p in ps:
+        p.start()
+    for p in ps:
+        p.join(600)
+        assert p.exitcode == 0
+    (p0, l0), (p1, l1) = (torch.load(os.path.join(str(tmp_path), f"w2r{r}.pt")) for r in range(2))
+    ps1, l_single = torch.load(os.path.join(str(tmp_path), "w1r0.pt"))
+    assert torch.equal(p0, p1), "ranks diverged"
+    assert abs((l0 + l1) / 2 - l_single) < 5e-3 * abs(l_single)
+    rel = float((p0 - ps1).norm() / ps1.norm())
+    assert rel < 2e-3, rel          # one lr = 1e-3 Adam step of sign-like updates on |param| ~ 3e-2: both runs move the same way
 
 
 def test_two_rank_full_step_matches_single_process_on_the_global_batch(tmp_path):
