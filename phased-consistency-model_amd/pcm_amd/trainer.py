@@ -153,10 +153,7 @@ class Distiller:
         # fp16 build (precision.set_precision("fp16"), the reference's --mixed_precision=fp16): the backward runs on S * d(loss) with the
         # GradScaler state in device memory (S = 65536 at start, x2 after 2000 finite steps, x0.5 and no update after a non-finite
         # gradient norm: torch.cuda.amp.GradScaler defaults, which accelerate uses at train_pcm_lora_sd15.py:1034) -- capturable.
-        self.loss_scale_dev = self.loss_good_dev = None
-        if precision.precision() == "fp16":
-            self.loss_scale_dev = torch.full((1,), float(os.environ.get("PCM_LOSS_SCALE", "65536")), dtype=torch.float32, device=self.device)
-            self.loss_good_dev = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._init_loss_scaler()
         self.comm_events = None           # a list: step_graphed appends (start, end) events around the gradient exchange
         self._seg = None                  # SegmentedGraph being captured (AdvDistiller.capture_adv at world_size > 1)
         # two-bucket gradient exchange (world_size > 1): the mid/up-block bucket is reduced while the down blocks back-propagate
@@ -164,6 +161,28 @@ class Distiller:
         self.ema = None
         if cfg.ema_rate is not None:
             self.ema = lora.params.clone()
+
+    def _init_loss_scaler(self):
+        """device-side GradScaler state under precision "fp16" (None otherwise); shared by the UNet and MMDiT trainers"""
+        self.loss_scale_dev = self.loss_good_dev = None
+        if precision.precision() == "fp16":
+            self.loss_scale_dev = torch.full((1,), float(os.environ.get("PCM_LOSS_SCALE", "65536")), dtype=torch.float32, device=self.device)
+            self.loss_good_dev = torch.zeros(1, dtype=torch.int32, device=self.device)
+
+    def _disc_adamw(self, d, adv_lr, adv_lr_dev):
+        """AdamW(betas = (0, 0.999)) + global-norm clip over the discriminator heads ``d`` (already reduced over ranks); under the half build
+        on loss-scaled gradients with the trainer's one GradScaler state, updated once per global step as accelerate does"""
+        cfg = self.cfg
+        d.step_dev += 1
+        ops.sumsq(d.grads, d.gradsq)
+        if self.loss_scale_dev is not None:
+            ops.adamw_clip_step_scaled(d.params, d.grads, d.exp_avg, d.exp_avg_sq, d.gradsq, cfg.max_grad_norm, adv_lr, 0.0, 0.999,
+                                       cfg.adam_epsilon, cfg.adam_weight_decay, 1.0 / self.world_size, d.step_dev, adv_lr_dev, self.loss_scale_dev)
+            ops.loss_scale_update(self.loss_scale_dev, self.loss_good_dev, d.step_dev, d.gradsq)
+        else:
+            ops.adamw_clip_step(d.params, d.grads, d.exp_avg, d.exp_avg_sq, d.gradsq, cfg.max_grad_norm, adv_lr, 0.0, 0.999,
+                                cfg.adam_epsilon, cfg.adam_weight_decay, 1, 1.0 / self.world_size, step_dev=d.step_dev, lr_dev=adv_lr_dev)
+        d.repack()
 
     # ---- a2: timestep sampling (train_pcm_lora_sd15.py:1143-1155) ----
     def timesteps_for(self, index):
@@ -575,13 +594,4 @@ class AdvDistiller(Distiller):
         cfg, d = self.cfg, self.disc
         if self.world_size > 1 or SEG_FORCE:
             self._collective(self._disc_finish_exchange)
-        d.step_dev += 1
-        ops.sumsq(d.grads, d.gradsq)
-        if self.loss_scale_dev is not None:      # one GradScaler for both optimizers, updated once per global step (accelerate)
-            ops.adamw_clip_step_scaled(d.params, d.grads, d.exp_avg, d.exp_avg_sq, d.gradsq, cfg.max_grad_norm, self.adv_lr, 0.0, 0.999,
-                                       cfg.adam_epsilon, cfg.adam_weight_decay, 1.0 / self.world_size, d.step_dev, self.adv_lr_dev, self.loss_scale_dev)
-            ops.loss_scale_update(self.loss_scale_dev, self.loss_good_dev, d.step_dev, d.gradsq)
-        else:
-            ops.adamw_clip_step(d.params, d.grads, d.exp_avg, d.exp_avg_sq, d.gradsq, cfg.max_grad_norm, self.adv_lr, 0.0, 0.999,
-                                cfg.adam_epsilon, cfg.adam_weight_decay, 1, 1.0 / self.world_size, step_dev=d.step_dev, lr_dev=self.adv_lr_dev)
-        d.repack()
+        self._disc_adamw(d, self.adv_lr, self.adv_lr_dev)

@@ -28,10 +28,6 @@ class SD3Distiller(Distiller):
 
     def __init__(self, weights: MMDiTWeights, lora: LoraState, cfg: SD3StepConfig, world_size=1, process_group=None):
         # (Distiller.__init__ builds the UNet runners and DDIM tables; this variant has its own, the optimizer half is inherited)
-        from . import precision
-        if precision.precision() == "fp16":
-            # the flow-matching step seeds its backward without the loss scale: in half its gradients would silently underflow
-            raise RuntimeError("the SD3 / MMDiT trainer runs on the bf16 build of the library only (precision.set_precision('bf16'))")
         self.W, self.lora, self.cfg = weights, lora, cfg
         self.device = lora.device
         self.solver = fm.EulerSolver(fm.flow_sigmas(cfg.num_train_timesteps, cfg.shift), cfg.num_train_timesteps, cfg.num_euler_timesteps, self.device)
@@ -42,6 +38,7 @@ class SD3Distiller(Distiller):
         self.step_dev = torch.zeros(1, dtype=torch.int64, device=self.device)
         self.lr_dev = torch.full((1,), float(cfg.learning_rate), dtype=torch.float32, device=self.device)
         self._graph = None
+        self._init_loss_scaler()          # half build (--mixed_precision=fp16, every recipe of text_to_image_sd3/run.sh): device-side GradScaler state
         self.ema = lora.params.clone() if cfg.ema_rate is not None else None
 
     def forward_backward(self, model_input, prompt_embeds, pooled_prompt_embeds, uncond_prompt_embeds, uncond_pooled_prompt_embeds, noise,
@@ -69,6 +66,8 @@ class SD3Distiller(Distiller):
         # d model_pred / d pred = sigma_prev[end] - sigma[index]  (per sample)
         coef = (S.sigmas_prev[end_index] - S.sigmas[index].double()).float().contiguous()
         loss, d_pred = ops.consistency_loss(model_pred32, target32, coef, True, cfg.huber_c, grad_scale=grad_scale)   # :1374-1379
+        if self.loss_scale_dev is not None:
+            ops.scale_by_dev(d_pred, self.loss_scale_dev)
         out = dict(loss=loss, noisy_model_input=noisy, model_output=pred, model_pred=model_pred64, cond_teacher_output=cond,
                    uncond_teacher_output=uncond, x_prev=x_prev64, target_pred=target_pred, target=target64, timesteps=timesteps,
                    timesteps_prev=timesteps_prev, end_index=end_index)
@@ -107,7 +106,10 @@ class SD3Distiller(Distiller):
                             uncond_pooled_prompt_embeds=torch.zeros(B, mc.pooled_projection_dim, **f32),
                             noise=torch.zeros(B, mc.in_channels, H, W, **f32), index=torch.zeros(B, dtype=torch.int64, device=dev))
         lo = self.lora
-        saved = [t.clone() for t in (lo.params, lo.exp_avg, lo.exp_avg_sq, self.step_dev, self.lr_dev)]
+        state = [lo.params, lo.exp_avg, lo.exp_avg_sq, self.step_dev, self.lr_dev]
+        if self.loss_scale_dev is not None:
+            state += [self.loss_scale_dev, self.loss_good_dev]
+        saved = [t.clone() for t in state]
         if self.ema is not None:
             saved.append(self.ema.clone())
         count = self.step_count
@@ -123,7 +125,7 @@ class SD3Distiller(Distiller):
             self._static_out = self.forward_backward(**self._static)
         with torch.cuda.graph(self._g_opt, pool=self._g_fb.pool(), capture_error_mode="thread_local"):
             self._optimizer_apply()
-        for dst, src in zip((lo.params, lo.exp_avg, lo.exp_avg_sq, self.step_dev, self.lr_dev), saved):
+        for dst, src in zip(state, saved):
             dst.copy_(src)
         if self.ema is not None:
             self.ema.copy_(saved[-1])
@@ -197,16 +199,18 @@ class SD3AdvDistiller(SD3Distiller):
                                          torch.cat([pooled_prompt_embeds, pooled_prompt_embeds]), features=True)
             logits, dtape = disc.forward(self._feats(feats, H, Wd), save=True)
             disc.grads.zero_()
-            out["d_loss"] = disc.d_loss_backward(logits, dtape, B)                                         # :1446-1466
+            out["d_loss"] = disc.d_loss_backward(logits, dtape, B, loss_scale_dev=self.loss_scale_dev)     # :1446-1466
             out["real_adv"] = real32
             self._disc_optimizer_step()
             return out
         feats, utape = self.teacher.forward(fake32, t_adv, prompt_embeds, pooled_prompt_embeds, features=True, save=True)
         logits, dtape = disc.forward(self._feats(feats, H, Wd), save=True)
-        g_loss, d_feats = disc.g_loss_backward(logits, dtape, grad_scale=self.adv_weight)                  # :1492-1500
+        g_loss, d_feats = disc.g_loss_backward(logits, dtape, grad_scale=self.adv_weight, loss_scale_dev=self.loss_scale_dev)   # :1492-1500
         d_fake = self.teacher.backward(None, utape, d_feats=d_feats, need_input_grad=True)
         coef = (S.sigmas_prev[end_index] - S.sigmas[index].double()).float().contiguous()                  # d model_pred / d pred
         loss_cm, d_pred = ops.consistency_loss(model_pred32, target32, coef, self.loss_type == "huber", cfg.huber_c)   # :1468-1481
+        if self.loss_scale_dev is not None:
+            ops.scale_by_dev(d_pred, self.loss_scale_dev)
         ops.scale_add_rows(d_pred, d_fake, ratio, coef)        # d fake_adv / d model_pred = ratio; d model_pred / d pred = coef
         out.update(loss_cm=loss_cm, g_loss=g_loss, d_fake_adv=d_fake, d_pred=d_pred)
         self.lora.zero_grad()
@@ -222,8 +226,4 @@ class SD3AdvDistiller(SD3Distiller):
         cfg, d = self.cfg, self.disc
         if self.world_size > 1:
             torch.distributed.all_reduce(d.grads, op=torch.distributed.ReduceOp.SUM, group=self.pg)
-        d.step_dev += 1
-        ops.sumsq(d.grads, d.gradsq)
-        ops.adamw_clip_step(d.params, d.grads, d.exp_avg, d.exp_avg_sq, d.gradsq, cfg.max_grad_norm, self.adv_lr, 0.0, 0.999,
-                            cfg.adam_epsilon, cfg.adam_weight_decay, 1, 1.0 / self.world_size, step_dev=d.step_dev, lr_dev=self.adv_lr_dev)
-        d.repack()
+        self._disc_adamw(d, self.adv_lr, self.adv_lr_dev)

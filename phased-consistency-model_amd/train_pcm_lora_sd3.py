@@ -205,6 +205,7 @@ def main(args):
         torch.cuda.set_device(local_rank)
         torch.distributed.init_process_group("nccl", rank=rank, world_size=world)
     device = pick_device(local_rank)
+    base.apply_mixed_precision(args)          # fp16 (every recipe of text_to_image_sd3/run.sh): the half build + device-side GradScaler
     capi.lib()
     if args.seed is not None:
         torch.manual_seed(args.seed + rank)

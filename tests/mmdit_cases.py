@@ -88,6 +88,7 @@ def run_step_case(dev, not_apply_cfg_solver=False):
     ref["loss"].backward()
     cfg = SD3StepConfig(multiphase=4, not_apply_cfg_solver=not_apply_cfg_solver)
     D = SD3Distiller(W, lora, cfg)
+    gsc = float(D.loss_scale_dev.item()) if D.loss_scale_dev is not None else 1.0      # half build: the gradient buffers hold S * grad
     p0 = lora.params.clone()
     out = D.step(*(t.to(dev) for t in (x0, pe, pp, upe, upp, noise, index)))
     assert torch.equal(out["end_index"].cpu(), ref["end_index"])
@@ -100,7 +101,7 @@ def run_step_case(dev, not_apply_cfg_solver=False):
     assert abs(float(out["loss"]) - rl) < 5e-2 * abs(rl), (float(out["loss"]), rl)
     num = den = 0.0
     for p, m in lora.modules.items():
-        for got, r in ((m.gA[:32].cpu(), olora[p][0].grad), (m.gB[:, :32].cpu(), olora[p][1].grad)):
+        for got, r in ((m.gA[:32].cpu() / gsc, olora[p][0].grad), (m.gB[:, :32].cpu() / gsc, olora[p][1].grad)):
             num += float(((got - r) ** 2).sum())
             den += float((r ** 2).sum())
     print("loss %.5f (oracle %.5f), LoRA grad rel err %.3e" % (float(out["loss"]), rl, (num / den) ** 0.5))
@@ -189,6 +190,7 @@ def run_adv_case(dev, global_step):
     off = torch.clamp((adv_u * span).long(), max=span - 1)
     ref = OS.distill_step_sd3_adv(oc, sd, olora, dsd, x0, pe, pp, upe, upp, noise, index, off, nf, nr, global_step, multiphase=4, adv_weight=0.1)
     D = SD3AdvDistiller(W, lora, SD3StepConfig(multiphase=4), disc, adv_weight=0.1, adv_lr=1e-5)
+    gsc = float(D.loss_scale_dev.item()) if D.loss_scale_dev is not None else 1.0      # half build: the gradient buffers hold S * grad
     p0, d0 = lora.params.clone(), disc.params.clone()
     out = D.step_adv(global_step, *(t.to(dev) for t in (x0, pe, pp, upe, upp, noise, index, nf, nr, adv_u)))
     assert torch.equal(out["adv_index"].cpu(), ref["adv_index"])
@@ -203,7 +205,7 @@ def run_adv_case(dev, global_step):
             h = cnt.get(k, 0)
             cnt[k] = h + 1
             for n, t in hd.g.items():
-                v = t.detach().cpu().clone()
+                v = t.detach().cpu().clone() / gsc
                 got[f"heads.{k}.{h}.{n}"] = v
         num = den = 0.0
         for n, gref in ref["head_grads"].items():
@@ -224,7 +226,7 @@ def run_adv_case(dev, global_step):
     assert abs(float(out["loss_cm"]) - rl) < 5e-2 * abs(rl) and abs(float(out["g_loss"]) - rg) < 5e-2 * abs(rg), (float(out["loss_cm"]), rl, float(out["g_loss"]), rg)
     num = den = 0.0
     for p, m in lora.modules.items():
-        for got, r in ((m.gA[:32].cpu(), olora[p][0].grad), (m.gB[:, :32].cpu(), olora[p][1].grad)):
+        for got, r in ((m.gA[:32].cpu() / gsc, olora[p][0].grad), (m.gB[:, :32].cpu() / gsc, olora[p][1].grad)):
             r = r.view_as(got)
             num += float(((got - r) ** 2).sum())
             den += float((r ** 2).sum())

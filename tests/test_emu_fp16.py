@@ -187,3 +187,14 @@ def test_cli_mixed_precision_fp16_end_to_end(tmp_path, monkeypatch):
     st = json.load(open(out / "checkpoint-2" / "trainer_state.json"))
     log = [json.loads(l) for l in open(out / "logs" / "text2image-fine-tune.jsonl")]
     assert log[-1]["step"] == 3 and math.isfinite(log[-1]["loss"])
+
+
+@pytest.mark.parametrize("case", ["step", "adv_d", "adv_g"])
+def test_sd3_mmdit_half_build(case):
+    """SD3 / MMDiT trainers through the half emulator build: the flow-matching step and the adversarial D / G steps with the loss-scaled
+    backward (narrow config, live oracle; tests/mmdit_cases.py)"""
+    import mmdit_cases as M
+    if case == "step":
+        M.run_step_case("cpu")
+    else:
+        M.run_adv_case("cpu", 0 if case == "adv_d" else 1)
