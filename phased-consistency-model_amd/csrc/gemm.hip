@@ -365,7 +365,7 @@ extern "C" void pcm_debug_gemm_conv_order(int chunk_outer) { g_conv_co = chunk_o
 extern "C" void pcm_debug_gemm_conv_md(int mask_delta) { g_conv_md = mask_delta < 0 ? -1 : (mask_delta ? 1 : 0); }
 static int g_ablate = 0;      // see PCM_ABL in gemm_dev.h (no effect in the product build); bits 8.. = gemm4w start stagger override + 1
 extern "C" void pcm_debug_gemm_ablate(int mask) { g_ablate = mask; }
-static int g_last_plan = 0;   // tests only: 1000*big_fn + splitk of the most recent pcm_gemm_bf16 launch (gemm4w: 10000 + 1000*fn + 1)
+static int g_last_plan = 0;   // tests only: 1000*big_fn + splitk of the most recent pcm_gemm_bf16 launch (gemm4w: 10000 + 1000*fn + 1; 64 / 65: rank-64 kernels; 32: gemm_smallm)
 extern "C" int pcm_debug_last_gemm_plan(void) { return g_last_plan; }
 // A/B only: PCM_GEMM_PLAN_LEGACY=1 = the planner as it was before the round-4 re-fit (flat 15 % price of a K split, K split for every
 // under-filled small-tile grid)
@@ -537,9 +537,23 @@ static bool gemm_n64_ok(const pcm_gemm_seg* segs, int nseg, const pcm_gemm_epi* 
   return big_mode() > 0 && !g_force_bm && nseg == 1 && segs[0].mode == PCM_SEG_PLAIN && e->N == 64 && (segs[0].K % 64) == 0 &&
          e->out_dtype != PCM_F32 && !e->bias && !e->rowvec && !e->residual && e->act == PCM_ACT_NONE;
 }
+// batch-row projections (M <= 32: time embedding, time_emb_proj, adaLN modulation) that the weight-streaming kernel (gemm_smallm.hip) takes;
+// PCM_GEMM_SMALLM=0 switches it off (A/B)
+static int smallm_on() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("PCM_GEMM_SMALLM"); v = e ? atoi(e) : 1; }
+  return v;
+}
+static bool gemm_smallm_ok(const pcm_gemm_seg* segs, int nseg, const pcm_gemm_epi* e) {
+  if (!smallm_on() || big_mode() <= 0 || g_force_bm || e->M > 32 || (e->N % 4) || e->rowvec || e->residual) return false;
+  if (e->act != PCM_ACT_NONE && e->act != PCM_ACT_SILU) return false;
+  for (int i = 0; i < nseg; i++)
+    if (segs[i].mode != PCM_SEG_PLAIN || (segs[i].K % 32) || (segs[i].lda % 8)) return false;
+  return true;
+}
 extern "C" size_t pcm_gemm_workspace_bytes(const pcm_gemm_seg* segs, int nseg, const pcm_gemm_epi* e) {
   if (!segs || !e || nseg < 1 || nseg > 2 || e->M <= 0 || e->N <= 0) return 0;
-  if (gemm_n64_ok(segs, nseg, e)) return 0;
+  if (gemm_smallm_ok(segs, nseg, e) || gemm_n64_ok(segs, nseg, e)) return 0;
   // the workspace is sized for the plan that would be used WITH a workspace; pcm_gemm_bf16 re-plans identically
   return gemm_plan(e->M, e->N, gemm_total_kt(segs, nseg), true, gemm_big_ok(segs, nseg, e), e->act == PCM_ACT_GEGLU, gemm_w4_ok(segs, nseg)).ws_bytes;
 }
@@ -601,6 +615,12 @@ extern "C" int pcm_gemm_bf16(const pcm_gemm_seg* segs, int nseg, const pcm_gemm_
     const int rc = pcm_conv_r64_launch(g, stream);
     if (rc < 0) return rc;
     if (rc == 0) { g_last_plan = 65; return pcm_post_launch("pcm_gemm_bf16"); }
+  }
+  if (gemm_smallm_ok(segs, nseg, e)) {
+    g_last_plan = 32;
+    int rc = pcm_gemm_smallm_launch(g, stream);
+    if (rc) return rc;
+    return pcm_post_launch("pcm_gemm_bf16");
   }
   if (gemm_n64_ok(segs, nseg, e)) {
     g_last_plan = 64;

@@ -702,6 +702,39 @@ def case_gemm_n64(dev, M, K):
     return float((err - (2e-2 + 1e-2 * ref.abs())).max())
 
 
+def case_gemm_smallm(dev, M, N, Ks, act=0, bias=True, out_f32=False, alpha=1.0):
+    """batch-row projections (M <= 32: time-embedding MLP, time_emb_proj, adaLN modulation) through the weight-streaming kernel
+    (gemm_smallm.hip, plan 32) vs torch fp32 on the same 16-bit operands AND vs the generic tile path (big_mode 0); returns the excess."""
+    from pcm_amd import capi, ops
+    g = torch.Generator().manual_seed(M * 7 + N)
+    segs, ref = [], torch.zeros(M, N)
+    for K in Ks:
+        x = torch.randn(M, K, generator=g).to(ops.BF16).to(dev)
+        w = (torch.randn(N, K, generator=g) * 0.05).to(ops.BF16).to(dev)
+        segs.append(ops.Seg(x, w))
+        ref = ref + x.float().cpu() @ w.float().cpu().T
+    b = torch.randn(N, generator=g).to(dev) if bias else None
+    ref = alpha * ref + (b.cpu() if bias else 0.0)
+    if act:
+        ref = F.silu(ref)
+    dll = capi.lib().dll
+    outs = []
+    for mode in (1, 0):
+        dll.pcm_debug_gemm_big_mode(mode)
+        try:
+            out = torch.full((M, N + 8), 7.0, dtype=torch.float32 if out_f32 else ops.BF16, device=dev)     # row stride > N, sentinel in the gap
+            ops.gemm(segs, M, N, out, bias=b, act=capi.ACT_SILU if act else capi.ACT_NONE, alpha=alpha, ldo=N + 8)
+            assert (dll.pcm_debug_last_gemm_plan() == 32) == (mode == 1), (mode, dll.pcm_debug_last_gemm_plan())
+        finally:
+            dll.pcm_debug_gemm_big_mode(1)
+        assert bool((out[:, N:].float() == 7.0).all()), "wrote past N"
+        outs.append(out[:, :N].float().cpu())
+    err = (outs[0] - ref).abs()
+    tol = (2e-3 if out_f32 else 2e-2) + (2e-3 if out_f32 else 1e-2) * ref.abs()
+    assert float((outs[0] - outs[1]).abs().max()) <= float((2 * tol).max()), "small-M kernel vs generic tile"
+    return float((err - tol).max())
+
+
 def case_conv_r64(dev, B, H, W, C, expect_kernel=True):
     """conv LoRA down-projection t = conv3x3(x, A), A: C -> 64 (N = 64 implicit GEMM): the halo-window kernel (conv_r64.hip) where the
     geometry allows it, the generic tile otherwise -- both against torch conv2d on the same bf16 operands."""
