@@ -696,7 +696,7 @@ def case_gemm_n64(dev, M, K):
     w = (torch.randn(64, K, generator=g) * 0.1).to(ops.BF16).to(dev)
     out = torch.empty(M, 64, dtype=ops.BF16, device=dev)
     ops.gemm([ops.Seg(x, w)], M, 64, out)
-    assert capi.lib().dll.pcm_debug_last_gemm_plan() == 64
+    assert capi.lib().dll.pcm_debug_last_gemm_plan() == (32 if M <= 32 else 64)     # (batch-row calls, M <= 32: gemm_smallm.hip takes them first)
     ref = x.float() @ w.float().T
     err = (out.float() - ref).abs()
     return float((err - (2e-2 + 1e-2 * ref.abs())).max())
