@@ -537,7 +537,7 @@ static bool gemm_n64_ok(const pcm_gemm_seg* segs, int nseg, const pcm_gemm_epi* 
   return big_mode() > 0 && !g_force_bm && nseg == 1 && segs[0].mode == PCM_SEG_PLAIN && e->N == 64 && (segs[0].K % 64) == 0 &&
          e->out_dtype != PCM_F32 && !e->bias && !e->rowvec && !e->residual && e->act == PCM_ACT_NONE;
 }
-// batch-row projections (M <= 32: time embedding, time_emb_proj, adaLN modulation) that the weight-streaming kernel (gemm_smallm.hip) takes;
+// batch-row projections (M <= 16: time embedding, time_emb_proj, adaLN modulation) that the weight-streaming kernel (gemm_smallm.hip) takes;
 // PCM_GEMM_SMALLM=0 switches it off (A/B)
 static int smallm_on() {
   static int v = -1;
@@ -545,7 +545,7 @@ static int smallm_on() {
   return v;
 }
 static bool gemm_smallm_ok(const pcm_gemm_seg* segs, int nseg, const pcm_gemm_epi* e) {
-  if (!smallm_on() || big_mode() <= 0 || g_force_bm || e->M > 32 || (e->N % 4) || e->rowvec || e->residual) return false;
+  if (!smallm_on() || big_mode() <= 0 || g_force_bm || e->M > 16 || (e->N % 4) || e->rowvec || e->residual) return false;
   if (e->act != PCM_ACT_NONE && e->act != PCM_ACT_SILU) return false;
   for (int i = 0; i < nseg; i++)
     if (segs[i].mode != PCM_SEG_PLAIN || (segs[i].K % 32) || (segs[i].lda % 8)) return false;

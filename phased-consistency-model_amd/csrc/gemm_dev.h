@@ -106,5 +106,5 @@ int pcm_gemm4w_launch(const GemmDev& g, int fn, void* stream);
 int pcm_conv_r64_launch(const GemmDev& g, void* stream);
 // streaming kernel for the rank-64 projections (gemm_n64.hip)
 int pcm_gemm_n64_launch(const GemmDev& g, void* stream);
-// weight-streaming kernel for the batch-row projections, M <= 32 (gemm_smallm.hip)
+// weight-streaming kernel for the batch-row projections, M <= 16 (gemm_smallm.hip)
 int pcm_gemm_smallm_launch(const GemmDev& g, void* stream);

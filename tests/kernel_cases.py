@@ -696,14 +696,14 @@ def case_gemm_n64(dev, M, K):
     w = (torch.randn(64, K, generator=g) * 0.1).to(ops.BF16).to(dev)
     out = torch.empty(M, 64, dtype=ops.BF16, device=dev)
     ops.gemm([ops.Seg(x, w)], M, 64, out)
-    assert capi.lib().dll.pcm_debug_last_gemm_plan() == (32 if M <= 32 else 64)     # (batch-row calls, M <= 32: gemm_smallm.hip takes them first)
+    assert capi.lib().dll.pcm_debug_last_gemm_plan() == (32 if M <= 16 else 64)     # (batch-row calls, M <= 16: gemm_smallm.hip takes them first)
     ref = x.float() @ w.float().T
     err = (out.float() - ref).abs()
     return float((err - (2e-2 + 1e-2 * ref.abs())).max())
 
 
 def case_gemm_smallm(dev, M, N, Ks, act=0, bias=True, out_f32=False, alpha=1.0):
-    """batch-row projections (M <= 32: time-embedding MLP, time_emb_proj, adaLN modulation) through the weight-streaming kernel
+    """batch-row projections (M <= 16: time-embedding MLP, time_emb_proj, adaLN modulation) through the weight-streaming kernel
     (gemm_smallm.hip, plan 32) vs torch fp32 on the same 16-bit operands AND vs the generic tile path (big_mode 0); returns the excess."""
     from pcm_amd import capi, ops
     g = torch.Generator().manual_seed(M * 7 + N)

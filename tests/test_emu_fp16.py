@@ -34,6 +34,7 @@ def test_kernel_cases_half_build():
     K.case_wgrad_plain("cpu", 70, 64, 128)
     K.case_wgrad_conv("cpu", 1, 6, 5, 64, 1, 0)
     assert K.case_gemm_n64("cpu", 200, 192) <= 0
+    assert K.case_gemm_smallm("cpu", 13, 320, (64, 64), 1, True, False) <= 0 and K.case_gemm_smallm("cpu", 2, 144, (96,), 0, True, True) <= 0
     K.case_conv_r64("cpu", 1, 8, 8, 64, expect_kernel=False)
     K.case_lora_repack("cpu")
 

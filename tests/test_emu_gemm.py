@@ -184,9 +184,9 @@ def test_fused_geglu_epilogue():
     assert KC.case_gemm_geglu("cpu", M=256, K=64, inner=128) <= 0
 
 
-@pytest.mark.parametrize("M,N,Ks,act,bias,f32", [(32, 64, (128,), 0, True, False), (2, 144, (96,), 1, True, False), (17, 320, (64, 64), 1, True, False),
+@pytest.mark.parametrize("M,N,Ks,act,bias,f32", [(16, 64, (128,), 0, True, False), (2, 144, (96,), 1, True, False), (13, 320, (64, 64), 1, True, False),
                                                    (16, 32, (32,), 0, False, True), (4, 100, (160, 32), 0, True, True), (1, 16, (2048,), 0, True, False)])
 def test_batch_row_projection_kernel(M, N, Ks, act, bias, f32):
-    """gemm_smallm.hip: M <= 32 (one or two 16-row tiles, ragged M and N, one or two K segments, K steps not a multiple of waves x unroll)"""
+    """gemm_smallm.hip: M <= 16 (ragged M and N, one or two K segments, K steps not a multiple of waves x unroll)"""
     import kernel_cases as KC
     assert KC.case_gemm_smallm("cpu", M, N, Ks, act, bias, f32, alpha=0.5 if f32 else 1.0) <= 0

@@ -47,6 +47,7 @@ def test_kernels_half_build():
     K.case_lora_repack("cuda")
     assert K.case_gemm_n64("cuda", 8192, 1280) <= 0 and K.case_gemm_n64("cuda", 65536, 320) <= 0        # (these cases return the excess over tolerance)
     K.case_conv_r64("cuda", 4, 32, 32, 640)
+    assert K.case_gemm_smallm("cuda", 16, 1280, (1280, 64), 0, True, False) <= 0 and K.case_gemm_smallm("cuda", 2, 9216, (1536,), 1, True, False) <= 0
     assert K.case_gemm_geglu("cuda") <= 0 and K.case_gemm_geglu("cuda", M=8192, K=1280, inner=5120) <= 0
 
 

@@ -1,4 +1,4 @@
-"""Times of the batch-row projections (M <= 32) of the four configs through pcm_gemm_bf16; run once with PCM_GEMM_SMALLM=0 (the generic
+"""Times of the batch-row projections (M <= 16) of the four configs through pcm_gemm_bf16; run once with PCM_GEMM_SMALLM=0 (the generic
 tiles / rank-64 kernel they used before) and once with the default (gemm_smallm.hip) and compare.  3 operand sets rotated, median of 5 rounds."""
 import os
 import sys

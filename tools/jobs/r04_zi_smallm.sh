@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 4, call ZI: the batch-row projection kernel (gemm_smallm.hip, M <= 32): GPU tests, per-shape times with the kernel off / on, whole steps of C2 and C5 off / on
+# round 4, call ZI: the batch-row projection kernel (gemm_smallm.hip, M <= 16): GPU tests, per-shape times with the kernel off / on, whole steps of C2 and C5 off / on
 cd $GRAFT_REPO_ROOT; O=gpurun_out/r04zi; mkdir -p $O; export TMPDIR=/tmp
 timeout 600 python -m pytest tests/test_gpu_gemm.py -q -x -k "batch_row or plain_gemm" > $O/pytest.txt 2>&1; echo "pytest rc=$?" >> $O/rc.log
 PCM_GEMM_SMALLM=0 timeout 300 python tools/gemm_smallm_probe.py > $O/probe_off.txt 2> $O/probe.err; echo "probe off rc=$?" >> $O/rc.log
