@@ -11,7 +11,9 @@
  *  - plain pointers + sizes; the CALLER owns every buffer; the library never allocates or frees
  *    device memory.  Global state: one immutable 16-byte zero page in the code object (out-of-bounds
  *    LDS-DMA lanes), once-only hipFuncSetAttribute flags, environment switches read once
- *    (PCM_GEMM_BIG, PCM_GEMM_4W_MAXKT, PCM_GEMM_CONV_CO / _MD), and the pcm_debug_* tuning / test hooks
+ *    (A/B and tuning switches, all optional, none needed by a caller: PCM_GEMM_BIG, PCM_GEMM_4W_MAXKT / _STAGGER,
+ *    PCM_GEMM_CONV_CO / _MD, PCM_GEMM_PLAN_LEGACY, PCM_GEMM_SMALLM, PCM_N64_RF, PCM_CONV_R64, PCM_WGRAD_TR,
+ *    PCM_WGRAD_DENSE_MSPLIT), and the pcm_debug_* tuning / test hooks
  *    (tile forcing, kernel-family mode, last-plan read-back, ...) -- process-wide, not thread-safe,
  *    used by tools/ and tests/ only; a product caller never touches them.
  *  - every call enqueues on `stream` (a hipStream_t passed as void*; torch's current stream)
