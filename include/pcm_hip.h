@@ -126,11 +126,18 @@ typedef struct {
   int M;
   float* out; long g_stride, r_stride; int out_conv;
   float alpha;
+  /* abi >= 4 -- reproducible form.  NULL / 0: the M split's partial sums meet in `out` as fp32 atomics (fastest; the summation ORDER, and
+   * with it the last bits of the gradient, changes from run to run).  A workspace of >= pcm_lora_wgrad_workspace_bytes(a): every
+   * block of the M split stores its partial tile to its own slab and an ordered finalize launch adds the slabs to `out` in split order:
+   * bitwise identical results run to run (what cuDNN/cuBLAS "deterministic algorithms" buy the reference under
+   * torch.use_deterministic_algorithms; costs the slab round trip and one more launch per job). */
+  void* workspace; size_t workspace_bytes;
 } pcm_wgrad_args;
+size_t pcm_lora_wgrad_workspace_bytes(const pcm_wgrad_args* a);   /* bytes the reproducible form of this job needs (0: bad arguments) */
 int pcm_lora_wgrad_bf16(const pcm_wgrad_args* a, void* stream);
 /* n (1..64) independent jobs of the call above in as few launches as possible: the weight gradients of one autograd node (lora_A and
  * lora_B of a module; the six of a fused q/k/v projection) are 3-20 us kernels each, so they share launches.  Same result as n calls. */
-int pcm_lora_wgrad_multi_bf16(const pcm_wgrad_args* list, int n, void* stream);
+int pcm_lora_wgrad_multi_bf16(const pcm_wgrad_args* list, int n, void* stream);   /* jobs that carry a workspace run one by one (the same workspace may serve them all) */
 
 /* ---- Dense conv3x3 weight gradient, channels-last  (autograd of the trainable nn.Conv2d(C, C, 3, 1, 1) layers of DiscriminatorHead,
  * discriminator_sd15.py:349-362, in the discriminator step train_pcm_lora_sd15_adv.py:1383-1391) --------------------------------
@@ -215,6 +222,10 @@ int pcm_concat_channels(const void* a, int Ca, const void* b, int Cb, void* out,
 int pcm_split_channels(const void* in, void* a, int Ca, void* b, int Cb, long rows, int accumulate_a, void* stream);
 int pcm_add_bf16(const void* a, const void* b, void* out, long n, void* stream);
 int pcm_colsum_bf16(const void* x, void* out /*fp32 [B][C], zeroed by the call*/, int B, int HW, int C, void* stream); /* d(time_emb_proj out) */
+/* reproducible forms (abi >= 4): the cross-block fp32 / fp64 atomics of the call above (summation order changes run to run) become
+ * per-block partials in `workspace` + one ordered finalize launch -> bitwise identical results run to run. */
+size_t pcm_colsum_workspace_bytes(int B, int HW, int C);
+int pcm_colsum_bf16_ws(const void* x, void* out, int B, int HW, int C, void* workspace, size_t workspace_bytes, void* stream);
 int pcm_silu_bf16(const void* x, void* y, long n, void* stream);
 /* dx = dy * silu'(x): backward of the SiLU on the conditioning vector (silu(temb), and between the two embedder linears) when the
  * SD3 adversarial trainers' LoRA list adapts the conditioning path (train_pcm_lora_sd3_adv.py:992-1015) */
@@ -327,6 +338,10 @@ int pcm_fm_sampler_step(const float* model_output, const float* model_output_unc
 int pcm_consistency_loss(const float* model_pred, const float* target, const float* coef, int huber,
                          float huber_c, double* loss, float* d_eps, float grad_scale, int B,
                          int per_sample, void* stream);
+/* the same with per-block fp64 partials + an ordered finalize instead of one fp64 atomic per block (workspace >= PCM_REDUCE_WS_BYTES) */
+#define PCM_REDUCE_WS_BYTES 32768
+int pcm_consistency_loss_ws(const float* model_pred, const float* target, const float* coef, int huber, float huber_c, double* loss,
+                            float* d_eps, float grad_scale, int B, int per_sample, void* workspace, size_t workspace_bytes, void* stream);
 
 /* noise_travel: scheduling_ddpm_modified.py:526-554 (fp32); sqrt_r[b] = d out / d x (optional) */
 int pcm_noise_travel(const float* x, const float* noise, const float* alphas_cumprod, const int64_t* t_cur,
@@ -342,6 +357,7 @@ int pcm_scale_add_rows(float* out, const float* x, const float* s1, const float*
 
 /* ---- optimizer (torch.optim.AdamW + clip_grad_norm_, train_pcm_lora_sd15.py:1297-1301) ---- */
 int pcm_sumsq_f32(const float* g, double* out /*1, zeroed by the call*/, long n, void* stream);
+int pcm_sumsq_f32_ws(const float* g, double* out, long n, void* workspace /* >= PCM_REDUCE_WS_BYTES */, size_t workspace_bytes, void* stream);
 int pcm_adamw_clip_step(float* p, const float* g, float* m, float* v, const double* gradsq,
                         float max_norm, float lr, float beta1, float beta2, float eps, float wd,
                         int step, float grad_scale, long n,

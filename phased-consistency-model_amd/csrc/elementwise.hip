@@ -253,7 +253,8 @@ extern "C" int pcm_geglu_bwd_interleaved(const void* pre, int ldp, const void* d
 }
 
 // ---- pixel sum: out[b][c] = sum_hw x[b][hw][c]  (fp32, zeroed here) ----
-__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* x, float* out, int HW, int C, int CVL, int ppb) {
+// part != nullptr (reproducible form): block (chunk, b, zc) stores its sums to part[chunk][b][C]; colsum_finalize_kernel adds the chunks in order
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* x, float* out, int HW, int C, int CVL, int ppb, float* part) {
   const int b = blockIdx.y, zc = blockIdx.z;
   const int cvl = threadIdx.x % CVL, pl = threadIdx.x / CVL, k = blockDim.x / CVL;
   const int c0 = (zc * CVL + cvl) * 8;
@@ -288,20 +289,50 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* x, float* out
   for (int i = threadIdx.x; i < CVL * 8; i += blockDim.x) {
     float t = 0.f;
     for (int j = 0; j < k; j++) t += red[j * CVL * 8 + i];
-    atomicAdd(&out[(size_t)b * C + zc * CVL * 8 + i], t);
+    if (part) part[((size_t)blockIdx.x * gridDim.y + b) * C + zc * CVL * 8 + i] = t;
+    else atomicAdd(&out[(size_t)b * C + zc * CVL * 8 + i], t);
   }
 }
-extern "C" int pcm_colsum_bf16(const void* x, void* out, int B, int HW, int C, void* stream) {
-  PCM_CHECK(x && out && (C % 8) == 0 && PCM_ALIGNED16(x), PCM_EALIGN, "pcm_colsum_bf16: C%%8, alignment");
+__global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* part, float* out, int chunks, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float t = 0.f;
+    for (int c = 0; c < chunks; c++) t += part[(size_t)c * n + i];
+    out[i] = t;
+  }
+}
+static void colsum_geometry(int B, int HW, int C, int* split_, int* CVL_, int* k_, int* chunks_, int* ppb_) {
   int CV = C / 8, split = 1;
   while (CV / split > 256 || (CV % split) != 0) split++;
   int CVL = CV / split, k = 256 / CVL;
   int chunks = (PCM_GRID_CAP(1024) + B * split - 1) / (B * split);
   int maxc = (HW + k - 1) / k; if (chunks > maxc) chunks = maxc; if (chunks < 1) chunks = 1;
   int ppb = (HW + chunks - 1) / chunks; chunks = (HW + ppb - 1) / ppb;
+  *split_ = split; *CVL_ = CVL; *k_ = k; *chunks_ = chunks; *ppb_ = ppb;
+}
+extern "C" int pcm_colsum_bf16(const void* x, void* out, int B, int HW, int C, void* stream) {
+  PCM_CHECK(x && out && B > 0 && HW > 0 && C > 0 && (C % 8) == 0 && PCM_ALIGNED16(x), PCM_EALIGN, "pcm_colsum_bf16: C%%8, alignment");
+  int split, CVL, k, chunks, ppb;
+  colsum_geometry(B, HW, C, &split, &CVL, &k, &chunks, &ppb);
   pcm_zero_async(out, sizeof(float) * (size_t)B * C, stream);
-  PCM_LAUNCH(colsum_kernel, dim3(chunks, B, split), dim3(CVL * k), 0, stream, (const bf16_t*)x, (float*)out, HW, C, CVL, ppb);
+  PCM_LAUNCH(colsum_kernel, dim3(chunks, B, split), dim3(CVL * k), 0, stream, (const bf16_t*)x, (float*)out, HW, C, CVL, ppb, (float*)nullptr);
   return pcm_post_launch("pcm_colsum_bf16");
+}
+extern "C" size_t pcm_colsum_workspace_bytes(int B, int HW, int C) {
+  if (B <= 0 || HW <= 0 || C <= 0 || (C % 8)) return 0;
+  int split, CVL, k, chunks, ppb;
+  colsum_geometry(B, HW, C, &split, &CVL, &k, &chunks, &ppb);
+  return sizeof(float) * (size_t)chunks * B * C;
+}
+extern "C" int pcm_colsum_bf16_ws(const void* x, void* out, int B, int HW, int C, void* workspace, size_t workspace_bytes, void* stream) {
+  PCM_CHECK(x && out && workspace && B > 0 && HW > 0 && C > 0 && (C % 8) == 0 && PCM_ALIGNED16(x), PCM_EALIGN, "pcm_colsum_bf16_ws: C%%8, alignment");
+  int split, CVL, k, chunks, ppb;
+  colsum_geometry(B, HW, C, &split, &CVL, &k, &chunks, &ppb);
+  PCM_CHECK(workspace_bytes >= sizeof(float) * (size_t)chunks * B * C, PCM_EINVAL, "pcm_colsum_bf16_ws: workspace too small");
+  PCM_LAUNCH(colsum_kernel, dim3(chunks, B, split), dim3(CVL * k), 0, stream, (const bf16_t*)x, (float*)out, HW, C, CVL, ppb, (float*)workspace);
+  const long n = (long)B * C;
+  long blocks = (n + 255) / 256; if (blocks > PCM_GRID_CAP(1024)) blocks = PCM_GRID_CAP(1024);
+  PCM_LAUNCH(colsum_finalize_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const float*)workspace, (float*)out, chunks, n);
+  return pcm_post_launch("pcm_colsum_bf16_ws");
 }
 
 // Stage n fp32 weights into LDS through a per-element index map.  The global loads are issued in batches of 8 per thread

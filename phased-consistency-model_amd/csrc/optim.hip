@@ -7,20 +7,48 @@
 #define OP_LOOP(i, n) for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (long)gridDim.x * blockDim.x)
 static inline int op_blocks(long n) { long b = (n + 255) / 256; return (int)(b > PCM_GRID_CAP(2048) ? PCM_GRID_CAP(2048) : (b < 1 ? 1 : b)); }
 
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* g, double* out, long n) {
+// part != nullptr (reproducible form): block b stores its sum to part[b]; pcm_reduce_partials_kernel adds them in order
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* g, double* out, long n, double* part) {
   __shared__ double red[4];
   double acc = 0.0;
   OP_LOOP(i, n) { double v = (double)g[i]; acc += v * v; }
   for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+  if (threadIdx.x == 0) {
+    const double t = red[0] + red[1] + red[2] + red[3];
+    if (part) part[blockIdx.x] = t; else atomicAdd(out, t);
+  }
+}
+// out[0] = scale * sum_i part[i], one block, fixed order (thread t sums i = t, t + 256, ...; then a fixed tree)
+__global__ __launch_bounds__(256) void pcm_reduce_partials_kernel(const double* part, int n, double* out, double scale) {
+  __shared__ double red[256];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) acc += part[i];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = red[0] * scale;
+}
+void pcm_reduce_partials_launch(const double* part, int n, double* out, double scale, void* stream) {
+  PCM_LAUNCH(pcm_reduce_partials_kernel, dim3(1), dim3(256), 0, stream, part, n, out, scale);
 }
 extern "C" int pcm_sumsq_f32(const float* g, double* out, long n, void* stream) {
   PCM_CHECK(g && out && n > 0, PCM_EINVAL, "pcm_sumsq_f32: null/empty");
   pcm_zero_async(out, sizeof(double), stream);
-  PCM_LAUNCH(sumsq_kernel, dim3(op_blocks(n)), dim3(256), 0, stream, g, out, n);
+  PCM_LAUNCH(sumsq_kernel, dim3(op_blocks(n)), dim3(256), 0, stream, g, out, n, (double*)nullptr);
   return pcm_post_launch("pcm_sumsq_f32");
+}
+extern "C" int pcm_sumsq_f32_ws(const float* g, double* out, long n, void* workspace, size_t workspace_bytes, void* stream) {
+  PCM_CHECK(g && out && n > 0 && workspace && ((uintptr_t)workspace % 8) == 0 && workspace_bytes >= PCM_REDUCE_WS_BYTES, PCM_EINVAL,
+            "pcm_sumsq_f32_ws: null/empty or workspace < PCM_REDUCE_WS_BYTES");
+  const int nb = op_blocks(n);          // <= 2048 partials = 16 KB
+  PCM_LAUNCH(sumsq_kernel, dim3(nb), dim3(256), 0, stream, g, out, n, (double*)workspace);
+  pcm_reduce_partials_launch((const double*)workspace, nb, out, 1.0, stream);
+  return pcm_post_launch("pcm_sumsq_f32_ws");
 }
 
 // torch.optim.AdamW single-tensor semantics; g' = g * grad_scale * min(1, max_norm/(||g*grad_scale|| + 1e-6)).

@@ -152,7 +152,7 @@ extern "C" int pcm_sampler_ddim_step(const float* eps_c, const float* eps_u, con
 
 // train_pcm_lora_sd15.py:1283-1293 + d loss / d eps of the online branch
 __global__ __launch_bounds__(256) void loss_kernel(const float* mp, const float* tg, const float* coef, int huber, float hc,
-                                                   double* loss, float* d_eps, float gscale, int B, int ps) {
+                                                   double* loss, float* d_eps, float gscale, int B, int ps, double* part) {
   __shared__ double red[4];
   long n = (long)B * ps;
   double acc = 0.0;
@@ -175,13 +175,29 @@ __global__ __launch_bounds__(256) void loss_kernel(const float* mp, const float*
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(loss, (red[0] + red[1] + red[2] + red[3]) / (double)n);
+  if (threadIdx.x == 0) {
+    if (part) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];     // reproducible form: ordered finalize (optim.hip), scaled by 1/n there
+    else atomicAdd(loss, (red[0] + red[1] + red[2] + red[3]) / (double)n);
+  }
+}
+void pcm_reduce_partials_launch(const double* part, int n, double* out, double scale, void* stream);   // optim.hip
+extern "C" int pcm_consistency_loss_ws(const float* model_pred, const float* target, const float* coef, int huber, float huber_c,
+                                       double* loss, float* d_eps, float grad_scale, int B, int per_sample, void* workspace,
+                                       size_t workspace_bytes, void* stream) {
+  PCM_CHECK(model_pred && target && loss && B > 0 && per_sample > 0 && (!d_eps || coef), PCM_EINVAL, "pcm_consistency_loss_ws: null/empty");
+  const int nb = pm_blocks((long)B * per_sample);
+  PCM_CHECK(workspace && ((uintptr_t)workspace % 8) == 0 && workspace_bytes >= PCM_REDUCE_WS_BYTES && (size_t)nb * 8 <= PCM_REDUCE_WS_BYTES,
+            PCM_EINVAL, "pcm_consistency_loss_ws: workspace < PCM_REDUCE_WS_BYTES");
+  PCM_LAUNCH(loss_kernel, dim3(nb), dim3(256), 0, stream, model_pred, target, coef, huber, huber_c, loss, d_eps, grad_scale, B, per_sample,
+             (double*)workspace);
+  pcm_reduce_partials_launch((const double*)workspace, nb, loss, 1.0 / (double)((long)B * per_sample), stream);
+  return pcm_post_launch("pcm_consistency_loss_ws");
 }
 extern "C" int pcm_consistency_loss(const float* model_pred, const float* target, const float* coef, int huber, float huber_c,
                                     double* loss, float* d_eps, float grad_scale, int B, int per_sample, void* stream) {
   PCM_CHECK(model_pred && target && loss && B > 0 && per_sample > 0 && (!d_eps || coef), PCM_EINVAL, "pcm_consistency_loss: null/empty");
   pcm_zero_async(loss, sizeof(double), stream);
-  PCM_LAUNCH(loss_kernel, dim3(pm_blocks((long)B * per_sample)), dim3(256), 0, stream, model_pred, target, coef, huber, huber_c, loss, d_eps, grad_scale, B, per_sample);
+  PCM_LAUNCH(loss_kernel, dim3(pm_blocks((long)B * per_sample)), dim3(256), 0, stream, model_pred, target, coef, huber, huber_c, loss, d_eps, grad_scale, B, per_sample, (double*)nullptr);
   return pcm_post_launch("pcm_consistency_loss");
 }
 

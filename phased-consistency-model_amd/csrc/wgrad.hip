@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void pcm_wgrad_kernel(WgDev a) {
 #pragma unroll
       for (int q = 0; q < 16; q++) {
         int r = 32 * wr + (q & 3) + 8 * (q >> 2) + 4 * hi;
-        atomicAdd(a.out + (size_t)g * a.g_stride + (size_t)r * a.r_stride, acc[q] * a.alpha);
+        wg_emit(a, (size_t)g * a.g_stride + (size_t)r * a.r_stride, blockIdx.y, g, r, acc[q] * a.alpha);
       }
     }
     return;
@@ -118,7 +118,27 @@ __global__ __launch_bounds__(256) void pcm_wgrad_kernel(WgDev a) {
     } else {
       off = (size_t)g * a.g_stride + (size_t)r * a.r_stride;
     }
-    atomicAdd(a.out + off, acc[q] * a.alpha);
+    wg_emit(a, off, blockIdx.y, g, r, acc[q] * a.alpha);
+  }
+}
+
+// reproducible form: out[off(g, r)] += sum over the M split's slabs, in split order (4 independent chains, combined in a fixed tree)
+__global__ __launch_bounds__(256) void pcm_wgrad_finalize_kernel(const float* part, int msplit, int G, float* out, long g_stride, long r_stride,
+                                                                 int out_conv, int C) {
+  const long n = (long)G * 64;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    int by = 0;
+    for (; by + 3 < msplit; by += 4) {
+#pragma unroll
+      for (int u = 0; u < 4; u++) s[u] += part[(size_t)(by + u) * n + i];
+    }
+    for (int u = 0; by < msplit; by++, u++) s[u] += part[(size_t)by * n + i];
+    const int g = (int)(i >> 6), r = (int)(i & 63);
+    size_t off;
+    if (out_conv) { const int tap = g / C, ci = g - tap * C; off = (size_t)r * 9 * C + (size_t)ci * 9 + tap; }
+    else off = (size_t)g * g_stride + (size_t)r * r_stride;
+    out[off] += (s[0] + s[1]) + (s[2] + s[3]);
   }
 }
 
@@ -139,6 +159,7 @@ static int wg_convert(const pcm_wgrad_args* p, WgDev& a) {
   a.small_ = (const bf16_t*)p->small_; a.lds_ = p->lds_; a.M = p->M; a.out = p->out; a.g_stride = p->g_stride;
   a.r_stride = p->r_stride; a.out_conv = p->out_conv; a.alpha = p->alpha;
   a.swap = (!p->out_conv && p->g_stride < p->r_stride) ? 1 : 0;
+  a.part = nullptr;
   if (p->mode == PCM_SEG_CONV3X3) {
     PCM_CHECK(p->C > 0 && (p->C % 64) == 0 && p->G == 9 * p->C && (p->M % (a.Ho * a.Wo)) == 0 && (p->stride == 1 || p->stride == 2),
               PCM_EINVAL, "pcm_lora_wgrad_bf16: conv view needs C%%64==0, G==9*C, M==B*Ho*Wo");
@@ -154,8 +175,10 @@ extern "C" int pcm_lora_wgrad_multi_bf16(const pcm_wgrad_args* list, int n, void
   PCM_CHECK(list && n > 0 && n <= 64, PCM_EINVAL, "pcm_lora_wgrad_multi_bf16: 1..64 jobs");
   WgDev jobs[64];
   unsigned char taken[64];
-  for (int i = 0; i < n; i++)
+  for (int i = 0; i < n; i++) {
     if (int rc = wg_convert(list + i, jobs[i])) return rc;
+    jobs[i].part = (float*)list[i].workspace;     // reproducible-form jobs are refused by the shared-launch planner and run as single calls
+  }
   if (int rc = pcm_wgrad_tr_launch_multi(jobs, n, taken, stream)) return rc;
   for (int i = 0; i < n; i++)
     if (!taken[i])
@@ -163,14 +186,8 @@ extern "C" int pcm_lora_wgrad_multi_bf16(const pcm_wgrad_args* list, int n, void
   return pcm_post_launch("pcm_lora_wgrad_multi_bf16");
 }
 
-extern "C" int pcm_lora_wgrad_bf16(const pcm_wgrad_args* p, void* stream) {
-  WgDev a;
-  if (int rc = wg_convert(p, a)) return rc;
-  {   // LDS-DMA + transpose-read kernels (wgrad_tr.hip) for the plain and the stride-1 3x3 views; everything else stays here
-    const int rc = pcm_wgrad_tr_launch(a, stream);
-    if (rc == 0) return pcm_post_launch("pcm_lora_wgrad_bf16");
-    if (rc < 0) return rc;
-  }
+// the M split of the register-transposing kernel (fills a.m_per_block)
+static int wg_plan_split(const pcm_wgrad_args* p, WgDev& a, int* tiles_g_out) {
   int tiles_g = (p->G + 63) / 64;
   int chunks = (p->M + 127) / 128;
   // M split.  Every block ends with 4096 fp32 atomics, i.e. msplit*G*256 B of atomic traffic against M*G*2 B of operand reads:
@@ -189,7 +206,52 @@ extern "C" int pcm_lora_wgrad_bf16(const pcm_wgrad_args* p, void* stream) {
   if (msplit > chunks) msplit = chunks;
   if (msplit < 1) msplit = 1;
   a.m_per_block = ((chunks + msplit - 1) / msplit) * 128;
-  msplit = (p->M + a.m_per_block - 1) / a.m_per_block;
-  PCM_LAUNCH(pcm_wgrad_kernel, dim3(tiles_g, msplit), dim3(256), 0, stream, a);
+  *tiles_g_out = tiles_g;
+  return (p->M + a.m_per_block - 1) / a.m_per_block;
+}
+// slabs of the reproducible form = the M split the call would take (same planner as the launch; > 0, or < 0 on error)
+static int wg_msplit(const pcm_wgrad_args* p, WgDev& a) {
+  int ms = 0;
+  const int rc = pcm_wgrad_tr_launch(a, nullptr, &ms, true);
+  if (rc < 0) return rc;
+  if (rc == 0) return ms;
+  int tg;
+  return wg_plan_split(p, a, &tg);
+}
+extern "C" size_t pcm_lora_wgrad_workspace_bytes(const pcm_wgrad_args* p) {
+  WgDev a;
+  if (wg_convert(p, a)) return 0;
+  const int ms = wg_msplit(p, a);
+  return ms > 0 ? (size_t)ms * p->G * 64 * sizeof(float) : 0;
+}
+
+extern "C" int pcm_lora_wgrad_bf16(const pcm_wgrad_args* p, void* stream) {
+  WgDev a;
+  if (int rc = wg_convert(p, a)) return rc;
+  int msplit = 0;
+  if (p->workspace) {
+    WgDev t = a;
+    msplit = wg_msplit(p, t);
+    if (msplit < 0) return msplit;
+    PCM_CHECK(((uintptr_t)p->workspace % 16) == 0 && p->workspace_bytes >= (size_t)msplit * p->G * 64 * sizeof(float), PCM_EINVAL,
+              "pcm_lora_wgrad_bf16: workspace too small (%zu < %zu)", p->workspace_bytes, (size_t)msplit * p->G * 64 * sizeof(float));
+    a.part = (float*)p->workspace;
+  }
+  auto finalize = [&]() {
+    if (!a.part) return;
+    const long n = (long)p->G * 64;
+    long blocks = (n + 255) / 256; if (blocks > PCM_GRID_CAP(1024)) blocks = PCM_GRID_CAP(1024);
+    PCM_LAUNCH(pcm_wgrad_finalize_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const float*)a.part, msplit, p->G, a.out, a.g_stride, a.r_stride,
+               a.out_conv, a.C);
+  };
+  {   // LDS-DMA + transpose-read kernels (wgrad_tr.hip) for the plain and the stride-1 3x3 views; everything else stays here
+    const int rc = pcm_wgrad_tr_launch(a, stream);
+    if (rc == 0) { finalize(); return pcm_post_launch("pcm_lora_wgrad_bf16"); }
+    if (rc < 0) return rc;
+  }
+  int tiles_g;
+  const int ms = wg_plan_split(p, a, &tiles_g);
+  PCM_LAUNCH(pcm_wgrad_kernel, dim3(tiles_g, ms), dim3(256), 0, stream, a);
+  finalize();
   return pcm_post_launch("pcm_lora_wgrad_bf16");
 }

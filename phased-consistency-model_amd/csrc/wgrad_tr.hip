@@ -111,7 +111,7 @@ __device__ __forceinline__ void pcm_wgrad_tr_body(const WG& a, const int bx, con
     for (int e = 0; e < 16; e++) {
       const int ii = (e & 3) + 8 * (e >> 2) + 4 * hi;
       const int g = g0 + 32 * wave + (SWAP ? l31 : ii), r = 32 * rt + (SWAP ? ii : l31);
-      if (g < a.G) atomicAdd(a.out + (size_t)g * a.g_stride + (size_t)r * a.r_stride, acc[rt][e] * a.alpha);
+      if (g < a.G) wg_emit(a, (size_t)g * a.g_stride + (size_t)r * a.r_stride, by, g, r, acc[rt][e] * a.alpha);
     }
 }
 template <bool SWAP>
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256) void pcm_wgrad_tr_conv_kernel(WgDev a) {
 #pragma unroll
     for (int e = 0; e < 16; e++) {
       const int r = 32 * wr + (e & 3) + 8 * (e >> 2) + 4 * hi;
-      atomicAdd(a.out + (size_t)(t * C + c) * a.g_stride + (size_t)r * a.r_stride, acc[t][e] * a.alpha);
+      wg_emit(a, (size_t)(t * C + c) * a.g_stride + (size_t)r * a.r_stride, blockIdx.y, t * C + c, r, acc[t][e] * a.alpha);
     }
 #endif
 }
@@ -276,7 +276,7 @@ extern "C" void pcm_debug_wgrad_tr_blocks(int n) { g_wgtr_auto = n <= 0; g_wgtr_
 // plain view: is it one of this file's, and how is it split?  (fills a.m_per_block; returns false -> caller falls back)
 static bool wgtr_plan_plain(WgDev& a, int* tiles_g_out, int* msplit_out) {
   if (g_wgtr_mode < 0) { const char* e = getenv("PCM_WGRAD_TR"); g_wgtr_mode = e ? atoi(e) : 1; }
-  if (!g_wgtr_mode || a.out_conv || a.mode == PCM_SEG_CONV3X3) return false;
+  if (!g_wgtr_mode || a.out_conv || a.mode == PCM_SEG_CONV3X3 || a.part) return false;     // reproducible-form jobs run one by one
   if ((size_t)a.M * a.lds_ * 2 >= 0x7ff00000u || (size_t)a.M * a.ldb * 2 >= 0x7ff00000u) return false;
   auto cdiv = [](long x, long y) { return (int)((x + y - 1) / y); };
   const int tiles_g = cdiv(a.G, 128), stages = cdiv(a.M, 64);
@@ -323,7 +323,8 @@ int pcm_wgrad_tr_launch_multi(const WgDev* jobs, int n, unsigned char* taken, vo
   return 0;
 }
 
-int pcm_wgrad_tr_launch(const WgDev& a0, void* stream) {
+// msplit_out: the M split taken (= slabs of the reproducible form); plan_only: decide and report, launch nothing
+int pcm_wgrad_tr_launch(const WgDev& a0, void* stream, int* msplit_out, bool plan_only) {
   if (g_wgtr_mode < 0) { const char* e = getenv("PCM_WGRAD_TR"); g_wgtr_mode = e ? atoi(e) : 1; }
   if (!g_wgtr_mode || a0.out_conv) return 1;
   WgDev a = a0;
@@ -344,6 +345,8 @@ int pcm_wgrad_tr_launch(const WgDev& a0, void* stream) {
     if (msplit < 1) msplit = 1;
     a.m_per_block = cdiv(stages, msplit) * 64;
     msplit = cdiv(a.M, a.m_per_block);
+    if (msplit_out) *msplit_out = msplit;
+    if (plan_only) return 0;
     const size_t smem = 2 * (64 * 256 + 64 * 128);
     if (a.swap) PCM_LAUNCH((pcm_wgrad_tr_kernel<true>), dim3(tiles_g, msplit), dim3(256), smem, stream, a);
     else PCM_LAUNCH((pcm_wgrad_tr_kernel<false>), dim3(tiles_g, msplit), dim3(256), smem, stream, a);
@@ -363,6 +366,8 @@ int pcm_wgrad_tr_launch(const WgDev& a0, void* stream) {
   if (msplit < 1) msplit = 1;
   a.m_per_block = cdiv(stages, msplit) * 64;
   msplit = cdiv(a.M, a.m_per_block);
+  if (msplit_out) *msplit_out = msplit;
+  if (plan_only) return 0;
   const size_t smem = 2 * (64 * 128 + 28 * 1024);
   static bool lds_ok = false;
   if (!lds_ok) {

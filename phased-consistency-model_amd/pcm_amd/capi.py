@@ -14,6 +14,7 @@ DEFAULT_LIB = os.path.join(HERE, "lib", "libpcm_hip.so")
 F16_LIB = os.path.join(HERE, "lib", "libpcm_hip_f16.so")      # the same sources compiled with -DPCM_ACT_F16 (pcm_amd/precision.py)
 
 PCM_BF16, PCM_F32 = 0, 1
+REDUCE_WS_BYTES = 32768     # include/pcm_hip.h PCM_REDUCE_WS_BYTES
 ACT_NONE, ACT_SILU, ACT_LEAKY, ACT_GEGLU = 0, 1, 2, 3
 SEG_PLAIN, SEG_CONV3X3 = 0, 1
 SRC_DIRECT, SRC_UPSAMPLE2, SRC_ZEROINS2 = 0, 1, 2
@@ -40,7 +41,7 @@ class WgradArgs(C.Structure):
                 ("Ws", C.c_int), ("C", C.c_int), ("stride", C.c_int), ("src_mode", C.c_int),
                 ("Ho", C.c_int), ("Wo", C.c_int), ("small_", vp), ("lds_", C.c_int), ("M", C.c_int),
                 ("out", vp), ("g_stride", C.c_long), ("r_stride", C.c_long), ("out_conv", C.c_int),
-                ("alpha", C.c_float)]
+                ("alpha", C.c_float), ("workspace", vp), ("workspace_bytes", C.c_size_t)]
 
 
 class PackDesc(C.Structure):
@@ -83,6 +84,7 @@ _PROTOS = {
     "pcm_split_channels": [vp, vp, i32, vp, i32, i64, i32, vp],
     "pcm_add_bf16": [vp, vp, vp, i64, vp],
     "pcm_colsum_bf16": [vp, vp, i32, i32, i32, vp],
+    "pcm_colsum_bf16_ws": [vp, vp, i32, i32, i32, vp, C.c_size_t, vp],
     "pcm_silu_bf16": [vp, vp, i64, vp],
     "pcm_silu_bwd_bf16": [vp, vp, vp, i64, vp],
     "pcm_conv_in_fwd": [vp, vp, vp, vp, i32, i32, i32, i32, vp],
@@ -108,7 +110,9 @@ _PROTOS = {
     "pcm_fm_sampler_step": [vp, vp, f32, vp, f32, f32, vp, vp, C.c_long, vp],
     "pcm_cfg_ddim_step": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
     "pcm_consistency_loss": [vp, vp, vp, i32, f32, vp, vp, f32, i32, i32, vp],
+    "pcm_consistency_loss_ws": [vp, vp, vp, i32, f32, vp, vp, f32, i32, i32, vp, C.c_size_t, vp],
     "pcm_sumsq_f32": [vp, vp, i64, vp],
+    "pcm_sumsq_f32_ws": [vp, vp, i64, vp, C.c_size_t, vp],
     "pcm_adamw_clip_step": [vp, vp, vp, vp, vp, f32, f32, f32, f32, f32, f32, i32, f32, i64, vp, vp, vp],
     "pcm_adamw_clip_step_scaled": [vp, vp, vp, vp, vp, f32, f32, f32, f32, f32, f32, f32, i64, vp, vp, vp, vp],
     "pcm_loss_scale_update": [vp, vp, vp, vp, f32, f32, i32, vp],
@@ -153,6 +157,10 @@ class Lib:
         self.dll.pcm_attn_workspace_bytes.argtypes = [C.c_int] * 6
         self.dll.pcm_groupnorm_workspace_bytes.restype = C.c_size_t
         self.dll.pcm_groupnorm_workspace_bytes.argtypes = [C.c_int] * 4
+        self.dll.pcm_lora_wgrad_workspace_bytes.restype = C.c_size_t
+        self.dll.pcm_lora_wgrad_workspace_bytes.argtypes = [C.POINTER(WgradArgs)]
+        self.dll.pcm_colsum_workspace_bytes.restype = C.c_size_t
+        self.dll.pcm_colsum_workspace_bytes.argtypes = [C.c_int] * 3
         self.fn = {}
         for name, argt in _PROTOS.items():
             f = getattr(self.dll, name, None)

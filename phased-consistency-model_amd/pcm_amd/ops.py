@@ -13,6 +13,32 @@ from .precision import act_dtype as _act_dtype  # noqa: E402
 BF16 = _act_dtype()      # the library's 16-bit dtype: bfloat16, or float16 after precision.set_precision("fp16") (which rebinds this name)
 GEMM_PROFILE = None  # set to a list by bench.py to time every pcm_gemm_bf16 launch
 
+# Reproducible reductions (include/pcm_hip.h, abi >= 4).  The fast forms of the cross-workgroup sums -- LoRA weight gradients (fp32 atomics),
+# GroupNorm statistics / gradient norm / loss (fp64 atomics), the time-embedding pixel sums (fp32 atomics) -- add their partial sums in
+# whatever order the workgroups finish: the last bits of a step change run to run, as cuDNN / cuBLAS do for the reference unless
+# torch.use_deterministic_algorithms(True) is set.  set_deterministic(True) is that switch here: every such sum goes through per-workgroup
+# partials in a caller-owned workspace and an ordered finalize launch -- bitwise identical steps run to run, ~1-2 % slower.
+DETERMINISTIC = False
+_DET_WS = {}
+
+
+def set_deterministic(on=True):
+    global DETERMINISTIC
+    DETERMINISTIC = bool(on)
+    if not on:
+        _DET_WS.clear()
+
+
+def _det_ws(device, nbytes, key="ws"):
+    """stream-ordered scratch of the reproducible forms: one growing buffer per (device, key); a call's finalize has consumed it before
+    the next call on the same stream writes it"""
+    k = (str(device), key)
+    t = _DET_WS.get(k)
+    if t is None or t.numel() < nbytes:
+        t = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _DET_WS[k] = t
+    return t
+
 
 def _chk(t, dtype=None):
     assert t.is_contiguous(), "pcm_amd.ops: tensor must be contiguous"
@@ -113,7 +139,7 @@ class StatArena:
     @classmethod
     def for_pass(cls, device, W, B, G):
         """arena for one UNet pass over batch B (None when the partials form is used instead)."""
-        if B < GN_ATOMIC_MIN_BATCH:
+        if B < GN_ATOMIC_MIN_BATCH or DETERMINISTIC:
             return None
         return cls(device, slots=sum(1 for k in W.norms if "transformer_blocks" not in k) + 2, per_slot=B * G * 2)
 
@@ -256,6 +282,11 @@ def colsum(x):
     """x [B, HW, C] bf16 -> fp32 [B, C]"""
     B, HW, Cc = x.shape
     out = torch.empty(B, Cc, dtype=torch.float32, device=x.device)
+    if DETERMINISTIC:
+        n = capi.lib().dll.pcm_colsum_workspace_bytes(B, HW, Cc)
+        ws = _det_ws(x.device, n)
+        capi.lib().call("pcm_colsum_bf16_ws", ptr(x), ptr(out), B, HW, Cc, ptr(ws), n, _stream())
+        return out
     capi.lib().call("pcm_colsum_bf16", ptr(x), ptr(out), B, HW, Cc, _stream())
     return out
 
@@ -417,6 +448,11 @@ def consistency_loss(model_pred, target, coef, huber, huber_c, grad_scale=1.0, w
     B = model_pred.shape[0]
     loss = torch.empty(1, dtype=torch.float64, device=model_pred.device)
     d_eps = torch.empty_like(model_pred) if want_grad else None
+    if DETERMINISTIC:
+        ws = _det_ws(model_pred.device, capi.REDUCE_WS_BYTES, "reduce")
+        capi.lib().call("pcm_consistency_loss_ws", ptr(model_pred), ptr(target), ptr(coef), 1 if huber else 0, huber_c,
+                        ptr(loss), ptr(d_eps), grad_scale, B, model_pred.numel() // B, ptr(ws), capi.REDUCE_WS_BYTES, _stream())
+        return loss, d_eps
     capi.lib().call("pcm_consistency_loss", ptr(model_pred), ptr(target), ptr(coef), 1 if huber else 0, huber_c,
                     ptr(loss), ptr(d_eps), grad_scale, B, model_pred.numel() // B, _stream())
     return loss, d_eps
@@ -425,6 +461,10 @@ def consistency_loss(model_pred, target, coef, huber, huber_c, grad_scale=1.0, w
 # ---- optimizer ----
 def sumsq(g, out=None):
     out = out if out is not None else torch.empty(1, dtype=torch.float64, device=g.device)
+    if DETERMINISTIC:
+        ws = _det_ws(g.device, capi.REDUCE_WS_BYTES, "reduce")
+        capi.lib().call("pcm_sumsq_f32_ws", ptr(g), ptr(out), g.numel(), ptr(ws), capi.REDUCE_WS_BYTES, _stream())
+        return out
     capi.lib().call("pcm_sumsq_f32", ptr(g), ptr(out), g.numel(), _stream())
     return out
 
@@ -456,7 +496,7 @@ def ema_update(target, source, rate):
 
 
 def lora_wgrad(big, small, out, alpha, M, G=None, conv=None, g_stride=None, r_stride=None, out_conv=False, ldb=None, lds=None):
-    """out[g][r] += alpha * sum_m Big[m][g] * Small[m][r]  (fp32 atomics into ``out``).
+    """out[g][r] += alpha * sum_m Big[m][g] * Small[m][r]  (fp32 atomics into ``out``; slabs + ordered finalize under set_deterministic).
     plain: big [M, G]; conv: big NHWC with conv=dict(Hs, Ws, Ho, Wo, stride=1, src_mode=0)."""
     a = WgradArgs()
     a.big, a.small_, a.out = ptr(big), ptr(small), ptr(out)
@@ -478,8 +518,15 @@ def lora_wgrad(big, small, out, alpha, M, G=None, conv=None, g_stride=None, r_st
     a.g_stride = g_stride if g_stride is not None else 0
     a.r_stride = r_stride if r_stride is not None else 0
     a.out_conv = 1 if out_conv else 0
+    a.workspace, a.workspace_bytes = None, 0
+    ws = None
+    if DETERMINISTIC:        # per-block slabs + ordered finalize instead of fp32 atomics (the jobs of a batch then run one by one)
+        n = capi.lib().dll.pcm_lora_wgrad_workspace_bytes(C.byref(a))
+        assert n > 0, "pcm_lora_wgrad_workspace_bytes: bad arguments"
+        ws = _det_ws(out.device, n)
+        a.workspace, a.workspace_bytes = ptr(ws), ws.numel()
     if _WG_BATCH is not None:
-        _WG_BATCH.append((a, big, small))      # the tensors stay referenced until the batch is launched
+        _WG_BATCH.append((a, big, small, ws))  # the tensors stay referenced until the batch is launched
         return
     capi.lib().call("pcm_lora_wgrad_bf16", C.byref(a), _stream())
 

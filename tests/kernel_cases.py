@@ -301,6 +301,64 @@ def case_wgrad_dense(dev, B, H, W, Cin, Cout, alpha=1.0, prefill=True):
     close(dW.cpu() - pre, ref, 2e-3, 2e-3 * M ** 0.5 * alpha, "dense conv3x3 wgrad %s" % ((B, H, W, Cin, Cout),))
 
 
+def case_reproducible_reductions(dev, big=False):
+    """The reproducible forms (include/pcm_hip.h abi 4; ops.set_deterministic): every cross-workgroup sum through per-workgroup partials +
+    an ordered finalize.  (1) the existing parity cases hold with the switch on, (2) the results agree with the atomic forms to summation
+    rounding, (3) accumulation into a PRE-FILLED gradient buffer (the finalize adds, it does not overwrite), (4) two runs are BITWISE equal
+    (on the GPU the atomic forms are not: that is what the switch is for)."""
+    from pcm_amd.model import BF16  # noqa: F401
+    sizes = dict(M=40000, N=640, K=320, B=4, H=32, C=128) if big else dict(M=700, N=200, K=136, B=2, H=8, C=64)
+    M, N, Kk, B, Hs, C = (sizes[k] for k in ("M", "N", "K", "B", "H", "C"))
+
+    def run_all():
+        out = {}
+        dy, t, x, u = rnd(M, N, seed=1, dev=dev), rnd(M, 64, seed=2, dev=dev), rnd(M, Kk, seed=3, dev=dev), rnd(M, 64, seed=4, dev=dev)
+        dB = torch.full((N, 64), 0.25, dtype=torch.float32, device=dev)
+        dA = torch.full((64, Kk), -0.5, dtype=torch.float32, device=dev)
+        with ops.wgrad_batch():
+            ops.lora_wgrad(dy, t, dB, 0.125, M, g_stride=64, r_stride=1)
+            ops.lora_wgrad(x, u, dA, 0.125, M, g_stride=1, r_stride=Kk)
+        out["dB"], out["dA"] = dB, dA
+        xc, uc = rnd(B, Hs, Hs, C, seed=5, dev=dev), rnd(B * Hs * Hs, 64, seed=6, dev=dev)
+        geo = dict(Hs=Hs, Ws=Hs, Ho=Hs, Wo=Hs)
+        dAc = torch.full((64, 3, 3, C), 1.0, dtype=torch.float32, device=dev)
+        ops.lora_wgrad(xc, uc, dAc, 1.0, B * Hs * Hs, conv=geo, g_stride=1, r_stride=9 * C)           # transpose-read 3x3 kernel (M >= 4096) or wgrad.hip
+        dAp = torch.zeros(64, C, 3, 3, dtype=torch.float32, device=dev)
+        ops.lora_wgrad(xc, uc, dAp, 1.0, B * Hs * Hs, conv=geo, out_conv=True)                         # peft layout: register-transposing kernel
+        out["dA_conv"], out["dA_conv_peft"] = dAc, dAp
+        out["colsum"] = ops.colsum(rnd(B, Hs * Hs, 4 * C, seed=7, dev=dev))
+        g = rnd(300001 if big else 5001, seed=8, dev=dev, dtype=torch.float32)
+        out["sumsq"] = ops.sumsq(g).clone()
+        mp, tg = rnd(B, 4, Hs, Hs, seed=9, dev=dev, dtype=torch.float32), rnd(B, 4, Hs, Hs, seed=10, dev=dev, dtype=torch.float32)
+        coef = torch.ones(B, dtype=torch.float32, device=dev)
+        loss, d_eps = ops.consistency_loss(mp, tg, coef, True, 1e-3)
+        out["loss"], out["d_eps"] = loss.clone(), d_eps
+        xg = rnd(B, Hs * Hs, 4 * C, seed=11, dev=dev)
+        gam, bet = rnd(4 * C, seed=12, dtype=torch.float32, dev=dev), rnd(4 * C, seed=13, dtype=torch.float32, dev=dev)
+        y, st = ops.groupnorm_fwd(xg, gam, bet, 32, 1e-5, 1)
+        out["gn_y"], out["gn_stats"] = y, st.clone()
+        out["gn_dx"] = ops.groupnorm_bwd(xg, rnd(B, Hs * Hs, 4 * C, seed=14, dev=dev), st, gam, bet, 32, 1e-5, 1)
+        return {k: v.detach().cpu().clone() for k, v in out.items()}
+
+    assert not ops.DETERMINISTIC
+    fast = run_all()
+    ops.set_deterministic(True)
+    try:
+        det1, det2 = run_all(), run_all()
+        case_wgrad_plain(dev, 333, 200, 136)
+        case_wgrad_multi(dev)
+        case_wgrad_conv(dev, 2, 6, 5, 64, 2)
+        case_optim(dev)
+    finally:
+        ops.set_deterministic(False)
+    for k in fast:
+        assert torch.equal(det1[k], det2[k]), "reproducible form of %s differs between two runs" % k
+        a, b = det1[k].double(), fast[k].double()
+        tol = 1e-12 if a.dtype == torch.float64 and k in ("sumsq", "loss", "gn_stats") else 2e-5
+        assert float((a - b).abs().max()) <= tol * max(1.0, float(b.abs().max())) + (1e-2 if k in ("gn_y", "gn_dx") else 0.0), \
+            (k, float((a - b).abs().max()), float(b.abs().max()))
+
+
 def case_attention(dev, B, H, Lq, Lk, d, spike=False, spike_at=None):
     q = rnd(B, Lq, H * d, seed=1, dev=dev)
     k = rnd(B, Lk, H * d, seed=2, dev=dev)

@@ -104,6 +104,26 @@ def test_wgrad_dense_conv3x3_rejects_unsupported_geometry():
     assert not ops.conv3x3_wgrad_ok(6, 8, 64, 64) and not ops.conv3x3_wgrad_ok(8, 8, 64, 96)
 
 
+def test_reproducible_reduction_forms():
+    """ops.set_deterministic: slabs / partials + ordered finalize instead of fp32 / fp64 atomics (the emulator runs workgroups serially, so
+    the bitwise run-to-run half of the case is trivially true here; the GPU test is the one that can fail on it)"""
+    K.case_reproducible_reductions("cpu")
+
+
+def test_reproducible_wgrad_refuses_a_short_workspace():
+    a = capi.WgradArgs()
+    big, small = torch.zeros(256, 64, dtype=ops.BF16), torch.zeros(256, 64, dtype=ops.BF16)
+    out, ws = torch.zeros(64, 64), torch.zeros(16)
+    a.big, a.small_, a.out = capi.ptr(big), capi.ptr(small), capi.ptr(out)
+    a.ldb, a.G, a.mode, a.lds_, a.M, a.g_stride, a.r_stride, a.alpha = 64, 64, capi.SEG_PLAIN, 64, 256, 64, 1, 1.0
+    a.stride = 1
+    need = capi.lib().dll.pcm_lora_wgrad_workspace_bytes(ctypes.byref(a))
+    assert need >= 64 * 64 * 4
+    a.workspace, a.workspace_bytes = capi.ptr(ws), ws.numel() * 4
+    with pytest.raises(capi.PcmError, match="workspace too small"):
+        capi.lib().call("pcm_lora_wgrad_bf16", ctypes.byref(a), capi.Lib.stream())
+
+
 def test_wgrad_multi_job_launch():
     import ctypes
     from pcm_amd import capi

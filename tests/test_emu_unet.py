@@ -284,3 +284,37 @@ def test_teacher_shared_prefix_equals_plain_2b_pass():
         ea, eb = rel(a, ref), rel(b, ref)
         assert eb <= 1.2 * ea + 1e-3 and rel(a, b) <= 1.5 * max(ea, eb), (B, ea, eb, rel(a, b))
         assert rel(a[:B], a[B:]) > 0.1, B        # the text conditioning is live
+
+
+def test_deterministic_step_equals_the_atomic_step_to_rounding():
+    """ops.set_deterministic(True) (slab / partial reductions, include/pcm_hip.h abi 4) through a whole Distiller step on the tiny SD1.5
+    topology: same loss, same LoRA gradients and gradient norm to summation rounding as the atomic forms, and bitwise the same twice.
+    (The GPU run of the same property at the real size is tests/test_gpu_step.py::test_deterministic_step_is_bitwise_reproducible.)"""
+    from oracle import pcm_step as OS
+    from oracle import unet_sd15 as O
+    from pcm_amd import ops
+    from pcm_amd.model import LoraState, UNetWeights
+    from pcm_amd.trainer import Distiller, StepConfig
+    oc, pc = tiny_cfgs()
+    sd = O.init_state_dict(oc, 0)
+    W = UNetWeights(pc, sd, "cpu")
+    ocfg = OS.StepConfig(multiphase=2, loss_type="huber", w_min=4.0, w_max=5.0)
+    inp = OS.draw_inputs(2, ocfg, seed=7, latent_hw=8, ctx_len=7, ctx_dim=64)
+    cfg = StepConfig(multiphase=2, loss_type="huber", w_min=4.0, w_max=5.0)
+
+    def one(det):
+        lora = LoraState(pc, 64, 8.0, "cpu", seed=1, b_std=0.05)
+        D = Distiller(W, lora, cfg)
+        ops.set_deterministic(det)
+        try:
+            out = D.step(inp["latents"], inp["prompt_embeds"], inp["uncond_prompt_embeds"], inp["noise"], inp["index"], inp["w"])
+        finally:
+            ops.set_deterministic(False)
+        return float(out["loss"]), lora.grads.clone(), float(lora.gradsq), lora.params.clone()
+
+    l0, g0, q0, p0 = one(False)
+    l1, g1, q1, p1 = one(True)
+    l2, g2, q2, p2 = one(True)
+    assert l1 == l2 and q1 == q2 and torch.equal(g1, g2) and torch.equal(p1, p2)
+    assert abs(l1 - l0) <= 1e-6 * abs(l0) and abs(q1 - q0) <= 1e-4 * q0
+    assert float((g1 - g0).norm() / g0.norm()) < 1e-4

@@ -243,7 +243,8 @@ def test_c2_as_benchmarked_vs_oracle():
     assert rep["lora_grad"]["rel_vs_matched"] <= 1.5 * ref["grad_m32_vs_fp32"] + 5e-3, rep["lora_grad"]
 
 
-def test_loss_curve_20_steps_real_size_vs_oracle():
+@pytest.mark.parametrize("deterministic", [False, True])
+def test_loss_curve_20_steps_real_size_vs_oracle(deterministic):
     """north_star: 'loss curves matching reference to 1e-3 rel' (sd15.py:1283-1301) -- 20 consecutive optimizer steps at the REAL SD1.5 size:
     bs 2, 2 phases, the recipe's lr 5e-6 / weight decay, LoRA B = 0 as the reference starts, fresh seeded inputs every step.  The oracle side
     (tests/golden/step_sd15_curve20_bs2.safetensors, tests/step_golden_cases.py::ref_curve20) holds per step the fp32 oracle's loss along
@@ -267,9 +268,14 @@ def test_loss_curve_20_steps_real_size_vs_oracle():
     _, scfg = S.step_cfgs(2)
     D = Distiller(W, lora, scfg)
     rows = []
+    from pcm_amd import ops
     for step in range(1, S.CURVE_STEPS + 1):
         inp = {k: v.cuda() for k, v in S.curve_inputs(step).items()}
-        out = D.step(inp["latents"], inp["prompt_embeds"], inp["uncond_prompt_embeds"], inp["noise"], inp["index"], inp["w"])
+        ops.set_deterministic(deterministic)        # reproducible reductions (ops.set_deterministic): the statistic below is then ONE number
+        try:
+            out = D.step(inp["latents"], inp["prompt_embeds"], inp["uncond_prompt_embeds"], inp["noise"], inp["index"], inp["w"])
+        finally:
+            ops.set_deterministic(False)
         assert out["timesteps"].tolist() == ref["timesteps"][step - 1] and out["end_timesteps"].tolist() == ref["end_timesteps"][step - 1]
         lh, lf, lm, l16 = float(out["loss"].item()), ref["fp32"][step - 1], ref["matched"][step - 1], ref["bf16_autocast"][step - 1]
         rows.append(dict(step=step, hip=lh, oracle_fp32=lf, matched=lm, ref_bf16_autocast=l16, hip_vs_matched=(lh - lm) / lm,
@@ -289,7 +295,7 @@ def test_loss_curve_20_steps_real_size_vs_oracle():
         print("step %2d  fp32 %.6f  matched %+.2e  ref-bf16 %+.2e  hip-vs-fp32 %+.2e  hip-vs-matched %+.2e" %
               (r["step"], r["oracle_fp32"], (r["matched"] - r["oracle_fp32"]) / r["oracle_fp32"], r["ref_bf16_vs_fp32"], r["hip_vs_fp32"], r["hip_vs_matched"]))
     os.makedirs("gpurun_out", exist_ok=True)
-    json.dump(rep, open("gpurun_out/loss_curve_20_real_size.json", "w"), indent=1)
+    json.dump(rep, open("gpurun_out/loss_curve_20_real_size%s.json" % ("_deterministic" if deterministic else ""), "w"), indent=1)
     assert all(math.isfinite(r["hip"]) for r in rows)
     # the north-star number, against the oracle that rounds where the HIP path does.  The statistic is NOT deterministic: the LoRA gradients are fp32
     # atomics, their summation order changes from run to run, the updated parameters differ in their last bits and the bf16 trajectory amplifies
@@ -297,7 +303,11 @@ def test_loss_curve_20_steps_real_size_vs_oracle():
     # 0.91 +- 0.10 e-3 around the matched oracle's OWN fp64-vs-fp32 floor of 0.86e-3.  A bound of exactly 1e-3 on that is a coin with a 20 % red
     # side; the per-run assertion is 1.5 x the oracle's floor (1.29e-3, 3.8 sigma), the mean over runs is what meets 1e-3.  The half build's curve
     # (tests/test_gpu_fp16.py) asserts 1e-3 against the PLAIN fp32 oracle with a factor of 8 to spare.
-    assert rep["mean_abs_hip_vs_matched"] <= max(1e-3, 1.5 * rep["matched_floor_mean_of_3"]), rep
+    # With the reproducible reductions the statistic is one number per build (same bits every run): the hard north-star bound holds on it.
+    if deterministic:
+        assert rep["mean_abs_hip_vs_matched"] <= 1e-3, rep
+    else:
+        assert rep["mean_abs_hip_vs_matched"] <= max(1e-3, 1.5 * rep["matched_floor_mean_of_3"]), rep
     assert rep["last5_hip_vs_matched"] <= rep["first5_hip_vs_matched"] + 1e-3, rep      # does not compound over optimizer updates
     assert rep["mean_abs_hip_vs_fp32"] <= rep["mean_abs_ref_bf16_autocast_vs_fp32"] + 1e-3, rep
     assert rep["last5_hip_vs_fp32"] <= rep["first5_hip_vs_fp32"] + 3e-3, rep

@@ -69,6 +69,12 @@ def test_wgrad_plain(M, N, K_):
     K.case_wgrad_plain("cuda", M, N, K_)
 
 
+def test_reproducible_reduction_forms_bitwise_run_to_run():
+    """ops.set_deterministic at step-like sizes: the slab / partial forms agree with the atomic forms to summation rounding and two runs are
+    bitwise equal (LoRA weight gradients, GroupNorm statistics, pixel sums, gradient norm, loss)"""
+    K.case_reproducible_reductions("cuda", big=True)
+
+
 def test_wgrad_multi_job_launch():
     K.case_wgrad_multi("cuda")
 

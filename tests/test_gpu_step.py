@@ -81,3 +81,40 @@ def test_full_step_vs_oracle(setup, b_std):
     assert report["loss_rel"] < 9e-3
     assert report["grad_rel"] < 6e-2 and report["grad_norm_rel"] < 0.02
     assert report["param_rel"] < 2e-4 and report["update_cos"] > 0.94
+
+
+def test_deterministic_step_is_bitwise_reproducible(setup):
+    """ops.set_deterministic(True): the LoRA weight gradients / GroupNorm statistics / pixel sums / gradient norm / loss go through slabs
+    or partials + an ordered finalize (include/pcm_hip.h abi 4) instead of fp32 / fp64 atomics.  At the real SD1.5 size: three optimizer
+    steps run twice from the same state are BITWISE equal in loss, gradient norm, gradients and updated parameters; against the atomic
+    forms they agree to summation rounding.  (With the atomic forms the same comparison differs in the last bits on every run:
+    profiles/r04_zk_loss_curve_run_to_run_spread.txt.)"""
+    import step_golden_cases as S
+    from pcm_amd import ops
+    from pcm_amd.model import LoraState
+    from pcm_amd.trainer import Distiller
+    from pcm_amd.unet_spec import UNetConfig
+    oc, sd, W = setup
+    _, cfg = S.step_cfgs(2)
+
+    def run(det, steps=3):
+        lora = LoraState(UNetConfig.sd15(), 64, 8.0, "cuda", seed=1, b_std=0.02)
+        D = Distiller(W, lora, cfg)
+        ops.set_deterministic(det)
+        losses, norms = [], []
+        try:
+            for step in range(1, steps + 1):
+                inp = {k: v.cuda() for k, v in S.curve_inputs(step).items()}
+                out = D.step(inp["latents"], inp["prompt_embeds"], inp["uncond_prompt_embeds"], inp["noise"], inp["index"], inp["w"])
+                losses.append(float(out["loss"].item())); norms.append(float(lora.gradsq.item()))
+            torch.cuda.synchronize()
+        finally:
+            ops.set_deterministic(False)
+        return losses, norms, lora.grads.clone(), lora.params.clone()
+
+    la, na, ga, pa = run(True)
+    lb, nb, gb, pb = run(True)
+    assert la == lb and na == nb, (la, lb, na, nb)
+    assert torch.equal(ga, gb) and torch.equal(pa, pb)
+    lf, nf, gf, pf = run(False, steps=1)
+    assert abs(lf[0] - la[0]) <= 1e-6 * abs(la[0]) and abs(nf[0] - na[0]) <= 1e-4 * na[0], (lf, la, nf, na)
