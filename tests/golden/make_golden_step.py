@@ -35,6 +35,8 @@ def registry():
         "sd15_curve20_bs2": S.ref_curve20,
         "sdxl_fullsize_one_sample": S.ref_sdxl_one_sample,
         "sd3_fullsize_one_sample": S.ref_sd3_one_sample,
+        "sdxl_fullsize_step_one_sample": S.ref_sdxl_step_fullsize,
+        "sd3_fullsize_step_one_sample": S.ref_sd3_step_fullsize,
     }
     for gs in (0, 1):
         reg["sd15_adv_c3_bs2_step%d" % gs] = (lambda gs=gs: A.ref_adv_c3(S.SD15_KW, ADAPTER_DIMS, 2, 64, 77, 768, gs, nh=4, index=[30, 12]))

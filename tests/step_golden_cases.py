@@ -286,3 +286,110 @@ def ref_sd3_one_sample():
         ref_t = O.mmdit_forward(oc, sd, x, t, ctx, pooled)
         ref_s = O.mmdit_forward(oc, sd, x, t, ctx, pooled, olora, 8.0)
     return dict(teacher=ref_t, student=ref_s, oracle_seconds=time.time() - t0)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# SDXL / SD3-medium at their real sizes: ONE WHOLE distillation step of one sample -- forward tensors, loss, LoRA gradients, AdamW
+# update (train_pcm_lora_sdxl_adv.py:1358-1480 consistency branch; train_pcm_lora_sd3.py:1270-1390)
+# ---------------------------------------------------------------------------------------------------------------------------------
+SDXL_STEP_KEYS = ("noise_pred", "cond_teacher_output", "uncond_teacher_output", "x_prev", "target_noise_pred", "model_pred", "target")
+SD3_STEP_KEYS = ("model_output", "cond_teacher_output", "uncond_teacher_output", "x_prev", "target_pred", "model_pred", "target")
+
+
+def sdxl_step_cfgs():
+    """the SDXL recipe's step: 4 phases over 40 DDIM steps, w in [6, 7], huber, lr 2e-6 (train_pcm_lora_sdxl_adv.sh)"""
+    from oracle import pcm_step as OS
+    from pcm_amd.trainer import StepConfig
+    kw = dict(multiphase=4, loss_type="huber", w_min=6.0, w_max=7.0, num_ddim_timesteps=40, adam_weight_decay=0.0)
+    return OS.StepConfig(lr=2e-6, **kw), StepConfig(learning_rate=2e-6, **kw)
+
+
+def sdxl_step_inputs():
+    from oracle import pcm_step as OS
+    ocfg, _ = sdxl_step_cfgs()
+    inp = OS.draw_inputs(1, ocfg, seed=31, latent_hw=128, ctx_len=77, ctx_dim=2048)
+    inp["index"] = torch.tensor([23])
+    g = torch.Generator().manual_seed(32)
+    tids = torch.tensor([[1024, 1024, 0, 0, 1024, 1024]])
+    inp["added_cond"] = dict(text_embeds=torch.randn(1, 1280, generator=g), time_ids=tids)
+    inp["uncond_added_cond"] = dict(text_embeds=torch.zeros(1, 1280), time_ids=tids)          # sdxl_adv.py:1216-1221
+    return inp
+
+
+def ref_sdxl_step_fullsize():
+    from oracle import pcm_step as OS
+    from oracle import unet_sd15 as O
+    from pcm_amd.unet_spec import UNetConfig, random_state_dict
+    cfg = UNetConfig.sdxl()
+    sd = random_state_dict(cfg, 0, "cpu")
+    ocfg, _ = sdxl_step_cfgs()
+    inp = sdxl_step_inputs()
+    lora = _cpu_lora(cfg, 3, 0.02)
+    olora = olora_of(lora)
+    p_before = lora_flat(lora, "p")
+    t0 = time.time()
+    ref = OS.distill_step(O.UNetConfig.sdxl(), sd, olora, inp, ocfg, {}, 1)
+    secs = time.time() - t0
+    print("SDXL full-size oracle step %.1f s" % secs, flush=True)
+    out = {k: ref[k] for k in TS + ("noisy_model_input",) + SDXL_STEP_KEYS}
+    out["loss"], out["grad_norm"], out["oracle_seconds"] = float(ref["loss"]), float(ref["grad_norm"]), secs
+    coef = min(1.0, 1.0 / (out["grad_norm"] + 1e-6))
+    out["sk_grad"] = sketch_cat(ref["grads"]) / coef                       # the oracle's gradients are post-clip: undo
+    p_after = torch.cat([t.reshape(-1) for ab in olora.values() for t in ab])
+    out["sk_param_before"], out["sk_param_after"], out["sk_update"] = sketch(p_before), sketch(p_after), sketch(p_after - p_before)
+    return out
+
+
+def sd3_step_inputs():
+    g = torch.Generator().manual_seed(41)
+    x0, noise = torch.randn(1, 16, 128, 128, generator=g), torch.randn(1, 16, 128, 128, generator=g)
+    pe, upe = torch.randn(1, 154, 4096, generator=g), torch.randn(1, 154, 4096, generator=g)
+    pp, upp = torch.randn(1, 2048, generator=g), torch.randn(1, 2048, generator=g)
+    return x0, pe, pp, upe, upp, noise, torch.tensor([29])
+
+
+def sd3_lora_flat(lora, which, rank=32):
+    """flat LoRA parameters / gradients of the MMDiT in the oracle's order (A [r, K], B [N, r] of the live ranks), on the CPU"""
+    out = []
+    for m in lora.modules.values():
+        a, b = (m.A, m.B) if which == "p" else (m.gA, m.gB)
+        out += [a[:rank].detach().cpu().reshape(-1), b[:, :rank].detach().cpu().reshape(-1)]
+    return torch.cat(out)
+
+
+def ref_sd3_step_fullsize():
+    """SD3-medium, 2-step deterministic recipe (BASELINE configs[4]: multiphase 2), one sample: forward tensors, loss, LoRA gradients and the
+    AdamW update (torch.optim.AdamW semantics: oracle/pcm_step.adamw_step, lr 5e-6, weight decay 1e-2, clip 1.0)"""
+    from oracle import mmdit_sd3 as O
+    from oracle import pcm_step as OSD
+    from oracle import pcm_step_sd3 as OS
+    from pcm_amd.mmdit import sd3_lora_state
+    from pcm_amd.mmdit_spec import MMDiTConfig, random_state_dict
+    cfg = MMDiTConfig.sd3_medium()
+    sd = random_state_dict(cfg, 0, "cpu")
+    with cpu_capi():
+        lora = sd3_lora_state(cfg, 32, 8.0, "cpu", seed=3, b_std=0.05)
+    olora = {p: (m.A[:32].detach().cpu().clone().requires_grad_(True), m.B[:, :32].detach().cpu().clone().requires_grad_(True))
+             for p, m in lora.modules.items()}
+    p_before = sd3_lora_flat(lora, "p")
+    a = sd3_step_inputs()
+    t0 = time.time()
+    ref = OS.distill_step_sd3(O.MMDiTConfig.sd3_medium(), sd, olora, *a, multiphase=2)
+    ref["loss"].backward()
+    secs = time.time() - t0
+    print("SD3-medium full-size oracle step %.1f s" % secs, flush=True)
+    leaves = [t for ab in olora.values() for t in ab]
+    grads = [torch.zeros_like(l) if l.grad is None else l.grad.detach().clone() for l in leaves]
+    out = {k: ref[k].detach() for k in ("noisy_model_input",) + SD3_STEP_KEYS}
+    out["end_index"] = ref["end_index"]
+    out["loss"], out["oracle_seconds"] = float(ref["loss"].detach()), secs
+    out["sk_grad"] = sketch_cat(grads)
+    out["grad_norm"] = float(torch.cat([g.reshape(-1) for g in grads]).double().norm())
+    scfg = OSD.StepConfig(lr=5e-6, adam_weight_decay=1e-2)
+    OSD.clip_grad_norm_(grads, scfg.max_grad_norm)
+    params = [l.detach() for l in leaves]
+    with torch.no_grad():
+        OSD.adamw_step(params, grads, {}, 1, scfg)
+    p_after = torch.cat([p.reshape(-1) for p in params])
+    out["sk_param_before"], out["sk_param_after"], out["sk_update"] = sketch(p_before), sketch(p_after), sketch(p_after - p_before)
+    return out

@@ -20,6 +20,7 @@ def test_sdxl_full_size_properties():
     del sd
     torch.cuda.empty_cache()
     _oracle_parity_one_sample(cfg, W, dev)
+    _oracle_parity_whole_step(cfg, W, dev)
     lora = LoraState(cfg, 64, 8.0, dev, seed=1)                                  # B = 0 (peft init)
     g = torch.Generator(device=dev).manual_seed(0)
     r = lambda *s: torch.randn(*s, generator=g, device=dev)   # noqa: E731
@@ -70,3 +71,54 @@ def _oracle_parity_one_sample(cfg, W, dev):
     json.dump(rep, open("gpurun_out/sdxl_fullsize_oracle_parity.json", "w"), indent=1)
     assert rep["teacher_eps_rel_l2"] < 1.5e-2 and rep["student_eps_rel_l2"] < 1.5e-2, rep
     assert rep["lora_effect_rel"] > 3 * rep["student_eps_rel_l2"], rep           # the LoRA branch is visible above the error
+
+
+def _oracle_parity_whole_step(cfg, W, dev):
+    """ONE WHOLE distillation step of one sample at the real SDXL size against the fp32 oracle (train_pcm_lora_sdxl_adv.py:1358-1480, the
+    consistency branch: student forward with LoRA, teacher cond / uncond, CFG solver step over 40 DDIM steps, target forward, 4-phase jump,
+    huber loss, LoRA-only backward, clip, AdamW): forward tensors, loss, the 2 x 743 LoRA gradient tensors through their count-sketch, the
+    gradient norm and the AdamW update.  Oracle side: tests/golden/step_sdxl_fullsize_step_one_sample.safetensors
+    (tests/step_golden_cases.py::ref_sdxl_step_fullsize).  Bounds: the SD1.5-size bounds of tests/test_gpu_step.py scaled for the ~3x
+    deeper transformer stack (the forward bound of _oracle_parity_one_sample, 1.5e-2)."""
+    import json
+    import math
+    import os
+    import step_golden_cases as S
+    from golden_fixture import golden, sk_cos, sk_rel, sketch
+    from pcm_amd.model import LoraState
+    from pcm_amd.trainer import Distiller
+    ref = golden("sdxl_fullsize_step_one_sample", S.ref_sdxl_step_fullsize)
+    inp = S.sdxl_step_inputs()
+    lora = LoraState(cfg, 64, 8.0, dev, seed=3, b_std=0.02)
+    p_before = S.lora_flat(lora, "p")
+    assert sk_rel(sketch(p_before), ref["sk_param_before"]) < 1e-6          # the fixture was made from the same seeded LoRA factors
+    _, scfg = S.sdxl_step_cfgs()
+    D = Distiller(W, lora, scfg)
+    cu = lambda v: {k: x.to(dev) for k, x in v.items()} if isinstance(v, dict) else v.to(dev)   # noqa: E731
+    out = D.step(*(cu(inp[k]) for k in ("latents", "prompt_embeds", "uncond_prompt_embeds", "noise", "index", "w")),
+                 added_cond=cu(inp["added_cond"]), uncond_added_cond=cu(inp["uncond_added_cond"]))
+    torch.cuda.synchronize()
+    for k in S.TS:
+        assert torch.equal(out[k].cpu(), ref[k]), k
+    rel = lambda a, b: float((a.double().cpu() - b.double()).norm() / (b.double().norm() + 1e-30))   # noqa: E731
+    rep = {k: rel(out[k], ref[k]) for k in S.SDXL_STEP_KEYS if k in out}
+    loss, rloss = float(out["loss"].item()), float(ref["loss"])
+    rep["loss_rel"] = abs(loss - rloss) / abs(rloss)
+    gn = math.sqrt(float(out["grad_sumsq"].item()))
+    rep["grad_norm_rel"] = abs(gn - float(ref["grad_norm"])) / float(ref["grad_norm"])
+    sg = sketch(S.lora_flat(lora, "g"))
+    rep["grad_rel"], rep["grad_cos"] = sk_rel(sg, ref["sk_grad"]), sk_cos(sg, ref["sk_grad"])
+    p_after = S.lora_flat(lora, "p")
+    rep["param_rel"] = sk_rel(sketch(p_after), ref["sk_param_after"])
+    rep["update_cos"] = sk_cos(sketch(p_after - p_before), ref["sk_update"])
+    rep.update(loss=loss, oracle_loss=rloss, oracle_seconds=ref["oracle_seconds"])
+    print("SDXL full-size WHOLE STEP vs fp32 oracle (1 sample):", {k: "%.3e" % v for k, v in rep.items()})
+    os.makedirs("gpurun_out", exist_ok=True)
+    json.dump(rep, open("gpurun_out/sdxl_fullsize_step_parity.json", "w"), indent=1)
+    assert rep["noise_pred"] < 1.5e-2 and rep["cond_teacher_output"] < 1.5e-2 and rep["target_noise_pred"] < 1.5e-2, rep
+    assert rep["x_prev"] < 3e-3 and rep["model_pred"] < 5e-3 and rep["target"] < 5e-3, rep
+    assert rep["loss_rel"] < 1.5e-2, rep
+    assert rep["grad_cos"] > 0.99 and rep["grad_rel"] < 0.12 and rep["grad_norm_rel"] < 0.03, rep
+    assert rep["param_rel"] < 2e-4 and rep["update_cos"] > 0.9, rep
+    del D, lora
+    torch.cuda.empty_cache()
