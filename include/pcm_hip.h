@@ -215,6 +215,18 @@ int pcm_attn_bwd_ws(const void* q, const void* k, const void* v, const void* o, 
                     void* dk, void* dv, int B, int H, int Lq, int Lk, int d, int ldq, int ldk, int ldo, float scale, void* workspace,
                     size_t workspace_bytes, void* stream);
 
+/* The same attention with a PRE-SCALED query (abi >= 4): q' = q * (d^-1/2 * log2 e), i.e. the caller folds the softmax scale AND the
+ * base change into the to_q projection (its packed weights and its LoRA factor s*B; pcm_amd/model.py), so the scores leave the QK^T MFMA
+ * in the log2 domain and the kernels spend no VALU work on scaling: for head dims with spare contraction slots (40) the reference
+ * subtraction rides the MFMA too, and the forward tracks no running maximum after the first key tile (csrc/attention_ps.hip).
+ * Same layouts and strides as pcm_attn_fwd / pcm_attn_bwd; no `scale` argument.  lse is in the log2 domain as before.
+ * pcm_attn_bwd_prescaled returns dq' = dL/dq' (the gradient with respect to the PRE-SCALED query: back-propagating it through the
+ * scaled to_q weights gives dL/dx directly); dk / dv as before (both NULL: only dq').  `o` must be given (delta is computed in the call). */
+int pcm_attn_fwd_prescaled(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int Lq, int Lk, int d, int ldq,
+                           int ldk, int ldo, void* stream);
+int pcm_attn_bwd_prescaled(const void* q, const void* k, const void* v, const void* o, const void* dO, const float* lse, float* delta,
+                           void* dq, void* dk, void* dv, int B, int H, int Lq, int Lk, int d, int ldq, int ldk, int ldo, void* stream);
+
 /* ---- small data-movement ops of the UNet wiring (discriminator_sd15.py:312-342) ---------- */
 int pcm_upsample2x_nhwc(const void* x, void* y, int B, int H, int W, int C, void* stream);
 int pcm_pool2x_sum_nhwc(const void* dy, void* dx, int B, int H, int W, int C, void* stream); /* bwd of upsample: dx[H][W] from dy[2H][2W] */

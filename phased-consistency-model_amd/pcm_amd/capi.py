@@ -76,6 +76,8 @@ _PROTOS = {
     "pcm_geglu_bwd_interleaved": [vp, i32, vp, vp, i32, i32, vp],
     "pcm_attn_fwd": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp],
     "pcm_attn_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp],
+    "pcm_attn_fwd_prescaled": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp],
+    "pcm_attn_bwd_prescaled": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "pcm_attn_fwd_ws": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp, C.c_size_t, vp],
     "pcm_attn_bwd_ws": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp, C.c_size_t, vp],
     "pcm_upsample2x_nhwc": [vp, vp, i32, i32, i32, i32, vp],

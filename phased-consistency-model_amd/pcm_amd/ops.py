@@ -570,13 +570,26 @@ class wgrad_batch:
         return False
 
 
-def attn_fwd(q, k, v, H, d, scale=None):
-    """q [B, Lq, >=H*d] (row stride = q.stride(1)), k/v [B, Lk, ...] -> (o [B, Lq, H*d], lse [B,H,Lq])."""
+LOG2E = 1.4426950408889634
+
+
+def attn_q_scale(d):
+    """what a PRE-SCALED query carries (include/pcm_hip.h pcm_attn_fwd_prescaled): softmax scale times the base change to log2"""
+    return d ** -0.5 * LOG2E
+
+
+def attn_fwd(q, k, v, H, d, scale=None, prescaled=False):
+    """q [B, Lq, >=H*d] (row stride = q.stride(1)), k/v [B, Lk, ...] -> (o [B, Lq, H*d], lse [B,H,Lq]).
+    ``prescaled``: q already carries attn_q_scale(d) (folded into the to_q projection): csrc/attention_ps.hip."""
     B, Lq, Lk = q.shape[0], q.shape[1], k.shape[1]
     scale = scale if scale is not None else d ** -0.5
     o = torch.empty(B, Lq, H * d, dtype=BF16, device=q.device)
     lse = torch.empty(B, H, Lq, dtype=torch.float32, device=q.device)
     assert q.stride(2) == 1 and k.stride(2) == 1 and v.stride(2) == 1 and k.stride(1) == v.stride(1)
+    if prescaled:
+        capi.lib().call("pcm_attn_fwd_prescaled", ptr(q), ptr(k), ptr(v), ptr(o), ptr(lse), B, H, Lq, Lk, d, q.stride(1), k.stride(1),
+                        o.stride(1), _stream())
+        return o, lse
     wsb = capi.lib().dll.pcm_attn_workspace_bytes(B, H, Lq, Lk, d, 0)     # packed V^T tile images for long sequences (0: not used)
     ws = torch.empty(wsb, dtype=torch.uint8, device=q.device) if wsb else None
     capi.lib().call("pcm_attn_fwd_ws", ptr(q), ptr(k), ptr(v), ptr(o), ptr(lse), B, H, Lq, Lk, d, q.stride(1), k.stride(1),
@@ -584,9 +597,10 @@ def attn_fwd(q, k, v, H, d, scale=None):
     return o, lse
 
 
-def attn_bwd(q, k, v, o, dO, lse, H, d, scale=None, need_dkv=True, out=None):
+def attn_bwd(q, k, v, o, dO, lse, H, d, scale=None, need_dkv=True, out=None, prescaled=False):
     """q/k/v may be column slices of a wider row (unit inner stride; dq shares q's row stride, dk/dv share k's).
-    ``out`` = (dq, dk, dv) preallocated with those strides, e.g. slices of one [.., 3C] buffer."""
+    ``out`` = (dq, dk, dv) preallocated with those strides, e.g. slices of one [.., 3C] buffer.
+    ``prescaled``: q carries attn_q_scale(d); the returned dq is then the gradient with respect to that pre-scaled q."""
     B, Lq, Lk = q.shape[0], q.shape[1], k.shape[1]
     scale = scale if scale is not None else d ** -0.5
     assert q.stride(2) == 1 and k.stride(2) == 1 and v.stride(2) == 1 and k.stride(1) == v.stride(1)
@@ -602,6 +616,10 @@ def attn_bwd(q, k, v, o, dO, lse, H, d, scale=None, need_dkv=True, out=None):
         assert dq is not None and (not need_dkv or (k.is_contiguous() and v.is_contiguous())), "attn_bwd: strided q/k/v need out="
         dk = torch.empty_like(k) if need_dkv else None
         dv = torch.empty_like(v) if need_dkv else None
+    if prescaled:
+        capi.lib().call("pcm_attn_bwd_prescaled", ptr(q), ptr(k), ptr(v), ptr(o), ptr(dO), ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv),
+                        B, H, Lq, Lk, d, q.stride(1), k.stride(1), o.stride(1), _stream())
+        return dq, dk, dv
     wsb = capi.lib().dll.pcm_attn_workspace_bytes(B, H, Lq, Lk, d, 1)     # packed K^T, Q^T, dO^T tile images
     ws = torch.empty(wsb, dtype=torch.uint8, device=q.device) if wsb else None
     capi.lib().call("pcm_attn_bwd_ws", ptr(q), ptr(k), ptr(v), ptr(o), ptr(dO), ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv),

@@ -359,7 +359,11 @@ def case_reproducible_reductions(dev, big=False):
             (k, float((a - b).abs().max()), float(b.abs().max()))
 
 
-def case_attention(dev, B, H, Lq, Lk, d, spike=False, spike_at=None):
+def case_attention(dev, B, H, Lq, Lk, d, spike=False, spike_at=None, prescaled=False, spike_overflow=False):
+    """``prescaled``: the pre-scaled-query kernels (csrc/attention_ps.hip): q carries d^-1/2 * log2(e) (rounded ONCE to the 16-bit
+    format, as the folded to_q weights deliver it), the reference is the softmax of that q' in base 2, and dq is the gradient with
+    respect to q'.  ``spike_overflow``: a late key row so far above the first tile's maximum that exp2 against the first tile's
+    reference overflows -> the forward's one-time check must catch it and repeat the workgroup with maximum tracking."""
     q = rnd(B, Lq, H * d, seed=1, dev=dev)
     k = rnd(B, Lk, H * d, seed=2, dev=dev)
     v = rnd(B, Lk, H * d, seed=3, dev=dev)
@@ -367,14 +371,19 @@ def case_attention(dev, B, H, Lq, Lk, d, spike=False, spike_at=None):
         k[:, Lk - 3, :] = k[:, Lk - 3, :] * 6
     for pos in (spike_at or ()):   # ... and in the middle of the stream: the pipelined forward rescales O one tile after the move
         k[:, pos, :] = k[:, pos, :] * 5
+    if spike_overflow:
+        assert Lk > 70
+        k[:, Lk - 5, :] = q[:, 3, :] * 40       # query row 3 of every head: score ~ 40 |q|^2 / sqrt(d) ~ 250 in the log2 domain
     dO = rnd(B, Lq, H * d, seed=4, dev=dev)
+    if prescaled:
+        q = (q.float() * ops.attn_q_scale(d)).to(q.dtype)
     qr, kr, vr = [t.float().cpu().requires_grad_(True) for t in (q, k, v)]
 
     def heads(t, L):
         return t.view(B, L, H, d).transpose(1, 2)
-    s = heads(qr, Lq) @ heads(kr, Lk).transpose(-1, -2) * d ** -0.5
+    s = heads(qr, Lq) @ heads(kr, Lk).transpose(-1, -2) * (0.6931471805599453 if prescaled else d ** -0.5)
     ref = (torch.softmax(s, -1) @ heads(vr, Lk)).transpose(1, 2).reshape(B, Lq, H * d)
-    o, lse = ops.attn_fwd(q, k, v, H, d)
+    o, lse = ops.attn_fwd(q, k, v, H, d, prescaled=prescaled)
     # Relative bounds: at L=4096 the output rms is ~0.026, so an absolute 2e-2 would accept zeros.  bf16 output rounding alone is
     # 2^-9 = 2e-3 per element; P is rounded to bf16 before the PV MFMA (another ~2e-3, averaged down over the keys).
     rel_l2(o, ref.detach(), 5e-3, "attn fwd")
@@ -382,11 +391,11 @@ def case_attention(dev, B, H, Lq, Lk, d, spike=False, spike_at=None):
     ref_lse = torch.logsumexp(s.detach(), -1) * 1.4426950408889634
     close(lse, ref_lse, 1e-3, 2e-2, "lse")
     ref.backward(dO.float().cpu())
-    dq, dk, dv = ops.attn_bwd(q, k, v, o, dO, lse, H, d)
+    dq, dk, dv = ops.attn_bwd(q, k, v, o, dO, lse, H, d, prescaled=prescaled)
     for name, got, want in (("dq", dq, qr.grad), ("dk", dk, kr.grad), ("dv", dv, vr.grad)):
         # (several x5 / x6 key spikes make the softmax nearly one-hot: dS = P (dP - delta) is then a difference of nearly equal bf16-rounded
         # terms -- those stress cases get 2.5e-2)
-        rel_l2(got, want, 2.5e-2 if spike_at else 1.5e-2, name)
+        rel_l2(got, want, 2.5e-2 if (spike_at or spike_overflow) else 1.5e-2, name)
         close(got, want, 3e-2, 3e-2 * float(want.abs().max()), name + " (max-abs, scaled by |ref|max)")
 
 

@@ -151,6 +151,29 @@ def test_attention(B, H, Lq, Lk, d, spike):
     K.case_attention("cpu", B, H, Lq, Lk, d, spike)
 
 
+@pytest.mark.parametrize("B,H,Lq,Lk,d,spike", [(1, 2, 100, 77, 40, False), (2, 1, 70, 130, 80, True), (1, 1, 40, 64, 160, False), (1, 1, 300, 330, 40, True),
+                                               (1, 2, 90, 90, 64, True), (1, 1, 33, 64, 40, False), (1, 1, 70, 13, 40, False), (1, 1, 40, 400, 32, True)])
+@pytest.mark.parametrize("track", [0, 1])
+def test_attention_prescaled_query(B, H, Lq, Lk, d, spike, track):
+    """csrc/attention_ps.hip: forward + dQ' + dK/dV with the softmax scale folded into q (spare-slot reference subtraction at d = 40, no
+    running maximum after the first key tile); track = 1 forces the per-tile maximum tracking the overflow fallback runs"""
+    dll = capi.lib().dll
+    dll.pcm_debug_attn_ps_track(track)
+    try:
+        K.case_attention("cpu", B, H, Lq, Lk, d, spike, prescaled=True)
+    finally:
+        dll.pcm_debug_attn_ps_track(0)
+
+
+@pytest.mark.parametrize("B,H,Lq,Lk,d", [(1, 2, 70, 330, 40), (1, 1, 40, 200, 64), (1, 1, 140, 150, 80)])
+def test_attention_prescaled_query_overflow_fallback(B, H, Lq, Lk, d):
+    """a late key ~250 (log2 domain) above the first tile's row maximum: exp2 against the first tile's reference is inf, the one-time row-sum
+    check after the loop catches it and the workgroup repeats with maximum tracking -- results as accurate as ever; and mid-stream
+    spikes that stay finite (reference never moved: P up to 2^30) keep their relative precision"""
+    K.case_attention("cpu", B, H, Lq, Lk, d, spike=True, prescaled=True, spike_overflow=True)
+    K.case_attention("cpu", B, H, Lq, Lk, d, spike=True, spike_at=(70, 130), prescaled=True)
+
+
 @pytest.mark.parametrize("B,H,Lq,Lk,d,at", [(1, 1, 70, 520, 40, (130, 300)), (1, 2, 40, 450, 64, (70, 200, 330)), (1, 1, 40, 400, 80, (100,)),
                                             (1, 1, 40, 390, 32, (64, 128, 320)), (1, 1, 33, 64, 40, None), (1, 1, 33, 128, 64, (70,))])
 def test_attention_pipelined_forward_steady_state(B, H, Lq, Lk, d, at):

@@ -116,6 +116,29 @@ def test_attention_pipelined_forward(B, H, Lq, Lk, d, at):
         dll.pcm_debug_attn_fwd_variant(-1)
 
 
+@pytest.mark.parametrize("B,H,Lq,Lk,d,spike", [(1, 8, 1024, 1024, 40, False), (2, 8, 256, 77, 80, False), (2, 8, 256, 256, 160, True),
+                                               (1, 2, 4096, 4096, 40, True), (1, 8, 4096, 77, 40, False), (2, 8, 1024, 1024, 80, True),
+                                               (1, 20, 1024, 1024, 64, True), (1, 10, 2176, 2176, 64, False)])
+@pytest.mark.parametrize("track", [0, 1])
+def test_attention_prescaled_query(B, H, Lq, Lk, d, spike, track):
+    """csrc/attention_ps.hip at the step's shapes (SD1.5 levels, text cross-attention, SDXL head dim 64): the softmax scale lives in q, the
+    reference subtraction rides the MFMA at d = 40, no running maximum after the first tile; track = 1: the tracking fallback from the start"""
+    from pcm_amd import capi
+    dll = capi.lib().dll
+    dll.pcm_debug_attn_ps_track(track)
+    try:
+        K.case_attention("cuda", B, H, Lq, Lk, d, spike, prescaled=True)
+    finally:
+        dll.pcm_debug_attn_ps_track(0)
+
+
+@pytest.mark.parametrize("B,H,Lq,Lk,d", [(1, 8, 1024, 1024, 40), (1, 10, 1024, 1024, 64)])
+def test_attention_prescaled_query_overflow_fallback(B, H, Lq, Lk, d):
+    """a late key ~250 (log2 domain) above the first tile's maximum -> non-finite row sum -> the workgroup repeats with tracking"""
+    K.case_attention("cuda", B, H, Lq, Lk, d, spike=True, prescaled=True, spike_overflow=True)
+    K.case_attention("cuda", B, H, Lq, Lk, d, spike=True, spike_at=(300, 700), prescaled=True)
+
+
 def test_lora_repack():
     K.case_lora_repack("cuda")
 
