@@ -389,6 +389,9 @@ int pcm_loss_scale_update(float* scale, int* good_steps, int64_t* step_dev /*may
                           float growth, float backoff, int interval, void* stream);
 /* update_ema (train_pcm_lora_sd15.py:344-355; defined by the reference, never called) */
 int pcm_ema_update(float* target, const float* source, float rate, long n, void* stream);
+/* the same, skipped when *gradsq (the squared global gradient norm of the optimizer step it follows) is not finite: with loss-scaled half
+ * gradients pcm_adamw_clip_step_scaled skips such a step (torch.cuda.amp.GradScaler.step), and the EMA must not move either (abi >= 4) */
+int pcm_ema_update_gated(float* target, const float* source, float rate, long n, const double* gradsq, void* stream);
 
 /* ---- operand packing (fp32 master -> bf16 MFMA operand layouts) -------------------------- */
 /* linear weight [N][K] fp32 -> bf16 [N][K] (scaled) and/or transposed bf16 [K][N] */

@@ -303,17 +303,24 @@ class _Net:
         t = self.sd.get(key)
         return None if t is None else _derived(t, False, self.dt)
 
-    def _lora_ops(self, path):
+    def _lora_ops(self, path, fold=1.0):
         A, B = self.lora[path]
         s = self.alpha / A.shape[0]
         if self.bf16:        # operands the kernels read: bf16(A) and bf16(s * B), both rounded from the fp32 master values
-            return self.q(A).to(self.dt), self.q(B * s).to(self.dt), 1.0
-        return A.to(self.dt), B.to(self.dt), s
+            return self.q(A).to(self.dt), self.q(B * (s * fold)).to(self.dt), 1.0
+        return A.to(self.dt), B.to(self.dt), s * fold
 
-    def linear(self, path, x, keep_f32=False, weight_f32=False):
-        y = F.linear(x, self.par(path + ".weight") if weight_f32 else self.w(path), self.par(path + ".bias"))
+    def linear(self, path, x, keep_f32=False, weight_f32=False, fold=1.0):
+        """``fold``: a constant folded into the projection's operands (the attention query scale, see attention): in the matched mode the
+        bf16 operands are rounded from fold * (fp32 master value), as pcm_amd/model.py packs them"""
+        if fold != 1.0:
+            w0, b0 = self.sd[path + ".weight"], self.sd.get(path + ".bias")
+            w = _RoundBF16.apply(w0 * fold).to(self.dt) if self.bf16 else (w0 * fold).to(self.dt)
+            y = F.linear(x, w, None if b0 is None else (b0 * fold).to(self.dt))
+        else:
+            y = F.linear(x, self.par(path + ".weight") if weight_f32 else self.w(path), self.par(path + ".bias"))
         if path in self.lora:
-            A, B, s = self._lora_ops(path)
+            A, B, s = self._lora_ops(path, fold)
             y = y + F.linear(self.q(F.linear(x, A)), B) * s
         return y if keep_f32 else self.q(y)
 
@@ -343,14 +350,21 @@ class _Net:
 
     def attention(self, p, x, ctx, H):
         B, L, C = x.shape
-        q = self.linear(p + "to_q", x)
+        d = C // H
+        if self.bf16:
+            # rounding points of the HIP path (round 5): the softmax scale AND the base change live in the query projection -- q is stored once,
+            # already in the log2 domain (weights packed from d^-1/2 * log2(e) * W_q, LoRA copy from that times s * B_q); the scores are 2^(q'k)
+            q = self.linear(p + "to_q", x, fold=d ** -0.5 * 1.4426950408889634)
+            post = 0.6931471805599453
+        else:
+            q = self.linear(p + "to_q", x)
+            post = d ** -0.5
         k = self.linear(p + "to_k", ctx)
         v = self.linear(p + "to_v", ctx)
-        d = C // H
         q = q.view(B, L, H, d).transpose(1, 2)
         k = k.view(B, -1, H, d).transpose(1, 2)
         v = v.view(B, -1, H, d).transpose(1, 2)
-        s = torch.softmax(q @ k.transpose(-1, -2) * (d ** -0.5), dim=-1)
+        s = torch.softmax(q @ k.transpose(-1, -2) * post, dim=-1)
         if self.bf16:
             # the kernel feeds bf16 probabilities to the PV MFMA and takes the row sum of the SAME rounded values as the denominator
             s = self.q(s)

@@ -138,13 +138,24 @@ extern "C" int pcm_scale_f32_dev(float* x, const float* scale_dev, long n, void*
   return pcm_post_launch("pcm_scale_f32_dev");
 }
 
-__global__ __launch_bounds__(256) void ema_kernel(float* t, const float* s, float rate, long n) {
+// gradsq != nullptr (half build): the optimizer step this EMA follows was SKIPPED when the global gradient norm is not finite
+// (adamw_kernel above, GradScaler.step semantics) -- the EMA of an unchanged parameter vector must not advance either
+__global__ __launch_bounds__(256) void ema_kernel(float* t, const float* s, float rate, long n, const double* gradsq) {
+  if (gradsq) {
+    const double gs = *gradsq;
+    if (!(gs == gs) || gs > 1.7e308) return;
+  }
   OP_LOOP(i, n) t[i] = t[i] * rate + s[i] * (1.0f - rate);  // targ.mul_(rate).add_(src, alpha=1-rate)
 }
 extern "C" int pcm_ema_update(float* target, const float* source, float rate, long n, void* stream) {
   PCM_CHECK(target && source && n > 0, PCM_EINVAL, "pcm_ema_update: null/empty");
-  PCM_LAUNCH(ema_kernel, dim3(op_blocks(n)), dim3(256), 0, stream, target, source, rate, n);
+  PCM_LAUNCH(ema_kernel, dim3(op_blocks(n)), dim3(256), 0, stream, target, source, rate, n, (const double*)nullptr);
   return pcm_post_launch("pcm_ema_update");
+}
+extern "C" int pcm_ema_update_gated(float* target, const float* source, float rate, long n, const double* gradsq, void* stream) {
+  PCM_CHECK(target && source && n > 0, PCM_EINVAL, "pcm_ema_update_gated: null/empty");
+  PCM_LAUNCH(ema_kernel, dim3(op_blocks(n)), dim3(256), 0, stream, target, source, rate, n, gradsq);
+  return pcm_post_launch("pcm_ema_update_gated");
 }
 
 __global__ __launch_bounds__(256) void cast_f2b_kernel(const float* x, bf16_t* y, long n) { OP_LOOP(i, n) y[i] = f2bf(x[i]); }

@@ -120,6 +120,7 @@ _PROTOS = {
     "pcm_loss_scale_update": [vp, vp, vp, vp, f32, f32, i32, vp],
     "pcm_scale_f32_dev": [vp, vp, i64, vp],
     "pcm_ema_update": [vp, vp, f32, i64, vp],
+    "pcm_ema_update_gated": [vp, vp, f32, i64, vp, vp],
     "pcm_pack_linear": [vp, vp, vp, i32, i32, f32, vp],
     "pcm_pack_conv3x3": [vp, vp, vp, i32, i32, f32, i32, vp],
     "pcm_pack_segmented": [vp, vp, vp, vp, i32, i32, vp],

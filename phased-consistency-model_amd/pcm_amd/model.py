@@ -43,18 +43,21 @@ class PackedLayer:
     """One Linear / conv1x1 / conv3x3 of the base model in MFMA operand layouts."""
     __slots__ = ("kind", "N", "K", "C", "w_fwd", "w_bwd", "bias", "w_geglu", "bias_geglu")
 
-    def __init__(self, w, bias, device, need_bwd):
+    def __init__(self, w, bias, device, need_bwd, scale=1.0):
+        """``scale``: folded into the packed operands (both orientations) and the bias -- ONE rounding of scale * w from the fp32 values
+        (the attention query projections carry the softmax scale: UNetWeights)"""
         w = w.to(device=device, dtype=torch.float32).contiguous()
         self.N = w.shape[0]
-        self.bias = None if bias is None else bias.to(device=device, dtype=torch.float32).contiguous()
+        self.bias = None if bias is None else (bias.to(device=device, dtype=torch.float32) * scale).contiguous()
         if w.dim() == 4 and w.shape[-1] == 3:
+            assert scale == 1.0
             self.kind, self.C = "conv3", w.shape[1]
             self.K = 9 * self.C
             self.w_fwd, self.w_bwd = ops.pack_conv3x3(w, True, need_bwd)
         else:
             self.kind, self.C = "lin", 0
             self.K = w.numel() // self.N
-            self.w_fwd, self.w_bwd = ops.pack_linear(w.view(self.N, self.K), True, need_bwd)
+            self.w_fwd, self.w_bwd = ops.pack_linear(w.view(self.N, self.K), True, need_bwd, scale=scale)
         self.w_geglu = self.bias_geglu = None
 
     def pack_geglu(self):
@@ -80,7 +83,7 @@ class UNetWeights:
         for k, shp in spec:
             if tuple(state_dict[k].shape) != tuple(shp):
                 raise ValueError(f"UNetWeights: {k} has shape {tuple(state_dict[k].shape)}, expected {shp}")
-        self.layers, self.norms = {}, {}
+        self.layers, self.norms, self.q_scale = {}, {}, {}
         f32 = dict(device=self.device, dtype=torch.float32)
         for k, shp in spec:
             if not k.endswith(".weight"):
@@ -92,7 +95,12 @@ class UNetWeights:
             elif path in ("conv_in", "conv_out"):
                 continue
             else:
-                self.layers[path] = PackedLayer(state_dict[k], state_dict.get(path + ".bias"), self.device, need_bwd)
+                # attention query projections are packed times head_dim^-1/2 * log2(e): the attention kernels take a PRE-SCALED query
+                # (csrc/attention_ps.hip) and q is stored once, already in the log2 domain; LoraState scales the matching s*B copies
+                qs = cfg.q_scale_of_path(path, shp[0])
+                self.layers[path] = PackedLayer(state_dict[k], state_dict.get(path + ".bias"), self.device, need_bwd, scale=qs or 1.0)
+                if qs is not None:
+                    self.q_scale[path] = qs
                 if path.endswith("ff.net.0.proj"):
                     self.layers[path].pack_geglu()
         # self-attention q/k/v of the frozen (LoRA-free, no-grad) pass as ONE projection: rows [Wq; Wk; Wv], the
@@ -154,6 +162,10 @@ class LoraState:
         self.cfg, self.rank, self.alpha, self.scaling = cfg, rank, lora_alpha, lora_alpha / self.real_rank
         self.device = torch.device(device)
         targets = targets if targets is not None else lora_target_modules(cfg)
+        # UNet attention query projections: the packed s*B copies (and the dB gradient factor, layer_bwd) carry the query scale the base
+        # weights carry (UNetWeights.q_scale); the fp32 master factors -- what checkpoints hold -- are untouched
+        qsf = getattr(cfg, "q_scale_of_path", None)
+        self.q_scale = {path: qsf(path, shp[0]) for path, shp in targets if qsf is not None and qsf(path, shp[0]) is not None}
         total = 0
         layout = []
         for path, shp in targets:
@@ -227,7 +239,7 @@ class LoraState:
                     descs.append((oa + tap * m.C, -1, o_ab + (8 - tap) * r, r, m.C, m.K, 0, 9 * r, 1.0))
             else:
                 descs.append((oa, o_af, o_ab, r, m.K, m.K, m.K, r, 1.0))               # A [r][K] -> copy + A^T [K][r]
-            descs.append((ob, o_bf, o_bb, m.N, r, r, r, m.N, self.scaling))             # s*B [N][r] -> copy + transpose [r][N]
+            descs.append((ob, o_bf, o_bb, m.N, r, r, r, m.N, self.scaling * self.q_scale.get(path, 1.0)))   # s*B [N][r] -> copy + transpose [r][N]
             if path.endswith("ff.net.0.proj") and m.kind == "lin" and m.N % 16 == 0:
                 # fused-GEGLU forward operand: rows of s*B interleaved [G values, G gates, ...] like Layer.w_geglu -- two strided copies
                 # of (G rows x r) blocks: values block j -> rows 2Gj.., gates block j -> rows 2Gj+G..
@@ -254,7 +266,8 @@ class LoraState:
             for j, t in enumerate(trio):
                 oa_j, ob_j = offs[t.path]
                 descs.append((oa_j, o_caf + j * r * Kc, o_cab + j * r, r, Kc, Kc, Kc, 3 * r, 1.0))
-                descs.append((ob_j, o_cbf + j * Nc * 3 * r + j * r, o_cbb + j * r * 3 * Nc + j * Nc, Nc, r, r, 3 * r, 3 * Nc, self.scaling))
+                descs.append((ob_j, o_cbf + j * Nc * 3 * r + j * r, o_cbb + j * r * 3 * Nc + j * Nc, Nc, r, r, 3 * r, 3 * Nc,
+                              self.scaling * self.q_scale.get(t.path, 1.0)))
         self.operands = torch.zeros(ototal, dtype=BF16, device=self.device)
         self.qkv = {}
         for p, Kc, Nc, o_caf, o_cab, o_cbf, o_cbb in qkv_layout:
@@ -407,7 +420,7 @@ def layer_bwd(W: UNetWeights, lora, path, dy, saved, need_dx=True, residual=None
 
         def wg():
             with ops.wgrad_batch():       # dB and dA share one launch where the kernels allow it
-                ops.lora_wgrad(dy, t, lm.gB, lora.scaling, M, G=L.N, g_stride=lm.r, r_stride=1)   # dB = s dy^T t
+                ops.lora_wgrad(dy, t, lm.gB, lora.scaling * lora.q_scale.get(path, 1.0), M, G=L.N, g_stride=lm.r, r_stride=1)   # dB = s dy^T t
                 if L.kind == "conv3":
                     ops.lora_wgrad(x, u, lm.gA, 1.0, M, conv=dict(Hs=geo.Hs, Ws=geo.Ws, Ho=geo.Ho, Wo=geo.Wo, stride=geo.stride,
                                                                   src_mode=geo.src_mode), g_stride=1, r_stride=L.K)
@@ -529,7 +542,7 @@ class UNet:
             qkv = torch.empty(M, 3 * C, dtype=BF16, device=xn.device)
             ops.gemm([Seg(xn, W.qkv[p])], M, 3 * C, qkv)
             qkv = qkv.view(B, L, 3 * C)
-            o, lse = ops.attn_fwd(qkv[:, :, :C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:], Hh, d)
+            o, lse = ops.attn_fwd(qkv[:, :, :C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:], Hh, d, prescaled=True)
             return layer_fwd(W, lora, p + "to_out.0", o.view(M, C), M, residual=resid)
         fq = lora.qkv.get(p) if (lora is not None and FUSE_LORA_QKV and ctx is xn and p in W.qkv and (sv is None or p in W.qkv_bwd)) else None
         if fq is not None:
@@ -540,7 +553,7 @@ class UNet:
             qkv = torch.empty(M, 3 * C, dtype=BF16, device=xn.device)
             ops.gemm([Seg(xn, W.qkv[p]), Seg(t3, fq.Bs_cat_fwd, k_algo=lora.rank)], M, 3 * C, qkv)
             q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
-            o, lse = ops.attn_fwd(q.unflatten(0, (B, L)), k.unflatten(0, (B, L)), v.unflatten(0, (B, L)), Hh, d)
+            o, lse = ops.attn_fwd(q.unflatten(0, (B, L)), k.unflatten(0, (B, L)), v.unflatten(0, (B, L)), Hh, d, prescaled=True)
             out = layer_fwd(W, lora, p + "to_out.0", o.view(M, C), M, save=so, residual=resid)
             if sv is not None:
                 sv.update(fused=True, x=xn, t3=t3, so=so, q=q, k=k, v=v, o=o, lse=lse, L=L, Lk=Lk)
@@ -548,7 +561,7 @@ class UNet:
         q = layer_fwd(W, lora, p + "to_q", xn, M, save=sq)
         k = layer_fwd(W, lora, p + "to_k", ctx, Mk, save=sk)
         v = layer_fwd(W, lora, p + "to_v", ctx, Mk, save=svv)
-        o, lse = ops.attn_fwd(q.view(B, L, C), k.view(B, Lk, C), v.view(B, Lk, C), Hh, d)
+        o, lse = ops.attn_fwd(q.view(B, L, C), k.view(B, Lk, C), v.view(B, Lk, C), Hh, d, prescaled=True)
         out = layer_fwd(W, lora, p + "to_out.0", o.view(M, C), M, save=so, residual=resid)
         if sv is not None:
             sv.update(sq=sq, sk=sk, sv=svv, so=so, q=q, k=k, v=v, o=o, lse=lse, L=L, Lk=Lk)
@@ -565,20 +578,21 @@ class UNet:
             d3 = torch.empty(M, 3 * C, dtype=BF16, device=d_o.device)        # [dq | dk | dv], written in place by attention
             dq, dk, dv = d3[:, :C], d3[:, C:2 * C], d3[:, 2 * C:]
             ops.attn_bwd(q.unflatten(0, (B, L)), k.unflatten(0, (B, L)), v.unflatten(0, (B, L)), sv["o"], d_o.view(B, L, C),
-                         sv["lse"], Hh, d, out=(dq, dk, dv))
+                         sv["lse"], Hh, d, out=(dq, dk, dv), prescaled=True)
             u3 = torch.empty(M, fq.r3, dtype=BF16, device=d_o.device)
             ops.gemm([Seg(d3, fq.Bs_cat_bwd, k_algo=C)], M, fq.r3, u3)                  # u_j = d_j (s B_j): block-diagonal operand
             def wg():
                 with ops.wgrad_batch():       # six weight gradients, one launch
                     for j, (lm, dj) in enumerate(((fq.q, dq), (fq.k, dk), (fq.v, dv))):
-                        ops.lora_wgrad(dj, t3[:, j * r:(j + 1) * r], lm.gB, lora.scaling, M, G=C, g_stride=r, r_stride=1, ldb=3 * C, lds=fq.r3)
+                        ops.lora_wgrad(dj, t3[:, j * r:(j + 1) * r], lm.gB, lora.scaling * lora.q_scale.get(lm.path, 1.0), M, G=C, g_stride=r,
+                                       r_stride=1, ldb=3 * C, lds=fq.r3)
                         ops.lora_wgrad(x, u3[:, j * r:(j + 1) * r], lm.gA, 1.0, M, G=fq.K, g_stride=1, r_stride=fq.K, lds=fq.r3)
             _wgrad(wg, d3, t3, x, u3)
             d_xn = torch.empty(M, fq.K, dtype=BF16, device=d_o.device)
             ops.gemm([Seg(d3, W.qkv_bwd[p]), Seg(u3, fq.A_cat_bwd)], M, fq.K, d_xn)
             return d_xn
         dq, dk, dv = ops.attn_bwd(sv["q"].view(B, L, C), sv["k"].view(B, Lk, C), sv["v"].view(B, Lk, C), sv["o"],
-                                  d_o.view(B, L, C), sv["lse"], Hh, d)
+                                  d_o.view(B, L, C), sv["lse"], Hh, d, prescaled=True)
         d_xn = layer_bwd(W, lora, p + "to_q", dq.view(B * L, C), sv["sq"])
         if need_dctx:  # self-attention: K/V inputs are xn too
             d_xn = layer_bwd(W, lora, p + "to_k", dk.view(B * Lk, C), sv["sk"], residual=d_xn)

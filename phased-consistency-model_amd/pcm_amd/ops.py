@@ -491,7 +491,11 @@ def scale_by_dev(x, scale_dev):
     capi.lib().call("pcm_scale_f32_dev", ptr(x), ptr(scale_dev), x.numel(), _stream())
 
 
-def ema_update(target, source, rate):
+def ema_update(target, source, rate, gradsq=None):
+    """``gradsq`` (device fp64 [1]): skip when the optimizer step before it was skipped for a non-finite gradient norm (half build)"""
+    if gradsq is not None:
+        capi.lib().call("pcm_ema_update_gated", ptr(target), ptr(source), rate, target.numel(), ptr(gradsq), _stream())
+        return
     capi.lib().call("pcm_ema_update", ptr(target), ptr(source), rate, target.numel(), _stream())
 
 

@@ -405,9 +405,16 @@ class Distiller:
             ops.adamw_clip_step(lo.params, lo.grads, lo.exp_avg, lo.exp_avg_sq, lo.gradsq, cfg.max_grad_norm,
                                 cfg.learning_rate, cfg.adam_beta1, cfg.adam_beta2, cfg.adam_epsilon,
                                 cfg.adam_weight_decay, 1, gscale, step_dev=self.step_dev, lr_dev=self.lr_dev)   # :1299
-        if self.ema is not None:
-            ops.ema_update(self.ema, lo.params, cfg.ema_rate)
+        if self.ema is not None:     # (half build: not after a step GradScaler semantics skipped)
+            ops.ema_update(self.ema, lo.params, cfg.ema_rate, gradsq=lo.gradsq if self.loss_scale_dev is not None else None)
         lo.repack()
+
+    def applied_steps(self):
+        """Host read of the number of optimizer steps actually APPLIED (device counter: with loss-scaled half gradients a step whose global
+        norm overflowed is skipped and pcm_loss_scale_update takes the count back).  accelerate steps the lr scheduler only when the
+        optimizer step was not skipped: the CLIs position their schedule with this under --mixed_precision=fp16 (one host sync per step, as
+        GradScaler's own found_inf read); bf16 / fp32 runs never skip and use the host counter."""
+        return int(self.step_dev.item())
 
     def grad_norm(self):
         """Host read of the last global grad norm (forces a sync; for logging only)."""

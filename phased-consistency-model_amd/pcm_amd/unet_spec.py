@@ -43,6 +43,23 @@ class UNetConfig:
         """up block i works at the resolution level of down block n-1-i."""
         return len(self.block_out_channels) - 1 - i
 
+    def heads_of_path(self, path):
+        """head count of the attention a parameter path (``down_blocks.1.attentions.0. ... attn1.to_q``) belongs to"""
+        parts = path.split(".")
+        if parts[0] == "down_blocks":
+            return self.heads_at(int(parts[1]))
+        if parts[0] == "up_blocks":
+            return self.heads_at(self.up_level(int(parts[1])))
+        return self.heads_at(len(self.block_out_channels) - 1)            # mid block
+
+    def q_scale_of_path(self, path, n_out):
+        """What the UNet's attention kernels expect folded into a ``to_q`` projection (csrc/attention_ps.hip): softmax scale x log2(e) for
+        the head dim n_out / heads; None for every other path."""
+        if not path.endswith(".to_q"):
+            return None
+        d = n_out // self.heads_of_path(path)
+        return d ** -0.5 * 1.4426950408889634
+
     def up_attn(self, i):
         return self.down_attn[self.up_level(i)]
 

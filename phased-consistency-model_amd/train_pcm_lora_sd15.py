@@ -216,6 +216,15 @@ def reseed_for_resume(src, args, rank, global_step):
     return torch.Generator().manual_seed((args.seed or 0) + rank + off)
 
 
+def sched_pos(D, args, host_steps):
+    """optimizer steps the lr scheduler has seen.  accelerate skips ``lr_scheduler.step()`` when GradScaler skipped the optimizer step
+    (fp16 overflow): under --mixed_precision=fp16 with a non-constant schedule the position is the trainer's device-side count of
+    APPLIED steps (one host sync per step, like GradScaler's own found_inf read); otherwise the host counter (no step is ever skipped)."""
+    if getattr(args, "mixed_precision", None) == "fp16" and args.lr_scheduler != "constant":
+        return D.applied_steps()
+    return host_steps
+
+
 def lr_at(args, step):
     """get_scheduler(args.lr_scheduler, ...) (:1026-1031): 'constant' ignores warmup (App. A.6)."""
     if args.lr_scheduler == "constant":
@@ -325,7 +334,7 @@ def main(args):
     cpu_gen = reseed_for_resume(src, args, rank, global_step)
     t_last = time.time()
     while global_step < args.max_train_steps:
-        lr = lr_at(args, sched_step(global_step, world))
+        lr = lr_at(args, sched_step(sched_pos(D, args, global_step), world))
         ga = args.gradient_accumulation_steps
         for micro in range(ga):                                # accelerator.accumulate(unet), :1120: one optimizer step per ga batches
             latents, pe = src.batch()

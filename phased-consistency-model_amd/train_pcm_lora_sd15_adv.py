@@ -93,7 +93,7 @@ def main(args):
         index = torch.randint(0, args.num_ddim_timesteps, (B,), generator=src.g, device=device)
         w = ((args.w_max - args.w_min) * torch.rand((B,), generator=cpu_gen) + args.w_min).to(device)
         adv_u = torch.rand(B, generator=src.g, device=device)
-        lr = base.lr_at(args, base.sched_step(gen_steps, world))
+        lr = base.lr_at(args, base.sched_step(base.sched_pos(D, args, gen_steps), world))
         t0 = time.time()
         out = D.step_adv(global_step, latents, pe, src.uncond, rn(), index, w, rn(), rn(), adv_u, lr=lr)
         if not out["is_d"]:

@@ -243,7 +243,7 @@ def main(args):
     logger.info("***** Running training *****  world=%d  per-GPU batch=%d  total steps=%d", world, args.train_batch_size, args.max_train_steps)
     t_last = time.time()
     while global_step < args.max_train_steps:
-        lr = base.lr_at(args, global_step)
+        lr = base.lr_at(args, base.sched_pos(D, args, global_step))
         ga = args.gradient_accumulation_steps
         for micro in range(ga):                                # accelerator.accumulate(transformer), :1267-1268
             latents, pe, pp = src.batch()

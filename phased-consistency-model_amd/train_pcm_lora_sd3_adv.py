@@ -115,7 +115,7 @@ def main(args):
         nf, nr = (torch.randn(latents.shape, generator=src.g, device=device, dtype=torch.float64) for _ in range(2))      # :1436-1445
         index = torch.randint(0, args.num_euler_timesteps, (B,), generator=src.g, device=device)
         adv_u = torch.rand(B, generator=src.g, device=device)                                                              # :1413-1422
-        lr = base.lr_at(args, gen_steps)                                                                                    # lr_scheduler.step() on G steps
+        lr = base.lr_at(args, base.sched_pos(D, args, gen_steps))                                                                                    # lr_scheduler.step() on G steps
         t0 = time.time()
         out = D.step_adv(global_step, latents, pe, pp, src.uncond, src.uncond_pooled, noise, index, nf, nr, adv_u, lr=lr)
         if not out["is_d"]:

@@ -155,13 +155,13 @@ def main(args):
         ac = dict(text_embeds=pooled, time_ids=src.time_ids)
         t0 = time.time()
         if adv:
-            lr = base.lr_at(args, base.sched_step(gen_steps, world))    # the lr schedule advances on generator steps only (:1527)
+            lr = base.lr_at(args, base.sched_step(base.sched_pos(D, args, gen_steps), world))    # the lr schedule advances on generator steps only (:1527)
             rn = lambda: torch.randn(latents.shape, generator=src.g, device=device)
             out = D.step_adv(global_step, latents, pe, src.uncond, noise, index, w, rn(), rn(), torch.rand(B, generator=src.g, device=device),
                              lr=lr, added_cond=ac, uncond_added_cond=uac)
             gen_steps += 0 if out["is_d"] else 1
         else:
-            lr = base.lr_at(args, base.sched_step(global_step, world))
+            lr = base.lr_at(args, base.sched_step(base.sched_pos(D, args, global_step), world))
             out = D.step(latents, pe, src.uncond, noise, index, w, lr=lr, added_cond=ac, uncond_added_cond=uac)
         global_step += 1
         if rank == 0:

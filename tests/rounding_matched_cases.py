@@ -104,13 +104,14 @@ def case_blocks(dev, kw, B, H, ctx_len, level=0, report=None):
         ops.gemm([Seg(n1.view(M, C), fq.A_cat_fwd)], M, fq.r3, t3)
         qkv = torch.empty(M, 3 * C, dtype=torch.bfloat16, device=dev)
         ops.gemm([Seg(n1.view(M, C), W.qkv[b + "attn1."]), Seg(t3, fq.Bs_cat_fwd, k_algo=lora.rank)], M, 3 * C, qkv)
-        for j, nm in enumerate(("to_q", "to_k", "to_v")):
-            rep["t.attn1." + nm] = rel(qkv[:, j * C:(j + 1) * C].reshape(B, L, C), net.linear(b + "attn1." + nm, n1f))
-        q3 = qkv.view(B, L, 3 * C)
         d = C // heads
-        o, _ = ops.attn_fwd(q3[:, :, :C], q3[:, :, C:2 * C], q3[:, :, 2 * C:], heads, d)
+        for j, nm in enumerate(("to_q", "to_k", "to_v")):      # the query projection carries d^-1/2 * log2(e) (pcm_amd/model.py, csrc/attention_ps.hip)
+            rep["t.attn1." + nm] = rel(qkv[:, j * C:(j + 1) * C].reshape(B, L, C),
+                                       net.linear(b + "attn1." + nm, n1f, fold=ops.attn_q_scale(d) if nm == "to_q" else 1.0))
+        q3 = qkv.view(B, L, 3 * C)
+        o, _ = ops.attn_fwd(q3[:, :, :C], q3[:, :, C:2 * C], q3[:, :, 2 * C:], heads, d, prescaled=True)
         qf, kf, vf = [q3[:, :, i * C:(i + 1) * C].float().cpu().view(B, L, heads, d).transpose(1, 2) for i in range(3)]
-        s = torch.softmax(qf @ kf.transpose(-1, -2) * d ** -0.5, -1)
+        s = torch.softmax(qf @ kf.transpose(-1, -2) * 0.6931471805599453, -1)
         # the probabilities' bf16 rounding is a different realisation in the kernel (unnormalised values against a lazily moved
         # reference); its size is the same: compare with the exact attention rounded once
         rep["t.attn1.core_vs_exact"] = rel(o, net.q((s @ vf).transpose(1, 2).reshape(B, L, C)))

@@ -110,6 +110,39 @@ def test_device_side_grad_scaler_semantics():
     assert torch.allclose(p, pr.detach(), rtol=5e-6, atol=1e-7) and int(step) == 3 and int(good) == 0 and float(scale) == S0
 
 
+def test_skipped_step_moves_neither_ema_nor_step_count_nor_lr_position():
+    """A non-finite loss-scaled gradient: GradScaler semantics skip the optimizer step -- and with it (accelerate) the lr scheduler step; the
+    EMA of the unchanged parameters must not advance either.  Through the trainer's own _optimizer_apply on a tiny LoRA state."""
+    from pcm_amd.model import LoraState, UNetWeights
+    from pcm_amd.trainer import Distiller, StepConfig
+    from pcm_amd.unet_spec import UNetConfig as PC
+    from oracle import unet_sd15 as O
+    import train_pcm_lora_sd15 as cli
+    kw = dict(block_out_channels=(64, 128, 128), cross_attention_dim=64, heads=2, norm_num_groups=32)
+    W = UNetWeights(PC(**kw), O.init_state_dict(O.UNetConfig(**kw), 0), "cpu")
+    lora = LoraState(PC(**kw), 64, 8.0, "cpu", seed=1, b_std=0.02)
+    D = Distiller(W, lora, StepConfig(multiphase=2, ema_rate=0.9))
+    assert D.loss_scale_dev is not None and D.ema is not None
+
+    class A:
+        mixed_precision, lr_scheduler, learning_rate, lr_warmup_steps, max_train_steps = "fp16", "linear", 1e-3, 2, 10
+    g = torch.Generator().manual_seed(3)
+    lora.grads.copy_(torch.randn(lora.grads.shape, generator=g) * 1e-3 * float(D.loss_scale_dev))
+    D.optimizer_step()                                       # finite: applied
+    assert D.applied_steps() == 1 and cli.sched_pos(D, A, 1) == 1
+    p1, e1, s1 = lora.params.clone(), D.ema.clone(), float(D.loss_scale_dev)
+    lora.grads[5] = float("inf")
+    D.optimizer_step()                                       # overflow: everything stays, the scale backs off
+    assert torch.equal(lora.params, p1) and torch.equal(D.ema, e1), "a skipped step moved the parameters or their EMA"
+    assert D.applied_steps() == 1 and cli.sched_pos(D, A, 2) == 1 and float(D.loss_scale_dev) == s1 / 2
+    assert cli.lr_at(A, cli.sched_pos(D, A, 2)) == cli.lr_at(A, 1)          # the schedule did not advance
+    A.lr_scheduler = "constant"
+    assert cli.sched_pos(D, A, 2) == 2                                     # constant schedule: no device read needed
+    lora.grads.copy_(torch.randn(lora.grads.shape, generator=g) * 1e-3 * float(D.loss_scale_dev))
+    D.optimizer_step()
+    assert D.applied_steps() == 2 and not torch.equal(D.ema, e1)
+
+
 def test_tiny_unet_forward_half_build_closer_to_fp32_than_bf16():
     """teacher forward of a 3-level SD1.5-topology UNet through the half emulator build against the fp32 oracle: the error sits at the
     half rounding level (the bf16 build: ~8x that, tests/test_emu_unet.py)."""
