@@ -467,7 +467,7 @@ def main():
         tms = sum(times)
         fam = flops / (tms * 1e-3) / 1e12
         # the dominant kernel of the step (rocprofv3: ~41 % of the kernel time) is the 256x320 phased tile pcm_gemm8p_kernel<3,false,false>
-        # (plan code 5xxx of pcm_debug_last_gemm_plan); the family aggregate is reported next to it
+        # (plan code 5xxx of pcm_gemm_plan_code); the family aggregate is reported next to it
         dom = [(p[0], t, p[5]) for p, t in zip(prof, times) if p[4] // 1000 == 5]
         d_fl, d_ms = sum(x[0] for x in dom), sum(x[1] for x in dom)
         ach = d_fl / (d_ms * 1e-3) / 1e12 if dom else fam

@@ -9,13 +9,12 @@
  *
  * Contract
  *  - plain pointers + sizes; the CALLER owns every buffer; the library never allocates or frees
- *    device memory.  Global state: one immutable 16-byte zero page in the code object (out-of-bounds
- *    LDS-DMA lanes), once-only hipFuncSetAttribute flags, environment switches read once
- *    (A/B and tuning switches, all optional, none needed by a caller: PCM_GEMM_BIG, PCM_GEMM_4W_MAXKT / _STAGGER,
- *    PCM_GEMM_CONV_CO / _MD, PCM_GEMM_PLAN_LEGACY, PCM_GEMM_SMALLM, PCM_N64_RF, PCM_CONV_R64, PCM_WGRAD_TR,
- *    PCM_WGRAD_DENSE_MSPLIT), and the pcm_debug_* tuning / test hooks
- *    (tile forcing, kernel-family mode, last-plan read-back, ...) -- process-wide, not thread-safe,
- *    used by tools/ and tests/ only; a product caller never touches them.
+ *    device memory.  Global state of the product libraries (libpcm_hip.so, libpcm_hip_f16.so): one immutable 16-byte
+ *    zero page in the code object (out-of-bounds LDS-DMA lanes) and once-only hipFuncSetAttribute flags -- nothing
+ *    mutable, no environment variable is read, no pcm_debug_* symbol is exported (`nm -D` shows none).  The A/B
+ *    switches, tile-forcing hooks, launch counters and environment switches of the development rounds exist only in
+ *    the TOOLS build of the same sources (-DPCM_TOOLS -> libpcm_hip_tools.so; csrc/pcm_common.h PCM_KNOB / PCM_LAZY_KNOB:
+ *    process-wide, not thread-safe), which tools/ and the hook-using tests load; its default behaviour is the product's.
  *  - every call enqueues on `stream` (a hipStream_t passed as void*; torch's current stream)
  *    and returns without synchronising; safe under hipGraph stream capture.
  *  - return 0 on success, a negative PCM_E* code otherwise; never throws.  pcm_last_error()
@@ -112,6 +111,12 @@ typedef struct {
 /* bytes of `workspace` the call would use (0: no split-K for this shape) */
 size_t pcm_gemm_workspace_bytes(const pcm_gemm_seg* segs, int nseg, const pcm_gemm_epi* epi);
 int pcm_gemm_bf16(const pcm_gemm_seg* segs, int nseg, const pcm_gemm_epi* epi, void* stream);
+/* Which kernel family and K split the call above takes for these arguments (a pure function of them, nothing is launched; abi >= 4):
+ *   1000 * F + splitk   the phased 8-wave tile gemm8p (F = 4: 256x256, F = 5: 256x320) or, F = 0, a 4-wave tile of gemm.hip;
+ *   10000 + 1000 * F + 1  gemm4w (two workgroups per CU);  64 the rank-64 streaming kernels;  65 the 3x3 halo-window rank-64 kernel;
+ *   32 the batch-row kernel (M <= 16).  Negative: the PCM_E* code the call would return.  bench.py's roofline leg classes its timed
+ * launches with it. */
+int pcm_gemm_plan_code(const pcm_gemm_seg* segs, int nseg, const pcm_gemm_epi* epi);
 
 /* LoRA weight gradients (autograd of peft lora.Linear / lora.Conv2d under loss.backward(),
  * train_pcm_lora_sd15.py:1296).  G[g][r] += alpha * sum_m Big[m][g] * Small[m][r], r in [0,64).

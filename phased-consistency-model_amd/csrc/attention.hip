@@ -478,8 +478,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16_t* q, con
   }
 }
 
-static int g_attn_xcd_remap = 0;
-extern "C" void pcm_debug_attn_xcd_remap(int on) { g_attn_xcd_remap = on ? 1 : 0; }
+PCM_KNOB int g_attn_xcd_remap = 0;
+PCM_TOOLS_ONLY(extern "C" void pcm_debug_attn_xcd_remap(int on) { g_attn_xcd_remap = on ? 1 : 0; })
 // attention_fwd.hip: the software-pipelined forward (false: no instantiation for this variant / head dim -> the kernel above runs)
 bool pcm_attn_fwd_pipe_launch(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int Lq, int Lk, int d, int ldq,
                               int ldk, int ldo, float scale, void* stream);
@@ -504,7 +504,7 @@ static int attn_check(const char* what, const void* q, const void* k, const void
 
 // The packed-operand pre-pass of round 1 is gone (the k-along-rows operands are LDS transpose reads of the row-major tiles), so no call
 // needs a workspace any more; the *_ws entry points and the size query stay in the ABI and accept / report an unused workspace.
-extern "C" void pcm_debug_attn_pack_min_len(int) {}
+PCM_TOOLS_ONLY(extern "C" void pcm_debug_attn_pack_min_len(int) {})
 extern "C" size_t pcm_attn_workspace_bytes(int, int, int, int, int, int) { return 0; }
 
 extern "C" int pcm_attn_fwd_ws(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int Lq, int Lk,

@@ -305,9 +305,9 @@ __global__ __launch_bounds__(256, WPS) void attn_fwd_pipe_kernel(const bf16_t* q
 // After the second pass (packed fma in the softmax: 81 instead of 95 VALU per d = 40 body; V^T reads streamed with the MFMA groups at
 // d = 80; profiles/r03_e_attention_fwd_variants.txt): d = 40 x0.99-1.00, d = 80 x1.11, d = 64 x1.01 (L 4096) / x1.05 (L 4250) / x0.98 (L 1024).
 // Default: the pipelined VGPR form where it measured faster (d = 80 from 8 key tiles, d = 64 from 32 key tiles), the first kernel elsewhere.
-static int g_attn_fwd_variant = -1;
-extern "C" void pcm_debug_attn_fwd_variant(int v) { g_attn_fwd_variant = v; }
-extern "C" int pcm_debug_attn_fwd_variant_get() { return g_attn_fwd_variant; }
+PCM_KNOB int g_attn_fwd_variant = -1;
+PCM_TOOLS_ONLY(extern "C" void pcm_debug_attn_fwd_variant(int v) { g_attn_fwd_variant = v; }
+               extern "C" int pcm_debug_attn_fwd_variant_get() { return g_attn_fwd_variant; })
 
 // returns false when the first kernel (attention.hip) is to run: by choice of the variant, or no pipelined instantiation for the head dim
 bool pcm_attn_fwd_pipe_launch(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int Lq, int Lk, int d, int ldq,

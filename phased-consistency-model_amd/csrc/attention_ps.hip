@@ -524,8 +524,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_ps_kernel(const bf16_t* q, 
 // ============================================================================ C ABI
 bool pcm_attn_fwd_pipe_launch(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int Lq, int Lk, int d, int ldq,
                               int ldk, int ldo, float scale, void* stream);
-static int g_attn_ps_track = 0;     // tests: 1 = run the forward with per-tile maximum tracking from the start (the fallback path of item 2)
-extern "C" void pcm_debug_attn_ps_track(int on) { g_attn_ps_track = on ? 1 : 0; }
+PCM_KNOB int g_attn_ps_track = 0;     // tests: 1 = run the forward with per-tile maximum tracking from the start (the fallback path of item 2)
+PCM_TOOLS_ONLY(extern "C" void pcm_debug_attn_ps_track(int on) { g_attn_ps_track = on ? 1 : 0; })
 
 static int attn_ps_check(const char* what, const void* q, const void* k, const void* v, int B, int H, int Lq, int Lk, int d, int ldq, int ldk,
                          int ldo) {

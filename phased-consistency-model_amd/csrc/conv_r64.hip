@@ -124,26 +124,28 @@ __global__ __launch_bounds__(512) void pcm_conv3x3_r64_kernel(ConvR64 g) {
 #endif
 }
 
-static int g_cr64_mode = -1;      // -1: PCM_CONV_R64 env (default 1); 0 = always the generic GEMM path (A/B, tests); 2 = also below the size threshold
-extern "C" void pcm_debug_conv_r64(int mode) { g_cr64_mode = mode; }
-static long g_cr64_count = 0;
-extern "C" long pcm_debug_conv_r64_count(void) { return g_cr64_count; }
+// -1: PCM_CONV_R64 env (default 1); 0 = always the generic GEMM path (A/B, tests); 2 = also below the size threshold
+PCM_LAZY_KNOB(cr64_mode, g_cr64_mode, "PCM_CONV_R64", 1)
+PCM_TOOLS_ONLY(extern "C" void pcm_debug_conv_r64(int mode) { g_cr64_mode = mode; }
+               static long g_cr64_count = 0;
+               extern "C" long pcm_debug_conv_r64_count(void) { return g_cr64_count; })
 
 // returns 0 when this kernel took the call, 1 when the call is not one of its shapes (caller falls back), < 0 on error
-int pcm_conv_r64_launch(const GemmDev& d, void* stream) {
-  if (g_cr64_mode < 0) { const char* e = getenv("PCM_CONV_R64"); g_cr64_mode = e ? atoi(e) : 1; }
+// plan_only: decide and report (0 / 1), launch nothing
+int pcm_conv_r64_launch(const GemmDev& d, void* stream, bool plan_only) {
   const SegDev& s = d.seg[0];
-  if (!g_cr64_mode || d.nseg != 1 || s.mode != PCM_SEG_CONV3X3 || d.N != 64 || d.out_f32 || d.bias || d.rowvec || d.res ||
+  if (!cr64_mode() || d.nseg != 1 || s.mode != PCM_SEG_CONV3X3 || d.N != 64 || d.out_f32 || d.bias || d.rowvec || d.res ||
       d.act != PCM_ACT_NONE || d.alpha != 1.0f || s.stride != 1 || s.src_mode != PCM_SRC_DIRECT || s.Hs != d.Ho || s.Ws != d.Wo || (s.C % 64) || (d.ldo % 4))
     return 1;
   const int H = d.Ho, W = d.Wo;
   if (W < 8 || (W & (W - 1)) || (size_t)d.M * s.C * 2 >= 0x7ff00000u) return 1;
   // one workgroup per 128 pixels and one workgroup per CU: below ~256 patches the generic tile (split over K) fills the chip better
   // (measured on MI355X, tools/conv_r64_ab.py: 64x64 x1.3-1.8, 32x32 x1.9-2.1 at M >= 32768; 16x16 at M = 8192 x0.5)
-  if (d.M < PCM_GRID_CAP(256) * 128 && g_cr64_mode != 2) return 1;
+  if (d.M < PCM_GRID_CAP(256) * 128 && cr64_mode() != 2) return 1;
   ConvR64 g;
   g.Wt = W < 64 ? W : 64; g.R = 128 / g.Wt;
   if (H % g.R) return 1;
+  if (plan_only) return 0;
   g.lw = 31 - __builtin_clz((unsigned)g.Wt);
   g.x = s.a; g.a = s.w; g.out = (bf16_t*)d.out; g.C = s.C; g.H = H; g.W = W; g.HW = H * W; g.ldo = d.ldo;
   g.tiles_x = W / g.Wt; g.tiles_per_img = g.tiles_x * (H / g.R);
@@ -156,6 +158,6 @@ int pcm_conv_r64_launch(const GemmDev& d, void* stream) {
     lds_ok = true;
   }
   PCM_LAUNCH(pcm_conv3x3_r64_kernel, dim3(nimg * g.tiles_per_img), dim3(512), smem, stream, g);
-  g_cr64_count++;
+  PCM_TOOLS_ONLY(g_cr64_count++;)
   return 0;
 }

@@ -355,31 +355,25 @@ __global__ __launch_bounds__(256) void pcm_gemm_finalize_kernel(GemmDev g) {
 
 // tile / split-K plan shared by pcm_gemm_bf16 and pcm_gemm_workspace_bytes
 struct GemmPlan { int BM, BN, tiles_m, tiles_n, splitk, kt_per_split; size_t ws_bytes; int big_fn; int w4_fn; };
-static int g_force_bm = 0, g_force_bn = 0;
+// Everything from here to gemm_plan is the TOOLS build's knob set (pcm_common.h): in the product build each is its shipped constant.
+PCM_KNOB int g_force_bm = 0, g_force_bn = 0;
 // -1: read PCM_GEMM_BIG once.  0 = 4-wave tiles of this file only, 1 = planner (default), 2 = gemm8p wherever eligible (no gemm4w),
 // 3 = gemm4w wherever eligible (else as 2), 4 = planner without gemm4w; tuning / A-B only
-static int g_big_mode = -1;
-extern "C" void pcm_debug_gemm_big_mode(int mode) { g_big_mode = mode; }
-static int g_conv_co = -1, g_conv_md = -1;    // -1: PCM_GEMM_CONV_CO / PCM_GEMM_CONV_MD env if set, else 0 (the shipped tap-outer / re-key path)
-extern "C" void pcm_debug_gemm_conv_order(int chunk_outer) { g_conv_co = chunk_outer < 0 ? -1 : (chunk_outer > 1 ? 2 : (chunk_outer ? 1 : 0)); }   // -1: default; 2: by shape
-extern "C" void pcm_debug_gemm_conv_md(int mask_delta) { g_conv_md = mask_delta < 0 ? -1 : (mask_delta ? 1 : 0); }
-static int g_ablate = 0;      // see PCM_ABL in gemm_dev.h (no effect in the product build); bits 8.. = gemm4w start stagger override + 1
-extern "C" void pcm_debug_gemm_ablate(int mask) { g_ablate = mask; }
-static int g_last_plan = 0;   // tests only: 1000*big_fn + splitk of the most recent pcm_gemm_bf16 launch (gemm4w: 10000 + 1000*fn + 1; 64 / 65: rank-64 kernels; 32: gemm_smallm)
-extern "C" int pcm_debug_last_gemm_plan(void) { return g_last_plan; }
+PCM_LAZY_KNOB(big_mode, g_big_mode, "PCM_GEMM_BIG", 1)
+PCM_TOOLS_ONLY(extern "C" void pcm_debug_gemm_big_mode(int mode) { g_big_mode = mode; })
+PCM_KNOB int g_conv_co = -1, g_conv_md = -1;    // -1: PCM_GEMM_CONV_CO / PCM_GEMM_CONV_MD env if set, else 0 (the shipped tap-outer / re-key path)
+PCM_TOOLS_ONLY(extern "C" void pcm_debug_gemm_conv_order(int chunk_outer) { g_conv_co = chunk_outer < 0 ? -1 : (chunk_outer > 1 ? 2 : (chunk_outer ? 1 : 0)); }   // -1: default; 2: by shape
+               extern "C" void pcm_debug_gemm_conv_md(int mask_delta) { g_conv_md = mask_delta < 0 ? -1 : (mask_delta ? 1 : 0); })
+PCM_KNOB int g_ablate = 0;      // see PCM_ABL in gemm_dev.h (-DPCM_ABLATE probe builds); bits 8.. = gemm4w start stagger override + 1
+PCM_TOOLS_ONLY(extern "C" void pcm_debug_gemm_ablate(int mask) { g_ablate = mask; }
+               static int g_last_plan = 0;   // the plan code (pcm_gemm_plan_code, include/pcm_hip.h) of the most recent pcm_gemm_bf16 launch
+               extern "C" int pcm_debug_last_gemm_plan(void) { return g_last_plan; })
 // A/B only: PCM_GEMM_PLAN_LEGACY=1 = the planner as it was before the round-4 re-fit (flat 15 % price of a K split, K split for every
 // under-filled small-tile grid)
-static bool plan_legacy() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("PCM_GEMM_PLAN_LEGACY"); v = e ? atoi(e) : 0; }
-  return v != 0;
-}
-static int big_mode() {
-  if (g_big_mode < 0) { const char* e = getenv("PCM_GEMM_BIG"); g_big_mode = e ? atoi(e) : 1; }
-  return g_big_mode;
-}
+PCM_LAZY_KNOB(plan_legacy_knob, g_plan_legacy, "PCM_GEMM_PLAN_LEGACY", 0)
+static bool plan_legacy() { return plan_legacy_knob() != 0; }
 // tuning hook (tools/ only): force the block tile (bm | ksplit << 16, bn) of subsequent pcm_gemm_bf16 calls; (0,0) restores the planner
-extern "C" void pcm_debug_force_gemm_tile(int bm, int bn) { g_force_bm = bm; g_force_bn = bn; }
+PCM_TOOLS_ONLY(extern "C" void pcm_debug_force_gemm_tile(int bm, int bn) { g_force_bm = bm; g_force_bn = bn; })
 
 // big_ok: the call satisfies gemm8p's preconditions (K%64==0 per segment, bf16 output with 16-B rows, < 2 GiB operands)
 // gemm4w.hip (two workgroups per CU, 128-row tiles).  Measured against gemm8p on every plain-segment launch of the bs-16 step
@@ -387,16 +381,8 @@ extern "C" void pcm_debug_force_gemm_tile(int bm, int bn) { g_force_bm = bm; g_f
 // (x0.91-0.93: their tile is epilogue-heavy and N = 8 x 320 gives 8192 small tiles to interleave); it loses 2-30 % elsewhere (twice the
 // weight traffic per flop, and the HBM-bound projections are bound by bytes, not by the missing overlap).  The planner follows that;
 // PCM_GEMM_4W_MAXKT (64-wide K-tiles incl. the LoRA segment, default 6) moves the boundary, PCM_GEMM_BIG=3 / 4 force it on / off.
-static int w4_max_kt() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("PCM_GEMM_4W_MAXKT"); v = e ? atoi(e) : 6; }
-  return v;
-}
-static int w4_stagger_default() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("PCM_GEMM_4W_STAGGER"); v = e ? atoi(e) : 0; }
-  return v;
-}
+PCM_LAZY_KNOB(w4_max_kt, g_w4_max_kt, "PCM_GEMM_4W_MAXKT", 6)
+PCM_LAZY_KNOB(w4_stagger_default, g_w4_stagger, "PCM_GEMM_4W_STAGGER", 0)
 static GemmPlan gemm_plan(int M, int N, int total_kt, bool allow_split, bool big_ok, bool must_big = false, bool w4_ok = false) {
   GemmPlan p;
   p.big_fn = 0; p.w4_fn = 0;
@@ -539,11 +525,7 @@ static bool gemm_n64_ok(const pcm_gemm_seg* segs, int nseg, const pcm_gemm_epi* 
 }
 // batch-row projections (M <= 16: time embedding, time_emb_proj, adaLN modulation) that the weight-streaming kernel (gemm_smallm.hip) takes;
 // PCM_GEMM_SMALLM=0 switches it off (A/B)
-static int smallm_on() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("PCM_GEMM_SMALLM"); v = e ? atoi(e) : 1; }
-  return v;
-}
+PCM_LAZY_KNOB(smallm_on, g_smallm_on, "PCM_GEMM_SMALLM", 1)
 static bool gemm_smallm_ok(const pcm_gemm_seg* segs, int nseg, const pcm_gemm_epi* e) {
   if (!smallm_on() || big_mode() <= 0 || g_force_bm || e->M > 16 || (e->N % 4) || e->rowvec || e->residual) return false;
   if (e->act != PCM_ACT_NONE && e->act != PCM_ACT_SILU) return false;
@@ -558,7 +540,20 @@ extern "C" size_t pcm_gemm_workspace_bytes(const pcm_gemm_seg* segs, int nseg, c
   return gemm_plan(e->M, e->N, gemm_total_kt(segs, nseg), true, gemm_big_ok(segs, nseg, e), e->act == PCM_ACT_GEGLU, gemm_w4_ok(segs, nseg)).ws_bytes;
 }
 
+// validation + kernel choice + launch; plan_only: stop after the choice.  *code = the plan code of include/pcm_hip.h pcm_gemm_plan_code
+static int gemm_run(const pcm_gemm_seg* segs, int nseg, const pcm_gemm_epi* e, void* stream, bool plan_only, int* code);
 extern "C" int pcm_gemm_bf16(const pcm_gemm_seg* segs, int nseg, const pcm_gemm_epi* e, void* stream) {
+  int code = 0;
+  const int rc = gemm_run(segs, nseg, e, stream, false, &code);
+  PCM_TOOLS_ONLY(if (rc == 0) g_last_plan = code;)
+  return rc;
+}
+extern "C" int pcm_gemm_plan_code(const pcm_gemm_seg* segs, int nseg, const pcm_gemm_epi* e) {
+  int code = 0;
+  const int rc = gemm_run(segs, nseg, e, nullptr, true, &code);
+  return rc ? rc : code;
+}
+static int gemm_run(const pcm_gemm_seg* segs, int nseg, const pcm_gemm_epi* e, void* stream, bool plan_only, int* code) {
   PCM_CHECK(segs && e && nseg >= 1 && nseg <= 2, PCM_EINVAL, "pcm_gemm_bf16: nseg must be 1 or 2");
   PCM_CHECK(e->M > 0 && e->N > 0 && (e->N % 4) == 0, PCM_EINVAL, "pcm_gemm_bf16: M>0, N>0, N%%4==0 required (M=%d N=%d)", e->M, e->N);
   GemmDev g;
@@ -606,36 +601,44 @@ extern "C" int pcm_gemm_bf16(const pcm_gemm_seg* segs, int nseg, const pcm_gemm_
   // interleaved A/B of round 3 (profiles/r03_k_conv_order_by_shape_ab.txt) -- not taken.
   // the environment is read ONCE (not per launch: ~5400 launches per eager step); -1 in g_conv_* = "the cached environment value", so the
   // debug hooks can still override and reset
-  static const int env_co = getenv("PCM_GEMM_CONV_CO") ? atoi(getenv("PCM_GEMM_CONV_CO")) : 0;
-  static const int env_md = getenv("PCM_GEMM_CONV_MD") ? (atoi(getenv("PCM_GEMM_CONV_MD")) ? 1 : 0) : 0;
+#if PCM_HAS_TOOLS
+  static const int env_co = pcm_env_int("PCM_GEMM_CONV_CO", 0);
+  static const int env_md = pcm_env_int("PCM_GEMM_CONV_MD", 0) ? 1 : 0;
   const int cco = g_conv_co < 0 ? env_co : g_conv_co, cmd = g_conv_md < 0 ? env_md : g_conv_md;
+#else
+  constexpr int cco = 0, cmd = 0;      // product build: the tap-outer order with the per-tap re-key, the only conv variant instantiated (gemm8p.hip)
+#endif
   g.conv_auto = cco == 2;
   g.conv_co = cco == 1; g.conv_md = cmd > 0 || cco == 1;
   if (e->N == 64 && nseg == 1 && segs[0].mode == PCM_SEG_CONV3X3) {   // conv LoRA down-projection: halo-window kernel where the geometry allows
-    const int rc = pcm_conv_r64_launch(g, stream);
+    const int rc = pcm_conv_r64_launch(g, stream, plan_only);
     if (rc < 0) return rc;
-    if (rc == 0) { g_last_plan = 65; return pcm_post_launch("pcm_gemm_bf16"); }
+    if (rc == 0) { *code = 65; return plan_only ? PCM_OK : pcm_post_launch("pcm_gemm_bf16"); }
   }
   if (gemm_smallm_ok(segs, nseg, e)) {
-    g_last_plan = 32;
+    *code = 32;
+    if (plan_only) return PCM_OK;
     int rc = pcm_gemm_smallm_launch(g, stream);
     if (rc) return rc;
     return pcm_post_launch("pcm_gemm_bf16");
   }
   if (gemm_n64_ok(segs, nseg, e)) {
-    g_last_plan = 64;
+    *code = 64;
+    if (plan_only) return PCM_OK;
     int rc = pcm_gemm_n64_launch(g, stream);
     if (rc) return rc;
     return pcm_post_launch("pcm_gemm_bf16");
   }
-  GemmPlan pl = gemm_plan(e->M, e->N, gemm_total_kt(segs, nseg), e->workspace != nullptr, gemm_big_ok(segs, nseg, e), geglu, gemm_w4_ok(segs, nseg));
+  // (plan_only: the plan a call WITH a workspace would take, as pcm_gemm_workspace_bytes sizes it)
+  GemmPlan pl = gemm_plan(e->M, e->N, gemm_total_kt(segs, nseg), plan_only || e->workspace != nullptr, gemm_big_ok(segs, nseg, e), geglu, gemm_w4_ok(segs, nseg));
+  *code = pl.w4_fn ? 10000 + 1000 * pl.w4_fn + 1 : 1000 * pl.big_fn + pl.splitk;
+  if (plan_only) return PCM_OK;
   if (pl.splitk > 1) {
     PCM_CHECK(e->workspace_bytes >= pl.ws_bytes && PCM_ALIGNED16(e->workspace), PCM_EINVAL,
               "pcm_gemm_bf16: workspace too small (%zu < %zu) or unaligned", (size_t)e->workspace_bytes, pl.ws_bytes);
     g.ws = (float*)e->workspace;
   }
   g.tiles_m = pl.tiles_m; g.tiles_n = pl.tiles_n; g.splitk = pl.splitk; g.kt_per_split = pl.kt_per_split;
-  g_last_plan = pl.w4_fn ? 10000 + 1000 * pl.w4_fn + 1 : 1000 * pl.big_fn + pl.splitk;
   if (pl.w4_fn) {
     int rc = pcm_gemm4w_launch(g, pl.w4_fn, stream);
     if (rc) return rc;

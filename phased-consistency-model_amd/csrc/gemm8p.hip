@@ -396,12 +396,12 @@ __global__ __launch_bounds__(512) void pcm_gemm8p_kernel(GemmDev g) {
 
 size_t pcm_gemm8p_lds_bytes(int fn) { return 2 * (size_t)(256 + 64 * fn) * 128; }
 
-static int g_last_8p_variant = -1;      // of the last launch: bit 0 = mask + delta addressing, bit 1 = chunk-outer K order (tests read it)
-extern "C" int pcm_debug_last_gemm8p_variant() { return g_last_8p_variant; }
+PCM_TOOLS_ONLY(static int g_last_8p_variant = -1;      // of the last launch: bit 0 = mask + delta addressing, bit 1 = chunk-outer K order (tests read it)
+               extern "C" int pcm_debug_last_gemm8p_variant() { return g_last_8p_variant; })
 
 template <int F0, bool MD, bool CO>
 static int launch8p(const GemmDev& g, void* stream) {
-  g_last_8p_variant = (MD ? 1 : 0) | (CO ? 2 : 0);
+  PCM_TOOLS_ONLY(g_last_8p_variant = (MD ? 1 : 0) | (CO ? 2 : 0);)
   const size_t smem = pcm_gemm8p_lds_bytes(F0 + 2);
   dim3 grid(g.tiles_m * g.tiles_n, g.splitk);
   static bool lds_ok = false;
@@ -414,6 +414,11 @@ static int launch8p(const GemmDev& g, void* stream) {
   return 0;
 }
 int pcm_gemm8p_launch(const GemmDev& g, int fn, void* stream) {
+#if !PCM_HAS_TOOLS
+  // product build: ONE conv addressing variant -- tap-outer K order with the per-tap re-key.  The mask + delta (MD) and chunk-outer (CO)
+  // instantiations measured slower on every step shape in rounds 2, 3 and 4; they live in the tools build for A/B only.
+  return fn == 5 ? launch8p<3, false, false>(g, stream) : launch8p<2, false, false>(g, stream);
+#else
   // mask + delta variant: the call has a 3x3 segment and every 3x3 segment is the stride-1 direct view (g.conv_md: A/B hook, default on)
   bool md = false;
   if (g.conv_md) {
@@ -436,4 +441,5 @@ int pcm_gemm8p_launch(const GemmDev& g, int fn, void* stream) {
   const bool co = md && g.conv_co;
   if (fn == 5) return co ? launch8p<3, true, true>(g, stream) : (md ? launch8p<3, true, false>(g, stream) : launch8p<3, false, false>(g, stream));
   return co ? launch8p<2, true, true>(g, stream) : (md ? launch8p<2, true, false>(g, stream) : launch8p<2, false, false>(g, stream));
+#endif
 }

@@ -158,7 +158,11 @@ int pcm_gemm_n64_launch(const GemmDev& g, void* stream) {
     // the grid still covers the chip: measured per shape with RF forced (profiles/r04_t_n64_ksplit_rows_per_block.txt), the fastest form
     // is RF = 4 (224 VGPRs) from 256 blocks of 64 rows, RF = 2 from 256 blocks of 32 rows, RF = 1 below (at M = 4096 RF = 2 is 15 % slower
     // at every K).  PCM_N64_RF overrides (tuning).
-    static const int env_rf = getenv("PCM_N64_RF") ? atoi(getenv("PCM_N64_RF")) : 0;
+#if PCM_HAS_TOOLS
+    static const int env_rf = pcm_env_int("PCM_N64_RF", 0);
+#else
+    constexpr int env_rf = 0;
+#endif
     int rf = env_rf ? env_rf : (g.M >= 64 * PCM_GRID_CAP(256) ? 4 : (g.M >= 32 * PCM_GRID_CAP(256) ? 2 : 1));
     if (K % 160 == 0) { if (rf == 4) launch_ksplit<4, 5>(g, K / 160, stream); else if (rf == 2) launch_ksplit<2, 5>(g, K / 160, stream); else launch_ksplit<1, 5>(g, K / 160, stream); }
     else { if (rf == 4) launch_ksplit<4, 4>(g, K / 128, stream); else if (rf == 2) launch_ksplit<2, 4>(g, K / 128, stream); else launch_ksplit<1, 4>(g, K / 128, stream); }

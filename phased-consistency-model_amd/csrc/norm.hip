@@ -286,8 +286,8 @@ static int gn_stats_geometry(const char* what, GNArgs& a, int B, int target, int
 
 // atomic mode: each block ends with LDS + fp64 global atomics (same-address fp64 atomics serialize at ~0.5 us each on this part):
 // ~2 blocks per CU, long pixel runs per thread.  Workspace mode: no atomics, any batch size gets ~1024 blocks (measured flat from 512 to 2048).
-static int g_gn_target_ws = 1024;
-extern "C" void pcm_debug_gn_target(int blocks) { g_gn_target_ws = blocks > 0 ? blocks : 1024; }   // tuning hook (tools/gn_probe.py)
+PCM_KNOB int g_gn_target_ws = 1024;
+PCM_TOOLS_ONLY(extern "C" void pcm_debug_gn_target(int blocks) { g_gn_target_ws = blocks > 0 ? blocks : 1024; })   // tuning hook (tools/gn_probe.py)
 #define GN_TARGET_ATOMIC PCM_GRID_CAP(512)
 #define GN_TARGET_WS PCM_GRID_CAP(g_gn_target_ws)
 

@@ -29,6 +29,31 @@
 
 #include "../../include/pcm_hip.h"
 
+// ---- process-wide tuning / test knobs exist in the TOOLS build only -------------------------------------------------------------------
+// The product library (libpcm_hip.so, libpcm_hip_f16.so) carries NO mutable global state besides once-only hipFuncSetAttribute flags: every
+// A/B switch, tile-forcing hook, launch counter and environment variable of the development rounds is compiled to its shipped constant, the
+// pcm_debug_* entry points are not exported and the kernel variants only they can reach are not instantiated.  -DPCM_TOOLS
+// (pcm_amd/build.py variant "tools" -> lib/libpcm_hip_tools.so, what tools/ and the hook-using tests load) and the host emulator build keep them.
+#if defined(PCM_TOOLS) || defined(PCM_HOST_EMU)
+#define PCM_HAS_TOOLS 1
+#include <stdlib.h>
+#define PCM_KNOB static                     /* PCM_KNOB int g_x = 0;  -- a variable with a pcm_debug_* setter */
+#define PCM_TOOLS_ONLY(...) __VA_ARGS__
+static inline int pcm_env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+// a knob whose -1 means "the environment switch `env` if set, else `dflt`", read once:  PCM_LAZY_KNOB(big_mode, g_big_mode, "PCM_GEMM_BIG", 1)
+#define PCM_LAZY_KNOB(fn, var, env, dflt)  \
+  static int var = -1;                     \
+  static int fn() {                        \
+    if (var < 0) var = pcm_env_int(env, dflt); \
+    return var;                            \
+  }
+#else
+#define PCM_HAS_TOOLS 0
+#define PCM_KNOB static constexpr
+#define PCM_TOOLS_ONLY(...)
+#define PCM_LAZY_KNOB(fn, var, env, dflt) static constexpr int fn() { return dflt; }
+#endif
+
 // compile-time loop: f(std::integral_constant<int, I>) for I in [I0, N) -- indices usable as asm immediates / register-array subscripts
 template <int I, int N, typename F>
 __device__ __forceinline__ void pcm_static_for(F&& f) {

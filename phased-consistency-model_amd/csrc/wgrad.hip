@@ -142,12 +142,12 @@ __global__ __launch_bounds__(256) void pcm_wgrad_finalize_kernel(const float* pa
   }
 }
 
-static int g_wg_target = 512, g_wg_minchunks = 4, g_wg_auto = 1;
-extern "C" void pcm_debug_wgrad_grid(int target_blocks, int min_chunks) {   // tuning hook (tools/wgrad_probe.py); 0, 0 = shipped rule
+PCM_KNOB int g_wg_target = 512, g_wg_minchunks = 4, g_wg_auto = 1;
+PCM_TOOLS_ONLY(extern "C" void pcm_debug_wgrad_grid(int target_blocks, int min_chunks) {   // tuning hook (tools/wgrad_probe.py); 0, 0 = shipped rule
   g_wg_auto = (target_blocks <= 0 && min_chunks <= 0) ? 1 : 0;
   g_wg_target = target_blocks > 0 ? target_blocks : 512;
   g_wg_minchunks = min_chunks > 0 ? min_chunks : 4;
-}
+})
 
 static int wg_convert(const pcm_wgrad_args* p, WgDev& a) {
   PCM_CHECK(p && p->big && p->small_ && p->out && p->M > 0 && p->G > 0, PCM_EINVAL, "pcm_lora_wgrad_bf16: null/empty");

@@ -181,9 +181,9 @@ __global__ __launch_bounds__(512) void pcm_wgrad_dense_kernel(WdDev a) {
 }
 
 // M split: only as fine as needed for about one block per CU (every extra split is 9 * Cin * Cout further fp32 atomics)
+PCM_LAZY_KNOB(wd_forced_msplit, g_wd_msplit, "PCM_WGRAD_DENSE_MSPLIT", 0)
 static int wd_msplit(int tiles, int stages) {
-  static int forced = -1;
-  if (forced < 0) { const char* e = getenv("PCM_WGRAD_DENSE_MSPLIT"); forced = e ? atoi(e) : 0; }
+  const int forced = wd_forced_msplit();
   int ms = forced > 0 ? forced : (tiles >= 160 ? 1 : PCM_GRID_CAP(256) / tiles);
   if (ms > stages / 8) ms = stages / 8;
   if (ms < 1) ms = 1;

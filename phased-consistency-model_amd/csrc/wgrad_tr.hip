@@ -266,17 +266,17 @@ __global__ __launch_bounds__(256) void pcm_wgrad_tr_conv_kernel(WgDev a) {
 #endif
 }
 
-static int g_wgtr_mode = -1;     // -1: PCM_WGRAD_TR env (default 1); 0 = always wgrad.hip (A/B, tests)
-extern "C" void pcm_debug_wgrad_tr(int mode) { g_wgtr_mode = mode; }
-static long g_wgtr_count[2] = {0, 0};   // tests: launches taken by the plain / conv kernel
-extern "C" long pcm_debug_wgrad_tr_count(int conv) { return g_wgtr_count[conv ? 1 : 0]; }
-static int g_wgtr_blocks = 512, g_wgtr_auto = 1;      // tuning hook: n > 0 forces ~n blocks, 0 restores the shipped rule
-extern "C" void pcm_debug_wgrad_tr_blocks(int n) { g_wgtr_auto = n <= 0; g_wgtr_blocks = n > 0 ? n : 512; }
+// -1: PCM_WGRAD_TR env (default 1); 0 = always wgrad.hip (A/B, tests)
+PCM_LAZY_KNOB(wgtr_mode, g_wgtr_mode, "PCM_WGRAD_TR", 1)
+PCM_TOOLS_ONLY(extern "C" void pcm_debug_wgrad_tr(int mode) { g_wgtr_mode = mode; }
+               static long g_wgtr_count[2] = {0, 0};   // tests: launches taken by the plain / conv kernel
+               extern "C" long pcm_debug_wgrad_tr_count(int conv) { return g_wgtr_count[conv ? 1 : 0]; })
+PCM_KNOB int g_wgtr_blocks = 512, g_wgtr_auto = 1;      // tuning hook: n > 0 forces ~n blocks, 0 restores the shipped rule
+PCM_TOOLS_ONLY(extern "C" void pcm_debug_wgrad_tr_blocks(int n) { g_wgtr_auto = n <= 0; g_wgtr_blocks = n > 0 ? n : 512; })
 
 // plain view: is it one of this file's, and how is it split?  (fills a.m_per_block; returns false -> caller falls back)
 static bool wgtr_plan_plain(WgDev& a, int* tiles_g_out, int* msplit_out) {
-  if (g_wgtr_mode < 0) { const char* e = getenv("PCM_WGRAD_TR"); g_wgtr_mode = e ? atoi(e) : 1; }
-  if (!g_wgtr_mode || a.out_conv || a.mode == PCM_SEG_CONV3X3 || a.part) return false;     // reproducible-form jobs run one by one
+  if (!wgtr_mode() || a.out_conv || a.mode == PCM_SEG_CONV3X3 || a.part) return false;     // reproducible-form jobs run one by one
   if ((size_t)a.M * a.lds_ * 2 >= 0x7ff00000u || (size_t)a.M * a.ldb * 2 >= 0x7ff00000u) return false;
   auto cdiv = [](long x, long y) { return (int)((x + y - 1) / y); };
   const int tiles_g = cdiv(a.G, 128), stages = cdiv(a.M, 64);
@@ -290,8 +290,8 @@ static bool wgtr_plan_plain(WgDev& a, int* tiles_g_out, int* msplit_out) {
   *tiles_g_out = tiles_g; *msplit_out = cdiv(a.M, a.m_per_block);
   return true;
 }
-static long g_wgtr_multi = 0;   // tests: multi-job launches
-extern "C" long pcm_debug_wgrad_tr_multi_count(void) { return g_wgtr_multi; }
+PCM_TOOLS_ONLY(static long g_wgtr_multi = 0;   // tests: multi-job launches
+               extern "C" long pcm_debug_wgrad_tr_multi_count(void) { return g_wgtr_multi; })
 // jobs[0..n): plain-view jobs that wgtr_plan_plain accepted are packed into launches of up to PCM_WGRAD_MULTI_MAX; taken[i] = 1 for those
 int pcm_wgrad_tr_launch_multi(const WgDev* jobs, int n, unsigned char* taken, void* stream) {
   WgMulti mm; memset(&mm, 0, sizeof(mm));
@@ -305,9 +305,9 @@ int pcm_wgrad_tr_launch_multi(const WgDev* jobs, int n, unsigned char* taken, vo
       else PCM_LAUNCH((pcm_wgrad_tr_kernel<false>), dim3(mm.tiles_g[0], msplit), dim3(256), smem, stream, a);
     } else {
       PCM_LAUNCH(pcm_wgrad_tr_multi_kernel, dim3(mm.blk_start[mm.n]), dim3(256), smem, stream, mm);
-      g_wgtr_multi++;
+      PCM_TOOLS_ONLY(g_wgtr_multi++;)
     }
-    g_wgtr_count[0] += mm.n;
+    PCM_TOOLS_ONLY(g_wgtr_count[0] += mm.n;)
     mm.n = 0;
   };
   for (int i = 0; i < n; i++) {
@@ -325,8 +325,7 @@ int pcm_wgrad_tr_launch_multi(const WgDev* jobs, int n, unsigned char* taken, vo
 
 // msplit_out: the M split taken (= slabs of the reproducible form); plan_only: decide and report, launch nothing
 int pcm_wgrad_tr_launch(const WgDev& a0, void* stream, int* msplit_out, bool plan_only) {
-  if (g_wgtr_mode < 0) { const char* e = getenv("PCM_WGRAD_TR"); g_wgtr_mode = e ? atoi(e) : 1; }
-  if (!g_wgtr_mode || a0.out_conv) return 1;
+  if (!wgtr_mode() || a0.out_conv) return 1;
   WgDev a = a0;
   const bool conv = a.mode == PCM_SEG_CONV3X3;
   if ((size_t)a.M * a.lds_ * 2 >= 0x7ff00000u) return 1;
@@ -350,7 +349,7 @@ int pcm_wgrad_tr_launch(const WgDev& a0, void* stream, int* msplit_out, bool pla
     const size_t smem = 2 * (64 * 256 + 64 * 128);
     if (a.swap) PCM_LAUNCH((pcm_wgrad_tr_kernel<true>), dim3(tiles_g, msplit), dim3(256), smem, stream, a);
     else PCM_LAUNCH((pcm_wgrad_tr_kernel<false>), dim3(tiles_g, msplit), dim3(256), smem, stream, a);
-    g_wgtr_count[0]++;
+    PCM_TOOLS_ONLY(g_wgtr_count[0]++;)
     return 0;
   }
   const int W = a.Wo, HW = a.Ho * a.Wo;
@@ -376,6 +375,6 @@ int pcm_wgrad_tr_launch(const WgDev& a0, void* stream, int* msplit_out, bool pla
     lds_ok = true;
   }
   PCM_LAUNCH(pcm_wgrad_tr_conv_kernel, dim3(tiles_c, msplit), dim3(256), smem, stream, a);
-  g_wgtr_count[1]++;
+  PCM_TOOLS_ONLY(g_wgtr_count[1]++;)
   return 0;
 }

@@ -34,7 +34,8 @@ def _stale(out, deps):
 
 # variants: the same sources, another 16-bit activation / weight format (csrc/pcm_common.h).  "bf16" is the product default and what
 # bench.py measures; "f16" (-DPCM_ACT_F16 -> lib/libpcm_hip_f16.so) serves --mixed_precision=fp16 and the fp32-oracle loss validation.
-VARIANTS = {"bf16": ("libpcm_hip.so", "obj", []), "f16": ("libpcm_hip_f16.so", "obj_f16", ["-DPCM_ACT_F16"])}
+VARIANTS = {"bf16": ("libpcm_hip.so", "obj", []), "f16": ("libpcm_hip_f16.so", "obj_f16", ["-DPCM_ACT_F16"]),
+            "tools": ("libpcm_hip_tools.so", "obj_tools", ["-DPCM_TOOLS"]), "tools_f16": ("libpcm_hip_tools_f16.so", "obj_tools_f16", ["-DPCM_TOOLS", "-DPCM_ACT_F16"])}
 
 
 def lib_path(variant="bf16"):

@@ -12,6 +12,10 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(HERE, "lib", "libpcm_hip.so")
 F16_LIB = os.path.join(HERE, "lib", "libpcm_hip_f16.so")      # the same sources compiled with -DPCM_ACT_F16 (pcm_amd/precision.py)
+# TOOLS builds (-DPCM_TOOLS): the same kernels plus the pcm_debug_* hooks / environment switches / A-B kernel variants that tools/ and
+# the hook-using tests need (csrc/pcm_common.h); never loaded by the product path
+TOOLS_LIB = os.path.join(HERE, "lib", "libpcm_hip_tools.so")
+TOOLS_F16_LIB = os.path.join(HERE, "lib", "libpcm_hip_tools_f16.so")
 
 PCM_BF16, PCM_F32 = 0, 1
 REDUCE_WS_BYTES = 32768     # include/pcm_hip.h PCM_REDUCE_WS_BYTES
@@ -156,6 +160,8 @@ class Lib:
         self.act_dtype = int(self.dll.pcm_act_dtype())       # 0: bfloat16 build, 1: IEEE-half build (include/pcm_hip.h PCM_FMT_*)
         self.dll.pcm_gemm_workspace_bytes.restype = C.c_size_t
         self.dll.pcm_gemm_workspace_bytes.argtypes = [C.POINTER(GemmSeg), C.c_int, C.POINTER(GemmEpi)]
+        self.dll.pcm_gemm_plan_code.restype = C.c_int
+        self.dll.pcm_gemm_plan_code.argtypes = [C.POINTER(GemmSeg), C.c_int, C.POINTER(GemmEpi)]
         self.dll.pcm_attn_workspace_bytes.restype = C.c_size_t
         self.dll.pcm_attn_workspace_bytes.argtypes = [C.c_int] * 6
         self.dll.pcm_groupnorm_workspace_bytes.restype = C.c_size_t
@@ -204,3 +210,13 @@ def set_lib(l):
     """Tests only: point the op layer at another build of the same C ABI (tests/emu)."""
     global _LIB
     _LIB = l
+
+
+_TOOLS = {}
+
+
+def tools_lib(f16=False):
+    """the TOOLS build (pcm_debug_* hooks, A/B variants) of the library for tools/ and hook-using tests: ``capi.set_lib(capi.tools_lib())``"""
+    if f16 not in _TOOLS:
+        _TOOLS[f16] = Lib(TOOLS_F16_LIB if f16 else TOOLS_LIB)
+    return _TOOLS[f16]

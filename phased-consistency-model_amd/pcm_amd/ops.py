@@ -60,7 +60,8 @@ class Seg:
 
     def fill(self, s: GemmSeg):
         # both operands in the loaded library's 16-bit format (a bfloat16 tensor handed to the half build would be read as garbage)
-        assert self.a.dtype == BF16 and self.w.dtype == BF16, f"pcm_gemm_bf16 operands must be {BF16}: got {self.a.dtype}, {self.w.dtype}"
+        if self.a.dtype != BF16 or self.w.dtype != BF16:       # (not an assert: python -O must not turn a format mix-up into garbage reads)
+            raise TypeError(f"pcm_gemm_bf16 operands must be {BF16}: got {self.a.dtype}, {self.w.dtype}")
         s.a, s.w = ptr(self.a), ptr(self.w)
         s.K = self.w.shape[-1]
         if self.conv is None:
@@ -112,7 +113,7 @@ def gemm(segs, M, N, out, bias=None, rowvec=None, rows_per_batch=0, residual=Non
         nbytes += M * out_cols * out.element_size() + (M * N * 2 if residual is not None else 0) + (pre_out.numel() * 2 if pre_out is not None else 0)
         GEMM_PROFILE.append((2.0 * M * N * sum(s.k_algo for s in segs), ev0, ev1,
                              (M, N, tuple(s.w.shape[-1] for s in segs), "conv" if segs[0].conv else "lin"),
-                             capi.lib().dll.pcm_debug_last_gemm_plan(), nbytes))
+                             capi.lib().dll.pcm_gemm_plan_code(arr, len(segs), C.byref(e)), nbytes))
         return out
     capi.lib().call("pcm_gemm_bf16", arr, len(segs), C.byref(e), capi.Lib.stream())
     return out

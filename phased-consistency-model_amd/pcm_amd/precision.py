@@ -25,20 +25,26 @@ def act_dtype():
     return _DTYPES[_NAME]
 
 
-def set_precision(name, lib=None):
-    """name: "bf16" | "fp16" (there is no fp32-storage build).  ``lib``: tests pass an emulator build of the matching variant."""
+def set_precision(name, lib=None, tools=False):
+    """name: "bf16" | "fp16" (there is no fp32-storage build).  ``lib``: tests pass an emulator build of the matching variant;
+    ``tools``: the TOOLS build of the variant (pcm_debug_* hooks; tools/ and hook-using tests only).
+    Nothing is switched unless the library loads and reports the requested format: a missing / mismatched file leaves the process in
+    its previous precision."""
     global _NAME
     if name not in _DTYPES:
         raise ValueError("precision must be 'bf16' or 'fp16', got %r" % (name,))
     want = 1 if name == "fp16" else 0
+    path = None
     if lib is None:
-        capi._LIB_PATH = capi.F16_LIB if name == "fp16" else capi.DEFAULT_LIB      # capi.set_lib(None) / lib() keep loading this variant
-        lib = capi.Lib(capi._LIB_PATH)
+        path = (capi.TOOLS_F16_LIB if tools else capi.F16_LIB) if name == "fp16" else (capi.TOOLS_LIB if tools else capi.DEFAULT_LIB)
+        lib = capi.Lib(path)                                                       # raises when the file is missing: nothing switched yet
     if lib.act_dtype != want:
         raise RuntimeError("%s was built for %s, not %s" % (lib.path, "fp16" if lib.act_dtype else "bf16", name))
+    if path is not None:
+        capi._LIB_PATH = path                                                      # capi.set_lib(None) / lib() keep loading this variant
     capi.set_lib(lib)
     _NAME = name
-    for mod in ("pcm_amd.ops", "pcm_amd.model", "pcm_amd.discriminator", "pcm_amd.mmdit"):
-        m = sys.modules.get(mod)
-        if m is not None and hasattr(m, "BF16"):
+    # every host module that holds the "library's 16-bit dtype" constant (BF16) -- found by attribute, not by a hard-coded list
+    for mod_name, m in list(sys.modules.items()):
+        if mod_name.startswith("pcm_amd.") and m is not None and isinstance(getattr(m, "BF16", None), torch.dtype):
             m.BF16 = _DTYPES[name]

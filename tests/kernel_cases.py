@@ -410,7 +410,7 @@ def case_lora_repack(dev):
             f, d = ops.pack_conv3x3(m.A, khwc=True)
         else:
             f, d = ops.pack_linear(m.A.view(64, m.K))
-        bf, bd = ops.pack_linear(m.B.view(m.N, 64), scale=lora.scaling)
+        bf, bd = ops.pack_linear(m.B.view(m.N, 64), scale=lora.scaling * lora.q_scale.get(m.path, 1.0))    # (to_q: the folded attention scale)
         assert torch.equal(m.A_fwd.cpu(), f.cpu()) and torch.equal(m.A_bwd.cpu(), d.cpu().view_as(m.A_bwd)), m.path
         assert torch.equal(m.Bs_fwd.cpu(), bf.cpu()) and torch.equal(m.Bs_bwd.cpu(), bd.cpu()), m.path
 

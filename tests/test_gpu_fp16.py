@@ -18,7 +18,9 @@ pytestmark = pytest.mark.gpu
 def _half_build():
     from pcm_amd import capi, precision
     assert torch.cuda.is_available()
-    precision.set_precision("fp16")          # raises if lib/libpcm_hip_f16.so is missing: no fallback
+    # the TOOLS build of the half library: the kernel cases below force kernel families / read plan codes through pcm_debug_* hooks, which
+    # the product libraries do not export; the step / trainer tests further down run the same kernels (default knobs = the product's)
+    precision.set_precision("fp16", tools=True)          # raises if the library is missing: no fallback
     assert capi.lib().act_dtype == 1 and K.ops.BF16 == torch.float16
     yield
     torch.cuda.synchronize()

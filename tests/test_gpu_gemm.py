@@ -9,10 +9,12 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(autouse=True)
 def _hip():
     from pcm_amd import capi
-    capi.set_lib(None)
     assert torch.cuda.is_available()
-    capi.lib()  # raises loudly if libpcm_hip.so is missing
+    # the TOOLS build (same kernels + the pcm_debug_* hooks these cases force kernel families with); the product library's own run of the
+    # hook-free cases is tests/test_gpu_product_lib.py, and every step-level GPU test runs on it
+    capi.set_lib(capi.tools_lib())  # raises loudly if libpcm_hip_tools.so is missing
     yield
+    capi.set_lib(None)
 
 
 def rnd(*shape, seed=0, scale=1.0):

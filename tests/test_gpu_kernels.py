@@ -10,11 +10,13 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(autouse=True)
 def _hip():
     from pcm_amd import capi
-    capi.set_lib(None)
     assert torch.cuda.is_available()
-    capi.lib()  # raises loudly if libpcm_hip.so is missing
+    # TOOLS build: several cases select kernels / read counters through pcm_debug_* hooks (tests/test_gpu_product_lib.py runs the hook-free
+    # cases on the product library)
+    capi.set_lib(capi.tools_lib())  # raises loudly if libpcm_hip_tools.so is missing
     yield
     torch.cuda.synchronize()
+    capi.set_lib(None)
 
 
 @pytest.mark.parametrize("B,HW,C,G,act", [(2, 4096, 320, 32, 1), (2, 1024, 640, 32, 0), (2, 256, 2560, 32, 1),

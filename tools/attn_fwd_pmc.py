@@ -5,6 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "phased-consistency-model_amd"))
 import torch
 from pcm_amd import capi, ops
+capi.set_lib(capi.tools_lib())      # the TOOLS build of the library: the pcm_debug_* hooks used below are not in the product build
 dll = capi.lib().dll
 for (B, L, H, d) in [(16, 4096, 8, 40), (4, 4096, 10, 64)]:
     q = torch.randn(B, L, H * d, device="cuda").bfloat16(); k = torch.randn(B, L, H * d, device="cuda").bfloat16()

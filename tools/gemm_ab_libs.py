@@ -6,6 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "phased-consistency-model_amd"))
 import torch
 from pcm_amd import ops, capi
+capi.set_lib(capi.tools_lib())      # the TOOLS build of the library: the pcm_debug_* hooks used below are not in the product build
 libs = [capi.Lib(os.path.abspath(p)) for p in sys.argv[1:] if p.endswith(".so")]
 # third column: library B with its persistent tile loop switched off (when it has the hook) -- isolates the epilogue changes
 cfgs = [(l, None) for l in libs]

@@ -5,6 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "phased-consistency-model_amd"))
 import torch
 from pcm_amd import ops, capi
+capi.set_lib(capi.tools_lib())      # the TOOLS build of the library: the pcm_debug_* hooks used below are not in the product build
 dll = capi.lib().dll
 flush = torch.zeros(128 * 1024 * 1024, device="cuda")
 def bench(fn, n=6, cold=True):

@@ -9,6 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "phased-consistency-model_amd"))
 import torch  # noqa: E402
 from pcm_amd import capi, ops  # noqa: E402
+capi.set_lib(capi.tools_lib())      # the TOOLS build of the library: the pcm_debug_* hooks used below are not in the product build
 
 dll = capi.lib().dll
 lin = [(2048, 1280, 1280), (4096, 1280, 1280), (1024, 1280, 1280), (8192, 640, 640), (16384, 640, 640), (32768, 320, 320), (2048, 1280, 5120),

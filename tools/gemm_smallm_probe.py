@@ -7,6 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "phased-consistency-model_amd"))
 import torch  # noqa: E402
 from pcm_amd import capi, ops  # noqa: E402
+capi.set_lib(capi.tools_lib())      # the TOOLS build of the library: the pcm_debug_* hooks used below are not in the product build
 
 shapes = [(32, 1280, (320,), 1), (32, 1280, (1280,), 0), (32, 1280, (1280, 64), 0), (32, 640, (1280, 64), 0), (32, 320, (1280, 64), 0), (32, 64, (1280,), 0), (16, 64, (1280,), 0),
           (16, 1280, (1280,), 0), (8, 1280, (2816,), 1), (8, 1280, (1280, 64), 0), (2, 9216, (1536,), 0), (4, 9216, (1536,), 0), (2, 3072, (1536,), 0), (4, 1536, (1536,), 1)]

@@ -6,6 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "phased-consistency-model_amd"))
 import torch
 from pcm_amd import capi
+capi.set_lib(capi.tools_lib())      # the TOOLS build of the library: the pcm_debug_* hooks used below are not in the product build
 from pcm_amd.ops import ptr
 L = capi.lib()
 S = capi.Lib.stream
