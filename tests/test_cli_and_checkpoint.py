@@ -99,11 +99,15 @@ def test_capi_exports_every_declared_symbol():
     from pcm_amd import capi
     header = open(os.path.join(ROOT, "include", "pcm_hip.h")).read()
     declared = set(re.findall(r"^\s*(?:int|const char\*)\s+(pcm_\w+)\s*\(", header, flags=re.M))
-    for variant in B.VARIANTS:              # the bfloat16 build and the IEEE-half build export the same C ABI
+    declared |= set(re.findall(r"^\s*size_t\s+(pcm_\w+)\s*\(", header, flags=re.M))        # the *_workspace_bytes queries
+    for variant in B.VARIANTS:              # bfloat16 / IEEE-half, product / tools: the same C ABI ...
         L = capi.Lib(B.build(variant=variant))
         for name in declared:
             assert hasattr(L.dll, name), f"{name} declared in include/pcm_hip.h but not exported by the {variant} build"
-    assert declared - {"pcm_last_error", "pcm_abi_version", "pcm_act_dtype"} == set(capi._PROTOS), (declared ^ set(capi._PROTOS))
+        # ... and the pcm_debug_* hooks (declared nowhere in the header) only in the TOOLS builds
+        assert hasattr(L.dll, "pcm_debug_gemm_big_mode") == variant.startswith("tools"), variant
+    queries = {n for n in declared if n.endswith("_workspace_bytes")} | {"pcm_last_error", "pcm_abi_version", "pcm_act_dtype", "pcm_gemm_plan_code"}
+    assert declared - queries == set(capi._PROTOS), (declared - queries) ^ set(capi._PROTOS)
 
 
 def test_missing_library_fails_loudly(tmp_path):
