@@ -27,6 +27,9 @@
 #include "attn_dev.h"
 
 #define LN2 0.6931471805599453f
+#ifndef PCM_ATTN_PS_DMA_DEFAULT      // (A/B builds: tools/probes/build_variant.py nodma -DPCM_ATTN_PS_DMA_DEFAULT=0)
+#define PCM_ATTN_PS_DMA_DEFAULT 1
+#endif
 
 template <int D>
 struct SlotCfg {
@@ -67,17 +70,21 @@ __device__ __forceinline__ void fill_pad_chunks_w(char* dst, int tid, unsigned f
 }
 
 // ============================================================================ forward
-template <int D>
+// DMA: the K / V tiles are staged by LDS-DMA into a double-buffered pair of images (attn_dev.h DmaTile): tile j+1 is in flight while tile j is
+// computed on, ONE barrier per tile, no staging registers and no ds_write pass; otherwise the register staging of attention.hip (two barriers)
+template <int D, bool DMA>
 __global__ __launch_bounds__(256, (D <= 40 ? 3 : 1)) void attn_fwd_ps_kernel(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t* o,
                                                                               float* lse, int H, int Lq, int Lk, int ldq, int ldk, int ldo,
                                                                               int force_track) {
   using C = AttnCfg<D>;
   using SC = SlotCfg<D>;
   constexpr bool SLOT = SC::ON;
-  __shared__ __attribute__((aligned(16))) char Ks[TileBytes<D>::value];
-  __shared__ __attribute__((aligned(16))) char Vs[TileBytes<D>::value];
+  constexpr int TB = TileBytes<D>::value, NBUF = DMA ? 2 : 1;
+  __shared__ __attribute__((aligned(16))) char KVs[NBUF * 2 * TB];      // [buffer][K, V]
+  char* Ks = KVs;
+  char* Vs = KVs + TB;
   __shared__ int s_redo;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, hi = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 128 + wave * 32;
   const bf16_t* qb = q + (size_t)b * Lq * ldq + h * D;
   const bf16_t* kb = k + (size_t)b * Lk * ldk + h * D;
@@ -87,12 +94,17 @@ __global__ __launch_bounds__(256, (D <= 40 ? 3 : 1)) void attn_fwd_ps_kernel(con
   for (int s = 0; s < C::DK16; s++) qf[s] = gfrag<D>(qb, ldq, q0 + l31, Lq, s, hi);
   // column D of the V tile = ones: the PV MFMA also produces the softmax denominator in accumulator row D (attention.hip)
   constexpr bool ONES = C::DV * 32 > D && C::RKU > C::DG;
-  fill_pad_chunks_w<D, 64>(Ks, tid, SLOT ? PCM_TWO_ONES : 0u);
-  fill_pad_chunks_w<D, 64>(Vs, tid, ONES ? (unsigned)PCM_ONE_BITS : 0u);
+#pragma unroll
+  for (int bf = 0; bf < NBUF; bf++) {
+    fill_pad_chunks_w<D, 64>(KVs + (2 * bf) * TB, tid, SLOT ? PCM_TWO_ONES : 0u);
+    fill_pad_chunks_w<D, 64>(KVs + (2 * bf + 1) * TB, tid, ONES ? (unsigned)PCM_ONE_BITS : 0u);
+  }
   if (tid == 0) s_redo = 0;
   const TrFrag<D> trf(lane);
   const RowGeom<D, 64> geo(ldk, tid);
   RowStage<D, 64> kst, vst;
+  const DmaTile<D, 64> dma(ldk, lane, wave);
+  if constexpr (DMA) __syncthreads();     // the pad fills above are ordinary stores: they must land before a DMA'd tile next to them is read
   f32x16 acc_o[C::DV];
   float m_run = 0.f, l_run = 0.f;
   bool track = force_track != 0;         // workgroup-uniform: per-tile maximum tracking (the fallback of item 2; tests force it)
@@ -103,17 +115,28 @@ __global__ __launch_bounds__(256, (D <= 40 ? 3 : 1)) void attn_fwd_ps_kernel(con
       for (int r = 0; r < 16; r++) acc_o[i][r] = 0.f;
     m_run = 0.f; l_run = 0.f;
     if constexpr (SLOT) set_slot<D>(qf, hi, 0u);
-    if (AttnPrefetch<D>::value) { kst.load(geo, kb, ldk, 0, Lk, tid); vst.load(geo, vb, ldk, 0, Lk, tid); }
+    if constexpr (DMA) {
+      dma.issue(kb, ldk, 0, Lk, KVs, wave); dma.issue(vb, ldk, 0, Lk, KVs + TB, wave);
+    } else if (AttnPrefetch<D>::value) { kst.load(geo, kb, ldk, 0, Lk, tid); vst.load(geo, vb, ldk, 0, Lk, tid); }
     for (int kv0 = 0; kv0 < Lk; kv0 += 64) {
-      __syncthreads();
-      if (AttnPrefetch<D>::value) {
-        kst.store(geo, Ks, Lk, tid); vst.store(geo, Vs, Lk, tid);
+      if constexpr (DMA) {
+        // this wave's pieces of tile kv0 have landed; past the barrier every wave's have, and every wave is done reading the OTHER buffer
+        // (tile kv0 - 64): the next tile goes there while this one is computed on
+        PCM_WAIT_VMCNT(0);
+        __syncthreads();
+        const int cur = (kv0 >> 6) & 1;
+        Ks = KVs + (2 * cur) * TB; Vs = Ks + TB;
       } else {
-        load_rowmajor<D, 64>(Ks, kb, ldk, kv0, Lk, tid);
-        load_rowmajor<D, 64>(Vs, vb, ldk, kv0, Lk, tid);
+        __syncthreads();
+        if (AttnPrefetch<D>::value) {
+          kst.store(geo, Ks, Lk, tid); vst.store(geo, Vs, Lk, tid);
+        } else {
+          load_rowmajor<D, 64>(Ks, kb, ldk, kv0, Lk, tid);
+          load_rowmajor<D, 64>(Vs, vb, ldk, kv0, Lk, tid);
+        }
+        __syncthreads();
+        if (AttnPrefetch<D>::value && kv0 + 64 < Lk) { kst.load(geo, kb, ldk, kv0 + 64, Lk, tid); vst.load(geo, vb, ldk, kv0 + 64, Lk, tid); }
       }
-      __syncthreads();
-      if (AttnPrefetch<D>::value && kv0 + 64 < Lk) { kst.load(geo, kb, ldk, kv0 + 64, Lk, tid); vst.load(geo, vb, ldk, kv0 + 64, Lk, tid); }
       f32x16 s_[2];
 #pragma unroll
       for (int t = 0; t < 2; t++) {
@@ -123,6 +146,15 @@ __global__ __launch_bounds__(256, (D <= 40 ? 3 : 1)) void attn_fwd_ps_kernel(con
         for (int s = 0; s < C::DK16; s++) {
           bf16x8 kf = *(const bf16x8*)(Ks + ((32 * t + l31) * C::RKU + 2 * s + hi) * 16);
           s_[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], s_[t], 0, 0, 0);      // SLOT: s' - m_run;  else s'
+        }
+      }
+      if constexpr (DMA) {
+        // the next tile's DMA is issued AFTER this tile's last compiler-tracked LDS read (the K fragments above): hipcc orders every tracked
+        // ds_read behind pending LDS-DMA with s_waitcnt vmcnt(0), which in front of the K reads would drain the prefetch it just issued
+        // (pcm_common.h PCM_TR16_ISSUE); the V^T reads below are untracked asm reads of the CURRENT buffer
+        if (kv0 + 64 < Lk) {
+          char* nx = KVs + (2 * (((kv0 >> 6) & 1) ^ 1)) * TB;
+          dma.issue(kb, ldk, kv0 + 64, Lk, nx, wave); dma.issue(vb, ldk, kv0 + 64, Lk, nx + TB, wave);
         }
       }
       constexpr bool V_EARLY = D <= 80;
@@ -238,16 +270,18 @@ __global__ __launch_bounds__(256, (D <= 40 ? 3 : 1)) void attn_fwd_ps_kernel(con
 }
 
 // ============================================================================ backward: dQ'  (gradient with respect to the pre-scaled q')
-template <int D>
+template <int D, bool DMA>
 __global__ __launch_bounds__(256, (D <= 40 ? 3 : 1)) void attn_bwd_dq_ps_kernel(const bf16_t* q, const bf16_t* k, const bf16_t* v, const bf16_t* dO,
                                                                                  const float* lse, float* delta, const bf16_t* o, bf16_t* dq, int H,
                                                                                  int Lq, int Lk, int ldq, int ldk, int ldo) {
   using C = AttnCfg<D>;
   using SC = SlotCfg<D>;
   constexpr bool SLOT = SC::ON;
-  __shared__ __attribute__((aligned(16))) char Ks[TileBytes<D>::value];
-  __shared__ __attribute__((aligned(16))) char Vs[TileBytes<D>::value];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  constexpr int TB = TileBytes<D>::value, NBUF = DMA ? 2 : 1;
+  __shared__ __attribute__((aligned(16))) char KVs[NBUF * 2 * TB];      // [buffer][K, V]  (DMA: double-buffered, see the forward)
+  char* Ks = KVs;
+  char* Vs = KVs + TB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, hi = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 128 + wave * 32;
   const bf16_t* qb = q + (size_t)b * Lq * ldq + h * D;
   const bf16_t* dob = dO + (size_t)b * Lq * ldo + h * D;
@@ -285,24 +319,34 @@ __global__ __launch_bounds__(256, (D <= 40 ? 3 : 1)) void attn_bwd_dq_ps_kernel(
   for (int i = 0; i < C::DV; i++)
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[i][r] = 0.f;
-  fill_pad_chunks_w<D, 64>(Ks, tid, SLOT ? PCM_TWO_ONES : 0u);
-  fill_pad_chunks_w<D, 64>(Vs, tid, SLOT ? PCM_TWO_ONES : 0u);
+#pragma unroll
+  for (int bf = 0; bf < 2 * NBUF; bf++) fill_pad_chunks_w<D, 64>(KVs + bf * TB, tid, SLOT ? PCM_TWO_ONES : 0u);
   const TrFrag<D> trf(lane);
   const RowGeom<D, 64> geo(ldk, tid);
   RowStage<D, 64> kst, vst;
-  if (AttnPrefetch<D>::value) { kst.load(geo, kb, ldk, 0, Lk, tid); vst.load(geo, vb, ldk, 0, Lk, tid); }
+  const DmaTile<D, 64> dma(ldk, lane, wave);
+  if constexpr (DMA) {
+    __syncthreads();
+    dma.issue(kb, ldk, 0, Lk, KVs, wave); dma.issue(vb, ldk, 0, Lk, KVs + TB, wave);
+  } else if (AttnPrefetch<D>::value) { kst.load(geo, kb, ldk, 0, Lk, tid); vst.load(geo, vb, ldk, 0, Lk, tid); }
   const f32x2 nl2 = {-L2, -L2}, ndl2 = {-dl, -dl};
   for (int kv0 = 0; kv0 < Lk; kv0 += 64) {
-    __syncthreads();
-    if (AttnPrefetch<D>::value) {
-      kst.store(geo, Ks, Lk, tid); vst.store(geo, Vs, Lk, tid);
+    if constexpr (DMA) {
+      PCM_WAIT_VMCNT(0);
+      __syncthreads();
+      Ks = KVs + (2 * ((kv0 >> 6) & 1)) * TB; Vs = Ks + TB;
     } else {
-      load_rowmajor<D, 64>(Ks, kb, ldk, kv0, Lk, tid);
-      load_rowmajor<D, 64>(Vs, vb, ldk, kv0, Lk, tid);
-    }
-    __syncthreads();
-    if (AttnPrefetch<D>::value && kv0 + 64 < Lk) {
-      kst.load(geo, kb, ldk, kv0 + 64, Lk, tid); vst.load(geo, vb, ldk, kv0 + 64, Lk, tid);
+      __syncthreads();
+      if (AttnPrefetch<D>::value) {
+        kst.store(geo, Ks, Lk, tid); vst.store(geo, Vs, Lk, tid);
+      } else {
+        load_rowmajor<D, 64>(Ks, kb, ldk, kv0, Lk, tid);
+        load_rowmajor<D, 64>(Vs, vb, ldk, kv0, Lk, tid);
+      }
+      __syncthreads();
+      if (AttnPrefetch<D>::value && kv0 + 64 < Lk) {
+        kst.load(geo, kb, ldk, kv0 + 64, Lk, tid); vst.load(geo, vb, ldk, kv0 + 64, Lk, tid);
+      }
     }
     f32x16 s_[2], dp[2];
 #pragma unroll
@@ -315,6 +359,12 @@ __global__ __launch_bounds__(256, (D <= 40 ? 3 : 1)) void attn_bwd_dq_ps_kernel(
         bf16x8 vf = *(const bf16x8*)(Vs + ((32 * t + l31) * C::RKU + 2 * s + hi) * 16);
         s_[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], s_[t], 0, 0, 0);     // SLOT: s' - lse
         dp[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[s], dp[t], 0, 0, 0);    // SLOT: dP - delta
+      }
+    }
+    if constexpr (DMA) {      // after the tile's last compiler-tracked LDS reads (see the forward); the K^T reads below are untracked asm reads
+      if (kv0 + 64 < Lk) {
+        char* nx = KVs + (2 * (((kv0 >> 6) & 1) ^ 1)) * TB;
+        dma.issue(kb, ldk, kv0 + 64, Lk, nx, wave); dma.issue(vb, ldk, kv0 + 64, Lk, nx + TB, wave);
       }
     }
     // dS'^T = p * (dP - delta): the 1/sqrt(d) (times ln 2 for the log2-domain q') multiplies the output once, in the epilogue
@@ -367,17 +417,23 @@ __global__ __launch_bounds__(256, (D <= 40 ? 3 : 1)) void attn_bwd_dq_ps_kernel(
 }
 
 // ============================================================================ backward: dK, dV
-template <int D>
+// DMA (only with the slot trick, i.e. d = 40 in the bfloat16 build: without it the softmax reads the -lse / -delta side arrays with tracked
+// LDS reads late in the tile, behind which hipcc would drain a DMA issued earlier): Q / dO tiles by LDS-DMA into a double buffer, the
+// per-row (-lse, -delta) pairs written into the NEXT buffer's pad columns one tile ahead.
+template <int D, bool DMA_>
 __global__ __launch_bounds__(256) void attn_bwd_dkdv_ps_kernel(const bf16_t* q, const bf16_t* k, const bf16_t* v, const bf16_t* dO,
                                                                const float* lse, const float* delta, bf16_t* dk, bf16_t* dv, int H, int Lq,
                                                                int Lk, int ldq, int ldk, int ldo) {
   using C = AttnCfg<D>;
   using SC = SlotCfg<D>;
   constexpr bool SLOT = SC::ON;
-  __shared__ __attribute__((aligned(16))) char Qs[TileBytes<D>::value];
-  __shared__ __attribute__((aligned(16))) char Os[TileBytes<D>::value];
+  constexpr bool DMA = DMA_ && SLOT;
+  constexpr int TB = TileBytes<D>::value, NBUF = DMA ? 2 : 1;
+  __shared__ __attribute__((aligned(16))) char QOs[NBUF * 2 * TB];      // [buffer][Q, dO]
+  char* Qs = QOs;
+  char* Os = QOs + TB;
   __shared__ __attribute__((aligned(16))) float L2s[64], dls[64];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, hi = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y, kv0 = blockIdx.x * 128 + wave * 32;
   const bf16_t* qb = q + (size_t)b * Lq * ldq + h * D;
   const bf16_t* dob = dO + (size_t)b * Lq * ldo + h * D;
@@ -400,8 +456,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_ps_kernel(const bf16_t* q, 
     for (int r = 0; r < 16; r++) { acc_k[i][r] = 0.f; acc_v[i][r] = 0.f; }
   const bool kv_ok = (kv0 + l31) < Lk;
   const bool blk_full = ((int)blockIdx.x * 128 + 128) <= Lk;
-  fill_pad_chunks<D, 64>(Qs, tid, false);
-  fill_pad_chunks<D, 64>(Os, tid, false);
+#pragma unroll
+  for (int bf = 0; bf < 2 * NBUF; bf++) fill_pad_chunks<D, 64>(QOs + bf * TB, tid, false);
   const TrFrag<D> trf(lane);
   const RowGeom<D, 64> geq(ldq, tid), geo(ldo, tid);
   RowStage<D, 64> qst, ost;
@@ -421,31 +477,51 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_ps_kernel(const bf16_t* q, 
       dlr = dl_bh[qr];
     }
   };
-  // per-row -lse / -delta of the staged tile: SLOT -> (hi, lo) pairs into the tile rows' pad columns; else the fp32 side arrays
-  auto publish_rows = [&](float l2v, float dlv) {
+  // per-row -lse / -delta of a staged tile: SLOT -> (hi, lo) pairs into the tile rows' pad columns; else the fp32 side arrays
+  auto publish_rows = [&](char* qdst, char* odst, float l2v, float dlv) {
     if (tid < 64) {
       if constexpr (SLOT) {
-        *(unsigned*)(Qs + (tid * C::RKU + C::DG) * 16) = split_hi_lo(-l2v);
-        *(unsigned*)(Os + (tid * C::RKU + C::DG) * 16) = split_hi_lo(-dlv);
+        *(unsigned*)(qdst + (tid * C::RKU + C::DG) * 16) = split_hi_lo(-l2v);
+        *(unsigned*)(odst + (tid * C::RKU + C::DG) * 16) = split_hi_lo(-dlv);
       } else {
         L2s[tid] = -l2v; dls[tid] = -dlv;
       }
     }
   };
-  if (AttnPrefetch<D>::value) stage_load(0);
+  auto rows_load = [&](int q0_) {          // -lse / -delta of the 64 rows of tile q0_ (clamped on the ragged last tile)
+    int qr = q0_ + (tid & 63);
+    if (qr >= Lq) qr = Lq - 1;
+    l2r = lse_bh[qr];
+    dlr = dl_bh[qr];
+  };
+  const DmaTile<D, 64> dmaq(ldq, lane, wave), dmao(ldo, lane, wave);
+  if constexpr (DMA) {
+    rows_load(0);
+    __syncthreads();                       // the pad fills above (zeros, by other threads) before the row pairs that go into the same chunks
+    publish_rows(QOs, QOs + TB, l2r, dlr);
+    __syncthreads();                       // ... and both before any DMA'd tile is read
+    dmaq.issue(qb, ldq, 0, Lq, QOs, wave); dmao.issue(dob, ldo, 0, Lq, QOs + TB, wave);
+    if (64 < Lq) rows_load(64);
+  } else if (AttnPrefetch<D>::value) stage_load(0);
   for (int qq0 = 0; qq0 < Lq; qq0 += 64) {
-    __syncthreads();
-    if (AttnPrefetch<D>::value) {
-      qst.store(geq, Qs, Lq, tid); ost.store(geo, Os, Lq, tid);
-      publish_rows(l2r, dlr);
+    if constexpr (DMA) {
+      PCM_WAIT_VMCNT(0);
+      __syncthreads();
+      Qs = QOs + (2 * ((qq0 >> 6) & 1)) * TB; Os = Qs + TB;
     } else {
-      load_rowmajor<D, 64>(Qs, qb, ldq, qq0, Lq, tid);
-      load_rowmajor<D, 64>(Os, dob, ldo, qq0, Lq, tid);
-      const int qr = qq0 + tid;
-      publish_rows((tid < 64 && qr < Lq) ? lse_bh[qr] : 0.f, (tid < 64 && qr < Lq) ? dl_bh[qr] : 0.f);
+      __syncthreads();
+      if (AttnPrefetch<D>::value) {
+        qst.store(geq, Qs, Lq, tid); ost.store(geo, Os, Lq, tid);
+        publish_rows(Qs, Os, l2r, dlr);
+      } else {
+        load_rowmajor<D, 64>(Qs, qb, ldq, qq0, Lq, tid);
+        load_rowmajor<D, 64>(Os, dob, ldo, qq0, Lq, tid);
+        const int qr = qq0 + tid;
+        publish_rows(Qs, Os, (tid < 64 && qr < Lq) ? lse_bh[qr] : 0.f, (tid < 64 && qr < Lq) ? dl_bh[qr] : 0.f);
+      }
+      __syncthreads();
+      if (AttnPrefetch<D>::value && qq0 + 64 < Lq) stage_load(qq0 + 64);
     }
-    __syncthreads();
-    if (AttnPrefetch<D>::value && qq0 + 64 < Lq) stage_load(qq0 + 64);
     f32x16 s_[2], dp[2];
 #pragma unroll
     for (int t = 0; t < 2; t++) {
@@ -457,6 +533,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_ps_kernel(const bf16_t* q, 
         bf16x8 ofr = *(const bf16x8*)(Os + ((32 * t + l31) * C::RKU + 2 * s + hi) * 16);
         s_[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfr, kf[s], s_[t], 0, 0, 0);   // S'[q][kv]  (SLOT: - lse[q])
         dp[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ofr, vf[s], dp[t], 0, 0, 0);   // dP[q][kv]  (SLOT: - delta[q])
+      }
+    }
+    if constexpr (DMA) {
+      // the OTHER buffer is free (every wave is past this tile's barrier, i.e. done with the previous tile): first the next tile's row
+      // pairs (ordinary LDS stores, values loaded one tile ago), THEN its DMA -- a tracked LDS access after a DMA issue would make hipcc
+      // drain it -- then the global loads of the row values one tile further
+      if (qq0 + 64 < Lq) {
+        char* nx = QOs + (2 * (((qq0 >> 6) & 1) ^ 1)) * TB;
+        publish_rows(nx, nx + TB, l2r, dlr);
+        dmaq.issue(qb, ldq, qq0 + 64, Lq, nx, wave); dmao.issue(dob, ldo, qq0 + 64, Lq, nx + TB, wave);
+        if (qq0 + 128 < Lq) rows_load(qq0 + 128);
       }
     }
 #pragma unroll
@@ -526,6 +613,9 @@ bool pcm_attn_fwd_pipe_launch(const void* q, const void* k, const void* v, void*
                               int ldk, int ldo, float scale, void* stream);
 PCM_KNOB int g_attn_ps_track = 0;     // tests: 1 = run the forward with per-tile maximum tracking from the start (the fallback path of item 2)
 PCM_TOOLS_ONLY(extern "C" void pcm_debug_attn_ps_track(int on) { g_attn_ps_track = on ? 1 : 0; })
+// K / V staging of the forward: 1 = LDS-DMA double buffer (head dims <= 80), 0 = register staging; A/B hook in the tools build
+PCM_KNOB int g_attn_ps_dma = PCM_ATTN_PS_DMA_DEFAULT;
+PCM_TOOLS_ONLY(extern "C" void pcm_debug_attn_ps_dma(int on) { g_attn_ps_dma = on ? 1 : 0; })
 
 static int attn_ps_check(const char* what, const void* q, const void* k, const void* v, int B, int H, int Lq, int Lk, int d, int ldq, int ldk,
                          int ldo) {
@@ -555,9 +645,14 @@ extern "C" int pcm_attn_fwd_prescaled(const void* q, const void* k, const void* 
       pcm_attn_fwd_pipe_launch(q, k, v, o, lse, B, H, Lq, Lk, d, ldq, ldk, ldo, 1.0f / LOG2E, stream))
     return pcm_post_launch("pcm_attn_fwd_prescaled");
   dim3 grid((Lq + 127) / 128, H, B), block(256);
-#define FWD_PS_CALL(DD)                                                                                                            \
-  PCM_LAUNCH((attn_fwd_ps_kernel<DD>), grid, block, 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse, \
+#define FWD_PS_CALL_(DD, DM)                                                                                                            \
+  PCM_LAUNCH((attn_fwd_ps_kernel<DD, DM>), grid, block, 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse, \
              H, Lq, Lk, ldq, ldk, ldo, g_attn_ps_track)
+#if PCM_HAS_TOOLS
+#define FWD_PS_CALL(DD) if (g_attn_ps_dma && DD <= 80) { FWD_PS_CALL_(DD, (DD <= 80)); } else { FWD_PS_CALL_(DD, false); }
+#else
+#define FWD_PS_CALL(DD) FWD_PS_CALL_(DD, (PCM_ATTN_PS_DMA_DEFAULT && DD <= 80))
+#endif
   ATTN_PS_DISPATCH(d, FWD_PS_CALL)
   return pcm_post_launch("pcm_attn_fwd_prescaled");
 }
@@ -568,16 +663,26 @@ extern "C" int pcm_attn_bwd_prescaled(const void* q, const void* k, const void* 
   PCM_CHECK(o && dO && lse && delta && dq && PCM_ALIGNED16(o) && PCM_ALIGNED16(dO), PCM_EALIGN, "pcm_attn_bwd_prescaled: o/dO/lse/delta/dq");
   {
     dim3 grid((Lq + 127) / 128, H, B), block(256);
-#define DQ_PS_CALL(DD)                                                                                                             \
-  PCM_LAUNCH((attn_bwd_dq_ps_kernel<DD>), grid, block, 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)dO, \
+#define DQ_PS_CALL_(DD, DM)                                                                                                        \
+  PCM_LAUNCH((attn_bwd_dq_ps_kernel<DD, DM>), grid, block, 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)dO, \
              lse, delta, (const bf16_t*)o, (bf16_t*)dq, H, Lq, Lk, ldq, ldk, ldo)
+#if PCM_HAS_TOOLS
+#define DQ_PS_CALL(DD) if (g_attn_ps_dma && DD <= 80) { DQ_PS_CALL_(DD, (DD <= 80)); } else { DQ_PS_CALL_(DD, false); }
+#else
+#define DQ_PS_CALL(DD) DQ_PS_CALL_(DD, (PCM_ATTN_PS_DMA_DEFAULT && DD <= 80))
+#endif
     ATTN_PS_DISPATCH(d, DQ_PS_CALL)
   }
   if (dk && dv) {
     dim3 grid((Lk + 127) / 128, H, B), block(256);
-#define DKV_PS_CALL(DD)                                                                                                            \
-  PCM_LAUNCH((attn_bwd_dkdv_ps_kernel<DD>), grid, block, 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)dO, \
+#define DKV_PS_CALL_(DD, DM)                                                                                                       \
+  PCM_LAUNCH((attn_bwd_dkdv_ps_kernel<DD, DM>), grid, block, 0, stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)dO, \
              lse, delta, (bf16_t*)dk, (bf16_t*)dv, H, Lq, Lk, ldq, ldk, ldo)
+#if PCM_HAS_TOOLS
+#define DKV_PS_CALL(DD) if (g_attn_ps_dma && DD <= 80) { DKV_PS_CALL_(DD, (DD <= 80)); } else { DKV_PS_CALL_(DD, false); }
+#else
+#define DKV_PS_CALL(DD) DKV_PS_CALL_(DD, (PCM_ATTN_PS_DMA_DEFAULT && DD <= 80))
+#endif
     ATTN_PS_DISPATCH(d, DKV_PS_CALL)
   }
   return pcm_post_launch("pcm_attn_bwd_prescaled");

@@ -181,6 +181,51 @@ struct RowStage {
     }
   }
 };
+// ---- LDS-DMA staging (csrc/attention_ps.hip, round 5): a ROWS x D row-major tile goes from global memory straight into the padded LDS
+// image (buffer_load ... lds, 16 B per lane, no VGPR round trip, no ds_write).  Wave-instruction j of a tile fills LDS pieces 64j .. 64j+63
+// (16 B each, contiguous: the DMA writes LDS linearly); piece p = row p / RKU, chunk p % RKU of the image.  Lanes that fall on the pad chunks
+// of a row are MASKED OFF, so the pad keeps what fill_pad_chunks put there once (zeros, or the ones columns of the slot / row-sum
+// tricks); rows beyond the tensor are fetched out of range, i.e. zero-filled by the buffer hardware.  The four waves split the
+// instructions of a tile round-robin.  All per-lane geometry is computed once per kernel.
+template <int D, int ROWS>
+struct DmaTile {
+  using C = AttnCfg<D>;
+  static constexpr int NI = (ROWS * C::RKU + 63) / 64;     // wave-instructions per tile (7 at d = 40)
+  static constexpr int PW = (NI + 3) / 4;                  // ... per wave
+  static_assert((ROWS * C::RKU) % 64 == 0, "tile image must be whole 1-KiB DMA instructions");
+  unsigned voff[PW];
+  int row[PW];
+  bool act[PW];
+  __device__ __forceinline__ DmaTile(int ld, int lane, int wave) {
+#pragma unroll
+    for (int i = 0; i < PW; i++) {
+      const int j = wave + 4 * i, p = 64 * j + lane, r = p / C::RKU, c = p - r * C::RKU;
+      act[i] = j < NI && c < C::DG;
+      row[i] = r;
+      voff[i] = (unsigned)(r * ld + 8 * c) * 2u;
+    }
+  }
+  // tile rows row0 .. row0 + ROWS - 1 of ``src`` (row stride ld elements) -> image at ``dst`` (wave-uniform LDS address)
+  __device__ __forceinline__ void issue(const bf16_t* src, int ld, int row0, int nrows_valid, char* dst, int wave) const {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, 0x80000000u, 0x00020000);
+    const unsigned soff = (unsigned)(row0 * ld) * 2u;
+    const int left = nrows_valid - row0;           // rows of this tile inside the tensor
+    if (left >= ROWS) {                            // full tile (wave-uniform test, kept a real branch): no per-lane validity select
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < PW; i++) {
+        const int j = wave + 4 * i;
+        if (j < NI) PCM_DMA16_MASKED(rs, dst + 1024 * j, voff[i], soff, act[i]);
+      }
+      return;
+    }
+#pragma unroll
+    for (int i = 0; i < PW; i++) {
+      const int j = wave + 4 * i;
+      if (j < NI) PCM_DMA16_MASKED(rs, dst + 1024 * j, row[i] < left ? voff[i] : 0x80000000u, soff, act[i]);
+    }
+  }
+};
 template <int D> struct AttnPrefetch { static constexpr bool value = D <= 80; };
 // LDS bytes of one row-major tile; the k-along-rows reads of the last 32-column group run up to 32*DV columns wide, i.e. past the end
 // of short rows into the next row (finite data feeding accumulator rows >= D that are never stored) -- 64 B of slack behind the last row

@@ -15,6 +15,11 @@
 // counted waits for hand-pipelined LDS-DMA loops (hipcc never emits these for LDS-DMA -> ds_read dependences)
 #define PCM_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define PCM_WAIT_LGKMCNT0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+// 16-byte-per-lane LDS-DMA with lanes masked off: an inactive lane transfers nothing and its LDS slot keeps its contents (EXEC mask)
+#define PCM_DMA16_MASKED(rs, lds, voff, soff, active)                                                   \
+  do {                                                                                                  \
+    if (active) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, PCM_AS3(lds), 16, voff, soff, 0, 0);       \
+  } while (0)
 #endif
 #include <stdint.h>
 #include <string.h>

@@ -244,6 +244,20 @@ inline void buffer_load_lds(BufferRsrc rs, void* lds, int size, uint32_t voff, u
   dma_issue((char*)w.lp[bsel][0] + (size_t)l * size, oob ? nullptr : rs.base + voff + soff, size);
 }
 
+// the same with an EXEC mask: every lane of the wave makes the call (the emulator's wave rendezvous needs all of them), inactive lanes
+// transfer nothing and leave their LDS slot untouched -- what `if (active) buffer_load ... lds` does on the hardware
+inline void buffer_load_lds_masked(BufferRsrc rs, void* lds, int size, uint32_t voff, uint32_t soff, bool active) {
+  WaveScratch& w = wave();
+  int bsel = w.gen & 1, l = lane_id();
+  w.lp[bsel][l] = lds;
+  w.u64[bsel][l] = soff;
+  wave_sync();
+  if (w.u64[bsel][0] != soff) { fprintf(stderr, "emu: buffer_load_lds soffset must be wave-uniform\n"); abort(); }
+  if (!active) return;
+  bool oob = soff > rs.num_records || voff >= rs.num_records - soff;
+  dma_issue((char*)w.lp[bsel][0] + (size_t)l * size, oob ? nullptr : rs.base + voff + soff, size);
+}
+
 // plain buffer load of 16 bytes per lane (register destination): same address rule as buffer_load_lds, synchronous
 typedef int emu_v4i __attribute__((ext_vector_type(4)));
 inline emu_v4i buffer_load_b128(BufferRsrc rs, uint32_t voff, uint32_t soff, int) {
@@ -274,6 +288,7 @@ typedef pcm_emu::BufferRsrc __amdgpu_buffer_rsrc_t;
 #define __builtin_amdgcn_make_buffer_rsrc(p, stride, n, flags) pcm_emu::make_buffer_rsrc((const void*)(p), stride, n, flags)
 #define __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, l, size, voff, soff, imm, aux) pcm_emu::buffer_load_lds(rs, (void*)(l), size, voff, soff, imm, aux)
 #define __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, aux) pcm_emu::buffer_load_b128(rs, voff, soff, aux)
+#define PCM_DMA16_MASKED(rs, lds, voff, soff, active) pcm_emu::buffer_load_lds_masked(rs, (void*)(lds), 16, voff, soff, active)
 #define PCM_WAIT_VMCNT(n) pcm_emu::wait_vmcnt(n)
 #define PCM_WAIT_LGKMCNT0() ((void)0)
 

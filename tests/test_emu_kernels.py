@@ -153,16 +153,21 @@ def test_attention(B, H, Lq, Lk, d, spike):
 
 @pytest.mark.parametrize("B,H,Lq,Lk,d,spike", [(1, 2, 100, 77, 40, False), (2, 1, 70, 130, 80, True), (1, 1, 40, 64, 160, False), (1, 1, 300, 330, 40, True),
                                                (1, 2, 90, 90, 64, True), (1, 1, 33, 64, 40, False), (1, 1, 70, 13, 40, False), (1, 1, 40, 400, 32, True)])
-@pytest.mark.parametrize("track", [0, 1])
-def test_attention_prescaled_query(B, H, Lq, Lk, d, spike, track):
+@pytest.mark.parametrize("track,dma", [(0, 1), (1, 1), (0, 0)])
+def test_attention_prescaled_query(B, H, Lq, Lk, d, spike, track, dma, monkeypatch):
     """csrc/attention_ps.hip: forward + dQ' + dK/dV with the softmax scale folded into q (spare-slot reference subtraction at d = 40, no
-    running maximum after the first key tile); track = 1 forces the per-tile maximum tracking the overflow fallback runs"""
+    running maximum after the first key tile); track = 1 forces the per-tile maximum tracking the overflow fallback runs; dma: K / V (Q / dO)
+    tiles by double-buffered LDS-DMA (run with the emulator's DMA landing lazily, i.e. only at the counted wait: a read placed before its
+    wait would see stale LDS) or through registers"""
+    monkeypatch.setenv("PCM_EMU_LAZY_DMA", "1")
     dll = capi.lib().dll
     dll.pcm_debug_attn_ps_track(track)
+    dll.pcm_debug_attn_ps_dma(dma)
     try:
         K.case_attention("cpu", B, H, Lq, Lk, d, spike, prescaled=True)
     finally:
         dll.pcm_debug_attn_ps_track(0)
+        dll.pcm_debug_attn_ps_dma(1)
 
 
 @pytest.mark.parametrize("B,H,Lq,Lk,d", [(1, 2, 70, 330, 40), (1, 1, 40, 200, 64), (1, 1, 140, 150, 80)])

@@ -121,17 +121,19 @@ def test_attention_pipelined_forward(B, H, Lq, Lk, d, at):
 @pytest.mark.parametrize("B,H,Lq,Lk,d,spike", [(1, 8, 1024, 1024, 40, False), (2, 8, 256, 77, 80, False), (2, 8, 256, 256, 160, True),
                                                (1, 2, 4096, 4096, 40, True), (1, 8, 4096, 77, 40, False), (2, 8, 1024, 1024, 80, True),
                                                (1, 20, 1024, 1024, 64, True), (1, 10, 2176, 2176, 64, False)])
-@pytest.mark.parametrize("track", [0, 1])
-def test_attention_prescaled_query(B, H, Lq, Lk, d, spike, track):
+@pytest.mark.parametrize("track,dma", [(0, 1), (1, 1), (0, 0)])
+def test_attention_prescaled_query(B, H, Lq, Lk, d, spike, track, dma):
     """csrc/attention_ps.hip at the step's shapes (SD1.5 levels, text cross-attention, SDXL head dim 64): the softmax scale lives in q, the
     reference subtraction rides the MFMA at d = 40, no running maximum after the first tile; track = 1: the tracking fallback from the start"""
     from pcm_amd import capi
     dll = capi.lib().dll
     dll.pcm_debug_attn_ps_track(track)
+    dll.pcm_debug_attn_ps_dma(dma)            # K / V (Q / dO) tiles by double-buffered LDS-DMA, or through registers
     try:
         K.case_attention("cuda", B, H, Lq, Lk, d, spike, prescaled=True)
     finally:
         dll.pcm_debug_attn_ps_track(0)
+        dll.pcm_debug_attn_ps_dma(1)
 
 
 @pytest.mark.parametrize("B,H,Lq,Lk,d", [(1, 8, 1024, 1024, 40), (1, 10, 1024, 1024, 64)])

@@ -94,6 +94,7 @@ def _oracle_parity_whole_step(cfg, W, dev):
     assert sk_rel(sketch(p_before), ref["sk_param_before"]) < 1e-6          # the fixture was made from the same seeded LoRA factors
     _, scfg = S.sdxl_step_cfgs()
     D = Distiller(W, lora, scfg)
+    gsc = float(D.loss_scale_dev.item()) if D.loss_scale_dev is not None else 1.0      # half build (tests/test_gpu_fp16.py): the gradient buffers hold S * grad
     cu = lambda v: {k: x.to(dev) for k, x in v.items()} if isinstance(v, dict) else v.to(dev)   # noqa: E731
     out = D.step(*(cu(inp[k]) for k in ("latents", "prompt_embeds", "uncond_prompt_embeds", "noise", "index", "w")),
                  added_cond=cu(inp["added_cond"]), uncond_added_cond=cu(inp["uncond_added_cond"]))
@@ -104,9 +105,9 @@ def _oracle_parity_whole_step(cfg, W, dev):
     rep = {k: rel(out[k], ref[k]) for k in S.SDXL_STEP_KEYS if k in out}
     loss, rloss = float(out["loss"].item()), float(ref["loss"])
     rep["loss_rel"] = abs(loss - rloss) / abs(rloss)
-    gn = math.sqrt(float(out["grad_sumsq"].item()))
+    gn = math.sqrt(float(out["grad_sumsq"].item())) / gsc
     rep["grad_norm_rel"] = abs(gn - float(ref["grad_norm"])) / float(ref["grad_norm"])
-    sg = sketch(S.lora_flat(lora, "g"))
+    sg = sketch(S.lora_flat(lora, "g")) / gsc
     rep["grad_rel"], rep["grad_cos"] = sk_rel(sg, ref["sk_grad"]), sk_cos(sg, ref["sk_grad"])
     p_after = S.lora_flat(lora, "p")
     rep["param_rel"] = sk_rel(sketch(p_after), ref["sk_param_after"])

@@ -8,7 +8,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "phased-consistency-model_amd"))
 import torch
 from pcm_amd import ops, capi
-capi.lib()
+capi.set_lib(capi.tools_lib())      # the TOOLS build of the library: pcm_debug_attn_ps_dma selects the staging of the new kernels
+dll = capi.lib().dll
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 
 
@@ -47,19 +48,24 @@ for (B, L, Lk, d, H) in [(32, 4096, 4096, 40, 8), (16, 4096, 4096, 40, 8), (32, 
     o1, l1 = ops.attn_fwd(qs, k, v, H, d, prescaled=True)
     g0 = ops.attn_bwd(q, k, v, o0, dO, l0, H, d)
     g1 = ops.attn_bwd(qs, k, v, o1, dO, l1, H, d, prescaled=True)
-    for key in ("f0", "f1", "b0", "b1"):
+    for key in ("f0", "f1", "b0", "b1", "f2", "b2"):
         t[key] = 1e9
     for _ in range(rounds):
         t["f0"] = min(t["f0"], bench(lambda: ops.attn_fwd(q, k, v, H, d)))
-        t["f1"] = min(t["f1"], bench(lambda: ops.attn_fwd(qs, k, v, H, d, prescaled=True)))
         t["b0"] = min(t["b0"], bench(lambda: ops.attn_bwd(q, k, v, o0, dO, l0, H, d)))
+        dll.pcm_debug_attn_ps_dma(1)
+        t["f1"] = min(t["f1"], bench(lambda: ops.attn_fwd(qs, k, v, H, d, prescaled=True)))
         t["b1"] = min(t["b1"], bench(lambda: ops.attn_bwd(qs, k, v, o1, dO, l1, H, d, prescaled=True)))
+        dll.pcm_debug_attn_ps_dma(0)            # register staging of the same kernels
+        t["f2"] = min(t["f2"], bench(lambda: ops.attn_fwd(qs, k, v, H, d, prescaled=True)))
+        t["b2"] = min(t["b2"], bench(lambda: ops.attn_bwd(qs, k, v, o1, dO, l1, H, d, prescaled=True)))
+        dll.pcm_debug_attn_ps_dma(1)
     nb = min(B, 2)       # accuracy on the first images only (fp32 reference on the GPU)
     sl = lambda x: x[:nb]    # noqa: E731
     r0 = ref_fp32(sl(q), sl(k), sl(v), sl(dO), H, d, d ** -0.5)
     r1 = ref_fp32(sl(qs), sl(k), sl(v), sl(dO), H, d, 0.6931471805599453)
     e0 = [rel(sl(a), b) for a, b in zip((o0,) + tuple(g0), r0)]
     e1 = [rel(sl(a), b) for a, b in zip((o1,) + tuple(g1), r1)]
-    print("B=%2d H=%2d L=%4d Lk=%4d d=%3d | fwd %7.3f -> %7.3f ms (x%.3f, %4.0f -> %4.0f TF/s) | bwd %7.3f -> %7.3f ms (x%.3f) | rel-L2 o/dq/dk/dv old %s new %s"
-          % (B, H, L, Lk, d, t["f0"], t["f1"], t["f0"] / t["f1"], fl / t["f0"] / 1e9, fl / t["f1"] / 1e9, t["b0"], t["b1"], t["b0"] / t["b1"],
+    print("B=%2d H=%2d L=%4d Lk=%4d d=%3d | fwd %7.3f -> %7.3f ms (x%.3f, %4.0f -> %4.0f TF/s; register staging %7.3f) | bwd %7.3f -> %7.3f ms (x%.3f; register staging %7.3f) | rel-L2 o/dq/dk/dv old %s new %s"
+          % (B, H, L, Lk, d, t["f0"], t["f1"], t["f0"] / t["f1"], fl / t["f0"] / 1e9, fl / t["f1"] / 1e9, t["f2"], t["b0"], t["b1"], t["b0"] / t["b1"], t["b2"],
              " ".join("%.1e" % x for x in e0), " ".join("%.1e" % x for x in e1)), flush=True)
