@@ -608,6 +608,23 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_ps_kernel(const bf16_t* q, 
   }
 }
 
+// Explicit instantiations of every (head dim, staging) pair the launchers below name.  (hipcc 7.2 emitted no host-side launch stub for some
+// of the DMA-staged kernels when they were only instantiated implicitly through the launch macros: "undefined symbol __device_stub__..."
+// at dlopen; the explicit form is emitted unconditionally.)
+#define PCM_ATTN_PS_INST(DD, DM)                                                                                                              \
+  template __global__ void attn_fwd_ps_kernel<DD, DM>(const bf16_t*, const bf16_t*, const bf16_t*, bf16_t*, float*, int, int, int, int, int, int, int); \
+  template __global__ void attn_bwd_dq_ps_kernel<DD, DM>(const bf16_t*, const bf16_t*, const bf16_t*, const bf16_t*, const float*, float*,     \
+                                                         const bf16_t*, bf16_t*, int, int, int, int, int, int);                                \
+  template __global__ void attn_bwd_dkdv_ps_kernel<DD, DM>(const bf16_t*, const bf16_t*, const bf16_t*, const bf16_t*, const float*,           \
+                                                           const float*, bf16_t*, bf16_t*, int, int, int, int, int, int);
+#if PCM_HAS_TOOLS
+PCM_ATTN_PS_INST(32, true) PCM_ATTN_PS_INST(40, true) PCM_ATTN_PS_INST(64, true) PCM_ATTN_PS_INST(80, true)
+PCM_ATTN_PS_INST(32, false) PCM_ATTN_PS_INST(40, false) PCM_ATTN_PS_INST(64, false) PCM_ATTN_PS_INST(80, false) PCM_ATTN_PS_INST(160, false)
+#else
+PCM_ATTN_PS_INST(32, (PCM_ATTN_PS_DMA_DEFAULT != 0)) PCM_ATTN_PS_INST(40, (PCM_ATTN_PS_DMA_DEFAULT != 0)) PCM_ATTN_PS_INST(64, (PCM_ATTN_PS_DMA_DEFAULT != 0))
+PCM_ATTN_PS_INST(80, (PCM_ATTN_PS_DMA_DEFAULT != 0)) PCM_ATTN_PS_INST(160, false)
+#endif
+
 // ============================================================================ C ABI
 bool pcm_attn_fwd_pipe_launch(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int Lq, int Lk, int d, int ldq,
                               int ldk, int ldo, float scale, void* stream);

@@ -4,6 +4,7 @@
 # -DPCM_ATTN_PS_DMA_DEFAULT=0), interleaved twice; (2) run-to-run repeatability of the LoRA gradient, atomics vs reproducible forms
 # (tools/grad_repeatability.py); (3) the attention kernel tests on both stagings
 cd $GRAFT_REPO_ROOT; O=gpurun_out/r05c; mkdir -p $O; export TMPDIR=/tmp
+python -c "import sys; sys.path.insert(0, \"phased-consistency-model_amd\"); from pcm_amd import capi; [capi.Lib(p) for p in (capi.DEFAULT_LIB, capi.TOOLS_LIB, \"tools/probes/libpcm_nodma.so\")]; print(\"libs load\")" || exit 7
 timeout 300 python tools/attn_ps_ab.py 3 > $O/attn_ps_ab.txt 2>&1; echo "attn ab rc=$?" >> $O/rc.log
 timeout 600 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_product_lib.py -q -k "attention or product" > $O/pytest_attention.txt 2>&1; echo "pytest rc=$?" >> $O/rc.log
 timeout 300 python tools/grad_repeatability.py 16 > $O/grad_repeatability.txt 2>&1; echo "repeat rc=$?" >> $O/rc.log
