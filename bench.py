@@ -469,7 +469,7 @@ def main():
         # the dominant kernel of the step (rocprofv3: ~41 % of the kernel time) is the 256x320 phased tile pcm_gemm8p_kernel<3,false,false>
         # (plan code 5xxx of pcm_gemm_plan_code); the family aggregate is reported next to it
         dom = [(p[0], t, p[5]) for p, t in zip(prof, times) if p[4] // 1000 == 5]
-        d_fl, d_ms = sum(x[0] for x in dom), sum(x[1] for x in dom)
+        d_fl, d_ms, d_nb = sum(x[0] for x in dom), sum(x[1] for x in dom), sum(x[2] for x in dom)
         ach = d_fl / (d_ms * 1e-3) / 1e12 if dom else fam
         # The kernel's launches fall into two classes with different roofs.  A launch is "hbm" when moving its ALGORITHMIC bytes at the
         # 8 TB/s peak takes longer than its flops at the 2.5 PFLOP/s peak (arithmetic intensity below 312 flop/byte: the 1x1 / linear
@@ -509,7 +509,22 @@ def main():
         # correction calibrated on a known copy): profiles/r02_pmc_gemm8p_traffic.json (round 1: r01_e_...).  It is for ONE launch of the largest
         # 64x64-resolution conv (M=131072, 320->320 + LoRA; algorithmic 186 MB): the 9 taps re-read the activation tile through
         # the fabric (served by the 256 MB Infinity Cache, not by HBM); see DESIGN.md section 6.
-        traffic, traffic_note, traffic_source = None, None, None
+        traffic, traffic_note, traffic_source, pmc = None, None, None, None
+        try:
+            # the per-kernel PMC table of one eager step on the final tree (tools/jobs/r05_e_pmc.sh -> tools/pmc_step_table.py: three separate
+            # rocprofv3 --pmc passes): MFMA utilisation and fabric-side bytes of THIS kernel averaged over all its launches of a step -- the same
+            # population `achieved` is taken over.  Committed measurement, named here; a PMC pass cannot run inside the timed process.
+            import glob
+            tabs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_step_table.txt")))
+            for ln in open(tabs[-1]):
+                if ln.startswith("void pcm_gemm8p_kernel<3, false, false>"):
+                    f = ln.split()
+                    calls, dur_ms, util, rd, wr, gbs = int(f[-8]), float(f[-7]), float(f[-6]), float(f[-3]), float(f[-2]), float(f[-1])
+                    pmc = {"source": "profiles/" + os.path.basename(tabs[-1]), "launches": calls, "kernel_ms": dur_ms, "mfma_util": util,
+                           "read_MB_per_launch": rd, "write_MB_per_launch": wr, "fabric_GB_s": gbs,
+                           "note": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 128); FETCH_SIZE x 2 (gfx950) and WRITE_SIZE, separate passes"}
+        except Exception:
+            pmc = None
         try:
             # NOT measured in this run (PMC passes need their own rocprofv3 runs): the newest committed measurement is copied in and named
             import glob
@@ -518,14 +533,22 @@ def main():
                            key=lambda f: (int(re.match(r"r(\d+)", os.path.basename(f)).group(1)), os.path.basename(f)))
             pj = json.load(open(cands[-1]))
             kern = pj["kernel"] if "kernel" in pj else pj["tap_outer_K_order (shipped)"]
+            if pmc is not None:      # per average launch of the step (same population as `achieved`), from the PMC table above
+                raise LookupError
             traffic = round(kern["traffic_MB_corrected"] * 1e6)
             traffic_source = "profiles/" + os.path.basename(cands[-1]) + " (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 per the gfx950 note; not re-measured by this run)"
             traffic_note = "bytes per launch of the M=131072 320->320 conv3x3 (+LoRA) launch of this kernel; algorithmic %.0f MB" % (
                 pj["algorithmic_MB"]["read"] + pj["algorithmic_MB"]["write"])
         except Exception:
             pass
+        if pmc is not None:
+            traffic = round((pmc["read_MB_per_launch"] + pmc["write_MB_per_launch"]) * 1e6)
+            traffic_source = pmc["source"] + " (committed rocprofv3 --pmc passes over one eager step of this tree; not re-measured by this run)"
+            traffic_note = "fabric-side bytes per AVERAGE launch of this kernel over the %d launches of a step (Infinity-Cache hits included); algorithmic %.0f MB per average launch" % (
+                len(dom), d_nb / max(1, len(dom)) / 1e6)
         roofline = {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_note": traffic_note, "traffic_source": traffic_source,
+                    "pmc": pmc,
                     "kernel": "pcm_gemm8p_kernel<3,false,false> (256x320 phased tile; all its launches of one step)",
                     "launches": len(dom), "avg_launch_us": round(1e3 * d_ms / max(1, len(dom)), 1),
                     "algorithmic_tflop": round(d_fl / 1e12, 2), "kernel_ms_per_step": round(d_ms, 2), "classes": classes,

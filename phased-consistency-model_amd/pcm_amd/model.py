@@ -113,6 +113,20 @@ class UNetWeights:
                 self.qkv[base] = torch.cat([lq.w_fwd.view(lq.N, lq.K), lk.w_fwd.view(lk.N, lk.K), lv.w_fwd.view(lv.N, lv.K)]).contiguous()
                 if need_bwd and lq.N == lk.N == lv.N:   # dgrad operand of the fused projection: [K][3N] = [Wq^T | Wk^T | Wv^T]
                     self.qkv_bwd[base] = torch.cat([lq.w_bwd.view(lq.K, lq.N), lk.w_bwd.view(lk.K, lk.N), lv.w_bwd.view(lv.K, lv.N)], dim=1).contiguous()
+        # cross-attention K / V of the frozen pass: the text embeddings are the SAME input for every transformer block, so all their to_k / to_v
+        # projections are ONE GEMM per pass (rows [Wk_0; Wv_0; Wk_1; ...], 32 launches of 14-17 us -> one at SD1.5 size); attention reads
+        # each block's K / V in place with the wide row stride
+        self.kv_cat, self.kv_off = None, {}
+        kv_paths = [p_[:-4] for p_ in self.layers if p_.endswith("attn2.to_k")]
+        if kv_paths and all(self.layers[b + n].bias is None for b in kv_paths for n in ("to_k", "to_v")) and \
+                len({self.layers[b + "to_k"].K for b in kv_paths}) == 1:
+            off, rows = 0, []
+            for b in kv_paths:
+                lk, lv = self.layers[b + "to_k"], self.layers[b + "to_v"]
+                self.kv_off[b] = (off, lk.N)
+                rows += [lk.w_fwd.view(lk.N, lk.K), lv.w_fwd.view(lv.N, lv.K)]
+                off += lk.N + lv.N
+            self.kv_cat = torch.cat(rows).contiguous()
         self.conv_in = (state_dict["conv_in.weight"].to(**f32).contiguous(), state_dict["conv_in.bias"].to(**f32).contiguous())
         self.conv_out = (state_dict["conv_out.weight"].to(**f32).contiguous(), state_dict["conv_out.bias"].to(**f32).contiguous())
 
@@ -135,6 +149,8 @@ class HalfSaved:
 
 # debug hook: PCM_FUSE_GEGLU=0 keeps the feed-forward's GEGLU as a separate pass in the grad-requiring forward (A/B measurement)
 FUSE_GEGLU_GRAD = os.environ.get("PCM_FUSE_GEGLU", "1") != "0"
+# debug hook: PCM_TEXT_KV=0 runs the frozen pass's cross-attention K / V projections layer by layer (A/B measurement)
+FUSE_TEXT_KV = os.environ.get("PCM_TEXT_KV", "1") != "0"
 # debug hook: PCM_LORA_QKV=0 runs the self-attention q/k/v LoRA projections as three separate layers (A/B measurement)
 FUSE_LORA_QKV = os.environ.get("PCM_LORA_QKV", "1") != "0"
 
@@ -467,6 +483,7 @@ class UNet:
     def __init__(self, weights: UNetWeights, lora: LoraState = None):
         self.W, self.lora, self.cfg = weights, lora, weights.cfg
         self._arena = None      # per-pass arena of pre-zeroed GroupNorm statistics (ops.StatArena)
+        self._kv_all = None     # frozen pass: every cross-attention's K / V projection of the text, one GEMM (UNetWeights.kv_cat)
         self._side = None       # WgradSide of this runner's backward passes
         self._save_half = False
 
@@ -559,6 +576,12 @@ class UNet:
                 sv.update(fused=True, x=xn, t3=t3, so=so, q=q, k=k, v=v, o=o, lse=lse, L=L, Lk=Lk)
             return out
         q = layer_fwd(W, lora, p + "to_q", xn, M, save=sq)
+        if lora is None and sv is None and self._kv_all is not None and p in W.kv_off:
+            # frozen pass: this block's K / V are column slices of the pass-wide text projection (UNetWeights.kv_cat)
+            off, Ck = W.kv_off[p]
+            kv = self._kv_all.view(B, Lk, -1)
+            o, lse = ops.attn_fwd(q.view(B, L, C), kv[:, :, off:off + Ck], kv[:, :, off + Ck:off + 2 * Ck], Hh, d, prescaled=True)
+            return layer_fwd(W, lora, p + "to_out.0", o.view(M, C), M, residual=resid)
         k = layer_fwd(W, lora, p + "to_k", ctx, Mk, save=sk)
         v = layer_fwd(W, lora, p + "to_v", ctx, Mk, save=svv)
         o, lse = ops.attn_fwd(q.view(B, L, C), k.view(B, Lk, C), v.view(B, Lk, C), Hh, d, prescaled=True)
@@ -709,6 +732,11 @@ class UNet:
         tape = [] if save else None
         self._arena = ops.StatArena.for_pass(sample.device, W, B, cfg.norm_num_groups)
         text = encoder_hidden_states if encoder_hidden_states.dtype == BF16 else ops.cast_bf16(encoder_hidden_states.contiguous())
+        self._kv_all = None
+        if lora is None and not save and W.kv_cat is not None and FUSE_TEXT_KV:
+            Mt = text.shape[0] * text.shape[1]
+            self._kv_all = torch.empty(Mt, W.kv_cat.shape[0], dtype=BF16, device=text.device)
+            ops.gemm([Seg(text.view(Mt, -1), W.kv_cat)], Mt, W.kv_cat.shape[0], self._kv_all)
         t_emb = ops.timestep_embedding(timesteps, boc[0])
         e1 = layer_fwd(W, None, "time_embedding.linear_1", t_emb, B, act=capi.ACT_SILU)
         if cfg.addition_time_embed_dim:

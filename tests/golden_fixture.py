@@ -62,6 +62,20 @@ def path(name):
     return os.path.join(GOLDEN, "step_%s.safetensors" % name)
 
 
+def source_stamp():
+    """what a fixture was computed FROM: sha256 over the oracle sources and the builders, plus the torch version.  Stored in the
+    fixture's metadata when it is written; ``load`` warns when a stamped fixture no longer matches the tree (a later edit of oracle/*.py
+    or of the seeded input builders would otherwise leave the GPU tests comparing against stale numbers without anyone noticing)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    root = os.path.dirname(HERE)
+    for f in sorted(glob.glob(os.path.join(root, "oracle", "*.py"))) + [os.path.join(HERE, n) for n in ("step_golden_cases.py", "adv_cases.py")]:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return {"oracle_sha256": h.hexdigest(), "torch": torch.__version__}
+
+
 def save(name, d):
     """d: {key: tensor | float | int | list of floats}.  Scalars / lists go to the metadata JSON (exact repr)."""
     from safetensors.torch import save_file
@@ -74,7 +88,14 @@ def save(name, d):
             meta[k] = v
     if not tensors:
         tensors["_empty"] = torch.zeros(1)
-    save_file(tensors, path(name), metadata={"scalars": json.dumps(meta)})
+    save_file(tensors, path(name), metadata={"scalars": json.dumps(meta), "stamp": json.dumps(source_stamp())})
+
+
+def stamp_of(name):
+    from safetensors import safe_open
+    with safe_open(path(name), framework="pt") as f:
+        s = (f.metadata() or {}).get("stamp")
+    return json.loads(s) if s else None
 
 
 def load(name):
@@ -84,7 +105,14 @@ def load(name):
         for k in f.keys():
             if k != "_empty":
                 out[k] = f.get_tensor(k)
-        out.update(json.loads((f.metadata() or {}).get("scalars", "{}")))
+        md = f.metadata() or {}
+        out.update(json.loads(md.get("scalars", "{}")))
+    if md.get("stamp"):      # (fixtures written before round 5 carry no stamp)
+        st, now = json.loads(md["stamp"]), source_stamp()
+        if st.get("oracle_sha256") != now["oracle_sha256"]:
+            import warnings
+            warnings.warn("oracle fixture %s was written from other oracle / builder sources than this tree's (stamp %s..., tree %s...): "
+                          "re-run tests/golden/make_golden_step.py --only %s" % (name, st.get("oracle_sha256", "")[:10], now["oracle_sha256"][:10], name))
     return out
 
 
