@@ -420,8 +420,11 @@ __global__ __launch_bounds__(256, (D <= 40 ? 3 : 1)) void attn_bwd_dq_ps_kernel(
 // DMA (only with the slot trick, i.e. d = 40 in the bfloat16 build: without it the softmax reads the -lse / -delta side arrays with tracked
 // LDS reads late in the tile, behind which hipcc would drain a DMA issued earlier): Q / dO tiles by LDS-DMA into a double buffer, the
 // per-row (-lse, -delta) pairs written into the NEXT buffer's pad columns one tile ahead.
+#ifndef PCM_ATTN_DKDV_WAVES      // minimum waves per SIMD of the d <= 40 instantiations (A/B builds: -DPCM_ATTN_DKDV_WAVES=3 spills 38 registers)
+#define PCM_ATTN_DKDV_WAVES 1
+#endif
 template <int D, bool DMA_>
-__global__ __launch_bounds__(256) void attn_bwd_dkdv_ps_kernel(const bf16_t* q, const bf16_t* k, const bf16_t* v, const bf16_t* dO,
+__global__ __launch_bounds__(256, (D <= 40 ? PCM_ATTN_DKDV_WAVES : 1)) void attn_bwd_dkdv_ps_kernel(const bf16_t* q, const bf16_t* k, const bf16_t* v, const bf16_t* dO,
                                                                const float* lse, const float* delta, bf16_t* dk, bf16_t* dv, int H, int Lq,
                                                                int Lk, int ldq, int ldk, int ldo) {
   using C = AttnCfg<D>;

@@ -11,6 +11,18 @@ from pcm_amd import ops, capi
 capi.set_lib(capi.tools_lib())      # the TOOLS build of the library: pcm_debug_attn_ps_dma selects the staging of the new kernels
 dll = capi.lib().dll
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+# optional third arm: the pre-scaled kernels of ANOTHER build of the library (a tools/probes/build_variant.py variant), e.g. a different
+# launch bound / staging of one kernel:  attn_ps_ab.py 3 tools/probes/libpcm_<name>.so
+ALT = capi.Lib(os.path.abspath(sys.argv[2])) if len(sys.argv) > 2 else None
+MAIN = capi.lib()
+
+
+def with_alt(fn):
+    capi.set_lib(ALT)
+    try:
+        return fn()
+    finally:
+        capi.set_lib(MAIN)
 
 
 def bench(fn, n=6):
@@ -60,6 +72,9 @@ for (B, L, Lk, d, H) in [(32, 4096, 4096, 40, 8), (16, 4096, 4096, 40, 8), (32, 
         t["f2"] = min(t["f2"], bench(lambda: ops.attn_fwd(qs, k, v, H, d, prescaled=True)))
         t["b2"] = min(t["b2"], bench(lambda: ops.attn_bwd(qs, k, v, o1, dO, l1, H, d, prescaled=True)))
         dll.pcm_debug_attn_ps_dma(1)
+        if ALT is not None:
+            t["f3"] = min(t.get("f3", 1e9), with_alt(lambda: bench(lambda: ops.attn_fwd(qs, k, v, H, d, prescaled=True))))
+            t["b3"] = min(t.get("b3", 1e9), with_alt(lambda: bench(lambda: ops.attn_bwd(qs, k, v, o1, dO, l1, H, d, prescaled=True))))
     nb = min(B, 2)       # accuracy on the first images only (fp32 reference on the GPU)
     sl = lambda x: x[:nb]    # noqa: E731
     r0 = ref_fp32(sl(q), sl(k), sl(v), sl(dO), H, d, d ** -0.5)
@@ -68,4 +83,5 @@ for (B, L, Lk, d, H) in [(32, 4096, 4096, 40, 8), (16, 4096, 4096, 40, 8), (32, 
     e1 = [rel(sl(a), b) for a, b in zip((o1,) + tuple(g1), r1)]
     print("B=%2d H=%2d L=%4d Lk=%4d d=%3d | fwd %7.3f -> %7.3f ms (x%.3f, %4.0f -> %4.0f TF/s; register staging %7.3f) | bwd %7.3f -> %7.3f ms (x%.3f; register staging %7.3f) | rel-L2 o/dq/dk/dv old %s new %s"
           % (B, H, L, Lk, d, t["f0"], t["f1"], t["f0"] / t["f1"], fl / t["f0"] / 1e9, fl / t["f1"] / 1e9, t["f2"], t["b0"], t["b1"], t["b0"] / t["b1"], t["b2"],
-             " ".join("%.1e" % x for x in e0), " ".join("%.1e" % x for x in e1)), flush=True)
+             " ".join("%.1e" % x for x in e0), " ".join("%.1e" % x for x in e1)) +
+          ((" | alt lib fwd %7.3f bwd %7.3f" % (t["f3"], t["b3"])) if ALT is not None else ""), flush=True)

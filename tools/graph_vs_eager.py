@@ -11,6 +11,8 @@ from pcm_amd import capi, ops
 from pcm_amd.model import LoraState, UNetWeights
 from pcm_amd.trainer import Distiller, StepConfig
 from pcm_amd.unet_spec import UNetConfig
+if len(sys.argv) > 2:      # another build of the library (tools/probes/build_variant.py), e.g. the register-staged attention kernels
+    capi.set_lib(capi.Lib(os.path.abspath(sys.argv[2])))
 capi.lib()
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 cfg = UNetConfig.sd15()
