@@ -88,8 +88,30 @@ def test_graph_replay_equals_eager_bs16_and_batch_split(sd15):
     loss_g, grads_g = float(D._static_out["loss"].item()), lora.grads.clone()
     rep = {"loss_eager": loss_e, "loss_graph": loss_g, "loss_rel": abs(loss_g - loss_e) / abs(loss_e),
            "grad_rel_graph_vs_eager": rel(grads_g, grads_e), "eps_rel_graph_vs_eager": rel(D._static_out["noise_pred"], eps_e)}
-    # same kernels, same launch order; the only freedom is the order of fp32 / fp64 atomics (LoRA wgrad, GroupNorm statistics)
-    assert rep["loss_rel"] < 1e-6 and rep["eps_rel_graph_vs_eager"] < 1e-6 and rep["grad_rel_graph_vs_eager"] < 1e-5, rep   # measured: 0, 0, 1.1e-7
+    # same kernels, same launch order; the only freedom is the order of fp32 / fp64 atomics (LoRA wgrad, GroupNorm statistics, the pixel sums
+    # behind time_emb_proj).  Typically 1.2e-7 on the whole vector; a last-bit difference of an atomically summed value that is then STORED in
+    # bf16 (the time-embedding cotangent) can flip that rounding and move one small module by 1e-4 (tools/graph_vs_eager.py,
+    # profiles/r05_f_*): seen as 1.65e-5 on the whole vector once.  The bitwise statement is made below with the reproducible reductions.
+    assert rep["loss_rel"] < 1e-6 and rep["eps_rel_graph_vs_eager"] < 1e-6 and rep["grad_rel_graph_vs_eager"] < 1e-4, rep   # measured: 0, 0, 1.2e-7
+    from pcm_amd import ops
+    ops.set_deterministic(True)      # slabs / partials + ordered finalize (include/pcm_hip.h abi 4): graph replay == eager, bit for bit
+    try:
+        lora_d = LoraState(cfg, 64, 8.0, dev, seed=1, b_std=0.02)
+        Dd = Distiller(W, lora_d, scfg)
+        od = Dd.forward_backward(**inp)
+        torch.cuda.synchronize()
+        loss_de, grads_de, eps_de = float(od["loss"].item()), lora_d.grads.clone(), od["noise_pred"].clone()
+        Dd.capture(B)
+        for k, v in inp.items():
+            Dd._static[k].copy_(v)
+        lora_d.grads.fill_(float("nan"))
+        Dd._g_fb.replay()
+        torch.cuda.synchronize()
+        assert float(Dd._static_out["loss"].item()) == loss_de and torch.equal(Dd._static_out["noise_pred"], eps_de)
+        assert torch.equal(lora_d.grads, grads_de), rel(lora_d.grads, grads_de)
+        del Dd, lora_d
+    finally:
+        ops.set_deterministic(False)
     rep["worst_module_grad_rel"] = assert_grads_match_per_module(lora, grads_g, grads_e)
     # one whole optimizer step through both paths from the same state
     p0 = [t.clone() for t in (lora.params, lora.exp_avg, lora.exp_avg_sq, D.step_dev)]
