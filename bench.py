@@ -286,10 +286,16 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16"],
                     help="16-bit format of activations / weights / MFMA operands.  bf16 = BASELINE.json's configs (the default and the headline number); "
                          "fp16 = the IEEE-half build of the library (the reference's --mixed_precision=fp16 recipes), same MFMA rate, loss-scaled backward")
+    ap.add_argument("--deterministic", action="store_true",
+                    help="reproducible reductions (ops.set_deterministic: slabs / partials + ordered finalize instead of fp32 / fp64 atomics; "
+                         "bitwise identical steps run to run) -- NOT the headline configuration, a cost measurement")
     args = ap.parse_args()
     if args.precision == "fp16":
         from pcm_amd import precision
         precision.set_precision("fp16")
+    if args.deterministic:
+        from pcm_amd import ops as _ops
+        _ops.set_deterministic(True)
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # plain ``python bench.py --gpus N`` (no torchrun): become the launcher -- one child process per GPU with the torchrun
@@ -569,7 +575,7 @@ def main():
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
                 "config": {"workload": "SD1.5 PCM-LoRA distillation step, %d phases, 64x64x4 latents, per-GPU batch %d, "
                                        "LoRA r=64 (67.25M trainable), huber, AdamW, random-init UNet (859.5M)" % (args.multiphase, B),
-                           "global_batch": world * B, "parallelism": "dp%d" % world, "comm": comm, "launch": "hipGraph replay" if use_graph else "eager", "loss_last": round(loss, 6),
+                           "global_batch": world * B, "parallelism": "dp%d" % world, "comm": comm, "launch": "hipGraph replay" if use_graph else "eager", "reductions": "reproducible" if args.deterministic else "atomics", "loss_last": round(loss, 6),
                            "host_ms_per_step_idle_queue": round(host_idle_ms, 2)},
                 "roofline": roofline, "cpu_baseline": cpu}
         print(json.dumps(line), flush=True)
