@@ -75,6 +75,8 @@ for (B, L, Lk, d, H) in [(32, 4096, 4096, 40, 8), (16, 4096, 4096, 40, 8), (32, 
         if ALT is not None:
             t["f3"] = min(t.get("f3", 1e9), with_alt(lambda: bench(lambda: ops.attn_fwd(qs, k, v, H, d, prescaled=True))))
             t["b3"] = min(t.get("b3", 1e9), with_alt(lambda: bench(lambda: ops.attn_bwd(qs, k, v, o1, dO, l1, H, d, prescaled=True))))
+            ga = with_alt(lambda: ops.attn_bwd(qs, k, v, o1, dO, l1, H, d, prescaled=True))
+            t["alt_err"] = max(rel(a, b.float()) for a, b in zip(ga, g1))            # the alternate library's gradients against the main library's
     nb = min(B, 2)       # accuracy on the first images only (fp32 reference on the GPU)
     sl = lambda x: x[:nb]    # noqa: E731
     r0 = ref_fp32(sl(q), sl(k), sl(v), sl(dO), H, d, d ** -0.5)
@@ -84,4 +86,4 @@ for (B, L, Lk, d, H) in [(32, 4096, 4096, 40, 8), (16, 4096, 4096, 40, 8), (32, 
     print("B=%2d H=%2d L=%4d Lk=%4d d=%3d | fwd %7.3f -> %7.3f ms (x%.3f, %4.0f -> %4.0f TF/s; register staging %7.3f) | bwd %7.3f -> %7.3f ms (x%.3f; register staging %7.3f) | rel-L2 o/dq/dk/dv old %s new %s"
           % (B, H, L, Lk, d, t["f0"], t["f1"], t["f0"] / t["f1"], fl / t["f0"] / 1e9, fl / t["f1"] / 1e9, t["f2"], t["b0"], t["b1"], t["b0"] / t["b1"], t["b2"],
              " ".join("%.1e" % x for x in e0), " ".join("%.1e" % x for x in e1)) +
-          ((" | alt lib fwd %7.3f bwd %7.3f" % (t["f3"], t["b3"])) if ALT is not None else ""), flush=True)
+          ((" | alt lib fwd %7.3f bwd %7.3f (gradients vs main lib %.1e)" % (t["f3"], t["b3"], t["alt_err"])) if ALT is not None else ""), flush=True)
