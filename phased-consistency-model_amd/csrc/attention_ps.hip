@@ -420,9 +420,6 @@ __global__ __launch_bounds__(256, (D <= 40 ? 3 : 1)) void attn_bwd_dq_ps_kernel(
 // DMA (only with the slot trick, i.e. d = 40 in the bfloat16 build: without it the softmax reads the -lse / -delta side arrays with tracked
 // LDS reads late in the tile, behind which hipcc would drain a DMA issued earlier): Q / dO tiles by LDS-DMA into a double buffer, the
 // per-row (-lse, -delta) pairs written into the NEXT buffer's pad columns one tile ahead.
-#ifndef PCM_ATTN_DKDV_HALVES     // (A/B builds with PCM_ATTN_DKDV_WAVES=3: score / softmax phase one query half at a time)
-#define PCM_ATTN_DKDV_HALVES 0
-#endif
 #ifndef PCM_ATTN_DKDV_WAVES      // minimum waves per SIMD of the d <= 40 instantiations (A/B builds: -DPCM_ATTN_DKDV_WAVES=3 spills 38 registers)
 #define PCM_ATTN_DKDV_WAVES 1
 #endif
@@ -528,36 +525,35 @@ __global__ __launch_bounds__(256, (D <= 40 ? PCM_ATTN_DKDV_WAVES : 1)) void attn
       __syncthreads();
       if (AttnPrefetch<D>::value && qq0 + 64 < Lq) stage_load(qq0 + 64);
     }
-    constexpr bool LEAN = PCM_ATTN_DKDV_WAVES >= 3 && D <= 40;      // register-lean schedule for three waves per SIMD (A/B build)
-    bf16x8 pf[4], df[4];
-    auto next_tile = [&]() {
-      if constexpr (DMA) {
-        // the OTHER buffer is free (every wave is past this tile's barrier, i.e. done with the previous tile): first the next tile's row
-        // pairs (ordinary LDS stores, values loaded one tile ago), THEN its DMA -- a tracked LDS access after a DMA issue would make hipcc
-        // drain it -- then the global loads of the row values one tile further
-        if (qq0 + 64 < Lq) {
-          char* nx = QOs + (2 * (((qq0 >> 6) & 1) ^ 1)) * TB;
-          publish_rows(nx, nx + TB, l2r, dlr);
-          dmaq.issue(qb, ldq, qq0 + 64, Lq, nx, wave); dmao.issue(dob, ldo, qq0 + 64, Lq, nx + TB, wave);
-          if (qq0 + 128 < Lq) rows_load(qq0 + 128);
-        }
-      }
-    };
-    auto scores = [&](f32x16& st, f32x16& dt, int t) {           // S' and dP of the tile's query half t (tracked LDS reads of the Q / dO rows)
+    f32x16 s_[2], dp[2];
 #pragma unroll
-      for (int r = 0; r < 16; r++) { st[r] = 0.f; dt[r] = 0.f; }
+    for (int t = 0; t < 2; t++) {
+#pragma unroll
+      for (int r = 0; r < 16; r++) { s_[t][r] = 0.f; dp[t][r] = 0.f; }
 #pragma unroll
       for (int s = 0; s < C::DK16; s++) {
         bf16x8 qfr = *(const bf16x8*)(Qs + ((32 * t + l31) * C::RKU + 2 * s + hi) * 16);
         bf16x8 ofr = *(const bf16x8*)(Os + ((32 * t + l31) * C::RKU + 2 * s + hi) * 16);
-        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfr, kf[s], st, 0, 0, 0);   // S'[q][kv]  (SLOT: - lse[q])
-        dt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ofr, vf[s], dt, 0, 0, 0);   // dP[q][kv]  (SLOT: - delta[q])
+        s_[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qfr, kf[s], s_[t], 0, 0, 0);   // S'[q][kv]  (SLOT: - lse[q])
+        dp[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ofr, vf[s], dp[t], 0, 0, 0);   // dP[q][kv]  (SLOT: - delta[q])
       }
-    };
-    auto softmax_half = [&](f32x16& st, f32x16& dt, int t) {     // p = exp2(s' - lse), dS' = p (dP - delta); masks; packed fragments 2t, 2t + 1
+    }
+    if constexpr (DMA) {
+      // the OTHER buffer is free (every wave is past this tile's barrier, i.e. done with the previous tile): first the next tile's row
+      // pairs (ordinary LDS stores, values loaded one tile ago), THEN its DMA -- a tracked LDS access after a DMA issue would make hipcc
+      // drain it -- then the global loads of the row values one tile further
+      if (qq0 + 64 < Lq) {
+        char* nx = QOs + (2 * (((qq0 >> 6) & 1) ^ 1)) * TB;
+        publish_rows(nx, nx + TB, l2r, dlr);
+        dmaq.issue(qb, ldq, qq0 + 64, Lq, nx, wave); dmao.issue(dob, ldo, qq0 + 64, Lq, nx + TB, wave);
+        if (qq0 + 128 < Lq) rows_load(qq0 + 128);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; t++)
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
-        f32x2 x = {st[r], st[r + 1]}, g = {dt[r], dt[r + 1]};
+        f32x2 x = {s_[t][r], s_[t][r + 1]}, g = {dp[t][r], dp[t][r + 1]};
         if constexpr (!SLOT) {
           const int ql = 32 * t + 4 * hi + (r & 3) + 8 * (r >> 2);     // r even -> ql even: the pair (ql, ql + 1) is one 8-byte LDS read
           x = x + *(const f32x2*)&L2s[ql];
@@ -565,63 +561,36 @@ __global__ __launch_bounds__(256, (D <= 40 ? PCM_ATTN_DKDV_WAVES : 1)) void attn
         }
         const f32x2 p = {PCM_EXP2F(x[0]), PCM_EXP2F(x[1])};
         const f32x2 y = g * p;                                          // dS'[q][kv] (unscaled)
-        dt[r] = y[0]; dt[r + 1] = y[1];
-        st[r] = p[0]; st[r + 1] = p[1];
+        dp[t][r] = y[0]; dp[t][r + 1] = y[1];
+        s_[t][r] = p[0]; s_[t][r + 1] = p[1];
       }
-      if (!blk_full || qq0 + 64 > Lq) {
-        asm volatile("" ::: "memory");
+    if (!blk_full || qq0 + 64 > Lq) {
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int t = 0; t < 2; t++)
 #pragma unroll
         for (int r = 0; r < 16; r++) {
           int ql = 32 * t + 4 * hi + (r & 3) + 8 * (r >> 2);
-          if (!kv_ok || (qq0 + ql) >= Lq) { st[r] = 0.f; dt[r] = 0.f; }
+          if (!kv_ok || (qq0 + ql) >= Lq) { s_[t][r] = 0.f; dp[t][r] = 0.f; }
         }
-      }
-      pf[2 * t] = pack_frag(st, 0); pf[2 * t + 1] = pack_frag(st, 1);
-      df[2 * t] = pack_frag(dt, 0); df[2 * t + 1] = pack_frag(dt, 1);
-    };
-    if constexpr (LEAN && PCM_ATTN_DKDV_HALVES) {
-      // one query half at a time: 32 score registers live instead of 64
-      f32x16 sa, da;
-      scores(sa, da, 0);
-      softmax_half(sa, da, 0);
-      __builtin_amdgcn_sched_barrier(0);      // (hipcc otherwise hoists the second half's MFMAs above the first half's packing: both live again)
-      scores(sa, da, 1);
-      next_tile();
-      softmax_half(sa, da, 1);
-      __builtin_amdgcn_sched_barrier(0);
-    } else {
-      f32x16 s_[2], dp[2];
-      scores(s_[0], dp[0], 0);
-      scores(s_[1], dp[1], 1);
-      next_tile();
-      softmax_half(s_[0], dp[0], 0);
-      softmax_half(s_[1], dp[1], 1);
     }
+    bf16x8 pf[4], df[4];
+#pragma unroll
+    for (int ss = 0; ss < 4; ss++) { pf[ss] = pack_frag(s_[ss >> 1], ss & 1); df[ss] = pack_frag(dp[ss >> 1], ss & 1); }
     TrQuad<D> oq, qq;
     oq.template issue<0>(Os, trf);
     qq.template issue<0>(Qs, trf);
     pcm_static_for<0, C::DV>([&](auto it) {
       constexpr int i = decltype(it)::value;
       oq.wait(); qq.keep();
-      if constexpr (PCM_ATTN_DKDV_WAVES >= 3 && D <= 40) {
-        // register-lean form (three waves per SIMD): the next 32-row group's fragments are requested only after this group's MFMAs have
-        // consumed theirs -- no second fragment set in flight (32 VGPRs); the co-resident waves cover the LDS latency instead
+      bf16x8 of[4], qf4[4];
 #pragma unroll
-        for (int ss = 0; ss < 4; ss++) {
-          acc_v[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(oq.frag(ss), pf[ss], acc_v[i], 0, 0, 0);
-          acc_k[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qq.frag(ss), df[ss], acc_k[i], 0, 0, 0);
-        }
-        if constexpr (i + 1 < C::DV) { oq.template issue<i + 1>(Os, trf); qq.template issue<i + 1>(Qs, trf); }
-      } else {
-        bf16x8 of[4], qf4[4];
+      for (int ss = 0; ss < 4; ss++) { of[ss] = oq.frag(ss); qf4[ss] = qq.frag(ss); }
+      if constexpr (i + 1 < C::DV) { oq.template issue<i + 1>(Os, trf); qq.template issue<i + 1>(Qs, trf); }
 #pragma unroll
-        for (int ss = 0; ss < 4; ss++) { of[ss] = oq.frag(ss); qf4[ss] = qq.frag(ss); }
-        if constexpr (i + 1 < C::DV) { oq.template issue<i + 1>(Os, trf); qq.template issue<i + 1>(Qs, trf); }
-#pragma unroll
-        for (int ss = 0; ss < 4; ss++) {
-          acc_v[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(of[ss], pf[ss], acc_v[i], 0, 0, 0);   // dV^T[d][kv]  (rows >= D: never stored)
-          acc_k[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf4[ss], df[ss], acc_k[i], 0, 0, 0);  // dK^T[d][kv]
-        }
+      for (int ss = 0; ss < 4; ss++) {
+        acc_v[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(of[ss], pf[ss], acc_v[i], 0, 0, 0);   // dV^T[d][kv]  (rows >= D: never stored)
+        acc_k[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf4[ss], df[ss], acc_k[i], 0, 0, 0);  // dK^T[d][kv]
       }
     });
   }
