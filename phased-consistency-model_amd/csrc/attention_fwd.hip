@@ -96,7 +96,6 @@ __device__ __forceinline__ void pv_tile(const char* Vt, const TrFrag<D>& trf, co
 // VALU / transcendental work behind it.
 template <int D>
 __device__ __forceinline__ void fwd_sched_pipeline() {
-#ifndef PCM_HOST_EMU
   using C = AttnCfg<D>;
   constexpr int NM = 2 * C::DK16 + 4 * C::DV;           // MFMAs per body
   constexpr int NR = 2 * C::DK16 + 8 * C::DV;           // LDS fragment reads per body
@@ -134,7 +133,6 @@ __device__ __forceinline__ void fwd_sched_pipeline() {
     __builtin_amdgcn_sched_group_barrier(0x400, 3, 0);
     __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
   });
-#endif
 }
 
 // One pipelined tile body (see the file header): stage K_{j+2} / V_j into the free LDS images, issue the loads of K_{j+3} / V_{j+1},
@@ -167,12 +165,10 @@ __device__ __forceinline__ void fwd_body(int j, char* Ks, char* Vs, const RowGeo
   float alpha;
   bool moved;
   softmax_tile<D, false>(s_, sc, m_run, l_run, pn, alpha, moved, j * 64, Lk, hi);
-#ifndef PCM_HOST_EMU
   // P_j is only consumed by the NEXT body: without this pin hipcc sinks the 32 exponentials below the branch at the end of this body, out
   // of the block that holds the MFMAs they are meant to run under
-  asm volatile("" : "+v"(pn[0]), "+v"(pn[1]), "+v"(pn[2]), "+v"(pn[3]));
+  PCM_HW_ONLY(asm volatile("" : "+v"(pn[0]), "+v"(pn[1]), "+v"(pn[2]), "+v"(pn[3])));
   if constexpr (FULL) fwd_sched_pipeline<D>();
-#endif
   __syncthreads();
   if (moved) {
 #pragma unroll
@@ -195,9 +191,7 @@ __global__ __launch_bounds__(256, WPS) void attn_fwd_pipe_kernel(const bf16_t* q
   const bf16_t* qb = q + (size_t)b * Lq * ldq + h * D;
   const bf16_t* kb = k + (size_t)b * Lk * ldk + h * D;
   const bf16_t* vb = v + (size_t)b * Lk * ldk + h * D;
-#ifndef PCM_HOST_EMU
-  if constexpr (AG) asm volatile("; AccVGPR accumulators requested" : : "a"(0));   // an 'a' operand makes the function use the AGPR MFMA forms
-#endif
+  PCM_HW_ONLY(if constexpr (AG) asm volatile("; AccVGPR accumulators requested" : : "a"(0)));   // an 'a' operand makes the function use the AGPR MFMA forms
   bf16x8 qf[C::DK16];
 #pragma unroll
   for (int s = 0; s < C::DK16; s++) qf[s] = gfrag<D>(qb, ldq, q0 + l31, Lq, s, hi);

@@ -29,7 +29,7 @@ struct ConvR64 {
 };
 
 __global__ __launch_bounds__(512) void pcm_conv3x3_r64_kernel(ConvR64 g) {
-#if defined(__HIP_DEVICE_COMPILE__) || defined(PCM_HOST_EMU)
+#if PCM_KERNEL_BODY
   PCM_DYN_SMEM(smem);
   char* const Win = smem;                     // [2][CR_WIN]
   char* const Abuf = smem + 2 * CR_WIN;       // [3][CR_ATH]

@@ -36,7 +36,7 @@ extern "C" int pcm_debug_gemm4w_stamps(unsigned long long* dst) { return (int)hi
 
 template <int FN>
 __global__ __launch_bounds__(256, 2) void pcm_gemm4w_kernel(GemmDev g) {
-#if defined(__HIP_DEVICE_COMPILE__) || defined(PCM_HOST_EMU)   // the host pass only needs the launch stub (buffer-resource builtins are device-only)
+#if PCM_KERNEL_BODY   // the host pass only needs the launch stub (buffer-resource builtins are device-only)
   constexpr int WNC = 16 * FN, BN = 4 * WNC, BM = 128;
   constexpr int OFF_B = BM * 64, STAGE = (BM + BN) * 64;
   constexpr int AI = BM / 64, WI = BN / 64;       // LDS-DMA instructions per wave and K-step: 16 rows x 64 B each
@@ -53,7 +53,6 @@ __global__ __launch_bounds__(256, 2) void pcm_gemm4w_kernel(GemmDev g) {
 #ifdef PCM_ABLATE
   const bool stamp_on = blockIdx.x == gridDim.x / 2;
 #endif
-#ifndef PCM_HOST_EMU
   if (g.w4_stagger > 0) {
     // HW_REG_HW_ID (id 4): bits 19:16 = TG_ID, the slot of this workgroup on its CU.  The two co-resident workgroups of a CU hold slots of
     // opposite parity; the odd one starts late, which turns "both in their MFMA phases, then both in their epilogues" into alternation.
@@ -64,7 +63,6 @@ __global__ __launch_bounds__(256, 2) void pcm_gemm4w_kernel(GemmDev g) {
     if ((hwid >> 16) & 1)
       for (int i = 0; i < g.w4_stagger; i++) __builtin_amdgcn_s_sleep(32);
   }
-#endif
   G4_STAMP(0);
 
   // ---- loader: lane -> row lane>>2 of a 16-row group, 16-B slot lane&3; this wave owns groups wn + 4j of both operands

@@ -35,7 +35,7 @@ extern "C" int pcm_debug_gemm8p_stamps(unsigned long long* dst) { return (int)hi
 
 template <int F0, bool MD, bool CO>
 __global__ __launch_bounds__(512) void pcm_gemm8p_kernel(GemmDev g) {
-#if defined(__HIP_DEVICE_COMPILE__) || defined(PCM_HOST_EMU)   // the host pass only needs the launch stub (buffer-resource builtins are device-only)
+#if PCM_KERNEL_BODY   // the host pass only needs the launch stub (buffer-resource builtins are device-only)
   constexpr int F1 = 2, FN = F0 + F1, WNC = 16 * FN, BN = 4 * WNC;
   constexpr int RB0 = 64 * F0;                                         // LDS rows of B part 0 (4 waves x 16*F0)
   constexpr int OFF_A1 = 128 * 128, OFF_B0 = 256 * 128, OFF_B1 = OFF_B0 + RB0 * 128;

@@ -94,13 +94,12 @@ struct PcmEpi {
 
   template <typename Acc>
   static __device__ __forceinline__ void run(const GemmDev& g, char* smem, const Acc& acc, int tid, int wm, int wn, int m0, int n0, bool sync_first) {
-#ifndef PCM_HOST_EMU
     // the piece geometry below is a function of tid only: opaque copies keep hipcc from computing it (or anything shared with it) ahead of
     // the K loop and carrying it through the loop -- the 256 x 320 tile has no register to spare there (measured: 60+ spills, reloads inside
     // the K loop, without this)
-    asm volatile("" : "+v"(tid));
-    asm volatile("" : "+s"(m0), "+s"(n0));
-#endif
+    PCM_PIN_V(tid);
+    PCM_PIN_S(m0);
+    PCM_PIN_S(n0);
     if (g.act == PCM_ACT_GEGLU) { run_geglu(g, smem, acc, tid, wm, wn, m0, n0, sync_first); return; }
     const int lane = tid & 63, frow = lane & 15, fk = lane >> 4;
     // residual pieces are requested a pass ahead of their use (one register set of IT pieces; a row vector rides in the loop: L2-resident)

@@ -20,6 +20,22 @@
   do {                                                                                                  \
     if (active) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, PCM_AS3(lds), 16, voff, soff, 0, 0);       \
   } while (0)
+// code-generation controls with no meaning off the hardware (the emulator header defines the same names as no-ops, so that kernel files
+// never test PCM_HOST_EMU themselves): PCM_HW_ONLY(statements) = scheduler hints / register-class requests / hardware-register reads;
+// PCM_PIN_V / PCM_PIN_S = opaque copy of a vector / scalar value (keeps hipcc from hoisting what depends on it);
+// PCM_KERNARG_REF(T, arr, i) = element i of an array that is the FIRST member of the kernel's argument struct, read from the kernarg
+// segment by scalar loads (no per-job copy of the argument block in registers)
+#define PCM_HW_ONLY(...) __VA_ARGS__
+#define PCM_PIN_V(x) asm volatile("" : "+v"(x))
+#define PCM_PIN_S(x) asm volatile("" : "+s"(x))
+#define PCM_KERNARG_REF(T, arr, i) (((const __attribute__((address_space(4))) T*)__builtin_amdgcn_kernarg_segment_ptr())[i])
+#endif
+// HIP compiles a kernel file twice; the host pass only needs the launch stubs (device builtins do not exist there): kernel bodies are
+// wrapped in #if PCM_KERNEL_BODY
+#if defined(__HIP_DEVICE_COMPILE__) || defined(PCM_HOST_EMU)
+#define PCM_KERNEL_BODY 1
+#else
+#define PCM_KERNEL_BODY 0
 #endif
 #include <stdint.h>
 #include <string.h>

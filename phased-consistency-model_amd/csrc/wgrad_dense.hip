@@ -35,7 +35,7 @@ struct WdDev {
 };
 
 __global__ __launch_bounds__(512) void pcm_wgrad_dense_kernel(WdDev a) {
-#if defined(__HIP_DEVICE_COMPILE__) || defined(PCM_HOST_EMU)
+#if PCM_KERNEL_BODY
   constexpr int XB = 64 * 256, UB = 128 * 128, STAGE = XB + UB, NBUF = 3;
   PCM_DYN_SMEM(smem);
   const int tid = threadIdx.x, lane = tid & 63;

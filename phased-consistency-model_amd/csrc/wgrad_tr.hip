@@ -116,7 +116,7 @@ __device__ __forceinline__ void pcm_wgrad_tr_body(const WG& a, const int bx, con
 }
 template <bool SWAP>
 __global__ __launch_bounds__(256) void pcm_wgrad_tr_kernel(WgDev a) {
-#if defined(__HIP_DEVICE_COMPILE__) || defined(PCM_HOST_EMU)
+#if PCM_KERNEL_BODY
   PCM_DYN_SMEM(smem);
   pcm_wgrad_tr_body<SWAP>(a, blockIdx.x, blockIdx.y, smem);
 #endif
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void pcm_wgrad_tr_kernel(WgDev a) {
 // prefix table and reads that job's argument block from the kernarg segment by index (scalar loads; no per-job copies in registers).
 struct WgMulti { WgDev d[PCM_WGRAD_MULTI_MAX]; int blk_start[PCM_WGRAD_MULTI_MAX + 1]; int tiles_g[PCM_WGRAD_MULTI_MAX]; int n; };
 __global__ __launch_bounds__(256) void pcm_wgrad_tr_multi_kernel(WgMulti mm) {
-#if defined(__HIP_DEVICE_COMPILE__) || defined(PCM_HOST_EMU)
+#if PCM_KERNEL_BODY
   PCM_DYN_SMEM(smem);
   const int bid = blockIdx.x;
   int i = 0;
@@ -135,12 +135,7 @@ __global__ __launch_bounds__(256) void pcm_wgrad_tr_multi_kernel(WgMulti mm) {
     if (k < mm.n && bid >= mm.blk_start[k]) i = k;
   const int lid = bid - mm.blk_start[i], tg = mm.tiles_g[i];
   const int by = lid / tg, bx = lid - by * tg;
-#ifdef PCM_HOST_EMU
-  const WgDev& a = mm.d[i];
-#else
-  typedef const __attribute__((address_space(4))) WgDev* kptr;
-  const __attribute__((address_space(4))) WgDev& a = ((kptr)__builtin_amdgcn_kernarg_segment_ptr())[i];   // d[] is the first member
-#endif
+  const auto& a = PCM_KERNARG_REF(WgDev, mm.d, i);   // d[] is the first member
   if (a.swap) pcm_wgrad_tr_body<true>(a, bx, by, smem);
   else pcm_wgrad_tr_body<false>(a, bx, by, smem);
 #endif
@@ -150,7 +145,7 @@ __global__ __launch_bounds__(256) void pcm_wgrad_tr_multi_kernel(WgMulti mm) {
 // stage = 64 consecutive pixels of one image: Wt = min(W, 64) columns x R = 64/Wt rows at (y0, x0); u window = (R+2) x (Wt+2) entries of
 // 128 B, entry (ry, cx) <-> pixel (y0 - 1 + ry, x0 - 1 + cx), zero outside the image.  LDS: x tile 8 KB + window 28 KB, two stages.
 __global__ __launch_bounds__(256) void pcm_wgrad_tr_conv_kernel(WgDev a) {
-#if defined(__HIP_DEVICE_COMPILE__) || defined(PCM_HOST_EMU)
+#if PCM_KERNEL_BODY
   constexpr int XB = 64 * 128, UB = 28 * 1024, STAGE = XB + UB;
   PCM_DYN_SMEM(smem);
   const int tid = threadIdx.x, lane = tid & 63;

@@ -277,6 +277,14 @@ inline emu_v4i buffer_load_b128(BufferRsrc rs, uint32_t voff, uint32_t soff, int
 #define __builtin_amdgcn_s_barrier() pcm_emu::block_sync()
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define __builtin_amdgcn_sched_group_barrier(...) ((void)0)
+#define __builtin_amdgcn_s_sleep(x) ((void)0)
+#define __builtin_amdgcn_s_getreg(x) 0u
+// hardware-only code-generation controls of csrc/pcm_common.h
+#define PCM_HW_ONLY(...)
+#define PCM_PIN_V(x) ((void)0)
+#define PCM_PIN_S(x) ((void)0)
+#define PCM_KERNARG_REF(T, arr, i) ((arr)[i])
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16 pcm_emu::mfma_32x32x16_bf16
 #define __builtin_amdgcn_mfma_f32_16x16x32_bf16 pcm_emu::mfma_16x16x32_bf16
