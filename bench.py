@@ -289,6 +289,9 @@ def main():
     ap.add_argument("--deterministic", action="store_true",
                     help="reproducible reductions (ops.set_deterministic: slabs / partials + ordered finalize instead of fp32 / fp64 atomics; "
                          "bitwise identical steps run to run) -- NOT the headline configuration, a cost measurement")
+    ap.add_argument("--teacher-fp16", action="store_true",
+                    help="(c2, bf16) the ODE-solver teacher pass in IEEE half next to the bfloat16 student, as the reference's dtype-less "
+                         "torch.autocast('cuda') does (train_pcm_lora_sd15.py:1218); a second packing of the frozen weights.  NOT the headline configuration")
     args = ap.parse_args()
     if args.precision == "fp16":
         from pcm_amd import precision
@@ -347,11 +350,16 @@ def main():
     with torch.no_grad():
         sd = random_state_dict(ucfg, seed=0, device=dev)
         W = UNetWeights(ucfg, sd, dev)
+        Wt = None
+        if args.teacher_fp16 and args.precision == "bf16":
+            from pcm_amd import precision
+            with precision.format_scope("fp16"):
+                Wt = UNetWeights(ucfg, sd, dev, need_bwd=False)
         del sd
         lora = LoraState(ucfg, 64, 8.0, dev, seed=1)   # peft init (B = 0), as the reference starts
     cfg = StepConfig(multiphase=args.multiphase, loss_type="huber", learning_rate=5e-6, adam_weight_decay=1e-3,
                      w_min=4.0, w_max=5.0)                 # train_pcm_lora_sd15.sh:5-29 hyper-parameters
-    D = Distiller(W, lora, cfg, world_size=world)
+    D = Distiller(W, lora, cfg, world_size=world, teacher_weights=Wt)
     torch.cuda.synchronize()
     log("weights packed, LoRA state ready (%.1f GB allocated)" % (torch.cuda.memory_allocated() / 2**30))
     B = args.batch
@@ -575,7 +583,7 @@ def main():
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
                 "config": {"workload": "SD1.5 PCM-LoRA distillation step, %d phases, 64x64x4 latents, per-GPU batch %d, "
                                        "LoRA r=64 (67.25M trainable), huber, AdamW, random-init UNet (859.5M)" % (args.multiphase, B),
-                           "global_batch": world * B, "parallelism": "dp%d" % world, "comm": comm, "launch": "hipGraph replay" if use_graph else "eager", "reductions": "reproducible" if args.deterministic else "atomics", "loss_last": round(loss, 6),
+                           "global_batch": world * B, "parallelism": "dp%d" % world, "comm": comm, "launch": "hipGraph replay" if use_graph else "eager", "reductions": "reproducible" if args.deterministic else "atomics", "teacher_pass": "fp16" if (Wt is not None or args.precision == "fp16") else "bf16", "loss_last": round(loss, 6),
                            "host_ms_per_step_idle_queue": round(host_idle_ms, 2)},
                 "roofline": roofline, "cpu_baseline": cpu}
         print(json.dumps(line), flush=True)

@@ -21,7 +21,7 @@ from . import capi, ops
 from .ops import Seg
 from .unet_spec import UNetConfig, lora_target_modules, param_spec
 
-from .precision import act_dtype as _act_dtype  # noqa: E402
+from .precision import act_dtype as _act_dtype, precision  # noqa: E402
 
 BF16 = _act_dtype()      # the library's 16-bit dtype: bfloat16, or float16 after precision.set_precision("fp16") (which rebinds this name)
 
@@ -76,6 +76,7 @@ class UNetWeights:
 
     def __init__(self, cfg: UNetConfig, state_dict, device, need_bwd=True):
         self.cfg, self.device = cfg, torch.device(device)
+        self.format = precision()            # the 16-bit format the operands below are packed in (pcm_amd/precision.py)
         spec = param_spec(cfg)
         missing = [k for k, _ in spec if k not in state_dict]
         if missing:

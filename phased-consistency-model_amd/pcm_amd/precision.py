@@ -15,6 +15,7 @@ from . import capi
 
 _NAME = "bf16"
 _DTYPES = {"bf16": torch.bfloat16, "fp16": torch.float16}
+_LIBS = {}        # format name -> the capi.Lib last validated for it (set_precision / register_lib); format_scope switches between them
 
 
 def precision():
@@ -30,7 +31,6 @@ def set_precision(name, lib=None, tools=False):
     ``tools``: the TOOLS build of the variant (pcm_debug_* hooks; tools/ and hook-using tests only).
     Nothing is switched unless the library loads and reports the requested format: a missing / mismatched file leaves the process in
     its previous precision."""
-    global _NAME
     if name not in _DTYPES:
         raise ValueError("precision must be 'bf16' or 'fp16', got %r" % (name,))
     want = 1 if name == "fp16" else 0
@@ -42,9 +42,55 @@ def set_precision(name, lib=None, tools=False):
         raise RuntimeError("%s was built for %s, not %s" % (lib.path, "fp16" if lib.act_dtype else "bf16", name))
     if path is not None:
         capi._LIB_PATH = path                                                      # capi.set_lib(None) / lib() keep loading this variant
+    _LIBS[name] = lib
+    _activate(name, lib)
+
+
+def _activate(name, lib):
+    global _NAME
     capi.set_lib(lib)
     _NAME = name
     # every host module that holds the "library's 16-bit dtype" constant (BF16) -- found by attribute, not by a hard-coded list
     for mod_name, m in list(sys.modules.items()):
         if mod_name.startswith("pcm_amd.") and m is not None and isinstance(getattr(m, "BF16", None), torch.dtype):
             m.BF16 = _DTYPES[name]
+
+
+def register_lib(name, lib):
+    """the library ``format_scope(name)`` switches to (tests: an emulator build of that variant; default: the product library of the
+    format, loaded on first use).  Validated like set_precision; does not switch anything."""
+    if name not in _DTYPES:
+        raise ValueError("precision must be 'bf16' or 'fp16', got %r" % (name,))
+    if lib.act_dtype != (1 if name == "fp16" else 0):
+        raise RuntimeError("%s was built for %s, not %s" % (lib.path, "fp16" if lib.act_dtype else "bf16", name))
+    _LIBS[name] = lib
+
+
+class format_scope:
+    """``with format_scope("fp16"): ...`` -- run the enclosed host code (operand packing, a forward pass) against the OTHER 16-bit build of the
+    kernel library, then switch back.  Both builds live in one process (distinct shared objects; a pointer handed to one is just memory
+    to the other, fp32 tensors cross freely, 16-bit tensors must stay on their side -- ops.Seg checks the dtype).  This is how the
+    reference's teacher pass is reproduced under --mixed_precision=bf16: its ``torch.autocast("cuda")`` (train_pcm_lora_sd15.py:1218)
+    names no dtype and therefore runs the frozen teacher in IEEE half while the student runs in bfloat16 (trainer.Distiller
+    ``teacher_weights``).  Switching is a handful of attribute writes; under hipGraph capture it happens at capture time only."""
+
+    def __init__(self, name):
+        if name not in _DTYPES:
+            raise ValueError("precision must be 'bf16' or 'fp16', got %r" % (name,))
+        self.name = name
+
+    def __enter__(self):
+        self.prev = (_NAME, capi.lib())
+        if self.name != _NAME:
+            lib = _LIBS.get(self.name)
+            if lib is None:
+                lib = capi.Lib(capi.F16_LIB if self.name == "fp16" else capi.DEFAULT_LIB)     # raises when the file is missing
+                register_lib(self.name, lib)
+            _LIBS.setdefault(self.prev[0], self.prev[1])
+            _activate(self.name, lib)
+        return self
+
+    def __exit__(self, *exc):
+        if self.prev[0] != _NAME:
+            _activate(*self.prev)
+        return False

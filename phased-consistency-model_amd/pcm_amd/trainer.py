@@ -7,6 +7,7 @@ Behavioural notes kept from the reference: the "target network" 
 LoRA weights under no-grad (update_ema is defined but never called; ``ema_rate`` here defaults to
 None = reference behaviour); ``w`` only scales the teacher CFG step; index 0 is a boundary sample.
 """
+import contextlib
 import gc
 import math
 import os
@@ -135,12 +136,21 @@ class Distiller:
     comm_events = None     # a list: step_graphed appends (start, end) events around the gradient exchange
     loss_scale_dev = loss_good_dev = None      # device-side GradScaler state, set by __init__ under precision "fp16"
 
-    def __init__(self, weights: UNetWeights, lora: LoraState, cfg: StepConfig, world_size=1, process_group=None):
+    def __init__(self, weights: UNetWeights, lora: LoraState, cfg: StepConfig, world_size=1, process_group=None, teacher_weights=None):
+        """``teacher_weights``: a second packing of the SAME frozen state dict in the other 16-bit format (built under
+        ``precision.format_scope``), used for the ODE-solver teacher pass only.  The reference runs that pass under
+        ``torch.autocast("cuda")`` with no dtype (train_pcm_lora_sd15.py:1217-1218), i.e. in IEEE half even when the student trains under
+        --mixed_precision=bf16; ``teacher_weights`` packed in "fp16" next to a bf16 student reproduces exactly that split.  None (default):
+        every pass runs in the process's one format."""
         self.W, self.lora, self.cfg = weights, lora, cfg
         self.device = lora.device
         self.tables = DDIMTables(cfg, self.device)
         self.student = UNet(weights, lora)
         self.teacher = UNet(weights, None)
+        self.teacher_ode, self._ode_scope = self.teacher, contextlib.nullcontext
+        if teacher_weights is not None and teacher_weights.format != precision.precision():
+            fmt = teacher_weights.format
+            self.teacher_ode, self._ode_scope = UNet(teacher_weights, None), (lambda: precision.format_scope(fmt))
         self.world_size, self.pg = world_size, process_group
         self.step_count = 0
         self.fuse_online_target = True    # online + target forward as one 2B-sample schedule (False: two B-sample passes)
@@ -203,15 +213,16 @@ class Distiller:
         noisy = ops.add_noise(latents, noise, T.acp, start_t)                                   # :1178
         # teacher cond (+ uncond) in ONE batched forward (no grad, no LoRA) --------------------- :1217-1252
         # (scheduled first: the online forward does not depend on it, the target forward does)
-        if cfg.not_apply_cfg_solver:
-            eps_c = self.teacher.forward(noisy, start_t, prompt_embeds, added_cond=added_cond)
-            eps_u = eps_c
-        else:
-            # (the halves share sample and timestep: the prefix up to the first cross-attention is computed once, UNet.forward dup_halves)
-            both = self.teacher.forward(torch.cat([noisy, noisy]), torch.cat([start_t, start_t]),
-                                        torch.cat([prompt_embeds, uncond_prompt_embeds]), added_cond=cat2(added_cond, uncond_added_cond),
-                                        dup_halves=DEDUP_TEACHER_PREFIX)
-            eps_c, eps_u = both[:B], both[B:]
+        with self._ode_scope():     # (the other 16-bit build for this pass when the teacher was packed in it: Distiller.__init__)
+            if cfg.not_apply_cfg_solver:
+                eps_c = self.teacher_ode.forward(noisy, start_t, prompt_embeds, added_cond=added_cond)
+                eps_u = eps_c
+            else:
+                # (the halves share sample and timestep: the prefix up to the first cross-attention is computed once, UNet.forward dup_halves)
+                both = self.teacher_ode.forward(torch.cat([noisy, noisy]), torch.cat([start_t, start_t]),
+                                                torch.cat([prompt_embeds, uncond_prompt_embeds]), added_cond=cat2(added_cond, uncond_added_cond),
+                                                dup_halves=DEDUP_TEACHER_PREFIX)
+                eps_c, eps_u = both[:B], both[B:]
         x_prev64, x_prev32 = ops.cfg_ddim_step(eps_c, eps_u, noisy, start_t, index, w, T.acp, T.acp_prev)   # :1254-1258
         if self.fuse_online_target:
             # online student forward at t_{n+k} (grad, :1192) and target forward at (x_prev, t_n) (same online weights incl.
@@ -426,8 +437,8 @@ class AdvDistiller(Distiller):
     """PCM-LoRA + latent adversarial consistency (reference: train_pcm_lora_sd15_adv.py:1288-1431).
     Even ``global_step``: discriminator update only; odd: student update with loss_cm + adv_weight * g_loss."""
 
-    def __init__(self, weights, lora, cfg, discriminator, adv_weight=0.1, adv_lr=1e-5, world_size=1, process_group=None):
-        super().__init__(weights, lora, cfg, world_size, process_group)
+    def __init__(self, weights, lora, cfg, discriminator, adv_weight=0.1, adv_lr=1e-5, world_size=1, process_group=None, teacher_weights=None):
+        super().__init__(weights, lora, cfg, world_size, process_group, teacher_weights=teacher_weights)
         self.disc, self.adv_weight, self.adv_lr = discriminator, adv_weight, adv_lr
         self.adv_lr_dev = torch.full((1,), float(adv_lr), dtype=torch.float32, device=self.device)
 
@@ -451,13 +462,14 @@ class AdvDistiller(Distiller):
         span = cfg.num_train_timesteps // cfg.multiphase
         adv_t = end_t + torch.clamp((adv_u * span).long(), max=span - 1)
         fake_adv, sr = ops.noise_travel(model_pred, noise_fake, T.acp, end_t, adv_t)            # :1303-1305
-        if cfg.not_apply_cfg_solver:
-            eps_c = self.teacher.forward(noisy, start_t, prompt_embeds, added_cond=ac)
-            eps_u = eps_c
-        else:
-            both = self.teacher.forward(torch.cat([noisy, noisy]), torch.cat([start_t, start_t]), torch.cat([prompt_embeds, uncond_prompt_embeds]),
-                                        added_cond=cat2(ac, uac))
-            eps_c, eps_u = both[:B], both[B:]
+        with self._ode_scope():     # the ODE-solver teacher pass (sd15_adv.py:1312 ``torch.autocast("cuda")``); the discriminator's feature passes stay in the build format
+            if cfg.not_apply_cfg_solver:
+                eps_c = self.teacher_ode.forward(noisy, start_t, prompt_embeds, added_cond=ac)
+                eps_u = eps_c
+            else:
+                both = self.teacher_ode.forward(torch.cat([noisy, noisy]), torch.cat([start_t, start_t]), torch.cat([prompt_embeds, uncond_prompt_embeds]),
+                                                added_cond=cat2(ac, uac))
+                eps_c, eps_u = both[:B], both[B:]
         x_prev64, x_prev32 = ops.cfg_ddim_step(eps_c, eps_u, noisy, start_t, index, w, T.acp, T.acp_prev)
         eps_t = self.student.forward(x_prev32, t_n, prompt_embeds, added_cond=ac)
         target, _, _ = ops.phase_jump(eps_t, x_prev64, t_n, index, T.acp, T.acp_prev, T.ddim_timesteps_prev, T.edges, target_mode=True)

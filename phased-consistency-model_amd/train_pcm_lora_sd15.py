@@ -79,6 +79,11 @@ def parse_args(argv=None):
     p.add_argument("--mixed_precision", type=str, default=None, choices=["no", "fp16", "bf16"])
     p.add_argument("--allow_tf32", action="store_true")
     p.add_argument("--cast_teacher_unet", action="store_true")
+    p.add_argument("--teacher_precision", type=str, default="same", choices=["same", "fp16"],
+                   help="format of the ODE-solver teacher pass.  The reference runs it under torch.autocast('cuda') with no dtype "
+                        "(train_pcm_lora_sd15.py:1218), i.e. in IEEE half whatever --mixed_precision says; 'fp16' reproduces that next to a "
+                        "bfloat16 student (a second, half packing of the frozen weights: +1.7 GB at SD1.5 size).  'same' (default): one format "
+                        "for every pass, one weight packing")
     p.add_argument("--enable_xformers_memory_efficient_attention", action="store_true")
     p.add_argument("--gradient_checkpointing", action="store_true")
     p.add_argument("--local_rank", type=int, default=-1)
@@ -273,6 +278,19 @@ def apply_mixed_precision(args):
         logger.info("--mixed_precision=fp16: half build of the kernel library (lib/libpcm_hip_f16.so), dynamic loss scaling on the device")
 
 
+def teacher_weights_for(args, ucfg, sd, device):
+    """--teacher_precision fp16 under a bfloat16 student: the frozen weights packed a second time, in IEEE half, for the ODE-solver teacher pass
+    (trainer.Distiller ``teacher_weights``); None when every pass runs in the one format of the process.  No backward operands: the pass has none."""
+    from pcm_amd import precision
+    from pcm_amd.model import UNetWeights
+    if getattr(args, "teacher_precision", "same") != "fp16" or precision.precision() == "fp16":
+        return None
+    with precision.format_scope("fp16"):
+        Wt = UNetWeights(ucfg, sd, device, need_bwd=False)
+    logger.info("--teacher_precision=fp16: ODE-solver teacher pass in IEEE half (lib/libpcm_hip_f16.so) next to the bfloat16 student")
+    return Wt
+
+
 def main(args):
     from pcm_amd import capi, checkpoint as ck
     from pcm_amd.model import LoraState, UNetWeights
@@ -303,6 +321,7 @@ def main(args):
     else:
         sd = ck.load_unet_state_dict(args.pretrained_teacher_model)
     W = UNetWeights(ucfg, sd, device)
+    Wt = teacher_weights_for(args, ucfg, sd, device)
     del sd
     lora = LoraState(ucfg, args.lora_rank, 8.0, device, seed=(args.seed or 0))
     if world > 1:
@@ -313,7 +332,7 @@ def main(args):
                      adam_beta2=args.adam_beta2, adam_weight_decay=args.adam_weight_decay, adam_epsilon=args.adam_epsilon,
                      max_grad_norm=args.max_grad_norm, lora_rank=args.lora_rank, not_apply_cfg_solver=args.not_apply_cfg_solver,
                      ema_rate=args.ema_rate)
-    D = Distiller(W, lora, cfg, world_size=world)
+    D = Distiller(W, lora, cfg, world_size=world, teacher_weights=Wt)
     src = LatentSource(args, rank, world, device)
     steps_per_epoch = agreed_steps_per_epoch(len(src), world)
     if args.max_train_steps is None:

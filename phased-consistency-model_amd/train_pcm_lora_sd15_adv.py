@@ -60,6 +60,7 @@ def main(args):
     ucfg = base.unet_config(args)
     sd = random_state_dict(ucfg, 0, device) if args.pretrained_teacher_model == "random" else ck.load_unet_state_dict(args.pretrained_teacher_model)
     W = UNetWeights(ucfg, sd, device)
+    Wt = base.teacher_weights_for(args, ucfg, sd, device)
     del sd
     lora = LoraState(ucfg, args.lora_rank, 8.0, device, seed=(args.seed or 0))
     b = tuple(ucfg.block_out_channels)                            # feature taps: every down-block output, mid, every up-block output
@@ -72,7 +73,7 @@ def main(args):
                      loss_type=args.loss_type, huber_c=args.huber_c, learning_rate=args.learning_rate, adam_beta1=args.adam_beta1,
                      adam_beta2=args.adam_beta2, adam_weight_decay=args.adam_weight_decay, adam_epsilon=args.adam_epsilon,
                      max_grad_norm=args.max_grad_norm, lora_rank=args.lora_rank, not_apply_cfg_solver=args.not_apply_cfg_solver)
-    D = AdvDistiller(W, lora, cfg, disc, adv_weight=args.adv_weight, adv_lr=args.adv_lr, world_size=world)
+    D = AdvDistiller(W, lora, cfg, disc, adv_weight=args.adv_weight, adv_lr=args.adv_lr, world_size=world, teacher_weights=Wt)
     src = base.LatentSource(args, rank, world, device)
     if args.max_train_steps is None:
         args.max_train_steps = args.num_train_epochs * base.agreed_steps_per_epoch(len(src), world)

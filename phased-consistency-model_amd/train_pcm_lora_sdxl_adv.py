@@ -114,6 +114,7 @@ def main(args):
     ucfg = base.unet_config(args, "sdxl")
     sd = random_state_dict(ucfg, 0, device) if args.pretrained_teacher_model == "random" else ck.load_unet_state_dict(args.pretrained_teacher_model)
     W = UNetWeights(ucfg, sd, device)
+    Wt = base.teacher_weights_for(args, ucfg, sd, device)
     del sd
     lora = LoraState(ucfg, args.lora_rank, 8.0, device, seed=(args.seed or 0))
     if world > 1:
@@ -129,9 +130,9 @@ def main(args):
         disc = Discriminator(dims, num_h_per_head=1, device=device, seed=(args.seed or 0) + 1, ksize=1, taps="down_mid")
         if world > 1:
             torch.distributed.broadcast(disc.params, src=0); disc.repack()
-        D = AdvDistiller(W, lora, cfg, disc, adv_weight=args.adv_weight, adv_lr=args.adv_lr, world_size=world)
+        D = AdvDistiller(W, lora, cfg, disc, adv_weight=args.adv_weight, adv_lr=args.adv_lr, world_size=world, teacher_weights=Wt)
     else:
-        D = Distiller(W, lora, cfg, world_size=world)
+        D = Distiller(W, lora, cfg, world_size=world, teacher_weights=Wt)
     src = SdxlSource(args, rank, world, device)
     if args.max_train_steps is None:
         args.max_train_steps = args.num_train_epochs * base.agreed_steps_per_epoch(len(src), world)

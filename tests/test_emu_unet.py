@@ -318,3 +318,90 @@ def test_deterministic_step_equals_the_atomic_step_to_rounding():
     assert l1 == l2 and q1 == q2 and torch.equal(g1, g2) and torch.equal(p1, p2)
     assert abs(l1 - l0) <= 1e-6 * abs(l0) and abs(q1 - q0) <= 1e-4 * q0
     assert float((g1 - g0).norm() / g0.norm()) < 1e-4
+
+
+def test_fp16_teacher_next_to_a_bf16_student_is_exactly_the_two_pure_builds():
+    """Distiller(teacher_weights = the frozen weights packed in IEEE half): the reference's ODE-solver teacher pass runs under
+    torch.autocast("cuda") with no dtype, i.e. in half, even when the student trains in bfloat16 (train_pcm_lora_sd15.py:1217-1218).  The
+    split must be clean: the teacher outputs (and x_prev, a function of them and of fp32 inputs only) are BITWISE those of an all-half
+    process, the student's noise prediction is BITWISE that of an all-bfloat16 process, and nothing of the process's format leaks out
+    of the scope.  (GPU run at the real size: tests/test_gpu_step.py::test_fp16_teacher_bf16_student_split.)"""
+    from oracle import pcm_step as OS
+    from oracle import unet_sd15 as O
+    from pcm_amd import ops, precision
+    from pcm_amd.model import LoraState, UNetWeights
+    from pcm_amd.trainer import Distiller, StepConfig
+    oc, pc = tiny_cfgs()
+    sd = O.init_state_dict(oc, 0)
+    ocfg = OS.StepConfig(multiphase=2, loss_type="huber", w_min=4.0, w_max=5.0)
+    inp = OS.draw_inputs(2, ocfg, seed=7, latent_hw=8, ctx_len=7, ctx_dim=64)
+    cfg = StepConfig(multiphase=2, loss_type="huber", w_min=4.0, w_max=5.0)
+    args = (inp["latents"], inp["prompt_embeds"], inp["uncond_prompt_embeds"], inp["noise"], inp["index"], inp["w"])
+    keys = ("cond_teacher_output", "uncond_teacher_output", "x_prev", "noise_pred", "target_noise_pred", "loss")
+
+    def run(teacher_weights=None):
+        W = UNetWeights(pc, sd, "cpu")
+        lora = LoraState(pc, 64, 8.0, "cpu", seed=1, b_std=0.05)
+        out = Distiller(W, lora, cfg, teacher_weights=teacher_weights).forward_backward(*args)
+        return {k: out[k].clone() for k in keys}, lora.grads.clone()
+
+    precision.set_precision("bf16", lib=emu_lib("bf16"))
+    precision.register_lib("fp16", emu_lib("f16"))
+    try:
+        pure_b, g_b = run()
+        with precision.format_scope("fp16"):
+            assert ops.BF16 == torch.float16 and capi.lib().act_dtype == 1
+            Wt = UNetWeights(pc, sd, "cpu")
+        assert Wt.format == "fp16" and ops.BF16 == torch.bfloat16 and capi.lib().act_dtype == 0 and precision.precision() == "bf16"
+        mixed, g_m = run(Wt)
+        assert ops.BF16 == torch.bfloat16 and capi.lib().act_dtype == 0
+        precision.set_precision("fp16", lib=emu_lib("f16"))
+        pure_h, _ = run()
+    finally:
+        precision.set_precision("bf16", lib=emu_lib("bf16"))
+    for k in ("cond_teacher_output", "uncond_teacher_output", "x_prev"):
+        assert torch.equal(mixed[k], pure_h[k]), k
+        assert not torch.equal(mixed[k], pure_b[k]), k
+    assert torch.equal(mixed["noise_pred"], pure_b["noise_pred"])
+    # the target pass starts from the teacher's x_prev: it follows the half teacher, at bf16-student precision
+    rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())   # noqa: E731
+    assert 0 < rel(mixed["target_noise_pred"], pure_b["target_noise_pred"]) < 2e-2
+    assert abs(float(mixed["loss"]) - float(pure_b["loss"])) < 5e-2 * abs(float(pure_b["loss"]))
+    # (the gradient is proportional to model_pred - target, a small difference on this narrow net: it moves by tens of percent with the target)
+    assert float((g_m.double() * g_b.double()).sum() / (g_m.double().norm() * g_b.double().norm())) > 0.9 and not torch.equal(g_m, g_b)
+
+
+def test_cli_teacher_precision_fp16_end_to_end(tmp_path, monkeypatch):
+    """train_pcm_lora_sd15.py --teacher_precision fp16 as a program (narrow UNet, host emulators of both builds): the flag packs the frozen
+    weights a second time in half, the steps run with the student in bfloat16 (no loss scaler), and the logged losses differ from the
+    one-format run's on the same seeds (the teacher pass really ran in the other build)."""
+    import importlib.util
+    import json
+    import math
+    import os
+    from safetensors.torch import save_file
+    from pcm_amd import ops, precision
+    pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "phased-consistency-model_amd")
+    spec = importlib.util.spec_from_file_location("pcm_cli_teacher_fp16", os.path.join(pkg, "train_pcm_lora_sd15.py"))
+    cli = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cli)
+    g = torch.Generator().manual_seed(0)
+    shards = tmp_path / "s"
+    shards.mkdir()
+    save_file({"latents": torch.randn(6, 4, 8, 8, generator=g), "prompt_embeds": torch.randn(6, 7, 64, generator=g),
+               "uncond_prompt_embeds": torch.randn(7, 64, generator=g)}, str(shards / "a.safetensors"))
+    monkeypatch.setenv("PCM_CLI_DEVICE", "cpu")
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    precision.set_precision("bf16", lib=emu_lib("bf16"))
+    precision.register_lib("fp16", emu_lib("f16"))
+    logs = {}
+    for mode in ("same", "fp16"):
+        out = tmp_path / mode
+        cli.main(cli.parse_args(["--pretrained_teacher_model", "random", "--tiny_model", "--latents_dir", str(shards), "--train_batch_size", "1",
+                                 "--learning_rate", "1e-3", "--multiphase", "2", "--seed", "1", "--output_dir", str(out), "--loss_type", "huber",
+                                 "--max_train_steps", "2", "--teacher_precision", mode]))
+        assert ops.BF16 == torch.bfloat16 and capi.lib().act_dtype == 0 and precision.precision() == "bf16"
+        logs[mode] = [json.loads(l) for l in open(out / "logs" / "text2image-fine-tune.jsonl")]
+        assert [r["step"] for r in logs[mode]] == [1, 2] and all(math.isfinite(r["loss"]) for r in logs[mode])
+    a, b = logs["same"][0]["loss"], logs["fp16"][0]["loss"]
+    assert a != b and abs(a - b) < 0.1 * abs(a), (a, b)

@@ -118,3 +118,58 @@ def test_deterministic_step_is_bitwise_reproducible(setup):
     assert torch.equal(ga, gb) and torch.equal(pa, pb)
     lf, nf, gf, pf = run(False, steps=1)
     assert abs(lf[0] - la[0]) <= 1e-6 * abs(la[0]) and abs(nf[0] - na[0]) <= 1e-4 * na[0], (lf, la, nf, na)
+
+
+def test_fp16_teacher_bf16_student_split(setup):
+    """Distiller(teacher_weights = the frozen SD1.5 weights packed in IEEE half) next to the bfloat16 student: the reference's ODE-solver
+    teacher pass runs under ``torch.autocast("cuda")`` with no dtype (train_pcm_lora_sd15.py:1217-1218), i.e. in half whatever
+    --mixed_precision says.  At the real size, on the fixture's inputs: (1) the split is clean -- teacher outputs and x_prev BITWISE equal
+    an all-half process's, the student's prediction BITWISE equals the all-bfloat16 process's; (2) the half teacher is closer to the fp32
+    oracle than the bfloat16 one (11 significand bits against 8), and with it x_prev; (3) the loss against the fp32 oracle stays inside the
+    all-bfloat16 bound.  Both kernel libraries live in this one process (pcm_amd/precision.py format_scope)."""
+    import step_golden_cases as S
+    from golden_fixture import golden
+    from pcm_amd import capi, ops, precision
+    from pcm_amd.model import LoraState, UNetWeights
+    from pcm_amd.trainer import Distiller
+    from pcm_amd.unet_spec import UNetConfig
+    oc, sd, W = setup
+    ref = golden(S.step_name(0.02), lambda: S.ref_sd15_step(0.02))
+    dev = {k: v.cuda() for k, v in S.step_inputs().items()}
+    args = (dev["latents"], dev["prompt_embeds"], dev["uncond_prompt_embeds"], dev["noise"], dev["index"], dev["w"])
+    _, cfg = S.step_cfgs(2)
+    keys = ("cond_teacher_output", "uncond_teacher_output", "x_prev", "noise_pred", "target_noise_pred", "loss")
+
+    def run(weights, teacher_weights=None):
+        lora = LoraState(UNetConfig.sd15(), 64, 8.0, "cuda", seed=1, b_std=0.02)
+        out = Distiller(weights, lora, cfg, teacher_weights=teacher_weights).forward_backward(*args)
+        torch.cuda.synchronize()
+        return {k: out[k].clone() for k in keys}
+
+    assert precision.precision() == "bf16"
+    pure_b = run(W)
+    with precision.format_scope("fp16"):
+        assert ops.BF16 == torch.float16 and capi.lib().act_dtype == 1
+        Wt = UNetWeights(UNetConfig.sd15(), sd, "cuda")
+    assert Wt.format == "fp16" and ops.BF16 == torch.bfloat16 and capi.lib().act_dtype == 0
+    mixed = run(W, Wt)
+    assert ops.BF16 == torch.bfloat16 and capi.lib().act_dtype == 0
+    try:
+        precision.set_precision("fp16")
+        pure_h = run(Wt)
+    finally:
+        precision.set_precision("bf16")
+        capi.set_lib(None)
+    for k in ("cond_teacher_output", "uncond_teacher_output", "x_prev"):
+        assert torch.equal(mixed[k], pure_h[k]) and not torch.equal(mixed[k], pure_b[k]), k
+    assert torch.equal(mixed["noise_pred"], pure_b["noise_pred"])
+    rep = {k: (rel(mixed[k], ref[k]), rel(pure_b[k], ref[k])) for k in keys[:5]}
+    rloss = float(ref["loss"])
+    rep["loss_rel"] = (abs(float(mixed["loss"]) - rloss) / abs(rloss), abs(float(pure_b["loss"]) - rloss) / abs(rloss))
+    print("fp16 teacher + bf16 student vs all-bf16, rel. to the fp32 oracle:", {k: "%.3e / %.3e" % v for k, v in rep.items()})
+    import json, os
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/step_parity_fp16_teacher.json", "w") as f:
+        json.dump({k: {"fp16_teacher": v[0], "all_bf16": v[1]} for k, v in rep.items()}, f)
+    assert rep["cond_teacher_output"][0] < 0.5 * rep["cond_teacher_output"][1] and rep["x_prev"][0] < 0.5 * rep["x_prev"][1], rep
+    assert rep["loss_rel"][0] < 9e-3 and rep["target_noise_pred"][0] < 1.2e-2
