@@ -40,9 +40,10 @@ def sd15():
     return cfg, W
 
 
-def assert_grads_match_per_module(lora, grads_a, grads_b, tol_all=1e-5, tol_mod=2e-4):
+def assert_grads_match_per_module(lora, grads_a, grads_b, tol_all=1e-4, tol_mod=5e-4):
     """graph replay vs eager launches run the same kernels in the same order: the LoRA gradient buffers may differ only by the order of
-    fp32 atomics.  Checked on the whole flat buffer AND per LoRA module (a corrupted module -- the round-2 hipMemset-node bug hit
+    fp32 atomics (typically 1.2e-7 of the whole vector; 1.65e-5 when one atomically summed value that is then stored in bf16 flips its
+    rounding, which moves ONE small module by 1e-4 of its norm -- a corrupted module is off by O(1)).  Checked on the whole flat buffer AND per LoRA module (a corrupted module -- the round-2 hipMemset-node bug hit
     time_emb_proj only -- hides under a whole-buffer norm), relative to the module's own gradient norm."""
     assert rel(grads_a, grads_b) < tol_all, rel(grads_a, grads_b)
     base = lora.grads.data_ptr()
@@ -112,6 +113,8 @@ def test_graph_replay_equals_eager_bs16_and_batch_split(sd15):
         del Dd, lora_d
     finally:
         ops.set_deterministic(False)
+    # (atomics: the whole-vector bound of the comment above; per module 5e-4 -- the flipped bf16 rounding sits in ONE small module, 1e-4 of its
+    # norm, and a corrupted module is off by O(1))
     rep["worst_module_grad_rel"] = assert_grads_match_per_module(lora, grads_g, grads_e)
     # one whole optimizer step through both paths from the same state
     p0 = [t.clone() for t in (lora.params, lora.exp_avg, lora.exp_avg_sq, D.step_dev)]
