@@ -21,6 +21,7 @@ from . import capi, ops
 from .mmdit_spec import MMDiTConfig, buffer_spec, lora_target_modules, param_spec
 from .model import BF16, LoraState, PackedLayer, layer_bwd, layer_fwd
 from .ops import Seg
+from .precision import precision
 
 # debug hook: PCM_MMDIT_QKV=0 runs the six q/k/v projections of a block as separate layers (A/B measurement)
 FUSE_QKV = os.environ.get("PCM_MMDIT_QKV", "1") != "0"
@@ -31,6 +32,7 @@ class MMDiTWeights:
 
     def __init__(self, cfg: MMDiTConfig, state_dict, device, need_bwd=True):
         self.cfg, self.device = cfg, torch.device(device)
+        self.format = precision()            # the 16-bit format the operands below are packed in (pcm_amd/precision.py)
         spec = param_spec(cfg) + buffer_spec(cfg)
         missing = [k for k, _ in spec if k not in state_dict]
         if missing:

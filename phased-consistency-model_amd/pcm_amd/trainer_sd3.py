@@ -5,9 +5,11 @@ multiphase jumps (float64 through sigma_prev, like the reference), huber loss, L
 
 Shares the optimizer / gradient-exchange half with the SD1.5 Distiller (same flat fp32 LoRA buffer, one all-reduce).
 """
+import contextlib
+
 import torch
 
-from . import fm, ops
+from . import fm, ops, precision
 from .mmdit import MMDiT, MMDiTWeights
 from .model import LoraState
 from .trainer import Distiller
@@ -26,13 +28,19 @@ class SD3StepConfig:
 class SD3Distiller(Distiller):
     """Owns the frozen MMDiT weights, the LoRA state and the optimizer state of one rank."""
 
-    def __init__(self, weights: MMDiTWeights, lora: LoraState, cfg: SD3StepConfig, world_size=1, process_group=None):
+    def __init__(self, weights: MMDiTWeights, lora: LoraState, cfg: SD3StepConfig, world_size=1, process_group=None, teacher_weights=None):
+        """``teacher_weights``: the frozen weights packed in the OTHER 16-bit format for the ODE-solver teacher pass, which the reference runs
+        under a dtype-less ``torch.autocast("cuda")`` = IEEE half (train_pcm_lora_sd3.py:1334); see trainer.Distiller."""
         # (Distiller.__init__ builds the UNet runners and DDIM tables; this variant has its own, the optimizer half is inherited)
         self.W, self.lora, self.cfg = weights, lora, cfg
         self.device = lora.device
         self.solver = fm.EulerSolver(fm.flow_sigmas(cfg.num_train_timesteps, cfg.shift), cfg.num_train_timesteps, cfg.num_euler_timesteps, self.device)
         self.student = MMDiT(weights, lora)
         self.teacher = MMDiT(weights, None)
+        self.teacher_ode, self._ode_scope = self.teacher, contextlib.nullcontext
+        if teacher_weights is not None and teacher_weights.format != precision.precision():
+            fmt = teacher_weights.format
+            self.teacher_ode, self._ode_scope = MMDiT(teacher_weights, None), (lambda: precision.format_scope(fmt))
         self.world_size, self.pg = world_size, process_group
         self.step_count = 0
         self.step_dev = torch.zeros(1, dtype=torch.int64, device=self.device)
@@ -48,14 +56,16 @@ class SD3Distiller(Distiller):
         timesteps, timesteps_prev = S.timesteps(index, cfg.num_train_timesteps)                               # :1291-1300
         noisy = S.add_noise(model_input, noise, index)                                                        # :1301
         # frozen teacher, cond (+ uncond) as one 2B pass, fixed-w CFG + Euler step ----------------------------- :1332-1357
+        with self._ode_scope():
+            if cfg.not_apply_cfg_solver:
+                cond = uncond = self.teacher_ode.forward(noisy, timesteps, prompt_embeds, pooled_prompt_embeds)
+            else:
+                both = self.teacher_ode.forward(torch.cat([noisy, noisy]), torch.cat([timesteps, timesteps]),
+                                                torch.cat([prompt_embeds, uncond_prompt_embeds]), torch.cat([pooled_prompt_embeds, uncond_pooled_prompt_embeds]))
+                cond, uncond = both[:B], both[B:]
         if cfg.not_apply_cfg_solver:
-            cond = self.teacher.forward(noisy, timesteps, prompt_embeds, pooled_prompt_embeds)
             x_prev64, x_prev32 = S.euler_step(noisy, cond, index, None)
-            uncond = cond
         else:
-            both = self.teacher.forward(torch.cat([noisy, noisy]), torch.cat([timesteps, timesteps]),
-                                        torch.cat([prompt_embeds, uncond_prompt_embeds]), torch.cat([pooled_prompt_embeds, uncond_pooled_prompt_embeds]))
-            cond, uncond = both[:B], both[B:]
             x_prev64, x_prev32 = S.euler_step(noisy, cond, index, uncond, cfg.w)
         # online prediction (grad) and its jump to the phase edge ------------------------------------------------ :1304-1315
         pred, tape = self.student.forward(noisy, timesteps, prompt_embeds, pooled_prompt_embeds, save=True)
@@ -156,8 +166,9 @@ class SD3AdvDistiller(SD3Distiller):
     The discriminator = the frozen teacher transformer's per-block image-stream states + one 1x1-conv head per block
     (``pcm_amd.discriminator.Discriminator([D] * num_layers, num_h_per_head=1, ksize=1)``)."""
 
-    def __init__(self, weights, lora, cfg, discriminator, adv_weight=0.1, adv_lr=1e-5, loss_type="huber", world_size=1, process_group=None):
-        super().__init__(weights, lora, cfg, world_size, process_group)
+    def __init__(self, weights, lora, cfg, discriminator, adv_weight=0.1, adv_lr=1e-5, loss_type="huber", world_size=1, process_group=None,
+                 teacher_weights=None):
+        super().__init__(weights, lora, cfg, world_size, process_group, teacher_weights=teacher_weights)
         self.disc, self.adv_weight, self.adv_lr, self.loss_type = discriminator, adv_weight, adv_lr, loss_type
         self.adv_lr_dev = torch.full((1,), float(adv_lr), dtype=torch.float32, device=self.device)
         assert discriminator.head_num == weights.cfg.num_layers and discriminator.ksize == 1 and discriminator.nh == 1
@@ -174,12 +185,15 @@ class SD3AdvDistiller(SD3Distiller):
         is_d = (global_step % 2 == 0)
         timesteps, timesteps_prev = S.timesteps(index, cfg.num_train_timesteps)
         noisy = S.add_noise(model_input, noise, index)
+        with self._ode_scope():     # the ODE-solver teacher pass only (sd3_adv.py:1408); the discriminator's feature passes stay in the build format
+            if cfg.not_apply_cfg_solver:
+                cond = self.teacher_ode.forward(noisy, timesteps, prompt_embeds, pooled_prompt_embeds)
+            else:
+                both = self.teacher_ode.forward(torch.cat([noisy, noisy]), torch.cat([timesteps, timesteps]),
+                                                torch.cat([prompt_embeds, uncond_prompt_embeds]), torch.cat([pooled_prompt_embeds, uncond_pooled_prompt_embeds]))
         if cfg.not_apply_cfg_solver:
-            cond = self.teacher.forward(noisy, timesteps, prompt_embeds, pooled_prompt_embeds)
             x_prev64, x_prev32 = S.euler_step(noisy, cond, index, None)
         else:
-            both = self.teacher.forward(torch.cat([noisy, noisy]), torch.cat([timesteps, timesteps]),
-                                        torch.cat([prompt_embeds, uncond_prompt_embeds]), torch.cat([pooled_prompt_embeds, uncond_pooled_prompt_embeds]))
             x_prev64, x_prev32 = S.euler_step(noisy, both[:B], index, both[B:], cfg.w)
         if is_d:        # the student forward is not back-propagated on discriminator steps: no tape
             pred, tape = self.student.forward(noisy, timesteps, prompt_embeds, pooled_prompt_embeds), None

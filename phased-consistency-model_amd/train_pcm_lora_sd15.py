@@ -79,11 +79,7 @@ def parse_args(argv=None):
     p.add_argument("--mixed_precision", type=str, default=None, choices=["no", "fp16", "bf16"])
     p.add_argument("--allow_tf32", action="store_true")
     p.add_argument("--cast_teacher_unet", action="store_true")
-    p.add_argument("--teacher_precision", type=str, default="same", choices=["same", "fp16"],
-                   help="format of the ODE-solver teacher pass.  The reference runs it under torch.autocast('cuda') with no dtype "
-                        "(train_pcm_lora_sd15.py:1218), i.e. in IEEE half whatever --mixed_precision says; 'fp16' reproduces that next to a "
-                        "bfloat16 student (a second, half packing of the frozen weights: +1.7 GB at SD1.5 size).  'same' (default): one format "
-                        "for every pass, one weight packing")
+    p.add_argument("--teacher_precision", type=str, default="same", choices=["same", "fp16"], help=TEACHER_PRECISION_HELP)
     p.add_argument("--enable_xformers_memory_efficient_attention", action="store_true")
     p.add_argument("--gradient_checkpointing", action="store_true")
     p.add_argument("--local_rank", type=int, default=-1)
@@ -278,15 +274,23 @@ def apply_mixed_precision(args):
         logger.info("--mixed_precision=fp16: half build of the kernel library (lib/libpcm_hip_f16.so), dynamic loss scaling on the device")
 
 
-def teacher_weights_for(args, ucfg, sd, device):
+TEACHER_PRECISION_HELP = ("format of the ODE-solver teacher pass.  The reference runs it under torch.autocast('cuda') with no dtype "
+                          "(train_pcm_lora_sd15.py:1218), i.e. in IEEE half whatever --mixed_precision says; 'fp16' reproduces that next to a "
+                          "bfloat16 student (a second, half packing of the frozen weights: +1.7 GB at SD1.5 size).  'same' (default): one format "
+                          "for every pass, one weight packing")
+
+
+def teacher_weights_for(args, ucfg, sd, device, weights_cls=None):
     """--teacher_precision fp16 under a bfloat16 student: the frozen weights packed a second time, in IEEE half, for the ODE-solver teacher pass
-    (trainer.Distiller ``teacher_weights``); None when every pass runs in the one format of the process.  No backward operands: the pass has none."""
+    (trainer.Distiller ``teacher_weights``); None when every pass runs in the one format of the process.  No backward operands: the pass has none.
+    ``weights_cls``: UNetWeights (default) or MMDiTWeights."""
     from pcm_amd import precision
-    from pcm_amd.model import UNetWeights
+    if weights_cls is None:
+        from pcm_amd.model import UNetWeights as weights_cls
     if getattr(args, "teacher_precision", "same") != "fp16" or precision.precision() == "fp16":
         return None
     with precision.format_scope("fp16"):
-        Wt = UNetWeights(ucfg, sd, device, need_bwd=False)
+        Wt = weights_cls(ucfg, sd, device, need_bwd=False)
     logger.info("--teacher_precision=fp16: ODE-solver teacher pass in IEEE half (lib/libpcm_hip_f16.so) next to the bfloat16 student")
     return Wt
 

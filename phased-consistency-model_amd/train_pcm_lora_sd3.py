@@ -91,6 +91,7 @@ def parse_args(argv=None):
     p.add_argument("--allow_tf32", action="store_true")
     p.add_argument("--report_to", type=str, default="tensorboard")
     p.add_argument("--mixed_precision", type=str, default=None, choices=["no", "fp16", "bf16"])
+    p.add_argument("--teacher_precision", type=str, default="same", choices=["same", "fp16"], help=base.TEACHER_PRECISION_HELP)
     p.add_argument("--prior_generation_precision", type=str, default=None)
     p.add_argument("--local_rank", type=int, default=-1)
     p.add_argument("--num_euler_timesteps", type=int, default=50)
@@ -215,6 +216,7 @@ def main(args):
     else:
         sd = ck.load_transformer_state_dict(args.pretrained_teacher_model)
     W = MMDiTWeights(mcfg, sd, device)
+    Wt = base.teacher_weights_for(args, mcfg, sd, device, MMDiTWeights)
     del sd
     lora = sd3_lora_state(mcfg, args.lora_rank, 8.0, device, seed=(args.seed or 0))
     if world > 1:
@@ -224,7 +226,7 @@ def main(args):
                         learning_rate=args.learning_rate, adam_beta1=args.adam_beta1, adam_beta2=args.adam_beta2,
                         adam_weight_decay=args.adam_weight_decay, adam_epsilon=args.adam_epsilon, max_grad_norm=args.max_grad_norm,
                         lora_rank=args.lora_rank, not_apply_cfg_solver=args.not_apply_cfg_solver)
-    D = SD3Distiller(W, lora, cfg, world_size=world)
+    D = SD3Distiller(W, lora, cfg, world_size=world, teacher_weights=Wt)
     src = SD3Source(args, rank, world, device, mcfg)
     if args.max_train_steps is None:
         args.max_train_steps = args.num_train_epochs * base.agreed_steps_per_epoch(len(src), world)

@@ -82,6 +82,7 @@ def main(args):
     else:
         sd = ck.load_transformer_state_dict(args.pretrained_teacher_model)
     W = MMDiTWeights(mcfg, sd, device)
+    Wt = base.teacher_weights_for(args, mcfg, sd, device, MMDiTWeights)
     del sd
     lora = sd3_lora_state(mcfg, args.lora_rank, 8.0, device, seed=(args.seed or 0), targets=lora_targets(), init="kaiming")
     disc = Discriminator([mcfg.inner_dim] * mcfg.num_layers, num_h_per_head=1, device=device, seed=(args.seed or 0) + 1, ksize=1)   # discriminator_sd3.py:171-190
@@ -92,7 +93,7 @@ def main(args):
                         learning_rate=args.learning_rate, adam_beta1=args.adam_beta1, adam_beta2=args.adam_beta2,
                         adam_weight_decay=args.adam_weight_decay, adam_epsilon=args.adam_epsilon, max_grad_norm=args.max_grad_norm,
                         lora_rank=args.lora_rank, not_apply_cfg_solver=args.not_apply_cfg_solver)
-    D = SD3AdvDistiller(W, lora, cfg, disc, adv_weight=args.adv_weight, adv_lr=args.adv_lr, loss_type=args.loss_type, world_size=world)
+    D = SD3AdvDistiller(W, lora, cfg, disc, adv_weight=args.adv_weight, adv_lr=args.adv_lr, loss_type=args.loss_type, world_size=world, teacher_weights=Wt)
     src = sd3.SD3Source(args, rank, world, device, mcfg)
     if args.max_train_steps is None:
         args.max_train_steps = args.num_train_epochs * base.agreed_steps_per_epoch(len(src), world)

@@ -86,3 +86,49 @@ def test_property_case_on_a_narrow_config():
     pc = MMDiTConfig(**kw)
     W = MMDiTWeights(pc, O.init_state_dict(O.MMDiTConfig(**kw), 0), "cpu")
     run_property_case("cpu", pc, W, sd3_lora_state(pc, 32, 8.0, "cpu", seed=1), 8, 5)
+
+
+def test_sd3_fp16_teacher_next_to_a_bf16_student_is_exactly_the_two_pure_builds():
+    """SD3Distiller(teacher_weights = the frozen MMDiT weights packed in IEEE half): the reference's teacher pass sits under a dtype-less
+    ``torch.autocast("cuda")`` (train_pcm_lora_sd3.py:1334).  Same statement as the UNet twin in tests/test_emu_unet.py: teacher output and
+    x_prev bitwise an all-half process's, the online prediction bitwise the all-bfloat16 process's."""
+    from oracle import mmdit_sd3 as O
+    from pcm_amd import ops, precision
+    from pcm_amd.mmdit import MMDiTWeights, sd3_lora_state
+    from pcm_amd.mmdit_spec import MMDiTConfig
+    from pcm_amd.trainer_sd3 import SD3Distiller, SD3StepConfig
+    kw = dict(sample_size=16, num_layers=2, attention_head_dim=64, num_attention_heads=2, joint_attention_dim=96, caption_projection_dim=128,
+              pooled_projection_dim=64, pos_embed_max_size=12)
+    oc, pc = O.MMDiTConfig(**kw), MMDiTConfig(**kw)
+    sd = O.init_state_dict(oc, 0)
+    B, H, Wd, Lc = 2, 8, 8, 5
+    g = torch.Generator().manual_seed(5)
+    x0, noise = torch.randn(B, 16, H, Wd, generator=g), torch.randn(B, 16, H, Wd, generator=g)
+    pe, upe = torch.randn(B, Lc, 96, generator=g), torch.randn(B, Lc, 96, generator=g)
+    pp, upp = torch.randn(B, 64, generator=g), torch.randn(B, 64, generator=g)
+    args = (x0, pe, pp, upe, upp, noise, torch.tensor([49, 13]))
+    cfg = SD3StepConfig(multiphase=4)
+
+    def run(teacher_weights=None):
+        W = MMDiTWeights(pc, sd, "cpu")
+        lora = sd3_lora_state(pc, 32, 8.0, "cpu", seed=1, b_std=0.1)
+        out = SD3Distiller(W, lora, cfg, teacher_weights=teacher_weights).forward_backward(*args)
+        return {k: out[k].clone() for k in ("cond_teacher_output", "uncond_teacher_output", "x_prev", "model_output", "loss")}
+
+    precision.set_precision("bf16", lib=emu_lib("bf16"))
+    precision.register_lib("fp16", emu_lib("f16"))
+    try:
+        pure_b = run()
+        with precision.format_scope("fp16"):
+            Wt = MMDiTWeights(pc, sd, "cpu", need_bwd=False)
+        assert Wt.format == "fp16" and ops.BF16 == torch.bfloat16 and capi.lib().act_dtype == 0
+        mixed = run(Wt)
+        assert ops.BF16 == torch.bfloat16 and capi.lib().act_dtype == 0 and precision.precision() == "bf16"
+        precision.set_precision("fp16", lib=emu_lib("f16"))
+        pure_h = run()
+    finally:
+        precision.set_precision("bf16", lib=emu_lib("bf16"))
+    for k in ("cond_teacher_output", "uncond_teacher_output", "x_prev"):
+        assert torch.equal(mixed[k], pure_h[k]) and not torch.equal(mixed[k], pure_b[k]), k
+    assert torch.equal(mixed["model_output"], pure_b["model_output"])
+    assert abs(float(mixed["loss"]) - float(pure_b["loss"])) < 5e-2 * abs(float(pure_b["loss"]))
