@@ -67,9 +67,58 @@ def test_two_rank_allreduce_and_step(tmp_path):
     assert torch.allclose(p0, ref_p, rtol=1e-5, atol=1e-7)
 
 
-def _step_worker(rank, world, port, outdir, prec="bf16"):
+def _install_host_graphs(D, B, hw, ctx_len, ctx_dim):
+    """Stand-ins for the three captured hipGraphs of ``Distiller.capture`` at world_size > 1 (there is no hipGraph on the host emulator): a
+    "replay" runs the launches the graph would hold.  The forward + backward is ONE call that is cut where the backward leaves the mid
+    block (``on_late``), exactly like the capture: replay of graph A runs it up to the cut and parks it, replay of graph B lets it finish.
+    With these in place the REAL ``Distiller.step_graphed`` runs its replay order -- A, late-bucket all-reduce, B, early bucket + wait,
+    optimizer -- over gloo, so the first RCCL run of bench.py is not the first execution of that ordering."""
+    import threading
+    a_done, go_b, st = threading.Event(), threading.Event(), {}
+
+    def body():
+        def cut():
+            st["cuts"] = st.get("cuts", 0) + 1
+            a_done.set()
+            go_b.wait()
+        try:
+            D._static_out = D.forward_backward(**D._static, on_late=cut)
+            D._static_out["grad_sumsq"] = D.lora.gradsq
+        except BaseException as e:      # surfaced by the replay that joins the thread
+            st["err"] = e
+            a_done.set()
+
+    class GraphA:
+        def replay(self):
+            a_done.clear(); go_b.clear()
+            st["t"] = threading.Thread(target=body)
+            st["t"].start()
+            a_done.wait()
+            if "err" in st:
+                raise st["err"]
+
+    class GraphB:
+        def replay(self):
+            go_b.set()
+            st["t"].join()
+            if "err" in st:
+                raise st["err"]
+
+    class GraphOpt:
+        def replay(self):
+            D._optimizer_apply()
+    f32 = dict(dtype=torch.float32)
+    D._static = dict(latents=torch.zeros(B, 4, hw, hw, **f32), prompt_embeds=torch.zeros(B, ctx_len, ctx_dim, **f32),
+                     uncond_prompt_embeds=torch.zeros(B, ctx_len, ctx_dim, **f32), noise=torch.zeros(B, 4, hw, hw, **f32),
+                     index=torch.zeros(B, dtype=torch.int64), w=torch.ones(B, **f32))
+    D._g_fb, D._g_fb2, D._g_opt, D._graph = GraphA(), GraphB(), GraphOpt(), True
+    return st
+
+
+def _step_worker(rank, world, port, outdir, prec="bf16", graphed=False):
     """Full distillation step (fused online+target forward, LoRA backward, all-reduce, clip + AdamW) of a tiny UNet on this rank's shard.
-    ``prec`` "fp16": through the half build of the emulator library, loss-scaled (the all-reduce then sums S * grad)."""
+    ``prec`` "fp16": through the half build of the emulator library, loss-scaled (the all-reduce then sums S * grad).
+    ``graphed``: through Distiller.step_graphed with host stand-ins for the captured graphs (_install_host_graphs)."""
     sys.path[:0] = [ROOT, os.path.join(ROOT, "phased-consistency-model_amd"), os.path.join(ROOT, "tests")]
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     if world > 1:
@@ -100,11 +149,17 @@ def _step_worker(rank, world, port, outdir, prec="bf16"):
         assert lora.late_offset is not None and 0 < lora.late_offset < lora.numel
         orig = D._all_reduce_late
         D._all_reduce_late = lambda: (fired.append(1), orig())[1]
-    out = D.step(*(inp[k][sl].contiguous() for k in ("latents", "prompt_embeds", "uncond_prompt_embeds", "noise", "index", "w")))
+    args = [inp[k][sl].contiguous() for k in ("latents", "prompt_embeds", "uncond_prompt_embeds", "noise", "index", "w")]
+    if graphed:
+        st = _install_host_graphs(D, n, 8, 7, 64)
+        out = D.step_graphed(*args)
+        assert st["cuts"] == 1 and D.step_count == 1
+    else:
+        out = D.step(*args)
     assert (world == 1) or (fired == [1] and D._late_work is None)
     if prec == "fp16":      # a finite step: applied, counted, the scale unchanged -- on every rank alike
         assert float(D.loss_scale_dev) == 65536.0 and int(D.loss_good_dev) == 1 and int(D.step_dev) == 1
-    torch.save((lora.params.clone(), float(out["loss"])), os.path.join(outdir, f"w{world}r{rank}.pt"))
+    torch.save((lora.params.clone(), float(out["loss"])), os.path.join(outdir, f"w{world}r{rank}{'g' if graphed else ''}.pt"))
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
@@ -127,6 +182,25 @@ def test_two_rank_full_step_half_build(tmp_path):
     assert abs((l0 + l1) / 2 - l_single) < 5e-3 * abs(l_single)
     rel = float((p0 - ps1).norm() / ps1.norm())
     assert rel < 2e-3, rel          # one lr = 1e-3 Adam step of sign-like updates on |param| ~ 3e-2: both runs move the same way
+
+
+def test_two_rank_split_graph_replay_order_equals_the_eager_bucketed_step(tmp_path):
+    """bench.py at N > 1 replays the step as graph A / late-bucket all-reduce / graph B / early bucket + wait / optimizer graph
+    (Distiller.step_graphed).  The same control flow over gloo with host stand-ins for the graphs must land BITWISE on the eager bucketed
+    step of the same two ranks (the emulator runs launches sequentially and a 2-rank sum has one order): the late bucket is final at the
+    cut, nothing after it writes into that bucket, and the exchange sees every gradient exactly once."""
+    ctx = mp.get_context("spawn")
+    ps = [ctx.Process(target=_step_worker, args=(r, 2, 29771, str(tmp_path), "bf16", True)) for r in range(2)]
+    ps += [ctx.Process(target=_step_worker, args=(r, 2, 29772, str(tmp_path))) for r in range(2)]
+    for p in ps:
+        p.start()
+    for p in ps:
+        p.join(600)
+        assert p.exitcode == 0
+    (g0, lg0), (g1, lg1) = (torch.load(os.path.join(str(tmp_path), f"w2r{r}g.pt")) for r in range(2))
+    (e0, le0), (e1, le1) = (torch.load(os.path.join(str(tmp_path), f"w2r{r}.pt")) for r in range(2))
+    assert torch.equal(g0, g1) and torch.equal(e0, e1), "ranks diverged"
+    assert torch.equal(g0, e0) and lg0 == le0 and lg1 == le1
 
 
 def test_two_rank_full_step_matches_single_process_on_the_global_batch(tmp_path):
