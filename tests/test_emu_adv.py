@@ -206,3 +206,47 @@ def test_segmented_capture_cuts_at_every_collective(monkeypatch):
         calls.clear()
     assert shapes == {0: "g" + "hg" * 6, 1: "ghg"}, shapes
     assert D.step_count == 0      # the captured pass does not advance the host-side step counter (step_adv_graphed does)
+
+
+@pytest.mark.parametrize("global_step", [0, 1])
+def test_adv_step_with_fp16_teacher_pass_keeps_the_discriminator_in_the_build_format(global_step):
+    """AdvDistiller(teacher_weights = half packing): only the ODE-solver teacher pass (sd15_adv.py:1312, a dtype-less autocast) runs in IEEE
+    half; the discriminator's feature passes through the frozen UNet -- which are back-propagated -- stay in the process's format.  So on
+    the same inputs ``fake_adv`` (student only) is BITWISE the one-format step's, the target-side quantities move a little with the better
+    teacher, the step applies, and the process is back in bfloat16 afterwards."""
+    import adv_cases as A
+    from oracle import unet_sd15 as O
+    from pcm_amd import ops, precision
+    from pcm_amd.model import UNetWeights
+    from pcm_amd.trainer import AdvDistiller
+    kw = dict(block_out_channels=(64, 128), layers_per_block=1, cross_attention_dim=64, heads=2, norm_num_groups=32)
+    dims = (64, 128, 128, 128, 64)
+    precision.set_precision("bf16", lib=emu_lib("bf16"))
+    precision.register_lib("fp16", emu_lib("f16"))
+
+    def run(split):
+        oc, pc, lora, disc, ocfg, cfg, inp = A._setup("cpu", kw, dims, 2, 8, 7, 64, 1, 5e-6, None, 11)
+        sd = O.init_state_dict(oc, 0)
+        W, Wt = UNetWeights(pc, sd, "cpu"), None
+        if split:
+            with precision.format_scope("fp16"):
+                Wt = UNetWeights(pc, sd, "cpu", need_bwd=False)
+        D = AdvDistiller(W, lora, cfg, disc, adv_weight=0.1, adv_lr=1e-5, teacher_weights=Wt)
+        p_l, p_d = lora.params.clone(), disc.params.clone()
+        out = D.step_adv(global_step, inp["latents"], inp["prompt_embeds"], inp["uncond_prompt_embeds"], inp["noise"], inp["index"], inp["w"],
+                         inp["noise_fake"], inp["noise_real"], inp["adv_u"])
+        assert ops.BF16 == torch.bfloat16 and capi.lib().act_dtype == 0 and precision.precision() == "bf16"
+        moved = (not torch.equal(lora.params, p_l), not torch.equal(disc.params, p_d))
+        return {k: (v.clone() if torch.is_tensor(v) else v) for k, v in out.items()}, moved
+
+    try:
+        a, moved_a = run(False)
+        b, moved_b = run(True)
+    finally:
+        precision.set_precision("bf16", lib=emu_lib("bf16"))
+    assert moved_a == moved_b == ((False, True) if global_step % 2 == 0 else (True, False))
+    assert torch.equal(a["fake_adv"], b["fake_adv"]) and torch.equal(a["model_pred"], b["model_pred"])
+    rel = lambda x, y: float((x.double() - y.double()).norm() / y.double().norm())   # noqa: E731
+    assert 0 < rel(b["target"], a["target"]) < 2e-2
+    key = "d_loss" if global_step % 2 == 0 else "g_loss"
+    assert abs(float(b[key]) - float(a[key])) < 5e-2 * abs(float(a[key])) + 1e-6, (float(a[key]), float(b[key]))
