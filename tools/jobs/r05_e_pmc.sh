@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 5, call E: the north star's own evidence on the final tree -- MFMA utilisation and HBM GB/s per kernel of one eager bs-16 step, from
 # three separate rocprofv3 --pmc passes (SQ counters; FETCH_SIZE; WRITE_SIZE -- each with --kernel-trace only), merged by tools/pmc_step_table.py
-cd $GRAFT_REPO_ROOT; O=gpurun_out/r05e; mkdir -p $O; export TMPDIR=/tmp
+cd $GRAFT_REPO_ROOT; O=gpurun_out/${PCM_JOB_OUT:-r05e}; mkdir -p $O; export TMPDIR=/tmp
 CMD="python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-graph --no-cpu-baseline --no-roofline"
 (cd /tmp && timeout 420 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE --kernel-trace -d /tmp/pmc_s -o s -- $CMD > $GRAFT_REPO_ROOT/$O/pmc_s.log 2>&1); echo "pmc S rc=$?" >> $O/rc.log
 (cd /tmp && timeout 420 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/pmc_f -o f -- $CMD > $GRAFT_REPO_ROOT/$O/pmc_f.log 2>&1); echo "pmc F rc=$?" >> $O/rc.log
