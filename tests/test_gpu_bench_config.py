@@ -40,10 +40,11 @@ def sd15():
     return cfg, W
 
 
-def assert_grads_match_per_module(lora, grads_a, grads_b, tol_all=1e-4, tol_mod=5e-4):
+def assert_grads_match_per_module(lora, grads_a, grads_b, tol_all=1e-4, tol_mod=5e-3):
     """graph replay vs eager launches run the same kernels in the same order: the LoRA gradient buffers may differ only by the order of
     fp32 atomics (typically 1.2e-7 of the whole vector; 1.65e-5 when one atomically summed value that is then stored in bf16 flips its
-    rounding, which moves ONE small module by 1e-4 of its norm -- a corrupted module is off by O(1)).  Checked on the whole flat buffer AND per LoRA module (a corrupted module -- the round-2 hipMemset-node bug hit
+    rounding, which moves ONE small module -- measured: up_blocks.3.resnets.0.time_emb_proj by 1.29e-3 of its norm, the same two-state
+    value on four of five runs of one box and on none of another's; a corrupted module is off by O(1)).  Checked on the whole flat buffer AND per LoRA module (a corrupted module -- the round-2 hipMemset-node bug hit
     time_emb_proj only -- hides under a whole-buffer norm), relative to the module's own gradient norm."""
     assert rel(grads_a, grads_b) < tol_all, rel(grads_a, grads_b)
     base = lora.grads.data_ptr()
@@ -91,7 +92,7 @@ def test_graph_replay_equals_eager_bs16_and_batch_split(sd15):
            "grad_rel_graph_vs_eager": rel(grads_g, grads_e), "eps_rel_graph_vs_eager": rel(D._static_out["noise_pred"], eps_e)}
     # same kernels, same launch order; the only freedom is the order of fp32 / fp64 atomics (LoRA wgrad, GroupNorm statistics, the pixel sums
     # behind time_emb_proj).  Typically 1.2e-7 on the whole vector; a last-bit difference of an atomically summed value that is then STORED in
-    # bf16 (the time-embedding cotangent) can flip that rounding and move one small module by 1e-4 (tools/graph_vs_eager.py,
+    # bf16 (the time-embedding cotangent) can flip that rounding and move one small module by up to 1.3e-3 of its norm (tools/graph_vs_eager.py,
     # profiles/r05_f_*): seen as 1.65e-5 on the whole vector once.  The bitwise statement is made below with the reproducible reductions.
     assert rep["loss_rel"] < 1e-6 and rep["eps_rel_graph_vs_eager"] < 1e-6 and rep["grad_rel_graph_vs_eager"] < 1e-4, rep   # measured: 0, 0, 1.2e-7
     from pcm_amd import ops
@@ -113,8 +114,6 @@ def test_graph_replay_equals_eager_bs16_and_batch_split(sd15):
         del Dd, lora_d
     finally:
         ops.set_deterministic(False)
-    # (atomics: the whole-vector bound of the comment above; per module 5e-4 -- the flipped bf16 rounding sits in ONE small module, 1e-4 of its
-    # norm, and a corrupted module is off by O(1))
     rep["worst_module_grad_rel"] = assert_grads_match_per_module(lora, grads_g, grads_e)
     # one whole optimizer step through both paths from the same state
     p0 = [t.clone() for t in (lora.params, lora.exp_avg, lora.exp_avg_sq, D.step_dev)]
