@@ -21,7 +21,7 @@
 //  3. The 1/sqrt(d) of dS is folded into the epilogue (dq', dK are scaled by ln 2 once per output element).
 // Per 64-key tile and wave, d = 40 forward: 14 MFMAs + 32 v_exp + 16 v_cvt_pk + staging, against + 16 v_pk_fma + 24 v_max3 + compares.
 //
-// Head dims without spare slots (32, 64, 160) and the IEEE-half build (-DPCM_ACT_F16: -delta of loss-scaled gradients can leave the
+// Head dims without spare slots (32, 64, 80, 160) and the IEEE-half build (-DPCM_ACT_F16: -delta of loss-scaled gradients can leave the
 // half range) keep the subtraction on the VALU (s' + (-m), one packed add per score pair) and gain only items 2 and 3.
 // Replaces F.scaled_dot_product_attention / xformers (train_pcm_lora_sd15.py:947-957) for every attention of the UNet passes.
 #include "attn_dev.h"
