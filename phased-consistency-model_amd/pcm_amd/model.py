@@ -128,6 +128,17 @@ class UNetWeights:
                 rows += [lk.w_fwd.view(lk.N, lk.K), lv.w_fwd.view(lv.N, lv.K)]
                 off += lk.N + lv.N
             self.kv_cat = torch.cat(rows).contiguous()
+        # every resnet's time_emb_proj reads the same [B, K] input: ONE GEMM per pass (rows [W_0; W_1; ...], 22 launches -> one at SD1.5 size;
+        # UNet._temb_all scatters the [B, sum N] result into per-resnet contiguous row vectors with one segmented-pack launch)
+        self.temb_cat, self.temb_bias, self.temb_off = None, None, {}
+        tp = [p_ for p_ in self.layers if p_.endswith("time_emb_proj")]
+        if len(tp) >= 2 and all(self.layers[t].kind == "lin" and self.layers[t].bias is not None for t in tp) and len({self.layers[t].K for t in tp}) == 1:
+            off = 0
+            for t in tp:
+                self.temb_off[t] = (off, self.layers[t].N)
+                off += self.layers[t].N
+            self.temb_cat = torch.cat([self.layers[t].w_fwd.view(self.layers[t].N, self.layers[t].K) for t in tp]).contiguous()
+            self.temb_bias = torch.cat([self.layers[t].bias.reshape(-1) for t in tp]).contiguous()
         self.conv_in = (state_dict["conv_in.weight"].to(**f32).contiguous(), state_dict["conv_in.bias"].to(**f32).contiguous())
         self.conv_out = (state_dict["conv_out.weight"].to(**f32).contiguous(), state_dict["conv_out.bias"].to(**f32).contiguous())
 
@@ -152,8 +163,14 @@ class HalfSaved:
 FUSE_GEGLU_GRAD = os.environ.get("PCM_FUSE_GEGLU", "1") != "0"
 # debug hook: PCM_TEXT_KV=0 runs the frozen pass's cross-attention K / V projections layer by layer (A/B measurement)
 FUSE_TEXT_KV = os.environ.get("PCM_TEXT_KV", "1") != "0"
+FUSE_TEMB = os.environ.get("PCM_TEMB_BATCH", "1") != "0"      # every resnet's time_emb_proj of a pass as one GEMM (UNet._temb_all); 0: one GEMM per resnet
 # debug hook: PCM_LORA_QKV=0 runs the self-attention q/k/v LoRA projections as three separate layers (A/B measurement)
 FUSE_LORA_QKV = os.environ.get("PCM_LORA_QKV", "1") != "0"
+
+
+class LoraTemb:
+    """concatenated operands of every resnet's time_emb_proj LoRA (LoraState.temb): paths in row order, off[path] = (first row, N, index)"""
+    __slots__ = ("paths", "K", "N", "off", "A_cat", "Bs_cat")
 
 
 class LoraQKV:
@@ -285,7 +302,31 @@ class LoraState:
                 descs.append((oa_j, o_caf + j * r * Kc, o_cab + j * r, r, Kc, Kc, Kc, 3 * r, 1.0))
                 descs.append((ob_j, o_cbf + j * Nc * 3 * r + j * r, o_cbb + j * r * 3 * Nc + j * Nc, Nc, r, r, 3 * r, 3 * Nc,
                               self.scaling * self.q_scale.get(t.path, 1.0)))
+        # every resnet's time_emb_proj reads the SAME input (silu of the time embedding, [B, 1280]): their rank-64 down-projections are one
+        # [B, K] x [K, n*r] GEMM and their up-projections ride ONE batched base GEMM as a block-diagonal K = n*r segment (UNet._temb_all;
+        # off-diagonal blocks stay at the zeros this buffer is created with):  A_cat [n*r][K],  Bs_cat [sum N][n*r]
+        temb_layout = None
+        tp = [path for path, _, _, _ in layout if path.endswith("time_emb_proj") and self.modules[path].kind == "lin"]
+        if len(tp) >= 2 and len({self.modules[t].K for t in tp}) == 1:
+            nt, Kt, SNt = len(tp), self.modules[tp[0]].K, sum(self.modules[t].N for t in tp)
+            o_tc, o_tb = alloc(nt * r * Kt), alloc(SNt * nt * r)
+            roff, toff = 0, {}
+            for j, t in enumerate(tp):
+                oa_j, ob_j = offs[t]
+                descs.append((oa_j, o_tc + j * r * Kt, -1, r, Kt, Kt, Kt, 0, 1.0))
+                descs.append((ob_j, o_tb + roff * nt * r + j * r, -1, self.modules[t].N, r, r, nt * r, 0, self.scaling))
+                toff[t] = (roff, self.modules[t].N, j)
+                roff += self.modules[t].N
+            temb_layout = (tp, Kt, SNt, o_tc, o_tb, toff)
         self.operands = torch.zeros(ototal, dtype=BF16, device=self.device)
+        self.temb = None
+        if temb_layout is not None:
+            tp, Kt, SNt, o_tc, o_tb, toff = temb_layout
+            f = LoraTemb()
+            f.paths, f.K, f.N, f.off = tp, Kt, SNt, toff
+            f.A_cat = self.operands[o_tc:o_tc + len(tp) * r * Kt].view(len(tp) * r, Kt)
+            f.Bs_cat = self.operands[o_tb:o_tb + SNt * len(tp) * r].view(SNt, len(tp) * r)
+            self.temb = f
         self.qkv = {}
         for p, Kc, Nc, o_caf, o_cab, o_cbf, o_cbb in qkv_layout:
             f = LoraQKV()
@@ -487,6 +528,11 @@ class UNet:
         self._kv_all = None     # frozen pass: every cross-attention's K / V projection of the text, one GEMM (UNetWeights.kv_cat)
         self._side = None       # WgradSide of this runner's backward passes
         self._save_half = False
+        self._temb = None       # this pass's time_emb_proj outputs of every resnet, one batched GEMM (_temb_all); None: per-resnet GEMMs
+        self._temb_plans = {}   # (batch, rank) -> device descriptor tables of the two scatter launches
+        # the LoRA state's block-diagonal operand is laid out in ITS module order: batch only when that is the weights' order (same rows)
+        self._temb_orders_agree = (lora is not None and getattr(lora, "temb", None) is not None and list(weights.temb_off) == list(lora.temb.paths)
+                                   and all(weights.temb_off[t] == lora.temb.off[t][:2] for t in lora.temb.paths) and lora.temb.K == weights.temb_cat.shape[1])
 
     # ---- norm helpers ----
     def _gn(self, path, x, act, eps, save):
@@ -500,6 +546,57 @@ class UNet:
         g, b = self.W.norms[path]
         return ops.groupnorm_bwd(saved["gn_x"], dy, saved["gn_stats"], g, b, self.cfg.norm_num_groups, eps, act, arena=self._arena)
 
+    # ---- every resnet's time_emb_proj of one pass ----
+    def _temb_all(self, emb_act, B):
+        """{path: (temb [B, N] bf16 contiguous, t [B, r] bf16 contiguous or None)} for every resnet of the pass from ONE base GEMM (+ ONE rank-64
+        down-projection GEMM with LoRA): all of them read the same ``emb_act`` [B, K].  The GEMMs write fp32 ([B, sum N] / [B, n*r]); one
+        segmented-pack launch each rounds to the 16-bit format -- the same single rounding of the fp32 accumulator the per-resnet GEMM
+        epilogue does -- and scatters the columns into per-resnet CONTIGUOUS blocks (conv1's epilogue reads its row vector with row stride
+        N; the backward reads t with row stride r).  22 + 22 + 22 launches of 8-16 us -> 2 + 4 per step at SD1.5 size."""
+        W, lora = self.W, self.lora
+        dev = emb_act.device
+        paths, SN = list(W.temb_off), W.temb_cat.shape[0]
+        nt = len(paths)
+        r = lora.rank if lora is not None else 0
+        key = (B, r)
+        plan = self._temb_plans.get(key)
+        if plan is None:
+            import numpy as np
+
+            def table(descs):
+                arr = (capi.PackDesc * len(descs))()
+                starts = np.zeros(len(descs) + 1, dtype=np.int32)
+                for i, d in enumerate(descs):
+                    (arr[i].src_off, arr[i].dst_copy_off, arr[i].dst_t_off, arr[i].R, arr[i].Cc, arr[i].lds, arr[i].ldc, arr[i].ldt, arr[i].scale) = d
+                    starts[i + 1] = starts[i] + ((d[3] + 31) // 32) * ((d[4] + 31) // 32)
+                return (torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev), torch.from_numpy(starts).to(dev), len(descs), int(starts[-1]))
+            # out32 [B][SN] -> blocks [B][N_j] at element offset B * off_j (every N_j is a multiple of 8: 16-byte aligned blocks)
+            d_out = [(off, B * off, -1, B, N, SN, N, 0, 1.0) for off, N in (W.temb_off[t] for t in paths)]
+            d_t = None
+            if r:
+                # t32 [B][nt*r] -> the whole matrix (the batched GEMM's second segment) at 0, then blocks [B][r] behind it
+                d_t = [(0, 0, -1, B, nt * r, nt * r, nt * r, 0, 1.0)] + [(j * r, B * nt * r + j * B * r, -1, B, r, nt * r, r, 0, 1.0) for j in range(nt)]
+            plan = self._temb_plans[key] = (table(d_out), table(d_t) if d_t else None)
+        t_all, t_blocks, segs = None, None, [Seg(emb_act, W.temb_cat)]
+        if r:
+            t32 = torch.empty(B, nt * r, dtype=torch.float32, device=dev)
+            ops.gemm([Seg(emb_act, lora.temb.A_cat)], B, nt * r, t32)
+            tb = torch.empty(2 * B * nt * r, dtype=BF16, device=dev)
+            dsc, st, nd, nb = plan[1]
+            capi.lib().call("pcm_pack_segmented", ops.ptr(t32), ops.ptr(tb), ops.ptr(dsc), ops.ptr(st), nd, nb, capi.Lib.stream())
+            t_all, t_blocks = tb[:B * nt * r].view(B, nt * r), tb[B * nt * r:]
+            segs.append(Seg(t_all, lora.temb.Bs_cat))
+        out32 = torch.empty(B, SN, dtype=torch.float32, device=dev)
+        ops.gemm(segs, B, SN, out32, bias=W.temb_bias)
+        ob = torch.empty(B * SN, dtype=BF16, device=dev)
+        dsc, st, nd, nb = plan[0]
+        capi.lib().call("pcm_pack_segmented", ops.ptr(out32), ops.ptr(ob), ops.ptr(dsc), ops.ptr(st), nd, nb, capi.Lib.stream())
+        res = {}
+        for j, t in enumerate(paths):
+            off, N = W.temb_off[t]
+            res[t] = (ob[B * off:B * (off + N)].view(B, N), t_blocks[j * B * r:(j + 1) * B * r].view(B, r) if r else None)
+        return res
+
     # ---- resnet ----
     def resnet_fwd(self, p, x, emb_act, B, H, Wd, tape):
         W, lora = self.W, self.lora
@@ -509,7 +606,14 @@ class UNet:
         s1 = {} if sv is not None else None
         n1 = self._gn(p + "norm1", x, capi.ACT_SILU, self.cfg.norm_eps, s1)
         st = {} if sv is not None else None
-        temb = layer_fwd(W, lora, p + "time_emb_proj", emb_act, B, save=st)                 # [B, Cout]
+        if self._temb is not None:
+            # (one batched GEMM per pass: _temb_all; a pass that runs this resnet on the first rows only -- dup_halves -- takes the prefix)
+            temb, t_r = self._temb[p + "time_emb_proj"]
+            temb, t_r = temb[:B], (t_r[:B] if t_r is not None else None)
+            if st is not None:
+                st["x"], st["t"], st["M"], st["geo"] = emb_act, t_r, B, None
+        else:
+            temb = layer_fwd(W, lora, p + "time_emb_proj", emb_act, B, save=st)             # [B, Cout]
         geo = Geo(H, Wd)
         c1 = {} if sv is not None else None
         h = layer_fwd(W, lora, p + "conv1", n1, M, geo, save=c1, rowvec=temb, rows_per_batch=H * Wd)
@@ -755,6 +859,9 @@ class UNet:
             emb_act = ops.silu(emb)
         else:
             emb_act = layer_fwd(W, None, "time_embedding.linear_2", e1, B, act=capi.ACT_SILU)  # silu(emb): only use of emb
+        self._temb = None
+        if FUSE_TEMB and W.temb_cat is not None and (lora is None or (lora.temb is not None and self._temb_orders_agree)):
+            self._temb = self._temb_all(emb_act, B)
         if dup_halves:
             Bh = B // 2
             h = ops.conv_in_fwd(sample[:Bh].contiguous(), W.conv_in[0], W.conv_in[1], boc[0])
