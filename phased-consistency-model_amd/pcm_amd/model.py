@@ -163,9 +163,16 @@ class HalfSaved:
 FUSE_GEGLU_GRAD = os.environ.get("PCM_FUSE_GEGLU", "1") != "0"
 # debug hook: PCM_TEXT_KV=0 runs the frozen pass's cross-attention K / V projections layer by layer (A/B measurement)
 FUSE_TEXT_KV = os.environ.get("PCM_TEXT_KV", "1") != "0"
+FUSE_TEXT_KV_LORA = os.environ.get("PCM_TEXT_KV_LORA", "1") != "0"   # LoRA pass: pass-wide rank-64 down-projection of the text + one K|V GEMM per block
 FUSE_TEMB = os.environ.get("PCM_TEMB_BATCH", "1") != "0"      # every resnet's time_emb_proj of a pass as one GEMM (UNet._temb_all); 0: one GEMM per resnet
 # debug hook: PCM_LORA_QKV=0 runs the self-attention q/k/v LoRA projections as three separate layers (A/B measurement)
 FUSE_LORA_QKV = os.environ.get("PCM_LORA_QKV", "1") != "0"
+
+
+class LoraTextKV:
+    """concatenated operands of the cross-attention to_k / to_v LoRA factors (LoraState.text_kv): A_cat [2 * nb * r][K] (block i: rows of
+    to_k then to_v), Bs_kv[block prefix] = block-diagonal [2C][2r], index[block prefix] = i"""
+    __slots__ = ("paths", "K", "A_cat", "Bs_kv", "index")
 
 
 class LoraTemb:
@@ -318,7 +325,35 @@ class LoraState:
                 toff[t] = (roff, self.modules[t].N, j)
                 roff += self.modules[t].N
             temb_layout = (tp, Kt, SNt, o_tc, o_tb, toff)
+        # cross-attention to_k / to_v of every transformer block read the SAME text: their rank-64 down-projections are ONE pass-wide
+        # [M_text, K] x [K, 2 * nb * r] GEMM (A_kv_cat), and per block the K and V projections are one GEMM with a block-diagonal K = 2r second
+        # segment (Bs_kv[block]: [2C][2r]) over the rows [W_k; W_v] of UNetWeights.kv_cat (UNet._text_kv_t / _attn_fwd)
+        kv_layout = None
+        kvp = [path[:-4] for path, _, _, _ in layout if path.endswith("attn2.to_k") and (path[:-4] + "to_v") in self.modules]
+        if len(kvp) >= 1 and len({self.modules[b + "to_k"].K for b in kvp} | {self.modules[b + "to_v"].K for b in kvp}) == 1 and \
+                all(self.modules[b + "to_k"].N == self.modules[b + "to_v"].N and self.modules[b + n].kind == "lin" for b in kvp for n in ("to_k", "to_v")):
+            nb, Kx = len(kvp), self.modules[kvp[0] + "to_k"].K
+            o_ka = alloc(2 * nb * r * Kx)
+            blocks = []
+            for i, b in enumerate(kvp):
+                Cb = self.modules[b + "to_k"].N
+                o_kb = alloc(2 * Cb * 2 * r)
+                for jj, nme in enumerate(("to_k", "to_v")):
+                    oa_j, ob_j = offs[b + nme]
+                    descs.append((oa_j, o_ka + (2 * i + jj) * r * Kx, -1, r, Kx, Kx, Kx, 0, 1.0))
+                    descs.append((ob_j, o_kb + jj * Cb * 2 * r + jj * r, -1, Cb, r, r, 2 * r, 0, self.scaling))
+                blocks.append((b, Cb, o_kb))
+            kv_layout = (kvp, Kx, o_ka, blocks)
         self.operands = torch.zeros(ototal, dtype=BF16, device=self.device)
+        self.text_kv = None
+        if kv_layout is not None:
+            kvp, Kx, o_ka, blocks = kv_layout
+            f = LoraTextKV()
+            f.paths, f.K = kvp, Kx
+            f.A_cat = self.operands[o_ka:o_ka + 2 * len(kvp) * r * Kx].view(2 * len(kvp) * r, Kx)
+            f.Bs_kv = {b: self.operands[o:o + 4 * Cb * r].view(2 * Cb, 2 * r) for b, Cb, o in blocks}
+            f.index = {b: i for i, b in enumerate(kvp)}
+            self.text_kv = f
         self.temb = None
         if temb_layout is not None:
             tp, Kt, SNt, o_tc, o_tb, toff = temb_layout
@@ -472,13 +507,14 @@ def layer_bwd(W: UNetWeights, lora, path, dy, saved, need_dx=True, residual=None
     lm = lora.modules.get(path) if lora is not None else None
     x, t, M, geo = saved["x"], saved["t"], saved["M"], saved["geo"]
     u = None
+    ldy = dy.stride(0) if (L.kind != "conv3" and dy.dim() == 2) else None     # (a column slice of a wider matrix: the fused K|V gradient)
     if lm is not None:
         u = torch.empty(M, lm.r, dtype=BF16, device=dy.device)
-        ops.gemm([Seg(dy, lm.Bs_bwd)], M, lm.r, u)                      # u = dy (sB)   [M, r]
+        ops.gemm([Seg(dy, lm.Bs_bwd, lda=ldy)], M, lm.r, u)              # u = dy (sB)   [M, r]
 
         def wg():
             with ops.wgrad_batch():       # dB and dA share one launch where the kernels allow it
-                ops.lora_wgrad(dy, t, lm.gB, lora.scaling * lora.q_scale.get(path, 1.0), M, G=L.N, g_stride=lm.r, r_stride=1)   # dB = s dy^T t
+                ops.lora_wgrad(dy, t, lm.gB, lora.scaling * lora.q_scale.get(path, 1.0), M, G=L.N, g_stride=lm.r, r_stride=1, ldb=ldy)   # dB = s dy^T t
                 if L.kind == "conv3":
                     ops.lora_wgrad(x, u, lm.gA, 1.0, M, conv=dict(Hs=geo.Hs, Ws=geo.Ws, Ho=geo.Ho, Wo=geo.Wo, stride=geo.stride,
                                                                   src_mode=geo.src_mode), g_stride=1, r_stride=L.K)
@@ -503,7 +539,7 @@ def layer_bwd(W: UNetWeights, lora, path, dy, saved, need_dx=True, residual=None
         dx = torch.empty(Min, L.C, dtype=BF16, device=dy.device)
         ops.gemm(segs, Min, L.C, dx, residual=residual, Ho=Hin, Wo=Win)
         return dx
-    segs = [Seg(dy, L.w_bwd)]
+    segs = [Seg(dy, L.w_bwd, lda=ldy)]
     if lm is not None:
         segs.append(Seg(u, lm.A_bwd))
     dx = torch.empty(M, L.K, dtype=BF16, device=dy.device)
@@ -526,6 +562,7 @@ class UNet:
         self.W, self.lora, self.cfg = weights, lora, weights.cfg
         self._arena = None      # per-pass arena of pre-zeroed GroupNorm statistics (ops.StatArena)
         self._kv_all = None     # frozen pass: every cross-attention's K / V projection of the text, one GEMM (UNetWeights.kv_cat)
+        self._text_t = None     # LoRA pass: rank-64 down-projections of the text for every cross-attention's to_k / to_v, one GEMM (_text_kv_t)
         self._side = None       # WgradSide of this runner's backward passes
         self._save_half = False
         self._temb = None       # this pass's time_emb_proj outputs of every resnet, one batched GEMM (_temb_all); None: per-resnet GEMMs
@@ -546,6 +583,43 @@ class UNet:
         g, b = self.W.norms[path]
         return ops.groupnorm_bwd(saved["gn_x"], dy, saved["gn_stats"], g, b, self.cfg.norm_num_groups, eps, act, arena=self._arena)
 
+    @staticmethod
+    def _scatter_table(descs, dev):
+        """device descriptor table of one pcm_pack_segmented launch that rounds an fp32 matrix to the 16-bit format and scatters column
+        ranges into contiguous blocks: descs = [(src_off, dst_off, -1, R, Cc, lds, ldc, 0, 1.0)]"""
+        import numpy as np
+        arr = (capi.PackDesc * len(descs))()
+        starts = np.zeros(len(descs) + 1, dtype=np.int32)
+        for i, d in enumerate(descs):
+            (arr[i].src_off, arr[i].dst_copy_off, arr[i].dst_t_off, arr[i].R, arr[i].Cc, arr[i].lds, arr[i].ldc, arr[i].ldt, arr[i].scale) = d
+            starts[i + 1] = starts[i] + ((d[3] + 31) // 32) * ((d[4] + 31) // 32)
+        return (torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev), torch.from_numpy(starts).to(dev), len(descs), int(starts[-1]))
+
+    # ---- LoRA pass: rank-64 down-projections of the text for every cross-attention's to_k / to_v ----
+    def _text_kv_t(self, text2d):
+        """{block prefix: (t_kv [Mt, 2r], t_k [Mt, r], t_v [Mt, r])}, all contiguous: ONE GEMM [Mt, K] x [K, 2 * nb * r] in fp32 + one scatter launch
+        (the same single rounding of the fp32 accumulator as the per-module down-projection); t_kv feeds the block's fused K|V GEMM, t_k / t_v
+        are what the backward's weight-gradient jobs read"""
+        lora = self.lora
+        f, r, Mt, dev = lora.text_kv, lora.rank, text2d.shape[0], text2d.device
+        nb = len(f.paths)
+        plan = self._temb_plans.get(("kv", Mt))
+        if plan is None:
+            W2 = 2 * nb * r
+            descs = [(2 * i * r, i * Mt * 2 * r, -1, Mt, 2 * r, W2, 2 * r, 0, 1.0) for i in range(nb)]
+            descs += [(j * r, nb * Mt * 2 * r + j * Mt * r, -1, Mt, r, W2, r, 0, 1.0) for j in range(2 * nb)]
+            plan = self._temb_plans[("kv", Mt)] = self._scatter_table(descs, dev)
+        t32 = torch.empty(Mt, 2 * nb * r, dtype=torch.float32, device=dev)
+        ops.gemm([Seg(text2d, f.A_cat)], Mt, 2 * nb * r, t32)
+        tb = torch.empty(2 * nb * Mt * 2 * r, dtype=BF16, device=dev)
+        dsc, st, nd, nblk = plan
+        capi.lib().call("pcm_pack_segmented", ops.ptr(t32), ops.ptr(tb), ops.ptr(dsc), ops.ptr(st), nd, nblk, capi.Lib.stream())
+        res, base = {}, nb * Mt * 2 * r
+        for i, b in enumerate(f.paths):
+            res[b] = (tb[i * Mt * 2 * r:(i + 1) * Mt * 2 * r].view(Mt, 2 * r),
+                      tb[base + 2 * i * Mt * r:base + (2 * i + 1) * Mt * r].view(Mt, r), tb[base + (2 * i + 1) * Mt * r:base + (2 * i + 2) * Mt * r].view(Mt, r))
+        return res
+
     # ---- every resnet's time_emb_proj of one pass ----
     def _temb_all(self, emb_act, B):
         """{path: (temb [B, N] bf16 contiguous, t [B, r] bf16 contiguous or None)} for every resnet of the pass from ONE base GEMM (+ ONE rank-64
@@ -561,15 +635,7 @@ class UNet:
         key = (B, r)
         plan = self._temb_plans.get(key)
         if plan is None:
-            import numpy as np
-
-            def table(descs):
-                arr = (capi.PackDesc * len(descs))()
-                starts = np.zeros(len(descs) + 1, dtype=np.int32)
-                for i, d in enumerate(descs):
-                    (arr[i].src_off, arr[i].dst_copy_off, arr[i].dst_t_off, arr[i].R, arr[i].Cc, arr[i].lds, arr[i].ldc, arr[i].ldt, arr[i].scale) = d
-                    starts[i + 1] = starts[i] + ((d[3] + 31) // 32) * ((d[4] + 31) // 32)
-                return (torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev), torch.from_numpy(starts).to(dev), len(descs), int(starts[-1]))
+            table = lambda descs: self._scatter_table(descs, dev)   # noqa: E731
             # out32 [B][SN] -> blocks [B][N_j] at element offset B * off_j (every N_j is a multiple of 8: 16-byte aligned blocks)
             d_out = [(off, B * off, -1, B, N, SN, N, 0, 1.0) for off, N in (W.temb_off[t] for t in paths)]
             d_t = None
@@ -585,7 +651,7 @@ class UNet:
             dsc, st, nd, nb = plan[1]
             capi.lib().call("pcm_pack_segmented", ops.ptr(t32), ops.ptr(tb), ops.ptr(dsc), ops.ptr(st), nd, nb, capi.Lib.stream())
             t_all, t_blocks = tb[:B * nt * r].view(B, nt * r), tb[B * nt * r:]
-            segs.append(Seg(t_all, lora.temb.Bs_cat))
+            segs.append(Seg(t_all, lora.temb.Bs_cat, k_algo=r))       # (block-diagonal: r of the nt * r columns are non-zero per output row)
         out32 = torch.empty(B, SN, dtype=torch.float32, device=dev)
         ops.gemm(segs, B, SN, out32, bias=W.temb_bias)
         ob = torch.empty(B * SN, dtype=BF16, device=dev)
@@ -687,9 +753,24 @@ class UNet:
             kv = self._kv_all.view(B, Lk, -1)
             o, lse = ops.attn_fwd(q.view(B, L, C), kv[:, :, off:off + Ck], kv[:, :, off + Ck:off + 2 * Ck], Hh, d, prescaled=True)
             return layer_fwd(W, lora, p + "to_out.0", o.view(M, C), M, residual=resid)
-        k = layer_fwd(W, lora, p + "to_k", ctx, Mk, save=sk)
-        v = layer_fwd(W, lora, p + "to_v", ctx, Mk, save=svv)
-        o, lse = ops.attn_fwd(q.view(B, L, C), k.view(B, Lk, C), v.view(B, Lk, C), Hh, d, prescaled=True)
+        if lora is not None and ctx is not xn and self._text_t is not None and p in self._text_t and W.kv_off[p][1] == C and ctx.numel() == Mk * W.kv_cat.shape[1] \
+                and self._text_t[p][0].shape[0] == Mk:
+            # LoRA cross-attention: K and V of this block as ONE GEMM over the rows [W_k; W_v] of the pass-wide text operand with a block-diagonal
+            # K = 2r second segment; the rank-64 down-projections of the text were computed for every block at once (_text_kv_t).  Attention
+            # reads k / v in place (row stride 2C); the backward's weight-gradient jobs read the contiguous t_k / t_v
+            off, _ = W.kv_off[p]
+            t_kv, t_k, t_v = self._text_t[p]
+            ctx2 = ctx.view(Mk, -1)
+            kv = torch.empty(Mk, 2 * C, dtype=BF16, device=xn.device)
+            ops.gemm([Seg(ctx2, W.kv_cat[off:off + 2 * C]), Seg(t_kv, lora.text_kv.Bs_kv[p], k_algo=lora.rank)], Mk, 2 * C, kv)
+            k, v = kv[:, :C], kv[:, C:]
+            if sv is not None:
+                sk.update(x=ctx2, t=t_k, M=Mk, geo=None)
+                svv.update(x=ctx2, t=t_v, M=Mk, geo=None)
+        else:
+            k = layer_fwd(W, lora, p + "to_k", ctx, Mk, save=sk)
+            v = layer_fwd(W, lora, p + "to_v", ctx, Mk, save=svv)
+        o, lse = ops.attn_fwd(q.view(B, L, C), k.unflatten(0, (B, Lk)), v.unflatten(0, (B, Lk)), Hh, d, prescaled=True)
         out = layer_fwd(W, lora, p + "to_out.0", o.view(M, C), M, save=so, residual=resid)
         if sv is not None:
             sv.update(sq=sq, sk=sk, sv=svv, so=so, q=q, k=k, v=v, o=o, lse=lse, L=L, Lk=Lk)
@@ -719,15 +800,23 @@ class UNet:
             d_xn = torch.empty(M, fq.K, dtype=BF16, device=d_o.device)
             ops.gemm([Seg(d3, W.qkv_bwd[p]), Seg(u3, fq.A_cat_bwd)], M, fq.K, d_xn)
             return d_xn
-        dq, dk, dv = ops.attn_bwd(sv["q"].view(B, L, C), sv["k"].view(B, Lk, C), sv["v"].view(B, Lk, C), sv["o"],
-                                  d_o.view(B, L, C), sv["lse"], Hh, d, prescaled=True)
+        if sv["k"].stride(0) != C:       # fused K|V forward (row stride 2C): the gradients are written into one [Mk, 2C] matrix with the same strides
+            dq = torch.empty(B * L, C, dtype=BF16, device=d_o.device)
+            dkv = torch.empty(B * Lk, 2 * C, dtype=BF16, device=d_o.device)
+            dk, dv = dkv[:, :C], dkv[:, C:]
+            ops.attn_bwd(sv["q"].view(B, L, C), sv["k"].unflatten(0, (B, Lk)), sv["v"].unflatten(0, (B, Lk)), sv["o"], d_o.view(B, L, C),
+                         sv["lse"], Hh, d, out=(dq, dk, dv), prescaled=True)
+        else:
+            dq, dk, dv = ops.attn_bwd(sv["q"].view(B, L, C), sv["k"].view(B, Lk, C), sv["v"].view(B, Lk, C), sv["o"],
+                                      d_o.view(B, L, C), sv["lse"], Hh, d, prescaled=True)
+            dk, dv = dk.view(B * Lk, C), dv.view(B * Lk, C)
         d_xn = layer_bwd(W, lora, p + "to_q", dq.view(B * L, C), sv["sq"])
         if need_dctx:  # self-attention: K/V inputs are xn too
-            d_xn = layer_bwd(W, lora, p + "to_k", dk.view(B * Lk, C), sv["sk"], residual=d_xn)
-            d_xn = layer_bwd(W, lora, p + "to_v", dv.view(B * Lk, C), sv["sv"], residual=d_xn)
+            d_xn = layer_bwd(W, lora, p + "to_k", dk, sv["sk"], residual=d_xn)
+            d_xn = layer_bwd(W, lora, p + "to_v", dv, sv["sv"], residual=d_xn)
         else:          # cross-attention: text embeddings need no gradient
-            layer_bwd(W, lora, p + "to_k", dk.view(B * Lk, C), sv["sk"], need_dx=False)
-            layer_bwd(W, lora, p + "to_v", dv.view(B * Lk, C), sv["sv"], need_dx=False)
+            layer_bwd(W, lora, p + "to_k", dk, sv["sk"], need_dx=False)
+            layer_bwd(W, lora, p + "to_v", dv, sv["sv"], need_dx=False)
         return d_xn
 
     def transformer_fwd(self, p, x, text, B, H, Wd, tape, depth=1, heads=None, dup_after_attn1=False):
@@ -859,6 +948,10 @@ class UNet:
             emb_act = ops.silu(emb)
         else:
             emb_act = layer_fwd(W, None, "time_embedding.linear_2", e1, B, act=capi.ACT_SILU)  # silu(emb): only use of emb
+        self._text_t = None
+        if lora is not None and FUSE_TEXT_KV_LORA and W.kv_cat is not None and getattr(lora, "text_kv", None) is not None and \
+                lora.text_kv.K == W.kv_cat.shape[1] and all(b in W.kv_off for b in lora.text_kv.paths):
+            self._text_t = self._text_kv_t(text.view(text.shape[0] * text.shape[1], -1))
         self._temb = None
         if FUSE_TEMB and W.temb_cat is not None and (lora is None or (lora.temb is not None and self._temb_orders_agree)):
             self._temb = self._temb_all(emb_act, B)

@@ -473,3 +473,59 @@ def test_batched_time_embedding_projections_equal_the_per_resnet_ones():
                 o0 = (t.data_ptr() - base) // 4
                 x, y = ga[o0:o0 + t.numel()], gb[o0:o0 + t.numel()]
                 assert float(y.norm()) > 0 and rel(x, y) < 0.5, (path, rel(x, y))
+
+
+def test_fused_text_kv_of_the_lora_pass_equals_the_per_module_projections():
+    """LoRA pass: the rank-64 down-projections of the text for EVERY cross-attention's to_k / to_v are one GEMM + one scatter launch, and per block
+    K and V are one GEMM over [W_k; W_v] with a block-diagonal K = 2r second segment (UNet._text_kv_t / _attn_fwd).  Against one down-projection
+    and one GEMM per module (PCM_TEXT_KV_LORA=0): the same products in the same order -- t_k / t_v, predictions, loss and gradients bitwise."""
+    from oracle import pcm_step as OS
+    from oracle import unet_sd15 as O
+    from pcm_amd import model as M
+    from pcm_amd.model import LoraState, UNet, UNetWeights, layer_fwd
+    from pcm_amd.trainer import Distiller, StepConfig
+    oc, pc = tiny_cfgs()
+    sd = O.init_state_dict(oc, 0)
+    W = UNetWeights(pc, sd, "cpu")
+    lora0 = LoraState(pc, 64, 8.0, "cpu", seed=1, b_std=0.05)
+    assert lora0.text_kv is not None and set(lora0.text_kv.paths) == set(W.kv_off)
+    # (1) the pass-wide down-projection, value by value
+    text = torch.randn(4 * 7, 64, generator=torch.Generator().manual_seed(0)).bfloat16()
+    U = UNet(W, lora0)
+    for b, (t_kv, t_k, t_v) in U._text_kv_t(text).items():
+        for nme, t in (("to_k", t_k), ("to_v", t_v)):
+            st = {}
+            layer_fwd(W, lora0, b + nme, text, 28, save=st)
+            assert t.is_contiguous() and torch.equal(t, st["t"]), b + nme
+        assert torch.equal(t_kv[:, :64], t_k) and torch.equal(t_kv[:, 64:], t_v)
+    # (2) whole step, both ways
+    ocfg = OS.StepConfig(multiphase=2, loss_type="huber", w_min=4.0, w_max=5.0)
+    inp = OS.draw_inputs(2, ocfg, seed=7, latent_hw=8, ctx_len=7, ctx_dim=64)
+    cfg = StepConfig(multiphase=2, loss_type="huber", w_min=4.0, w_max=5.0)
+    args = (inp["latents"], inp["prompt_embeds"], inp["uncond_prompt_embeds"], inp["noise"], inp["index"], inp["w"])
+
+    def run(fused):
+        old, M.FUSE_TEXT_KV_LORA = M.FUSE_TEXT_KV_LORA, fused
+        try:
+            lora = LoraState(pc, 64, 8.0, "cpu", seed=1, b_std=0.05)
+            D = Distiller(W, lora, cfg)
+            out = D.forward_backward(*args)
+            assert (D.student._text_t is not None) == fused and D.teacher._text_t is None
+            return {k: out[k].clone() for k in ("noise_pred", "target_noise_pred", "loss")}, lora.grads.clone(), lora
+        finally:
+            M.FUSE_TEXT_KV_LORA = old
+
+    a, ga, la = run(True)
+    b, gb, _ = run(False)
+    rel = lambda x, y: float((x.double() - y.double()).norm() / (y.double().norm() + 1e-300))   # noqa: E731
+    rels = {k: rel(a[k], b[k]) for k in a}
+    print("fused text K|V vs per-module:", {k: "%.2e" % v for k, v in rels.items()}, "grads %.2e" % rel(ga, gb))
+    # measured: bitwise -- the zero blocks add exact zeros, the K|V GEMM runs the kernel the per-module GEMMs run, attention reads the same values
+    assert max(rels.values()) == 0.0 and rel(ga, gb) < 1e-6
+    base = la.grads.data_ptr()
+    for path, m in la.modules.items():          # the to_k / to_v modules themselves: their gradients come through the strided k / v and the scattered t
+        if path.endswith(("attn2.to_k", "attn2.to_v")):
+            for t in (m.gA, m.gB):
+                o0 = (t.data_ptr() - base) // 4
+                x, y = ga[o0:o0 + t.numel()], gb[o0:o0 + t.numel()]
+                assert float(y.norm()) > 0 and rel(x, y) < 1e-6, (path, rel(x, y))
