@@ -106,6 +106,19 @@ typedef struct {
    * (the grad-requiring half of a batch); pcm_geglu_bwd_interleaved reads it.  NULL / 0: nothing kept. */
   void* pre_out;
   int pre_rows, ldp;
+  /* abi >= 5 -- two fusions of the glue around a contraction (diffusers' UNet wiring, discriminator_sd15.py:264-342):
+   *  out2 / ldo2: a SECOND copy of the bf16 output rows, out2[m][ldo2] (same values as out).  The producer of a down-path skip tensor
+   *    writes it straight into the channel range of the buffer the up path will read as torch.cat([h, skip], dim=1): no concat pass
+   *    (bf16 output only, not with PCM_ACT_GEGLU; ldo2 % 4 == 0, 8-byte aligned).  NULL: none.
+   *  chstats / stats_rows: per-(sample, channel) {sum, sum of squares} of the STORED (16-bit-rounded) output values, accumulated with fp64
+   *    atomics into chstats[m / stats_rows][n][2] (pre-zeroed by the caller; stats_rows = rows per sample, a multiple of 64): what the
+   *    GroupNorm that reads this tensor next needs (pcm_groupnorm_apply_chstats), so no statistics pass over it.  Only where
+   *    pcm_gemm_emits_chstats() says so for the same arguments -- other plans ignore the field and the caller runs pcm_groupnorm_stats.
+   *    NULL: none. */
+  void* out2;
+  int ldo2;
+  double* chstats;
+  int stats_rows;
 } pcm_gemm_epi;
 
 /* bytes of `workspace` the call would use (0: no split-K for this shape) */
@@ -117,6 +130,9 @@ int pcm_gemm_bf16(const pcm_gemm_seg* segs, int nseg, const pcm_gemm_epi* epi, v
  *   32 the batch-row kernel (M <= 16).  Negative: the PCM_E* code the call would return.  bench.py's roofline leg classes its timed
  * launches with it. */
 int pcm_gemm_plan_code(const pcm_gemm_seg* segs, int nseg, const pcm_gemm_epi* epi);
+/* 1 when pcm_gemm_bf16 with these arguments (epi->chstats set or not: it is not read) accumulates the per-channel statistics described at
+ * pcm_gemm_epi.chstats, 0 when the plan it takes does not (the caller then runs the statistics pass), < 0: the PCM_E* code (abi >= 5) */
+int pcm_gemm_emits_chstats(const pcm_gemm_seg* segs, int nseg, const pcm_gemm_epi* epi);
 
 /* LoRA weight gradients (autograd of peft lora.Linear / lora.Conv2d under loss.backward(),
  * train_pcm_lora_sd15.py:1296).  G[g][r] += alpha * sum_m Big[m][g] * Small[m][r], r in [0,64).
@@ -158,6 +174,14 @@ int pcm_conv3x3_wgrad_bf16(const void* x, const void* dy, float* dW, int B, int 
 int pcm_groupnorm_stats(const void* x, double* stats, int B, int HW, int C, int G, void* stream);
 int pcm_groupnorm_apply(const void* x, const double* stats, const float* gamma, const float* beta,
                         void* y, int B, int HW, int C, int G, float eps, int act, void* stream);
+/* abi >= 5: the same apply when the producing contraction(s) accumulated per-(sample, channel) sums (pcm_gemm_epi.chstats, fp64 {sum, sumsq}):
+ * channel c < c_split of sample b reads chstats[(b * stats_ld + c) * 2 ..], channel c >= c_split reads chstats2[(b * stats_ld2 + c - c_split) * 2 ..]
+ * (x = torch.cat([h, skip], dim=1) of the up blocks: two producers; chstats2 NULL: one source for all C channels).  Group statistics are
+ * formed from them in the call (no statistics pass over x) and also written to stats_out[B][G][2] (may be NULL) in the format of
+ * pcm_groupnorm_stats, which the backward entry points read */
+int pcm_groupnorm_apply_chstats(const void* x, const double* chstats, int stats_ld, const double* chstats2, int stats_ld2, int c_split,
+                                double* stats_out, const float* gamma, const float* beta, void* y, int B, int HW, int C, int G,
+                                float eps, int act, void* stream);
 /* backward wrt x only (norm affine params are frozen): two launches */
 int pcm_groupnorm_bwd_stats(const void* x, const void* dy, const double* stats, const float* gamma,
                             const float* beta, double* bstats, int B, int HW, int C, int G,

@@ -244,9 +244,25 @@ __global__ __launch_bounds__(256, (D <= 40 ? 3 : 1)) void attn_fwd_ps_kernel(con
     }
     l_run = l_chk;
     if (track) break;
-    // item 2: a row whose later scores outgrew the first tile's maximum by ~2^120 has a non-finite sum -> the workgroup repeats with tracking
+    // item 2: a row whose later scores outgrew the first tile's maximum by ~2^120 has a non-finite sum -> the workgroup repeats with tracking.
+    // The check also reads every OUTPUT accumulator (round 6): where the row sum is the fp32 VALU sum (head dims without the ones column:
+    // 32 / 64 / 160) P is packed to the 16-bit format AFTER that sum -- in the IEEE-half build a p above 65504 (a late score ~16 above the
+    // first tile's maximum in the log2 domain) is inf in the PV MFMA while the fp32 sum stays finite, and a finite sum near the threshold
+    // times |v| can overflow the accumulators on its own: the threshold is 1e30 (was 1e37), which leaves |v| * Lk 2^27 of headroom in every
+    // build.  x * 0 is NaN for inf / NaN and 0 otherwise.
+    float chk = l_chk;
+#ifdef PCM_ACT_F16
+    // (half build, sums on the VALU only: the bfloat16 build's P cannot overflow before the fp32 sum does, and reading the accumulators here
+    //  cost its d = 40 forward 17 % -- 4.67 -> 5.48 ms per two-timestep forward, profiles/r06_c_* -- although the code sits behind the loop)
+    if constexpr (!ONES) {
+#pragma unroll
+      for (int i = 0; i < C::DV; i++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) chk += acc_o[i][r] * 0.f;
+    }
+#endif
     __syncthreads();
-    if (!(l_chk < 1e37f)) s_redo = 1;
+    if (!(chk < 1e30f)) s_redo = 1;
     __syncthreads();
     if (!s_redo) break;
     track = true;

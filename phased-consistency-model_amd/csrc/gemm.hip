@@ -272,7 +272,9 @@ __global__ __launch_bounds__(64 * NW) void pcm_gemm_kernel(GemmDev g) {
 #pragma unroll
         for (int e = 0; e < 4; e++) { v[2 * e] += bf2f((bf16_t)(tw[e] & 0xffff)); v[2 * e + 1] += bf2f((bf16_t)(tw[e] >> 16)); }
       }
-      *(uint4*)((bf16_t*)g.out + (size_t)m * g.ldo + n) = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+      const uint4 o = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+      *(uint4*)((bf16_t*)g.out + (size_t)m * g.ldo + n) = o;
+      if (g.out2) *(uint4*)(g.out2 + (size_t)m * g.ldo2 + n) = o;
     }
     return;
   }
@@ -311,7 +313,9 @@ __global__ __launch_bounds__(64 * NW) void pcm_gemm_kernel(GemmDev g) {
         if (g.out_f32) {
           *(float4*)((float*)g.out + (size_t)m * g.ldo + n) = make_float4(v[0], v[1], v[2], v[3]);
         } else {
-          *(uint2*)((bf16_t*)g.out + (size_t)m * g.ldo + n) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+          const uint2 o = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+          *(uint2*)((bf16_t*)g.out + (size_t)m * g.ldo + n) = o;
+          if (g.out2) *(uint2*)(g.out2 + (size_t)m * g.ldo2 + n) = o;
         }
       }
     }
@@ -349,8 +353,96 @@ __global__ __launch_bounds__(256) void pcm_gemm_finalize_kernel(GemmDev g) {
       v[2] += bf2f((bf16_t)(t.y & 0xffff)); v[3] += bf2f((bf16_t)(t.y >> 16));
     }
     if (g.out_f32) *(float4*)((float*)g.out + (size_t)m * g.ldo + n) = make_float4(v[0], v[1], v[2], v[3]);
-    else *(uint2*)((bf16_t*)g.out + (size_t)m * g.ldo + n) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+    else {
+      const uint2 o = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+      *(uint2*)((bf16_t*)g.out + (size_t)m * g.ldo + n) = o;
+      if (g.out2) *(uint2*)(g.out2 + (size_t)m * g.ldo2 + n) = o;
+    }
   }
+}
+
+// the same finalize for an output that a GroupNorm reads next (abi 5, pcm_gemm_epi.chstats): a block owns `rpb` consecutive rows of ONE sample
+// (rpb divides stats_rows); a thread keeps a fixed group of 4 channels and walks the block's rows in steps of the row lanes (blockDim.x / (N/4),
+// four rows' slab loads in flight), so the per-channel sums of the STORED values stay in registers; the row lanes meet in LDS and the block
+// issues N x 2 fp64 atomics -- the statistics pass over the tensor is not needed.
+__global__ __launch_bounds__(320) void pcm_gemm_finalize_stats_kernel(GemmDev g, int rpb, int nq_per_block) {
+  __shared__ float red[320][8];                    // [row lane * nq_per_block + channel quad of the block][4 sums, 4 sums of squares]
+  const int NQ = g.N / 4;
+  const int q0 = blockIdx.y * nq_per_block;
+  int nqb = NQ - q0; if (nqb > nq_per_block) nqb = nq_per_block;
+  const int RL = blockDim.x / nq_per_block;        // row lanes (>= 1, <= 8)
+  const int ql = threadIdx.x % nq_per_block, rl = threadIdx.x / nq_per_block;
+  const int r0 = blockIdx.x * rpb;
+  int r1 = r0 + rpb; if (r1 > g.M) r1 = g.M;
+  const bool on = ql < nqb && rl < RL;
+  const int n = 4 * (q0 + (on ? ql : 0));
+  float sm[4] = {0.f, 0.f, 0.f, 0.f}, sq[4] = {0.f, 0.f, 0.f, 0.f};
+  if (on) {
+    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (g.bias) b4 = *(const float4*)(g.bias + n);
+    constexpr int U = 4;
+    for (int mb = r0 + rl; mb < r1; mb += U * RL) {
+      float4 acc[U];
+      uint2 rv[U], rs[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        int m = mb + u * RL; if (m > r1 - 1) m = r1 - 1;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int s_ = 0; s_ < g.splitk; s_++) {
+          const float4 p = *(const float4*)(g.ws + ((size_t)s_ * g.M + m) * g.N + n);
+          a.x += p.x; a.y += p.y; a.z += p.z; a.w += p.w;
+        }
+        acc[u] = a;
+        rv[u] = g.rowvec ? *(const uint2*)(g.rowvec + (size_t)(m / g.rpb) * g.N + n) : make_uint2(0u, 0u);
+        rs[u] = g.res ? *(const uint2*)(g.res + (size_t)m * g.ldr + n) : make_uint2(0u, 0u);
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int m = mb + u * RL;
+        if (m >= r1) continue;
+        float v[4] = {acc[u].x * g.alpha + b4.x, acc[u].y * g.alpha + b4.y, acc[u].z * g.alpha + b4.z, acc[u].w * g.alpha + b4.w};
+        if (g.rowvec) {
+          v[0] += bf2f((bf16_t)(rv[u].x & 0xffff)); v[1] += bf2f((bf16_t)(rv[u].x >> 16));
+          v[2] += bf2f((bf16_t)(rv[u].y & 0xffff)); v[3] += bf2f((bf16_t)(rv[u].y >> 16));
+        }
+        if (g.act == PCM_ACT_SILU) {
+#pragma unroll
+          for (int e = 0; e < 4; e++) v[e] = silu_f(v[e]);
+        }
+        if (g.res) {
+          v[0] += bf2f((bf16_t)(rs[u].x & 0xffff)); v[1] += bf2f((bf16_t)(rs[u].x >> 16));
+          v[2] += bf2f((bf16_t)(rs[u].y & 0xffff)); v[3] += bf2f((bf16_t)(rs[u].y >> 16));
+        }
+        const uint2 o = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+        *(uint2*)((bf16_t*)g.out + (size_t)m * g.ldo + n) = o;
+        if (g.out2) *(uint2*)(g.out2 + (size_t)m * g.ldo2 + n) = o;
+        const float x[4] = {bf2f((bf16_t)(o.x & 0xffff)), bf2f((bf16_t)(o.x >> 16)), bf2f((bf16_t)(o.y & 0xffff)), bf2f((bf16_t)(o.y >> 16))};
+#pragma unroll
+        for (int e = 0; e < 4; e++) { sm[e] += x[e]; sq[e] = fmaf(x[e], x[e], sq[e]); }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; e++) { red[threadIdx.x][e] = sm[e]; red[threadIdx.x][4 + e] = sq[e]; }
+  }
+  __syncthreads();
+  // channel quad ql, value e (0..7: 4 sums, 4 sums of squares): one fp64 atomic per (channel, statistic) and block
+  for (int i = threadIdx.x; i < nqb * 8; i += blockDim.x) {
+    const int qq = i >> 3, e = i & 7;
+    float t = 0.f;
+    for (int l = 0; l < RL; l++) t += red[l * nq_per_block + qq][e];
+    double* dst = g.chstats + ((size_t)(r0 / g.stats_rows) * g.N + 4 * (q0 + qq) + (e & 3)) * 2 + (e >> 2);
+    atomicAdd(dst, (double)t);
+  }
+}
+// geometry of the kernel above: rows per block (divides stats_rows; >= ~256 blocks where M allows), channel quads per block (<= 320), threads
+static void finalize_stats_geometry(int M, int N, int stats_rows, int* rpb_, int* nqpb_, int* threads_, int* ny_) {
+  const int NQ = N / 4;
+  int ny = (NQ + 319) / 320;
+  const int nqpb = (NQ + ny - 1) / ny;
+  int rl = 320 / nqpb; if (rl > 8) rl = 8; if (rl < 1) rl = 1;
+  int rpb = 64;
+  while (rpb > 8 && ((stats_rows % rpb) || (long)((M + rpb - 1) / rpb) * ny < 256)) rpb >>= 1;
+  *rpb_ = rpb; *nqpb_ = nqpb; *threads_ = nqpb * rl; *ny_ = ny;
 }
 
 // tile / split-K plan shared by pcm_gemm_bf16 and pcm_gemm_workspace_bytes
@@ -494,6 +586,17 @@ static GemmPlan gemm_plan(int M, int N, int total_kt, bool allow_split, bool big
   p.tiles_n = (N + p.BN - 1) / p.BN;
   return p;
 }
+static void launch_finalize(const GemmDev& g, const pcm_gemm_epi* e, void* stream) {
+  if (g.chstats) {
+    int rpb, nqpb, threads, ny;
+    finalize_stats_geometry(e->M, e->N, g.stats_rows, &rpb, &nqpb, &threads, &ny);
+    PCM_LAUNCH(pcm_gemm_finalize_stats_kernel, dim3((e->M + rpb - 1) / rpb, ny), dim3(threads), 0, stream, g, rpb, nqpb);
+    return;
+  }
+  long nq = (long)e->M * (e->N / 4);
+  long fb = (nq + 255) / 256; if (fb > PCM_GRID_CAP(2048)) fb = PCM_GRID_CAP(2048);
+  PCM_LAUNCH(pcm_gemm_finalize_kernel, dim3((int)fb), dim3(256), 0, stream, g);
+}
 static int gemm_total_kt(const pcm_gemm_seg* segs, int nseg) {
   int t = 0;
   for (int i = 0; i < nseg; i++) t += (segs[i].K + 63) / 64;
@@ -553,6 +656,20 @@ extern "C" int pcm_gemm_plan_code(const pcm_gemm_seg* segs, int nseg, const pcm_
   const int rc = gemm_run(segs, nseg, e, nullptr, true, &code);
   return rc ? rc : code;
 }
+static bool gemm_plan_emits_chstats(const GemmPlan& pl, const pcm_gemm_epi* e) {
+  if (e->out_dtype == PCM_F32 || e->act == PCM_ACT_GEGLU || e->stats_rows <= 0 || (e->stats_rows % 64) || (e->M % e->stats_rows) || (e->N % 8)) return false;
+  return pl.splitk > 1 || (pl.big_fn != 0 && pl.w4_fn == 0);
+}
+extern "C" int pcm_gemm_emits_chstats(const pcm_gemm_seg* segs, int nseg, const pcm_gemm_epi* e) {
+  int code = 0;
+  const int rc = gemm_run(segs, nseg, e, nullptr, true, &code);
+  if (rc) return rc;
+  if (code == 32 || code == 64 || code == 65 || code >= 10000) return 0;
+  pcm_gemm_epi probe = *e;
+  GemmPlan pl; memset(&pl, 0, sizeof(pl));
+  pl.big_fn = code / 1000; pl.splitk = code % 1000;
+  return gemm_plan_emits_chstats(pl, &probe) ? 1 : 0;
+}
 static int gemm_run(const pcm_gemm_seg* segs, int nseg, const pcm_gemm_epi* e, void* stream, bool plan_only, int* code) {
   PCM_CHECK(segs && e && nseg >= 1 && nseg <= 2, PCM_EINVAL, "pcm_gemm_bf16: nseg must be 1 or 2");
   PCM_CHECK(e->M > 0 && e->N > 0 && (e->N % 4) == 0, PCM_EINVAL, "pcm_gemm_bf16: M>0, N>0, N%%4==0 required (M=%d N=%d)", e->M, e->N);
@@ -587,6 +704,12 @@ static int gemm_run(const pcm_gemm_seg* segs, int nseg, const pcm_gemm_epi* e, v
   if (e->pre_out)
     PCM_CHECK(geglu && PCM_ALIGNED16(e->pre_out) && (e->ldp % 8) == 0 && e->ldp >= e->N && e->pre_rows >= 0, PCM_EINVAL,
               "pcm_gemm_bf16: pre_out needs PCM_ACT_GEGLU, 16-byte alignment, ldp%%8==0, ldp >= N");
+  if (e->out2)
+    PCM_CHECK(!geglu && e->out_dtype != PCM_F32 && (((uintptr_t)e->out2) & 7) == 0 && (e->ldo2 % 4) == 0 && e->ldo2 >= e->N && e->N != 64 && e->M > 16, PCM_EUNSUPPORTED,
+              "pcm_gemm_bf16: out2 needs a bf16 output without PCM_ACT_GEGLU, 8-byte alignment, ldo2%%4==0, ldo2 >= N (not the rank-64 / batch-row kernels)");
+  if (e->chstats)
+    PCM_CHECK(e->stats_rows > 0 && (e->stats_rows % 64) == 0 && (e->M % e->stats_rows) == 0 && (((uintptr_t)e->chstats) & 7) == 0, PCM_EINVAL,
+              "pcm_gemm_bf16: chstats needs stats_rows %% 64 == 0 and M %% stats_rows == 0");
   if (e->residual) PCM_CHECK((((uintptr_t)e->residual) & 7) == 0 && (e->ldr % 4) == 0, PCM_EALIGN, "pcm_gemm_bf16: residual alignment");
   if (e->rowvec) PCM_CHECK(e->rows_per_batch > 0, PCM_EINVAL, "pcm_gemm_bf16: rows_per_batch");
   g.nseg = nseg; g.M = e->M; g.N = e->N; g.Ho = e->Ho > 0 ? e->Ho : 1; g.Wo = e->Wo > 0 ? e->Wo : 1;
@@ -595,6 +718,7 @@ static int gemm_run(const pcm_gemm_seg* segs, int nseg, const pcm_gemm_epi* e, v
   g.out_f32 = e->out_dtype == PCM_F32; g.act = e->act; g.alpha = e->alpha; g.dbg = g_ablate & 0xff;
   g.w4_stagger = (g_ablate >> 8) ? (g_ablate >> 8) - 1 : w4_stagger_default();
   g.pre_out = (bf16_t*)e->pre_out; g.pre_rows = e->pre_out ? e->pre_rows : 0; g.ldp = e->ldp;
+  g.out2 = (bf16_t*)e->out2; g.ldo2 = e->ldo2;
   // conv addressing / K order: explicit choice through the env / debug hooks, otherwise by shape (gemm8p.hip launcher)
   // default: the tap-outer order with the per-tap re-key everywhere.  PCM_GEMM_CONV_CO=2 / pcm_debug_gemm_conv_order(2) = chunk-outer BY SHAPE
   // (8x8 maps only): x1.12 on that launch alone with cold operands (round 2), but 117.5-117.7 vs 117.2-117.3 ms per bs-16 step in the
@@ -639,6 +763,9 @@ static int gemm_run(const pcm_gemm_seg* segs, int nseg, const pcm_gemm_epi* e, v
     g.ws = (float*)e->workspace;
   }
   g.tiles_m = pl.tiles_m; g.tiles_n = pl.tiles_n; g.splitk = pl.splitk; g.kt_per_split = pl.kt_per_split;
+  // per-channel statistics (abi 5): the unsplit phased tile's epilogue and every split-K finalize emit them; other plans ignore the field
+  // (pcm_gemm_emits_chstats tells the caller, who then runs the statistics pass)
+  if (e->chstats && gemm_plan_emits_chstats(pl, e)) { g.chstats = e->chstats; g.stats_rows = e->stats_rows; }
   if (pl.w4_fn) {
     int rc = pcm_gemm4w_launch(g, pl.w4_fn, stream);
     if (rc) return rc;
@@ -647,11 +774,7 @@ static int gemm_run(const pcm_gemm_seg* segs, int nseg, const pcm_gemm_epi* e, v
   if (pl.big_fn) {
     int rc = pcm_gemm8p_launch(g, pl.big_fn, stream);
     if (rc) return rc;
-    if (pl.splitk > 1) {
-      long nq = (long)e->M * (e->N / 4);
-      long fb = (nq + 255) / 256; if (fb > PCM_GRID_CAP(2048)) fb = PCM_GRID_CAP(2048);
-      PCM_LAUNCH(pcm_gemm_finalize_kernel, dim3((int)fb), dim3(256), 0, stream, g);
-    }
+    if (pl.splitk > 1) launch_finalize(g, e, stream);
     return pcm_post_launch("pcm_gemm_bf16");
   }
   dim3 grid(g.tiles_m * g.tiles_n, pl.splitk);
@@ -673,10 +796,6 @@ static int gemm_run(const pcm_gemm_seg* segs, int nseg, const pcm_gemm_epi* e, v
   else if (pl.BM == 256 && pl.BN == 64) PCM_GEMM_LAUNCH(4, 4, 2, 2);
   else if (pl.BM == 128 && pl.BN == 64) PCM_GEMM_LAUNCH(4, 2, 2, 1);
   else PCM_GEMM_LAUNCH(4, 2, 1, 1);
-  if (pl.splitk > 1) {
-    long nq = (long)e->M * (e->N / 4);
-    long fb = (nq + 255) / 256; if (fb > PCM_GRID_CAP(2048)) fb = PCM_GRID_CAP(2048);
-    PCM_LAUNCH(pcm_gemm_finalize_kernel, dim3((int)fb), dim3(256), 0, stream, g);
-  }
+  if (pl.splitk > 1) launch_finalize(g, e, stream);
   return pcm_post_launch("pcm_gemm_bf16");
 }

@@ -26,6 +26,10 @@ struct GemmDev {
   bf16_t* pre_out;            // PCM_ACT_GEGLU: optional second output, the interleaved pre-activation of rows < pre_rows (row stride ldp)
   int pre_rows, ldp;
   int dbg;                    // ablation mask: only read by -DPCM_ABLATE builds (tools/probes/build_ablate.py), 0 otherwise
+  bf16_t* out2;               // abi 5: second copy of the bf16 output rows (row stride ldo2) -- a skip tensor written straight into the channel
+  int ldo2;                   // range of its future concat buffer (no concat pass); nullptr: none
+  double* chstats;            // abi 5: per-(sample, channel) {sum, sumsq} of the stored output, fp64 atomics into [M / stats_rows][N][2] (pre-zeroed);
+  int stats_rows;             // gemm8p's unsplit epilogue (gemm_epilogue.h stats_pass) and the split-K finalize emit it; nullptr: none
   int w4_stagger;             // gemm4w.hip: start delay (units of ~0.85 us) of the odd-numbered workgroup slot of a CU, so that the two
                               // co-resident workgroups do not run their MFMA and their epilogue phases in lockstep; 0 = none
 };
@@ -62,7 +66,9 @@ __device__ __forceinline__ void pcm_epi_store8(const GemmDev& g, int m, int n, f
 #pragma unroll
     for (int e = 0; e < 4; e++) { v[2 * e] += bf2f((bf16_t)(tw[e] & 0xffff)); v[2 * e + 1] += bf2f((bf16_t)(tw[e] >> 16)); }
   }
-  *(uint4*)((bf16_t*)g.out + (size_t)m * g.ldo + n) = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+  const uint4 o = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+  *(uint4*)((bf16_t*)g.out + (size_t)m * g.ldo + n) = o;
+  if (g.out2) *(uint4*)(g.out2 + (size_t)m * g.ldo2 + n) = o;
 }
 
 // The same epilogue split into a LOAD half and a FINISH half so that a kernel can put the global loads (row vector, residual) of several
@@ -94,7 +100,9 @@ __device__ __forceinline__ void pcm_epi_finish8(const GemmDev& g, int m, int n, 
 #pragma unroll
     for (int e = 0; e < 4; e++) { v[2 * e] += bf2f((bf16_t)(tw[e] & 0xffff)); v[2 * e + 1] += bf2f((bf16_t)(tw[e] >> 16)); }
   }
-  *(uint4*)((bf16_t*)g.out + (size_t)m * g.ldo + n) = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+  const uint4 o = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+  *(uint4*)((bf16_t*)g.out + (size_t)m * g.ldo + n) = o;
+  if (g.out2) *(uint4*)(g.out2 + (size_t)m * g.ldo2 + n) = o;
 }
 
 // 256 x (64*FN) phased kernel (gemm8p.hip).  fn = 5 -> 256x320, fn = 4 -> 256x256.  grid = (tiles_m*tiles_n, splitk)

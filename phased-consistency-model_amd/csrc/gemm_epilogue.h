@@ -92,8 +92,16 @@ struct PcmEpi {
     }
   }
 
+  // X ("extras", abi 5): a second copy of the output rows (g.out2) and / or the per-channel statistics of the tile (g.chstats).  A
+  // COMPILE-TIME flag selected once per tile: the common tile runs exactly the piece loops it ran before (run-time tests of the two
+  // pointers inside them cost the unswitched form, see finish below; measured +2.5 ms on the two-timestep forward: profiles/r06_b_*)
   template <typename Acc>
   static __device__ __forceinline__ void run(const GemmDev& g, char* smem, const Acc& acc, int tid, int wm, int wn, int m0, int n0, bool sync_first) {
+    if (g.out2 || (WM == 2 && g.chstats)) run_impl<true>(g, smem, acc, tid, wm, wn, m0, n0, sync_first);
+    else run_impl<false>(g, smem, acc, tid, wm, wn, m0, n0, sync_first);
+  }
+  template <bool X, typename Acc>
+  static __device__ __forceinline__ void run_impl(const GemmDev& g, char* smem, const Acc& acc, int tid, int wm, int wn, int m0, int n0, bool sync_first) {
     // the piece geometry below is a function of tid only: opaque copies keep hipcc from computing it (or anything shared with it) ahead of
     // the K loop and carrying it through the loop -- the 256 x 320 tile has no register to spare there (measured: 60+ spills, reloads inside
     // the K loop, without this)
@@ -113,6 +121,17 @@ struct PcmEpi {
     for (int it = 0; it < IT; it++) pf[it] = pf_on ? fetch(g, g.res, true, tid, it, 0, m0, n0) : make_uint4(0u, 0u, 0u, 0u);
     // the tile's BN bias values: ONE global load by BN/4 threads, kept in LDS behind the staging area for all four passes
     float4* bias_lds = (float4*)(smem + (size_t)ROWS * CH * 16);
+    // statistics image behind the bias row (WM == 2 only: the 256-row tile's dead K-loop stages have the room), see stats_pass
+    char* sb = (X && WM == 2 && g.chstats) ? smem + (size_t)ROWS * CH * 16 + BN * 4 : nullptr;
+    const bool st_merge = (g.stats_rows % (128 * WM)) == 0;
+    ColAcc st;
+    stats_zero(st);
+    auto after_pass = [&](int q) {       // the pass's stored pieces are parked in sb: add them up (workgroup-uniform branch)
+      if (!X || !sb) return;
+      __syncthreads();
+      stats_pass(sb, st, tid);
+      if (!st_merge || q == 3) stats_flush(g, st, tid, n0, m0 + 32 * q, m0 + 128 + 32 * q, st_merge);
+    };
     float4 b_mine = make_float4(0.f, 0.f, 0.f, 0.f);
     if (tid < BN / 4 && g.bias && n0 + 4 * tid < g.N) b_mine = *(const float4*)(g.bias + n0 + 4 * tid);
 #pragma unroll
@@ -137,38 +156,46 @@ struct PcmEpi {
           piece(tid, it, q, m0, n0, lr, c8, m, n);
           const uint4 px = pf[it];
           if (q < 3) pf[it] = fetch(g, g.res, true, tid, it, q + 1, m0, n0);    // the same piece of the next pass, a pass ahead
-          if (m >= g.M || n >= g.N) continue;
+          char* sbp = (X && sb) ? sb + (size_t)(tid + NT * it) * 16 : nullptr;
+          if (m >= g.M || n >= g.N) { if (X && sbp) *(uint4*)sbp = make_uint4(0u, 0u, 0u, 0u); continue; }
           const float4 lo = *(const float4*)(smem + ((size_t)lr * CH + ((2 * c8) ^ (lr & 15))) * 16);
           const float4 hi4 = *(const float4*)(smem + ((size_t)lr * CH + ((2 * c8 + 1) ^ (lr & 15))) * 16);
           float v[8] = {lo.x, lo.y, lo.z, lo.w, hi4.x, hi4.y, hi4.z, hi4.w};
           if (PCM_ABL(1)) { if (v[0] != 123456.f) continue; }
-          finish_any(g, bias_lds, m, n, c8, v, px);
+          finish_any<X>(g, bias_lds, m, n, c8, v, px, sbp);
         }
+        after_pass(q);
         continue;
       }
       // no residual: bias-free (q / k / v, LoRA-down style projections), bias only, bias + time-embedding row (resnet conv1), generic
       if (g.act != PCM_ACT_SILU) {
-        if (!g.rowvec) { if (g.bias) plain_pass<true, false>(g, smem, bias_lds, tid, q, m0, n0); else plain_pass<false, false>(g, smem, bias_lds, tid, q, m0, n0); continue; }
-        if (g.bias) { plain_pass<true, true>(g, smem, bias_lds, tid, q, m0, n0); continue; }
+        if (!g.rowvec) {
+          if (g.bias) plain_pass<true, false, X>(g, smem, bias_lds, tid, q, m0, n0, sb); else plain_pass<false, false, X>(g, smem, bias_lds, tid, q, m0, n0, sb);
+          after_pass(q);
+          continue;
+        }
+        if (g.bias) { plain_pass<true, true, X>(g, smem, bias_lds, tid, q, m0, n0, sb); after_pass(q); continue; }
       }
       for (int idx = tid; idx < ROWS * C8; idx += NT) {
         const int lr = idx / C8, c8 = idx - lr * C8;
         const int m = m0 + 128 * (lr >> 5) + 32 * q + (lr & 31), n = n0 + 8 * c8;
-        if (m >= g.M || n >= g.N) continue;
+        char* sbp = (X && sb) ? sb + (size_t)idx * 16 : nullptr;
+        if (m >= g.M || n >= g.N) { if (X && sbp) *(uint4*)sbp = make_uint4(0u, 0u, 0u, 0u); continue; }
         const float4 lo = *(const float4*)(smem + ((size_t)lr * CH + ((2 * c8) ^ (lr & 15))) * 16);
         const float4 hi4 = *(const float4*)(smem + ((size_t)lr * CH + ((2 * c8 + 1) ^ (lr & 15))) * 16);
         float v[8] = {lo.x, lo.y, lo.z, lo.w, hi4.x, hi4.y, hi4.z, hi4.w};
         if (PCM_ABL(1)) { if (v[0] != 123456.f) continue; }
-        finish_any(g, bias_lds, m, n, c8, v, make_uint4(0u, 0u, 0u, 0u));
+        finish_any<X>(g, bias_lds, m, n, c8, v, make_uint4(0u, 0u, 0u, 0u), sbp);
       }
+      after_pass(q);
     }
   }
 
   // bias (LDS copy of the tile's bias row), row vector, SiLU, residual (already loaded: ``res``), one 16-B bf16 store.  The flags are
   // COMPILE-TIME: the piece loops are instantiated per flag set and selected once per tile (hipcc unswitched the old single loop by itself;
   // it does not do so for this one: measured as 96 instead of 56 instructions per piece and +3-6 % on the bias-free projections)
-  template <bool BIAS, bool RV, bool SILU, bool RES>
-  static __device__ __forceinline__ void finish(const GemmDev& g, const float4* bias_lds, int m, int n, int c8, float (&v)[8], const uint4 res) {
+  template <bool BIAS, bool RV, bool SILU, bool RES, bool X>
+  static __device__ __forceinline__ void finish(const GemmDev& g, const float4* bias_lds, int m, int n, int c8, float (&v)[8], const uint4 res, char* sbp = nullptr) {
     if (BIAS) {
       const float4 b0 = bias_lds[2 * c8], b1 = bias_lds[2 * c8 + 1];
       v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
@@ -188,10 +215,16 @@ struct PcmEpi {
 #pragma unroll
       for (int e = 0; e < 4; e++) { v[2 * e] += bf2f((bf16_t)(tw[e] & 0xffff)); v[2 * e + 1] += bf2f((bf16_t)(tw[e] >> 16)); }
     }
-    *(uint4*)((bf16_t*)g.out + (size_t)m * g.ldo + n) = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+    const uint4 o = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+    *(uint4*)((bf16_t*)g.out + (size_t)m * g.ldo + n) = o;
+    if (X) {
+      if (g.out2) *(uint4*)(g.out2 + (size_t)m * g.ldo2 + n) = o;    // (wave-uniform: a skip tensor's second home, its concat buffer)
+      if (sbp) *(uint4*)sbp = o;                                      // the STORED values, for the per-channel statistics pass (stats_pass)
+    }
   }
   // the generic form (flags read at run time): the residual path and the rare flag sets
-  static __device__ __forceinline__ void finish_any(const GemmDev& g, const float4* bias_lds, int m, int n, int c8, float (&v)[8], const uint4 res) {
+  template <bool X>
+  static __device__ __forceinline__ void finish_any(const GemmDev& g, const float4* bias_lds, int m, int n, int c8, float (&v)[8], const uint4 res, char* sbp = nullptr) {
     if (g.bias) {
       const float4 b0 = bias_lds[2 * c8], b1 = bias_lds[2 * c8 + 1];
       v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
@@ -211,20 +244,67 @@ struct PcmEpi {
 #pragma unroll
       for (int e = 0; e < 4; e++) { v[2 * e] += bf2f((bf16_t)(tw[e] & 0xffff)); v[2 * e + 1] += bf2f((bf16_t)(tw[e] >> 16)); }
     }
-    *(uint4*)((bf16_t*)g.out + (size_t)m * g.ldo + n) = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+    const uint4 o = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+    *(uint4*)((bf16_t*)g.out + (size_t)m * g.ldo + n) = o;
+    if (X) {
+      if (g.out2) *(uint4*)(g.out2 + (size_t)m * g.ldo2 + n) = o;    // (wave-uniform: a skip tensor's second home, its concat buffer)
+      if (sbp) *(uint4*)sbp = o;                                      // the STORED values, for the per-channel statistics pass (stats_pass)
+    }
   }
   // one pass of the plain piece loop with compile-time flags
-  template <bool BIAS, bool RV>
-  static __device__ __forceinline__ void plain_pass(const GemmDev& g, const char* smem, const float4* bias_lds, int tid, int q, int m0, int n0) {
+  template <bool BIAS, bool RV, bool X>
+  static __device__ __forceinline__ void plain_pass(const GemmDev& g, const char* smem, const float4* bias_lds, int tid, int q, int m0, int n0, char* sb) {
     for (int idx = tid; idx < ROWS * C8; idx += NT) {
       const int lr = idx / C8, c8 = idx - lr * C8;
       const int m = m0 + 128 * (lr >> 5) + 32 * q + (lr & 31), n = n0 + 8 * c8;
-      if (m >= g.M || n >= g.N) continue;
+      char* sbp = (X && sb) ? sb + (size_t)idx * 16 : nullptr;
+      if (m >= g.M || n >= g.N) { if (X && sbp) *(uint4*)sbp = make_uint4(0u, 0u, 0u, 0u); continue; }
       const float4 lo = *(const float4*)(smem + ((size_t)lr * CH + ((2 * c8) ^ (lr & 15))) * 16);
       const float4 hi4 = *(const float4*)(smem + ((size_t)lr * CH + ((2 * c8 + 1) ^ (lr & 15))) * 16);
       float v[8] = {lo.x, lo.y, lo.z, lo.w, hi4.x, hi4.y, hi4.z, hi4.w};
       if (PCM_ABL(1)) { if (v[0] != 123456.f) continue; }
-      finish<BIAS, RV, false, false>(g, bias_lds, m, n, c8, v, make_uint4(0u, 0u, 0u, 0u));
+      finish<BIAS, RV, false, false, X>(g, bias_lds, m, n, c8, v, make_uint4(0u, 0u, 0u, 0u), sbp);
+    }
+  }
+
+  // ---- per-channel statistics of the tile (abi 5, pcm_gemm_epi.chstats): the GroupNorm that reads this output next needs sum / sum of squares
+  // per (sample, group) of the STORED values.  The piece loops park the packed 16-bit pieces of a pass in an LDS image [ROWS][BN]; here
+  // thread t < BN/2 adds up columns 2t, 2t+1 over the pass's two 32-row runs (rows 32q.. of each 128-row half of the tile).  A tile that
+  // lies inside one sample (stats_rows % (128 * WM) == 0) keeps the sums in registers and issues its BN x 2 fp64 atomics once; smaller feature maps
+  // (8x8, 16x8: a run of 32 rows is still inside one sample) flush after every pass.
+  struct ColAcc { float s[2][2], q[2][2]; };       // [row run][column of the pair]
+  static __device__ __forceinline__ void stats_zero(ColAcc& a) {
+#pragma unroll
+    for (int h = 0; h < 2; h++) { a.s[h][0] = a.s[h][1] = a.q[h][0] = a.q[h][1] = 0.f; }
+  }
+  static __device__ __forceinline__ void stats_flush(const GemmDev& g, ColAcc& a, int tid, int n0, int m_run0, int m_run1, bool merge) {
+    const int n = n0 + 2 * tid;
+    if (tid < BN / 2 && n < g.N) {
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        if (merge && h == 1) break;
+        const int mrow = h ? m_run1 : m_run0;
+        if (mrow >= g.M) continue;
+        double* dst = g.chstats + ((size_t)(mrow / g.stats_rows) * g.N + n) * 2;
+        const float s0 = merge ? a.s[0][0] + a.s[1][0] : a.s[h][0], s1 = merge ? a.s[0][1] + a.s[1][1] : a.s[h][1];
+        const float q0 = merge ? a.q[0][0] + a.q[1][0] : a.q[h][0], q1 = merge ? a.q[0][1] + a.q[1][1] : a.q[h][1];
+        atomicAdd(dst, (double)s0); atomicAdd(dst + 1, (double)q0);
+        atomicAdd(dst + 2, (double)s1); atomicAdd(dst + 3, (double)q1);
+      }
+    }
+    stats_zero(a);
+  }
+  static __device__ __forceinline__ void stats_pass(const char* sb, ColAcc& a, int tid) {
+    if (tid < BN / 2) {
+#pragma unroll
+      for (int h = 0; h < WM; h++)
+#pragma unroll 8
+        for (int r = 0; r < 32; r++) {
+          const unsigned w = *(const unsigned*)(sb + (size_t)(32 * h + r) * (BN * 2) + 4 * tid);
+          const float x0 = bf2f((bf16_t)(w & 0xffff)), x1 = bf2f((bf16_t)(w >> 16));
+          a.s[h][0] += x0; a.q[h][0] = fmaf(x0, x0, a.q[h][0]);
+          a.s[h][1] += x1; a.q[h][1] = fmaf(x1, x1, a.q[h][1]);
+        }
     }
   }
 };

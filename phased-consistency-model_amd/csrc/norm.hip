@@ -168,6 +168,10 @@ struct GNApply {
   const bf16_t* x;
   const bf16_t* dy;
   const double* stats;
+  const double* chstats;   // MODE 0, abi 5: per-(sample, channel) {sum, sumsq} from the producing GEMM's epilogue INSTEAD of `stats`; the group sums
+  double* stats_out;       // are formed here and block 0 of each sample also writes them to stats_out[b][g][2] (what the backward reads)
+  const double* chstats2;  // channels [c_split, C) come from a second producer (x = torch.cat([h, skip], dim=1): discriminator_sd15.py:312-342)
+  int c_split, ld1, ld2;   // per-sample strides (channels) of the two sources
   const double* bstats;
   const float* gamma;
   const float* beta;
@@ -189,9 +193,40 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GNApply a) {
   __shared__ float gm[32], gr[32], g1[32], g2[32];
   const int b = blockIdx.y;
   const double n = (double)a.HW * a.cpg;
+  __shared__ double gsum[32][8][2];
+  if (MODE == 0 && a.chstats) {
+    // group sums from the per-channel sums: 8 threads per group, each cpg/8 channels (<= 10 loads of 16 B, L2-resident), partials through LDS
+    const int g = threadIdx.x >> 3, j = threadIdx.x & 7;
+    if (g < a.G) {
+      // (all of a thread's <= 10 loads are issued before the first is used: one round trip, not ten)
+      struct __attribute__((aligned(16))) D2 { double x, y; };
+      D2 vv[10];
+#pragma unroll
+      for (int u = 0; u < 10; u++) {
+        const int cc = j + 8 * u;
+        const int c = g * a.cpg + (cc < a.cpg ? cc : 0);      // (clamped lanes re-read the group's first channel; their value is not added)
+        const double* p = c < a.c_split ? a.chstats + ((size_t)b * a.ld1 + c) * 2 : a.chstats2 + ((size_t)b * a.ld2 + (c - a.c_split)) * 2;
+        vv[u] = *(const D2*)p;
+      }
+      double s = 0.0, ss = 0.0;
+#pragma unroll
+      for (int u = 0; u < 10; u++)
+        if (j + 8 * u < a.cpg) { s += vv[u].x; ss += vv[u].y; }
+      gsum[g][j][0] = s; gsum[g][j][1] = ss;
+    }
+    __syncthreads();
+  }
   if ((int)threadIdx.x < a.G) {
     int g = threadIdx.x;
-    double s = a.stats[((size_t)b * a.G + g) * 2], ss = a.stats[((size_t)b * a.G + g) * 2 + 1];
+    double s, ss;
+    if (MODE == 0 && a.chstats) {
+      s = ss = 0.0;
+#pragma unroll
+      for (int j = 0; j < 8; j++) { s += gsum[g][j][0]; ss += gsum[g][j][1]; }
+      if (blockIdx.x == 0 && a.stats_out) { a.stats_out[((size_t)b * a.G + g) * 2] = s; a.stats_out[((size_t)b * a.G + g) * 2 + 1] = ss; }
+    } else {
+      s = a.stats[((size_t)b * a.G + g) * 2]; ss = a.stats[((size_t)b * a.G + g) * 2 + 1];
+    }
     double m = s / n, var = ss / n - m * m;
     gm[g] = (float)m;
     gr[g] = (float)(1.0 / sqrt((var > 0 ? var : 0) + (double)a.eps));
@@ -399,6 +434,24 @@ extern "C" int pcm_groupnorm_apply(const void* x, const double* stats, const flo
   a.x = (const bf16_t*)x; a.stats = stats; a.gamma = gamma; a.beta = beta; a.y = (bf16_t*)y;
   a.HW = HW; a.C = C; a.G = G; a.cpg = C / G; a.act = act; a.eps = eps;
   return gn_apply_launch<0>("pcm_groupnorm_apply", a, B, stream);
+}
+
+/* abi 5: the same apply with the statistics taken from per-(sample, channel) sums accumulated by the producing contractions' epilogues
+ * (pcm_gemm_epi.chstats); also writes the group statistics to stats_out[B][G][2] for the backward */
+extern "C" int pcm_groupnorm_apply_chstats(const void* x, const double* chstats, int stats_ld, const double* chstats2, int stats_ld2, int c_split,
+                                           double* stats_out, const float* gamma, const float* beta, void* y, int B, int HW, int C, int G,
+                                           float eps, int act, void* stream) {
+  if (int rc = gn_check("pcm_groupnorm_apply_chstats", B, HW, C, G)) return rc;
+  PCM_CHECK(x && chstats && gamma && beta && y && PCM_ALIGNED16(x) && PCM_ALIGNED16(y) && ((uintptr_t)chstats % 8) == 0 && C <= 2560, PCM_EALIGN,
+            "pcm_groupnorm_apply_chstats: null/unaligned argument or C>2560");
+  if (!chstats2) c_split = C;
+  PCM_CHECK(c_split > 0 && c_split <= C && stats_ld >= c_split && (!chstats2 || (stats_ld2 >= C - c_split && ((uintptr_t)chstats2 % 8) == 0)), PCM_EINVAL,
+            "pcm_groupnorm_apply_chstats: bad channel split / strides (C=%d split=%d ld=%d ld2=%d)", C, c_split, stats_ld, stats_ld2);
+  GNApply a; memset(&a, 0, sizeof(a));
+  a.x = (const bf16_t*)x; a.chstats = chstats; a.chstats2 = chstats2; a.c_split = c_split; a.ld1 = stats_ld; a.ld2 = stats_ld2;
+  a.stats_out = stats_out; a.gamma = gamma; a.beta = beta; a.y = (bf16_t*)y;
+  a.HW = HW; a.C = C; a.G = G; a.cpg = C / G; a.act = act; a.eps = eps;
+  return gn_apply_launch<0>("pcm_groupnorm_apply_chstats", a, B, stream);
 }
 
 extern "C" int pcm_groupnorm_bwd_apply(const void* x, const void* dy, const double* stats, const double* bstats,

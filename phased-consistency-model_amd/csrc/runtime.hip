@@ -36,7 +36,7 @@ void pcm_zero_async(void* p, size_t bytes, void* stream) {
 }
 
 extern "C" const char* pcm_last_error(void) { return g_err; }
-extern "C" int pcm_abi_version(void) { return 4; }   // 2: pcm_gemm_epi gained pre_out / pre_rows / ldp (PCM_ACT_GEGLU second output); 3: PCM_ACT_GEGLU rows interleaved in groups of 2 (was 8); 4: pcm_wgrad_args gained workspace / workspace_bytes, the *_ws reproducible reductions
+extern "C" int pcm_abi_version(void) { return 5; }   // 2: pcm_gemm_epi gained pre_out / pre_rows / ldp (PCM_ACT_GEGLU second output); 3: PCM_ACT_GEGLU rows interleaved in groups of 2 (was 8); 4: pcm_wgrad_args gained workspace / workspace_bytes, the *_ws reproducible reductions; 5: pcm_gemm_epi gained out2 / ldo2 (second output copy: concat-free skips) and chstats / stats_rows (GroupNorm statistics from the producing epilogue), pcm_gemm_emits_chstats, pcm_groupnorm_apply_chstats
 // the 16-bit activation / weight format this library was compiled for (pcm_common.h): 0 = bfloat16 (libpcm_hip.so), 1 = IEEE half
 // (libpcm_hip_f16.so, -DPCM_ACT_F16).  The host side checks it against the tensors it is about to pass.
 #ifdef PCM_ACT_F16

@@ -37,7 +37,8 @@ class GemmEpi(C.Structure):
                 ("rowvec", vp), ("rows_per_batch", C.c_int), ("residual", vp), ("ldr", C.c_int),
                 ("out", vp), ("ldo", C.c_int), ("out_dtype", C.c_int), ("act", C.c_int),
                 ("alpha", C.c_float), ("workspace", vp), ("workspace_bytes", C.c_size_t),
-                ("pre_out", vp), ("pre_rows", C.c_int), ("ldp", C.c_int)]
+                ("pre_out", vp), ("pre_rows", C.c_int), ("ldp", C.c_int),
+                ("out2", vp), ("ldo2", C.c_int), ("chstats", vp), ("stats_rows", C.c_int)]      # abi 5
 
 
 class WgradArgs(C.Structure):
@@ -64,6 +65,7 @@ _PROTOS = {
     "pcm_groupnorm_stats_ws": [vp, vp, i32, i32, i32, i32, vp, C.c_size_t, vp],
     "pcm_groupnorm_bwd_stats_ws": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp, C.c_size_t, vp],
     "pcm_groupnorm_apply": [vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp],
+    "pcm_groupnorm_apply_chstats": [vp, vp, i32, vp, i32, i32, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp],
     "pcm_groupnorm_bwd_stats": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp],
     "pcm_groupnorm_bwd_stats_acc": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp],
     "pcm_groupnorm_bwd_apply": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp],
@@ -162,6 +164,8 @@ class Lib:
         self.dll.pcm_gemm_workspace_bytes.argtypes = [C.POINTER(GemmSeg), C.c_int, C.POINTER(GemmEpi)]
         self.dll.pcm_gemm_plan_code.restype = C.c_int
         self.dll.pcm_gemm_plan_code.argtypes = [C.POINTER(GemmSeg), C.c_int, C.POINTER(GemmEpi)]
+        self.dll.pcm_gemm_emits_chstats.restype = C.c_int
+        self.dll.pcm_gemm_emits_chstats.argtypes = [C.POINTER(GemmSeg), C.c_int, C.POINTER(GemmEpi)]
         self.dll.pcm_attn_workspace_bytes.restype = C.c_size_t
         self.dll.pcm_attn_workspace_bytes.argtypes = [C.c_int] * 6
         self.dll.pcm_groupnorm_workspace_bytes.restype = C.c_size_t

@@ -19,7 +19,6 @@ from .ops import Seg
 
 from .precision import act_dtype as _act_dtype  # noqa: E402
 
-BF16 = _act_dtype()      # the library's 16-bit dtype: bfloat16, or float16 after precision.set_precision("fp16") (which rebinds this name)
 ADAPTER_DIMS = (320, 640, 1280, 1280, 1280, 1280, 1280, 640, 320)   # discriminator_sd15.py:377
 ADAPTER_DIMS_SDXL = (320, 640, 1280, 1280)                            # discriminator_sdxl.py:377-386 (down blocks + mid only)
 
@@ -77,8 +76,8 @@ class Discriminator:
             bound = 1.0 / math.sqrt(C)
             hd.p["conv_out.weight"].copy_(((torch.rand(C, generator=g) * 2 - 1) * bound).to(self.device))
             hd.p["conv_out.bias"].copy_(((torch.rand(1, generator=g) * 2 - 1) * bound).to(self.device))
-            hd.wf = {cv: torch.empty(C, ksize * ksize * C, dtype=BF16, device=self.device) for cv in ("conv1.0", "conv2.0")}
-            hd.wb = {cv: torch.empty(C, ksize * ksize * C, dtype=BF16, device=self.device) for cv in ("conv1.0", "conv2.0")}
+            hd.wf = {cv: torch.empty(C, ksize * ksize * C, dtype=_act_dtype(), device=self.device) for cv in ("conv1.0", "conv2.0")}
+            hd.wb = {cv: torch.empty(C, ksize * ksize * C, dtype=_act_dtype(), device=self.device) for cv in ("conv1.0", "conv2.0")}
             self.heads.append((k, hd))
         self.repack()
 
@@ -126,10 +125,10 @@ class Discriminator:
             B, C = f.shape[0], hd.C
             M = B * H * W
             geo = dict(Hs=H, Ws=W) if self.ksize == 3 else None
-            a1 = torch.empty(M, C, dtype=BF16, device=f.device)
+            a1 = torch.empty(M, C, dtype=_act_dtype(), device=f.device)
             ops.gemm([Seg(f if geo else f.reshape(M, C), hd.wf["conv1.0"], conv=geo)], M, C, a1, bias=hd.p["conv1.0.bias"], Ho=H, Wo=W)
             n1, st1 = ops.groupnorm_fwd(a1.view(B, H * W, C), hd.p["conv1.1.weight"], hd.p["conv1.1.bias"], self.G, 1e-5, capi.ACT_LEAKY)
-            a2 = torch.empty(M, C, dtype=BF16, device=f.device)
+            a2 = torch.empty(M, C, dtype=_act_dtype(), device=f.device)
             ops.gemm([Seg(n1 if geo else n1.reshape(M, C), hd.wf["conv2.0"], conv=geo)], M, C, a2, bias=hd.p["conv2.0.bias"], Ho=H, Wo=W)
             n2, st2 = ops.groupnorm_fwd(a2.view(B, H * W, C), hd.p["conv2.1.weight"], hd.p["conv2.1.bias"], self.G, 1e-5, capi.ACT_LEAKY)
             h2 = ops.add(n2, n1)                                                         # x = conv2(x) + x   (:366)
@@ -164,7 +163,7 @@ class Discriminator:
             d_a2 = ops.groupnorm_bwd(a2, d_h2, sv["st2"], gam2, bet2, self.G, 1e-5, capi.ACT_LEAKY)
             if param_grads:
                 self._conv_param_grads(hd, "conv2.0", sv["n1"], d_a2.view(M, C), M, wg)
-            d_n1 = torch.empty(M, C, dtype=BF16, device=dl.device)                     # dgrad(conv2) + skip branch
+            d_n1 = torch.empty(M, C, dtype=_act_dtype(), device=dl.device)                     # dgrad(conv2) + skip branch
             ops.gemm([Seg(d_a2 if geo else d_a2.reshape(M, C), hd.wb["conv2.0"], conv=geo)], M, C, d_n1, residual=d_h2.view(M, C), Ho=H, Wo=W)
             gam1, bet1 = hd.p["conv1.1.weight"], hd.p["conv1.1.bias"]
             a1 = sv["a1"].view(B, H * W, C)
@@ -174,7 +173,7 @@ class Discriminator:
             if param_grads:
                 self._conv_param_grads(hd, "conv1.0", sv["f"], d_a1.view(M, C), M, wg)
             if feature_grads:
-                d_f = torch.empty(M, C, dtype=BF16, device=dl.device)
+                d_f = torch.empty(M, C, dtype=_act_dtype(), device=dl.device)
                 ops.gemm([Seg(d_a1 if geo else d_a1.reshape(M, C), hd.wb["conv1.0"], conv=geo)], M, C, d_f, residual=None if d_feats[k] is None else d_feats[k].view(M, C),
                          Ho=H, Wo=W)                                                   # 4 heads share one feature: sum in the epilogue
                 d_feats[k] = d_f.view(B, H * W, C)
@@ -230,3 +229,10 @@ class Discriminator:
             d_logits.append(df)
         d_feats = self.backward(d_logits, tape, param_grads=False, feature_grads=True)
         return loss, d_feats
+
+
+def __getattr__(name):
+    # ``<module>.BF16`` = "the library's 16-bit dtype" for external readers (tests, tools): a call-time lookup, never a captured constant
+    if name == "BF16":
+        return _act_dtype()
+    raise AttributeError(name)

@@ -19,7 +19,8 @@ import torch
 
 from . import capi, ops
 from .mmdit_spec import MMDiTConfig, buffer_spec, lora_target_modules, param_spec
-from .model import BF16, LoraState, PackedLayer, layer_bwd, layer_fwd
+from .precision import act_dtype as _act_dtype
+from .model import LoraState, PackedLayer, layer_bwd, layer_fwd
 from .ops import Seg
 from .precision import precision
 
@@ -74,7 +75,7 @@ class MMDiTWeights:
             if hp > S or wp > S:
                 raise ValueError(f"MMDiTWeights: token grid {hp}x{wp} exceeds pos_embed_max_size {S}")
             top, left = (S - hp) // 2, (S - wp) // 2
-            self._pos_cache[key] = self.pos_embed[top:top + hp, left:left + wp].reshape(hp * wp, -1).to(BF16).contiguous()
+            self._pos_cache[key] = self.pos_embed[top:top + hp, left:left + wp].reshape(hp * wp, -1).to(_act_dtype()).contiguous()
         return self._pos_cache[key]
 
 
@@ -139,7 +140,7 @@ class MMDiT:
         x = layer_fwd(W, lora, "pos_embed.proj", tok, Mx, save=spos, residual=W.pos_crop(hp, wp).repeat(B, 1))
         # CombinedTimestepTextProjEmbeddings: linear_2(silu(linear_1(.))) for the timestep projection and the pooled text embedding
         tp = ops.timestep_embedding_f32(timestep.float().contiguous(), 256)
-        pooled = pooled_projections if pooled_projections.dtype == BF16 else ops.cast_bf16(pooled_projections.float().contiguous())
+        pooled = pooled_projections if pooled_projections.dtype == _act_dtype() else ops.cast_bf16(pooled_projections.float().contiguous())
         emb = {}
         for name, inp in (("timestep_embedder", tp), ("text_embedder", pooled)):
             s1, s2 = S(), S()
@@ -152,7 +153,7 @@ class MMDiT:
             emb[name] = (layer_fwd(W, lora, pre + ".linear_2", h1, B, save=s2), s1, s2, z1)
         temb = ops.add(emb["timestep_embedder"][0], emb["text_embedder"][0])
         semb = ops.silu(temb)
-        ctx = encoder_hidden_states if encoder_hidden_states.dtype == BF16 else ops.cast_bf16(encoder_hidden_states.float().contiguous())
+        ctx = encoder_hidden_states if encoder_hidden_states.dtype == _act_dtype() else ops.cast_bf16(encoder_hidden_states.float().contiguous())
         sctx = S()
         c = layer_fwd(W, lora, "context_embedder", ctx.view(Mc, -1), Mc, save=sctx)
         feats = []
@@ -188,12 +189,12 @@ class MMDiT:
                 segs = [Seg(xn, W.qkv[pa])]
                 fq = lora.qkv.get(pa) if lora is not None else None
                 if fq is not None:
-                    t3 = torch.empty(Mx, fq.r3, dtype=BF16, device=xn.device)
+                    t3 = torch.empty(Mx, fq.r3, dtype=_act_dtype(), device=xn.device)
                     ops.gemm([Seg(xn, fq.A_cat_fwd)], Mx, fq.r3, t3)
                     segs.append(Seg(t3, fq.Bs_cat_fwd, k_algo=lora.rank))
-                qkv_x = torch.empty(Mx, 3 * D, dtype=BF16, device=xn.device)
+                qkv_x = torch.empty(Mx, 3 * D, dtype=_act_dtype(), device=xn.device)
                 ops.gemm(segs, Mx, 3 * D, qkv_x, bias=W.qkv_bias[pa])
-                qkv_c = torch.empty(Mc, 3 * D, dtype=BF16, device=xn.device)
+                qkv_c = torch.empty(Mc, 3 * D, dtype=_act_dtype(), device=xn.device)
                 ops.gemm([Seg(cn, W.cqkv[pa])], Mc, 3 * D, qkv_c, bias=W.cqkv_bias[pa])
                 j3 = torch.cat([qkv_x.view(B, Lx, 3 * D), qkv_c.view(B, Lc, 3 * D)], 1)
                 q, k, v = j3[:, :, :D], j3[:, :, D:2 * D], j3[:, :, 2 * D:]
@@ -270,7 +271,7 @@ class MMDiT:
 
         def mod_bwd(path, parts, saved):
             nonlocal d_semb
-            dm = torch.stack(parts, 1).reshape(B, -1).to(BF16).contiguous()
+            dm = torch.stack(parts, 1).reshape(B, -1).to(_act_dtype()).contiguous()
             g = layer_bwd(W, lora, path, dm, saved).float()
             d_semb = g if d_semb is None else d_semb + g
         if fin["features"]:
@@ -302,7 +303,7 @@ class MMDiT:
                 dg_a, _ = ops.mod_grad(r["a_x"], d_x1, B, want_b=False)
             # context stream (absent in the last block: its attention output for the text tokens is dropped)
             if r["last"] or d_c is None:
-                d_oc = torch.zeros(B, Lc, D, dtype=BF16, device=d_ox.device)
+                d_oc = torch.zeros(B, Lc, D, dtype=_act_dtype(), device=d_ox.device)
                 d_c1 = None
                 cparts = None
             else:
@@ -318,14 +319,14 @@ class MMDiT:
             d_o = torch.cat([d_ox.view(B, Lx, D), d_oc], 1)
             pa = b + "attn."
             if r["fuse"]:
-                d3 = torch.empty(B, Lx + Lc, 3 * D, dtype=BF16, device=d_o.device)      # [dq | dk | dv], written in place by attention
+                d3 = torch.empty(B, Lx + Lc, 3 * D, dtype=_act_dtype(), device=d_o.device)      # [dq | dk | dv], written in place by attention
                 ops.attn_bwd(r["q"], r["k"], r["v"], r["o"], d_o, r["lse"], nh, hd, out=(d3[:, :, :D], d3[:, :, D:2 * D], d3[:, :, 2 * D:]))
                 d3x = d3[:, :Lx].contiguous().view(Mx, 3 * D)
                 segs = [Seg(d3x, W.qkv_bwd[pa])]
                 fq = lora.qkv.get(pa) if lora is not None else None
                 if fq is not None:
                     rk, t3, xn_ = lora.rank, r["t3"], r["xn"]
-                    u3 = torch.empty(Mx, fq.r3, dtype=BF16, device=d_o.device)
+                    u3 = torch.empty(Mx, fq.r3, dtype=_act_dtype(), device=d_o.device)
                     ops.gemm([Seg(d3x, fq.Bs_cat_bwd, k_algo=D)], Mx, fq.r3, u3)
                     with ops.wgrad_batch():
                         for jj, lm in enumerate((fq.q, fq.k, fq.v)):
@@ -333,7 +334,7 @@ class MMDiT:
                                            ldb=3 * D, lds=fq.r3)
                             ops.lora_wgrad(xn_, u3[:, jj * rk:(jj + 1) * rk], lm.gA, 1.0, Mx, G=fq.K, g_stride=1, r_stride=fq.K, lds=fq.r3)
                     segs.append(Seg(u3, fq.A_cat_bwd))
-                d_xn = torch.empty(Mx, D, dtype=BF16, device=d_o.device)
+                d_xn = torch.empty(Mx, D, dtype=_act_dtype(), device=d_o.device)
                 ops.gemm(segs, Mx, D, d_xn)
                 dq = dk = dv = None
             else:
@@ -350,7 +351,7 @@ class MMDiT:
             need_dc = i > 0 or self.ctx_in_lora or self.mod_lora
             if need_dc:
                 if r["fuse"]:
-                    d_cn = torch.empty(Mc, D, dtype=BF16, device=d_o.device)
+                    d_cn = torch.empty(Mc, D, dtype=_act_dtype(), device=d_o.device)
                     ops.gemm([Seg(d3[:, Lx:].contiguous().view(Mc, 3 * D), W.cqkv_bwd[pa])], Mc, D, d_cn)
                 else:
                     d_cn = layer_bwd(W, lora, b + "attn.add_q_proj", dq[:, Lx:].contiguous().view(Mc, D), r["cq"])
@@ -369,7 +370,7 @@ class MMDiT:
         if d_c is not None and self.ctx_in_lora:
             layer_bwd(W, lora, "context_embedder", d_c, fin["sctx"], need_dx=False)
         if d_semb is not None and self.emb_lora:
-            d_temb = ops.silu_bwd(fin["temb"], d_semb.to(BF16).contiguous())          # semb = silu(temb), temb = te + pe
+            d_temb = ops.silu_bwd(fin["temb"], d_semb.to(_act_dtype()).contiguous())          # semb = silu(temb), temb = te + pe
             for name in ("timestep_embedder", "text_embedder"):
                 _, s1, s2, z1 = fin["emb"][name]
                 pre = "time_text_embed." + name
@@ -383,3 +384,10 @@ class MMDiT:
         if not need_input_grad:
             return None
         return ops.unpatchify2x2(d_tok0.float(), B, cfg.in_channels, H, Wd, order=0)
+
+
+def __getattr__(name):
+    # ``<module>.BF16`` = "the library's 16-bit dtype" for external readers (tests, tools): a call-time lookup, never a captured constant
+    if name == "BF16":
+        return _act_dtype()
+    raise AttributeError(name)

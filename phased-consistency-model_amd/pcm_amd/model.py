@@ -23,7 +23,6 @@ from .unet_spec import UNetConfig, lora_target_modules, param_spec
 
 from .precision import act_dtype as _act_dtype, precision  # noqa: E402
 
-BF16 = _act_dtype()      # the library's 16-bit dtype: bfloat16, or float16 after precision.set_precision("fp16") (which rebinds this name)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -167,6 +166,36 @@ FUSE_TEXT_KV_LORA = os.environ.get("PCM_TEXT_KV_LORA", "1") != "0"   # LoRA pass
 FUSE_TEMB = os.environ.get("PCM_TEMB_BATCH", "1") != "0"      # every resnet's time_emb_proj of a pass as one GEMM (UNet._temb_all); 0: one GEMM per resnet
 # debug hook: PCM_LORA_QKV=0 runs the self-attention q/k/v LoRA projections as three separate layers (A/B measurement)
 FUSE_LORA_QKV = os.environ.get("PCM_LORA_QKV", "1") != "0"
+
+
+# round 6 (include/pcm_hip.h abi 5).  PCM_GN_FUSE=1: GroupNorm statistics from the producing contraction's epilogue instead of their own pass
+# over the tensor; PCM_CAT_FUSE=0: torch.cat([h, skip], dim=1) of the up blocks as a copy kernel instead of the producers writing
+# straight into the concatenated buffer (A/B measurement hooks)
+FUSE_GN_STATS = os.environ.get("PCM_GN_FUSE", "0") == "1"      # opt-in: built and measured SLOWER on MI355X (fp64 atomic traffic + the column pass)
+FUSE_CONCAT = os.environ.get("PCM_CAT_FUSE", "1") != "0"
+
+
+def _cs_of(t):
+    """the per-channel statistics a producing contraction attached to its output (ops.ChStats, or a pair for a concatenation); None: none"""
+    return getattr(t, "_pcm_cs", None)
+
+
+def _view(t, *shape):
+    """t.view(*shape) that keeps the attached statistics (a view is a new tensor object)"""
+    v = t.view(*shape)
+    cs = _cs_of(t)
+    if cs is not None:
+        v._pcm_cs = cs
+    return v
+
+
+class Skip:
+    """one entry of the down path's skip stack.  ``cb``: the [B, HW, Ch + Cs] buffer the up path will read as torch.cat([h, skip], dim=1) whose
+    right-hand channels were already written by this skip's producer (pcm_gemm_epi.out2); None: concatenate with a copy"""
+    __slots__ = ("t", "H", "W", "cb")
+
+    def __init__(self, t, H, W, cb=None):
+        self.t, self.H, self.W, self.cb = t, H, W, cb
 
 
 class LoraTextKV:
@@ -344,7 +373,7 @@ class LoraState:
                     descs.append((ob_j, o_kb + jj * Cb * 2 * r + jj * r, -1, Cb, r, r, 2 * r, 0, self.scaling))
                 blocks.append((b, Cb, o_kb))
             kv_layout = (kvp, Kx, o_ka, blocks)
-        self.operands = torch.zeros(ototal, dtype=BF16, device=self.device)
+        self.operands = torch.zeros(ototal, dtype=_act_dtype(), device=self.device)
         self.text_kv = None
         if kv_layout is not None:
             kvp, Kx, o_ka, blocks = kv_layout
@@ -445,22 +474,33 @@ class Geo:
 
 
 def layer_fwd(W: UNetWeights, lora, path, x, M, geo=None, save=None, rowvec=None, rows_per_batch=0, residual=None,
-              act=capi.ACT_NONE, out_dtype=None):
+              act=capi.ACT_NONE, out_dtype=None, out=None, out2=None, stats=None):
     """y = base(x) + s*B(A(x)) [+ bias + rowvec + residual].  x: [M, K] (lin) or NHWC source (conv3).
-    ``save`` (dict) receives what the backward needs."""
+    ``save`` (dict) receives what the backward needs.  ``out``: write into this [M, N] view (row stride out.stride(0): the left-hand channels of
+    a concatenated buffer); ``out2``: also write a second copy there (a skip's slot in its concatenated buffer); ``stats`` = (ops.ChStatArena,
+    rows per sample): ask the epilogue for the per-channel statistics of the output -- attached to the returned tensor when the plan emits them."""
     L = W.layers[path]
-    out_dtype = BF16 if out_dtype is None else out_dtype
+    out_dtype = _act_dtype() if out_dtype is None else out_dtype
     lm = lora.modules.get(path) if lora is not None else None
     conv = geo.conv() if L.kind == "conv3" else None
     Ho, Wo = (geo.Ho, geo.Wo) if conv else (0, 0)
     segs = [Seg(x, L.w_fwd, conv=conv)]
     t = None
     if lm is not None:
-        t = torch.empty(M, lm.r, dtype=BF16, device=x.device)
+        t = torch.empty(M, lm.r, dtype=_act_dtype(), device=x.device)
         ops.gemm([Seg(x, lm.A_fwd, conv=conv)], M, lm.r, t, Ho=Ho, Wo=Wo)
         segs.append(Seg(t, lm.Bs_fwd))
-    y = torch.empty(M, L.N, dtype=out_dtype, device=x.device)
-    ops.gemm(segs, M, L.N, y, bias=L.bias, rowvec=rowvec, rows_per_batch=rows_per_batch, residual=residual, act=act, Ho=Ho, Wo=Wo)
+    y = out if out is not None else torch.empty(M, L.N, dtype=out_dtype, device=x.device)
+    cs = None
+    if stats is not None and stats[0] is not None and FUSE_GN_STATS and y.dtype == _act_dtype():
+        cs = stats[0].take(M // stats[1], L.N, stats[1])
+    if out2 is not None and (L.N == 64 or M <= 16):
+        raise ValueError("layer_fwd: out2 is not served by the rank-64 / batch-row kernels")
+    ops.gemm(segs, M, L.N, y, bias=L.bias, rowvec=rowvec, rows_per_batch=rows_per_batch, residual=residual, act=act, Ho=Ho, Wo=Wo,
+             ldo=y.stride(0), ldr=(residual.stride(-2) if residual is not None else None), out2=out2, ldo2=(out2.stride(0) if out2 is not None else None),
+             chstats=cs)
+    if cs is not None and cs.rows:
+        y._pcm_cs = cs
     if save is not None:
         save["x"], save["t"], save["M"], save["geo"] = x, t, M, geo
     return y
@@ -509,7 +549,7 @@ def layer_bwd(W: UNetWeights, lora, path, dy, saved, need_dx=True, residual=None
     u = None
     ldy = dy.stride(0) if (L.kind != "conv3" and dy.dim() == 2) else None     # (a column slice of a wider matrix: the fused K|V gradient)
     if lm is not None:
-        u = torch.empty(M, lm.r, dtype=BF16, device=dy.device)
+        u = torch.empty(M, lm.r, dtype=_act_dtype(), device=dy.device)
         ops.gemm([Seg(dy, lm.Bs_bwd, lda=ldy)], M, lm.r, u)              # u = dy (sB)   [M, r]
 
         def wg():
@@ -536,13 +576,13 @@ def layer_bwd(W: UNetWeights, lora, path, dy, saved, need_dx=True, residual=None
         segs = [Seg(dy, L.w_bwd, conv=dconv)]
         if lm is not None:
             segs.append(Seg(u, lm.A_bwd, conv=dconv))
-        dx = torch.empty(Min, L.C, dtype=BF16, device=dy.device)
+        dx = torch.empty(Min, L.C, dtype=_act_dtype(), device=dy.device)
         ops.gemm(segs, Min, L.C, dx, residual=residual, Ho=Hin, Wo=Win)
         return dx
     segs = [Seg(dy, L.w_bwd, lda=ldy)]
     if lm is not None:
         segs.append(Seg(u, lm.A_bwd))
-    dx = torch.empty(M, L.K, dtype=BF16, device=dy.device)
+    dx = torch.empty(M, L.K, dtype=_act_dtype(), device=dy.device)
     ops.gemm(segs, M, L.K, dx, residual=residual)
     return dx
 
@@ -567,6 +607,10 @@ class UNet:
         self._save_half = False
         self._temb = None       # this pass's time_emb_proj outputs of every resnet, one batched GEMM (_temb_all); None: per-resnet GEMMs
         self._temb_plans = {}   # (batch, rank) -> device descriptor tables of the two scatter launches
+        self._cs_arena = None   # per-pass arena of pre-zeroed per-channel statistics the contraction epilogues fill (ops.ChStatArena)
+        # channels whose per-channel statistics a pass may request: every resnet conv1 / conv2, transformer proj_out, down / up-sampler conv
+        self._cs_channels = sum(L.N for path, L in weights.layers.items()
+                                if path.endswith(("conv1", "conv2", "proj_out", "downsamplers.0.conv", "upsamplers.0.conv")))
         # the LoRA state's block-diagonal operand is laid out in ITS module order: batch only when that is the weights' order (same rows)
         self._temb_orders_agree = (lora is not None and getattr(lora, "temb", None) is not None and list(weights.temb_off) == list(lora.temb.paths)
                                    and all(weights.temb_off[t] == lora.temb.off[t][:2] for t in lora.temb.paths) and lora.temb.K == weights.temb_cat.shape[1])
@@ -574,7 +618,11 @@ class UNet:
     # ---- norm helpers ----
     def _gn(self, path, x, act, eps, save):
         g, b = self.W.norms[path]
-        y, stats = ops.groupnorm_fwd(x, g, b, self.cfg.norm_num_groups, eps, act, arena=self._arena)
+        cs = _cs_of(x) if FUSE_GN_STATS else None
+        cs, cs2 = cs if isinstance(cs, tuple) else (cs, None)
+        if cs is not None and (cs.rows != x.shape[1] or cs.B != x.shape[0] or cs.C + (cs2.C if cs2 is not None else 0) != x.shape[2]):
+            cs = cs2 = None          # (not this tensor's geometry: e.g. a duplicated half batch)
+        y, stats = ops.groupnorm_fwd(x, g, b, self.cfg.norm_num_groups, eps, act, arena=self._arena, chstats=cs, chstats2=cs2)
         if save is not None:
             save["gn_x"], save["gn_stats"] = x, stats
         return y
@@ -611,7 +659,7 @@ class UNet:
             plan = self._temb_plans[("kv", Mt)] = self._scatter_table(descs, dev)
         t32 = torch.empty(Mt, 2 * nb * r, dtype=torch.float32, device=dev)
         ops.gemm([Seg(text2d, f.A_cat)], Mt, 2 * nb * r, t32)
-        tb = torch.empty(2 * nb * Mt * 2 * r, dtype=BF16, device=dev)
+        tb = torch.empty(2 * nb * Mt * 2 * r, dtype=_act_dtype(), device=dev)
         dsc, st, nd, nblk = plan
         capi.lib().call("pcm_pack_segmented", ops.ptr(t32), ops.ptr(tb), ops.ptr(dsc), ops.ptr(st), nd, nblk, capi.Lib.stream())
         res, base = {}, nb * Mt * 2 * r
@@ -647,14 +695,14 @@ class UNet:
         if r:
             t32 = torch.empty(B, nt * r, dtype=torch.float32, device=dev)
             ops.gemm([Seg(emb_act, lora.temb.A_cat)], B, nt * r, t32)
-            tb = torch.empty(2 * B * nt * r, dtype=BF16, device=dev)
+            tb = torch.empty(2 * B * nt * r, dtype=_act_dtype(), device=dev)
             dsc, st, nd, nb = plan[1]
             capi.lib().call("pcm_pack_segmented", ops.ptr(t32), ops.ptr(tb), ops.ptr(dsc), ops.ptr(st), nd, nb, capi.Lib.stream())
             t_all, t_blocks = tb[:B * nt * r].view(B, nt * r), tb[B * nt * r:]
             segs.append(Seg(t_all, lora.temb.Bs_cat, k_algo=r))       # (block-diagonal: r of the nt * r columns are non-zero per output row)
         out32 = torch.empty(B, SN, dtype=torch.float32, device=dev)
         ops.gemm(segs, B, SN, out32, bias=W.temb_bias)
-        ob = torch.empty(B * SN, dtype=BF16, device=dev)
+        ob = torch.empty(B * SN, dtype=_act_dtype(), device=dev)
         dsc, st, nd, nb = plan[0]
         capi.lib().call("pcm_pack_segmented", ops.ptr(out32), ops.ptr(ob), ops.ptr(dsc), ops.ptr(st), nd, nb, capi.Lib.stream())
         res = {}
@@ -664,27 +712,29 @@ class UNet:
         return res
 
     # ---- resnet ----
-    def resnet_fwd(self, p, x, emb_act, B, H, Wd, tape):
+    def resnet_fwd(self, p, x, emb_act, B, H, Wd, tape, out=None, out2=None, want_stats=True):
+        """``out`` / ``out2`` / ``want_stats``: where the block's output goes (layer_fwd) and whether a GroupNorm reads it next"""
         W, lora = self.W, self.lora
         M = B * H * Wd
         Cout = W.layers[p + "conv1"].N
         sv = {} if tape is not None else None
         s1 = {} if sv is not None else None
         n1 = self._gn(p + "norm1", x, capi.ACT_SILU, self.cfg.norm_eps, s1)
-        st = {} if sv is not None else None
+        st_ = {} if sv is not None else None
         if self._temb is not None:
             # (one batched GEMM per pass: _temb_all; a pass that runs this resnet on the first rows only -- dup_halves -- takes the prefix)
             temb, t_r = self._temb[p + "time_emb_proj"]
             temb, t_r = temb[:B], (t_r[:B] if t_r is not None else None)
-            if st is not None:
-                st["x"], st["t"], st["M"], st["geo"] = emb_act, t_r, B, None
+            if st_ is not None:
+                st_["x"], st_["t"], st_["M"], st_["geo"] = emb_act, t_r, B, None
         else:
-            temb = layer_fwd(W, lora, p + "time_emb_proj", emb_act, B, save=st)             # [B, Cout]
+            temb = layer_fwd(W, lora, p + "time_emb_proj", emb_act, B, save=st_)            # [B, Cout]
         geo = Geo(H, Wd)
         c1 = {} if sv is not None else None
-        h = layer_fwd(W, lora, p + "conv1", n1, M, geo, save=c1, rowvec=temb, rows_per_batch=H * Wd)
+        st = (self._cs_arena, H * Wd) if (H * Wd) % 64 == 0 else None
+        h = layer_fwd(W, lora, p + "conv1", n1, M, geo, save=c1, rowvec=temb, rows_per_batch=H * Wd, stats=st)
         s2 = {} if sv is not None else None
-        n2 = self._gn(p + "norm2", h.view(B, H * Wd, Cout), capi.ACT_SILU, self.cfg.norm_eps, s2)
+        n2 = self._gn(p + "norm2", _view(h, B, H * Wd, Cout), capi.ACT_SILU, self.cfg.norm_eps, s2)
         sc = None
         if (p + "conv_shortcut") in W.layers:
             sc = {} if sv is not None else None
@@ -692,10 +742,10 @@ class UNet:
         else:
             res = x.view(M, -1)
         c2 = {} if sv is not None else None
-        out = layer_fwd(W, lora, p + "conv2", n2, M, geo, save=c2, residual=res)
+        out = layer_fwd(W, lora, p + "conv2", n2, M, geo, save=c2, residual=res, out=out, out2=out2, stats=st if want_stats else None)
         if tape is not None:
-            tape.append(("resnet", p, dict(s1=s1, st=st, c1=c1, s2=s2, sc=sc, c2=c2, B=B, H=H, W=Wd, Cout=Cout)))
-        return out.view(B, H * Wd, Cout)
+            tape.append(("resnet", p, dict(s1=s1, st=st_, c1=c1, s2=s2, sc=sc, c2=c2, B=B, H=H, W=Wd, Cout=Cout)))
+        return _view(out, B, H * Wd, Cout)
 
     def resnet_bwd(self, p, d_out, sv, need_dx=True):
         W, lora = self.W, self.lora
@@ -727,7 +777,7 @@ class UNet:
         sq, sk, svv, so = ({} if sv is not None else None for _ in range(4))
         Mk = B * Lk
         if lora is None and sv is None and ctx is xn and p in W.qkv:
-            qkv = torch.empty(M, 3 * C, dtype=BF16, device=xn.device)
+            qkv = torch.empty(M, 3 * C, dtype=_act_dtype(), device=xn.device)
             ops.gemm([Seg(xn, W.qkv[p])], M, 3 * C, qkv)
             qkv = qkv.view(B, L, 3 * C)
             o, lse = ops.attn_fwd(qkv[:, :, :C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:], Hh, d, prescaled=True)
@@ -736,9 +786,9 @@ class UNet:
         if fq is not None:
             # LoRA self-attention: the three rank-64 down-projections as one N=192 GEMM, then ONE QKV GEMM whose second
             # K-segment is the block-diagonal s*B operand; attention reads q/k/v in place (row stride 3C)
-            t3 = torch.empty(M, fq.r3, dtype=BF16, device=xn.device)
+            t3 = torch.empty(M, fq.r3, dtype=_act_dtype(), device=xn.device)
             ops.gemm([Seg(xn, fq.A_cat_fwd)], M, fq.r3, t3)
-            qkv = torch.empty(M, 3 * C, dtype=BF16, device=xn.device)
+            qkv = torch.empty(M, 3 * C, dtype=_act_dtype(), device=xn.device)
             ops.gemm([Seg(xn, W.qkv[p]), Seg(t3, fq.Bs_cat_fwd, k_algo=lora.rank)], M, 3 * C, qkv)
             q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
             o, lse = ops.attn_fwd(q.unflatten(0, (B, L)), k.unflatten(0, (B, L)), v.unflatten(0, (B, L)), Hh, d, prescaled=True)
@@ -761,7 +811,7 @@ class UNet:
             off, _ = W.kv_off[p]
             t_kv, t_k, t_v = self._text_t[p]
             ctx2 = ctx.view(Mk, -1)
-            kv = torch.empty(Mk, 2 * C, dtype=BF16, device=xn.device)
+            kv = torch.empty(Mk, 2 * C, dtype=_act_dtype(), device=xn.device)
             ops.gemm([Seg(ctx2, W.kv_cat[off:off + 2 * C]), Seg(t_kv, lora.text_kv.Bs_kv[p], k_algo=lora.rank)], Mk, 2 * C, kv)
             k, v = kv[:, :C], kv[:, C:]
             if sv is not None:
@@ -784,11 +834,11 @@ class UNet:
         if sv.get("fused"):
             fq, M, r = lora.qkv[p], B * L, lora.rank
             q, k, v, x, t3 = sv["q"], sv["k"], sv["v"], sv["x"], sv["t3"]
-            d3 = torch.empty(M, 3 * C, dtype=BF16, device=d_o.device)        # [dq | dk | dv], written in place by attention
+            d3 = torch.empty(M, 3 * C, dtype=_act_dtype(), device=d_o.device)        # [dq | dk | dv], written in place by attention
             dq, dk, dv = d3[:, :C], d3[:, C:2 * C], d3[:, 2 * C:]
             ops.attn_bwd(q.unflatten(0, (B, L)), k.unflatten(0, (B, L)), v.unflatten(0, (B, L)), sv["o"], d_o.view(B, L, C),
                          sv["lse"], Hh, d, out=(dq, dk, dv), prescaled=True)
-            u3 = torch.empty(M, fq.r3, dtype=BF16, device=d_o.device)
+            u3 = torch.empty(M, fq.r3, dtype=_act_dtype(), device=d_o.device)
             ops.gemm([Seg(d3, fq.Bs_cat_bwd, k_algo=C)], M, fq.r3, u3)                  # u_j = d_j (s B_j): block-diagonal operand
             def wg():
                 with ops.wgrad_batch():       # six weight gradients, one launch
@@ -797,12 +847,12 @@ class UNet:
                                        r_stride=1, ldb=3 * C, lds=fq.r3)
                         ops.lora_wgrad(x, u3[:, j * r:(j + 1) * r], lm.gA, 1.0, M, G=fq.K, g_stride=1, r_stride=fq.K, lds=fq.r3)
             _wgrad(wg, d3, t3, x, u3)
-            d_xn = torch.empty(M, fq.K, dtype=BF16, device=d_o.device)
+            d_xn = torch.empty(M, fq.K, dtype=_act_dtype(), device=d_o.device)
             ops.gemm([Seg(d3, W.qkv_bwd[p]), Seg(u3, fq.A_cat_bwd)], M, fq.K, d_xn)
             return d_xn
         if sv["k"].stride(0) != C:       # fused K|V forward (row stride 2C): the gradients are written into one [Mk, 2C] matrix with the same strides
-            dq = torch.empty(B * L, C, dtype=BF16, device=d_o.device)
-            dkv = torch.empty(B * Lk, 2 * C, dtype=BF16, device=d_o.device)
+            dq = torch.empty(B * L, C, dtype=_act_dtype(), device=d_o.device)
+            dkv = torch.empty(B * Lk, 2 * C, dtype=_act_dtype(), device=d_o.device)
             dk, dv = dkv[:, :C], dkv[:, C:]
             ops.attn_bwd(sv["q"].view(B, L, C), sv["k"].unflatten(0, (B, Lk)), sv["v"].unflatten(0, (B, Lk)), sv["o"], d_o.view(B, L, C),
                          sv["lse"], Hh, d, out=(dq, dk, dv), prescaled=True)
@@ -819,7 +869,7 @@ class UNet:
             layer_bwd(W, lora, p + "to_v", dv, sv["sv"], need_dx=False)
         return d_xn
 
-    def transformer_fwd(self, p, x, text, B, H, Wd, tape, depth=1, heads=None, dup_after_attn1=False):
+    def transformer_fwd(self, p, x, text, B, H, Wd, tape, depth=1, heads=None, dup_after_attn1=False, out=None, out2=None, want_stats=True):
         """Transformer2DModel: GroupNorm -> proj_in -> ``depth`` BasicTransformerBlocks -> proj_out + input residual.
         ``dup_after_attn1``: ``x`` holds B samples that stand for a batch [x; x] of 2B whose halves differ only in ``text`` (2B rows):
         everything up to and including the first self-attention is computed once and duplicated there; returns 2B samples."""
@@ -860,13 +910,13 @@ class UNet:
                 hg = None
                 segs, t_ff = [Seg(n3, Lff.w_geglu)], None
                 if lmff is not None:
-                    t_ff = torch.empty(M, lmff.r, dtype=BF16, device=n3.device)
+                    t_ff = torch.empty(M, lmff.r, dtype=_act_dtype(), device=n3.device)
                     ops.gemm([Seg(n3, lmff.A_fwd)], M, lmff.r, t_ff)
                     segs.append(Seg(t_ff, lmff.Bs_geglu))
                 if rec:
-                    pre = torch.empty(M // 2 if self._save_half else M, Lff.N, dtype=BF16, device=n3.device)
+                    pre = torch.empty(M // 2 if self._save_half else M, Lff.N, dtype=_act_dtype(), device=n3.device)
                     sf0["x"], sf0["t"], sf0["M"], sf0["geo"] = n3, t_ff, M, None
-                gg = torch.empty(M, Lff.N // 2, dtype=BF16, device=n3.device)
+                gg = torch.empty(M, Lff.N // 2, dtype=_act_dtype(), device=n3.device)
                 ops.gemm(segs, M, Lff.N, gg, bias=Lff.bias_geglu, act=capi.ACT_GEGLU, ldo=Lff.N // 2, pre_out=pre)
                 if pre is not None and self._save_half:
                     pre = HalfSaved(pre)
@@ -878,11 +928,12 @@ class UNet:
                 blocks.append(dict(sa1=sa1, sa2=sa2, sf0=sf0, sf2=sf2, h=h, mu1=mu1, rs1=rs1, h1=h1, mu2=mu2, rs2=rs2, h2=h2, mu3=mu3,
                                    rs3=rs3, hg=hg, pre=pre))
             h = h3
-        out = layer_fwd(W, lora, p + "proj_out", h, M, save=spo, residual=x.view(M, C))
+        st = (self._cs_arena, L) if (want_stats and L % 64 == 0) else None
+        out = layer_fwd(W, lora, p + "proj_out", h, M, save=spo, residual=x.view(M, C), out=out, out2=out2, stats=st)
         if rec:
             tape.append(("transformer", p, dict(sgn=sgn, spi=spi, spo=spo, B=B, H=H, W=Wd, C=C, heads=heads,
                                                 **{f"blk{k}": blocks[k] for k in range(depth)})))
-        return out.view(B, L, C)
+        return _view(out, B, L, C)
 
     def transformer_bwd(self, p, d_out, sv):
         W, lora = self.W, self.lora
@@ -925,11 +976,13 @@ class UNet:
         boc, n = cfg.block_out_channels, len(cfg.block_out_channels)
         tape = [] if save else None
         self._arena = ops.StatArena.for_pass(sample.device, W, B, cfg.norm_num_groups)
-        text = encoder_hidden_states if encoder_hidden_states.dtype == BF16 else ops.cast_bf16(encoder_hidden_states.contiguous())
+        # fp32 (what the CLIs pass) or already in THIS pass's 16-bit format; a 16-bit tensor of the other format (bfloat16 embeddings into a half
+        # teacher pass under format_scope) goes through fp32 -- the cast kernel reads 4-byte elements
+        text = encoder_hidden_states if encoder_hidden_states.dtype == _act_dtype() else ops.cast_bf16(encoder_hidden_states.float().contiguous())
         self._kv_all = None
         if lora is None and not save and W.kv_cat is not None and FUSE_TEXT_KV:
             Mt = text.shape[0] * text.shape[1]
-            self._kv_all = torch.empty(Mt, W.kv_cat.shape[0], dtype=BF16, device=text.device)
+            self._kv_all = torch.empty(Mt, W.kv_cat.shape[0], dtype=_act_dtype(), device=text.device)
             ops.gemm([Seg(text.view(Mt, -1), W.kv_cat)], Mt, W.kv_cat.shape[0], self._kv_all)
         t_emb = ops.timestep_embedding(timesteps, boc[0])
         e1 = layer_fwd(W, None, "time_embedding.linear_1", t_emb, B, act=capi.ACT_SILU)
@@ -941,7 +994,7 @@ class UNet:
             ids = added_cond["time_ids"].to(torch.int64).reshape(-1)
             tid = ops.timestep_embedding(ids, cfg.addition_time_embed_dim).view(B, -1)
             te = added_cond["text_embeds"]
-            te = te if te.dtype == BF16 else ops.cast_bf16(te.contiguous())
+            te = te if te.dtype == _act_dtype() else ops.cast_bf16(te.float().contiguous())
             add_in = torch.cat([te, tid], dim=1).contiguous()
             a1 = layer_fwd(W, None, "add_embedding.linear_1", add_in, B, act=capi.ACT_SILU)
             emb = layer_fwd(W, None, "add_embedding.linear_2", a1, B, residual=emb_t)
@@ -955,42 +1008,81 @@ class UNet:
         self._temb = None
         if FUSE_TEMB and W.temb_cat is not None and (lora is None or (lora.temb is not None and self._temb_orders_agree)):
             self._temb = self._temb_all(emb_act, B)
+        # ---- concat-free skips (round 6): the producer of a down-path skip tensor also writes it into the right-hand channels of the buffer the up
+        # path reads as torch.cat([h, skip], dim=1) (pcm_gemm_epi.out2), and the up path's producers write h into the left-hand channels
+        # (row stride = the buffer's): no concat pass.  cat_h[k] = channels of h when skip k is popped (from the config).
+        lpb = cfg.layers_per_block
+        n_skips = self._n_down_skips()
+        cat_h, ch, k_ = {}, boc[-1], n_skips - 1
+        rev = list(reversed(boc))
+        for i in range(n):
+            for j in range(lpb + 1):
+                cat_h[k_] = ch
+                ch = rev[i]
+                k_ -= 1
+        cat_on = FUSE_CONCAT and not features and capi.lib().dll.pcm_abi_version() >= 5
+        self._cs_arena = ops.ChStatArena(sample.device, B * self._cs_channels * 16) if (FUSE_GN_STATS and not ops.DETERMINISTIC) else None
+
+        def skip_slot(Cs, H_, W_):
+            """(concat buffer, out2 view) for the skip about to be produced at index len(skips), or (None, None)"""
+            k = len(skips)
+            if not cat_on or Cs == 64 or B * H_ * W_ <= 16:
+                return None, None
+            cb = torch.empty(B, H_ * W_, cat_h[k] + Cs, dtype=_act_dtype(), device=sample.device)
+            return cb, cb.view(B * H_ * W_, -1)[:, cat_h[k]:]
+
         if dup_halves:
             Bh = B // 2
             h = ops.conv_in_fwd(sample[:Bh].contiguous(), W.conv_in[0], W.conv_in[1], boc[0])
-            skips = [(torch.cat([h, h]), H, Wd)]
+            skips = [Skip(torch.cat([h, h]), H, Wd)]
         else:
             h = ops.conv_in_fwd(sample.contiguous(), W.conv_in[0], W.conv_in[1], boc[0])
-            skips = [(h, H, Wd)]
+            skips = [Skip(h, H, Wd)]
         feats = []
         for i in range(n):
-            for j in range(cfg.layers_per_block):
+            for j in range(lpb):
                 if dup_halves and i == 0 and j == 0:
                     h = self.resnet_fwd("down_blocks.0.resnets.0.", h, emb_act[:Bh].contiguous(), Bh, H, Wd, tape)
                     h = self.transformer_fwd("down_blocks.0.attentions.0.", h, text, Bh, H, Wd, tape, cfg.transformer_depth[0], cfg.heads_at(0),
                                              dup_after_attn1=True)
-                    skips.append((h, H, Wd))
+                    skips.append(Skip(h, H, Wd))
                     continue
-                h = self.resnet_fwd(f"down_blocks.{i}.resnets.{j}.", h, emb_act, B, H, Wd, tape)
+                cb, o2 = skip_slot(boc[i], H, Wd)
                 if cfg.down_attn[i]:
-                    h = self.transformer_fwd(f"down_blocks.{i}.attentions.{j}.", h, text, B, H, Wd, tape, cfg.transformer_depth[i], cfg.heads_at(i))
-                skips.append((h, H, Wd))
+                    h = self.resnet_fwd(f"down_blocks.{i}.resnets.{j}.", h, emb_act, B, H, Wd, tape)
+                    h = self.transformer_fwd(f"down_blocks.{i}.attentions.{j}.", h, text, B, H, Wd, tape, cfg.transformer_depth[i], cfg.heads_at(i), out2=o2)
+                else:
+                    h = self.resnet_fwd(f"down_blocks.{i}.resnets.{j}.", h, emb_act, B, H, Wd, tape, out2=o2)
+                skips.append(Skip(h, H, Wd, cb))
             if i < n - 1:
                 geo = Geo(H, Wd, stride=2)
                 sv = {} if save else None
-                h = layer_fwd(W, lora, f"down_blocks.{i}.downsamplers.0.conv", h, B * geo.Ho * geo.Wo, geo, save=sv)
+                cb, o2 = skip_slot(boc[i], geo.Ho, geo.Wo)
+                Mo = B * geo.Ho * geo.Wo
+                st = (self._cs_arena, geo.Ho * geo.Wo) if (geo.Ho * geo.Wo) % 64 == 0 else None
+                h = layer_fwd(W, lora, f"down_blocks.{i}.downsamplers.0.conv", h, Mo, geo, save=sv, out2=o2, stats=st)
                 H, Wd = geo.Ho, geo.Wo
-                h = h.view(B, H * Wd, -1)
+                h = _view(h, B, H * Wd, -1)
                 if save:
                     tape.append(("down", f"down_blocks.{i}.downsamplers.0.conv", dict(sv=sv, B=B, H=H, W=Wd)))
-                skips.append((h, H, Wd))
+                skips.append(Skip(h, H, Wd, cb))
             if features:
                 feats.append((h, H, Wd))
                 if save:
                     tape.append(("feat", None, dict(k=len(feats) - 1)))
+
+        def cat_target(Cout):
+            """where the tensor that will be concatenated with the NEXT skip goes: the left-hand channels of that skip's buffer (or None)"""
+            if not skips or skips[-1].cb is None:
+                return None
+            cb = skips[-1].cb
+            if cb.shape[-1] - skips[-1].t.shape[-1] != Cout:
+                return None
+            return cb.view(-1, cb.shape[-1])[:, :Cout]
+
         h = self.resnet_fwd("mid_block.resnets.0.", h, emb_act, B, H, Wd, tape)
         h = self.transformer_fwd("mid_block.attentions.0.", h, text, B, H, Wd, tape, cfg.mid_depth, cfg.heads_at(n - 1))
-        h = self.resnet_fwd("mid_block.resnets.1.", h, emb_act, B, H, Wd, tape)
+        h = self.resnet_fwd("mid_block.resnets.1.", h, emb_act, B, H, Wd, tape, out=None if features else cat_target(boc[-1]))
         if features:
             feats.append((h, H, Wd))
             if save:
@@ -1001,24 +1093,41 @@ class UNet:
                     return feats, tape
                 return feats
         for i in range(n):
-            for j in range(cfg.layers_per_block + 1):
-                s, _, _ = skips.pop()
+            Cout = rev[i]
+            for j in range(lpb + 1):
+                sk = skips.pop()
+                s = sk.t
                 Ch = h.shape[-1]
-                h = ops.concat_channels(h, s)
+                if sk.cb is not None and h.data_ptr() == sk.cb.data_ptr() and h.stride(-2) == sk.cb.shape[-1]:
+                    x = sk.cb                       # both halves are already in place
+                    ca, cb_ = _cs_of(h), _cs_of(s)
+                    if ca is not None and cb_ is not None and not isinstance(ca, tuple) and not isinstance(cb_, tuple):
+                        x._pcm_cs = (ca, cb_)       # statistics of the concatenation = the two producers', side by side
+                else:
+                    x = ops.concat_channels(h if h.is_contiguous() else h.contiguous(), s)
+                h = x
                 if save:
                     tape.append(("cat", None, dict(Ch=Ch, skip_index=len(skips))))
-                h = self.resnet_fwd(f"up_blocks.{i}.resnets.{j}.", h, emb_act, B, H, Wd, tape)
+                last = j == lpb
+                to_up = last and i < n - 1                                    # this layer's output feeds the upsampler conv, not a concat / norm
+                tgt = None if (to_up or features) else cat_target(Cout)
                 if cfg.up_attn(i):
                     lv = cfg.up_level(i)
-                    h = self.transformer_fwd(f"up_blocks.{i}.attentions.{j}.", h, text, B, H, Wd, tape, cfg.transformer_depth[lv], cfg.heads_at(lv))
+                    h = self.resnet_fwd(f"up_blocks.{i}.resnets.{j}.", h, emb_act, B, H, Wd, tape)
+                    h = self.transformer_fwd(f"up_blocks.{i}.attentions.{j}.", h, text, B, H, Wd, tape, cfg.transformer_depth[lv], cfg.heads_at(lv),
+                                             out=tgt, want_stats=not to_up)
+                else:
+                    h = self.resnet_fwd(f"up_blocks.{i}.resnets.{j}.", h, emb_act, B, H, Wd, tape, out=tgt, want_stats=not to_up)
             if i < n - 1:
                 geo = Geo(H, Wd, stride=1, src_mode=capi.SRC_UPSAMPLE2)   # nearest-2x fused into the conv loader
                 sv = {} if save else None
-                h = layer_fwd(W, lora, f"up_blocks.{i}.upsamplers.0.conv", h, B * geo.Ho * geo.Wo, geo, save=sv)
+                Mo = B * geo.Ho * geo.Wo
+                st = (self._cs_arena, geo.Ho * geo.Wo) if (geo.Ho * geo.Wo) % 64 == 0 else None
+                h = layer_fwd(W, lora, f"up_blocks.{i}.upsamplers.0.conv", h, Mo, geo, save=sv, out=None if features else cat_target(Cout), stats=st)
                 if save:
                     tape.append(("up", f"up_blocks.{i}.upsamplers.0.conv", dict(sv=sv, B=B, H=H, W=Wd)))
                 H, Wd = geo.Ho, geo.Wo
-                h = h.view(B, H * Wd, -1)
+                h = _view(h, B, H * Wd, -1)
             if features:
                 feats.append((h, H, Wd))
                 if save:
@@ -1158,3 +1267,10 @@ class UNet:
         cfg = self.cfg
         n = len(cfg.block_out_channels)
         return 1 + sum(cfg.layers_per_block + (1 if i < n - 1 else 0) for i in range(n))
+
+
+def __getattr__(name):
+    # ``<module>.BF16`` = "the library's 16-bit dtype" for external readers (tests, tools): a call-time lookup, never a captured constant
+    if name == "BF16":
+        return _act_dtype()
+    raise AttributeError(name)

@@ -10,7 +10,6 @@ from .capi import GemmEpi, GemmSeg, WgradArgs, ptr
 
 from .precision import act_dtype as _act_dtype  # noqa: E402
 
-BF16 = _act_dtype()      # the library's 16-bit dtype: bfloat16, or float16 after precision.set_precision("fp16") (which rebinds this name)
 GEMM_PROFILE = None  # set to a list by bench.py to time every pcm_gemm_bf16 launch
 
 # Reproducible reductions (include/pcm_hip.h, abi >= 4).  The fast forms of the cross-workgroup sums -- LoRA weight gradients (fp32 atomics),
@@ -60,8 +59,8 @@ class Seg:
 
     def fill(self, s: GemmSeg):
         # both operands in the loaded library's 16-bit format (a bfloat16 tensor handed to the half build would be read as garbage)
-        if self.a.dtype != BF16 or self.w.dtype != BF16:       # (not an assert: python -O must not turn a format mix-up into garbage reads)
-            raise TypeError(f"pcm_gemm_bf16 operands must be {BF16}: got {self.a.dtype}, {self.w.dtype}")
+        if self.a.dtype != _act_dtype() or self.w.dtype != _act_dtype():       # (not an assert: python -O must not turn a format mix-up into garbage reads)
+            raise TypeError(f"pcm_gemm_bf16 operands must be {_act_dtype()}: got {self.a.dtype}, {self.w.dtype}")
         s.a, s.w = ptr(self.a), ptr(self.w)
         s.K = self.w.shape[-1]
         if self.conv is None:
@@ -78,8 +77,36 @@ class Seg:
             s.src_mode = self.conv.get("src_mode", capi.SRC_DIRECT)
 
 
+class ChStats:
+    """Per-(sample, channel) {sum, sumsq} fp64 accumulators that a contraction's epilogue fills for the GroupNorm reading its output next
+    (include/pcm_hip.h abi 5, pcm_gemm_epi.chstats): ``buf`` [B, C, 2], pre-zeroed (a slice of a ChStatArena)."""
+    __slots__ = ("buf", "B", "C", "rows")
+
+    def __init__(self, buf, B, C, rows):
+        self.buf, self.B, self.C, self.rows = buf, B, C, rows
+
+
+class ChStatArena:
+    """ONE zero-fill per network pass for every ChStats of the pass (like StatArena for the group statistics)."""
+
+    def __init__(self, device, nbytes):
+        self.buf = torch.zeros(nbytes // 8, dtype=torch.float64, device=device)
+        self.used = 0
+
+    def take(self, B, C, rows):
+        n = B * C * 2
+        if self.used + n > self.buf.numel():
+            return None
+        s = self.buf[self.used:self.used + n].view(B, C, 2)
+        self.used += n
+        return ChStats(s, B, C, rows)
+
+
 def gemm(segs, M, N, out, bias=None, rowvec=None, rows_per_batch=0, residual=None, act=capi.ACT_NONE,
-         alpha=1.0, Ho=0, Wo=0, ldo=None, ldr=None, pre_out=None):
+         alpha=1.0, Ho=0, Wo=0, ldo=None, ldr=None, pre_out=None, out2=None, ldo2=None, chstats=None):
+    """``out2`` (+ ``ldo2``): second copy of the output rows (a skip tensor's slot in its future concat buffer).  ``chstats`` (ChStats): asks
+    the epilogue for the per-channel statistics of the stored output; returns True in ``chstats_done`` form: the call returns ``out`` and
+    sets ``chstats.rows`` to 0 when the plan taken does not emit them (the caller then runs the statistics pass)."""
     arr = (GemmSeg * len(segs))()
     for i, s in enumerate(segs):
         s.fill(arr[i])
@@ -95,6 +122,14 @@ def gemm(segs, M, N, out, bias=None, rowvec=None, rows_per_batch=0, residual=Non
     e.workspace, e.workspace_bytes = None, 0
     # fused GEGLU: optional second output = the interleaved pre-activation of the first pre_out.shape[0] rows (kept for the backward)
     e.pre_out, e.pre_rows, e.ldp = (ptr(pre_out), pre_out.shape[0], pre_out.shape[-1]) if pre_out is not None else (None, 0, 0)
+    e.out2, e.ldo2 = (ptr(out2), ldo2 if ldo2 is not None else out2.stride(-2)) if out2 is not None else (None, 0)
+    e.chstats, e.stats_rows = None, 0
+    if chstats is not None:
+        e.stats_rows = chstats.rows
+        if not DETERMINISTIC and capi.lib().dll.pcm_gemm_emits_chstats(arr, len(segs), C.byref(e)) == 1:
+            e.chstats = ptr(chstats.buf)
+        else:
+            e.stats_rows = chstats.rows = 0          # this plan does not emit them (or reproducible reductions are on: fp64 atomics)
     wsb = capi.lib().dll.pcm_gemm_workspace_bytes(arr, len(segs), C.byref(e))
     if wsb:   # split-K slabs (caller-owned scratch)
         ws = torch.empty(wsb // 4, dtype=torch.float32, device=out.device)
@@ -159,11 +194,19 @@ def _gn_workspace(x, B, HW, Cc, G):
     return torch.empty(n // 8, dtype=torch.float64, device=x.device), n
 
 
-def groupnorm_fwd(x, gamma, beta, G, eps, act, arena=None):
-    """x [B, HW, C] bf16 -> (y, stats[B,G,2] fp64)."""
+def groupnorm_fwd(x, gamma, beta, G, eps, act, arena=None, chstats=None, chstats2=None):
+    """x [B, HW, C] bf16 -> (y, stats[B,G,2] fp64).  ``chstats`` (ChStats with rows == HW): the producing contraction already accumulated the
+    per-channel sums -- no statistics pass (``chstats2``: the second producer of a channel concatenation)."""
     B, HW, Cc = x.shape
     y = torch.empty_like(x)
     L = capi.lib()
+    if chstats is not None:
+        stats = torch.empty(B, G, 2, dtype=torch.float64, device=x.device)
+        c1 = chstats.C
+        assert chstats.B == B and chstats.rows == HW and (c1 == Cc if chstats2 is None else (chstats2.C == Cc - c1 and chstats2.B == B and chstats2.rows == HW))
+        L.call("pcm_groupnorm_apply_chstats", ptr(x), ptr(chstats.buf), c1, ptr(chstats2.buf) if chstats2 is not None else None,
+               chstats2.C if chstats2 is not None else 0, c1, ptr(stats), ptr(gamma), ptr(beta), ptr(y), B, HW, Cc, G, eps, act, _stream())
+        return y, stats
     stats = arena.take(B, G) if arena is not None else None
     if stats is not None:
         L.call("pcm_groupnorm_stats_acc", ptr(x), ptr(stats), B, HW, Cc, G, _stream())
@@ -208,7 +251,7 @@ def layernorm_bwd(x, dy, gamma, mean, rstd, dres=None):
 
 def geglu_fwd(hg):
     M, C8 = hg.numel() // hg.shape[-1], hg.shape[-1]
-    out = torch.empty(*hg.shape[:-1], C8 // 2, dtype=BF16, device=hg.device)
+    out = torch.empty(*hg.shape[:-1], C8 // 2, dtype=_act_dtype(), device=hg.device)
     capi.lib().call("pcm_geglu_fwd", ptr(hg), ptr(out), M, C8 // 2, _stream())
     return out
 
@@ -224,14 +267,14 @@ def geglu_bwd_interleaved(pre, dout):
     """GEGLU gradient from the interleaved pre-activation a fused projection kept (gemm(..., act=ACT_GEGLU, pre_out=pre));
     the result is in the standard [values | gates] column order."""
     M, C2 = pre.shape[0], pre.shape[-1]
-    dhg = torch.empty(M, C2, dtype=BF16, device=pre.device)
+    dhg = torch.empty(M, C2, dtype=_act_dtype(), device=pre.device)
     capi.lib().call("pcm_geglu_bwd_interleaved", ptr(pre), C2, ptr(dout), ptr(dhg), M, C2 // 2, _stream())
     return dhg
 
 
 def upsample2x(x, B, H, W):
     Cc = x.shape[-1]
-    y = torch.empty(B, 4 * H * W, Cc, dtype=BF16, device=x.device)
+    y = torch.empty(B, 4 * H * W, Cc, dtype=_act_dtype(), device=x.device)
     capi.lib().call("pcm_upsample2x_nhwc", ptr(x), ptr(y), B, H, W, Cc, _stream())
     return y
 
@@ -239,14 +282,14 @@ def upsample2x(x, B, H, W):
 def pool2x_sum(dy, B, H, W):
     """dy [B, (2H)(2W), C] -> dx [B, HW, C]"""
     Cc = dy.shape[-1]
-    dx = torch.empty(B, H * W, Cc, dtype=BF16, device=dy.device)
+    dx = torch.empty(B, H * W, Cc, dtype=_act_dtype(), device=dy.device)
     capi.lib().call("pcm_pool2x_sum_nhwc", ptr(dy), ptr(dx), B, H, W, Cc, _stream())
     return dx
 
 
 def concat_channels(a, b):
     rows = a.numel() // a.shape[-1]
-    out = torch.empty(*a.shape[:-1], a.shape[-1] + b.shape[-1], dtype=BF16, device=a.device)
+    out = torch.empty(*a.shape[:-1], a.shape[-1] + b.shape[-1], dtype=_act_dtype(), device=a.device)
     capi.lib().call("pcm_concat_channels", ptr(a), a.shape[-1], ptr(b), b.shape[-1], ptr(out), rows, _stream())
     return out
 
@@ -255,8 +298,8 @@ def split_channels(x, Ca, a_out=None, accumulate_a=False):
     """x [..., Ca+Cb] -> (a, b); with accumulate_a, a_out += x[..., :Ca]."""
     Cb = x.shape[-1] - Ca
     rows = x.numel() // x.shape[-1]
-    a = a_out if a_out is not None else torch.empty(*x.shape[:-1], Ca, dtype=BF16, device=x.device)
-    b = torch.empty(*x.shape[:-1], Cb, dtype=BF16, device=x.device)
+    a = a_out if a_out is not None else torch.empty(*x.shape[:-1], Ca, dtype=_act_dtype(), device=x.device)
+    b = torch.empty(*x.shape[:-1], Cb, dtype=_act_dtype(), device=x.device)
     capi.lib().call("pcm_split_channels", ptr(x), ptr(a), Ca, ptr(b), Cb, rows, 1 if accumulate_a else 0, _stream())
     return a, b
 
@@ -294,7 +337,7 @@ def colsum(x):
 
 def conv_in_fwd(x_nchw, w, bias, C0):
     B, _, H, W = x_nchw.shape
-    y = torch.empty(B, H * W, C0, dtype=BF16, device=x_nchw.device)
+    y = torch.empty(B, H * W, C0, dtype=_act_dtype(), device=x_nchw.device)
     capi.lib().call("pcm_conv_in_fwd", ptr(x_nchw), ptr(w), ptr(bias), ptr(y), B, H, W, C0, _stream())
     return y
 
@@ -308,13 +351,13 @@ def conv_out_fwd(x, w, bias, B, H, W):
 
 def conv_out_bwd(dy_nchw, w, C0):
     B, _, H, W = dy_nchw.shape
-    dx = torch.empty(B, H * W, C0, dtype=BF16, device=dy_nchw.device)
+    dx = torch.empty(B, H * W, C0, dtype=_act_dtype(), device=dy_nchw.device)
     capi.lib().call("pcm_conv_out_bwd", ptr(dy_nchw), ptr(w), ptr(dx), B, H, W, C0, _stream())
     return dx
 
 
 def timestep_embedding(t, dim):
-    out = torch.empty(t.shape[0], dim, dtype=BF16, device=t.device)
+    out = torch.empty(t.shape[0], dim, dtype=_act_dtype(), device=t.device)
     capi.lib().call("pcm_timestep_embedding", ptr(t), ptr(out), t.shape[0], dim, _stream())
     return out
 
@@ -360,7 +403,7 @@ def gelu_tanh_bwd(x, dy):
 def patchify2x2(img, order):
     """fp32 [B,C,H,W] -> bf16 [B*(H/2)*(W/2), 4C]; order 0 = (c,p,q) columns, 1 = (p,q,c)."""
     B, Cc, H, W = img.shape
-    out = torch.empty(B * (H // 2) * (W // 2), 4 * Cc, dtype=BF16, device=img.device)
+    out = torch.empty(B * (H // 2) * (W // 2), 4 * Cc, dtype=_act_dtype(), device=img.device)
     capi.lib().call("pcm_patchify2x2", ptr(img), ptr(out), B, Cc, H, W, order, _stream())
     return out
 
@@ -383,13 +426,17 @@ def mod_grad(x, dy, B, mean=None, rstd=None, want_b=True):
 
 
 def timestep_embedding_f32(t, dim):
-    out = torch.empty(t.shape[0], dim, dtype=BF16, device=t.device)
+    out = torch.empty(t.shape[0], dim, dtype=_act_dtype(), device=t.device)
     capi.lib().call("pcm_timestep_embedding_f32", ptr(t), ptr(out), t.shape[0], dim, _stream())
     return out
 
 
 def cast_bf16(x):
-    y = torch.empty(x.shape, dtype=BF16, device=x.device)
+    """fp32 -> the library's 16-bit format.  The kernel reads 4-byte elements: anything but fp32 is a TypeError, not a garbage read
+    (a 16-bit tensor of the OTHER format, e.g. bfloat16 embeddings handed into a half teacher pass, must go through .float() first)."""
+    if x.dtype != torch.float32 or not x.is_contiguous():
+        raise TypeError(f"cast_bf16 takes a contiguous float32 tensor, got {x.dtype}{'' if x.is_contiguous() else ' (non-contiguous)'}")
+    y = torch.empty(x.shape, dtype=_act_dtype(), device=x.device)
     capi.lib().call("pcm_cast_f32_bf16", ptr(x), ptr(y), x.numel(), _stream())
     return y
 
@@ -402,8 +449,8 @@ def cast_f32(x):
 
 def pack_linear(w, want_nk=True, want_kn=True, scale=1.0, out_nk=None, out_kn=None):
     N, K = w.shape[0], w.numel() // w.shape[0]
-    nk = (out_nk if out_nk is not None else torch.empty(N, K, dtype=BF16, device=w.device)) if want_nk else None
-    kn = (out_kn if out_kn is not None else torch.empty(K, N, dtype=BF16, device=w.device)) if want_kn else None
+    nk = (out_nk if out_nk is not None else torch.empty(N, K, dtype=_act_dtype(), device=w.device)) if want_nk else None
+    kn = (out_kn if out_kn is not None else torch.empty(K, N, dtype=_act_dtype(), device=w.device)) if want_kn else None
     capi.lib().call("pcm_pack_linear", ptr(w), ptr(nk), ptr(kn), N, K, scale, _stream())
     return nk, kn
 
@@ -411,8 +458,8 @@ def pack_linear(w, want_nk=True, want_kn=True, scale=1.0, out_nk=None, out_kn=No
 def pack_conv3x3(w, want_fwd=True, want_dgrad=True, scale=1.0, out_fwd=None, out_dgrad=None, khwc=False):
     """w: [N, C, 3, 3] (khwc=False) or [N, 3, 3, C] (khwc=True)."""
     N, Cc = w.shape[0], (w.shape[3] if khwc else w.shape[1])
-    f = (out_fwd if out_fwd is not None else torch.empty(N, 9 * Cc, dtype=BF16, device=w.device)) if want_fwd else None
-    d = (out_dgrad if out_dgrad is not None else torch.empty(Cc, 9 * N, dtype=BF16, device=w.device)) if want_dgrad else None
+    f = (out_fwd if out_fwd is not None else torch.empty(N, 9 * Cc, dtype=_act_dtype(), device=w.device)) if want_fwd else None
+    d = (out_dgrad if out_dgrad is not None else torch.empty(Cc, 9 * N, dtype=_act_dtype(), device=w.device)) if want_dgrad else None
     capi.lib().call("pcm_pack_conv3x3", ptr(w), ptr(f), ptr(d), N, Cc, scale, 1 if khwc else 0, _stream())
     return f, d
 
@@ -588,7 +635,7 @@ def attn_fwd(q, k, v, H, d, scale=None, prescaled=False):
     ``prescaled``: q already carries attn_q_scale(d) (folded into the to_q projection): csrc/attention_ps.hip."""
     B, Lq, Lk = q.shape[0], q.shape[1], k.shape[1]
     scale = scale if scale is not None else d ** -0.5
-    o = torch.empty(B, Lq, H * d, dtype=BF16, device=q.device)
+    o = torch.empty(B, Lq, H * d, dtype=_act_dtype(), device=q.device)
     lse = torch.empty(B, H, Lq, dtype=torch.float32, device=q.device)
     assert q.stride(2) == 1 and k.stride(2) == 1 and v.stride(2) == 1 and k.stride(1) == v.stride(1)
     if prescaled:
@@ -682,3 +729,10 @@ def sampler_ddim_step(eps_c, eps_u, x, alpha_t, alpha_prev, guidance):
     capi.lib().call("pcm_sampler_ddim_step", ptr(eps_c), ptr(eps_u), ptr(x), float(alpha_t), float(alpha_prev), float(guidance), ptr(out),
                     x.numel(), _stream())
     return out
+
+
+def __getattr__(name):
+    # ``<module>.BF16`` = "the library's 16-bit dtype" for external readers (tests, tools): a call-time lookup, never a captured constant
+    if name == "BF16":
+        return _act_dtype()
+    raise AttributeError(name)

@@ -3,12 +3,11 @@
 The reference selects it with ``--mixed_precision`` (train_pcm_lora_sd15.py:1034 hands it to accelerate; every recipe in
 train_pcm_lora_sd15.sh passes fp16, BASELINE.json's configs bf16).  Here the format is a BUILD variant of the kernel library
 (csrc/pcm_common.h: one block of conversions + the two MFMA builtins), so ``set_precision("fp16")`` (1) loads lib/libpcm_hip_f16.so
-instead of lib/libpcm_hip.so and (2) rebinds the ``BF16`` dtype constant of the host modules (it means "the library's 16-bit dtype")
-to torch.float16.  Call it BEFORE building UNetWeights / LoraState / Distiller objects: packed operand buffers are allocated in the
+instead of lib/libpcm_hip.so and (2) makes ``act_dtype()`` -- what every host module asks AT THE POINT OF USE for "the library's 16-bit
+dtype" (no module holds it as a constant any more: round 6; ``ops.BF16`` etc. are module ``__getattr__`` lookups of the same function) --
+return torch.float16.  Call it BEFORE building UNetWeights / LoraState / Distiller objects: packed operand buffers are allocated in the
 current format.  fp16 needs loss scaling in the backward; trainer.Distiller does that with device-side GradScaler state.
 """
-import sys
-
 import torch
 
 from . import capi
@@ -49,11 +48,7 @@ def set_precision(name, lib=None, tools=False):
 def _activate(name, lib):
     global _NAME
     capi.set_lib(lib)
-    _NAME = name
-    # every host module that holds the "library's 16-bit dtype" constant (BF16) -- found by attribute, not by a hard-coded list
-    for mod_name, m in list(sys.modules.items()):
-        if mod_name.startswith("pcm_amd.") and m is not None and isinstance(getattr(m, "BF16", None), torch.dtype):
-            m.BF16 = _DTYPES[name]
+    _NAME = name      # act_dtype() is looked up at every use site: nothing to rebind, a module imported later sees the same answer
 
 
 def register_lib(name, lib):
@@ -72,7 +67,7 @@ class format_scope:
     to the other, fp32 tensors cross freely, 16-bit tensors must stay on their side -- ops.Seg checks the dtype).  This is how the
     reference's teacher pass is reproduced under --mixed_precision=bf16: its ``torch.autocast("cuda")`` (train_pcm_lora_sd15.py:1218)
     names no dtype and therefore runs the frozen teacher in IEEE half while the student runs in bfloat16 (trainer.Distiller
-    ``teacher_weights``).  Switching is a handful of attribute writes; under hipGraph capture it happens at capture time only."""
+    ``teacher_weights``).  Switching is two attribute writes (the library handle and the format name); under hipGraph capture it happens at capture time only."""
 
     def __init__(self, name):
         if name not in _DTYPES:

@@ -359,11 +359,13 @@ def case_reproducible_reductions(dev, big=False):
             (k, float((a - b).abs().max()), float(b.abs().max()))
 
 
-def case_attention(dev, B, H, Lq, Lk, d, spike=False, spike_at=None, prescaled=False, spike_overflow=False):
+def case_attention(dev, B, H, Lq, Lk, d, spike=False, spike_at=None, prescaled=False, spike_overflow=False, spike_gain=40):
     """``prescaled``: the pre-scaled-query kernels (csrc/attention_ps.hip): q carries d^-1/2 * log2(e) (rounded ONCE to the 16-bit
     format, as the folded to_q weights deliver it), the reference is the softmax of that q' in base 2, and dq is the gradient with
     respect to q'.  ``spike_overflow``: a late key row so far above the first tile's maximum that exp2 against the first tile's
-    reference overflows -> the forward's one-time check must catch it and repeat the workgroup with maximum tracking."""
+    reference overflows -> the forward's one-time check must catch it and repeat the workgroup with maximum tracking.  ``spike_gain``: 40 puts
+    that key ~250 above the first tile's maximum in the log2 domain (fp32 overflow); 4 .. 16 put it ~25 .. 100 above: finite in fp32 but beyond
+    the IEEE-half range of the packed P (65504 = 2^16), which the half build must catch as well."""
     q = rnd(B, Lq, H * d, seed=1, dev=dev)
     k = rnd(B, Lk, H * d, seed=2, dev=dev)
     v = rnd(B, Lk, H * d, seed=3, dev=dev)
@@ -373,7 +375,7 @@ def case_attention(dev, B, H, Lq, Lk, d, spike=False, spike_at=None, prescaled=F
         k[:, pos, :] = k[:, pos, :] * 5
     if spike_overflow:
         assert Lk > 70
-        k[:, Lk - 5, :] = q[:, 3, :] * 40       # query row 3 of every head: score ~ 40 |q|^2 / sqrt(d) ~ 250 in the log2 domain
+        k[:, Lk - 5, :] = q[:, 3, :] * spike_gain       # query row 3 of every head: score ~ 40 |q|^2 / sqrt(d) ~ 250 in the log2 domain at gain 40
     dO = rnd(B, Lq, H * d, seed=4, dev=dev)
     if prescaled:
         q = (q.float() * ops.attn_q_scale(d)).to(q.dtype)
@@ -683,6 +685,83 @@ def case_gemm_big(dev, which):
     err = (out.float() - ref).abs()
     tol = 2e-2 + 1e-2 * ref.abs()
     return float((err - tol).max()), float(err.max())
+
+
+def case_gemm_epilogue_fusions(dev, which):
+    """abi 5 (include/pcm_hip.h pcm_gemm_epi.out2 / chstats): the contraction's epilogue (a) writes a second copy of the output rows into a
+    strided slot (a skip tensor's place in its concat buffer) and (b) accumulates per-(sample, channel) sum / sum-of-squares of the STORED
+    values; pcm_groupnorm_apply_chstats then normalises from them without a statistics pass -- equal to the statistics pass + apply on the same
+    tensor.  ``which``: the phased tile's own epilogue (plain / residual / rowvec-conv flavours, small feature maps that flush per pass, ragged
+    N), the split-K finalize, and a plan that does not emit (the caller falls back)."""
+    import torch.nn.functional as F
+    from pcm_amd import capi, ops
+
+    def rnd(*shape, seed=0, scale=1.0):
+        g = torch.Generator().manual_seed(seed)
+        return (torch.randn(*shape, generator=g) * scale).to(ops.BF16).to(dev)
+
+    dll = capi.lib().dll
+    dll.pcm_debug_gemm_big_mode(2 if which != "small_tile" else 1)
+    try:
+        if which in ("plain", "res", "small_maps", "ragged_n", "splitk", "small_tile"):
+            B, HW, N, K = {"plain": (2, 256, 320, 128), "res": (3, 256, 320, 128), "small_maps": (10, 64, 320, 128), "ragged_n": (2, 256, 448, 64),
+                           "splitk": (1, 256, 320, 2048), "small_tile": (2, 64, 128, 64)}[which]
+            M = B * HW
+            x, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.1)
+            bias = torch.randn(N, generator=torch.Generator().manual_seed(5)).to(dev)
+            res = rnd(M, N, seed=6) if which in ("res", "small_maps", "splitk") else None
+            segs, kw = [ops.Seg(x, w)], dict(bias=bias, residual=res)
+        else:                      # resnet conv1 flavour: 3x3 conv + bias + per-sample row vector (time embedding)
+            B, Hs, Ci, N = 3, 16, 64, 320
+            HW, M = Hs * Hs, B * Hs * Hs
+            xi, w = rnd(B, Hs, Hs, Ci, seed=7), rnd(N, 9 * Ci, seed=8, scale=0.05)
+            temb = rnd(B, N, seed=9)
+            bias = torch.randn(N, generator=torch.Generator().manual_seed(5)).to(dev)
+            segs, kw = [ops.Seg(xi, w, conv=dict(Hs=Hs, Ws=Hs))], dict(bias=bias, rowvec=temb, rows_per_batch=HW, Ho=Hs, Wo=Hs)
+        ref_out = torch.empty(M, N, dtype=ops.BF16, device=dev)
+        ops.gemm(segs, M, N, ref_out, **kw)                                   # the same call without the fusions
+        arena = ops.ChStatArena(dev, B * N * 2 * 8)
+        cs = arena.take(B, N, HW)
+        cat = torch.full((M, N + 192), 3.0, dtype=ops.BF16, device=dev)       # the output's slot: columns [128, 128 + N) of a wider buffer
+        out = torch.empty(M, N, dtype=ops.BF16, device=dev)
+        ops.gemm(segs, M, N, out, out2=cat[:, 128:128 + N], ldo2=N + 192, chstats=cs, **kw)
+        plan = dll.pcm_debug_last_gemm_plan()
+        assert torch.equal(out.cpu(), ref_out.cpu()), "the fusions must not change the output"
+        assert torch.equal(cat[:, 128:128 + N].cpu(), out.cpu()) and bool((cat[:, :128].float() == 3.0).all()) and bool((cat[:, 128 + N:].float() == 3.0).all()), "out2 slot"
+        if which == "small_tile":
+            assert cs.rows == 0 and plan < 1000, ("a 4-wave tile does not emit statistics: the caller falls back", plan)
+            return
+        assert cs.rows == HW, ("statistics not emitted", which, plan)
+        assert (plan % 1000 > 1) == (which == "splitk"), plan
+        o = out.float().cpu().double().view(B, HW, N)
+        want = torch.stack([o.sum(1), (o * o).sum(1)], -1)                     # [B, N, 2]
+        got = cs.buf.cpu()
+        assert float((got - want).abs().max()) <= 2e-5 * float(want.abs().max()), (which, float((got - want).abs().max()), float(want.abs().max()))
+        # GroupNorm from the per-channel sums == statistics pass + apply (same kernel body downstream of the group sums)
+        G = 32
+        gamma, beta = torch.randn(N, generator=torch.Generator().manual_seed(3)).to(dev), torch.randn(N, generator=torch.Generator().manual_seed(4)).to(dev)
+        xo = out.view(B, HW, N)
+        y_ref, st_ref = ops.groupnorm_fwd(xo, gamma, beta, G, 1e-5, capi.ACT_SILU)
+        y, st = ops.groupnorm_fwd(xo, gamma, beta, G, 1e-5, capi.ACT_SILU, chstats=cs)
+        assert float((st.cpu() - st_ref.cpu()).abs().max()) <= 2e-5 * float(st_ref.abs().max())
+        close(y, y_ref.float().cpu(), 1e-2, 1e-2, "GroupNorm from epilogue statistics")
+        # ... and as the right-hand part of a channel concatenation [other | out]
+        Ca = 128
+        other = rnd(B, HW, Ca, seed=21)
+        oa = other.float().cpu().double()
+        csa = ops.ChStats(torch.stack([oa.sum(1), (oa * oa).sum(1)], -1).to(dev).contiguous(), B, Ca, HW)
+        xc = torch.cat([other, xo], -1).contiguous()
+        g2, b2 = torch.randn(Ca + N, generator=torch.Generator().manual_seed(13)).to(dev), torch.randn(Ca + N, generator=torch.Generator().manual_seed(14)).to(dev)
+        if (Ca + N) % G == 0:
+            yc_ref, stc_ref = ops.groupnorm_fwd(xc, g2, b2, G, 1e-5, capi.ACT_SILU)
+            yc, stc = ops.groupnorm_fwd(xc, g2, b2, G, 1e-5, capi.ACT_SILU, chstats=csa, chstats2=cs)
+            assert float((stc.cpu() - stc_ref.cpu()).abs().max()) <= 2e-5 * float(stc_ref.abs().max())
+            close(yc, yc_ref.float().cpu(), 1e-2, 1e-2, "GroupNorm of a concatenation from two producers' statistics")
+    finally:
+        dll.pcm_debug_gemm_big_mode(1)
+
+
+GEMM_EPI_FUSION_CASES = ["plain", "res", "small_maps", "ragged_n", "splitk", "conv_rowvec", "small_tile"]
 
 
 GEMM_BIG_CASES = ["plain_lora", "ragged", "two_tiles_k", "splitk", "conv", "conv_s2", "conv_up", "conv_zi", "conv_conv", "conv_splitk", "persist", "persist_splitk", "conv_persist", "conv_small_map"]

@@ -106,7 +106,7 @@ def test_capi_exports_every_declared_symbol():
             assert hasattr(L.dll, name), f"{name} declared in include/pcm_hip.h but not exported by the {variant} build"
         # ... and the pcm_debug_* hooks (declared nowhere in the header) only in the TOOLS builds
         assert hasattr(L.dll, "pcm_debug_gemm_big_mode") == variant.startswith("tools"), variant
-    queries = {n for n in declared if n.endswith("_workspace_bytes")} | {"pcm_last_error", "pcm_abi_version", "pcm_act_dtype", "pcm_gemm_plan_code"}
+    queries = {n for n in declared if n.endswith("_workspace_bytes")} | {"pcm_last_error", "pcm_abi_version", "pcm_act_dtype", "pcm_gemm_plan_code", "pcm_gemm_emits_chstats"}
     assert declared - queries == set(capi._PROTOS), (declared - queries) ^ set(capi._PROTOS)
 
 

@@ -44,6 +44,15 @@ def test_attention_half_build(Lq, Lk, d):
     K.case_attention("cpu", 1, 2, Lq, Lk, d)
 
 
+@pytest.mark.parametrize("Lq,Lk,d", [(40, 128, 32), (40, 128, 64), (40, 128, 160), (40, 77, 160), (40, 200, 40), (40, 150, 80)])
+@pytest.mark.parametrize("gain", [4, 8, 16, 40])
+def test_attention_half_build_late_key_beyond_the_half_range(Lq, Lk, d, gain):
+    """round-5 advisor finding: a late key ~25 .. 100 (log2 domain) above the first tile's row maximum makes p = exp2(s' - m_1) exceed 65504;
+    packed to IEEE half it is inf in the PV MFMA.  Head dims whose row sum is the fp32 VALU sum (32 / 64 / 160: no ones column in V) kept a
+    finite sum, so the one-time check never fired and the rows came out NaN.  The check now reads the output accumulators too."""
+    K.case_attention("cpu", 1, 1, Lq, Lk, d, spike=True, prescaled=True, spike_overflow=True, spike_gain=gain)
+
+
 def test_gemm_tiles_half_build():
     for excess, err in (K.case_gemm_big("cpu", "plain_lora"), K.case_gemm_big("cpu", "conv"), K.case_gemm_4w("cpu", "plain_lora")):
         assert excess <= 0, err

@@ -296,3 +296,9 @@ def test_abi_rejects_bad_arguments_with_a_message():
         L.call("pcm_lora_wgrad_bf16", ctypes.byref(a), S())
     with pytest.raises(capi.PcmError, match="not exported"):
         L.call("pcm_no_such_entry")
+
+
+@pytest.mark.parametrize("which", K.GEMM_EPI_FUSION_CASES)
+def test_gemm_epilogue_fusions_second_output_and_groupnorm_statistics(which):
+    """abi 5: a skip tensor's second home (out2) and the next GroupNorm's statistics (chstats) from the producing contraction's epilogue"""
+    K.case_gemm_epilogue_fusions("cpu", which)

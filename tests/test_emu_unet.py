@@ -302,22 +302,32 @@ def test_deterministic_step_equals_the_atomic_step_to_rounding():
     inp = OS.draw_inputs(2, ocfg, seed=7, latent_hw=8, ctx_len=7, ctx_dim=64)
     cfg = StepConfig(multiphase=2, loss_type="huber", w_min=4.0, w_max=5.0)
 
-    def one(det):
+    from pcm_amd import model as M_
+
+    def one(det, gn_fuse=True):
         lora = LoraState(pc, 64, 8.0, "cpu", seed=1, b_std=0.05)
         D = Distiller(W, lora, cfg)
         ops.set_deterministic(det)
+        keep, M_.FUSE_GN_STATS = M_.FUSE_GN_STATS, gn_fuse
         try:
             out = D.step(inp["latents"], inp["prompt_embeds"], inp["uncond_prompt_embeds"], inp["noise"], inp["index"], inp["w"])
         finally:
             ops.set_deterministic(False)
+            M_.FUSE_GN_STATS = keep
         return float(out["loss"]), lora.grads.clone(), float(lora.gradsq), lora.params.clone()
 
-    l0, g0, q0, p0 = one(False)
+    # the atomic forms of the SAME reductions (GroupNorm statistics by their own pass: PCM_GN_FUSE=0) against the reproducible forms
+    l0, g0, q0, p0 = one(False, gn_fuse=False)
     l1, g1, q1, p1 = one(True)
     l2, g2, q2, p2 = one(True)
     assert l1 == l2 and q1 == q2 and torch.equal(g1, g2) and torch.equal(p1, p2)
     assert abs(l1 - l0) <= 1e-6 * abs(l0) and abs(q1 - q0) <= 1e-4 * q0
     assert float((g1 - g0).norm() / g0.norm()) < 1e-4
+    # the default path takes the GroupNorm statistics from the producing contraction's epilogue (round 6): other fp32 partial sums (closer to
+    # the exact sums than the statistics pass), so isolated 16-bit roundings of the normalised activations flip -- the step agrees at the
+    # storage format's own noise level, not to summation rounding
+    l3, g3, q3, p3 = one(False)
+    assert abs(l3 - l0) <= 5e-3 * abs(l0) and float((g3 - g0).norm() / g0.norm()) < 5e-2, (l3, l0, float((g3 - g0).norm() / g0.norm()))
 
 
 def test_fp16_teacher_next_to_a_bf16_student_is_exactly_the_two_pure_builds():

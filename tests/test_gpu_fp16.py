@@ -58,6 +58,15 @@ def test_attention_half_build(B, H, Lq, Lk, d):
     K.case_attention("cuda", B, H, Lq, Lk, d)
 
 
+@pytest.mark.parametrize("B,H,Lq,Lk,d", [(2, 5, 1024, 77, 64), (2, 8, 256, 77, 160), (2, 8, 256, 256, 160), (1, 4, 200, 400, 32), (1, 8, 512, 512, 40)])
+@pytest.mark.parametrize("gain", [4, 8, 16])
+def test_attention_half_build_late_key_beyond_the_half_range(B, H, Lq, Lk, d, gain):
+    """a late key ~25 .. 100 (log2 domain) above the first tile's row maximum: p exceeds 65504, inf once packed to IEEE half -- the one-time
+    check must see it for the head dims whose row sum is the fp32 VALU sum too (SDXL d = 64 at Lk = 77, SD1.5 d = 160): round-5 advisor finding,
+    emulator twin in tests/test_emu_fp16.py"""
+    K.case_attention("cuda", B, H, Lq, Lk, d, spike=True, prescaled=True, spike_overflow=True, spike_gain=gain)
+
+
 @pytest.mark.parametrize("family,which", [("big", w) for w in K.GEMM_BIG_CASES[:6]] + [("4w", w) for w in K.GEMM_4W_CASES[:3]])
 def test_gemm_tiles_half_build(family, which):
     excess, err = (K.case_gemm_big if family == "big" else K.case_gemm_4w)("cuda", which)

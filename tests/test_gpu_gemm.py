@@ -177,3 +177,10 @@ def test_batch_row_projection_kernel(M, N, Ks, act, bias, f32):
     import kernel_cases as KC
     for _ in range(2):
         assert KC.case_gemm_smallm("cuda", M, N, Ks, act, bias, f32) <= 0
+
+
+@pytest.mark.parametrize("which", __import__("kernel_cases").GEMM_EPI_FUSION_CASES)
+def test_gemm_epilogue_fusions_second_output_and_groupnorm_statistics(which):
+    """abi 5: a skip tensor's second home (out2) and the next GroupNorm's statistics (chstats) from the producing contraction's epilogue"""
+    import kernel_cases as KC
+    KC.case_gemm_epilogue_fusions("cuda", which)

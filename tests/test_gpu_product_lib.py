@@ -29,7 +29,7 @@ def test_product_library_exports_no_debug_hooks():
     syms = [l.split()[-1] for l in out.splitlines() if " T " in l]
     assert syms and not [s for s in syms if s.startswith("pcm_debug")], [s for s in syms if s.startswith("pcm_debug")]
     assert not hasattr(capi.lib().dll, "pcm_debug_gemm_big_mode")
-    assert capi.lib().dll.pcm_abi_version() >= 4
+    assert capi.lib().dll.pcm_abi_version() >= 5
 
 
 def test_hook_free_kernel_cases_on_the_product_library():

@@ -97,10 +97,13 @@ def test_deterministic_step_is_bitwise_reproducible(setup):
     oc, sd, W = setup
     _, cfg = S.step_cfgs(2)
 
-    def run(det, steps=3):
+    from pcm_amd import model as M_
+
+    def run(det, steps=3, gn_fuse=True):
         lora = LoraState(UNetConfig.sd15(), 64, 8.0, "cuda", seed=1, b_std=0.02)
         D = Distiller(W, lora, cfg)
         ops.set_deterministic(det)
+        keep, M_.FUSE_GN_STATS = M_.FUSE_GN_STATS, gn_fuse
         losses, norms = [], []
         try:
             for step in range(1, steps + 1):
@@ -110,13 +113,19 @@ def test_deterministic_step_is_bitwise_reproducible(setup):
             torch.cuda.synchronize()
         finally:
             ops.set_deterministic(False)
+            M_.FUSE_GN_STATS = keep
         return losses, norms, lora.grads.clone(), lora.params.clone()
 
     la, na, ga, pa = run(True)
     lb, nb, gb, pb = run(True)
     assert la == lb and na == nb, (la, lb, na, nb)
     assert torch.equal(ga, gb) and torch.equal(pa, pb)
-    lf, nf, gf, pf = run(False, steps=1)
+    # the atomic forms of the SAME reductions (GroupNorm statistics by their own pass, as the reproducible mode takes them): summation rounding.
+    # The default path's statistics come from the producing contraction's epilogue (round 6): other partial sums, isolated 16-bit roundings
+    # of the normalised activations flip, and the step agrees at the storage format's noise level instead (second comparison)
+    lf, nf, gf, pf = run(False, steps=1, gn_fuse=False)
+    ld, nd, gd, pd = run(False, steps=1)
+    assert abs(ld[0] - la[0]) <= 5e-3 * abs(la[0]), (ld, la)
     assert abs(lf[0] - la[0]) <= 1e-6 * abs(la[0]) and abs(nf[0] - na[0]) <= 1e-4 * na[0], (lf, la, nf, na)
 
 
