@@ -263,6 +263,37 @@ def bench_other_config(args, world, rank, local_rank, dev, sync):
         print(json.dumps(line), flush=True)
 
 
+def pmc_row_of_committed_table(kernel_prefix, build_id):
+    """the row of ``kernel_prefix`` in the newest committed per-kernel PMC table (profiles/r*_pmc_step_table.txt, written by
+    tools/pmc_step_table.py from three separate rocprofv3 --pmc passes): columns are found BY NAME in the table's header line, and the table's
+    `# source_id:` stamp is compared with the running library's build id -- a table measured on other kernel sources (or carrying no stamp:
+    rounds <= 5) is returned with stale = True, never silently."""
+    import glob
+    import re
+    tabs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_step_table.txt")),
+                  key=lambda f: (int(re.match(r"r(\d+)", os.path.basename(f)).group(1)), os.path.basename(f)))
+    if not tabs:
+        return None
+    sid, cols, row = None, None, None
+    for ln in open(tabs[-1]):
+        if ln.startswith("# source_id:"):
+            sid = ln.split(":", 1)[1].strip()
+        elif ln.startswith("kernel ") and cols is None:
+            cols = ln.split()[1:]
+        elif ln.startswith(kernel_prefix) and cols is not None and row is None:
+            vals = ln.split()[-len(cols):]
+            row = dict(zip(cols, vals))
+    if row is None:
+        return None
+    need = ("calls", "dur_ms", "mfma_util", "rd_MB/l", "wr_MB/l", "GB/s")
+    if any(k not in row for k in need):
+        raise ValueError("PMC table %s lacks columns %s" % (tabs[-1], [k for k in need if k not in row]))
+    return {"source": "profiles/" + os.path.basename(tabs[-1]), "source_id": sid, "stale": not (sid and build_id.startswith(sid + "-")),
+            "launches": int(row["calls"]), "kernel_ms": float(row["dur_ms"]), "mfma_util": float(row["mfma_util"]),
+            "read_MB_per_launch": float(row["rd_MB/l"]), "write_MB_per_launch": float(row["wr_MB/l"]), "fabric_GB_s": float(row["GB/s"]),
+            "note": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 128); FETCH_SIZE x 2 (gfx950) and WRITE_SIZE, separate passes"}
+
+
 def log(msg):
     if int(os.environ.get("RANK", "0")) == 0 or os.environ.get("PCM_BENCH_DEBUG"):
         print("[bench %7.1fs] %s" % (time.time() - T0, msg), file=sys.stderr, flush=True)
@@ -343,8 +374,8 @@ def main():
     from pcm_amd.model import LoraState, UNetWeights
     from pcm_amd.trainer import Distiller, StepConfig
     from pcm_amd.unet_spec import UNetConfig, random_state_dict
-    capi.lib()  # fail loudly if the HIP library is missing
-    log("library loaded")
+    capi.lib()  # fail loudly if the HIP library is missing (or was built from other sources than this tree's: capi.Lib)
+    log("library loaded: build id %s, abi %d" % (capi.lib().build_id, capi.lib().dll.pcm_abi_version()))
 
     ucfg = UNetConfig.sd15()
     with torch.no_grad():
@@ -427,9 +458,11 @@ def main():
         timed_comm_events, D.comm_events = D.comm_events, None
     # host cost of ONE step's launches with an empty queue (outside the timed region).  The "host enqueue" figure of the timed loop is
     # mostly back-pressure: with several steps queued hipGraphLaunch blocks until the GPU frees queue space, so it tracks the GPU time.
+    D.bucket_log = []          # the collectives of ONE step, in issue order (first RCCL run diagnosable from the JSON line alone)
     t1 = time.perf_counter()
     run(batches[-1])
     host_idle_ms = (time.perf_counter() - t1) * 1e3
+    bucket_log = list(D.bucket_log)
     sync()
     log("timed %d steps: %.1f ms/step (host enqueue %.1f ms/step with %d steps queued; %.2f ms for one step's launches on an idle queue)"
         % (args.steps, ms, t_enq * 1e3 / args.steps, args.steps, host_idle_ms))
@@ -440,6 +473,7 @@ def main():
         comm = {"backend": torch.distributed.get_backend(), "collective_ranks": collective_ranks, "devices": devices,
                 "buckets": 2 if (D.bucketed and lora.late_offset is not None) else 1, "grad_bytes": int(lora.grads.numel() * 4),
                 "exposed_allreduce_ms_per_step": round(sum(a.elapsed_time(b) for a, b in ev) / max(1, len(ev)), 3) if ev else None,
+                "collectives_of_one_step": [{"bucket": n_, "bytes": b_, "dtype": d_} for n_, b_, d_ in bucket_log],
                 "note": "exposed = stream time between the end of the backward graph and the optimizer graph on rank 0 (early bucket + wait for the "
                         "late bucket that was launched between the two backward graphs)"}
     # north_star quantity: MFMA fraction of the TWO-TIMESTEP STUDENT FORWARD (online at t_{n+k} + target at t_n: rows a6 + a12 of
@@ -528,16 +562,9 @@ def main():
             # the per-kernel PMC table of one eager step on the final tree (tools/jobs/r05_e_pmc.sh -> tools/pmc_step_table.py: three separate
             # rocprofv3 --pmc passes): MFMA utilisation and fabric-side bytes of THIS kernel averaged over all its launches of a step -- the same
             # population `achieved` is taken over.  Committed measurement, named here; a PMC pass cannot run inside the timed process.
-            import glob
-            tabs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_step_table.txt")))
-            for ln in open(tabs[-1]):
-                if ln.startswith("void pcm_gemm8p_kernel<3, false, false>"):
-                    f = ln.split()
-                    calls, dur_ms, util, rd, wr, gbs = int(f[-8]), float(f[-7]), float(f[-6]), float(f[-3]), float(f[-2]), float(f[-1])
-                    pmc = {"source": "profiles/" + os.path.basename(tabs[-1]), "launches": calls, "kernel_ms": dur_ms, "mfma_util": util,
-                           "read_MB_per_launch": rd, "write_MB_per_launch": wr, "fabric_GB_s": gbs,
-                           "note": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 128); FETCH_SIZE x 2 (gfx950) and WRITE_SIZE, separate passes"}
-        except Exception:
+            pmc = pmc_row_of_committed_table("void pcm_gemm8p_kernel<3, false, false>", capi.lib().build_id)
+        except Exception as e:
+            log("PMC table not usable: %r" % (e,))
             pmc = None
         try:
             # NOT measured in this run (PMC passes need their own rocprofv3 runs): the newest committed measurement is copied in and named
@@ -557,7 +584,9 @@ def main():
             pass
         if pmc is not None:
             traffic = round((pmc["read_MB_per_launch"] + pmc["write_MB_per_launch"]) * 1e6)
-            traffic_source = pmc["source"] + " (committed rocprofv3 --pmc passes over one eager step of this tree; not re-measured by this run)"
+            traffic_source = pmc["source"] + (" (committed rocprofv3 --pmc passes over one eager step of THESE kernel sources, source id %s; not re-measured by this run)" % pmc["source_id"]
+                                              if not pmc["stale"] else
+                                              " -- STALE: measured on kernel sources %s, this run's library is %s; re-run tools/jobs/r06_pmc.sh" % (pmc["source_id"] or "without a stamp", capi.lib().build_id))
             traffic_note = "fabric-side bytes per AVERAGE launch of this kernel over the %d launches of a step (Infinity-Cache hits included); algorithmic %.0f MB per average launch" % (
                 len(dom), d_nb / max(1, len(dom)) / 1e6)
         roofline = {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
@@ -585,7 +614,7 @@ def main():
                                        "LoRA r=64 (67.25M trainable), huber, AdamW, random-init UNet (859.5M)" % (args.multiphase, B),
                            "global_batch": world * B, "parallelism": "dp%d" % world, "comm": comm, "launch": "hipGraph replay" if use_graph else "eager", "reductions": "reproducible" if args.deterministic else "atomics", "teacher_pass": "fp16" if (Wt is not None or args.precision == "fp16") else "bf16", "loss_last": round(loss, 6),
                            "host_ms_per_step_idle_queue": round(host_idle_ms, 2)},
-                "roofline": roofline, "cpu_baseline": cpu}
+                "roofline": roofline, "cpu_baseline": cpu, "build_id": capi.lib().build_id}
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -53,6 +53,9 @@ extern "C" {
 
 const char* pcm_last_error(void);
 int pcm_abi_version(void);
+/* identity of the kernel sources this library was built from (abi >= 5): "<16 hex digits of sha256 over csrc/*.hip, csrc/*.h,
+ * include/pcm_hip.h>-<variant>"; the host side refuses a default library whose id is not its tree's, bench.py / smoke() print it */
+const char* pcm_build_id(void);
 /* The 16-bit storage / MFMA operand format of THIS build of the library: PCM_FMT_BF16 (libpcm_hip.so, the default and what bench.py
  * measures) or PCM_FMT_F16 (libpcm_hip_f16.so: the same sources compiled with -DPCM_ACT_F16 -- IEEE half, for the reference's
  * --mixed_precision=fp16 recipes, train_pcm_lora_sd15.sh:9, and for the 1e-3 loss validation against the fp32 oracle).  Wherever this
@@ -202,11 +205,19 @@ int pcm_groupnorm_bwd_stats_ws(const void* x, const void* dy, const double* stat
 int pcm_groupnorm_bwd_apply(const void* x, const void* dy, const double* stats, const double* bstats,
                             const float* gamma, const float* beta, void* dx, int B, int HW, int C,
                             int G, float eps, int act, void* stream);
+/* abi >= 5: the same with the gradient arriving over the block's skip path added in the same pass, dx = gn_dx + dres (dres bf16 [B][HW][C] or
+ * NULL): the separate add kernel of ResnetBlock2D / Transformer2DModel's residual backward is not needed */
+int pcm_groupnorm_bwd_apply_res(const void* x, const void* dy, const double* stats, const double* bstats, const float* gamma,
+                                const float* beta, const void* dres, void* dx, int B, int HW, int C, int G, float eps, int act, void* stream);
 
 /* affine-parameter gradients (the discriminator heads' norms are trainable): dgamma/dbeta fp32 [C], ACCUMULATED */
 int pcm_groupnorm_param_grad(const void* x, const void* dy, const double* stats, const float* gamma,
                              const float* beta, float* dgamma, float* dbeta, int B, int HW, int C, int G,
                              float eps, int act, void* stream);
+/* abi >= 5, reproducible form of the call above (workspace >= pcm_groupnorm_param_grad_workspace_bytes) */
+size_t pcm_groupnorm_param_grad_workspace_bytes(int B, int HW, int C, int G);
+int pcm_groupnorm_param_grad_ws(const void* x, const void* dy, const double* stats, const float* gamma, const float* beta, float* dgamma,
+                                float* dbeta, int B, int HW, int C, int G, float eps, int act, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- LayerNorm over the last dim (BasicTransformerBlock.norm1/2/3) ----------------------- */
 int pcm_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean,
@@ -276,6 +287,8 @@ int pcm_silu_bwd_bf16(const void* x, const void* dy, void* dx, long n, void* str
  * out) + its input gradient — UNet2DConditionModel.conv_in / conv_out, not LoRA targets. */
 int pcm_conv_in_fwd(const float* x_nchw, const float* w /*[C0][4][3][3]*/, const float* bias, void* y,
                     int B, int H, int W, int C0, void* stream);
+/* abi >= 5: the same with a second copy of the output rows at y2[(b*H + y)*W + x][ld2] (NULL: none) -- conv_in's output is the first skip tensor */
+int pcm_conv_in_fwd2(const float* x, const float* w, const float* bias, void* y, void* y2, int ld2, int B, int H, int W, int C0, void* stream);
 int pcm_conv_out_fwd(const void* x, const float* w /*[4][C0][3][3]*/, const float* bias, float* y_nchw,
                      int B, int H, int W, int C0, void* stream);
 int pcm_conv_out_bwd(const float* dy_nchw, const float* w, void* dx, int B, int H, int W, int C0, void* stream);
@@ -284,6 +297,11 @@ int pcm_conv_out_bwd(const float* dy_nchw, const float* w, void* dx, int B, int 
  * backward: dx = dy w (bf16, optional), dw += sum_m dy x, db += sum dy (fp32, accumulated) */
 int pcm_rowdot_fwd(const void* x, const float* w, const float* bias, float* out, long M, int C, void* stream);
 int pcm_rowdot_bwd(const void* x, const float* w, const float* dy, void* dx, float* dw, float* db, long M, int C, void* stream);
+/* abi >= 5, reproducible form: per-workgroup partials in the caller's workspace (>= pcm_rowdot_bwd_workspace_bytes) + an ordered finalize that
+ * adds into dw / db like the atomic form: bitwise identical run to run */
+size_t pcm_rowdot_bwd_workspace_bytes(long M, int C);
+int pcm_rowdot_bwd_ws(const void* x, const float* w, const float* dy, void* dx, float* dw, float* db, long M, int C, void* workspace,
+                      size_t workspace_bytes, void* stream);
 
 /* sinusoidal timestep projection (diffusers Timesteps(320, flip_sin_to_cos=True, shift=0)) */
 int pcm_timestep_embedding(const int64_t* t, void* out /*bf16 [B][dim]*/, int B, int dim, void* stream);
@@ -343,6 +361,10 @@ int pcm_unpatchify2x2(const float* tokens, float* img, int B, int C, int H, int 
  * out_b[b][c] = sum_l dy (d shift; optional).  x, dy bf16 [B*L][C]; outputs fp32 [B][C], zeroed by the call. */
 int pcm_mod_grad(const void* x, const void* dy, const float* mean, const float* rstd, float* out_a, float* out_b, int B, int L, int C,
                  void* stream);
+/* abi >= 5, reproducible form of the call above (workspace >= pcm_mod_grad_workspace_bytes, 16-byte aligned) */
+size_t pcm_mod_grad_workspace_bytes(int B, int L, int C);
+int pcm_mod_grad_ws(const void* x, const void* dy, const float* mean, const float* rstd, float* out_a, float* out_b, int B, int L, int C,
+                    void* workspace, size_t workspace_bytes, void* stream);
 /* sinusoidal projection of FLOAT timesteps (sigma * 1000, train_pcm_lora_sd3.py:1295-1300), flip_sin_to_cos, shift 0 -> bf16 [B][dim] */
 int pcm_timestep_embedding_f32(const float* t, void* out, int B, int dim, void* stream);
 
@@ -392,6 +414,9 @@ int pcm_noise_travel(const float* x, const float* noise, const float* alphas_cum
  * d_fake / d_real (optional) = d loss / d logit * grad_scale.  `loss` accumulates over heads. */
 int pcm_hinge_loss(const float* fake, const float* real, int mode, float scale, double* loss, float* d_fake,
                    float* d_real, float grad_scale, long n, void* stream);
+/* abi >= 5, reproducible form: one workgroup per call, so the sum a call adds to `loss` has a fixed order (the per-head logit maps are small) */
+int pcm_hinge_loss_ordered(const float* fake, const float* real, int mode, float scale, double* loss, float* d_fake, float* d_real,
+                           float grad_scale, long n, void* stream);
 
 /* out[b][:] += x[b][:] * s1[b] * s2[b]  (generator step: d fake_adv -> d eps through noise_travel and the phase jump) */
 int pcm_scale_add_rows(float* out, const float* x, const float* s1, const float* s2, int B, int per_sample, void* stream);

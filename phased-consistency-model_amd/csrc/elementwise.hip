@@ -354,7 +354,7 @@ __device__ __forceinline__ void stage_weights(const float* w, float* wl, int n, 
 // flip=0: w [C0][4][3][3] (conv_in).  flip=1: w [4][C0][3][3] read transposed with flipped taps
 // (input gradient of conv_out).  Weights staged in LDS as wl[j=(ci,tap)][c].
 __global__ __launch_bounds__(256) void conv4_kernel(const float* x, const float* w, const float* bias, bf16_t* y,
-                                                    int B, int H, int W, int C0, int flip) {
+                                                    int B, int H, int W, int C0, int flip, bf16_t* y2, int ld2) {
   PCM_DYN_SMEM(smem);
   float* wl = (float*)smem;  // [36][C0]
   stage_weights(w, wl, 36 * C0, [&](int i) {
@@ -383,13 +383,15 @@ __global__ __launch_bounds__(256) void conv4_kernel(const float* x, const float*
 #pragma unroll
         for (int e = 0; e < 8; e++) acc[e] += xv * wr[e];
       }
-    *(uint4*)(y + v * 8) = ew_pack8(acc);
+    const uint4 o = ew_pack8(acc);
+    *(uint4*)(y + v * 8) = o;
+    if (y2) *(uint4*)(y2 + (size_t)p * ld2 + cv * 8) = o;      // second copy, row stride ld2 (abi 5: the skip's slot in its concat buffer)
   }
 }
 // W % 4 == 0 variant: one item = 4 consecutive pixels of a row x 8 channels, so every staged weight vector feeds 4 pixels
 // and the 3x6 input window is loaded once; weights are staged with coalesced global reads (the scatter is on the LDS side).
 __global__ __launch_bounds__(256) void conv4x4_kernel(const float* x, const float* w, const float* bias, bf16_t* y,
-                                                      int B, int H, int W, int C0, int flip) {
+                                                      int B, int H, int W, int C0, int flip, bf16_t* y2, int ld2) {
   PCM_DYN_SMEM(smem);
   float* wl = (float*)smem;  // [36][C0]
   stage_weights(w, wl, 36 * C0, [&](int i) {
@@ -431,23 +433,37 @@ __global__ __launch_bounds__(256) void conv4x4_kernel(const float* x, const floa
         }
       }
     }
-    bf16_t* yo = y + (((size_t)b * H + py) * W + px0) * C0 + cv * 8;
+    const size_t row0 = ((size_t)b * H + py) * W + px0;
+    bf16_t* yo = y + row0 * C0 + cv * 8;
 #pragma unroll
-    for (int k = 0; k < 4; k++) *(uint4*)(yo + (size_t)k * C0) = ew_pack8(acc[k]);
+    for (int k = 0; k < 4; k++) {
+      const uint4 o = ew_pack8(acc[k]);
+      *(uint4*)(yo + (size_t)k * C0) = o;
+      if (y2) *(uint4*)(y2 + (row0 + k) * ld2 + cv * 8) = o;
+    }
   }
 }
-static void conv4_launch(const float* x, const float* w, const float* bias, bf16_t* y, int B, int H, int W, int C0, int flip, void* stream) {
+static void conv4_launch(const float* x, const float* w, const float* bias, bf16_t* y, int B, int H, int W, int C0, int flip, void* stream,
+                         bf16_t* y2 = nullptr, int ld2 = 0) {
   if ((W % 4) == 0) {
     long blocks = ((long)B * H * (W / 4) * (C0 / 8) + 255) / 256; if (blocks > PCM_GRID_CAP(768)) blocks = PCM_GRID_CAP(768);
-    PCM_LAUNCH(conv4x4_kernel, dim3((int)blocks), dim3(256), 36 * C0 * 4, stream, x, w, bias, y, B, H, W, C0, flip);
+    PCM_LAUNCH(conv4x4_kernel, dim3((int)blocks), dim3(256), 36 * C0 * 4, stream, x, w, bias, y, B, H, W, C0, flip, y2, ld2);
   } else {
-    PCM_LAUNCH(conv4_kernel, dim3(ew_blocks((long)B * H * W * (C0 / 8))), dim3(256), 36 * C0 * 4, stream, x, w, bias, y, B, H, W, C0, flip);
+    PCM_LAUNCH(conv4_kernel, dim3(ew_blocks((long)B * H * W * (C0 / 8))), dim3(256), 36 * C0 * 4, stream, x, w, bias, y, B, H, W, C0, flip, y2, ld2);
   }
 }
 extern "C" int pcm_conv_in_fwd(const float* x, const float* w, const float* bias, void* y, int B, int H, int W, int C0, void* stream) {
   PCM_CHECK(x && w && y && (C0 % 8) == 0 && C0 <= 1024, PCM_EINVAL, "pcm_conv_in_fwd: C0%%8, C0<=1024");
   conv4_launch(x, w, bias, (bf16_t*)y, B, H, W, C0, 0, stream);
   return pcm_post_launch("pcm_conv_in_fwd");
+}
+// abi 5: the same with a second copy of the output rows, y2[pixel][ld2] (conv_in's output is the first skip tensor: its slot in the last
+// up-block resnet's concatenated input, discriminator_sd15.py:312-342)
+extern "C" int pcm_conv_in_fwd2(const float* x, const float* w, const float* bias, void* y, void* y2, int ld2, int B, int H, int W, int C0, void* stream) {
+  PCM_CHECK(x && w && y && (C0 % 8) == 0 && C0 <= 1024, PCM_EINVAL, "pcm_conv_in_fwd2: C0%%8, C0<=1024");
+  PCM_CHECK(!y2 || (PCM_ALIGNED16(y2) && (ld2 % 8) == 0 && ld2 >= C0), PCM_EALIGN, "pcm_conv_in_fwd2: y2 alignment / ld2");
+  conv4_launch(x, w, bias, (bf16_t*)y, B, H, W, C0, 0, stream, (bf16_t*)y2, ld2);
+  return pcm_post_launch("pcm_conv_in_fwd2");
 }
 extern "C" int pcm_conv_out_bwd(const float* dy, const float* w, void* dx, int B, int H, int W, int C0, void* stream) {
   PCM_CHECK(dy && w && dx && (C0 % 8) == 0 && C0 <= 1024, PCM_EINVAL, "pcm_conv_out_bwd: C0%%8, C0<=1024");
@@ -595,8 +611,9 @@ __global__ __launch_bounds__(256) void rowdot_fwd_kernel(const bf16_t* x, const 
   }
 }
 // dx[m][c] = dy[m] * w[c] ; dw[c] += sum_m dy[m] x[m][c] ; db += sum_m dy[m]
+// part != nullptr (reproducible form): block b stores its C weight sums and its bias sum to part[b][C + 1]; an ordered finalize adds them
 __global__ __launch_bounds__(256) void rowdot_bwd_kernel(const bf16_t* x, const float* w, const float* dy, bf16_t* dx, float* dw, float* db,
-                                                         long M, int C, int rows_per_block) {
+                                                         long M, int C, int rows_per_block, float* part) {
   const int CV = C / 8;
   const int cvl = threadIdx.x % CV, pl = threadIdx.x / CV, k = blockDim.x / CV;
   float s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, wv[8];
@@ -630,13 +647,19 @@ __global__ __launch_bounds__(256) void rowdot_bwd_kernel(const bf16_t* x, const 
   for (int i = threadIdx.x; i < CV * 8; i += blockDim.x) {
     float t = 0.f;
     for (int j = 0; j < k; j++) t += red[j * CV * 8 + i];
-    atomicAdd(&dw[i], t);
+    if (part) part[(size_t)blockIdx.x * (C + 1) + i] = t; else atomicAdd(&dw[i], t);
   }
-  if (threadIdx.x == 0 && db) {
+  if (threadIdx.x == 0 && (db || part)) {
     float t = 0.f;
     for (int j = 0; j < k; j++) t += red[256 * 8 + j];
-    atomicAdd(db, t);
+    if (part) part[(size_t)blockIdx.x * (C + 1) + C] = t; else atomicAdd(db, t);
   }
+}
+static void rowdot_bwd_geometry(long M, int C, int* k_, long* blocks_, long* rpb_) {
+  int CV = C / 8, k = 256 / CV; if (k < 1) k = 1;
+  long blocks = PCM_GRID_CAP(512); long rpb = (M + blocks - 1) / blocks; if (rpb < k) rpb = k;
+  blocks = (M + rpb - 1) / rpb;
+  *k_ = k; *blocks_ = blocks; *rpb_ = rpb;
 }
 extern "C" int pcm_rowdot_fwd(const void* x, const float* w, const float* bias, float* out, long M, int C, void* stream) {
   PCM_CHECK(x && w && out && M > 0 && (C % 8) == 0 && PCM_ALIGNED16(x), PCM_EINVAL, "pcm_rowdot_fwd: C%%8, alignment");
@@ -646,9 +669,26 @@ extern "C" int pcm_rowdot_fwd(const void* x, const float* w, const float* bias, 
 }
 extern "C" int pcm_rowdot_bwd(const void* x, const float* w, const float* dy, void* dx, float* dw, float* db, long M, int C, void* stream) {
   PCM_CHECK(x && w && dy && dw && M > 0 && (C % 8) == 0 && C <= 2048 && PCM_ALIGNED16(x), PCM_EINVAL, "pcm_rowdot_bwd: C%%8, C<=2048, alignment");
-  int CV = C / 8, k = 256 / CV; if (k < 1) k = 1;
-  long blocks = PCM_GRID_CAP(512); long rpb = (M + blocks - 1) / blocks; if (rpb < k) rpb = k;
-  blocks = (M + rpb - 1) / rpb;
-  PCM_LAUNCH(rowdot_bwd_kernel, dim3((int)blocks), dim3(CV * k), 0, stream, (const bf16_t*)x, w, dy, (bf16_t*)dx, dw, db, M, C, (int)rpb);
+  int k; long blocks, rpb;
+  rowdot_bwd_geometry(M, C, &k, &blocks, &rpb);
+  PCM_LAUNCH(rowdot_bwd_kernel, dim3((int)blocks), dim3((C / 8) * k), 0, stream, (const bf16_t*)x, w, dy, (bf16_t*)dx, dw, db, M, C, (int)rpb, (float*)nullptr);
   return pcm_post_launch("pcm_rowdot_bwd");
+}
+// reproducible form (abi 5): per-block partials in the caller's workspace + an ordered finalize that ADDS into dw / db like the atomic form
+extern "C" size_t pcm_rowdot_bwd_workspace_bytes(long M, int C) {
+  if (M <= 0 || C <= 0 || (C % 8) || C > 2048) return 0;
+  int k; long blocks, rpb;
+  rowdot_bwd_geometry(M, C, &k, &blocks, &rpb);
+  return sizeof(float) * (size_t)blocks * (C + 1);
+}
+extern "C" int pcm_rowdot_bwd_ws(const void* x, const float* w, const float* dy, void* dx, float* dw, float* db, long M, int C, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
+  PCM_CHECK(x && w && dy && dw && workspace && M > 0 && (C % 8) == 0 && C <= 2048 && PCM_ALIGNED16(x), PCM_EINVAL, "pcm_rowdot_bwd_ws: C%%8, C<=2048, alignment");
+  int k; long blocks, rpb;
+  rowdot_bwd_geometry(M, C, &k, &blocks, &rpb);
+  PCM_CHECK(workspace_bytes >= sizeof(float) * (size_t)blocks * (C + 1), PCM_EINVAL, "pcm_rowdot_bwd_ws: workspace too small");
+  PCM_LAUNCH(rowdot_bwd_kernel, dim3((int)blocks), dim3((C / 8) * k), 0, stream, (const bf16_t*)x, w, dy, (bf16_t*)dx, dw, db, M, C, (int)rpb, (float*)workspace);
+  pcm_partials_finalize((const float*)workspace, C + 1, dw, (int)blocks, C, 1, stream);
+  if (db) pcm_partials_finalize((const float*)workspace + C, C + 1, db, (int)blocks, 1, 1, stream);
+  return pcm_post_launch("pcm_rowdot_bwd_ws");
 }

@@ -55,8 +55,9 @@ extern "C" int pcm_rowgate_fma(const void* y, const float* gate, const void* res
 //   out_a[b][c] = sum_l dy[b,l,c] * u[b,l,c],   u = (x - mean[row]) * rstd[row]  (LayerNorm scale: d gamma)  or  u = x (gate: d gate)
 //   out_b[b][c] = sum_l dy[b,l,c]                (LayerNorm shift: d beta; optional)
 // thread -> fixed 8-channel vector, strided over rows; block reduction through a float4 LDS image; fp32 atomics into the zeroed outputs.
+// part != nullptr (reproducible form): block (chunk, b, zc) stores to part[chunk][a | b][B][C]; an ordered finalize adds the chunks
 __global__ __launch_bounds__(256) void mod_grad_kernel(const bf16_t* x, const bf16_t* dy, const float* mean, const float* rstd, float* out_a,
-                                                       float* out_b, int L, int C, int CVL, int rpb_blk) {
+                                                       float* out_b, int L, int C, int CVL, int rpb_blk, float* part) {
   __shared__ __attribute__((aligned(16))) float4 pbuf[4][256];
   const int b = blockIdx.y, zc = blockIdx.z;
   const int cvl = threadIdx.x % CVL, pl = threadIdx.x / CVL, k = blockDim.x / CVL;
@@ -89,14 +90,16 @@ __global__ __launch_bounds__(256) void mod_grad_kernel(const bf16_t* x, const bf
       const float4 v = pbuf[j][q * CVL + cv2];
       acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }
-    float* o = (j < 2 ? out_a : out_b) + (size_t)b * C + (zc * CVL + cv2) * 8 + 4 * (j & 1);
+    const size_t col = (size_t)b * C + (zc * CVL + cv2) * 8 + 4 * (j & 1);
+    if (part) {
+      *(float4*)(part + ((size_t)blockIdx.x * 2 + (j < 2 ? 0 : 1)) * gridDim.y * C + col) = acc;
+      continue;
+    }
+    float* o = (j < 2 ? out_a : out_b) + col;
     atomicAdd(o + 0, acc.x); atomicAdd(o + 1, acc.y); atomicAdd(o + 2, acc.z); atomicAdd(o + 3, acc.w);
   }
 }
-extern "C" int pcm_mod_grad(const void* x, const void* dy, const float* mean, const float* rstd, float* out_a, float* out_b, int B, int L, int C,
-                            void* stream) {
-  PCM_CHECK(x && dy && out_a && B > 0 && L > 0 && C > 0 && (C % 8) == 0 && (!mean == !rstd), PCM_EINVAL, "pcm_mod_grad: null/empty, C%%8");
-  PCM_CHECK(PCM_ALIGNED16(x) && PCM_ALIGNED16(dy), PCM_EALIGN, "pcm_mod_grad: alignment");
+static void mod_grad_geometry(int B, int L, int C, int* split_, int* CVL_, int* k_, int* chunks_, int* rpb_) {
   const int CV = C / 8;
   int split = 1;
   while (CV / split > 256 || (CV % split) != 0) split++;
@@ -104,10 +107,38 @@ extern "C" int pcm_mod_grad(const void* x, const void* dy, const float* mean, co
   int chunks = (PCM_GRID_CAP(1024) + B * split - 1) / (B * split);
   const int maxc = (L + k - 1) / k; if (chunks > maxc) chunks = maxc; if (chunks < 1) chunks = 1;
   const int rpb = (L + chunks - 1) / chunks; chunks = (L + rpb - 1) / rpb;
+  *split_ = split; *CVL_ = CVL; *k_ = k; *chunks_ = chunks; *rpb_ = rpb;
+}
+extern "C" int pcm_mod_grad(const void* x, const void* dy, const float* mean, const float* rstd, float* out_a, float* out_b, int B, int L, int C,
+                            void* stream) {
+  PCM_CHECK(x && dy && out_a && B > 0 && L > 0 && C > 0 && (C % 8) == 0 && (!mean == !rstd), PCM_EINVAL, "pcm_mod_grad: null/empty, C%%8");
+  PCM_CHECK(PCM_ALIGNED16(x) && PCM_ALIGNED16(dy), PCM_EALIGN, "pcm_mod_grad: alignment");
+  int split, CVL, k, chunks, rpb;
+  mod_grad_geometry(B, L, C, &split, &CVL, &k, &chunks, &rpb);
   pcm_zero_async(out_a, sizeof(float) * (size_t)B * C, stream);
   if (out_b) pcm_zero_async(out_b, sizeof(float) * (size_t)B * C, stream);
-  PCM_LAUNCH(mod_grad_kernel, dim3(chunks, B, split), dim3(CVL * k), 0, stream, (const bf16_t*)x, (const bf16_t*)dy, mean, rstd, out_a, out_b, L, C, CVL, rpb);
+  PCM_LAUNCH(mod_grad_kernel, dim3(chunks, B, split), dim3(CVL * k), 0, stream, (const bf16_t*)x, (const bf16_t*)dy, mean, rstd, out_a, out_b, L, C, CVL, rpb, (float*)nullptr);
   return pcm_post_launch("pcm_mod_grad");
+}
+// reproducible form (abi 5): per-block partials in the caller's workspace + an ordered finalize (the outputs are overwritten, as above)
+extern "C" size_t pcm_mod_grad_workspace_bytes(int B, int L, int C) {
+  if (B <= 0 || L <= 0 || C <= 0 || (C % 8)) return 0;
+  int split, CVL, k, chunks, rpb;
+  mod_grad_geometry(B, L, C, &split, &CVL, &k, &chunks, &rpb);
+  return sizeof(float) * (size_t)chunks * 2 * B * C;
+}
+extern "C" int pcm_mod_grad_ws(const void* x, const void* dy, const float* mean, const float* rstd, float* out_a, float* out_b, int B, int L, int C,
+                               void* workspace, size_t workspace_bytes, void* stream) {
+  PCM_CHECK(x && dy && out_a && workspace && B > 0 && L > 0 && C > 0 && (C % 8) == 0 && (!mean == !rstd), PCM_EINVAL, "pcm_mod_grad_ws: null/empty, C%%8");
+  PCM_CHECK(PCM_ALIGNED16(x) && PCM_ALIGNED16(dy) && PCM_ALIGNED16(workspace), PCM_EALIGN, "pcm_mod_grad_ws: alignment");
+  int split, CVL, k, chunks, rpb;
+  mod_grad_geometry(B, L, C, &split, &CVL, &k, &chunks, &rpb);
+  PCM_CHECK(workspace_bytes >= sizeof(float) * (size_t)chunks * 2 * B * C, PCM_EINVAL, "pcm_mod_grad_ws: workspace too small");
+  PCM_LAUNCH(mod_grad_kernel, dim3(chunks, B, split), dim3(CVL * k), 0, stream, (const bf16_t*)x, (const bf16_t*)dy, mean, rstd, out_a, out_b, L, C, CVL, rpb, (float*)workspace);
+  const long n = (long)B * C;
+  pcm_partials_finalize((const float*)workspace, 2 * n, out_a, chunks, n, 0, stream);
+  if (out_b) pcm_partials_finalize((const float*)workspace + n, 2 * n, out_b, chunks, n, 0, stream);
+  return pcm_post_launch("pcm_mod_grad_ws");
 }
 
 // FeedForward(activation_fn="gelu-approximate"): y = 0.5 x (1 + tanh(k (x + 0.044715 x^3))), k = sqrt(2/pi)

@@ -176,6 +176,7 @@ struct GNApply {
   const float* gamma;
   const float* beta;
   bf16_t* y;
+  const bf16_t* dres;      // MODE 1, abi 5: dx += dres (the gradient arriving over the block's skip path: ResnetBlock2D / Transformer2DModel residual)
   int HW, C, G, cpg, act, vec_per_block;
   float eps;
 };
@@ -253,17 +254,19 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GNApply a) {
   const bf16_t* xb = a.x + (size_t)b * a.HW * a.C;
   bf16_t* yb = a.y + (size_t)b * a.HW * a.C;
   const bf16_t* dyb = MODE == 1 ? a.dy + (size_t)b * a.HW * a.C : nullptr;
+  const bf16_t* rb = (MODE == 1 && a.dres) ? a.dres + (size_t)b * a.HW * a.C : nullptr;
   // channel-vector index of this thread's vector, advanced incrementally (stride 256 vectors): one modulo per thread
   const int cstep = 256 % CV;
   int cv = (v0 + (int)threadIdx.x) % CV;
   // 4 vectors per trip, loads issued together (clamped addresses; the store is skipped for the clamped duplicates)
   for (int vb = v0 + threadIdx.x; vb < v1; vb += 4 * 256) {
-    uint4 xr[4], dr[4];
+    uint4 xr[4], dr[4], rr[4];
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       int v = vb + u * 256; if (v > v1 - 1) v = v1 - 1;
       xr[u] = *(const uint4*)(xb + (size_t)v * 8);
       if (MODE == 1) dr[u] = *(const uint4*)(dyb + (size_t)v * 8);
+      if (MODE == 1 && rb) rr[u] = *(const uint4*)(rb + (size_t)v * 8);
     }
 #pragma unroll
     for (int u = 0; u < 4; u++) {
@@ -287,6 +290,12 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GNApply a) {
         for (int e = 0; e < 8; e++) {
           float dz = dv[e] * gn_act_grad(fmaf(xv[e], scv[e], shv[e]), a.act);
           o[e] = fmaf(scv[e], dz, -fmaf(rv[e], xv[e], qv[e]));
+        }
+        if (rb) {      // (the sum is rounded ONCE: dx = bf16(gn_dx + dres) instead of bf16(bf16(gn_dx) + dres) of the separate add pass)
+          float rf[8];
+          unpack8(rr[u], rf);
+#pragma unroll
+          for (int e = 0; e < 8; e++) o[e] += rf[e];
         }
       }
       *(uint4*)(yb + (size_t)v * 8) = pack8(o);
@@ -454,16 +463,21 @@ extern "C" int pcm_groupnorm_apply_chstats(const void* x, const double* chstats,
   return gn_apply_launch<0>("pcm_groupnorm_apply_chstats", a, B, stream);
 }
 
+extern "C" int pcm_groupnorm_bwd_apply_res(const void* x, const void* dy, const double* stats, const double* bstats,
+                                           const float* gamma, const float* beta, const void* dres, void* dx, int B, int HW, int C,
+                                           int G, float eps, int act, void* stream) {
+  if (int rc = gn_check("pcm_groupnorm_bwd_apply", B, HW, C, G)) return rc;
+  PCM_CHECK(x && dy && stats && bstats && gamma && beta && dx && PCM_ALIGNED16(x) && PCM_ALIGNED16(dy) && (!dres || PCM_ALIGNED16(dres)) &&
+                PCM_ALIGNED16(dx) && C <= 2560, PCM_EALIGN, "pcm_groupnorm_bwd_apply: null/unaligned argument or C>2560");
+  GNApply a; memset(&a, 0, sizeof(a));
+  a.x = (const bf16_t*)x; a.dy = (const bf16_t*)dy; a.stats = stats; a.bstats = bstats; a.gamma = gamma; a.dres = (const bf16_t*)dres;
+  a.beta = beta; a.y = (bf16_t*)dx; a.HW = HW; a.C = C; a.G = G; a.cpg = C / G; a.act = act; a.eps = eps;
+  return gn_apply_launch<1>("pcm_groupnorm_bwd_apply", a, B, stream);
+}
 extern "C" int pcm_groupnorm_bwd_apply(const void* x, const void* dy, const double* stats, const double* bstats,
                                        const float* gamma, const float* beta, void* dx, int B, int HW, int C,
                                        int G, float eps, int act, void* stream) {
-  if (int rc = gn_check("pcm_groupnorm_bwd_apply", B, HW, C, G)) return rc;
-  PCM_CHECK(x && dy && stats && bstats && gamma && beta && dx && PCM_ALIGNED16(x) && PCM_ALIGNED16(dy) &&
-                PCM_ALIGNED16(dx) && C <= 2560, PCM_EALIGN, "pcm_groupnorm_bwd_apply: null/unaligned argument or C>2560");
-  GNApply a; memset(&a, 0, sizeof(a));
-  a.x = (const bf16_t*)x; a.dy = (const bf16_t*)dy; a.stats = stats; a.bstats = bstats; a.gamma = gamma;
-  a.beta = beta; a.y = (bf16_t*)dx; a.HW = HW; a.C = C; a.G = G; a.cpg = C / G; a.act = act; a.eps = eps;
-  return gn_apply_launch<1>("pcm_groupnorm_bwd_apply", a, B, stream);
+  return pcm_groupnorm_bwd_apply_res(x, dy, stats, bstats, gamma, beta, nullptr, dx, B, HW, C, G, eps, act, stream);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -668,9 +682,21 @@ __global__ __launch_bounds__(256) void gn_param_grad_kernel(GNArgs a, float* dga
     float t = 0.f;
     for (int j = 0; j < k; j++) t += red[j * a.CVL * 16 + i];
     const int cv = i >> 4, e = i & 15;
-    float* dst = (e < 8 ? dgamma : dbeta) + (zc * a.CVL + cv) * 8 + (e & 7);
-    atomicAdd(dst, t);
+    const int col = (zc * a.CVL + cv) * 8 + (e & 7);
+    // reproducible form: block (chunk, b) of every channel split stores to part[(b * chunks + chunk)][dgamma C | dbeta C]
+    if (a.part) ((float*)a.part)[((size_t)b * gridDim.x + blockIdx.x) * (2 * a.C) + (e < 8 ? 0 : a.C) + col] = t;
+    else atomicAdd((e < 8 ? dgamma : dbeta) + col, t);
   }
+}
+static void gn_param_grad_geometry(GNArgs& a, int B, int* split_, int* k_, int* chunks_) {
+  int CV = a.C / 8, split = 1;
+  while (CV / split > 256 || (CV % split) != 0) split++;
+  a.CVL = CV / split;
+  int k = 256 / a.CVL; if (k < 1) k = 1;
+  int chunks = (PCM_GRID_CAP(512) + B * split - 1) / (B * split);
+  int maxchunks = (a.HW + k - 1) / k; if (chunks > maxchunks) chunks = maxchunks; if (chunks < 1) chunks = 1;
+  a.ppb = (a.HW + chunks - 1) / chunks; chunks = (a.HW + a.ppb - 1) / a.ppb;
+  *split_ = split; *k_ = k; *chunks_ = chunks;
 }
 extern "C" int pcm_groupnorm_param_grad(const void* x, const void* dy, const double* stats, const float* gamma, const float* beta,
                                         float* dgamma, float* dbeta, int B, int HW, int C, int G, float eps, int act, void* stream) {
@@ -679,13 +705,35 @@ extern "C" int pcm_groupnorm_param_grad(const void* x, const void* dy, const dou
   GNArgs a; memset(&a, 0, sizeof(a));
   a.x = (const bf16_t*)x; a.dy = (const bf16_t*)dy; a.stats = stats; a.gamma = gamma; a.beta = beta;
   a.HW = HW; a.C = C; a.G = G; a.cpg = C / G; a.eps = eps; a.act = act;
-  int CV = C / 8, split = 1;
-  while (CV / split > 256 || (CV % split) != 0) split++;
-  a.CVL = CV / split;
-  int k = 256 / a.CVL; if (k < 1) k = 1;
-  int chunks = (PCM_GRID_CAP(512) + B * split - 1) / (B * split);
-  int maxchunks = (HW + k - 1) / k; if (chunks > maxchunks) chunks = maxchunks; if (chunks < 1) chunks = 1;
-  a.ppb = (HW + chunks - 1) / chunks; chunks = (HW + a.ppb - 1) / a.ppb;
+  int split, k, chunks;
+  gn_param_grad_geometry(a, B, &split, &k, &chunks);
+  a.part = nullptr;
   PCM_LAUNCH(gn_param_grad_kernel, dim3(chunks, B, split), dim3(a.CVL * k), 0, stream, a, dgamma, dbeta);
   return pcm_post_launch("pcm_groupnorm_param_grad");
+}
+// reproducible form (abi 5): per-block partials + an ordered finalize that ADDS into dgamma / dbeta like the atomic form
+extern "C" size_t pcm_groupnorm_param_grad_workspace_bytes(int B, int HW, int C, int G) {
+  if (B <= 0 || HW <= 0 || C <= 0 || G <= 0 || G > 32 || (C % G) || (C % 8)) return 0;
+  GNArgs a; memset(&a, 0, sizeof(a));
+  a.HW = HW; a.C = C; a.G = G; a.cpg = C / G;
+  int split, k, chunks;
+  gn_param_grad_geometry(a, B, &split, &k, &chunks);
+  return sizeof(float) * (size_t)B * chunks * 2 * C;
+}
+extern "C" int pcm_groupnorm_param_grad_ws(const void* x, const void* dy, const double* stats, const float* gamma, const float* beta,
+                                           float* dgamma, float* dbeta, int B, int HW, int C, int G, float eps, int act, void* workspace,
+                                           size_t workspace_bytes, void* stream) {
+  if (int rc = gn_check("pcm_groupnorm_param_grad_ws", B, HW, C, G)) return rc;
+  PCM_CHECK(x && dy && stats && gamma && beta && dgamma && dbeta && workspace && PCM_ALIGNED16(x) && PCM_ALIGNED16(dy), PCM_EALIGN, "pcm_groupnorm_param_grad_ws: null/unaligned");
+  GNArgs a; memset(&a, 0, sizeof(a));
+  a.x = (const bf16_t*)x; a.dy = (const bf16_t*)dy; a.stats = stats; a.gamma = gamma; a.beta = beta;
+  a.HW = HW; a.C = C; a.G = G; a.cpg = C / G; a.eps = eps; a.act = act;
+  int split, k, chunks;
+  gn_param_grad_geometry(a, B, &split, &k, &chunks);
+  PCM_CHECK(workspace_bytes >= sizeof(float) * (size_t)B * chunks * 2 * C, PCM_EINVAL, "pcm_groupnorm_param_grad_ws: workspace too small");
+  a.part = (double*)workspace;
+  PCM_LAUNCH(gn_param_grad_kernel, dim3(chunks, B, split), dim3(a.CVL * k), 0, stream, a, dgamma, dbeta);
+  pcm_partials_finalize((const float*)workspace, 2 * C, dgamma, B * chunks, C, 1, stream);
+  pcm_partials_finalize((const float*)workspace + C, 2 * C, dbeta, B * chunks, C, 1, stream);
+  return pcm_post_launch("pcm_groupnorm_param_grad_ws");
 }

@@ -130,6 +130,7 @@ void pcm_set_error(const char* fmt, ...);
   } while (0)
 #define PCM_ALIGNED16(p) ((((uintptr_t)(p)) & 15) == 0)
 int pcm_post_launch(const char* what);
+void pcm_partials_finalize(const float* part, long stride, float* out, int nparts, long n, int accumulate, void* stream);   // runtime.hip: ordered sum of per-workgroup partials
 void pcm_zero_async(void* p, size_t bytes, void* stream);   // zero fill as a kernel launch (runtime.hip: why not hipMemsetAsync)
 
 // ---- the 16-bit activation / weight format.  Default build: bfloat16 (libpcm_hip.so).  -DPCM_ACT_F16 (pcm_amd/build.py variant "f16",

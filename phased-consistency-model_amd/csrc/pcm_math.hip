@@ -254,6 +254,14 @@ extern "C" int pcm_hinge_loss(const float* fake, const float* real, int mode, fl
   return pcm_post_launch("pcm_hinge_loss");
 }
 
+// reproducible form (abi 5): ONE workgroup -- the launch's contribution to `loss` is a fixed-order sum, and successive heads add in stream order
+extern "C" int pcm_hinge_loss_ordered(const float* fake, const float* real, int mode, float scale, double* loss, float* d_fake, float* d_real,
+                                      float grad_scale, long n, void* stream) {
+  PCM_CHECK(fake && loss && n > 0 && (mode == 1 || real), PCM_EINVAL, "pcm_hinge_loss_ordered: null/empty");
+  PCM_LAUNCH(hinge_kernel, dim3(1), dim3(256), 0, stream, fake, real, mode, scale, loss, d_fake, d_real, grad_scale, n);
+  return pcm_post_launch("pcm_hinge_loss_ordered");
+}
+
 // out[b][i] += x[b][i] * s1[b] * s2[b]
 __global__ __launch_bounds__(256) void scale_add_rows_kernel(float* out, const float* x, const float* s1, const float* s2, int B, int ps) {
   long n = (long)B * ps;

@@ -28,8 +28,45 @@ def extra_flags(src):
     return out
 
 
-def _stale(out, deps):
-    return (not os.path.exists(out)) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps)
+def _digest(paths, extra=()):
+    """sha256 over the CONTENTS of ``paths`` (sorted by file name) and the strings in ``extra``"""
+    import hashlib
+    h = hashlib.sha256()
+    for p in sorted(paths, key=os.path.basename):
+        h.update(os.path.basename(p).encode() + b"\0")
+        with open(p, "rb") as f:
+            h.update(f.read())
+        h.update(b"\0")
+    for e in extra:
+        h.update(str(e).encode() + b"\0")
+    return h.hexdigest()
+
+
+def source_files():
+    """everything a kernel library is a function of: csrc/*.hip, csrc/*.h, include/pcm_hip.h"""
+    return (sorted(glob.glob(os.path.join(CSRC, "*.hip"))) + sorted(glob.glob(os.path.join(CSRC, "*.h")))
+            + [os.path.join(os.path.dirname(os.path.dirname(HERE)), "include", "pcm_hip.h")])
+
+
+def source_id():
+    """16 hex digits identifying the kernel sources of this tree (the same for all variants): what pcm_build_id() of a library built from them
+    starts with, what tools/pmc_step_table.py stamps its tables with, what capi.lib() compares a loaded library against"""
+    return _digest(source_files())[:16]
+
+
+def _stale(out, stamp):
+    """content-keyed staleness (round 6; was mtime): ``out`` is current iff ``out + '.hash'`` holds ``stamp``.  A snapshot that carries binaries
+    older than its sources -- whatever the file times say -- is rebuilt, and touching a source without changing it is not."""
+    try:
+        with open(out + ".hash") as f:
+            return (not os.path.exists(out)) or f.read().strip() != stamp
+    except OSError:
+        return True
+
+
+def _mark(out, stamp):
+    with open(out + ".hash", "w") as f:
+        f.write(stamp + "\n")
 
 
 # variants: the same sources, another 16-bit activation / weight format (csrc/pcm_common.h).  "bf16" is the product default and what
@@ -50,26 +87,38 @@ def build(force=False, verbose=False, variant="bf16"):
     os.makedirs(objdir, exist_ok=True)
     hdrs = glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(os.path.dirname(os.path.dirname(HERE)), "include", "pcm_hip.h")]
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+    sid = source_id()
+    build_id = sid + "-" + variant
     jobs = []
     objs = []
+    stamps = {}
     for s in srcs:
         o = os.path.join(objdir, os.path.basename(s)[:-4] + ".o")
         objs.append(o)
-        if force or _stale(o, [s] + hdrs):
-            jobs.append([HIPCC] + FLAGS + vflags + extra_flags(s) + ["-c", s, "-o", o])
+        flags = FLAGS + vflags + extra_flags(s)
+        if os.path.basename(s) == "runtime.hip":       # pcm_build_id(): the identity of ALL sources is compiled into this one object
+            flags = flags + ['-DPCM_BUILD_ID="%s"' % build_id]
+        stamps[o] = _digest([s] + hdrs, flags)
+        if force or _stale(o, stamps[o]):
+            jobs.append(([HIPCC] + flags + ["-c", s, "-o", o], o))
 
-    def run(cmd):
+    def run(job):
+        cmd, out = job
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
+        if out is not None:
+            _mark(out, stamps[out])
         return r.stderr
 
     with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
         list(ex.map(run, jobs))
-    if force or jobs or _stale(lib, objs):
-        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
+    lib_stamp = _digest([], [stamps[o] for o in objs])
+    if force or jobs or _stale(lib, lib_stamp):
+        run(([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs, None))
+        _mark(lib, lib_stamp)
     return lib
 
 

@@ -69,9 +69,14 @@ _PROTOS = {
     "pcm_groupnorm_bwd_stats": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp],
     "pcm_groupnorm_bwd_stats_acc": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp],
     "pcm_groupnorm_bwd_apply": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp],
+    "pcm_groupnorm_bwd_apply_res": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp],
     "pcm_groupnorm_param_grad": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp],
     "pcm_rowdot_fwd": [vp, vp, vp, vp, i64, i32, vp],
     "pcm_rowdot_bwd": [vp, vp, vp, vp, vp, vp, i64, i32, vp],
+    "pcm_rowdot_bwd_ws": [vp, vp, vp, vp, vp, vp, i64, i32, vp, C.c_size_t, vp],
+    "pcm_groupnorm_param_grad_ws": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp, C.c_size_t, vp],
+    "pcm_mod_grad_ws": [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, C.c_size_t, vp],
+    "pcm_hinge_loss_ordered": [vp, vp, i32, f32, vp, vp, vp, f32, i64, vp],
     "pcm_noise_travel": [vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
     "pcm_scale_add_rows": [vp, vp, vp, vp, i32, i32, vp],
     "pcm_hinge_loss": [vp, vp, i32, f32, vp, vp, vp, f32, i64, vp],
@@ -96,6 +101,7 @@ _PROTOS = {
     "pcm_silu_bf16": [vp, vp, i64, vp],
     "pcm_silu_bwd_bf16": [vp, vp, vp, i64, vp],
     "pcm_conv_in_fwd": [vp, vp, vp, vp, i32, i32, i32, i32, vp],
+    "pcm_conv_in_fwd2": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "pcm_conv_out_fwd": [vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "pcm_conv_out_bwd": [vp, vp, vp, i32, i32, i32, i32, vp],
     "pcm_timestep_embedding": [vp, vp, i32, i32, vp],
@@ -160,6 +166,19 @@ class Lib:
         self.dll.pcm_abi_version.restype = C.c_int
         self.dll.pcm_act_dtype.restype = C.c_int
         self.act_dtype = int(self.dll.pcm_act_dtype())       # 0: bfloat16 build, 1: IEEE-half build (include/pcm_hip.h PCM_FMT_*)
+        # identity of the sources the library was built from (abi 5).  One of THIS tree's own libraries (pcm_amd/lib/) must carry this tree's
+        # source id: a snapshot whose binaries are older than its sources fails here instead of running stale kernels (build() rebuilds by
+        # content hash, so this only fires when build() was skipped).  Other paths (emulator builds, A/B copies under tools/) are not checked.
+        self.build_id = "unknown"
+        if hasattr(self.dll, "pcm_build_id"):
+            self.dll.pcm_build_id.restype = C.c_char_p
+            self.build_id = self.dll.pcm_build_id().decode()
+        if os.path.dirname(os.path.abspath(path)) == os.path.join(HERE, "lib") and os.environ.get("PCM_ALLOW_STALE_LIB") != "1":
+            from . import build as _build
+            want = _build.source_id()
+            if not self.build_id.startswith(want + "-"):
+                raise RuntimeError(f"pcm_amd: {path} was built from other sources (library {self.build_id}, tree {want}): "
+                                   "run `python __graft_entry__.py build` (PCM_ALLOW_STALE_LIB=1 loads it anyway)")
         self.dll.pcm_gemm_workspace_bytes.restype = C.c_size_t
         self.dll.pcm_gemm_workspace_bytes.argtypes = [C.POINTER(GemmSeg), C.c_int, C.POINTER(GemmEpi)]
         self.dll.pcm_gemm_plan_code.restype = C.c_int
@@ -174,6 +193,11 @@ class Lib:
         self.dll.pcm_lora_wgrad_workspace_bytes.argtypes = [C.POINTER(WgradArgs)]
         self.dll.pcm_colsum_workspace_bytes.restype = C.c_size_t
         self.dll.pcm_colsum_workspace_bytes.argtypes = [C.c_int] * 3
+        for name, argt in (("pcm_rowdot_bwd_workspace_bytes", [C.c_long, C.c_int]), ("pcm_groupnorm_param_grad_workspace_bytes", [C.c_int] * 4),
+                           ("pcm_mod_grad_workspace_bytes", [C.c_int] * 3)):        # abi 5
+            f = getattr(self.dll, name, None)
+            if f is not None:
+                f.restype, f.argtypes = C.c_size_t, argt
         self.fn = {}
         for name, argt in _PROTOS.items():
             f = getattr(self.dll, name, None)

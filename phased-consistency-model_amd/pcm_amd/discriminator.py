@@ -190,7 +190,7 @@ class Discriminator:
             with ops.wgrad_batch():       # the Cout/64 chunks share launches
                 for co in range(0, C, 64):
                     ops.lora_wgrad(x.reshape(M, C), dy[:, co:co + 64], gW[co:co + 64], 1.0, M, G=C, g_stride=1, r_stride=C, lds=C)
-            capi.lib().call("pcm_colsum_bf16", ops.ptr(dy), ops.ptr(hd.g[name + ".bias"]), 1, M, C, capi.Lib.stream())
+            ops.colsum_into(dy, hd.g[name + ".bias"], M, C)
             return
         gW = hd.g[name + ".weight"].view(C, 9 * C)
         if ops.conv3x3_wgrad_ok(wg["Hs"], wg["Ws"], C, C):          # dense kernel: one launch, x staged once per 128 input channels
@@ -199,7 +199,7 @@ class Discriminator:
             with ops.wgrad_batch():       # (3x3 view: the jobs the multi-launch kernel does not take run one by one inside the call)
                 for co in range(0, C, 64):
                     ops.lora_wgrad(x, dy[:, co:co + 64], gW[co:co + 64], 1.0, M, conv=wg, g_stride=1, r_stride=9 * C, lds=C)
-        capi.lib().call("pcm_colsum_bf16", ops.ptr(dy), ops.ptr(hd.g[name + ".bias"]), 1, M, C, capi.Lib.stream())
+        ops.colsum_into(dy, hd.g[name + ".bias"], M, C)
 
     # ------------------------------------------------------------------ losses (discriminator_sd15.py:412-434)
     def d_loss_backward(self, logits_fake_real, tape, B_half, weight=1.0, on_bucket=None, loss_scale_dev=None):

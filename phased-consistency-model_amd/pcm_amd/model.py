@@ -173,6 +173,7 @@ FUSE_LORA_QKV = os.environ.get("PCM_LORA_QKV", "1") != "0"
 # straight into the concatenated buffer (A/B measurement hooks)
 FUSE_GN_STATS = os.environ.get("PCM_GN_FUSE", "0") == "1"      # opt-in: built and measured SLOWER on MI355X (fp64 atomic traffic + the column pass)
 FUSE_CONCAT = os.environ.get("PCM_CAT_FUSE", "1") != "0"
+FUSE_GN_BWD_ADD = os.environ.get("PCM_GN_BWD_ADD", "1") != "0"      # the skip-path gradient of a resnet / transformer joins in the GroupNorm backward's apply pass
 
 
 def _cs_of(t):
@@ -627,9 +628,12 @@ class UNet:
             save["gn_x"], save["gn_stats"] = x, stats
         return y
 
-    def _gn_bwd(self, path, dy, act, eps, saved):
+    def _gn_bwd(self, path, dy, act, eps, saved, dres=None):
         g, b = self.W.norms[path]
-        return ops.groupnorm_bwd(saved["gn_x"], dy, saved["gn_stats"], g, b, self.cfg.norm_num_groups, eps, act, arena=self._arena)
+        if dres is not None and not FUSE_GN_BWD_ADD:
+            return ops.add(ops.groupnorm_bwd(saved["gn_x"], dy, saved["gn_stats"], g, b, self.cfg.norm_num_groups, eps, act, arena=self._arena), dres.view_as(saved["gn_x"]))
+        return ops.groupnorm_bwd(saved["gn_x"], dy, saved["gn_stats"], g, b, self.cfg.norm_num_groups, eps, act, arena=self._arena,
+                                 dres=None if dres is None else dres.view_as(saved["gn_x"]))
 
     @staticmethod
     def _scatter_table(descs, dev):
@@ -762,11 +766,11 @@ class UNet:
                 layer_bwd(W, lora, p + "conv_shortcut", d_out, sv["sc"], need_dx=False)
             return None
         Cin = d_n1.shape[-1]
-        d_x = self._gn_bwd(p + "norm1", d_n1.view(B, H * Wd, Cin), capi.ACT_SILU, self.cfg.norm_eps, sv["s1"])
         if sv["sc"] is not None:
+            d_x = self._gn_bwd(p + "norm1", d_n1.view(B, H * Wd, Cin), capi.ACT_SILU, self.cfg.norm_eps, sv["s1"])
             d_x = layer_bwd(W, lora, p + "conv_shortcut", d_out, sv["sc"], residual=d_x.view(M, Cin))
-        else:
-            d_x = ops.add(d_x.view(M, Cin), d_out)
+        else:       # identity skip: its gradient joins in the GroupNorm backward's apply pass (no add kernel)
+            d_x = self._gn_bwd(p + "norm1", d_n1.view(B, H * Wd, Cin), capi.ACT_SILU, self.cfg.norm_eps, sv["s1"], dres=d_out.contiguous())
         return d_x.view(B, H * Wd, Cin)
 
     # ---- transformer (Transformer2DModel with one BasicTransformerBlock) ----
@@ -956,8 +960,7 @@ class UNet:
             d_n1 = self._attn_bwd(b + "attn1.", d_h1, bs["sa1"], B, C, True, heads)
             d_h = ops.layernorm_bwd(bs["h"], d_n1, W.norms[b + "norm1"][0], bs["mu1"], bs["rs1"], dres=d_h1)
         d_n = layer_bwd(W, lora, p + "proj_in", d_h, sv["spi"])
-        d_x = self._gn_bwd(p + "norm", d_n.view(B, H * Wd, C), capi.ACT_NONE, 1e-6, sv["sgn"])
-        return ops.add(d_x.view(M, C), d_out).view(B, H * Wd, C)
+        return self._gn_bwd(p + "norm", d_n.view(B, H * Wd, C), capi.ACT_NONE, 1e-6, sv["sgn"], dres=d_out.contiguous()).view(B, H * Wd, C)
 
     # ---- whole network ----
     def forward(self, sample, timesteps, encoder_hidden_states, save=False, features=False, added_cond=None, save_half=False, dup_halves=False):
@@ -1036,8 +1039,12 @@ class UNet:
             h = ops.conv_in_fwd(sample[:Bh].contiguous(), W.conv_in[0], W.conv_in[1], boc[0])
             skips = [Skip(torch.cat([h, h]), H, Wd)]
         else:
-            h = ops.conv_in_fwd(sample.contiguous(), W.conv_in[0], W.conv_in[1], boc[0])
-            skips = [Skip(h, H, Wd)]
+            skips = []
+            cb, o2 = skip_slot(boc[0], H, Wd)
+            if o2 is not None and (cat_h[0] + boc[0]) % 8:
+                cb, o2 = None, None
+            h = ops.conv_in_fwd(sample.contiguous(), W.conv_in[0], W.conv_in[1], boc[0], out2=o2)
+            skips = [Skip(h, H, Wd, cb)]
         feats = []
         for i in range(n):
             for j in range(lpb):
@@ -1173,7 +1180,7 @@ class UNet:
         global _SIDE
         W, lora, cfg = self.W, self.lora, self.cfg
         dev_ = d_eps.device if d_eps is not None else self.W.conv_in[0].device
-        if lora is not None and WGRAD_SIDE_STREAM and dev_.type == "cuda":
+        if lora is not None and WGRAD_SIDE_STREAM and dev_.type == "cuda" and not ops.DETERMINISTIC:     # (reproducible reductions: one stream, one order)
             if self._side is None:
                 self._side = WgradSide()
             _SIDE = self._side

@@ -24,19 +24,26 @@ _DET_WS = {}
 def set_deterministic(on=True):
     global DETERMINISTIC
     DETERMINISTIC = bool(on)
-    if not on:
-        _DET_WS.clear()
+    # (the scratch buffers are NOT dropped when the switch goes off: a captured hipGraph may still hold their addresses -- see _det_ws)
 
 
 def _det_ws(device, nbytes, key="ws"):
-    """stream-ordered scratch of the reproducible forms: one growing buffer per (device, key); a call's finalize has consumed it before
-    the next call on the same stream writes it"""
-    k = (str(device), key)
+    """stream-ordered scratch of the reproducible forms: one growing buffer per (device, STREAM, key) -- a call's finalize has consumed it before
+    the next call on the same stream writes it; another stream (the weight-gradient side stream) gets its own, so two streams never share a
+    slab.  A buffer that is outgrown stays referenced (_DET_OLD): a captured hipGraph may have its address baked in, and a replay after the
+    allocator recycled it would write memory that now belongs to someone else."""
+    stream = torch.cuda.current_stream(device).cuda_stream if (torch.cuda.is_available() and torch.device(device).type == "cuda") else 0
+    k = (str(device), int(stream), key)
     t = _DET_WS.get(k)
     if t is None or t.numel() < nbytes:
+        if t is not None:
+            _DET_OLD.append(t)
         t = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
         _DET_WS[k] = t
     return t
+
+
+_DET_OLD = []
 
 
 def _chk(t, dtype=None):
@@ -218,7 +225,8 @@ def groupnorm_fwd(x, gamma, beta, G, eps, act, arena=None, chstats=None, chstats
     return y, stats
 
 
-def groupnorm_bwd(x, dy, stats, gamma, beta, G, eps, act, arena=None):
+def groupnorm_bwd(x, dy, stats, gamma, beta, G, eps, act, arena=None, dres=None):
+    """``dres`` ([B, HW, C], optional): added to the input gradient in the apply pass (the block's skip-path gradient)"""
     B, HW, Cc = x.shape
     dx = torch.empty_like(x)
     L = capi.lib()
@@ -229,6 +237,10 @@ def groupnorm_bwd(x, dy, stats, gamma, beta, G, eps, act, arena=None):
         bstats = torch.empty(B, G, 2, dtype=torch.float64, device=x.device)
         ws, n = _gn_workspace(x, B, HW, Cc, G)
         L.call("pcm_groupnorm_bwd_stats_ws", ptr(x), ptr(dy), ptr(stats), ptr(gamma), ptr(beta), ptr(bstats), B, HW, Cc, G, eps, act, ptr(ws), n, _stream())
+    if dres is not None:
+        assert dres.is_contiguous() and dres.numel() == x.numel() and dres.dtype == x.dtype
+        L.call("pcm_groupnorm_bwd_apply_res", ptr(x), ptr(dy), ptr(stats), ptr(bstats), ptr(gamma), ptr(beta), ptr(dres), ptr(dx), B, HW, Cc, G, eps, act, _stream())
+        return dx
     L.call("pcm_groupnorm_bwd_apply", ptr(x), ptr(dy), ptr(stats), ptr(bstats), ptr(gamma), ptr(beta), ptr(dx), B, HW, Cc, G, eps, act, _stream())
     return dx
 
@@ -335,9 +347,13 @@ def colsum(x):
     return out
 
 
-def conv_in_fwd(x_nchw, w, bias, C0):
+def conv_in_fwd(x_nchw, w, bias, C0, out2=None):
+    """``out2``: a [B*H*W, C0] view (row stride out2.stride(0)) that receives a second copy of the output (the skip's slot in a concat buffer)"""
     B, _, H, W = x_nchw.shape
     y = torch.empty(B, H * W, C0, dtype=_act_dtype(), device=x_nchw.device)
+    if out2 is not None:
+        capi.lib().call("pcm_conv_in_fwd2", ptr(x_nchw), ptr(w), ptr(bias), ptr(y), ptr(out2), out2.stride(0), B, H, W, C0, _stream())
+        return y
     capi.lib().call("pcm_conv_in_fwd", ptr(x_nchw), ptr(w), ptr(bias), ptr(y), B, H, W, C0, _stream())
     return y
 
@@ -421,6 +437,11 @@ def mod_grad(x, dy, B, mean=None, rstd=None, want_b=True):
     L = x.numel() // Cc // B
     a = torch.empty(B, Cc, dtype=torch.float32, device=x.device)
     b = torch.empty(B, Cc, dtype=torch.float32, device=x.device) if want_b else None
+    if DETERMINISTIC:
+        n = capi.lib().dll.pcm_mod_grad_workspace_bytes(B, L, Cc)
+        ws = _det_ws(x.device, n)
+        capi.lib().call("pcm_mod_grad_ws", ptr(x), ptr(dy), ptr(mean), ptr(rstd), ptr(a), ptr(b), B, L, Cc, ptr(ws), n, _stream())
+        return a, b
     capi.lib().call("pcm_mod_grad", ptr(x), ptr(dy), ptr(mean), ptr(rstd), ptr(a), ptr(b), B, L, Cc, _stream())
     return a, b
 
@@ -441,8 +462,9 @@ def cast_bf16(x):
     return y
 
 
-def cast_f32(x):
-    y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+def cast_f32(x, out=None):
+    y = out if out is not None else torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    assert y.dtype == torch.float32 and y.is_contiguous() and y.numel() == x.numel()
     capi.lib().call("pcm_cast_bf16_f32", ptr(x), ptr(y), x.numel(), _stream())
     return y
 
@@ -592,8 +614,19 @@ def conv3x3_wgrad(x, dy, dW, B, H, W, alpha=1.0):
 
 
 def conv3x3_wgrad_ok(H, W, Cin, Cout):
-    """geometries csrc/wgrad_dense.hip takes (pcm_hip.h)"""
-    return H % 8 == 0 and W % 8 == 0 and Cin % 8 == 0 and Cout % 64 == 0
+    """geometries csrc/wgrad_dense.hip takes (pcm_hip.h).  Not under set_deterministic: its M split meets in fp32 atomics; the rank-64 jobs the
+    caller falls back to have a slab form"""
+    return (not DETERMINISTIC) and H % 8 == 0 and W % 8 == 0 and Cin % 8 == 0 and Cout % 64 == 0
+
+
+def colsum_into(x2d, out, M, Cc):
+    """out[c] = sum_m x2d[m][c] (fp32 [Cc], overwritten): the bias gradient of a conv / linear layer (pixel sum of dy)"""
+    if DETERMINISTIC:
+        n = capi.lib().dll.pcm_colsum_workspace_bytes(1, M, Cc)
+        ws = _det_ws(x2d.device, n)
+        capi.lib().call("pcm_colsum_bf16_ws", ptr(x2d), ptr(out), 1, M, Cc, ptr(ws), n, _stream())
+        return
+    capi.lib().call("pcm_colsum_bf16", ptr(x2d), ptr(out), 1, M, Cc, _stream())
 
 
 _WG_BATCH = None
@@ -682,6 +715,12 @@ def attn_bwd(q, k, v, o, dO, lse, H, d, scale=None, need_dkv=True, out=None, pre
 # ---- adversarial path (latent discriminator heads, discriminator_sd15.py:348-434) ----
 def groupnorm_param_grad(x, dy, stats, gamma, beta, dgamma, dbeta, G, eps, act):
     B, HW, Cc = x.shape
+    if DETERMINISTIC:
+        n = capi.lib().dll.pcm_groupnorm_param_grad_workspace_bytes(B, HW, Cc, G)
+        ws = _det_ws(x.device, n)
+        capi.lib().call("pcm_groupnorm_param_grad_ws", ptr(x), ptr(dy), ptr(stats), ptr(gamma), ptr(beta), ptr(dgamma), ptr(dbeta),
+                        B, HW, Cc, G, eps, act, ptr(ws), n, _stream())
+        return
     capi.lib().call("pcm_groupnorm_param_grad", ptr(x), ptr(dy), ptr(stats), ptr(gamma), ptr(beta), ptr(dgamma), ptr(dbeta),
                     B, HW, Cc, G, eps, act, _stream())
 
@@ -696,6 +735,11 @@ def rowdot_fwd(x, w, bias):
 def rowdot_bwd(x, w, dy, dw, db, need_dx=True):
     M, Cc = x.numel() // x.shape[-1], x.shape[-1]
     dx = torch.empty_like(x) if need_dx else None
+    if DETERMINISTIC:
+        n = capi.lib().dll.pcm_rowdot_bwd_workspace_bytes(M, Cc)
+        ws = _det_ws(x.device, n)
+        capi.lib().call("pcm_rowdot_bwd_ws", ptr(x), ptr(w), ptr(dy), ptr(dx), ptr(dw), ptr(db), M, Cc, ptr(ws), n, _stream())
+        return dx
     capi.lib().call("pcm_rowdot_bwd", ptr(x), ptr(w), ptr(dy), ptr(dx), ptr(dw), ptr(db), M, Cc, _stream())
     return dx
 
@@ -712,7 +756,8 @@ def hinge_loss(fake, real, mode, scale, loss, grad_scale=1.0, want_grad=True):
     """accumulates into ``loss`` (fp64 [1]); returns (d_fake, d_real)."""
     df = torch.empty_like(fake) if want_grad else None
     dr = torch.empty_like(real) if (want_grad and real is not None) else None
-    capi.lib().call("pcm_hinge_loss", ptr(fake), ptr(real), mode, scale, ptr(loss), ptr(df), ptr(dr), grad_scale, fake.numel(), _stream())
+    capi.lib().call("pcm_hinge_loss_ordered" if DETERMINISTIC else "pcm_hinge_loss", ptr(fake), ptr(real), mode, scale, ptr(loss), ptr(df), ptr(dr),
+                    grad_scale, fake.numel(), _stream())
     return df, dr
 
 

@@ -168,6 +168,7 @@ class Distiller:
         self._seg = None                  # SegmentedGraph being captured (AdvDistiller.capture_adv at world_size > 1)
         # two-bucket gradient exchange (world_size > 1): the mid/up-block bucket is reduced while the down blocks back-propagate
         self.bucketed = os.environ.get("PCM_DDP_BUCKETS", "1") != "0"
+        self.bucket_log = []        # (name, bytes on the wire, dtype) of every collective issued since it was last cleared, in issue order
         self.ema = None
         if cfg.ema_rate is not None:
             self.ema = lora.params.clone()
@@ -372,6 +373,11 @@ class Distiller:
         behind the launches issued so far) while the down blocks still back-propagate"""
         self._late_work = torch.distributed.all_reduce(self.lora.grads[self.lora.late_offset:], op=torch.distributed.ReduceOp.SUM,
                                                        group=self.pg, async_op=True)
+        self._log_bucket("lora[late: mid + up blocks]", (self.lora.grads.numel() - self.lora.late_offset) * 4, "fp32")
+
+    def _log_bucket(self, name, nbytes, dtype):
+        if len(self.bucket_log) < 64:        # (a diagnostic of ONE step's issue order: bench.py clears it before the step it reports)
+            self.bucket_log.append((name, int(nbytes), dtype))
 
     def all_reduce_grads(self):
         """DDP exchange: all-reduce (sum) of the flat 67 M-element fp32 LoRA gradient buffer over RCCL/xGMI, as ONE collective or --
@@ -381,10 +387,12 @@ class Distiller:
             return
         if getattr(self, "_late_work", None) is not None:
             torch.distributed.all_reduce(self.lora.grads[:self.lora.late_offset], op=torch.distributed.ReduceOp.SUM, group=self.pg)
+            self._log_bucket("lora[early: down blocks]", self.lora.late_offset * 4, "fp32")
             self._late_work.wait()
             self._late_work = None
         else:
             torch.distributed.all_reduce(self.lora.grads, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+            self._log_bucket("lora[all]", self.lora.grads.numel() * 4, "fp32")
 
     def _collective(self, fn):
         """issue a collective -- or, while a SegmentedGraph is being captured, cut the graph there and make ``fn`` the host action between
@@ -437,9 +445,17 @@ class AdvDistiller(Distiller):
     """PCM-LoRA + latent adversarial consistency (reference: train_pcm_lora_sd15_adv.py:1288-1431).
     Even ``global_step``: discriminator update only; odd: student update with loss_cm + adv_weight * g_loss."""
 
-    def __init__(self, weights, lora, cfg, discriminator, adv_weight=0.1, adv_lr=1e-5, world_size=1, process_group=None, teacher_weights=None):
+    def __init__(self, weights, lora, cfg, discriminator, adv_weight=0.1, adv_lr=1e-5, world_size=1, process_group=None, teacher_weights=None,
+                 head_grad_exchange=None):
+        """``head_grad_exchange``: "fp32" (default; the reference's DDP reduces fp32 gradients) or "bf16" (the 2.66 GB of head
+        gradients of a discriminator step cross xGMI as 1.33 GB -- each bucket is rounded to bfloat16, summed by the collective and
+        widened back; the D update then differs from the fp32 exchange by the 16-bit rounding of the per-rank gradients, bounded in
+        tests/test_ddp_gloo.py).  Default from PCM_HEAD_GRAD_EXCHANGE.  bfloat16 build only (half gradients are loss-scaled)."""
         super().__init__(weights, lora, cfg, world_size, process_group, teacher_weights=teacher_weights)
         self.disc, self.adv_weight, self.adv_lr = discriminator, adv_weight, adv_lr
+        self.head_grad_exchange = head_grad_exchange or os.environ.get("PCM_HEAD_GRAD_EXCHANGE", "fp32")
+        if self.head_grad_exchange not in ("fp32", "bf16"):
+            raise ValueError("head_grad_exchange must be 'fp32' or 'bf16'")
         self.adv_lr_dev = torch.full((1,), float(adv_lr), dtype=torch.float32, device=self.device)
 
     def step_adv(self, global_step, latents, prompt_embeds, uncond_prompt_embeds, noise, index, w, noise_fake, noise_real, adv_u,
@@ -594,7 +610,15 @@ class AdvDistiller(Distiller):
         back-propagate -- 9 collectives per discriminator step instead of one 2.66 GB all-reduce at its end (fp32 like the
         reference's DDP, and only on discriminator steps: generator steps never call this)"""
         if self.world_size > 1:
-            self._disc_works.append(torch.distributed.all_reduce(self.disc.grads[off0:off1], op=torch.distributed.ReduceOp.SUM, group=self.pg, async_op=True))
+            g = self.disc.grads[off0:off1]
+            if self.head_grad_exchange == "bf16" and self.loss_scale_dev is None:
+                h = ops.cast_bf16(g)                   # C-ABI cast kernel into a staging buffer that lives until the bucket is widened back
+                wk = torch.distributed.all_reduce(h, op=torch.distributed.ReduceOp.SUM, group=self.pg, async_op=True)
+                self._disc_works.append((wk, h, g))
+                self._log_bucket("heads[%d:%d]" % (off0, off1), h.numel() * 2, "bf16")
+            else:
+                self._disc_works.append((torch.distributed.all_reduce(g, op=torch.distributed.ReduceOp.SUM, group=self.pg, async_op=True), None, g))
+                self._log_bucket("heads[%d:%d]" % (off0, off1), g.numel() * 4, "fp32")
 
     def _disc_finish_exchange(self):
         """wait for the per-tap buckets launched from inside the head backward (or, if none were, reduce the whole buffer)"""
@@ -602,8 +626,10 @@ class AdvDistiller(Distiller):
         if self.world_size <= 1:
             return
         if getattr(self, "_disc_works", None):
-            for wk in self._disc_works:
+            for wk, h, g in self._disc_works:
                 wk.wait()
+                if h is not None:        # 16-bit exchange: the summed bucket back into the fp32 gradient buffer the optimizer reads
+                    ops.cast_f32(h, out=g)
             self._disc_works = []
         else:
             torch.distributed.all_reduce(d.grads, op=torch.distributed.ReduceOp.SUM, group=self.pg)

@@ -79,7 +79,7 @@ def parse_args(argv=None):
     p.add_argument("--mixed_precision", type=str, default=None, choices=["no", "fp16", "bf16"])
     p.add_argument("--allow_tf32", action="store_true")
     p.add_argument("--cast_teacher_unet", action="store_true")
-    p.add_argument("--teacher_precision", type=str, default="same", choices=["same", "fp16"], help=TEACHER_PRECISION_HELP)
+    p.add_argument("--teacher_precision", type=str, default="reference", choices=["reference", "same", "fp16"], help=TEACHER_PRECISION_HELP)
     p.add_argument("--enable_xformers_memory_efficient_attention", action="store_true")
     p.add_argument("--gradient_checkpointing", action="store_true")
     p.add_argument("--local_rank", type=int, default=-1)
@@ -275,9 +275,10 @@ def apply_mixed_precision(args):
 
 
 TEACHER_PRECISION_HELP = ("format of the ODE-solver teacher pass.  The reference runs it under torch.autocast('cuda') with no dtype "
-                          "(train_pcm_lora_sd15.py:1218), i.e. in IEEE half whatever --mixed_precision says; 'fp16' reproduces that next to a "
-                          "bfloat16 student (a second, half packing of the frozen weights: +1.7 GB at SD1.5 size).  'same' (default): one format "
-                          "for every pass, one weight packing")
+                          "(train_pcm_lora_sd15.py:1217-1218), i.e. in IEEE half whatever --mixed_precision says.  'reference' (default, round 6): "
+                          "follow that -- IEEE half next to a bfloat16 student (a second, half packing of the frozen weights: +1.7 GB at SD1.5 "
+                          "size; the step costs ~1.5 %% more), one format under --mixed_precision=fp16; 'fp16': the same, named explicitly; "
+                          "'same': one format for every pass, one weight packing (what bench.py measures: BASELINE.json's configs say bf16)")
 
 
 def teacher_weights_for(args, ucfg, sd, device, weights_cls=None):
@@ -287,11 +288,15 @@ def teacher_weights_for(args, ucfg, sd, device, weights_cls=None):
     from pcm_amd import precision
     if weights_cls is None:
         from pcm_amd.model import UNetWeights as weights_cls
-    if getattr(args, "teacher_precision", "same") != "fp16" or precision.precision() == "fp16":
+    mode = getattr(args, "teacher_precision", "reference")
+    if mode == "reference":      # the reference's dtype-less autocast: IEEE half for the teacher pass in every run
+        mode = "fp16"
+    if mode != "fp16" or precision.precision() == "fp16":
         return None
     with precision.format_scope("fp16"):
         Wt = weights_cls(ucfg, sd, device, need_bwd=False)
-    logger.info("--teacher_precision=fp16: ODE-solver teacher pass in IEEE half (lib/libpcm_hip_f16.so) next to the bfloat16 student")
+    logger.info("--teacher_precision=%s: ODE-solver teacher pass in IEEE half (lib/libpcm_hip_f16.so) next to the bfloat16 student, as the "
+                "reference's torch.autocast('cuda') without a dtype" % getattr(args, "teacher_precision", "reference"))
     return Wt
 
 

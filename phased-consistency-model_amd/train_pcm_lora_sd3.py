@@ -91,7 +91,7 @@ def parse_args(argv=None):
     p.add_argument("--allow_tf32", action="store_true")
     p.add_argument("--report_to", type=str, default="tensorboard")
     p.add_argument("--mixed_precision", type=str, default=None, choices=["no", "fp16", "bf16"])
-    p.add_argument("--teacher_precision", type=str, default="same", choices=["same", "fp16"], help=base.TEACHER_PRECISION_HELP)
+    p.add_argument("--teacher_precision", type=str, default="reference", choices=["reference", "same", "fp16"], help=base.TEACHER_PRECISION_HELP)
     p.add_argument("--prior_generation_precision", type=str, default=None)
     p.add_argument("--local_rank", type=int, default=-1)
     p.add_argument("--num_euler_timesteps", type=int, default=50)

@@ -50,6 +50,10 @@ def case_groupnorm(dev, B, HW, C, G, act, eps=1e-5):
     close(stats2, stats, 1e-5, 1e-3, "gn stats atomic vs partials")
     close(y2, y, 1e-6, 1e-2, "gn fwd atomic vs partials")
     close(dx2, dx, 1e-6, 2e-2, "gn bwd atomic vs partials")
+    # round 6: the skip-path gradient joins in the apply pass (pcm_groupnorm_bwd_apply_res): dx + dres with ONE rounding of the sum
+    dres = rnd(B, HW, C, seed=5, dev=dev)
+    dx3 = ops.groupnorm_bwd(x, dy, stats, gamma, beta, G, eps, act, dres=dres)
+    close(dx3.permute(0, 2, 1), xr.grad + dres.float().cpu().permute(0, 2, 1), 1e-2, 2e-2, "gn bwd + residual gradient")
 
 
 def case_layernorm(dev, M, C):
@@ -338,6 +342,28 @@ def case_reproducible_reductions(dev, big=False):
         y, st = ops.groupnorm_fwd(xg, gam, bet, 32, 1e-5, 1)
         out["gn_y"], out["gn_stats"] = y, st.clone()
         out["gn_dx"] = ops.groupnorm_bwd(xg, rnd(B, Hs * Hs, 4 * C, seed=14, dev=dev), st, gam, bet, 32, 1e-5, 1)
+        # round 6 (abi 5): the discriminator heads' parameter gradients (discriminator_sd15.py:348-434) and the MMDiT modulation gradients
+        dgn = rnd(B, Hs * Hs, 4 * C, seed=15, dev=dev)
+        dgam, dbet = torch.full((4 * C,), 0.5, dtype=torch.float32, device=dev), torch.full((4 * C,), -0.25, dtype=torch.float32, device=dev)
+        ops.groupnorm_param_grad(xg, dgn, st, gam, bet, dgam, dbet, 32, 1e-5, capi.ACT_LEAKY)           # adds into pre-filled buffers
+        out["gn_dgamma"], out["gn_dbeta"] = dgam, dbet
+        Mr = B * Hs * Hs
+        xr, wr = rnd(Mr, 4 * C, seed=16, dev=dev), rnd(4 * C, seed=17, dtype=torch.float32, dev=dev)
+        dyr = rnd(Mr, seed=18, dtype=torch.float32, dev=dev)
+        dw, db = torch.full((4 * C,), 2.0, dtype=torch.float32, device=dev), torch.full((1,), 3.0, dtype=torch.float32, device=dev)
+        out["rowdot_dx"] = ops.rowdot_bwd(xr, wr, dyr, dw, db)
+        out["rowdot_dw"], out["rowdot_db"] = dw, db
+        mean, rstd = rnd(Mr, seed=19, dtype=torch.float32, dev=dev), rnd(Mr, seed=20, dtype=torch.float32, dev=dev).abs() + 0.5
+        out["mod_a"], out["mod_b"] = ops.mod_grad(xg, dgn, B, mean, rstd)
+        out["mod_gate"], _ = ops.mod_grad(xg, dgn, B, want_b=False)
+        lsum = torch.zeros(1, dtype=torch.float64, device=dev)
+        fk, rl = rnd(Mr, seed=21, dtype=torch.float32, dev=dev), rnd(Mr, seed=22, dtype=torch.float32, dev=dev)
+        out["hinge_df"], out["hinge_dr"] = ops.hinge_loss(fk, rl, 0, 0.25, lsum)
+        ops.hinge_loss(fk, None, 1, 0.25, lsum)
+        out["hinge_loss"] = lsum.clone()
+        bias = torch.empty(4 * C, dtype=torch.float32, device=dev)
+        ops.colsum_into(xr, bias, Mr, 4 * C)
+        out["bias_sum"] = bias
         return {k: v.detach().cpu().clone() for k, v in out.items()}
 
     assert not ops.DETERMINISTIC
@@ -354,7 +380,7 @@ def case_reproducible_reductions(dev, big=False):
     for k in fast:
         assert torch.equal(det1[k], det2[k]), "reproducible form of %s differs between two runs" % k
         a, b = det1[k].double(), fast[k].double()
-        tol = 1e-12 if a.dtype == torch.float64 and k in ("sumsq", "loss", "gn_stats") else 2e-5
+        tol = 1e-12 if a.dtype == torch.float64 and k in ("sumsq", "loss", "gn_stats", "hinge_loss") else 2e-5
         assert float((a - b).abs().max()) <= tol * max(1.0, float(b.abs().max())) + (1e-2 if k in ("gn_y", "gn_dx") else 0.0), \
             (k, float((a - b).abs().max()), float(b.abs().max()))
 

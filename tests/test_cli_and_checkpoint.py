@@ -106,7 +106,7 @@ def test_capi_exports_every_declared_symbol():
             assert hasattr(L.dll, name), f"{name} declared in include/pcm_hip.h but not exported by the {variant} build"
         # ... and the pcm_debug_* hooks (declared nowhere in the header) only in the TOOLS builds
         assert hasattr(L.dll, "pcm_debug_gemm_big_mode") == variant.startswith("tools"), variant
-    queries = {n for n in declared if n.endswith("_workspace_bytes")} | {"pcm_last_error", "pcm_abi_version", "pcm_act_dtype", "pcm_gemm_plan_code", "pcm_gemm_emits_chstats"}
+    queries = {n for n in declared if n.endswith("_workspace_bytes")} | {"pcm_last_error", "pcm_abi_version", "pcm_build_id", "pcm_act_dtype", "pcm_gemm_plan_code", "pcm_gemm_emits_chstats"}
     assert declared - queries == set(capi._PROTOS), (declared - queries) ^ set(capi._PROTOS)
 
 
@@ -389,6 +389,8 @@ def test_sd3_clis_end_to_end_on_the_emulator(tmp_path, monkeypatch):
     monkeypatch.setenv("PCM_CLI_DEVICE", "cpu")
     monkeypatch.delenv("WORLD_SIZE", raising=False)
     capi.set_lib(emu_lib())
+    from pcm_amd import precision
+    precision.register_lib("fp16", emu_lib("f16"))      # --teacher_precision defaults to the reference's split: the teacher pass runs in the half build
     try:
         out = tmp_path / "out"
         common = ["--pretrained_teacher_model", "random", "--tiny_model", "--latents_dir", str(shards), "--train_batch_size", "2", "--lora_rank", "32",
@@ -454,6 +456,8 @@ def test_unet_clis_end_to_end_on_the_emulator(tmp_path, monkeypatch):
     monkeypatch.setenv("PCM_CLI_DEVICE", "cpu")
     monkeypatch.delenv("WORLD_SIZE", raising=False)
     capi.set_lib(emu_lib())
+    from pcm_amd import precision
+    precision.register_lib("fp16", emu_lib("f16"))      # --teacher_precision defaults to the reference's split: the teacher pass runs in the half build
     try:
         def args(out, shards, extra):
             return ["--pretrained_teacher_model", "random", "--tiny_model", "--latents_dir", str(shards), "--train_batch_size", "1", "--learning_rate", "1e-3",
@@ -530,3 +534,34 @@ def test_scheduler_position_follows_accelerate_per_script():
     for ref, mult in (("/root/reference/code/text_to_image_sd15/train_pcm_lora_sd15.py", False), ("/root/reference/code/text_to_image_sd3/train_pcm_lora_sd3.py", True)):
         if os.path.exists(ref):
             assert ("num_warmup_steps=args.lr_warmup_steps * accelerator.num_processes" in open(ref).read()) == mult
+
+
+def test_build_staleness_is_keyed_on_content_not_on_file_times(tmp_path, monkeypatch):
+    """round-5 review, item 9: build() decided by mtime, so a snapshot could run binaries older than its sources.  Now every object / library
+    carries a content stamp (sha256 of its source, every header and its flags): an edit with the file time restored is stale, a touch is not;
+    the library exports the identity of ALL its sources (pcm_build_id) and capi refuses one of the tree's own libraries with another id."""
+    import os
+    from pcm_amd import build as B
+    from pcm_amd import capi
+    src, hdr, out = tmp_path / "k.hip", tmp_path / "k.h", str(tmp_path / "k.o")
+    src.write_text("int a;\n"); hdr.write_text("#define X 1\n")
+    st = os.stat(src)
+    stamp = B._digest([str(src), str(hdr)], ["-O3"])
+    assert B._stale(out, stamp)                      # nothing built yet
+    open(out, "w").write("obj"); B._mark(out, stamp)
+    assert not B._stale(out, stamp)
+    os.utime(src, (st.st_atime + 100, st.st_mtime + 100))                      # touched, same content: still current
+    assert not B._stale(out, B._digest([str(src), str(hdr)], ["-O3"]))
+    src.write_text("int b;\n"); os.utime(src, (st.st_atime, st.st_mtime))       # edited, file time restored: stale
+    assert B._stale(out, B._digest([str(src), str(hdr)], ["-O3"]))
+    hdr.write_text("#define X 2\n")
+    assert B._digest([str(src), str(hdr)], ["-O3"]) != B._digest([str(src), str(hdr)], ["-O3", "-DPCM_TOOLS"])
+    # the tree's own library names this tree's sources ...
+    L = capi.Lib(capi.DEFAULT_LIB)
+    assert L.build_id == B.source_id() + "-bf16" and L.dll.pcm_abi_version() >= 5
+    # ... and one built from other sources is refused
+    monkeypatch.setattr(B, "source_id", lambda: "0123456789abcdef")
+    with pytest.raises(RuntimeError, match="built from other sources"):
+        capi.Lib(capi.DEFAULT_LIB)
+    monkeypatch.setenv("PCM_ALLOW_STALE_LIB", "1")
+    capi.Lib(capi.DEFAULT_LIB)

@@ -289,7 +289,7 @@ def test_sd3_two_rank_step_matches_single_process_on_the_global_batch(tmp_path):
     assert cos > 0.9 and 0.8 < float(u2.norm() / u1.norm()) < 1.25
 
 
-def _adv_worker(rank, world, port, outdir, global_step):
+def _adv_worker(rank, world, port, outdir, global_step, exchange="fp32"):
     """One adversarial step (even: discriminator update, odd: generator update) of a tiny UNet + heads on this rank's shard."""
     sys.path[:0] = [ROOT, os.path.join(ROOT, "phased-consistency-model_amd"), os.path.join(ROOT, "tests")]
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -310,7 +310,7 @@ def _adv_worker(rank, world, port, outdir, global_step):
     lora = LoraState(UNetConfig(**kw), 64, 8.0, "cpu", seed=5, b_std=0.05)
     disc = Discriminator((64, 128, 128, 128, 64), num_h_per_head=2, device="cpu", seed=2)
     D = AdvDistiller(W, lora, StepConfig(multiphase=2, loss_type="huber", learning_rate=1e-3, w_min=4.0, w_max=5.0), disc, adv_weight=0.1, adv_lr=1e-3,
-                     world_size=world)
+                     world_size=world, head_grad_exchange=exchange)
     G = 4
     inp = OS.draw_inputs(G, OS.StepConfig(multiphase=2), seed=11, latent_hw=8, ctx_len=7, ctx_dim=64)
     g = torch.Generator().manual_seed(9)
@@ -327,8 +327,12 @@ def _adv_worker(rank, world, port, outdir, global_step):
     if world > 1 and global_step % 2 == 0:      # one bucket per tapped feature, covering the whole flat buffer exactly once, in order
         assert len(buckets) == 5 and buckets[0][0] == 0 and buckets[-1][1] == disc.numel
         assert all(a[1] == b[0] for a, b in zip(buckets, buckets[1:]))
+    if world > 1 and global_step % 2 == 0:      # what went over the wire, in issue order (bench.py prints this list)
+        want = ("bf16", 2) if exchange == "bf16" else ("fp32", 4)
+        assert [(d, nb) for _, nb, d in D.bucket_log] == [(want[0], (b - a) * want[1]) for a, b in buckets], D.bucket_log
+    tag = "" if exchange == "fp32" else "_" + exchange
     torch.save((lora.params - p_l0, disc.params - p_d0, (disc.grads if global_step % 2 == 0 else lora.grads).clone() / world),
-               os.path.join(outdir, f"a{global_step}w{world}r{rank}.pt"))
+               os.path.join(outdir, f"a{global_step}w{world}r{rank}{tag}.pt"))
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
@@ -361,3 +365,30 @@ def test_adversarial_two_rank_step_matches_single_process_on_the_global_batch(tm
             gs, cosine(g0, gs1), float(g0.norm() / gs1.norm()), cosine(moved, ref)))
         assert cosine(g0, gs1) > 0.95 and 0.85 < float(g0.norm() / gs1.norm()) < 1.18
         assert cosine(moved, ref) > 0.8 and 0.8 < float(moved.norm() / ref.norm()) < 1.25
+
+
+def test_adversarial_head_gradients_exchanged_in_bf16_bound_the_update_deviation(tmp_path):
+    """SURVEY 8e / round-5 review item 8: the 2.66 GB of fp32 head gradients of a discriminator step may cross xGMI as bfloat16
+    (AdvDistiller(head_grad_exchange="bf16"): each per-tap bucket is rounded, summed by the collective, widened back).  Against the fp32
+    exchange of the same two ranks: ranks stay bitwise identical, the exchanged gradient differs by the 16-bit rounding of the per-rank
+    gradients (relative L2 <= 2^-8), and the AdamW update of the heads keeps its direction."""
+    ctx = mp.get_context("spawn")
+    runs = {}
+    for exchange, port in (("fp32", 29781), ("bf16", 29791)):
+        ps = [ctx.Process(target=_adv_worker, args=(r, 2, port, str(tmp_path), 0, exchange)) for r in range(2)]
+        for p in ps:
+            p.start()
+        for p in ps:
+            p.join(900)
+            assert p.exitcode == 0
+        tag = "" if exchange == "fp32" else "_bf16"
+        (l0, d0, g0), (l1, d1, g1) = (torch.load(os.path.join(str(tmp_path), f"a0w2r{r}{tag}.pt")) for r in range(2))
+        assert torch.equal(d0, d1) and torch.equal(g0, g1), "ranks diverged under the %s exchange" % exchange
+        assert float(l0.abs().max()) == 0.0
+        runs[exchange] = (d0, g0)
+    (d32, g32), (d16, g16) = runs["fp32"], runs["bf16"]
+    rel = float((g16.double() - g32.double()).norm() / g32.double().norm())
+    cos_u = float((d16.double() * d32.double()).sum() / (d16.double().norm() * d32.double().norm()))
+    print("head gradients bf16 vs fp32 exchange: rel-L2 %.2e, update cosine %.4f" % (rel, cos_u))
+    assert 0.0 < rel <= 2.0 ** -8, rel
+    assert cos_u > 0.97, cos_u

@@ -74,7 +74,10 @@ def test_adv_steps_graph_replay_equals_eager():
         lg = float(og[key])
         oe = De.step_adv(step, *a)
         le = float(oe[key])
-        assert abs(lg - le) <= 1e-5 * abs(le) + 1e-9, (step, key, lg, le)
+        # (step 0 sees identical state; later steps see states that differ by the fp32-atomics order of the earlier updates -- under the half build's
+        #  11-bit significands that showed as 1.5e-4 on the fourth step in one of six runs, profiles/r06_f_*; the bitwise form of this
+        #  comparison runs under set_deterministic: tests/test_gpu_deterministic_adv.py)
+        assert abs(lg - le) <= (1e-5 if step == 0 else 5e-4) * abs(le) + 1e-9, (step, key, lg, le)
     rel = lambda x, y: float((x - y).norm() / (y.norm() + 1e-30))
     # Adam divides by sqrt(v): on entries whose gradient is at the fp32-atomics noise level the update direction itself is noise, so the
     # states agree to a fraction of one lr-sized step (lr 1e-4 against |param| ~ 2e-2), not bitwise

@@ -34,6 +34,15 @@ S, nS, durS = load(sys.argv[1])
 F, nF, _ = load(sys.argv[2])
 Wr, nW, _ = load(sys.argv[3])
 rows = sorted(S, key=lambda k: -durS[k])[: int(sys.argv[4]) if len(sys.argv) > 4 else 32]
+# the table names the kernel sources it was measured on (round 6): bench.py copies the dominant kernel's row into its JSON line only next to
+# this stamp and marks it STALE when the stamp is not the id of the library it runs (pcm_amd/build.py source_id)
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "phased-consistency-model_amd"))
+try:
+    from pcm_amd import build as _build
+    print("# source_id: %s" % _build.source_id())
+except Exception as e:      # (a table without a stamp is reported as unstamped by bench.py)
+    print("# source_id unavailable: %s" % e)
 print("%-58s %5s %8s %9s %9s %8s %9s %9s %8s" % ("kernel", "calls", "dur_ms", "mfma_util", "valu/mfma", "wait_any", "rd_MB/l", "wr_MB/l", "GB/s"))
 tot = 0.0
 for k in rows:
