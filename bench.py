@@ -146,7 +146,7 @@ def bench_other_config(args, world, rank, local_rank, dev, sync):
                     4.0 + torch.rand(B, generator=g, device=dev), rn(B, 4, 64, 64), rn(B, 4, 64, 64), torch.rand(B, generator=g, device=dev)]
         state = {"gs": 0}
 
-        def step(b):
+        def step(b, nxt=None):
             f = D.step_adv_graphed if use_graph else D.step_adv
             out = f(state["gs"], *b)
             state["d" if state["gs"] % 2 == 0 else "g"] = out
@@ -176,15 +176,17 @@ def bench_other_config(args, world, rank, local_rank, dev, sync):
         uac = dict(text_embeds=torch.zeros(B, 1280, device=dev), time_ids=tids)
         un = torch.zeros(B, 77, 2048, device=dev)
         use_graph = not args.no_graph
+        pipe = not args.no_prefetch          # the next batch's teacher pass beside this batch's student work (trainer.Distiller.step(prefetch=...))
         if use_graph:
-            D.capture(B, H=128, W=128, ctx_len=77, ctx_dim=2048, added_cond=ac, uncond_added_cond=uac)
+            D.capture(B, H=128, W=128, ctx_len=77, ctx_dim=2048, added_cond=ac, uncond_added_cond=uac, pipeline=pipe)
 
         def draw():
             return [rn(B, 4, 128, 128), rn(B, 77, 2048), un, rn(B, 4, 128, 128), torch.randint(0, 40, (B,), generator=g, device=dev),
                     6.0 + torch.rand(B, generator=g, device=dev)]
 
-        def step(b):
-            return (D.step_graphed if use_graph else D.step)(*b, added_cond=ac, uncond_added_cond=uac)
+        def step(b, nxt=None):
+            return (D.step_graphed if use_graph else D.step)(*b, added_cond=ac, uncond_added_cond=uac,
+                                                             prefetch=(tuple(nxt) + (ac, uac)) if (pipe and nxt is not None) else None)
         workload = "SDXL PCM-LoRA distillation step (2.57B UNet, text_time conditioning), 4 phases, 128x128x4 latents (1024 px), per-GPU batch %d, LoRA r=64" % B
         metric = "distillation images/sec SDXL 1024px"
     else:
@@ -207,19 +209,20 @@ def bench_other_config(args, world, rank, local_rank, dev, sync):
             return [rn(B, 16, 128, 128), rn(B, 154, 4096), rn(B, 2048), rn(B, 154, 4096), rn(B, 2048), rn(B, 16, 128, 128),
                     torch.randint(0, 100, (B,), generator=g, device=dev)]
 
-        def step(b):
+        def step(b, nxt=None):
             return (D.step_graphed if use_graph else D.step)(*b)
         workload = "SD3-medium (MMDiT 2.03B, 4096 image + 154 text tokens) PCM-LoRA distillation step, 2 phases, 128x128x16 latents, per-GPU batch %d, LoRA r=32" % B
         metric = "distillation images/sec SD3-medium 1024px"
     torch.cuda.synchronize()
     log("%s: model ready (%.1f GB allocated), %s" % (cfgname, torch.cuda.memory_allocated() / 2**30, "hipGraph replay" if use_graph else "eager"))
     batches = [draw() for _ in range(args.warmup + args.steps)]
-    for b in batches[:args.warmup]:
-        step(b)
+    nb = len(batches)
+    for i in range(args.warmup):
+        step(batches[i], batches[(i + 1) % nb])
     sync()
     t0 = time.perf_counter()
-    for b in batches[args.warmup:]:
-        step(b)
+    for i in range(args.warmup, nb):
+        step(batches[i], batches[(i + 1) % nb])      # (c4: the next batch is announced, also in the last timed step -- one teacher pass per step)
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -320,6 +323,10 @@ def main():
     ap.add_argument("--deterministic", action="store_true",
                     help="reproducible reductions (ops.set_deterministic: slabs / partials + ordered finalize instead of fp32 / fp64 atomics; "
                          "bitwise identical steps run to run) -- NOT the headline configuration, a cost measurement")
+    ap.add_argument("--no-prefetch", action="store_true",
+                    help="(c2) the step as ONE launch chain.  Default: the frozen teacher's pass of batch k+1 is issued on a second HIP stream beside the "
+                         "student's forward / backward on batch k (cross-step prefetch of the teacher targets, trainer.Distiller.step(prefetch=...)): "
+                         "every timed step still runs exactly one teacher pass, one two-timestep student pass, one backward and one optimizer step")
     ap.add_argument("--teacher-fp16", action="store_true",
                     help="(c2, bf16) the ODE-solver teacher pass in IEEE half next to the bfloat16 student, as the reference's dtype-less "
                          "torch.autocast('cuda') does (train_pcm_lora_sd15.py:1218); a second packing of the frozen weights.  NOT the headline configuration")
@@ -408,9 +415,10 @@ def main():
     batches = [draw() for _ in range(args.warmup + args.steps)]   # resident in HBM before timing
 
     use_graph = not args.no_graph
+    pipeline = not args.no_prefetch
     if use_graph:
         try:
-            D.capture(B)
+            D.capture(B, pipeline=pipeline)
             torch.cuda.synchronize()
             log("step captured into hipGraphs")
         except RuntimeError as e:      # same launches issued eagerly: slower on the host side, identical device work
@@ -418,9 +426,13 @@ def main():
             use_graph = False
             D._graph = None
 
-    def run(b, eager=False):
+    def tup(b):
+        return (b["latents"], b["prompt_embeds"], uncond, b["noise"], b["index"], b["w"])
+
+    def run(b, eager=False, nxt=None):
+        """one step on batch ``b``; ``nxt``: the batch of the next call (its teacher targets are computed beside this step's student work)"""
         f = D.step if (eager or not use_graph) else D.step_graphed
-        return f(b["latents"], b["prompt_embeds"], uncond, b["noise"], b["index"], b["w"])
+        return f(*tup(b), prefetch=tup(nxt) if (pipeline and nxt is not None) else None)
 
     def sync():
         if world > 1:
@@ -431,8 +443,9 @@ def main():
         torch.cuda.synchronize()
 
     log("rank %d: batches ready" % rank)
+    nb = len(batches)
     for i, b in enumerate(batches[:args.warmup]):
-        run(b)
+        run(b, nxt=batches[(i + 1) % nb])
         torch.cuda.synchronize()
         log("rank %d: warmup step %d done" % (rank, i))
     sync()
@@ -440,8 +453,9 @@ def main():
         D.comm_events = []
     t0 = time.perf_counter()
     last = None
-    for b in batches[args.warmup:]:
-        last = run(b)
+    for i in range(args.warmup, nb):
+        # (the last timed step announces batch 0 again: every timed step carries one teacher pass, the pipeline is never drained inside the region)
+        last = run(batches[i], nxt=batches[(i + 1) % nb])
     t_enq = time.perf_counter() - t0        # host time to ENQUEUE the steps (launch-bound if ~= dt)
     sync()
     dt = time.perf_counter() - t0
@@ -612,7 +626,9 @@ def main():
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
                 "config": {"workload": "SD1.5 PCM-LoRA distillation step, %d phases, 64x64x4 latents, per-GPU batch %d, "
                                        "LoRA r=64 (67.25M trainable), huber, AdamW, random-init UNet (859.5M)" % (args.multiphase, B),
-                           "global_batch": world * B, "parallelism": "dp%d" % world, "comm": comm, "launch": "hipGraph replay" if use_graph else "eager", "reductions": "reproducible" if args.deterministic else "atomics", "teacher_pass": "fp16" if (Wt is not None or args.precision == "fp16") else "bf16", "loss_last": round(loss, 6),
+                           "global_batch": world * B, "parallelism": "dp%d" % world, "comm": comm, "launch": "hipGraph replay" if use_graph else "eager",
+                           "teacher_prefetch": ("next batch's teacher pass on a second stream beside this batch's student forward / backward (same work per step, "
+                                                "same numbers; --no-prefetch: one launch chain)") if pipeline else "off", "reductions": "reproducible" if args.deterministic else "atomics", "teacher_pass": "fp16" if (Wt is not None or args.precision == "fp16") else "bf16", "loss_last": round(loss, 6),
                            "host_ms_per_step_idle_queue": round(host_idle_ms, 2)},
                 "roofline": roofline, "cpu_baseline": cpu, "build_id": capi.lib().build_id}
         print(json.dumps(line), flush=True)

@@ -160,6 +160,7 @@ class Distiller:
         self.lr_dev = torch.full((1,), float(cfg.learning_rate), dtype=torch.float32, device=self.device)
         self._graph = None
         self._late_work = None
+        self._side, self._prefetched = None, None        # cross-step teacher prefetch (step(prefetch=...) / capture(pipeline=True))
         # fp16 build (precision.set_precision("fp16"), the reference's --mixed_precision=fp16): the backward runs on S * d(loss) with the
         # GradScaler state in device memory (S = 65536 at start, x2 after 2000 finite steps, x0.5 and no update after a non-finite
         # gradient norm: torch.cuda.amp.GradScaler defaults, which accelerate uses at train_pcm_lora_sd15.py:1034) -- capturable.
@@ -201,11 +202,13 @@ class Distiller:
         t = torch.clamp(start - self.tables.topk, min=0)
         return start, t
 
-    def forward_backward(self, latents, prompt_embeds, uncond_prompt_embeds, noise, index, w, backward=True, added_cond=None,
-                         uncond_added_cond=None, grad_scale=1.0, zero_grad=True, on_late=None):
-        """Everything of the step before the gradient exchange: returns a dict of device tensors.
-        ``added_cond`` / ``uncond_added_cond``: SDXL ``added_cond_kwargs`` ({'text_embeds': [B,1280], 'time_ids': [B,6]},
-        train_pcm_lora_sdxl_adv.py:1113-1131, :1409-1421) for UNets with text_time conditioning; None for SD1.5."""
+    # ---- the part of the step that depends on nothing trainable: noisy latents, the frozen teacher's [cond; uncond] pass, the CFG DDIM step
+    TARGET_KEYS = ("noisy", "start_t", "t_n", "eps_c", "eps_u", "x_prev64", "x_prev32")
+
+    def teacher_targets(self, latents, prompt_embeds, uncond_prompt_embeds, noise, index, w, added_cond=None, uncond_added_cond=None):
+        """train_pcm_lora_sd15.py:1143-1178 + :1217-1258: timesteps, add_noise, teacher cond / uncond forward, CFG-augmented DDIM solver step.
+        A pure function of the batch and the FROZEN weights (the LoRA state is not read), which is what lets ``step(..., prefetch=next
+        batch)`` run it for the next batch on a side stream while the student works on the current one."""
         def cat2(a, b_):
             return None if a is None else {k: torch.cat([a[k], (b_ if b_ is not None else a)[k]]) for k in a}
         cfg, T = self.cfg, self.tables
@@ -213,7 +216,6 @@ class Distiller:
         start_t, t_n = self.timesteps_for(index)
         noisy = ops.add_noise(latents, noise, T.acp, start_t)                                   # :1178
         # teacher cond (+ uncond) in ONE batched forward (no grad, no LoRA) --------------------- :1217-1252
-        # (scheduled first: the online forward does not depend on it, the target forward does)
         with self._ode_scope():     # (the other 16-bit build for this pass when the teacher was packed in it: Distiller.__init__)
             if cfg.not_apply_cfg_solver:
                 eps_c = self.teacher_ode.forward(noisy, start_t, prompt_embeds, added_cond=added_cond)
@@ -225,6 +227,22 @@ class Distiller:
                                                 dup_halves=DEDUP_TEACHER_PREFIX)
                 eps_c, eps_u = both[:B], both[B:]
         x_prev64, x_prev32 = ops.cfg_ddim_step(eps_c, eps_u, noisy, start_t, index, w, T.acp, T.acp_prev)   # :1254-1258
+        return dict(noisy=noisy, start_t=start_t, t_n=t_n, eps_c=eps_c, eps_u=eps_u, x_prev64=x_prev64, x_prev32=x_prev32)
+
+    def forward_backward(self, latents, prompt_embeds, uncond_prompt_embeds, noise, index, w, backward=True, added_cond=None,
+                         uncond_added_cond=None, grad_scale=1.0, zero_grad=True, on_late=None, targets=None):
+        """Everything of the step before the gradient exchange: returns a dict of device tensors.
+        ``added_cond`` / ``uncond_added_cond``: SDXL ``added_cond_kwargs`` ({'text_embeds': [B,1280], 'time_ids': [B,6]},
+        train_pcm_lora_sdxl_adv.py:1113-1131, :1409-1421) for UNets with text_time conditioning; None for SD1.5.
+        ``targets``: the result of ``teacher_targets`` for THIS batch when it was computed ahead (cross-step prefetch); None: computed here,
+        first -- the online forward does not depend on it, the target forward does."""
+        def cat2(a, b_):
+            return None if a is None else {k: torch.cat([a[k], (b_ if b_ is not None else a)[k]]) for k in a}
+        cfg, T = self.cfg, self.tables
+        B = latents.shape[0]
+        if targets is None:
+            targets = self.teacher_targets(latents, prompt_embeds, uncond_prompt_embeds, noise, index, w, added_cond, uncond_added_cond)
+        noisy, start_t, t_n, eps_c, eps_u, x_prev64, x_prev32 = (targets[k] for k in self.TARGET_KEYS)
         if self.fuse_online_target:
             # online student forward at t_{n+k} (grad, :1192) and target forward at (x_prev, t_n) (same online weights incl.
             # LoRA, no grad, :1261-1268) as ONE 2B-sample schedule: samples are independent, so each half is exactly the
@@ -255,18 +273,49 @@ class Distiller:
         self.student.backward(d_eps, tape, on_late=on_late)                                      # :1296
         return out
 
+    # ---- cross-step prefetch of the teacher targets (round 6).  The frozen teacher's pass of batch k+1 depends on nothing the student's
+    # work on batch k produces, and on this chip two independent passes issued on two HIP streams finish 6 % sooner than back to back
+    # (blocks of one fill the CUs the other's under-filled deep-level launches leave idle: 69.9 -> 65.7 ms for backward + teacher,
+    # profiles/r06_g_*).  Results are the same numbers: only the launch order changes.
+    def _prefetch(self, batch):
+        """issue teacher_targets(batch) on the side stream; ``batch`` = (latents, prompt_embeds, uncond_prompt_embeds, noise, index, w[, added_cond,
+        uncond_added_cond]) of the NEXT step() call"""
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream() if self.device.type == "cuda" else False
+        key = tuple(t.data_ptr() for t in batch[:6])
+        if self._side:
+            self._side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._side):
+                tg = self.teacher_targets(*batch)
+        else:
+            tg = self.teacher_targets(*batch)              # (host emulator: same call order, no streams)
+        self._prefetched = (key, tg, batch)                # (the batch tensors stay referenced: the key is their addresses)
+
+    def _take_prefetched(self, batch):
+        pf, self._prefetched = getattr(self, "_prefetched", None), None
+        if pf is None:
+            return None
+        if self._side:
+            torch.cuda.current_stream().wait_stream(self._side)
+        return pf[1] if pf[0] == tuple(t.data_ptr() for t in batch) else None
+
     def step(self, latents, prompt_embeds, uncond_prompt_embeds, noise, index, w, lr=None, update=True, added_cond=None,
-             uncond_added_cond=None, accum=None):
+             uncond_added_cond=None, accum=None, prefetch=None):
         """One distillation step on this rank's batch (eager launches).  All inputs are device tensors:
         latents/noise [B,4,H,W] fp32, prompt embeds [B,77,768], index [B] int64, w [B] fp32.
         Returns a dict of device tensors (no host sync).
         ``accum=(i, k)``: micro-batch i of k under ``--gradient_accumulation_steps k`` (``accelerator.accumulate``, :1120): the loss
-        gradient is scaled by 1/k, gradients add up over the k calls, and exchange + clip + AdamW run with the last one only."""
+        gradient is scaled by 1/k, gradients add up over the k calls, and exchange + clip + AdamW run with the last one only.
+        ``prefetch``: the NEXT call's batch (same tuple order as this call's first six arguments [+ added_cond, uncond_added_cond]): its teacher
+        targets are computed on a side stream beside this call's student work, and the next call picks them up (matched by tensor address)."""
         i, k = accum if accum is not None else (0, 1)
         bucket = self.world_size > 1 and update and i == k - 1 and self.lora.late_offset is not None and self.bucketed
+        targets = self._take_prefetched((latents, prompt_embeds, uncond_prompt_embeds, noise, index, w))
+        if prefetch is not None:
+            self._prefetch(prefetch)
         out = self.forward_backward(latents, prompt_embeds, uncond_prompt_embeds, noise, index, w, backward=update, added_cond=added_cond,
                                     uncond_added_cond=uncond_added_cond, grad_scale=1.0 / k, zero_grad=(i == 0),
-                                    on_late=self._all_reduce_late if bucket else None)
+                                    on_late=self._all_reduce_late if bucket else None, targets=targets)
         if not update or i < k - 1:
             return out
         if lr is not None:
@@ -276,11 +325,14 @@ class Distiller:
         return out
 
     # ---- hipGraph replay of the step: ~5400 launches become two graph launches --------------------
-    def capture(self, B, H=64, W=64, ctx_len=77, ctx_dim=768, added_cond=None, uncond_added_cond=None):
+    def capture(self, B, H=64, W=64, ctx_len=77, ctx_dim=768, added_cond=None, uncond_added_cond=None, pipeline=False):
         """Capture forward+backward and the optimizer as two hipGraphs around the (eager) gradient
         all-reduce.  The eager warm-up pass runs on scratch state: LoRA / Adam state is restored.
         ``added_cond`` / ``uncond_added_cond`` (SDXL text_time conditioning): example dicts; their tensors become static graph inputs
-        that step_graphed refreshes."""
+        that step_graphed refreshes.
+        ``pipeline``: the captured step holds TWO branches -- the teacher targets of the NEXT batch (static inputs ``_static_next``, results
+        into ``_tg_next``) on a forked stream, and this batch's student forward / backward on the targets a previous replay left
+        (copied to ``_tg_cur`` before the fork); step_graphed(..., prefetch=next batch) feeds it."""
         dev = self.device
         f32 = dict(dtype=torch.float32, device=dev)
         self._static = dict(latents=torch.zeros(B, 4, H, W, **f32), prompt_embeds=torch.zeros(B, ctx_len, ctx_dim, **f32),
@@ -297,19 +349,45 @@ class Distiller:
         if self.ema is not None:
             saved.append(self.ema.clone())
         count = self.step_count
+        self._pipeline, self._pipe_key = bool(pipeline), None
+        if pipeline:
+            self._static_next = {k: ({kk: vv.clone() for kk, vv in v.items()} if isinstance(v, dict) else v.clone()) for k, v in self._static.items()}
+            self._pipe_side = torch.cuda.Stream()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                      # warm-up: lazy init, allocator pools
-            self.forward_backward(**self._static)
+            if pipeline:
+                tg = self.teacher_targets(**self._static_next)
+                self._tg_next = {k: v.clone() for k, v in tg.items()}
+                self._tg_cur = {k: v.clone() for k, v in tg.items()}
+                self.forward_backward(**self._static, targets=self._tg_cur)
+            else:
+                self.forward_backward(**self._static)
             self._optimizer_apply()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+
+        def body(on_late=None, join_before_cut=None):
+            """what one replay does (non-pipelined: the plain step)"""
+            if not pipeline:
+                return self.forward_backward(**self._static, on_late=on_late)
+            cur_s = torch.cuda.current_stream()
+            for k in self.TARGET_KEYS:                     # the targets a previous replay (or the eager prologue) left for THIS batch
+                self._tg_cur[k].copy_(self._tg_next[k])
+            self._pipe_side.wait_stream(cur_s)             # fork: behind the copies, so the branch may overwrite _tg_next
+            with torch.cuda.stream(self._pipe_side):
+                tgn = self.teacher_targets(**self._static_next)
+                for k in self.TARGET_KEYS:
+                    self._tg_next[k].copy_(tgn[k])
+            out_ = self.forward_backward(**self._static, on_late=on_late, targets=self._tg_cur)
+            torch.cuda.current_stream().wait_stream(self._pipe_side)      # join (a capture must end with every forked stream joined)
+            return out_
         self._g_fb, self._g_opt, self._g_fb2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), None
         split = (self.world_size > 1 and self.bucketed and lo.late_offset is not None) or os.environ.get("PCM_SPLIT_GRAPH") == "1"
         # thread_local: the RCCL watchdog thread of a multi-rank job may query its events while this thread captures
         if not split:
             with torch.cuda.graph(self._g_fb, capture_error_mode="thread_local"):
-                self._static_out = self.forward_backward(**self._static)
+                self._static_out = body()
         else:
             # data parallel: the forward + backward is captured as TWO graphs cut where the backward leaves the mid block, so that the
             # all-reduce of the up/mid-block gradient bucket (not captured) is enqueued between them and overlaps the second graph
@@ -319,11 +397,13 @@ class Distiller:
             cap.wait_stream(torch.cuda.current_stream())
 
             def cut():
+                if pipeline:       # the teacher branch of the next batch joins the first graph (it is long done: it started with the forward)
+                    torch.cuda.current_stream().wait_stream(self._pipe_side)
                 self._g_fb.capture_end()
                 self._g_fb2.capture_begin(pool=self._g_fb.pool(), capture_error_mode="thread_local")
             with torch.cuda.stream(cap):
                 self._g_fb.capture_begin(capture_error_mode="thread_local")
-                self._static_out = self.forward_backward(**self._static, on_late=cut)
+                self._static_out = body(on_late=cut)
                 self._g_fb2.capture_end()
             torch.cuda.current_stream().wait_stream(cap)
         with torch.cuda.graph(self._g_opt, pool=self._g_fb.pool(), capture_error_mode="thread_local"):
@@ -337,10 +417,7 @@ class Distiller:
         self._static_out["grad_sumsq"] = lo.gradsq
         self._graph = True
 
-    def step_graphed(self, latents, prompt_embeds, uncond_prompt_embeds, noise, index, w, lr=None, added_cond=None, uncond_added_cond=None):
-        """Same as step() through the captured graphs.  Returned tensors are the graph's static outputs
-        (overwritten by the next call)."""
-        st = self._static
+    def _fill_static(self, st, latents, prompt_embeds, uncond_prompt_embeds, noise, index, w, added_cond=None, uncond_added_cond=None):
         st["latents"].copy_(latents); st["prompt_embeds"].copy_(prompt_embeds)
         st["uncond_prompt_embeds"].copy_(uncond_prompt_embeds); st["noise"].copy_(noise)
         st["index"].copy_(index); st["w"].copy_(w)
@@ -348,6 +425,24 @@ class Distiller:
             if val is not None:
                 for k, v in val.items():
                     st[name][k].copy_(v)
+
+    def step_graphed(self, latents, prompt_embeds, uncond_prompt_embeds, noise, index, w, lr=None, added_cond=None, uncond_added_cond=None,
+                     prefetch=None):
+        """Same as step() through the captured graphs.  Returned tensors are the graph's static outputs
+        (overwritten by the next call).  ``prefetch`` (capture(pipeline=True)): the NEXT call's batch, as in step()."""
+        st = self._static
+        self._fill_static(st, latents, prompt_embeds, uncond_prompt_embeds, noise, index, w, added_cond, uncond_added_cond)
+        if getattr(self, "_pipeline", False):
+            key = tuple(t.data_ptr() for t in (latents, prompt_embeds, uncond_prompt_embeds, noise, index, w))
+            if self._pipe_key != key:
+                # prologue (first call, or a batch that was not announced): this batch's teacher targets, eagerly, where the graph expects them
+                tg = self.teacher_targets(latents, prompt_embeds, uncond_prompt_embeds, noise, index, w, added_cond, uncond_added_cond)
+                for k in self.TARGET_KEYS:
+                    self._tg_next[k].copy_(tg[k])
+            self._pipe_key = None
+            if prefetch is not None:
+                self._fill_static(self._static_next, *prefetch)
+                self._pipe_key = tuple(t.data_ptr() for t in prefetch[:6])
         if lr is not None:
             self.lr_dev.fill_(float(lr))
         self._g_fb.replay()
@@ -376,8 +471,11 @@ class Distiller:
         self._log_bucket("lora[late: mid + up blocks]", (self.lora.grads.numel() - self.lora.late_offset) * 4, "fp32")
 
     def _log_bucket(self, name, nbytes, dtype):
-        if len(self.bucket_log) < 64:        # (a diagnostic of ONE step's issue order: bench.py clears it before the step it reports)
-            self.bucket_log.append((name, int(nbytes), dtype))
+        log_ = getattr(self, "bucket_log", None)          # (subclasses / test doubles that do not run Distiller.__init__)
+        if log_ is None:
+            log_ = self.bucket_log = []
+        if len(log_) < 64:        # (a diagnostic of ONE step's issue order: bench.py clears it before the step it reports)
+            log_.append((name, int(nbytes), dtype))
 
     def all_reduce_grads(self):
         """DDP exchange: all-reduce (sum) of the flat 67 M-element fp32 LoRA gradient buffer over RCCL/xGMI, as ONE collective or --

@@ -361,15 +361,30 @@ def main(args):
     logger.info("***** Running training *****  world=%d  per-GPU batch=%d  total steps=%d", world, args.train_batch_size, args.max_train_steps)
     cpu_gen = reseed_for_resume(src, args, rank, global_step)
     t_last = time.time()
+    ga = args.gradient_accumulation_steps
+
+    def draw_batch():
+        """one (micro-)batch in the reference's draw order; drawn ONE call ahead of its use so that its teacher targets can be computed beside the
+        previous batch's student work (Distiller.step(prefetch=...)): the sequence of draws -- and with it every batch -- is unchanged"""
+        latents, pe = src.batch()
+        noise = torch.randn(latents.shape, generator=src.g, device=device)                                      # :1139
+        index = torch.randint(0, args.num_ddim_timesteps, (latents.shape[0],), generator=src.g, device=device)  # :1147
+        w = ((args.w_max - args.w_min) * torch.rand((latents.shape[0],), generator=cpu_gen) + args.w_min).to(device)  # :1183 CPU RNG
+        return (latents, pe, src.uncond, noise, index, w)
+
+    prefetch_on = os.environ.get("PCM_TEACHER_PREFETCH", "1") != "0"
+    left = (args.max_train_steps - global_step) * ga           # (micro-)batches still to draw
+    cur = None
+    if left > 0:
+        cur, left = draw_batch(), left - 1
     while global_step < args.max_train_steps:
         lr = lr_at(args, sched_step(sched_pos(D, args, global_step), world))
-        ga = args.gradient_accumulation_steps
         for micro in range(ga):                                # accelerator.accumulate(unet), :1120: one optimizer step per ga batches
-            latents, pe = src.batch()
-            noise = torch.randn(latents.shape, generator=src.g, device=device)                                      # :1139
-            index = torch.randint(0, args.num_ddim_timesteps, (latents.shape[0],), generator=src.g, device=device)  # :1147
-            w = ((args.w_max - args.w_min) * torch.rand((latents.shape[0],), generator=cpu_gen) + args.w_min).to(device)  # :1183 CPU RNG
-            out = D.step(latents, pe, src.uncond, noise, index, w, lr=lr, accum=(micro, ga))
+            nxt = None
+            if left > 0:
+                nxt, left = draw_batch(), left - 1
+            out = D.step(*cur, lr=lr, accum=(micro, ga), prefetch=nxt if prefetch_on else None)
+            cur = nxt
         global_step += 1
         if rank == 0:
             loss = float(out["loss"].item())                       # the reference's only per-step host sync (:1367)

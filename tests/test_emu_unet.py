@@ -542,3 +542,39 @@ def test_fused_text_kv_of_the_lora_pass_equals_the_per_module_projections():
                 o0 = (t.data_ptr() - base) // 4
                 x, y = ga[o0:o0 + t.numel()], gb[o0:o0 + t.numel()]
                 assert float(y.norm()) > 0 and rel(x, y) < 1e-6, (path, rel(x, y))
+
+
+def test_cross_step_teacher_prefetch_gives_the_same_training_sequence():
+    """Distiller.step(..., prefetch=next batch) (round 6): the frozen teacher's pass of batch k+1 is issued beside the student's work on batch k
+    (a side stream on the GPU; the same call order on the host emulator) and picked up by the next call.  It reads nothing trainable, so three
+    optimizer steps give the same losses, gradients and parameters as three plain steps -- bit for bit; a batch that was not announced (or
+    announced and then replaced) falls back to computing its targets in the call."""
+    from oracle import pcm_step as OS
+    from oracle import unet_sd15 as O
+    from pcm_amd.model import LoraState, UNetWeights
+    from pcm_amd.trainer import Distiller, StepConfig
+    oc, pc = tiny_cfgs()
+    sd = O.init_state_dict(oc, 0)
+    W = UNetWeights(pc, sd, "cpu")
+    ocfg = OS.StepConfig(multiphase=2, loss_type="huber", w_min=4.0, w_max=5.0)
+    cfg = StepConfig(multiphase=2, loss_type="huber", w_min=4.0, w_max=5.0, learning_rate=1e-3)
+    keys = ("latents", "prompt_embeds", "uncond_prompt_embeds", "noise", "index", "w")
+    batches = [tuple(OS.draw_inputs(2, ocfg, seed=20 + i, latent_hw=8, ctx_len=7, ctx_dim=64)[k] for k in keys) for i in range(4)]
+
+    def run(prefetch):
+        lora = LoraState(pc, 64, 8.0, "cpu", seed=1, b_std=0.05)
+        D = Distiller(W, lora, cfg)
+        losses = []
+        for i in range(3):
+            nxt = batches[i + 1] if prefetch else None
+            if prefetch == "wrong" and i == 1:
+                nxt = batches[0]                     # announced batch 0, the next call brings batch 2: must not use the stale targets
+            out = D.step(*batches[i], prefetch=nxt)
+            losses.append(float(out["loss"]))
+        return losses, lora.params.clone(), lora.grads.clone()
+
+    l0, p0, g0 = run(None)
+    l1, p1, g1 = run(True)
+    l2, p2, g2 = run("wrong")
+    assert l0 == l1 == l2 and torch.equal(p0, p1) and torch.equal(g0, g1) and torch.equal(p0, p2) and torch.equal(g0, g2)
+    assert len(set(l0)) == 3

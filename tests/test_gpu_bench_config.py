@@ -345,3 +345,43 @@ def test_loss_curve_20_steps_real_size_vs_oracle(deterministic):
     # sign-like steps; the parameters agree to a fraction of the total update
     # (MI355X: 2.5e-4, cosine 0.9955)
     assert rep["param_rel_after_20"] < 6e-4 and rep["update_cos_after_20"] > 0.98, rep
+
+
+def test_pipelined_graph_steps_equal_plain_eager_steps_bitwise(sd15):
+    """Distiller.capture(pipeline=True) + step_graphed(..., prefetch=next batch) -- what bench.py times since round 6: the frozen teacher's
+    pass of batch k+1 on a forked stream inside the captured step of batch k.  Under the reproducible reductions, four optimizer steps at the
+    benchmarked size give BITWISE the losses, gradients and parameters of four plain eager steps (teacher_targets reads nothing trainable:
+    only the launch order changes); a call whose batch was not announced computes its targets in the call."""
+    from pcm_amd import ops
+    from pcm_amd.model import LoraState
+    from pcm_amd.trainer import Distiller, StepConfig
+    cfg, W = sd15
+    dev = "cuda"
+    scfg = StepConfig(multiphase=4, loss_type="huber", learning_rate=5e-6, adam_weight_decay=1e-3, w_min=4.0, w_max=5.0)
+    B = 16
+    g = torch.Generator(device=dev).manual_seed(453645634)
+    keys = ("latents", "prompt_embeds", "uncond_prompt_embeds", "noise", "index", "w")
+    batches = [tuple(draw(B, g, dev)[k] for k in keys) for _ in range(5)]
+    ops.set_deterministic(True)
+    try:
+        lora_e = LoraState(cfg, 64, 8.0, dev, seed=1, b_std=0.02)
+        De = Distiller(W, lora_e, scfg)
+        losses_e = [float(De.step(*batches[i])["loss"]) for i in range(4)]
+        lora_p = LoraState(cfg, 64, 8.0, dev, seed=1, b_std=0.02)
+        Dp = Distiller(W, lora_p, scfg)
+        Dp.capture(B, pipeline=True)
+        losses_p = []
+        for i in range(4):
+            nxt = batches[i + 1] if i != 1 else None          # step 2's batch is NOT announced: the eager prologue must cover it
+            losses_p.append(float(Dp.step_graphed(*batches[i], prefetch=nxt)["loss"]))
+        torch.cuda.synchronize()
+        assert losses_p == losses_e, (losses_p, losses_e)
+        assert torch.equal(lora_p.params, lora_e.params) and torch.equal(lora_p.grads, lora_e.grads)
+        # the eager form of the same pipeline (side stream, no graph)
+        lora_s = LoraState(cfg, 64, 8.0, dev, seed=1, b_std=0.02)
+        Ds = Distiller(W, lora_s, scfg)
+        losses_s = [float(Ds.step(*batches[i], prefetch=batches[i + 1])["loss"]) for i in range(4)]
+        torch.cuda.synchronize()
+        assert losses_s == losses_e and torch.equal(lora_s.params, lora_e.params)
+    finally:
+        ops.set_deterministic(False)
