@@ -83,6 +83,35 @@ def main():
         main_s.wait_stream(side)
         return b
 
+    # the two halves of the student's two-timestep pass are independent too: ONE 2B pass (what the step runs) against two B passes on two streams
+    student_b = UNet(W, lora)                # (a second runner: per-pass state is per runner)
+
+    def two_halves_two_streams():
+        side.wait_stream(main_s)
+        with torch.cuda.stream(side):
+            b = student_b.forward(x2[B:], t2[B:], c2[B:])                          # target half: no tape
+        a = student.forward(x2[:B], t2[:B], c2[:B], save=True)                     # online half: tape for the backward
+        main_s.wait_stream(side)
+        return a, b
+
+    def two_halves_one_stream():
+        a = student.forward(x2[:B], t2[:B], c2[:B], save=True)
+        b = student_b.forward(x2[B:], t2[B:], c2[B:])
+        return a, b
+
+    for name, fn in (("student_2B_one_pass", f_student), ("student_two_B_passes_one_stream", two_halves_one_stream), ("student_two_B_passes_two_streams", two_halves_two_streams),
+                     ("student_2B_one_pass_again", f_student), ("student_two_B_passes_two_streams_again", two_halves_two_streams)):
+        keep = fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.reps):
+            keep = fn()
+        e1.record()
+        torch.cuda.synchronize()
+        del keep
+        print("%-40s %.3f ms (eager, %d reps)" % (name, e0.elapsed_time(e1) / args.reps, args.reps), flush=True)
+
     for name, fn in (("student_fwd_2t", f_student), ("student_fwd_2t_again", f_student), ("teacher_2b_shared_prefix", f_teacher), ("both_one_stream", both_serial),
                      ("both_two_streams", both_two_streams), ("both_one_stream_again", both_serial), ("both_two_streams_again", both_two_streams),
                      ("student_bwd", f_bwd), ("bwd_then_teacher_one_stream", bwd_teacher_serial), ("bwd_and_teacher_two_streams", bwd_teacher_two_streams),
