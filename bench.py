@@ -550,7 +550,15 @@ def main():
                 "achieved_tflops": round(tf_s, 1), "achieved_gb_s": round(gb_s, 1),
                 "frac_of_own_roof": round(tf_s / PEAK_BF16_TFLOPS if name == "mfma" else gb_s * 1e9 / PEAK_HBM_BYTES, 4)}
         # the two-workgroups-per-CU kernel (plan code 1xxxx: the K <= 384 fused-GEGLU feed-forward projections), against both roofs
-        w4l = [(p[0], t, p[5]) for p, t in zip(prof, times) if p[4] >= 10000]
+        w4l = [(p[0], t, p[5]) for p, t in zip(prof, times) if 10000 <= p[4] < 20000]
+        # the weights-stationary kernel (plan code 30000 + K/32, round 6: the N = 320 / 960, K = 320 (+ 64) projections of the 64x64 level), against both roofs
+        wsl = [(p[0], t, p[5]) for p, t in zip(prof, times) if p[4] >= 30000]
+        ws = None
+        if wsl:
+            s_fl, s_ms, s_nb = sum(x[0] for x in wsl), sum(x[1] for x in wsl), sum(x[2] for x in wsl)
+            ws = {"kernel": "pcm_gemm_ws_kernel (320-column weight slice in registers, 64-row activation tiles by LDS-DMA)", "launches": len(wsl),
+                  "kernel_ms_per_step": round(s_ms, 2), "achieved_tflops": round(s_fl / (s_ms * 1e-3) / 1e12, 1),
+                  "achieved_gb_s": round(s_nb / (s_ms * 1e-3) / 1e9, 1), "frac_hbm": round(s_nb / (s_ms * 1e-3) / PEAK_HBM_BYTES, 4)}
         w4 = None
         if w4l:
             w_fl, w_ms, w_nb = sum(x[0] for x in w4l), sum(x[1] for x in w4l), sum(x[2] for x in w4l)
@@ -609,7 +617,7 @@ def main():
                     "kernel": "pcm_gemm8p_kernel<3,false,false> (256x320 phased tile; all its launches of one step)",
                     "launches": len(dom), "avg_launch_us": round(1e3 * d_ms / max(1, len(dom)), 1),
                     "algorithmic_tflop": round(d_fl / 1e12, 2), "kernel_ms_per_step": round(d_ms, 2), "classes": classes,
-                    "short_k_kernel": w4,
+                    "short_k_kernel": w4, "weights_stationary_kernel": ws,
                     "gemm_family": {"kernels": "pcm_gemm8p<3>/<2>, pcm_gemm4w<5>, pcm_gemm_kernel tiles, pcm_gemm_n64 (every pcm_gemm_bf16 launch)",
                                     "launches": len(prof), "algorithmic_tflop_per_step": round(flops / 1e12, 2),
                                     "kernel_ms_per_step": round(tms, 2), "achieved": round(fam, 1), "frac": round(fam / PEAK_BF16_TFLOPS, 4)},

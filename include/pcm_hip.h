@@ -130,7 +130,7 @@ int pcm_gemm_bf16(const pcm_gemm_seg* segs, int nseg, const pcm_gemm_epi* epi, v
 /* Which kernel family and K split the call above takes for these arguments (a pure function of them, nothing is launched; abi >= 4):
  *   1000 * F + splitk   the phased 8-wave tile gemm8p (F = 4: 256x256, F = 5: 256x320) or, F = 0, a 4-wave tile of gemm.hip;
  *   10000 + 1000 * F + 1  gemm4w (two workgroups per CU);  64 the rank-64 streaming kernels;  65 the 3x3 halo-window rank-64 kernel;
- *   32 the batch-row kernel (M <= 16).  Negative: the PCM_E* code the call would return.  bench.py's roofline leg classes its timed
+ *   32 the batch-row kernel (M <= 16);  30000 + K/32 the weights-stationary kernel (abi 5: short-K projections, N % 320 == 0).  Negative: the PCM_E* code the call would return.  bench.py's roofline leg classes its timed
  * launches with it. */
 int pcm_gemm_plan_code(const pcm_gemm_seg* segs, int nseg, const pcm_gemm_epi* epi);
 /* 1 when pcm_gemm_bf16 with these arguments (epi->chstats set or not: it is not read) accumulates the per-channel statistics described at

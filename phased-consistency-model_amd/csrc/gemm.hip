@@ -636,9 +636,30 @@ static bool gemm_smallm_ok(const pcm_gemm_seg* segs, int nseg, const pcm_gemm_ep
     if (segs[i].mode != PCM_SEG_PLAIN || (segs[i].K % 32) || (segs[i].lda % 8)) return false;
   return true;
 }
+// weights-stationary kernel (gemm_ws.hip): the short-K projections of the 64x64 level -- N a multiple of 320 (one 320-column weight slice per
+// workgroup, held in registers), K total 320 or 384 (K + rank-64 LoRA), plain segments, enough 64-row tiles for every CU to amortise its weight
+// fill.  BUILT, BIT-IDENTICAL TO THE PHASED TILE, MEASURED SLOWER (x1.06-1.35 on every N = 320 shape, profiles/r06_l_*: with ONE wave per SIMD the
+// LDS-DMA issue slots, the LDS waits and the epilogue's ~700 instructions per 64 rows all ADD to the MFMA time -- 5.1 us per 64-row step against
+// 1.4 us of MFMAs): it exists in the TOOLS build only (PCM_GEMM_WS=1 / pcm_debug_gemm_ws), the product planner never takes it.
+PCM_LAZY_KNOB(ws_on, g_ws_on, "PCM_GEMM_WS", 0)
+PCM_TOOLS_ONLY(extern "C" void pcm_debug_gemm_ws(int on) { g_ws_on = on < 0 ? -1 : (on ? 1 : 0); })
+static bool gemm_ws_ok(const pcm_gemm_seg* segs, int nseg, const pcm_gemm_epi* e) {
+  if (!ws_on() || big_mode() != 1 || g_force_bm) return false;
+  if (e->out_dtype == PCM_F32 || e->act != PCM_ACT_NONE || e->rowvec || e->out2 || e->chstats || e->pre_out) return false;
+  if ((e->N % 320) || e->N > 960 || e->M < 16384 || (e->ldo % 8) || (((uintptr_t)e->out) & 15)) return false;
+  if (e->residual && ((e->ldr % 8) || (((uintptr_t)e->residual) & 15))) return false;
+  if (e->bias && (((uintptr_t)e->bias) & 15)) return false;
+  int kt = 0;
+  for (int i = 0; i < nseg; i++) {
+    const pcm_gemm_seg& s = segs[i];
+    if (s.mode != PCM_SEG_PLAIN || (s.K % 64) || (s.lda % 8) || (((uintptr_t)s.a) & 15) || (((uintptr_t)s.w) & 15)) return false;
+    kt += s.K;
+  }
+  return kt == 320 || kt == 384;
+}
 extern "C" size_t pcm_gemm_workspace_bytes(const pcm_gemm_seg* segs, int nseg, const pcm_gemm_epi* e) {
   if (!segs || !e || nseg < 1 || nseg > 2 || e->M <= 0 || e->N <= 0) return 0;
-  if (gemm_smallm_ok(segs, nseg, e) || gemm_n64_ok(segs, nseg, e)) return 0;
+  if (gemm_smallm_ok(segs, nseg, e) || gemm_n64_ok(segs, nseg, e) || gemm_ws_ok(segs, nseg, e)) return 0;
   // the workspace is sized for the plan that would be used WITH a workspace; pcm_gemm_bf16 re-plans identically
   return gemm_plan(e->M, e->N, gemm_total_kt(segs, nseg), true, gemm_big_ok(segs, nseg, e), e->act == PCM_ACT_GEGLU, gemm_w4_ok(segs, nseg)).ws_bytes;
 }
@@ -664,7 +685,7 @@ extern "C" int pcm_gemm_emits_chstats(const pcm_gemm_seg* segs, int nseg, const 
   int code = 0;
   const int rc = gemm_run(segs, nseg, e, nullptr, true, &code);
   if (rc) return rc;
-  if (code == 32 || code == 64 || code == 65 || code >= 10000) return 0;
+  if (code == 32 || code == 64 || code == 65 || code >= 10000) return 0;      // (batch-row, rank-64, gemm4w, weights-stationary: no statistics)
   pcm_gemm_epi probe = *e;
   GemmPlan pl; memset(&pl, 0, sizeof(pl));
   pl.big_fn = code / 1000; pl.splitk = code % 1000;
@@ -750,6 +771,13 @@ static int gemm_run(const pcm_gemm_seg* segs, int nseg, const pcm_gemm_epi* e, v
     *code = 64;
     if (plan_only) return PCM_OK;
     int rc = pcm_gemm_n64_launch(g, stream);
+    if (rc) return rc;
+    return pcm_post_launch("pcm_gemm_bf16");
+  }
+  if (gemm_ws_ok(segs, nseg, e)) {
+    *code = 30000 + (segs[0].K + (nseg > 1 ? segs[1].K : 0)) / 32;
+    if (plan_only) return PCM_OK;
+    int rc = pcm_gemm_ws_launch(g, stream);
     if (rc) return rc;
     return pcm_post_launch("pcm_gemm_bf16");
   }

@@ -25,6 +25,9 @@
 // PCM_PIN_V / PCM_PIN_S = opaque copy of a vector / scalar value (keeps hipcc from hoisting what depends on it);
 // PCM_KERNARG_REF(T, arr, i) = element i of an array that is the FIRST member of the kernel's argument struct, read from the kernarg
 // segment by scalar loads (no per-job copy of the argument block in registers)
+// a wave's LDS operations execute in issue order: lanes of ONE wave may hand data to each other through LDS without a workgroup barrier,
+// provided the compiler keeps the order (this is a scheduling fence, no instruction; the emulator's fibers rendezvous here)
+#define PCM_WAVE_LDS_FENCE() __builtin_amdgcn_wave_barrier()
 #define PCM_HW_ONLY(...) __VA_ARGS__
 #define PCM_PIN_V(x) asm volatile("" : "+v"(x))
 #define PCM_PIN_S(x) asm volatile("" : "+s"(x))

@@ -282,6 +282,7 @@ inline emu_v4i buffer_load_b128(BufferRsrc rs, uint32_t voff, uint32_t soff, int
 #define __builtin_amdgcn_s_getreg(x) 0u
 // hardware-only code-generation controls of csrc/pcm_common.h
 #define PCM_HW_ONLY(...)
+#define PCM_WAVE_LDS_FENCE() pcm_emu::wave_sync()
 #define PCM_PIN_V(x) ((void)0)
 #define PCM_PIN_S(x) ((void)0)
 #define PCM_KERNARG_REF(T, arr, i) ((arr)[i])

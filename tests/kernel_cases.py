@@ -787,6 +787,57 @@ def case_gemm_epilogue_fusions(dev, which):
         dll.pcm_debug_gemm_big_mode(1)
 
 
+def case_gemm_ws(dev, which):
+    """The weights-stationary kernel (csrc/gemm_ws.hip, round 6): the short-K projections of the 64x64 level -- a 320-column weight slice held in
+    registers per workgroup, 64-row activation tiles through a two-stage LDS-DMA ring.  Against torch fp32 on the same 16-bit operands AND bit for
+    bit against the phased tile (pcm_debug_gemm_ws(0)): same products, same accumulation order, same epilogue operation order."""
+    from pcm_amd import capi, ops
+
+    def rnd(*shape, seed=0, scale=1.0):
+        g = torch.Generator().manual_seed(seed)
+        return (torch.randn(*shape, generator=g) * scale).to(ops.BF16).to(dev)
+
+    M, N, lora, res, bias, strided = {"plain": (16384, 320, False, False, False, False), "lora_res": (16384, 320, True, True, True, False),
+                                      "qkv": (16384, 960, False, False, False, False), "tail_strided": (16384 + 72, 320, True, True, True, True)}[which]
+    K = 320
+    xw = rnd(M, K + 64, seed=1) if strided else None            # the activation as a column slice of a wider matrix (row stride K + 64)
+    x = xw[:, :K] if strided else rnd(M, K, seed=1)
+    w = rnd(N, K, seed=2, scale=0.1)
+    segs = [ops.Seg(x, w, lda=(K + 64) if strided else None)]
+    ref = x.float().cpu() @ w.float().cpu().T
+    if lora:
+        t, bl = rnd(M, 64, seed=3), rnd(N, 64, seed=4, scale=0.1)
+        segs.append(ops.Seg(t, bl))
+        ref = ref + t.float().cpu() @ bl.float().cpu().T
+    b = torch.randn(N, generator=torch.Generator().manual_seed(5)).to(dev) if bias else None
+    r = rnd(M, N, seed=6) if res else None
+    if b is not None:
+        ref = ref + b.cpu()
+    if r is not None:
+        ref = ref + r.float().cpu()
+    dll = capi.lib().dll
+    outs = []
+    for on in (1, 0):
+        dll.pcm_debug_gemm_ws(on)
+        try:
+            ow = torch.full((M, N + (64 if strided else 0)), 5.0, dtype=ops.BF16, device=dev)
+            ops.gemm(segs, M, N, ow[:, :N] if strided else ow, bias=b, residual=r, ldo=ow.shape[-1])
+            plan = dll.pcm_debug_last_gemm_plan()
+        finally:
+            dll.pcm_debug_gemm_ws(-1)
+        assert (plan // 10000 == 3) == bool(on), (which, on, plan)
+        outs.append(ow)
+    got = outs[0][:, :N].float().cpu()
+    err = (got - ref).abs()
+    assert float((err - (2e-2 + 1e-2 * ref.abs())).max()) <= 0, (which, float(err.max()))
+    assert torch.equal(outs[0].cpu(), outs[1].cpu()), (which, "weights-stationary kernel and phased tile differ", float((outs[0].float() - outs[1].float()).abs().max()))
+    if strided:
+        assert bool((outs[0][:, N:].float() == 5.0).all()), "columns beyond N touched"
+
+
+GEMM_WS_CASES = ["plain", "lora_res", "qkv", "tail_strided"]
+
+
 GEMM_EPI_FUSION_CASES = ["plain", "res", "small_maps", "ragged_n", "splitk", "conv_rowvec", "small_tile"]
 
 

@@ -184,3 +184,10 @@ def test_gemm_epilogue_fusions_second_output_and_groupnorm_statistics(which):
     """abi 5: a skip tensor's second home (out2) and the next GroupNorm's statistics (chstats) from the producing contraction's epilogue"""
     import kernel_cases as KC
     KC.case_gemm_epilogue_fusions("cuda", which)
+
+
+@pytest.mark.parametrize("which", __import__("kernel_cases").GEMM_WS_CASES)
+def test_gemm_weights_stationary_kernel(which):
+    """csrc/gemm_ws.hip: the short-K projections of the 64x64 level with the weight slice held in registers"""
+    import kernel_cases as KC
+    KC.case_gemm_ws("cuda", which)
