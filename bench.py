@@ -110,7 +110,7 @@ def bench_other_config(args, world, rank, local_rank, dev, sync):
     cfgname = args.config
     g = torch.Generator(device=dev).manual_seed(453645634 + rank)
     rn = lambda *s_, **k: torch.randn(*s_, generator=g, device=dev, **k)   # noqa: E731
-    note = None
+    note, pipe = None, False
     if cfgname == "c3":
         from pcm_amd.discriminator import ADAPTER_DIMS, Discriminator
         from pcm_amd.model import LoraState, UNetWeights
@@ -134,9 +134,10 @@ def bench_other_config(args, world, rank, local_rank, dev, sync):
         # replayed D step waits ~137 s for the nine async bucket all-reduces (profiles/r03_d_segmented_replay_timing.txt; the same
         # segmented graphs with no-op host actions replay at full speed): graphs only with RCCL there unless PCM_ADV_GRAPH=1
         use_graph = not args.no_graph and (world == 1 or torch.distributed.get_backend() == "nccl" or os.environ.get("PCM_ADV_GRAPH") == "1")
+        pipe = not args.no_prefetch and world == 1     # (world > 1: the D step is a segmented capture cut at its collectives -- one launch chain)
         if use_graph:
             try:
-                D.capture_adv(B)
+                D.capture_adv(B, pipeline=pipe)
             except RuntimeError as e:      # same launches issued eagerly (capture_adv leaves no capture open and no segment state behind)
                 log("adversarial hipGraph capture failed (%s); falling back to eager launches" % str(e).splitlines()[0])
                 use_graph = False
@@ -148,7 +149,7 @@ def bench_other_config(args, world, rank, local_rank, dev, sync):
 
         def step(b, nxt=None):
             f = D.step_adv_graphed if use_graph else D.step_adv
-            out = f(state["gs"], *b)
+            out = f(state["gs"], *b, prefetch=tuple(nxt[:6]) if (pipe and nxt is not None) else None)
             state["d" if state["gs"] % 2 == 0 else "g"] = out
             state["gs"] += 1
             return out
@@ -202,15 +203,16 @@ def bench_other_config(args, world, rank, local_rank, dev, sync):
         D = SD3Distiller(W, lora, SD3StepConfig(multiphase=2, num_euler_timesteps=100, learning_rate=5e-6, adam_weight_decay=1e-3), world_size=world)
         tf_sample = flops.step_tflop(flops.mmdit_macs(mcfg))["step"]
         use_graph = not args.no_graph
+        pipe = not args.no_prefetch
         if use_graph:
-            D.capture(B)
+            D.capture(B, pipeline=pipe)
 
         def draw():
             return [rn(B, 16, 128, 128), rn(B, 154, 4096), rn(B, 2048), rn(B, 154, 4096), rn(B, 2048), rn(B, 16, 128, 128),
                     torch.randint(0, 100, (B,), generator=g, device=dev)]
 
         def step(b, nxt=None):
-            return (D.step_graphed if use_graph else D.step)(*b)
+            return (D.step_graphed if use_graph else D.step)(*b, prefetch=tuple(nxt) if (pipe and nxt is not None) else None)
         workload = "SD3-medium (MMDiT 2.03B, 4096 image + 154 text tokens) PCM-LoRA distillation step, 2 phases, 128x128x16 latents, per-GPU batch %d, LoRA r=32" % B
         metric = "distillation images/sec SD3-medium 1024px"
     torch.cuda.synchronize()
@@ -258,7 +260,8 @@ def bench_other_config(args, world, rank, local_rank, dev, sync):
         line = {"metric": metric, "value": round(world * B / (dt / args.steps), 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
                 "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision,
                 "data": "synthetic", "config": {"workload": workload, "baseline_config": cfgname, "global_batch": world * B, "parallelism": "dp%d" % world,
-                                                "launch": "hipGraph replay" if use_graph else "eager", "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 1e9, 1), "losses": losses},
+                                                "launch": "hipGraph replay" if use_graph else "eager", "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 1e9, 1), "losses": losses,
+                                                "teacher_prefetch": "next batch's ODE-solver teacher pass on a second stream" if pipe else "off"},
                 "roofline": {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
                              "traffic": None, "what": "whole step, algorithmic TFLOP from the config walk of pcm_amd/flops.py",
                              "algorithmic_tflop_per_sample_step": round(tf_sample, 3), "note": note},

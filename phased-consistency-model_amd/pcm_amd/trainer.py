@@ -204,6 +204,7 @@ class Distiller:
 
     # ---- the part of the step that depends on nothing trainable: noisy latents, the frozen teacher's [cond; uncond] pass, the CFG DDIM step
     TARGET_KEYS = ("noisy", "start_t", "t_n", "eps_c", "eps_u", "x_prev64", "x_prev32")
+    N_BATCH_KEY = 6          # leading tensors of a batch tuple whose addresses identify it (the rest: optional added-cond dicts)
 
     def teacher_targets(self, latents, prompt_embeds, uncond_prompt_embeds, noise, index, w, added_cond=None, uncond_added_cond=None):
         """train_pcm_lora_sd15.py:1143-1178 + :1217-1258: timesteps, add_noise, teacher cond / uncond forward, CFG-augmented DDIM solver step.
@@ -282,7 +283,7 @@ class Distiller:
         uncond_added_cond]) of the NEXT step() call"""
         if getattr(self, "_side", None) is None:
             self._side = torch.cuda.Stream() if self.device.type == "cuda" else False
-        key = tuple(t.data_ptr() for t in batch[:6])
+        key = tuple(t.data_ptr() for t in batch[:self.N_BATCH_KEY])
         if self._side:
             self._side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self._side):
@@ -426,6 +427,20 @@ class Distiller:
                 for k, v in val.items():
                     st[name][k].copy_(v)
 
+    def _pipe_feed(self, batch, added_cond, uncond_added_cond, prefetch):
+        """pipelined capture, before a replay: make sure THIS batch's teacher targets are where the graph expects them, and hand the next
+        batch to the graph's teacher branch"""
+        key = tuple(t.data_ptr() for t in batch)
+        if self._pipe_key != key:
+            # prologue (first call, or a batch that was not announced): this batch's teacher targets, eagerly
+            tg = self.teacher_targets(*batch, added_cond, uncond_added_cond) if self.N_BATCH_KEY == 6 else self.teacher_targets(*batch)
+            for k in self.TARGET_KEYS:
+                self._tg_next[k].copy_(tg[k])
+        self._pipe_key = None
+        if prefetch is not None:
+            self._fill_static(self._static_next, *prefetch)
+            self._pipe_key = tuple(t.data_ptr() for t in prefetch[:self.N_BATCH_KEY])
+
     def step_graphed(self, latents, prompt_embeds, uncond_prompt_embeds, noise, index, w, lr=None, added_cond=None, uncond_added_cond=None,
                      prefetch=None):
         """Same as step() through the captured graphs.  Returned tensors are the graph's static outputs
@@ -433,16 +448,7 @@ class Distiller:
         st = self._static
         self._fill_static(st, latents, prompt_embeds, uncond_prompt_embeds, noise, index, w, added_cond, uncond_added_cond)
         if getattr(self, "_pipeline", False):
-            key = tuple(t.data_ptr() for t in (latents, prompt_embeds, uncond_prompt_embeds, noise, index, w))
-            if self._pipe_key != key:
-                # prologue (first call, or a batch that was not announced): this batch's teacher targets, eagerly, where the graph expects them
-                tg = self.teacher_targets(latents, prompt_embeds, uncond_prompt_embeds, noise, index, w, added_cond, uncond_added_cond)
-                for k in self.TARGET_KEYS:
-                    self._tg_next[k].copy_(tg[k])
-            self._pipe_key = None
-            if prefetch is not None:
-                self._fill_static(self._static_next, *prefetch)
-                self._pipe_key = tuple(t.data_ptr() for t in prefetch[:6])
+            self._pipe_feed((latents, prompt_embeds, uncond_prompt_embeds, noise, index, w), added_cond, uncond_added_cond, prefetch)
         if lr is not None:
             self.lr_dev.fill_(float(lr))
         self._g_fb.replay()
@@ -557,8 +563,10 @@ class AdvDistiller(Distiller):
         self.adv_lr_dev = torch.full((1,), float(adv_lr), dtype=torch.float32, device=self.device)
 
     def step_adv(self, global_step, latents, prompt_embeds, uncond_prompt_embeds, noise, index, w, noise_fake, noise_real, adv_u,
-                 lr=None, added_cond=None, uncond_added_cond=None):
-        """adv_u [B] in [0,1): adv_timesteps = end_timesteps + floor(adv_u * (T // multiphase))   (:1288-1298)."""
+                 lr=None, added_cond=None, uncond_added_cond=None, targets=None, prefetch=None):
+        """adv_u [B] in [0,1): adv_timesteps = end_timesteps + floor(adv_u * (T // multiphase))   (:1288-1298).
+        ``targets`` / ``prefetch``: as in Distiller.forward_backward / step -- the ODE-solver teacher's results for this batch computed ahead,
+        and the next call's batch whose teacher pass is issued on a side stream beside this call's work."""
         cfg, T, disc = self.cfg, self.tables, self.disc
         B = latents.shape[0]
         ac, uac, taps = added_cond, uncond_added_cond, getattr(disc, "taps", True)
@@ -566,8 +574,13 @@ class AdvDistiller(Distiller):
         def cat2(a, b_):
             return None if a is None else {k: torch.cat([a[k], (b_ if b_ is not None else a)[k]]) for k in a}
         is_d = (global_step % 2 == 0)                                                           # :1375 / :1399
-        start_t, t_n = self.timesteps_for(index)
-        noisy = ops.add_noise(latents, noise, T.acp, start_t)
+        if targets is None:
+            targets = self._take_prefetched((latents, prompt_embeds, uncond_prompt_embeds, noise, index, w))
+        if prefetch is not None:
+            self._prefetch(prefetch)
+        if targets is None:     # the ODE-solver teacher pass (sd15_adv.py:1312 ``torch.autocast("cuda")``) + the CFG DDIM step (:1307-1352)
+            targets = self.teacher_targets(latents, prompt_embeds, uncond_prompt_embeds, noise, index, w, ac, uac)
+        noisy, start_t, t_n, x_prev64, x_prev32 = (targets[k] for k in ("noisy", "start_t", "t_n", "x_prev64", "x_prev32"))
         if is_d:     # the student forward is not back-propagated on discriminator steps: no tape
             eps_s, tape = self.student.forward(noisy, start_t, prompt_embeds, added_cond=ac), None
         else:
@@ -576,15 +589,6 @@ class AdvDistiller(Distiller):
         span = cfg.num_train_timesteps // cfg.multiphase
         adv_t = end_t + torch.clamp((adv_u * span).long(), max=span - 1)
         fake_adv, sr = ops.noise_travel(model_pred, noise_fake, T.acp, end_t, adv_t)            # :1303-1305
-        with self._ode_scope():     # the ODE-solver teacher pass (sd15_adv.py:1312 ``torch.autocast("cuda")``); the discriminator's feature passes stay in the build format
-            if cfg.not_apply_cfg_solver:
-                eps_c = self.teacher_ode.forward(noisy, start_t, prompt_embeds, added_cond=ac)
-                eps_u = eps_c
-            else:
-                both = self.teacher_ode.forward(torch.cat([noisy, noisy]), torch.cat([start_t, start_t]), torch.cat([prompt_embeds, uncond_prompt_embeds]),
-                                                added_cond=cat2(ac, uac))
-                eps_c, eps_u = both[:B], both[B:]
-        x_prev64, x_prev32 = ops.cfg_ddim_step(eps_c, eps_u, noisy, start_t, index, w, T.acp, T.acp_prev)
         eps_t = self.student.forward(x_prev32, t_n, prompt_embeds, added_cond=ac)
         target, _, _ = ops.phase_jump(eps_t, x_prev64, t_n, index, T.acp, T.acp_prev, T.ddim_timesteps_prev, T.edges, target_mode=True)
         out = dict(model_pred=model_pred, target=target, end_timesteps=end_t, adv_timesteps=adv_t, fake_adv=fake_adv, is_d=is_d)
@@ -617,10 +621,13 @@ class AdvDistiller(Distiller):
         out["grad_sumsq"] = self.lora.gradsq
         return out
 
-    def capture_adv(self, B, H=64, W=64, ctx_len=77, ctx_dim=768, added_cond=None, uncond_added_cond=None):
+    def capture_adv(self, B, H=64, W=64, ctx_len=77, ctx_dim=768, added_cond=None, uncond_added_cond=None, pipeline=False):
         """Capture the discriminator step and the generator step as two hipGraphs (single GPU: the steps contain no host decision and
         no collective; ~3200 / ~4500 launches each, whose enqueue time otherwise bounds the adversarial step).  Warm-up runs on scratch
-        state: LoRA, heads and both optimizers are restored afterwards."""
+        state: LoRA, heads and both optimizers are restored afterwards.
+        ``pipeline`` (single GPU): both graphs carry the ODE-solver teacher pass of the NEXT batch as a forked branch, as in
+        Distiller.capture(pipeline=True); step_adv_graphed(..., prefetch=next batch) feeds it.  At the adversarial configs' batch sizes (2 per
+        GPU) the student / feature passes fill a fraction of the chip, which is what the branch runs in."""
         dev, d, lo = self.device, self.disc, self.lora
         f32 = dict(dtype=torch.float32, device=dev)
         st = dict(latents=torch.zeros(B, 4, H, W, **f32), prompt_embeds=torch.zeros(B, ctx_len, ctx_dim, **f32),
@@ -631,6 +638,12 @@ class AdvDistiller(Distiller):
             st["added_cond"] = {k: v.clone() for k, v in added_cond.items()}
             st["uncond_added_cond"] = {k: v.clone() for k, v in (uncond_added_cond or added_cond).items()}
         self._adv_static = st
+        pipeline = bool(pipeline) and self.world_size == 1 and not SEG_FORCE
+        self._pipeline, self._pipe_key = pipeline, None
+        if pipeline:
+            self._static_next = {k: ({kk: vv.clone() for kk, vv in v.items()} if isinstance(v, dict) else v.clone()) for k, v in st.items()
+                                 if k not in ("noise_fake", "noise_real", "adv_u")}
+            self._pipe_side = torch.cuda.Stream()
         keep = (lo.params, lo.exp_avg, lo.exp_avg_sq, self.step_dev, self.lr_dev, d.params, d.exp_avg, d.exp_avg_sq, d.step_dev)
         if self.loss_scale_dev is not None:
             keep += (self.loss_scale_dev, self.loss_good_dev)
@@ -639,16 +652,34 @@ class AdvDistiller(Distiller):
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
+            if pipeline:
+                tg = self.teacher_targets(**self._static_next)
+                self._tg_next = {k: v.clone() for k, v in tg.items()}
+                self._tg_cur = {k: v.clone() for k, v in tg.items()}
             self.step_adv(0, **st)
             self.step_adv(1, **st)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+
+        def body(gs):
+            if not pipeline:
+                return self.step_adv(gs, **st)
+            for k in self.TARGET_KEYS:                     # the targets a previous replay (or the eager prologue) left for THIS batch
+                self._tg_cur[k].copy_(self._tg_next[k])
+            self._pipe_side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._pipe_side):
+                tgn = self.teacher_targets(**self._static_next)
+                for k in self.TARGET_KEYS:
+                    self._tg_next[k].copy_(tgn[k])
+            out_ = self.step_adv(gs, **st, targets=self._tg_cur)
+            torch.cuda.current_stream().wait_stream(self._pipe_side)
+            return out_
         if self.world_size == 1 and not SEG_FORCE:
             self._g_d, self._g_g = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._g_d):
-                self._out_d = self.step_adv(0, **st)
+                self._out_d = body(0)
             with torch.cuda.graph(self._g_g, pool=self._g_d.pool()):
-                self._out_g = self.step_adv(1, **st)
+                self._out_g = body(1)
         else:
             # data parallel: the D step is cut at its nine head-gradient buckets (each all-reduce goes out between two segments and
             # overlaps the heads that are still back-propagating) and in front of the head optimizer; the G step in front of the LoRA
@@ -684,8 +715,9 @@ class AdvDistiller(Distiller):
         d.repack()
 
     def step_adv_graphed(self, global_step, latents, prompt_embeds, uncond_prompt_embeds, noise, index, w, noise_fake, noise_real, adv_u,
-                         lr=None, added_cond=None, uncond_added_cond=None):
-        """step_adv through the captured graphs; the returned tensors are the graph's static outputs."""
+                         lr=None, added_cond=None, uncond_added_cond=None, prefetch=None):
+        """step_adv through the captured graphs; the returned tensors are the graph's static outputs.  ``prefetch``
+        (capture_adv(pipeline=True)): the NEXT call's (latents, prompt_embeds, uncond_prompt_embeds, noise, index, w[, added_cond, uncond_added_cond])."""
         st = self._adv_static
         for k, v in (("latents", latents), ("prompt_embeds", prompt_embeds), ("uncond_prompt_embeds", uncond_prompt_embeds), ("noise", noise),
                      ("index", index), ("w", w), ("noise_fake", noise_fake), ("noise_real", noise_real), ("adv_u", adv_u)):
@@ -694,6 +726,8 @@ class AdvDistiller(Distiller):
             if val is not None:
                 for k, v in val.items():
                     st[name][k].copy_(v)
+        if getattr(self, "_pipeline", False):
+            self._pipe_feed((latents, prompt_embeds, uncond_prompt_embeds, noise, index, w), added_cond, uncond_added_cond, prefetch)
         if global_step % 2 == 0:
             self._g_d.replay()
             return self._out_d

@@ -49,13 +49,17 @@ class SD3Distiller(Distiller):
         self._init_loss_scaler()          # half build (--mixed_precision=fp16, every recipe of text_to_image_sd3/run.sh): device-side GradScaler state
         self.ema = lora.params.clone() if cfg.ema_rate is not None else None
 
-    def forward_backward(self, model_input, prompt_embeds, pooled_prompt_embeds, uncond_prompt_embeds, uncond_pooled_prompt_embeds, noise,
-                         index, backward=True, grad_scale=1.0, zero_grad=True):
+    # ---- the part of the step that reads nothing trainable (see trainer.Distiller.teacher_targets: same role, same cross-step prefetch) ----
+    TARGET_KEYS = ("timesteps", "timesteps_prev", "noisy", "cond", "uncond", "x_prev64", "x_prev32")
+    N_BATCH_KEY = 7
+
+    def teacher_targets(self, model_input, prompt_embeds, pooled_prompt_embeds, uncond_prompt_embeds, uncond_pooled_prompt_embeds, noise, index):
+        """train_pcm_lora_sd3.py:1291-1301 + :1332-1357: timesteps, flow-matching noising, the frozen teacher's cond (+ uncond) pass as one 2B
+        pass, fixed-w CFG + one Euler step."""
         cfg, S = self.cfg, self.solver
         B = model_input.shape[0]
         timesteps, timesteps_prev = S.timesteps(index, cfg.num_train_timesteps)                               # :1291-1300
         noisy = S.add_noise(model_input, noise, index)                                                        # :1301
-        # frozen teacher, cond (+ uncond) as one 2B pass, fixed-w CFG + Euler step ----------------------------- :1332-1357
         with self._ode_scope():
             if cfg.not_apply_cfg_solver:
                 cond = uncond = self.teacher_ode.forward(noisy, timesteps, prompt_embeds, pooled_prompt_embeds)
@@ -67,6 +71,14 @@ class SD3Distiller(Distiller):
             x_prev64, x_prev32 = S.euler_step(noisy, cond, index, None)
         else:
             x_prev64, x_prev32 = S.euler_step(noisy, cond, index, uncond, cfg.w)
+        return dict(timesteps=timesteps, timesteps_prev=timesteps_prev, noisy=noisy, cond=cond, uncond=uncond, x_prev64=x_prev64, x_prev32=x_prev32)
+
+    def forward_backward(self, model_input, prompt_embeds, pooled_prompt_embeds, uncond_prompt_embeds, uncond_pooled_prompt_embeds, noise,
+                         index, backward=True, grad_scale=1.0, zero_grad=True, targets=None):
+        cfg, S = self.cfg, self.solver
+        if targets is None:
+            targets = self.teacher_targets(model_input, prompt_embeds, pooled_prompt_embeds, uncond_prompt_embeds, uncond_pooled_prompt_embeds, noise, index)
+        timesteps, timesteps_prev, noisy, cond, uncond, x_prev64, x_prev32 = (targets[k] for k in self.TARGET_KEYS)
         # online prediction (grad) and its jump to the phase edge ------------------------------------------------ :1304-1315
         pred, tape = self.student.forward(noisy, timesteps, prompt_embeds, pooled_prompt_embeds, save=True)
         model_pred64, end_index, model_pred32 = S.euler_style_multiphase_pred(noisy, pred, index, cfg.multiphase, with_f32=True)
@@ -90,13 +102,17 @@ class SD3Distiller(Distiller):
         return out
 
     def step(self, model_input, prompt_embeds, pooled_prompt_embeds, uncond_prompt_embeds, uncond_pooled_prompt_embeds, noise, index,
-             lr=None, update=True, accum=None):
+             lr=None, update=True, accum=None, prefetch=None):
         """One distillation step on this rank's batch; all inputs device tensors (latents/noise [B,16,H,W] fp32, prompt embeds
         [B,Lc,4096], pooled [B,2048], index [B] int64).  Returns device tensors (no host sync).  ``accum=(i, k)``: micro-batch i of k
-        (``--gradient_accumulation_steps``, ``accelerator.accumulate``, :1267-1268)."""
+        (``--gradient_accumulation_steps``, ``accelerator.accumulate``, :1267-1268).  ``prefetch``: the NEXT call's seven batch tensors (its
+        teacher targets are computed on a side stream beside this call's student work, trainer.Distiller.step)."""
         i, k = accum if accum is not None else (0, 1)
+        targets = self._take_prefetched((model_input, prompt_embeds, pooled_prompt_embeds, uncond_prompt_embeds, uncond_pooled_prompt_embeds, noise, index))
+        if prefetch is not None:
+            self._prefetch(prefetch)
         out = self.forward_backward(model_input, prompt_embeds, pooled_prompt_embeds, uncond_prompt_embeds, uncond_pooled_prompt_embeds,
-                                    noise, index, backward=update, grad_scale=1.0 / k, zero_grad=(i == 0))
+                                    noise, index, backward=update, grad_scale=1.0 / k, zero_grad=(i == 0), targets=targets)
         if not update or i < k - 1:
             return out
         if lr is not None:
@@ -106,8 +122,14 @@ class SD3Distiller(Distiller):
         return out
 
     # ---- hipGraph replay (same scheme as Distiller.capture: forward+backward and the optimizer as two graphs around the eager
-    # gradient all-reduce).  NOT yet exercised on hardware: the CLIs launch eagerly; tools/sd3_step_probe.py tries it behind a guard. ----
-    def capture(self, B, H=128, W=128, ctx_len=154):
+    # gradient all-reduce; ``pipeline``: the next batch's teacher targets as a forked branch of the captured step) ----
+    _STATIC_ORDER = ("model_input", "prompt_embeds", "pooled_prompt_embeds", "uncond_prompt_embeds", "uncond_pooled_prompt_embeds", "noise", "index")
+
+    def _fill_static(self, st, *batch):
+        for k, v in zip(self._STATIC_ORDER, batch):
+            st[k].copy_(v)
+
+    def capture(self, B, H=128, W=128, ctx_len=154, pipeline=False):
         dev, mc = self.device, self.W.cfg
         f32 = dict(dtype=torch.float32, device=dev)
         self._static = dict(model_input=torch.zeros(B, mc.in_channels, H, W, **f32), prompt_embeds=torch.zeros(B, ctx_len, mc.joint_attention_dim, **f32),
@@ -123,16 +145,38 @@ class SD3Distiller(Distiller):
         if self.ema is not None:
             saved.append(self.ema.clone())
         count = self.step_count
+        self._pipeline, self._pipe_key = bool(pipeline), None
+        if pipeline:
+            self._static_next = {k: v.clone() for k, v in self._static.items()}
+            self._pipe_side = torch.cuda.Stream()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                      # warm-up: lazy init, allocator pools
+            if pipeline:
+                tg = self.teacher_targets(**self._static_next)
+                self._tg_next = {k: v.clone() for k, v in tg.items()}
+                self._tg_cur = {k: v.clone() for k, v in tg.items()}
             self.forward_backward(**self._static)
             self._optimizer_apply()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+
+        def body():
+            if not pipeline:
+                return self.forward_backward(**self._static)
+            for k in self.TARGET_KEYS:                     # the targets a previous replay (or the eager prologue) left for THIS batch
+                self._tg_cur[k].copy_(self._tg_next[k])
+            self._pipe_side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._pipe_side):
+                tgn = self.teacher_targets(**self._static_next)
+                for k in self.TARGET_KEYS:
+                    self._tg_next[k].copy_(tgn[k])
+            out_ = self.forward_backward(**self._static, targets=self._tg_cur)
+            torch.cuda.current_stream().wait_stream(self._pipe_side)
+            return out_
         self._g_fb, self._g_opt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._g_fb, capture_error_mode="thread_local"):
-            self._static_out = self.forward_backward(**self._static)
+            self._static_out = body()
         with torch.cuda.graph(self._g_opt, pool=self._g_fb.pool(), capture_error_mode="thread_local"):
             self._optimizer_apply()
         for dst, src in zip(state, saved):
@@ -144,13 +188,14 @@ class SD3Distiller(Distiller):
         self._static_out["grad_sumsq"] = lo.gradsq
         self._graph = True
 
-    def step_graphed(self, model_input, prompt_embeds, pooled_prompt_embeds, uncond_prompt_embeds, uncond_pooled_prompt_embeds, noise, index, lr=None):
-        """Same as step() through the captured graphs; returned tensors are the graph's static outputs."""
-        st = self._static
-        for k, v in (("model_input", model_input), ("prompt_embeds", prompt_embeds), ("pooled_prompt_embeds", pooled_prompt_embeds),
-                     ("uncond_prompt_embeds", uncond_prompt_embeds), ("uncond_pooled_prompt_embeds", uncond_pooled_prompt_embeds),
-                     ("noise", noise), ("index", index)):
-            st[k].copy_(v)
+    def step_graphed(self, model_input, prompt_embeds, pooled_prompt_embeds, uncond_prompt_embeds, uncond_pooled_prompt_embeds, noise, index, lr=None,
+                     prefetch=None):
+        """Same as step() through the captured graphs; returned tensors are the graph's static outputs.  ``prefetch`` (capture(pipeline=True)):
+        the NEXT call's seven batch tensors."""
+        batch = (model_input, prompt_embeds, pooled_prompt_embeds, uncond_prompt_embeds, uncond_pooled_prompt_embeds, noise, index)
+        self._fill_static(self._static, *batch)
+        if getattr(self, "_pipeline", False):
+            self._pipe_feed(batch, None, None, prefetch)
         if lr is not None:
             self.lr_dev.fill_(float(lr))
         self._g_fb.replay()

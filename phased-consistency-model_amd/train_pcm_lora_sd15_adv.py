@@ -87,16 +87,32 @@ def main(args):
             gen_steps = global_step // 2
     logf = open(os.path.join(args.output_dir, args.logging_dir, f"{args.tracker_project_name}.jsonl"), "a") if rank == 0 else None
     cpu_gen = base.reseed_for_resume(src, args, rank, global_step)
-    while global_step < args.max_train_steps:
+
+    def draw_batch():
+        """one batch in the reference's draw order, drawn one step ahead of its use (its ODE-solver teacher pass runs beside the previous step's
+        work, AdvDistiller.step_adv(prefetch=...)); the sequence of draws is unchanged"""
         latents, pe = src.batch()
         B = latents.shape[0]
         rn = lambda: torch.randn(latents.shape, generator=src.g, device=device)
         index = torch.randint(0, args.num_ddim_timesteps, (B,), generator=src.g, device=device)
         w = ((args.w_max - args.w_min) * torch.rand((B,), generator=cpu_gen) + args.w_min).to(device)
         adv_u = torch.rand(B, generator=src.g, device=device)
+        noise, noise_fake, noise_real = rn(), rn(), rn()
+        return (latents, pe, src.uncond, noise, index, w, noise_fake, noise_real, adv_u)
+
+    prefetch_on = os.environ.get("PCM_TEACHER_PREFETCH", "1") != "0"
+    left = args.max_train_steps - global_step
+    cur = None
+    if left > 0:
+        cur, left = draw_batch(), left - 1
+    while global_step < args.max_train_steps:
+        nxt = None
+        if left > 0:
+            nxt, left = draw_batch(), left - 1
         lr = base.lr_at(args, base.sched_step(base.sched_pos(D, args, gen_steps), world))
         t0 = time.time()
-        out = D.step_adv(global_step, latents, pe, src.uncond, rn(), index, w, rn(), rn(), adv_u, lr=lr)
+        out = D.step_adv(global_step, *cur, lr=lr, prefetch=nxt[:6] if (prefetch_on and nxt is not None) else None)
+        cur = nxt
         if not out["is_d"]:
             gen_steps += 1
         global_step += 1

@@ -244,14 +244,29 @@ def main(args):
     logf = open(os.path.join(args.output_dir, args.logging_dir, f"{args.tracker_project_name}.jsonl"), "a") if rank == 0 else None
     logger.info("***** Running training *****  world=%d  per-GPU batch=%d  total steps=%d", world, args.train_batch_size, args.max_train_steps)
     t_last = time.time()
+    ga = args.gradient_accumulation_steps
+
+    def draw_batch():
+        """one (micro-)batch in the reference's draw order, drawn one call ahead of its use (its teacher targets are computed beside the previous
+        batch's student work, SD3Distiller.step(prefetch=...)); the sequence of draws is unchanged"""
+        latents, pe, pp = src.batch()
+        noise = torch.randn(latents.shape, generator=src.g, device=device)                                            # :1281
+        index = torch.randint(0, args.num_euler_timesteps, (latents.shape[0],), generator=src.g, device=device)       # :1285-1287
+        return (latents, pe, pp, src.uncond, src.uncond_pooled, noise, index)
+
+    prefetch_on = os.environ.get("PCM_TEACHER_PREFETCH", "1") != "0"
+    left = (args.max_train_steps - global_step) * ga
+    cur = None
+    if left > 0:
+        cur, left = draw_batch(), left - 1
     while global_step < args.max_train_steps:
         lr = base.lr_at(args, base.sched_pos(D, args, global_step))
-        ga = args.gradient_accumulation_steps
         for micro in range(ga):                                # accelerator.accumulate(transformer), :1267-1268
-            latents, pe, pp = src.batch()
-            noise = torch.randn(latents.shape, generator=src.g, device=device)                                            # :1281
-            index = torch.randint(0, args.num_euler_timesteps, (latents.shape[0],), generator=src.g, device=device)       # :1285-1287
-            out = D.step(latents, pe, pp, src.uncond, src.uncond_pooled, noise, index, lr=lr, accum=(micro, ga))
+            nxt = None
+            if left > 0:
+                nxt, left = draw_batch(), left - 1
+            out = D.step(*cur, lr=lr, accum=(micro, ga), prefetch=nxt if prefetch_on else None)
+            cur = nxt
         global_step += 1
         if rank == 0:
             loss = float(out["loss"].item())

@@ -268,6 +268,52 @@ def run_accumulation_case(dev):
     assert cos > 0.98 and 0.9 < float(u2.norm() / u1.norm()) < 1.1, (cos, float(u2.norm() / u1.norm()))
 
 
+def run_prefetch_case(dev, graphs=False):
+    """SD3Distiller.step(..., prefetch=next batch): the frozen teacher's pass of the next batch issued ahead (on a side stream on the GPU) changes
+    nothing -- three steps give bitwise the same losses and LoRA parameters as three plain steps.  ``graphs`` (GPU): a third run through
+    capture(pipeline=True) / step_graphed(prefetch=...) joins the comparison, reductions in reproducible mode."""
+    from oracle import mmdit_sd3 as O
+    from pcm_amd import ops
+    from pcm_amd.mmdit import MMDiTWeights, sd3_lora_state
+    from pcm_amd.mmdit_spec import MMDiTConfig
+    from pcm_amd.trainer_sd3 import SD3Distiller, SD3StepConfig
+    kw = dict(sample_size=16, num_layers=2, attention_head_dim=64, num_attention_heads=2, joint_attention_dim=96, caption_projection_dim=128,
+              pooled_projection_dim=64, pos_embed_max_size=12)
+    sd = O.init_state_dict(O.MMDiTConfig(**kw), 0)
+    pc = MMDiTConfig(**kw)
+    W = MMDiTWeights(pc, {k: v.to(dev) for k, v in sd.items()}, dev)
+    g = torch.Generator().manual_seed(9)
+    B, H, Lc, n = 2, 8, 5, 3
+    batches = [tuple(t.to(dev) for t in (torch.randn(B, 16, H, H, generator=g), torch.randn(B, Lc, 96, generator=g), torch.randn(B, 64, generator=g),
+                                         torch.randn(B, Lc, 96, generator=g), torch.randn(B, 64, generator=g), torch.randn(B, 16, H, H, generator=g),
+                                         torch.randint(0, 50, (B,), generator=g))) for _ in range(n + 1)]
+
+    def run(mode):
+        lora = sd3_lora_state(pc, 32, 8.0, dev, seed=5, b_std=0.05)
+        D = SD3Distiller(W, lora, SD3StepConfig(multiphase=2, learning_rate=1e-3))
+        if mode == "graph":
+            D.capture(B, H=H, W=H, ctx_len=Lc, pipeline=True)
+        losses = []
+        for i in range(n):
+            nxt = batches[i + 1] if mode != "plain" else None
+            if mode != "plain" and i == 1:
+                nxt = None                                   # a step that announces nothing: the next one computes its own targets
+            out = (D.step_graphed if mode == "graph" else D.step)(*batches[i], prefetch=nxt)
+            losses.append(float(out["loss"]))
+        return losses, lora.params.clone()
+
+    if graphs:
+        ops.set_deterministic(True)
+    try:
+        runs = [run(m) for m in (("plain", "prefetch", "graph") if graphs else ("plain", "prefetch"))]
+    finally:
+        if graphs:
+            ops.set_deterministic(False)
+    for l, p_ in runs[1:]:
+        assert l == runs[0][0] and torch.equal(p_, runs[0][1]), (runs[0][0], l)
+    assert len(set(runs[0][0])) == n
+
+
 def run_property_case(dev, cfg, W, lora, hw, Lc):
     """size-independent properties of the MMDiT path (used at SD3-medium's real size on the GPU, where no fp32 oracle is affordable, and on
     a narrow config on the emulator): finite output, batch independence, B = 0 LoRA == teacher, one distillation step."""

@@ -250,3 +250,31 @@ def test_adv_step_with_fp16_teacher_pass_keeps_the_discriminator_in_the_build_fo
     assert 0 < rel(b["target"], a["target"]) < 2e-2
     key = "d_loss" if global_step % 2 == 0 else "g_loss"
     assert abs(float(b[key]) - float(a[key])) < 5e-2 * abs(float(a[key])) + 1e-6, (float(a[key]), float(b[key]))
+
+
+def test_adversarial_steps_with_teacher_prefetch_are_the_same_steps():
+    """AdvDistiller.step_adv(..., prefetch=next batch): the ODE-solver teacher pass of the next batch is issued ahead (side stream on the GPU,
+    same call order here) and the next step picks its results up -- a D and a G step give bitwise the losses, heads and LoRA of plain steps."""
+    import adv_cases as A
+    from oracle import unet_sd15 as O
+    from pcm_amd.model import UNetWeights
+    from pcm_amd.trainer import AdvDistiller
+    kw = dict(block_out_channels=(64, 128), layers_per_block=1, cross_attention_dim=64, heads=2, norm_num_groups=32)
+    dims = (64, 128, 128, 128, 64)
+    names = ("latents", "prompt_embeds", "uncond_prompt_embeds", "noise", "index", "w", "noise_fake", "noise_real", "adv_u")
+
+    def run(prefetch):
+        oc, pc, lora, disc, ocfg, cfg, inp0 = A._setup("cpu", kw, dims, 2, 8, 7, 64, 1, 1e-4, None, 11)
+        inp1 = A._setup("cpu", kw, dims, 2, 8, 7, 64, 1, 1e-4, None, 12)[-1]
+        W = UNetWeights(pc, O.init_state_dict(oc, 0), "cpu")
+        D = AdvDistiller(W, lora, cfg, disc, adv_weight=0.1, adv_lr=1e-4)
+        b0, b1 = [inp0[k] for k in names], [inp1[k] for k in names]
+        d = D.step_adv(0, *b0, prefetch=tuple(b1[:6]) if prefetch else None)
+        if prefetch:
+            assert D._prefetched is not None
+        g = D.step_adv(1, *b1)
+        assert D._prefetched is None
+        return float(d["d_loss"]), float(g["loss_cm"]), float(g["g_loss"]), lora.params.clone(), disc.params.clone()
+
+    a, b = run(False), run(True)
+    assert a[:3] == b[:3] and torch.equal(a[3], b[3]) and torch.equal(a[4], b[4])

@@ -17,8 +17,9 @@ def _adv_inputs(OS, ocfg, B, Hh, step):
 
 
 def test_sd15_adversarial_steps_are_bitwise_reproducible_and_graph_replay_equals_eager():
-    """D, G, D, G on three twin trainers (eager, eager, captured hipGraphs) of a narrow SD1.5-topology UNet with 5 taps x 2 heads at a map
-    size whose reductions span many workgroups: losses, LoRA and head parameters BITWISE equal after every step."""
+    """D, G, D, G on four twin trainers (eager, eager, captured hipGraphs, captured hipGraphs carrying the next batch's ODE-solver teacher pass as
+    a forked branch) of a narrow SD1.5-topology UNet with 5 taps x 2 heads at a map size whose reductions span many workgroups: losses, LoRA
+    and head parameters BITWISE equal after every step."""
     from oracle import pcm_step as OS
     from oracle import unet_sd15 as O
     from pcm_amd import capi, ops
@@ -37,20 +38,25 @@ def test_sd15_adversarial_steps_are_bitwise_reproducible_and_graph_replay_equals
     ops.set_deterministic(True)
     try:
         trainers = []
-        for _ in range(3):
+        for _ in range(4):
             lora = LoraState(pc, 64, 8.0, "cuda", seed=1, b_std=0.05)
             disc = Discriminator((64, 128, 128, 128, 64), num_h_per_head=2, device="cuda", seed=2)
             trainers.append(AdvDistiller(W, lora, cfg, disc, adv_weight=0.1, adv_lr=1e-4))
-        Da, Db, Dg = trainers
+        Da, Db, Dg, Dp = trainers
         B, Hh = 4, 32
         Dg.capture_adv(B, H=Hh, W=Hh, ctx_len=77, ctx_dim=64)
+        Dp.capture_adv(B, H=Hh, W=Hh, ctx_len=77, ctx_dim=64, pipeline=True)
+        batches = [_adv_inputs(OS, ocfg, B, Hh, step) for step in range(5)]
         for step in range(4):
-            a = _adv_inputs(OS, ocfg, B, Hh, step)
+            a = batches[step]
             key = "d_loss" if step % 2 == 0 else "loss_cm"
-            la, lb = float(Da.step_adv(step, *a)[key]), float(Db.step_adv(step, *a)[key])
+            # (Db: eager with the side-stream prefetch; step 2 announces nothing, so step 3 computes its own targets / runs the graph's eager prologue)
+            nxt = tuple(batches[step + 1][:6]) if step != 2 else None
+            la, lb = float(Da.step_adv(step, *a)[key]), float(Db.step_adv(step, *a, prefetch=nxt)[key])
             lg = float(Dg.step_adv_graphed(step, *a)[key])
-            assert la == lb == lg, (step, key, la, lb, lg)
-            for x, y in ((Da, Db), (Da, Dg)):
+            lp = float(Dp.step_adv_graphed(step, *a, prefetch=nxt)[key])
+            assert la == lb == lg == lp, (step, key, la, lb, lg, lp)
+            for x, y in ((Da, Db), (Da, Dg), (Da, Dp)):
                 assert torch.equal(x.lora.params, y.lora.params) and torch.equal(x.disc.params, y.disc.params), (step, "state differs")
                 assert torch.equal(x.disc.grads, y.disc.grads) if step % 2 == 0 else torch.equal(x.lora.grads, y.lora.grads), (step, "gradients differ")
     finally:

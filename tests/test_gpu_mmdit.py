@@ -30,3 +30,9 @@ def test_mmdit_full_lora_list_forward_backward_vs_oracle():
 def test_sd3_adversarial_step_vs_oracle(global_step):
     from mmdit_cases import run_adv_case
     run_adv_case("cuda", global_step)
+
+
+def test_teacher_prefetch_and_pipelined_graph_give_the_same_training_sequence():
+    """eager steps, eager steps with the next batch's teacher pass on a side stream, and the pipelined hipGraph: bitwise the same three steps"""
+    from mmdit_cases import run_prefetch_case
+    run_prefetch_case("cuda", graphs=True)
