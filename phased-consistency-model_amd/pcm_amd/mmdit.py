@@ -20,9 +20,13 @@ import torch
 from . import capi, ops
 from .mmdit_spec import MMDiTConfig, buffer_spec, lora_target_modules, param_spec
 from .precision import act_dtype as _act_dtype
+from . import model as _model
 from .model import LoraState, PackedLayer, layer_bwd, layer_fwd
 from .ops import Seg
 from .precision import precision
+
+# opt-in until measured (tools/jobs/r06_o_*): LoRA weight gradients of the backward on a second stream
+WGRAD_SIDE_STREAM = os.environ.get("PCM_SD3_WGRAD_SIDE", "0") == "1"
 
 # debug hook: PCM_MMDIT_QKV=0 runs the six q/k/v projections of a block as separate layers (A/B measurement)
 FUSE_QKV = os.environ.get("PCM_MMDIT_QKV", "1") != "0"
@@ -261,6 +265,20 @@ class MMDiT:
         (``forward(features=True, save=True)``) take ``d_feats`` (one gradient per block output, entries may be None) instead.
         ``need_input_grad``: also return d hidden_states [B,16,H,W] fp32 (the generator step's path through the frozen teacher of
         the discriminator, train_pcm_lora_sd3_adv.py:1492-1506)."""
+        # LoRA weight gradients beside the input-gradient chain on a second stream (model.WgradSide; PCM_SD3_WGRAD_SIDE=1)
+        dev_ = d_out.device if d_out is not None else self.W.device
+        if self.lora is not None and WGRAD_SIDE_STREAM and dev_.type == "cuda" and not ops.DETERMINISTIC:
+            if getattr(self, "_side", None) is None:
+                self._side = _model.WgradSide()
+            _model._SIDE = self._side
+        try:
+            return self._backward(d_out, tape, d_feats, need_input_grad)
+        finally:
+            if _model._SIDE is not None:
+                _model._SIDE.join()
+            _model._SIDE = None
+
+    def _backward(self, d_out, tape, d_feats, need_input_grad):
         cfg, W, lora = self.cfg, self.W, self.lora
         fin = tape[-1]
         B, H, Wd, Lx, Lc = fin["B"], fin["H"], fin["W"], fin["Lx"], fin["Lc"]
@@ -328,11 +346,13 @@ class MMDiT:
                     rk, t3, xn_ = lora.rank, r["t3"], r["xn"]
                     u3 = torch.empty(Mx, fq.r3, dtype=_act_dtype(), device=d_o.device)
                     ops.gemm([Seg(d3x, fq.Bs_cat_bwd, k_algo=D)], Mx, fq.r3, u3)
-                    with ops.wgrad_batch():
-                        for jj, lm in enumerate((fq.q, fq.k, fq.v)):
-                            ops.lora_wgrad(d3x[:, jj * D:(jj + 1) * D], t3[:, jj * rk:(jj + 1) * rk], lm.gB, lora.scaling, Mx, G=D, g_stride=rk, r_stride=1,
-                                           ldb=3 * D, lds=fq.r3)
-                            ops.lora_wgrad(xn_, u3[:, jj * rk:(jj + 1) * rk], lm.gA, 1.0, Mx, G=fq.K, g_stride=1, r_stride=fq.K, lds=fq.r3)
+                    def wg(d3x=d3x, t3=t3, xn_=xn_, u3=u3, fq=fq, rk=rk):
+                        with ops.wgrad_batch():
+                            for jj, lm in enumerate((fq.q, fq.k, fq.v)):
+                                ops.lora_wgrad(d3x[:, jj * D:(jj + 1) * D], t3[:, jj * rk:(jj + 1) * rk], lm.gB, lora.scaling, Mx, G=D, g_stride=rk, r_stride=1,
+                                               ldb=3 * D, lds=fq.r3)
+                                ops.lora_wgrad(xn_, u3[:, jj * rk:(jj + 1) * rk], lm.gA, 1.0, Mx, G=fq.K, g_stride=1, r_stride=fq.K, lds=fq.r3)
+                    _model._wgrad(wg, d3x, t3, xn_, u3)
                     segs.append(Seg(u3, fq.A_cat_bwd))
                 d_xn = torch.empty(Mx, D, dtype=_act_dtype(), device=d_o.device)
                 ops.gemm(segs, Mx, D, d_xn)

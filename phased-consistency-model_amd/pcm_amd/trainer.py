@@ -561,6 +561,8 @@ class AdvDistiller(Distiller):
         if self.head_grad_exchange not in ("fp32", "bf16"):
             raise ValueError("head_grad_exchange must be 'fp32' or 'bf16'")
         self.adv_lr_dev = torch.full((1,), float(adv_lr), dtype=torch.float32, device=self.device)
+        if os.environ.get("PCM_ADV_FUSE_PASSES") == "0":       # A/B switch: online and target forward as two B-sample passes (round <= 5)
+            self.fuse_online_target = False
 
     def step_adv(self, global_step, latents, prompt_embeds, uncond_prompt_embeds, noise, index, w, noise_fake, noise_real, adv_u,
                  lr=None, added_cond=None, uncond_added_cond=None, targets=None, prefetch=None):
@@ -581,7 +583,18 @@ class AdvDistiller(Distiller):
         if targets is None:     # the ODE-solver teacher pass (sd15_adv.py:1312 ``torch.autocast("cuda")``) + the CFG DDIM step (:1307-1352)
             targets = self.teacher_targets(latents, prompt_embeds, uncond_prompt_embeds, noise, index, w, ac, uac)
         noisy, start_t, t_n, x_prev64, x_prev32 = (targets[k] for k in ("noisy", "start_t", "t_n", "x_prev64", "x_prev32"))
-        if is_d:     # the student forward is not back-propagated on discriminator steps: no tape
+        eps_t = None
+        if self.fuse_online_target:
+            # online forward at t_{n+k} and target forward at (x_prev, t_n) as ONE 2B-sample schedule, as in Distiller.forward_backward (the
+            # teacher's results are at hand before either); discriminator steps back-propagate nothing through the student: no tape
+            eps_st = self.student.forward(torch.cat([noisy, x_prev32]), torch.cat([start_t, t_n]), torch.cat([prompt_embeds, prompt_embeds]),
+                                          save=not is_d, save_half=not is_d, added_cond=cat2(ac, None))
+            tape = None
+            if not is_d:
+                eps_st, tape2 = eps_st
+                tape = self.student.tape_first_half(tape2)
+            eps_s, eps_t = eps_st[:B], eps_st[B:]
+        elif is_d:
             eps_s, tape = self.student.forward(noisy, start_t, prompt_embeds, added_cond=ac), None
         else:
             eps_s, tape = self.student.forward(noisy, start_t, prompt_embeds, save=True, added_cond=ac)
@@ -589,7 +602,8 @@ class AdvDistiller(Distiller):
         span = cfg.num_train_timesteps // cfg.multiphase
         adv_t = end_t + torch.clamp((adv_u * span).long(), max=span - 1)
         fake_adv, sr = ops.noise_travel(model_pred, noise_fake, T.acp, end_t, adv_t)            # :1303-1305
-        eps_t = self.student.forward(x_prev32, t_n, prompt_embeds, added_cond=ac)
+        if eps_t is None:
+            eps_t = self.student.forward(x_prev32, t_n, prompt_embeds, added_cond=ac)
         target, _, _ = ops.phase_jump(eps_t, x_prev64, t_n, index, T.acp, T.acp_prev, T.ddim_timesteps_prev, T.edges, target_mode=True)
         out = dict(model_pred=model_pred, target=target, end_timesteps=end_t, adv_timesteps=adv_t, fake_adv=fake_adv, is_d=is_d)
         if is_d:

@@ -6,6 +6,7 @@ multiphase jumps (float64 through sigma_prev, like the reference), huber loss, L
 Shares the optimizer / gradient-exchange half with the SD1.5 Distiller (same flat fp32 LoRA buffer, one all-reduce).
 """
 import contextlib
+import os
 
 import torch
 
@@ -49,6 +50,14 @@ class SD3Distiller(Distiller):
         self._init_loss_scaler()          # half build (--mixed_precision=fp16, every recipe of text_to_image_sd3/run.sh): device-side GradScaler state
         self.ema = lora.params.clone() if cfg.ema_rate is not None else None
 
+    def _target_side(self):
+        """the HIP stream the no-grad target pass is issued on beside the online pass (None: one launch chain -- the host emulator, PCM_SD3_TARGET_SIDE=0)"""
+        if self.device.type != "cuda" or os.environ.get("PCM_SD3_TARGET_SIDE", "1") == "0":
+            return None
+        if getattr(self, "_tgt_side", None) is None:
+            self._tgt_side = torch.cuda.Stream()
+        return self._tgt_side
+
     # ---- the part of the step that reads nothing trainable (see trainer.Distiller.teacher_targets: same role, same cross-step prefetch) ----
     TARGET_KEYS = ("timesteps", "timesteps_prev", "noisy", "cond", "uncond", "x_prev64", "x_prev32")
     N_BATCH_KEY = 7
@@ -79,12 +88,25 @@ class SD3Distiller(Distiller):
         if targets is None:
             targets = self.teacher_targets(model_input, prompt_embeds, pooled_prompt_embeds, uncond_prompt_embeds, uncond_pooled_prompt_embeds, noise, index)
         timesteps, timesteps_prev, noisy, cond, uncond, x_prev64, x_prev32 = (targets[k] for k in self.TARGET_KEYS)
+        # target: the online weights (LoRA included) under no-grad at (x_prev, t_prev) ------------------------------ :1360-1370
+        def target_pass():
+            tp = self.student.forward(x_prev32, timesteps_prev.float(), prompt_embeds, pooled_prompt_embeds)
+            return (tp,) + tuple(S.euler_style_multiphase_pred(x_prev64, tp, index, cfg.multiphase, True, with_f32=True))
+        # (it shares nothing with the online pass but the weights: at this trainer's batch sizes -- 2 per GPU, 160 tiles of a 256-CU chip per
+        # contraction -- the two passes are issued on two HIP streams and run side by side; same launches, same numbers)
+        side = self._target_side()
+        if side is not None:
+            cur_s = torch.cuda.current_stream()
+            side.wait_stream(cur_s)
+            with torch.cuda.stream(side):
+                target_pred, target64, _, target32 = target_pass()
         # online prediction (grad) and its jump to the phase edge ------------------------------------------------ :1304-1315
         pred, tape = self.student.forward(noisy, timesteps, prompt_embeds, pooled_prompt_embeds, save=True)
         model_pred64, end_index, model_pred32 = S.euler_style_multiphase_pred(noisy, pred, index, cfg.multiphase, with_f32=True)
-        # target: the online weights (LoRA included) under no-grad at (x_prev, t_prev) ------------------------------ :1360-1370
-        target_pred = self.student.forward(x_prev32, timesteps_prev.float(), prompt_embeds, pooled_prompt_embeds)
-        target64, _, target32 = S.euler_style_multiphase_pred(x_prev64, target_pred, index, cfg.multiphase, True, with_f32=True)
+        if side is not None:
+            cur_s.wait_stream(side)
+        else:
+            target_pred, target64, _, target32 = target_pass()
         # d model_pred / d pred = sigma_prev[end] - sigma[index]  (per sample)
         coef = (S.sigmas_prev[end_index] - S.sigmas[index].double()).float().contiguous()
         loss, d_pred = ops.consistency_loss(model_pred32, target32, coef, True, cfg.huber_c, grad_scale=grad_scale)   # :1374-1379

@@ -289,6 +289,14 @@ def run_prefetch_case(dev, graphs=False):
                                          torch.randint(0, 50, (B,), generator=g))) for _ in range(n + 1)]
 
     def run(mode):
+        import os
+        os.environ["PCM_SD3_TARGET_SIDE"] = "0" if mode == "plain" else "1"      # plain: ONE launch chain (no side stream for the target pass either)
+        try:
+            return run_(mode)
+        finally:
+            del os.environ["PCM_SD3_TARGET_SIDE"]
+
+    def run_(mode):
         lora = sd3_lora_state(pc, 32, 8.0, dev, seed=5, b_std=0.05)
         D = SD3Distiller(W, lora, SD3StepConfig(multiphase=2, learning_rate=1e-3))
         if mode == "graph":
