@@ -260,6 +260,25 @@ class MMDiT:
             return out, tape
         return out
 
+    @staticmethod
+    def tape_first_half(tape):
+        """Tape of the first half of the batch of a ``forward(save=True)`` call (as model.UNet.tape_first_half): every saved tensor is batch-major
+        ([B, ...], [B*L, ...] rows or [B, heads, L]), so the first-half tape is the leading half of each (views) with the recorded ``B`` / ``M``
+        halved.  Lets the distillation step run its online (grad) and target (no-grad) forwards as ONE 2B-sample launch schedule."""
+        def half(v, key=None):
+            if isinstance(v, torch.Tensor):
+                assert v.shape[0] % 2 == 0, (key, tuple(v.shape))
+                return v[: v.shape[0] // 2]
+            if isinstance(v, dict):
+                return {k: half(x, k) for k, x in v.items()}
+            if isinstance(v, (list, tuple)):
+                return type(v)(half(x, key) for x in v)
+            if isinstance(v, int) and not isinstance(v, bool) and key in ("B", "M"):
+                assert v % 2 == 0, (key, v)
+                return v // 2
+            return v
+        return [half(r) for r in tape]
+
     def backward(self, d_out, tape, d_feats=None, need_input_grad=False):
         """d_out [B,16,H,W] fp32 -> LoRA gradients accumulated into ``self.lora.grads`` (if any).  Feature-tap tapes
         (``forward(features=True, save=True)``) take ``d_feats`` (one gradient per block output, entries may be None) instead.

@@ -50,9 +50,15 @@ class SD3Distiller(Distiller):
         self._init_loss_scaler()          # half build (--mixed_precision=fp16, every recipe of text_to_image_sd3/run.sh): device-side GradScaler state
         self.ema = lora.params.clone() if cfg.ema_rate is not None else None
 
+    @property
+    def online_target_mode(self):
+        """how the online and the target forward of a step are issued: "fused" | "side" | "serial" (PCM_SD3_ONLINE_TARGET; measured in
+        profiles/r06_n_*, r06_p_*)"""
+        return getattr(self, "_online_target_mode", None) or os.environ.get("PCM_SD3_ONLINE_TARGET", "side")
+
     def _target_side(self):
-        """the HIP stream the no-grad target pass is issued on beside the online pass (None: one launch chain -- the host emulator, PCM_SD3_TARGET_SIDE=0)"""
-        if self.device.type != "cuda" or os.environ.get("PCM_SD3_TARGET_SIDE", "1") == "0":
+        """the HIP stream the no-grad target pass is issued on beside the online pass in mode "side" (None on the host emulator: one launch chain)"""
+        if self.device.type != "cuda":
             return None
         if getattr(self, "_tgt_side", None) is None:
             self._tgt_side = torch.cuda.Stream()
@@ -88,22 +94,34 @@ class SD3Distiller(Distiller):
         if targets is None:
             targets = self.teacher_targets(model_input, prompt_embeds, pooled_prompt_embeds, uncond_prompt_embeds, uncond_pooled_prompt_embeds, noise, index)
         timesteps, timesteps_prev, noisy, cond, uncond, x_prev64, x_prev32 = (targets[k] for k in self.TARGET_KEYS)
-        # target: the online weights (LoRA included) under no-grad at (x_prev, t_prev) ------------------------------ :1360-1370
+        # online prediction (grad, :1304-1315) and target prediction (the online weights, LoRA included, under no-grad at (x_prev, t_prev),
+        # :1360-1370) with their jumps to the phase edge.  The two passes share nothing but the weights, and at this trainer's batch sizes (2 per
+        # GPU: 160 tiles of a 256-CU chip per contraction) neither fills the chip:
+        #   "side" (default): two B-sample passes issued on two HIP streams (one launch chain on the host emulator);
+        #   "fused": ONE 2B-sample launch schedule, back-propagated through the online half of its tape (as trainer.Distiller does);
+        #   "serial": one launch chain.   Measured on one MI355X, bs 2 (profiles/r06_p_*): serial 142.5, fused 136.1-136.8, side 134.8-134.9 ms per step.
         def target_pass():
             tp = self.student.forward(x_prev32, timesteps_prev.float(), prompt_embeds, pooled_prompt_embeds)
             return (tp,) + tuple(S.euler_style_multiphase_pred(x_prev64, tp, index, cfg.multiphase, True, with_f32=True))
-        # (it shares nothing with the online pass but the weights: at this trainer's batch sizes -- 2 per GPU, 160 tiles of a 256-CU chip per
-        # contraction -- the two passes are issued on two HIP streams and run side by side; same launches, same numbers)
-        side = self._target_side()
-        if side is not None:
-            cur_s = torch.cuda.current_stream()
-            side.wait_stream(cur_s)
-            with torch.cuda.stream(side):
-                target_pred, target64, _, target32 = target_pass()
-        # online prediction (grad) and its jump to the phase edge ------------------------------------------------ :1304-1315
-        pred, tape = self.student.forward(noisy, timesteps, prompt_embeds, pooled_prompt_embeds, save=True)
+        mode = self.online_target_mode
+        side = self._target_side() if mode == "side" else None
+        if mode == "fused":
+            B = model_input.shape[0]
+            both, tape2 = self.student.forward(torch.cat([noisy, x_prev32]), torch.cat([timesteps.float(), timesteps_prev.float()]),
+                                               torch.cat([prompt_embeds, prompt_embeds]), torch.cat([pooled_prompt_embeds, pooled_prompt_embeds]), save=True)
+            pred, target_pred, tape = both[:B], both[B:], self.student.tape_first_half(tape2)
+            del tape2
+        else:
+            if side is not None:
+                cur_s = torch.cuda.current_stream()
+                side.wait_stream(cur_s)
+                with torch.cuda.stream(side):
+                    target_pred, target64, _, target32 = target_pass()
+            pred, tape = self.student.forward(noisy, timesteps, prompt_embeds, pooled_prompt_embeds, save=True)
         model_pred64, end_index, model_pred32 = S.euler_style_multiphase_pred(noisy, pred, index, cfg.multiphase, with_f32=True)
-        if side is not None:
+        if mode == "fused":
+            target64, _, target32 = S.euler_style_multiphase_pred(x_prev64, target_pred, index, cfg.multiphase, True, with_f32=True)
+        elif side is not None:
             cur_s.wait_stream(side)
         else:
             target_pred, target64, _, target32 = target_pass()

@@ -290,11 +290,7 @@ def run_prefetch_case(dev, graphs=False):
 
     def run(mode):
         import os
-        os.environ["PCM_SD3_TARGET_SIDE"] = "0" if mode == "plain" else "1"      # plain: ONE launch chain (no side stream for the target pass either)
-        try:
-            return run_(mode)
-        finally:
-            del os.environ["PCM_SD3_TARGET_SIDE"]
+        return run_(mode)
 
     def run_(mode):
         lora = sd3_lora_state(pc, 32, 8.0, dev, seed=5, b_std=0.05)
@@ -320,6 +316,39 @@ def run_prefetch_case(dev, graphs=False):
     for l, p_ in runs[1:]:
         assert l == runs[0][0] and torch.equal(p_, runs[0][1]), (runs[0][0], l)
     assert len(set(runs[0][0])) == n
+
+
+def run_online_target_modes_case(dev):
+    """SD3Distiller.online_target_mode: the online and the target forward as two passes ("serial" / "side": the same launches on one or two streams ->
+    bitwise the same step) or as ONE 2B-sample pass whose tape is halved for the backward ("fused": the same arithmetic per sample, contraction plans
+    may differ with the row count -> equal to summation rounding)."""
+    from oracle import mmdit_sd3 as O
+    from pcm_amd.mmdit import MMDiTWeights, sd3_lora_state
+    from pcm_amd.mmdit_spec import MMDiTConfig
+    from pcm_amd.trainer_sd3 import SD3Distiller, SD3StepConfig
+    kw = dict(sample_size=16, num_layers=2, attention_head_dim=64, num_attention_heads=2, joint_attention_dim=96, caption_projection_dim=128,
+              pooled_projection_dim=64, pos_embed_max_size=12)
+    sd = O.init_state_dict(O.MMDiTConfig(**kw), 0)
+    pc = MMDiTConfig(**kw)
+    W = MMDiTWeights(pc, {k: v.to(dev) for k, v in sd.items()}, dev)
+    g = torch.Generator().manual_seed(11)
+    B, H, Lc = 2, 8, 5
+    batch = tuple(t.to(dev) for t in (torch.randn(B, 16, H, H, generator=g), torch.randn(B, Lc, 96, generator=g), torch.randn(B, 64, generator=g),
+                                      torch.randn(B, Lc, 96, generator=g), torch.randn(B, 64, generator=g), torch.randn(B, 16, H, H, generator=g),
+                                      torch.tensor([7, 33])))
+    res = {}
+    for mode in ("serial", "side", "fused"):
+        lora = sd3_lora_state(pc, 32, 8.0, dev, seed=5, b_std=0.05)
+        D = SD3Distiller(W, lora, SD3StepConfig(multiphase=2, learning_rate=1e-3))
+        D._online_target_mode = mode
+        out = D.step(*batch)
+        res[mode] = (float(out["loss"]), out["target"].double().cpu().clone(), lora.grads.double().cpu().clone())
+    assert res["serial"][0] == res["side"][0] and torch.equal(res["serial"][2], res["side"][2])
+    l0, t0, g0 = res["serial"]
+    l1, t1, g1 = res["fused"]
+    assert abs(l1 - l0) <= 2e-3 * abs(l0), (l0, l1)
+    assert float((t1 - t0).norm() / t0.norm()) < 2e-3
+    assert float((g1 * g0).sum() / (g1.norm() * g0.norm())) > 0.999 and float(g0.norm()) > 0
 
 
 def run_property_case(dev, cfg, W, lora, hw, Lc):

@@ -36,3 +36,8 @@ def test_teacher_prefetch_and_pipelined_graph_give_the_same_training_sequence():
     """eager steps, eager steps with the next batch's teacher pass on a side stream, and the pipelined hipGraph: bitwise the same three steps"""
     from mmdit_cases import run_prefetch_case
     run_prefetch_case("cuda", graphs=True)
+
+
+def test_online_and_target_forward_as_one_pass_or_two_is_the_same_step():
+    from mmdit_cases import run_online_target_modes_case
+    run_online_target_modes_case("cuda")
