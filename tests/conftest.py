@@ -10,6 +10,25 @@ for p in (ROOT, PKG):
         sys.path.insert(0, p)
 
 
+@pytest.hookimpl(tryfirst=True)
+def pytest_cmdline_main(config):
+    """The CPU suite (``-m "not gpu"``) is mostly the single-threaded wave64 host emulator stepping whole networks: one process takes about an
+    hour, the machine's cores take ~15 minutes.  When the caller asked for the CPU suite and gave no ``-n`` (and pytest-xdist is there), run it
+    on min(7, cores - 1) workers (what fits the build container's 64 GiB); PCM_TEST_WORKERS=N overrides, 0 keeps one process.  The ``-m gpu``
+    suite is never parallelised: its tests time kernels and share one device."""
+    opt = config.option
+    if os.environ.get("PYTEST_XDIST_WORKER") or hasattr(config, "workerinput"):      # (a worker: it must not spawn workers of its own)
+        return None
+    if getattr(opt, "markexpr", "") != "not gpu" or getattr(opt, "numprocesses", 0) is not None or not config.pluginmanager.hasplugin("xdist"):
+        return None
+    if getattr(opt, "collectonly", False) or getattr(opt, "usepdb", False):
+        return None
+    n = int(os.environ.get("PCM_TEST_WORKERS", min(7, max(1, (os.cpu_count() or 2) - 1))))
+    if n > 1:
+        opt.numprocesses = n          # (pytest-xdist's own pytest_cmdline_main, called after this one, turns it into n popen workers, --dist load)
+    return None
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "slow: long CPU test")

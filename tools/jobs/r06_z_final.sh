@@ -16,6 +16,9 @@ timeout 600 python bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-rooflin
 for c in c3 c4 c5; do
   timeout 600 python bench.py --config $c --steps 10 --warmup 4 > $O/bench_$c.json 2> $O/bench_$c.err; echo "$c rc=$?" >> $O/rc.log
 done
+PCM_FORCE_DEVICE=0 PCM_DIST_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > $O/bench2_rehearsal_c2.json 2> $O/bench2_c2.err; echo "2-rank rehearsal c2 rc=$?" >> $O/rc.log
+PCM_FORCE_DEVICE=0 PCM_DIST_BACKEND=gloo PCM_ADV_GRAPH=0 timeout 600 python bench.py --gpus 2 --config c3 --steps 2 --warmup 2 --no-graph > $O/bench2_rehearsal_c3.json 2> $O/bench2_c3.err; echo "2-rank rehearsal c3 rc=$?" >> $O/rc.log
+PCM_FORCE_DEVICE=0 PCM_DIST_BACKEND=gloo timeout 600 python bench.py --gpus 2 --config c5 --steps 2 --warmup 1 > $O/bench2_rehearsal_c5.json 2> $O/bench2_c5.err; echo "2-rank rehearsal c5 rc=$?" >> $O/rc.log
 timeout 600 python tools/fwd2t_trace.py > $O/fwd2t.txt 2>&1; echo "fwd2t rc=$?" >> $O/rc.log
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_z -o b -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-graph > $GRAFT_REPO_ROOT/$O/prof_bench.log 2>&1); echo "prof rc=$?" >> $O/rc.log
 python tools/prof_summary.py $(find /tmp/prof_z -name "*.db" | head -1) 70 > $O/kernel_stats_bench_bs16.txt 2>&1; echo "summary rc=$?" >> $O/rc.log
@@ -23,3 +26,4 @@ cp gpurun_out/*.json $O/ 2>/dev/null
 cat $O/libs.log $O/rc.log; tail -n 22 $O/pytest_gpu.log; tail -n 5 $O/smoke.log; cut -c1-900 $O/bench_c2_default_flags.json; echo; tail -n 6 $O/fwd2t.txt
 for f in c2_12_steps c2_no_prefetch c2_deterministic c2_teacher_fp16 c2_fp16 c3 c4 c5; do grep -o '"value": [0-9.]*, "unit": "images/sec", "n_gpus": 1, "steps": [0-9]*, "warmup": [0-9]*, "ms_per_step": [0-9.]*' $O/bench_$f.json | sed "s/^/$f /"; done
 cut -c1-170 $O/pmc_step_table.txt | head -12
+for f in c2 c3 c5; do cut -c1-260 $O/bench2_rehearsal_$f.json; echo; tail -n 2 $O/bench2_$f.err; done
