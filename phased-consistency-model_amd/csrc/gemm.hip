@@ -640,9 +640,11 @@ static bool gemm_smallm_ok(const pcm_gemm_seg* segs, int nseg, const pcm_gemm_ep
 // workgroup, held in registers), K total 320 or 384 (K + rank-64 LoRA), plain segments, enough 64-row tiles for every CU to amortise its weight
 // fill.  BUILT, BIT-IDENTICAL TO THE PHASED TILE, MEASURED SLOWER (x1.06-1.35 on every N = 320 shape, profiles/r06_l_*: with ONE wave per SIMD the
 // LDS-DMA issue slots, the LDS waits and the epilogue's ~700 instructions per 64 rows all ADD to the MFMA time -- 5.1 us per 64-row step against
-// 1.4 us of MFMAs): it exists in the TOOLS build only (PCM_GEMM_WS=1 / pcm_debug_gemm_ws), the product planner never takes it.
+// 1.4 us of MFMAs): it exists in the TOOLS build only (PCM_GEMM_WS=1 / pcm_debug_gemm_ws), the product planner never takes it.  Re-measured with the
+// epilogue's LDS accesses untracked and as an eight-wave form (PCM_GEMM_WS=2): on par with the phased tile at best -- the shapes run at the fabric's
+// 3.4-5 TB/s (header of gemm_ws.hip, profiles/r06_q_*).
 PCM_LAZY_KNOB(ws_on, g_ws_on, "PCM_GEMM_WS", 0)
-PCM_TOOLS_ONLY(extern "C" void pcm_debug_gemm_ws(int on) { g_ws_on = on < 0 ? -1 : (on ? 1 : 0); })
+PCM_TOOLS_ONLY(extern "C" void pcm_debug_gemm_ws(int on) { g_ws_on = on < 0 ? -1 : (on > 2 ? 1 : on); })      // 1: four-wave form, 2: eight-wave form
 static bool gemm_ws_ok(const pcm_gemm_seg* segs, int nseg, const pcm_gemm_epi* e) {
   if (!ws_on() || big_mode() != 1 || g_force_bm) return false;
   if (e->out_dtype == PCM_F32 || e->act != PCM_ACT_NONE || e->rowvec || e->out2 || e->chstats || e->pre_out) return false;
@@ -655,7 +657,7 @@ static bool gemm_ws_ok(const pcm_gemm_seg* segs, int nseg, const pcm_gemm_epi* e
     if (s.mode != PCM_SEG_PLAIN || (s.K % 64) || (s.lda % 8) || (((uintptr_t)s.a) & 15) || (((uintptr_t)s.w) & 15)) return false;
     kt += s.K;
   }
-  return kt == 320 || kt == 384;
+  return kt == 320 || (kt == 384 && ws_on() != 2);      // (the eight-wave form exists for K = 320 only)
 }
 extern "C" size_t pcm_gemm_workspace_bytes(const pcm_gemm_seg* segs, int nseg, const pcm_gemm_epi* e) {
   if (!segs || !e || nseg < 1 || nseg > 2 || e->M <= 0 || e->N <= 0) return 0;
@@ -775,9 +777,10 @@ static int gemm_run(const pcm_gemm_seg* segs, int nseg, const pcm_gemm_epi* e, v
     return pcm_post_launch("pcm_gemm_bf16");
   }
   if (gemm_ws_ok(segs, nseg, e)) {
-    *code = 30000 + (segs[0].K + (nseg > 1 ? segs[1].K : 0)) / 32;
+    const int form = ws_on() == 2 ? 2 : 1;
+    *code = 30000 + 1000 * (form - 1) + (segs[0].K + (nseg > 1 ? segs[1].K : 0)) / 32;
     if (plan_only) return PCM_OK;
-    int rc = pcm_gemm_ws_launch(g, stream);
+    int rc = pcm_gemm_ws_launch(g, stream, form);
     if (rc) return rc;
     return pcm_post_launch("pcm_gemm_bf16");
   }

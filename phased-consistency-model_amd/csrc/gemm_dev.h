@@ -111,7 +111,7 @@ size_t pcm_gemm8p_lds_bytes(int fn);
 // 128 x (64*FN) short-K kernel at two workgroups per CU (gemm4w.hip).  grid = tiles_m*tiles_n (tiles_m counts 128-row tiles); no split-K
 int pcm_gemm4w_launch(const GemmDev& g, int fn, void* stream);
 // weights-stationary kernel for the short-K projections of the 64x64 level (gemm_ws.hip): N % 320 == 0, K total 320 / 384, plain segments
-int pcm_gemm_ws_launch(const GemmDev& g, void* stream);
+int pcm_gemm_ws_launch(const GemmDev& g, void* stream, int form);      // form 1: four waves x 80 columns; 2: eight waves x 40 columns
 // rank-64 down-projection of a conv LoRA factor from a halo window (conv_r64.hip): 0 = launched, 1 = not one of its shapes, < 0 error
 int pcm_conv_r64_launch(const GemmDev& g, void* stream, bool plan_only = false);
 // streaming kernel for the rank-64 projections (gemm_n64.hip)

@@ -283,6 +283,15 @@ inline emu_v4i buffer_load_b128(BufferRsrc rs, uint32_t voff, uint32_t soff, int
 // hardware-only code-generation controls of csrc/pcm_common.h
 #define PCM_HW_ONLY(...)
 #define PCM_WAVE_LDS_FENCE() pcm_emu::wave_sync()
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#define PCM_LDS_LD64(dst, p) (dst) = *(const decltype(dst)*)(p)
+#define PCM_LDS_LD128(dst, p) (dst) = *(const decltype(dst)*)(p)
+#define PCM_LDS_ST64(p, val) *(decltype(val)*)(p) = (val)
+#define PCM_LDS_WAIT1(a) ((void)0)
+#define PCM_LDS_WAIT2(a, b) ((void)0)
+#define PCM_LDS_WAIT5(a, b, c, d, e) ((void)0)
+#define PCM_LDS_WAIT_ALL() ((void)0)
 #define PCM_PIN_V(x) ((void)0)
 #define PCM_PIN_S(x) ((void)0)
 #define PCM_KERNARG_REF(T, arr, i) ((arr)[i])

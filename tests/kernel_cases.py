@@ -787,7 +787,7 @@ def case_gemm_epilogue_fusions(dev, which):
         dll.pcm_debug_gemm_big_mode(1)
 
 
-def case_gemm_ws(dev, which):
+def case_gemm_ws(dev, which, form=1):
     """The weights-stationary kernel (csrc/gemm_ws.hip, round 6): the short-K projections of the 64x64 level -- a 320-column weight slice held in
     registers per workgroup, 64-row activation tiles through a two-stage LDS-DMA ring.  Against torch fp32 on the same 16-bit operands AND bit for
     bit against the phased tile (pcm_debug_gemm_ws(0)): same products, same accumulation order, same epilogue operation order."""
@@ -798,7 +798,8 @@ def case_gemm_ws(dev, which):
         return (torch.randn(*shape, generator=g) * scale).to(ops.BF16).to(dev)
 
     M, N, lora, res, bias, strided = {"plain": (16384, 320, False, False, False, False), "lora_res": (16384, 320, True, True, True, False),
-                                      "qkv": (16384, 960, False, False, False, False), "tail_strided": (16384 + 72, 320, True, True, True, True)}[which]
+                                      "qkv": (16384, 960, False, False, False, False), "tail_strided": (16384 + 72, 320, True, True, True, True),
+                                      "res_tail_strided": (16384 + 72, 320, False, True, True, True)}[which]
     K = 320
     xw = rnd(M, K + 64, seed=1) if strided else None            # the activation as a column slice of a wider matrix (row stride K + 64)
     x = xw[:, :K] if strided else rnd(M, K, seed=1)
@@ -817,7 +818,7 @@ def case_gemm_ws(dev, which):
         ref = ref + r.float().cpu()
     dll = capi.lib().dll
     outs = []
-    for on in (1, 0):
+    for on in (form, 0):
         dll.pcm_debug_gemm_ws(on)
         try:
             ow = torch.full((M, N + (64 if strided else 0)), 5.0, dtype=ops.BF16, device=dev)
@@ -825,7 +826,7 @@ def case_gemm_ws(dev, which):
             plan = dll.pcm_debug_last_gemm_plan()
         finally:
             dll.pcm_debug_gemm_ws(-1)
-        assert (plan // 10000 == 3) == bool(on), (which, on, plan)
+        assert (plan // 1000 == 29 + on) == bool(on), (which, on, plan)       # 30000 + K/32: four waves x 80 columns; 31000 + K/32: eight waves x 40
         outs.append(ow)
     got = outs[0][:, :N].float().cpu()
     err = (got - ref).abs()
@@ -835,7 +836,8 @@ def case_gemm_ws(dev, which):
         assert bool((outs[0][:, N:].float() == 5.0).all()), "columns beyond N touched"
 
 
-GEMM_WS_CASES = ["plain", "lora_res", "qkv", "tail_strided"]
+GEMM_WS_CASES = ["plain", "lora_res", "qkv", "tail_strided"]          # form 1 (four waves)
+GEMM_WS8_CASES = ["plain", "qkv", "res_tail_strided"]                    # form 2 (eight waves; K = 320 only)
 
 
 GEMM_EPI_FUSION_CASES = ["plain", "res", "small_maps", "ragged_n", "splitk", "conv_rowvec", "small_tile"]

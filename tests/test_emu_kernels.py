@@ -304,8 +304,9 @@ def test_gemm_epilogue_fusions_second_output_and_groupnorm_statistics(which):
     K.case_gemm_epilogue_fusions("cpu", which)
 
 
-@pytest.mark.parametrize("which", K.GEMM_WS_CASES)
-def test_gemm_weights_stationary_kernel(which):
-    """csrc/gemm_ws.hip: the short-K projections of the 64x64 level with the weight slice held in registers"""
+@pytest.mark.parametrize("which,form", [("lora_res", 1), ("tail_strided", 1), ("plain", 2), ("res_tail_strided", 2)])
+def test_gemm_weights_stationary_kernel(which, form):
+    """csrc/gemm_ws.hip: the short-K projections of the 64x64 level with the weight slice held in registers (form 1: four waves x 80 columns,
+    form 2: eight waves x 40 columns); all four cases of both forms run on the GPU"""
     import kernel_cases as KC
-    KC.case_gemm_ws("cpu", which)
+    KC.case_gemm_ws("cpu", which, form)

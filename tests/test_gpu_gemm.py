@@ -186,8 +186,8 @@ def test_gemm_epilogue_fusions_second_output_and_groupnorm_statistics(which):
     KC.case_gemm_epilogue_fusions("cuda", which)
 
 
-@pytest.mark.parametrize("which", __import__("kernel_cases").GEMM_WS_CASES)
-def test_gemm_weights_stationary_kernel(which):
-    """csrc/gemm_ws.hip: the short-K projections of the 64x64 level with the weight slice held in registers"""
+@pytest.mark.parametrize("which,form", [(w, 1) for w in __import__("kernel_cases").GEMM_WS_CASES] + [(w, 2) for w in __import__("kernel_cases").GEMM_WS8_CASES])
+def test_gemm_weights_stationary_kernel(which, form):
+    """csrc/gemm_ws.hip: the short-K projections of the 64x64 level with the weight slice held in registers (four-wave and eight-wave form)"""
     import kernel_cases as KC
-    KC.case_gemm_ws("cuda", which)
+    KC.case_gemm_ws("cuda", which, form)

@@ -1,5 +1,5 @@
 """Weights-stationary kernel (csrc/gemm_ws.hip) against the phased tile on the short-K projections of the 64x64 level, per shape, interleaved:
-    python tools/gemm_ws_ab.py        (TOOLS build: pcm_debug_gemm_ws switches the kernel)"""
+    python tools/gemm_ws_ab.py        (TOOLS build: pcm_debug_gemm_ws switches the kernel: 0 phased tile, 1 four-wave form, 2 eight-wave form)"""
 import os
 import sys
 
@@ -32,7 +32,7 @@ def bench(fn, reps=20):
     return e0.elapsed_time(e1) / reps * 1e3
 
 
-print("%-34s %-10s %9s %9s %7s   %s" % ("(M, N, K segments)", "epilogue", "8p us", "ws us", "x", "ws GB/s (algorithmic bytes)"))
+print("%-34s %-10s %9s %9s %7s %9s %7s   %s" % ("(M, N, K segments)", "epilogue", "8p us", "ws4 us", "x", "ws8 us", "x", "ws8 GB/s (algorithmic bytes)"))
 for M in (131072, 65536, 32768):
     for N, lora, res, bias in ((320, False, False, False), (320, False, True, True), (320, True, False, False), (320, True, True, True), (960, False, False, False)):
         K = 320
@@ -51,9 +51,13 @@ for M in (131072, 65536, 32768):
         # evict between shapes is not needed: every call streams >= 100 MB
         ts = {}
         for rnd_ in range(2):
-            for on in (0, 1):
+            for on in (0, 1, 2):
+                if on == 2 and lora:
+                    ts.setdefault(on, []).append(float("nan"))      # (the eight-wave form exists for K = 320 only)
+                    continue
                 dll.pcm_debug_gemm_ws(on)
                 ts.setdefault(on, []).append(bench(lambda: ops.gemm(segs, M, N, out, bias=b, residual=r)))
         dll.pcm_debug_gemm_ws(-1)
-        t8, tw = min(ts[0]), min(ts[1])
-        print("%-34s %-10s %9.1f %9.1f %7.3f   %.0f" % (str((M, N, (K, 64) if lora else (K,))), ("bias+res" if res else "none"), t8, tw, tw / t8, nbytes / tw / 1e3), flush=True)
+        t8, tw, tw8 = min(ts[0]), min(ts[1]), min(ts[2])
+        print("%-34s %-10s %9.1f %9.1f %7.3f %9.1f %7.3f   %.0f" % (str((M, N, (K, 64) if lora else (K,))), ("bias+res" if res else "none"), t8, tw, tw / t8, tw8, tw8 / t8,
+                                                                nbytes / tw8 / 1e3), flush=True)
