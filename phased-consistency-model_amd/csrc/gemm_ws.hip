@@ -21,7 +21,7 @@
 // ds_read / ds_write of the epilogue (it cannot tell which LDS bytes pending LDS-DMA will write) -- the tile prefetched two steps ahead was drained
 // every step.  With untracked LDS accesses (PCM_LDS_*, inline asm) the steady state holds only the counted waits, and an EIGHT-wave form
 // (pcm_gemm_ws8_kernel below: two waves per SIMD, 40 columns each) removes the one-wave-per-SIMD serialisation as well -- and both forms still only
-// MATCH the phased tile at M = 131072 (46.9 us phased, 48.6 four waves, 49.3 eight waves; with bias + residual 55.1 / 58.3 / 49.9) and lose at
+// MATCH the phased tile at M = 131072 (46.9 us phased, 49.0 four waves, 51.4 eight waves; with bias + residual 55.9 / 59.5 / 50.7) and lose at
 // M <= 65536 (the weight fill is amortised over 4 steps).  Because these launches are not issue-bound at all: 168-252 MB of activations in + out in
 // 47-55 us is 3.4-5.0 TB/s -- the fabric's rate for a read + write mix.  The phased tile already sits there; no kernel structure moves it.
 #include "gemm_dev.h"
@@ -175,7 +175,6 @@ __global__ __launch_bounds__(256, 1) void pcm_gemm_ws_kernel(GemmDev g, int step
         if (has_res) {
           u32x2 rr2;
           PCM_LDS_LD64(rr2, slot);
-          PCM_LDS_WAIT1(rr2);
           a[0] += bf2f((bf16_t)(rr2.x & 0xffff)); a[1] += bf2f((bf16_t)(rr2.x >> 16));
           a[2] += bf2f((bf16_t)(rr2.y & 0xffff)); a[3] += bf2f((bf16_t)(rr2.y >> 16));
         }
@@ -190,7 +189,6 @@ __global__ __launch_bounds__(256, 1) void pcm_gemm_ws_kernel(GemmDev g, int step
       const int m = 64 * s + r;
       u32x4 q;
       PCM_LDS_LD128(q, stage + p * 16);
-      PCM_LDS_WAIT1(q);
       if (m < g.M) *(u32x4*)((bf16_t*)g.out + (size_t)m * g.ldo + n0 + 8 * c) = q;
     }
   }
@@ -332,8 +330,8 @@ __global__ __launch_bounds__(512, 1) void pcm_gemm_ws8_kernel(GemmDev g, int ste
         char* slot = stage + (16 * i + frow) * 80 + 32 * f + 8 * fk;
         u32x4 b4u;
         u32x2 rr2 = u32x2{0u, 0u};
-        PCM_LDS_LD128(b4u, lbias + 16 * f + 4 * fk);
-        if (has_res) { PCM_LDS_LD64(rr2, slot); PCM_LDS_WAIT2(b4u, rr2); } else { PCM_LDS_WAIT1(b4u); }
+        if (has_res) PCM_LDS_LD128_LD64(b4u, lbias + 16 * f + 4 * fk, rr2, slot);
+        else PCM_LDS_LD128(b4u, lbias + 16 * f + 4 * fk);
         f32x4 a = acc[i][f] * g.alpha + f32x4{__uint_as_float(b4u.x), __uint_as_float(b4u.y), __uint_as_float(b4u.z), __uint_as_float(b4u.w)};
         if (has_res) {
           a[0] += bf2f((bf16_t)(rr2.x & 0xffff)); a[1] += bf2f((bf16_t)(rr2.x >> 16));
@@ -350,7 +348,6 @@ __global__ __launch_bounds__(512, 1) void pcm_gemm_ws8_kernel(GemmDev g, int ste
       const int m = 64 * s + r;
       u32x4 q;
       PCM_LDS_LD128(q, stage + p * 16);
-      PCM_LDS_WAIT1(q);
       if (m < g.M) *(u32x4*)((bf16_t*)g.out + (size_t)m * g.ldo + n0 + 8 * c) = q;
     }
   }

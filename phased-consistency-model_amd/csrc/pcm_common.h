@@ -31,15 +31,16 @@
 // LDS accesses hipcc does not track (inline asm; the emulator's are plain accesses).  Why: while LDS-DMA pieces are in flight hipcc puts
 // s_waitcnt vmcnt(0) in front of EVERY ds_read / ds_write it emits itself (it cannot tell which LDS bytes the DMA will write), which drains a
 // prefetched tile the moment an epilogue touches its staging area.  These are for regions the code itself has ordered against the DMA (a counted
-// PCM_WAIT_VMCNT).  A load's destination is valid after PCM_LDS_WAIT(dst...) -- which also is the data dependence for the consumers.
+// PCM_WAIT_VMCNT).  Each load is ONE asm statement with its own s_waitcnt: with the wait in a second statement hipcc may copy the destination
+// registers between the two (a v_mov of a register the LDS has not written yet -- seen on hardware as a wrong upper dword, never on the emulator).
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-#define PCM_LDS_LD64(dst, p) asm volatile("ds_read_b64 %0, %1" : "=v"(dst) : "v"((unsigned)(size_t)(p)))
-#define PCM_LDS_LD128(dst, p) asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"((unsigned)(size_t)(p)))
+#define PCM_LDS_LD64(dst, p) asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(dst) : "v"((unsigned)(size_t)(p)) : "memory")
+#define PCM_LDS_LD128(dst, p) asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(dst) : "v"((unsigned)(size_t)(p)) : "memory")
+#define PCM_LDS_LD128_LD64(d128, p128, d64, p64)                                                                             \
+  asm volatile("ds_read_b128 %0, %2\n\tds_read_b64 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(d128), "=&v"(d64)               \
+               : "v"((unsigned)(size_t)(p128)), "v"((unsigned)(size_t)(p64)) : "memory")
 #define PCM_LDS_ST64(p, val) asm volatile("ds_write_b64 %0, %1" : : "v"((unsigned)(size_t)(p)), "v"(val) : "memory")
-#define PCM_LDS_WAIT1(a) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a) : : "memory")
-#define PCM_LDS_WAIT2(a, b) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b) : : "memory")
-#define PCM_LDS_WAIT5(a, b, c, d, e) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e) : : "memory")
 #define PCM_LDS_WAIT_ALL() asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory")
 #define PCM_HW_ONLY(...) __VA_ARGS__
 #define PCM_PIN_V(x) asm volatile("" : "+v"(x))

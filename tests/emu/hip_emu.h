@@ -287,10 +287,8 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define PCM_LDS_LD64(dst, p) (dst) = *(const decltype(dst)*)(p)
 #define PCM_LDS_LD128(dst, p) (dst) = *(const decltype(dst)*)(p)
+#define PCM_LDS_LD128_LD64(d128, p128, d64, p64) do { (d128) = *(const decltype(d128)*)(p128); (d64) = *(const decltype(d64)*)(p64); } while (0)
 #define PCM_LDS_ST64(p, val) *(decltype(val)*)(p) = (val)
-#define PCM_LDS_WAIT1(a) ((void)0)
-#define PCM_LDS_WAIT2(a, b) ((void)0)
-#define PCM_LDS_WAIT5(a, b, c, d, e) ((void)0)
 #define PCM_LDS_WAIT_ALL() ((void)0)
 #define PCM_PIN_V(x) ((void)0)
 #define PCM_PIN_S(x) ((void)0)
