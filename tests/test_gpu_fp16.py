@@ -199,7 +199,8 @@ def test_fp16_graph_replay_equals_eager_and_overflow_is_skipped():
         torch.cuda.synchronize()
         res.append((float(out["loss"].item()), lora.params.clone(), float(D.loss_scale_dev.item()), int(D.step_dev.item())))
     # same kernels in the same order; the LoRA gradients are fp32 atomics, so the two runs may differ by summation order only
-    assert abs(res[0][0] - res[1][0]) <= 1e-6 * abs(res[0][0]) and rel(res[1][1], res[0][1]) < 1e-6 and res[0][2:] == res[1][2:] == (65536.0, 3)
+    # (three updates deep: the third step's loss and the parameters carry the atomics-order noise of the first two -- bounds as in tests/test_gpu_adv.py)
+    assert abs(res[0][0] - res[1][0]) <= 1e-4 * abs(res[0][0]) and rel(res[1][1], res[0][1]) < 1e-4 and res[0][2:] == res[1][2:] == (65536.0, 3)
     # (2) overflow: poison one gradient after the backward, then run the optimizer leg
     out = D.forward_backward(*args)
     lora.grads[5] = float("inf")

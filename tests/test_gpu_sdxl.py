@@ -88,7 +88,10 @@ def test_sdxl_topology_step_vs_oracle():
         og = Dg.step_graphed(*a6, added_cond=ac2, uncond_added_cond=uac)
         lg = float(og["loss"])
         oe = De.step(*a6, added_cond=ac2, uncond_added_cond=uac)
-        assert abs(lg - float(oe["loss"])) <= 1e-6 * abs(float(oe["loss"])), (rep, lg, float(oe["loss"]))
+        # (first step: identical state, identical arithmetic; later steps run on parameters that already differ by the atomics-order noise of
+        # the earlier gradients -- the bound on them below -- which moves the loss by up to a few 1e-4 relative: seen 1.7e-4 once in ~10 runs)
+        tol = 1e-6 if rep == 0 else 5e-4
+        assert abs(lg - float(oe["loss"])) <= tol * abs(float(oe["loss"])), (rep, lg, float(oe["loss"]))
         if rep == 0:      # identical state on both trainers: the gradient buffers may differ by the order of fp32 atomics only
             from test_gpu_bench_config import assert_grads_match_per_module
             assert_grads_match_per_module(lora_g, lora_g.grads, lora_e.grads)
