@@ -290,12 +290,16 @@ class MMDiT:
             if getattr(self, "_side", None) is None:
                 self._side = _model.WgradSide()
             _model._SIDE = self._side
+        elif self.lora is not None and _model.WGRAD_DEFER > 1:      # weight-gradient jobs collected across modules (model._wgrad / _flush_deferred)
+            _model._DEFER = []
         try:
-            return self._backward(d_out, tape, d_feats, need_input_grad)
+            out = self._backward(d_out, tape, d_feats, need_input_grad)
+            _model._flush_deferred()
+            return out
         finally:
             if _model._SIDE is not None:
                 _model._SIDE.join()
-            _model._SIDE = None
+            _model._SIDE = _model._DEFER = None
 
     def _backward(self, d_out, tape, d_feats, need_input_grad):
         cfg, W, lora = self.cfg, self.W, self.lora

@@ -534,9 +534,32 @@ _SIDE = None      # set by UNet.backward for the duration of one backward pass (
 WGRAD_SIDE_STREAM = os.environ.get("PCM_WGRAD_SIDE", "0") == "1"
 
 
+# PCM_WGRAD_DEFER=n (round 6): the weight-gradient jobs of up to n LoRA modules of a backward are collected and go out as ONE
+# pcm_lora_wgrad_multi_bf16 call (<= 64 jobs per launch) instead of one call per module -- they are leaves of the backward (they only feed the flat
+# gradient buffer) and the backward's tensors are never modified in place, so issuing them later changes nothing but the launch count (196 -> ~30
+# multi launches per SD1.5 step).  Measured on one MI355X, interleaved (profiles/r06_r_*): C2 105.0 -> 103.8 ms per step at n = 32 (16: 103.9, 64: 104.0,
+# one flush per backward: 104.2), C4 206.3 -> 204.4, C3 105.7 -> 105.3.  0 / 1: one call per module.  Under set_deterministic the jobs of a call run one by
+# one with their ordered finalize, so the gradients are bitwise the same either way (tests/test_emu_unet.py, tests/test_gpu_step.py).
+WGRAD_DEFER = int(os.environ.get("PCM_WGRAD_DEFER", "32"))
+_DEFER = None     # [(fn, operand tensors)] of the backward in progress
+
+
+def _flush_deferred():
+    if _DEFER:
+        jobs = list(_DEFER)
+        del _DEFER[:]
+        with ops.wgrad_batch():
+            for fn, _ in jobs:
+                fn()
+
+
 def _wgrad(fn, *tensors):
     if _SIDE is not None:
         _SIDE.run(fn, *tensors)
+    elif _DEFER is not None:
+        _DEFER.append((fn, tensors))      # (the operands stay referenced until the flush)
+        if len(_DEFER) >= WGRAD_DEFER:
+            _flush_deferred()
     else:
         fn()
 
@@ -1177,19 +1200,23 @@ class UNet:
         Feature-tap tapes (``forward(features=True, save=True)``) take ``d_feats`` (list of 9 gradients, entries may
         be None) instead of d_eps.  ``need_input_grad`` also back-propagates through the first resnet and conv_in and
         returns d sample [B,4,H,W] fp32 (the generator step's path through the frozen teacher, sd15_adv.py:1414-1424)."""
-        global _SIDE
+        global _SIDE, _DEFER
         W, lora, cfg = self.W, self.lora, self.cfg
         dev_ = d_eps.device if d_eps is not None else self.W.conv_in[0].device
         if lora is not None and WGRAD_SIDE_STREAM and dev_.type == "cuda" and not ops.DETERMINISTIC:     # (reproducible reductions: one stream, one order)
             if self._side is None:
                 self._side = WgradSide()
             _SIDE = self._side
+        elif lora is not None and WGRAD_DEFER > 1:
+            _DEFER = []
         try:
-            return self._backward(d_eps, tape, d_feats, need_input_grad, on_late)
+            out = self._backward(d_eps, tape, d_feats, need_input_grad, on_late)
+            _flush_deferred()
+            return out
         finally:
             if _SIDE is not None:
                 _SIDE.join()
-            _SIDE = None
+            _SIDE = _DEFER = None
 
     def _backward(self, d_eps, tape, d_feats, need_input_grad, on_late=None):
         W, lora, cfg = self.W, self.lora, self.cfg
@@ -1211,6 +1238,7 @@ class UNet:
                 # that bucket's all-reduce here, behind the rest of the backward
                 if _SIDE is not None:
                     _SIDE.join()
+                _flush_deferred()
                 on_late()
                 on_late = None
             if kind == "feat":

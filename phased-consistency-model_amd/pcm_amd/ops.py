@@ -639,12 +639,15 @@ class wgrad_batch:
 
     def __enter__(self):
         global _WG_BATCH
-        assert _WG_BATCH is None, "wgrad_batch does not nest"
-        _WG_BATCH = []
+        self.inner = _WG_BATCH is not None      # inside another batch (model._flush_deferred): its jobs join the outer one
+        if not self.inner:
+            _WG_BATCH = []
         return self
 
     def __exit__(self, et, ev, tb):
         global _WG_BATCH
+        if self.inner:
+            return False
         jobs, _WG_BATCH = _WG_BATCH, None
         if et is not None or not jobs:
             return False

@@ -351,6 +351,42 @@ def run_online_target_modes_case(dev):
     assert float((g1 * g0).sum() / (g1.norm() * g0.norm())) > 0.999 and float(g0.norm()) > 0
 
 
+def run_wgrad_defer_case(dev):
+    """model.WGRAD_DEFER: the LoRA weight-gradient jobs of a backward go out per module (0) or collected across modules into few multi-job
+    launches (32, the default; 3: a flush every third module, so that several flushes and the final one all happen in this narrow model).
+    Under set_deterministic every job has its ordered finalize, so one training step gives BITWISE the same gradients and parameters."""
+    from oracle import mmdit_sd3 as O
+    from pcm_amd import model, ops
+    from pcm_amd.mmdit import MMDiTWeights, sd3_lora_state
+    from pcm_amd.mmdit_spec import MMDiTConfig
+    from pcm_amd.trainer_sd3 import SD3Distiller, SD3StepConfig
+    kw = dict(sample_size=16, num_layers=2, attention_head_dim=64, num_attention_heads=2, joint_attention_dim=96, caption_projection_dim=128,
+              pooled_projection_dim=64, pos_embed_max_size=12)
+    sd = O.init_state_dict(O.MMDiTConfig(**kw), 0)
+    pc = MMDiTConfig(**kw)
+    W = MMDiTWeights(pc, {k: v.to(dev) for k, v in sd.items()}, dev)
+    g = torch.Generator().manual_seed(13)
+    B, H, Lc = 2, 8, 5
+    batch = tuple(t.to(dev) for t in (torch.randn(B, 16, H, H, generator=g), torch.randn(B, Lc, 96, generator=g), torch.randn(B, 64, generator=g),
+                                      torch.randn(B, Lc, 96, generator=g), torch.randn(B, 64, generator=g), torch.randn(B, 16, H, H, generator=g),
+                                      torch.tensor([5, 40])))
+    res, keep = [], model.WGRAD_DEFER
+    ops.set_deterministic(True)
+    try:
+        for n in (0, 3, 32):
+            model.WGRAD_DEFER = n
+            lora = sd3_lora_state(pc, 32, 8.0, dev, seed=5, b_std=0.05)
+            D = SD3Distiller(W, lora, SD3StepConfig(multiphase=2, learning_rate=1e-3))
+            out = D.step(*batch)
+            res.append((float(out["loss"]), lora.grads.clone(), lora.params.clone()))
+    finally:
+        model.WGRAD_DEFER = keep
+        ops.set_deterministic(False)
+    assert float(res[0][1].abs().max()) > 0
+    for l, g_, p_ in res[1:]:
+        assert l == res[0][0] and torch.equal(g_, res[0][1]) and torch.equal(p_, res[0][2])
+
+
 def run_property_case(dev, cfg, W, lora, hw, Lc):
     """size-independent properties of the MMDiT path (used at SD3-medium's real size on the GPU, where no fp32 oracle is affordable, and on
     a narrow config on the emulator): finite output, batch independence, B = 0 LoRA == teacher, one distillation step."""

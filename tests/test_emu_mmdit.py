@@ -29,7 +29,7 @@ def test_spec_counts():
     assert torch.equal(O.sincos_pos_embed(oc)[:, :7], P.sincos_pos_embed(pc)[:, :7])
 
 
-from mmdit_cases import run_accumulation_case, run_online_target_modes_case, run_prefetch_case, run_adv_case, run_case, run_sampler_case, run_step_case  # noqa: E402
+from mmdit_cases import run_accumulation_case, run_online_target_modes_case, run_prefetch_case, run_wgrad_defer_case, run_adv_case, run_case, run_sampler_case, run_step_case  # noqa: E402
 
 
 @pytest.mark.slow
@@ -77,6 +77,11 @@ def test_gradient_accumulation_matches_the_full_batch_step():
 @pytest.mark.slow
 def test_online_and_target_forward_as_one_pass_or_two_is_the_same_step():
     run_online_target_modes_case("cpu")
+
+
+@pytest.mark.slow
+def test_weight_gradient_jobs_collected_across_modules_give_the_same_gradients():
+    run_wgrad_defer_case("cpu")
 
 
 @pytest.mark.slow

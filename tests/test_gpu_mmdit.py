@@ -41,3 +41,8 @@ def test_teacher_prefetch_and_pipelined_graph_give_the_same_training_sequence():
 def test_online_and_target_forward_as_one_pass_or_two_is_the_same_step():
     from mmdit_cases import run_online_target_modes_case
     run_online_target_modes_case("cuda")
+
+
+def test_weight_gradient_jobs_collected_across_modules_give_the_same_gradients():
+    from mmdit_cases import run_wgrad_defer_case
+    run_wgrad_defer_case("cuda")

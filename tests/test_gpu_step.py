@@ -186,3 +186,38 @@ def test_fp16_teacher_bf16_student_split(setup):
         json.dump({k: {"fp16_teacher": v[0], "all_bf16": v[1]} for k, v in rep.items()}, f)
     assert rep["cond_teacher_output"][0] < 0.5 * rep["cond_teacher_output"][1] and rep["x_prev"][0] < 0.5 * rep["x_prev"][1], rep
     assert rep["loss_rel"][0] < 9e-3 and rep["target_noise_pred"][0] < 1.2e-2
+
+
+def test_weight_gradient_jobs_collected_across_modules_give_the_same_step():
+    """model.WGRAD_DEFER (round 6): the LoRA weight-gradient launches of a backward issued per module (0) or collected across modules (5: many
+    flushes; 32: the default) -- under set_deterministic two training steps of a narrow SD1.5-topology UNet are BITWISE the same (conv and linear
+    modules, the fused q/k/v six-job batches, the jobs the multi-launch kernel hands back to the single-job path)."""
+    from oracle import pcm_step as OS
+    from oracle import unet_sd15 as O
+    from pcm_amd import capi, model, ops
+    from pcm_amd.model import LoraState, UNetWeights
+    from pcm_amd.trainer import Distiller, StepConfig
+    from pcm_amd.unet_spec import UNetConfig
+    capi.set_lib(None)
+    capi.lib()
+    kw = dict(block_out_channels=(64, 128), layers_per_block=1, cross_attention_dim=64, heads=2, norm_num_groups=32)
+    W = UNetWeights(UNetConfig(**kw), O.init_state_dict(O.UNetConfig(**kw), 0), "cuda")
+    cfg = StepConfig(multiphase=2, loss_type="huber", w_min=4.0, w_max=5.0, learning_rate=1e-3)
+    ocfg = OS.StepConfig(multiphase=2, loss_type="huber", w_min=4.0, w_max=5.0)
+    keys = ("latents", "prompt_embeds", "uncond_prompt_embeds", "noise", "index", "w")
+    batches = [[OS.draw_inputs(4, ocfg, seed=30 + i, latent_hw=32, ctx_len=77, ctx_dim=64)[k].cuda() for k in keys] for i in range(2)]
+    res, keep = [], model.WGRAD_DEFER
+    ops.set_deterministic(True)
+    try:
+        for n in (0, 5, 32):
+            model.WGRAD_DEFER = n
+            lora = LoraState(UNetConfig(**kw), 64, 8.0, "cuda", seed=1, b_std=0.05)
+            D = Distiller(W, lora, cfg)
+            losses = [float(D.step(*b)["loss"]) for b in batches]
+            res.append((losses, lora.grads.clone(), lora.params.clone()))
+    finally:
+        model.WGRAD_DEFER = keep
+        ops.set_deterministic(False)
+    assert float(res[0][1].abs().max()) > 0
+    for l, g_, p_ in res[1:]:
+        assert l == res[0][0] and torch.equal(g_, res[0][1]) and torch.equal(p_, res[0][2])
